@@ -1,0 +1,430 @@
+"""ctypes front-end of the CPU oracle (TEST INFRASTRUCTURE ONLY).
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this module.  It orchestrates ``libcald_oracle.so`` (oracle/cald_oracle.c) into
+  * the scoring half of ``get_uncertainty`` (reference cald_train.py:91-231), and
+  * a Faster R-CNN ResNet-FPN forward (reference detection/frcnn_la.py:237-275 on top of
+    torchvision 0.8.2 semantics, SURVEY.md Appendix A -- "parity unpinned" for that half).
+Every function cites the reference lines it restates.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+c_f = C.POINTER(C.c_float)
+c_i = C.POINTER(C.c_int)
+c_u8 = C.POINTER(C.c_uint8)
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libcald_oracle.so")
+    src = os.path.join(_HERE, "cald_oracle.c")
+    if force or not os.path.exists(so) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(so)):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libcald_oracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "libcald_oracle.so")
+        if not os.path.exists(so):
+            build()
+        _LIB = C.CDLL(so)
+        _LIB.orc_exp.restype = C.c_float
+        _LIB.orc_exp.argtypes = [C.c_float]
+        _LIB.orc_log.restype = C.c_float
+        _LIB.orc_log.argtypes = [C.c_float]
+        _LIB.orc_js_divergence.restype = C.c_float
+        _LIB.orc_consistency_view.restype = C.c_float
+    return _LIB
+
+
+def _p(a, t=c_f):
+    return a.ctypes.data_as(t) if a is not None else None
+
+
+def f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+# ----------------------------------------------------------------------------- math
+def exp_array(x):
+    x = f32(x); y = np.empty_like(x)
+    lib().orc_exp_array(_p(x), _p(y), C.c_int(x.size))
+    return y
+
+
+def log_array(x):
+    x = f32(x); y = np.empty_like(x)
+    lib().orc_log_array(_p(x), _p(y), C.c_int(x.size))
+    return y
+
+
+def py_random(seed, n):
+    out = np.empty(n, np.float64)
+    lib().orc_py_random(C.c_uint64(seed), C.c_int(n), out.ctypes.data_as(C.POINTER(C.c_double)))
+    return out
+
+
+# ----------------------------------------------------------------------------- scoring (A2-A7)
+def js_divergence(p, q):
+    p = f32(p); q = f32(q)
+    return float(lib().orc_js_divergence(_p(p), _p(q), C.c_int(p.size)))
+
+
+def subsample_indices(n):
+    """cald_train.py:110-113"""
+    inds = np.empty(50, np.int32)
+    k = lib().orc_subsample_indices(C.c_int(n), _p(inds, c_i))
+    return inds[:k].copy()
+
+
+def cls_corr_view(scores, labels, num_cls):
+    """cald_train.py:114-117, :194-197"""
+    scores = f32(scores); labels = np.ascontiguousarray(labels, dtype=np.int64)
+    out = np.empty(num_cls - 1, np.float32)
+    lib().orc_cls_corr_view(C.c_int(scores.size), _p(scores), labels.ctypes.data_as(C.POINTER(C.c_int64)),
+                            C.c_int(num_cls), _p(out))
+    return out
+
+
+def consistency_view(aug_box, ref_scores_cls, ref_pm, boxes, scores_cls, pm, bp, detail=False):
+    """cald_train.py:189-224 for one augmented view."""
+    aug_box = f32(aug_box).reshape(-1, 4); ref_scores_cls = f32(ref_scores_cls); ref_pm = f32(ref_pm)
+    boxes = f32(boxes).reshape(-1, 4); scores_cls = f32(scores_cls); pm = f32(pm)
+    N, M = aug_box.shape[0], boxes.shape[0]
+    Ccls = ref_scores_cls.shape[1] if ref_scores_cls.ndim == 2 else 0
+    d = None
+    if detail:
+        d = (np.zeros(N, np.float32), np.zeros(N, np.int32), np.zeros(N, np.float32), np.zeros(N, np.float32))
+    r = lib().orc_consistency_view(C.c_int(N), _p(aug_box), _p(ref_scores_cls), _p(ref_pm), C.c_int(M), _p(boxes),
+                                   _p(scores_cls), _p(pm), C.c_int(Ccls), C.c_float(bp),
+                                   _p(d[0]) if d else None, _p(d[1], c_i) if d else None,
+                                   _p(d[2]) if d else None, _p(d[3]) if d else None)
+    return (float(r), d) if detail else float(r)
+
+
+# ----------------------------------------------------------------------------- augmentations (A8-A10)
+def flip_boxes(boxes, W):
+    """cald_helper.py:23-30: b[:, [0, 2]] = width - bbox[:, [2, 0]]"""
+    b = f32(boxes).copy().reshape(-1, 4)
+    src = f32(boxes).reshape(-1, 4)
+    b[:, 0] = np.float32(W) - src[:, 2]
+    b[:, 2] = np.float32(W) - src[:, 0]
+    return b
+
+
+def cutout_rects(seed, H, W, boxes, cut_num=2, remove_thres=0.4, min_thres=0.1):
+    """cald_helper.py:88-132 (rectangle selection; fill is applied by preprocess_view)."""
+    boxes = f32(boxes).reshape(-1, 4)
+    rects = np.zeros((max(cut_num, 1), 4), np.int32)
+    n = lib().orc_cutout_rects(C.c_uint64(seed), C.c_int(H), C.c_int(W), C.c_int(boxes.shape[0]), _p(boxes),
+                               C.c_int(cut_num), C.c_float(remove_thres), C.c_float(min_thres), _p(rects, c_i))
+    return rects[:n].copy()
+
+
+def pil_resize_bilinear(img, oh, ow):
+    """cald_helper.py:47-53: PIL.Image.resize((ow, oh), BILINEAR) on uint8 RGB."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    H, W, _ = img.shape
+    out = np.empty((oh, ow, 3), np.uint8)
+    lib().orc_pil_resize_bilinear(_p(img, c_u8), C.c_int(H), C.c_int(W), _p(out, c_u8), C.c_int(oh), C.c_int(ow))
+    return out
+
+
+def resize_aug(img, ratio):
+    H, W, _ = img.shape
+    ow, oh = int(W * ratio), int(H * ratio)
+    return pil_resize_bilinear(img, oh, ow)
+
+
+# ----------------------------------------------------------------------------- detector pieces
+def transform_size(H, W, min_size, max_size):
+    v = [C.c_int() for _ in range(4)]
+    lib().orc_transform_size(C.c_int(H), C.c_int(W), C.c_int(min_size), C.c_int(max_size), *[C.byref(x) for x in v])
+    return tuple(x.value for x in v)  # Hr, Wr, Hp, Wp
+
+
+def preprocess_view(img, min_size, max_size, flip=False, rects=None):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    H, W, _ = img.shape
+    Hr, Wr, Hp, Wp = transform_size(H, W, min_size, max_size)
+    out = np.empty((Hp, Wp, 4), np.float32)
+    r = np.ascontiguousarray(rects, dtype=np.int32).reshape(-1, 4) if rects is not None and len(rects) else None
+    lib().orc_preprocess_view(_p(img, c_u8), C.c_int(H), C.c_int(W), C.c_int(int(flip)),
+                              C.c_int(0 if r is None else r.shape[0]), _p(r, c_i) if r is not None else None,
+                              C.c_int(Hr), C.c_int(Wr), C.c_int(Hp), C.c_int(Wp), _p(out))
+    return out, (Hr, Wr, Hp, Wp)
+
+
+def conv2d(x, wk, KH, KW, stride, pad, bias=None, bn=None, residual=None, up=None, relu=False):
+    """x: [H][W][Cin]; wk: K-major [KH*KW*Cin][Cout]."""
+    x = f32(x); H, W, Cin = x.shape
+    Cout = wk.shape[1]
+    Ho = (H + 2 * pad - KH) // stride + 1
+    Wo = (W + 2 * pad - KW) // stride + 1
+    out = np.empty((Ho, Wo, Cout), np.float32)
+    upH = upW = 0
+    if up is not None:
+        up = f32(up); upH, upW = up.shape[:2]
+    lib().orc_conv2d_nhwc(_p(x), C.c_int(H), C.c_int(W), C.c_int(Cin), _p(wk), C.c_int(Cout), C.c_int(KH), C.c_int(KW),
+                          C.c_int(stride), C.c_int(pad), _p(bias), _p(bn[0]) if bn else None, _p(bn[1]) if bn else None,
+                          _p(f32(residual)) if residual is not None else None, _p(up), C.c_int(upH), C.c_int(upW),
+                          C.c_int(int(relu)), _p(out), C.c_int(Ho), C.c_int(Wo))
+    return out
+
+
+def linear(x, wk, bias=None, relu=False):
+    x = f32(x); M, K = x.shape
+    N = wk.shape[1]
+    out = np.empty((M, N), np.float32)
+    lib().orc_linear(_p(x), C.c_int(M), C.c_int(K), _p(wk), C.c_int(N), _p(bias), C.c_int(int(relu)), _p(out))
+    return out
+
+
+def maxpool3x3s2(x):
+    x = f32(x); H, W, Cc = x.shape
+    Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    out = np.empty((Ho, Wo, Cc), np.float32)
+    lib().orc_maxpool3x3s2(_p(x), C.c_int(H), C.c_int(W), C.c_int(Cc), _p(out), C.c_int(Ho), C.c_int(Wo))
+    return out
+
+
+def subsample2(x):
+    x = f32(x); H, W, Cc = x.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    out = np.empty((Ho, Wo, Cc), np.float32)
+    lib().orc_subsample2(_p(x), C.c_int(H), C.c_int(W), C.c_int(Cc), _p(out), C.c_int(Ho), C.c_int(Wo))
+    return out
+
+
+def base_anchors(sizes, ratios):
+    sizes = f32(sizes); ratios = f32(ratios)
+    out = np.empty((ratios.size * sizes.size, 4), np.float32)
+    lib().orc_base_anchors(_p(sizes), C.c_int(sizes.size), _p(ratios), C.c_int(ratios.size), _p(out))
+    return out
+
+
+def batched_nms(boxes, scores, groups, thr, max_keep=1 << 30):
+    boxes = f32(boxes).reshape(-1, 4); scores = f32(scores); groups = np.ascontiguousarray(groups, dtype=np.int32)
+    n = boxes.shape[0]
+    keep = np.empty(n + 1, np.int32)
+    k = lib().orc_batched_nms(_p(boxes), _p(scores), _p(groups, c_i), C.c_int(n), C.c_float(thr),
+                              C.c_int(min(max_keep, n + 1)), _p(keep, c_i))
+    return keep[:k].copy()
+
+
+def rpn_proposals(heads, base, Hp, Wp, Hr, Wr, A=3, pre_n=1000, post_n=1000, nms_thr=0.7, min_size=1e-3):
+    L = len(heads)
+    heads = [f32(h) for h in heads]
+    hp = (c_f * L)(*[_p(h) for h in heads])
+    fh = np.array([h.shape[0] for h in heads], np.int32)
+    fw = np.array([h.shape[1] for h in heads], np.int32)
+    hc = heads[0].shape[2]
+    base = f32(base)
+    props = np.empty((post_n, 4), np.float32); ps = np.empty(post_n, np.float32)
+    n = lib().orc_rpn_proposals(C.c_int(L), hp, _p(fh, c_i), _p(fw, c_i), C.c_int(hc), C.c_int(A), _p(base),
+                                C.c_int(Hp), C.c_int(Wp), C.c_int(Hr), C.c_int(Wr), C.c_int(pre_n), C.c_int(post_n),
+                                C.c_float(nms_thr), C.c_float(min_size), _p(props), _p(ps))
+    return props[:n].copy(), ps[:n].copy()
+
+
+def roi_align(feats, rois):
+    L = len(feats)
+    feats = [f32(f) for f in feats]
+    fp = (c_f * L)(*[_p(f) for f in feats])
+    fh = np.array([f.shape[0] for f in feats], np.int32)
+    fw = np.array([f.shape[1] for f in feats], np.int32)
+    Cc = feats[0].shape[2]
+    rois = f32(rois).reshape(-1, 4)
+    R = rois.shape[0]
+    out = np.empty((R, 49, Cc), np.float32)
+    lib().orc_roi_align(C.c_int(L), fp, _p(fh, c_i), _p(fw, c_i), C.c_int(Cc), _p(rois), C.c_int(R), _p(out))
+    return out
+
+
+def frcnn_postprocess(logits, deltas, proposals, Hr, Wr, Ho, Wo, score_thr=0.05, nms_thr=0.5, det_max=100):
+    logits = f32(logits); deltas = f32(deltas); proposals = f32(proposals).reshape(-1, 4)
+    R, Cc = logits.shape
+    ob = np.empty((det_max, 4), np.float32); os_ = np.empty(det_max, np.float32); ol = np.empty(det_max, np.int64)
+    op = np.empty((det_max, 4), np.float32); opm = np.empty(det_max, np.float32); osc = np.empty((det_max, Cc), np.float32)
+    n = lib().orc_frcnn_postprocess(C.c_int(R), C.c_int(Cc), _p(logits), _p(deltas), _p(proposals), C.c_int(Hr), C.c_int(Wr),
+                                    C.c_int(Ho), C.c_int(Wo), C.c_float(score_thr), C.c_float(nms_thr), C.c_int(det_max),
+                                    _p(ob), _p(os_), ol.ctypes.data_as(C.POINTER(C.c_int64)), _p(op), _p(opm), _p(osc))
+    return dict(boxes=ob[:n].copy(), scores=os_[:n].copy(), labels=ol[:n].copy(), props=op[:n].copy(),
+                prob_max=opm[:n].copy(), scores_cls=osc[:n].copy())
+
+
+# ----------------------------------------------------------------------------- model preparation
+def _kmajor_conv(w):
+    """torch conv weight [Cout][Cin][KH][KW] -> K-major [(kh,kw,cin)][Cout]"""
+    w = f32(w)
+    return np.ascontiguousarray(w.transpose(2, 3, 1, 0).reshape(-1, w.shape[0]))
+
+
+def _frozen_bn(sd, prefix, eps=1e-5):
+    """torchvision FrozenBatchNorm2d: scale = w * rsqrt(var + eps); bias = b - mean * scale"""
+    w, b = f32(sd[prefix + ".weight"]), f32(sd[prefix + ".bias"])
+    rm, rv = f32(sd[prefix + ".running_mean"]), f32(sd[prefix + ".running_var"])
+    scale = (w * (np.float32(1.0) / np.sqrt(rv + np.float32(eps)))).astype(np.float32)
+    shift = (b - rm * scale).astype(np.float32)
+    return scale, shift
+
+
+RESNET_LAYERS = {50: [3, 4, 6, 3], 101: [3, 4, 23, 3]}
+
+
+def prepare_frcnn(sd, num_classes, depth=50):
+    """sd: torchvision-layout state dict of numpy arrays (SURVEY section 8b key layout)."""
+    sd = {k: (v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)) for k, v in sd.items()}
+    P = {"num_classes": num_classes, "depth": depth}
+    w1 = f32(sd["backbone.body.conv1.weight"])
+    w1p = np.zeros((64, 4, 7, 7), np.float32); w1p[:, :3] = w1
+    P["conv1"] = (_kmajor_conv(w1p), _frozen_bn(sd, "backbone.body.bn1"))
+    blocks = []
+    for li, nb in enumerate(RESNET_LAYERS[depth]):
+        for bi in range(nb):
+            pre = "backbone.body.layer%d.%d" % (li + 1, bi)
+            blk = {"stride": 2 if (bi == 0 and li > 0) else 1}
+            for ci in (1, 2, 3):
+                blk["conv%d" % ci] = (_kmajor_conv(sd[pre + ".conv%d.weight" % ci]), _frozen_bn(sd, pre + ".bn%d" % ci))
+            if pre + ".downsample.0.weight" in sd:
+                blk["down"] = (_kmajor_conv(sd[pre + ".downsample.0.weight"]), _frozen_bn(sd, pre + ".downsample.1"))
+            blk["layer_end"] = (bi == nb - 1)
+            blocks.append(blk)
+    P["blocks"] = blocks
+    P["fpn_inner"] = [(_kmajor_conv(sd["backbone.fpn.inner_blocks.%d.weight" % i]), f32(sd["backbone.fpn.inner_blocks.%d.bias" % i])) for i in range(4)]
+    P["fpn_layer"] = [(_kmajor_conv(sd["backbone.fpn.layer_blocks.%d.weight" % i]), f32(sd["backbone.fpn.layer_blocks.%d.bias" % i])) for i in range(4)]
+    P["rpn_conv"] = (_kmajor_conv(sd["rpn.head.conv.weight"]), f32(sd["rpn.head.conv.bias"]))
+    wc, bc = f32(sd["rpn.head.cls_logits.weight"]), f32(sd["rpn.head.cls_logits.bias"])
+    wb, bb = f32(sd["rpn.head.bbox_pred.weight"]), f32(sd["rpn.head.bbox_pred.bias"])
+    P["rpn_head"] = (_kmajor_conv(np.concatenate([wc, wb], 0)), np.concatenate([bc, bb]).astype(np.float32))
+    w6 = f32(sd["roi_heads.box_head.fc6.weight"])  # [1024][c*49+bin] -> chain order (bin, c)
+    w6 = w6.reshape(w6.shape[0], 256, 49).transpose(0, 2, 1).reshape(w6.shape[0], -1)
+    P["fc6"] = (np.ascontiguousarray(w6.T), f32(sd["roi_heads.box_head.fc6.bias"]))
+    P["fc7"] = (np.ascontiguousarray(f32(sd["roi_heads.box_head.fc7.weight"]).T), f32(sd["roi_heads.box_head.fc7.bias"]))
+    wcs, bcs = f32(sd["roi_heads.box_predictor.cls_score.weight"]), f32(sd["roi_heads.box_predictor.cls_score.bias"])
+    wbp, bbp = f32(sd["roi_heads.box_predictor.bbox_pred.weight"]), f32(sd["roi_heads.box_predictor.bbox_pred.bias"])
+    P["pred"] = (np.ascontiguousarray(np.concatenate([wcs, wbp], 0).T), np.concatenate([bcs, bbp]).astype(np.float32))
+    P["anchors"] = np.stack([base_anchors([s], [0.5, 1.0, 2.0]) for s in (32, 64, 128, 256, 512)])  # [5][3][4]
+    return P
+
+
+def frcnn_backbone(P, x, keep=None):
+    """ResNet body + FPN (rows A15, A16).  x: [Hp][Wp][4].  Returns [P2..P5, pool]."""
+    wk, bn = P["conv1"]
+    y = conv2d(x, wk, 7, 7, 2, 3, bn=bn, relu=True)
+    if keep is not None: keep["conv1"] = y
+    y = maxpool3x3s2(y)
+    if keep is not None: keep["pool1"] = y
+    feats = []
+    for bi, blk in enumerate(P["blocks"]):
+        idn = y
+        if "down" in blk:
+            idn = conv2d(y, blk["down"][0], 1, 1, blk["stride"], 0, bn=blk["down"][1])
+        o = conv2d(y, blk["conv1"][0], 1, 1, 1, 0, bn=blk["conv1"][1], relu=True)
+        o = conv2d(o, blk["conv2"][0], 3, 3, blk["stride"], 1, bn=blk["conv2"][1], relu=True)
+        y = conv2d(o, blk["conv3"][0], 1, 1, 1, 0, bn=blk["conv3"][1], residual=idn, relu=True)
+        if blk["layer_end"]:
+            feats.append(y)
+    if keep is not None: keep["C"] = feats
+    inner = [None] * 4
+    inner[3] = conv2d(feats[3], P["fpn_inner"][3][0], 1, 1, 1, 0, bias=P["fpn_inner"][3][1])
+    for i in (2, 1, 0):
+        inner[i] = conv2d(feats[i], P["fpn_inner"][i][0], 1, 1, 1, 0, bias=P["fpn_inner"][i][1], up=inner[i + 1])
+    outs = [conv2d(inner[i], P["fpn_layer"][i][0], 3, 3, 1, 1, bias=P["fpn_layer"][i][1]) for i in range(4)]
+    outs.append(subsample2(outs[3]))
+    return outs
+
+
+def frcnn_forward(P, img, min_size, max_size, flip=False, rects=None, keep=None,
+                  score_thr=0.05, nms_thr=0.5, det_max=100):
+    """frcnn_la.py:237-275 for ONE view (batch 1, like the reference)."""
+    H, W, _ = img.shape
+    x, (Hr, Wr, Hp, Wp) = preprocess_view(img, min_size, max_size, flip, rects)
+    if keep is not None: keep["input"] = x; keep["sizes"] = (Hr, Wr, Hp, Wp)
+    feats = frcnn_backbone(P, x, keep)
+    if keep is not None: keep["fpn"] = feats
+    heads = []
+    for f in feats:
+        t = conv2d(f, P["rpn_conv"][0], 3, 3, 1, 1, bias=P["rpn_conv"][1], relu=True)
+        heads.append(conv2d(t, P["rpn_head"][0], 1, 1, 1, 0, bias=P["rpn_head"][1]))
+    if keep is not None: keep["rpn_head"] = heads
+    props, pscores = rpn_proposals(heads, P["anchors"], Hp, Wp, Hr, Wr)
+    if keep is not None: keep["proposals"] = props; keep["proposal_scores"] = pscores
+    Cn = P["num_classes"]
+    if props.shape[0] == 0:
+        z = np.zeros
+        return dict(boxes=z((0, 4), np.float32), scores=z(0, np.float32), labels=z(0, np.int64), props=z((0, 4), np.float32),
+                    prob_max=z(0, np.float32), scores_cls=z((0, Cn), np.float32))
+    roi = roi_align(feats[:4], props)
+    if keep is not None: keep["roi"] = roi
+    h = linear(roi.reshape(roi.shape[0], -1), P["fc6"][0], P["fc6"][1], relu=True)
+    h = linear(h, P["fc7"][0], P["fc7"][1], relu=True)
+    pred = linear(h, P["pred"][0], P["pred"][1])
+    if keep is not None: keep["fc7"] = h; keep["pred"] = pred
+    return frcnn_postprocess(pred[:, :Cn], pred[:, Cn:], props, Hr, Wr, H, W, score_thr, nms_thr, det_max)
+
+
+# ----------------------------------------------------------------------------- the sweep (A1)
+def image_seed(base_seed, pool_pos):
+    return (int(base_seed) * 1000003 + int(pool_pos)) & 0xFFFFFFFFFFFFFFFF
+
+
+def build_views(img, augs, ref, seed):
+    """cald_train.py:123-183 for the augmentations reachable from --augs F, C, D.
+    Returns list of (src_image, flip, rects, aug_boxes)."""
+    H, W, _ = img.shape
+    views = []
+    rb = ref["boxes"]
+    if "flip" in augs:
+        views.append((img, True, None, flip_boxes(rb, W)))
+    if "cut_out" in augs:
+        views.append((img, False, cutout_rects(seed, H, W, rb, 2), rb))
+    if "smaller_resize" in augs:
+        views.append((resize_aug(img, 0.8), False, None, (f32(rb) * np.float32(0.8)).astype(np.float32)))
+    return views
+
+
+def subsample_ref(out):
+    """cald_train.py:110-113"""
+    n = out["scores"].shape[0]
+    if n > 40:
+        inds = subsample_indices(n)
+        return {k: v[inds] for k, v in out.items()}
+    return out
+
+
+def score_image(ref, aug_outs, aug_boxes, num_cls, bp):
+    """cald_train.py:114-121, :187-228 given detector outputs.  ref is already sub-sampled."""
+    cls_corrs = [cls_corr_view(ref["scores"], ref["labels"], num_cls).astype(np.float64)]
+    if ref["boxes"].shape[0] == 0:
+        return 0.0, np.mean(cls_corrs, axis=0)
+    cons = []
+    for out, ab in zip(aug_outs, aug_boxes):
+        cls_corrs.append(cls_corr_view(out["scores"], out["labels"], num_cls).astype(np.float64))
+        cons.append(consistency_view(ab, ref["scores_cls"], ref["prob_max"], out["boxes"], out["scores_cls"],
+                                     out["prob_max"], bp))
+    return float(np.mean(np.array(cons, np.float64))), np.mean(np.array(cls_corrs), axis=0)
+
+
+def get_uncertainty(P, images, augs, num_cls, bp=1.3, min_size=600, max_size=1000, base_seed=0, positions=None):
+    """Restatement of cald_train.py:91-231 over an in-memory pool of uint8 HWC images."""
+    consistency_all, cls_all = [], []
+    for pos, img in enumerate(images):
+        gpos = pos if positions is None else positions[pos]
+        ref = subsample_ref(frcnn_forward(P, img, min_size, max_size))
+        if ref["boxes"].shape[0] == 0:
+            c, cc = score_image(ref, [], [], num_cls, bp)
+        else:
+            views = build_views(img, augs, ref, image_seed(base_seed, gpos))
+            outs = [frcnn_forward(P, v[0], min_size, max_size, v[1], v[2]) for v in views]
+            c, cc = score_image(ref, outs, [v[3] for v in views], num_cls, bp)
+        consistency_all.append(c); cls_all.append(cc)
+    return consistency_all, cls_all

@@ -1,0 +1,92 @@
+"""The CPU oracle against golden vectors captured from the imported reference
+(oracle/make_golden.py; reference cald_train.py:91-271, cald/cald_helper.py:23-243)."""
+import numpy as np
+import pytest
+
+SCORING = ["scoring_frcnn_F", "scoring_frcnn_FCD", "scoring_retina_FCD", "scoring_frcnn_coco_FD"]
+
+
+def _dets(g, i, v):
+    return {k: g["det%d_%d_%s" % (i, v, k)] for k in ("boxes", "labels", "scores", "prob_max", "scores_cls")}
+
+
+def materialize(orc, img, flip, rects):
+    out = img[:, ::-1].copy() if flip else img.copy()
+    if rects is not None:
+        for (l, t, r, b) in rects:
+            out[t:b, l:r] = 0
+    return out
+
+
+@pytest.mark.parametrize("name", SCORING)
+def test_scoring_matches_reference(oracle, golden, name):
+    g = golden(name)
+    augs = [str(a) for a in g["augs"]]
+    C, bp, base_seed = int(g["C"]), float(g["bp"]), int(g["base_seed"])
+    for i in range(int(g["n_images"])):
+        img = g["img%d" % i]
+        ref = oracle.subsample_ref(_dets(g, i, 0))
+        nviews = int(g["per_image"][i])
+        if nviews == 1:
+            c, cc = oracle.score_image(ref, [], [], C, bp)
+        else:
+            views = oracle.build_views(img, augs, ref, oracle.image_seed(base_seed, i))
+            assert len(views) == nviews - 1
+            outs = [_dets(g, i, v) for v in range(1, nviews)]
+            c, cc = oracle.score_image(ref, outs, [v[3] for v in views], C, bp)
+            if i < 3:   # pixel-exact augmented images as the reference's detector saw them
+                for vi, v in enumerate(views):
+                    np.testing.assert_array_equal(materialize(oracle, v[0], v[1], v[2]), g["seen%d_%d" % (i, vi + 1)])
+        assert abs(c - g["consistency"][i]) <= 1e-5, (name, i, c, g["consistency"][i])
+        np.testing.assert_allclose(cc, g["cls_all"][i], rtol=0, atol=1e-7)
+
+
+def test_js_matches_scipy(oracle, golden):
+    g = golden("js")
+    for p, q, (C, js) in zip(g["p"], g["q"], g["cj"]):
+        C = int(C)
+        got = oracle.js_divergence(p[:C], q[:C])
+        assert abs(got - js) <= 2e-6, (C, got, js)
+
+
+def test_helpers_match_reference(oracle, golden):
+    g = golden("helpers")
+    for i in range(4):
+        img, boxes = g["img%d" % i], g["boxes%d" % i]
+        H, W, _ = img.shape
+        np.testing.assert_array_equal(oracle.flip_boxes(boxes, W), g["flip_boxes%d" % i])
+        np.testing.assert_array_equal(img[:, ::-1], g["flip_img%d" % i])
+        for r10, r in ((8, 0.8), (12, 1.2), (7, 0.7)):
+            np.testing.assert_array_equal(oracle.resize_aug(img, r), g["resize%d_%d_img" % (i, r10)])
+            np.testing.assert_array_equal((boxes * np.float32(r)).astype(np.float32), g["resize%d_%d_boxes" % (i, r10)])
+        for s in (11, 12, 13):
+            rects = oracle.cutout_rects(s, H, W, boxes, 2)
+            np.testing.assert_array_equal(materialize(oracle, img, False, rects), g["cutout%d_%d_img" % (i, s)])
+    for s in (0, 1, 12345, (1 << 40) + 17):
+        np.testing.assert_array_equal(oracle.py_random(s, 8), g["pyrandom_%d" % s])
+
+
+def test_pil_resize_against_installed_pillow(oracle):
+    from PIL import Image
+    rs = np.random.RandomState(0)
+    for (H, W) in [(375, 500), (333, 500), (500, 375), (61, 47)]:
+        img = (rs.rand(H, W, 3) * 255).astype(np.uint8)
+        for r in (0.8, 1.2, 0.5):
+            ow, oh = int(W * r), int(H * r)
+            want = np.asarray(Image.fromarray(img).resize((ow, oh), Image.BILINEAR))
+            np.testing.assert_array_equal(oracle.pil_resize_bilinear(img, oh, ow), want)
+
+
+def test_subsample_indices(oracle):
+    for n in (1, 40, 41, 49, 50, 51, 100, 300, 6300):
+        want = np.arange(n) if n <= 40 else np.round(np.linspace(0, n - 1, 50)).astype(int)
+        np.testing.assert_array_equal(oracle.subsample_indices(n), want)
+
+
+def test_det_math_accuracy(oracle):
+    x = np.linspace(-80, 80, 20001).astype(np.float32)
+    e = oracle.exp_array(x)
+    np.testing.assert_allclose(e, np.exp(x.astype(np.float64)), rtol=3e-7)
+    y = np.concatenate([np.logspace(-30, 30, 20001), np.linspace(0.5, 2, 5001)]).astype(np.float32)
+    l = oracle.log_array(y)
+    np.testing.assert_allclose(l, np.log(y.astype(np.float64)), rtol=3e-7, atol=2e-7)
