@@ -1,0 +1,94 @@
+"""ctypes binding of libcaldhip.so (include/cald_hip.h).
+
+This is the thin FFI shim of the drop-in boundary: every symbol declared in include/cald_hip.h is
+bound here with its exact C signature.  There is NO fallback: if the library is missing, or no
+MI355X is visible when a compute call is made, the call raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcaldhip.so")
+_lib = None
+
+c_f = C.POINTER(C.c_float)
+c_i = C.POINTER(C.c_int)
+c_i64 = C.POINTER(C.c_int64)
+c_d = C.POINTER(C.c_double)
+c_u8 = C.POINTER(C.c_uint8)
+
+
+class ModelCfg(C.Structure):
+    _fields_ = [("arch", C.c_int), ("depth", C.c_int), ("num_classes", C.c_int), ("min_size", C.c_int),
+                ("max_size", C.c_int), ("box_score_thresh", C.c_float), ("box_nms_thresh", C.c_float),
+                ("detections_per_img", C.c_int), ("rpn_pre_nms_top_n", C.c_int), ("rpn_post_nms_top_n", C.c_int),
+                ("rpn_nms_thresh", C.c_float)]
+
+
+class View(C.Structure):
+    _fields_ = [("image_dev", C.c_void_p), ("H", C.c_int), ("W", C.c_int), ("flip", C.c_int), ("nrect", C.c_int),
+                ("rects", C.c_int * 16)]
+
+
+class Dets(C.Structure):
+    _fields_ = [("boxes_dev", C.c_void_p), ("scores_dev", C.c_void_p), ("labels_dev", C.c_void_p),
+                ("props_dev", C.c_void_p), ("prob_max_dev", C.c_void_p), ("scores_cls_dev", C.c_void_p),
+                ("count_dev", C.c_void_p), ("cap", C.c_int)]
+
+
+class SweepCfg(C.Structure):
+    _fields_ = [("aug_flip", C.c_int), ("aug_cutout", C.c_int), ("aug_resize", C.c_int), ("resize_ratio", C.c_float),
+                ("base_seed", C.c_uint64), ("bp", C.c_float), ("batch_images", C.c_int)]
+
+
+# name -> (restype, argtypes): must list every symbol of include/cald_hip.h
+SIGNATURES = {
+    "cald_last_error": (C.c_char_p, []),
+    "cald_version": (C.c_int, []),
+    "cald_ctx_create": (C.c_int, [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "cald_ctx_destroy": (C.c_int, [C.c_void_p]),
+    "cald_ctx_sync": (C.c_int, [C.c_void_p]),
+    "cald_model_create": (C.c_int, [C.c_void_p, C.POINTER(ModelCfg), C.POINTER(C.c_void_p)]),
+    "cald_model_load_tensor": (C.c_int, [C.c_void_p, C.c_char_p, c_f, c_i64, C.c_int]),
+    "cald_model_finalize": (C.c_int, [C.c_void_p]),
+    "cald_model_destroy": (C.c_int, [C.c_void_p]),
+    "cald_forward": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(View), C.POINTER(Dets)]),
+    "cald_sweep": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), c_i, c_i, c_i64, C.POINTER(SweepCfg), c_d, c_d]),
+    "cald_op_consistency": (C.c_int, [C.c_void_p, C.c_int, c_f, c_f, c_f, C.c_int, c_f, c_f, c_f, C.c_int, C.c_float, c_f]),
+    "cald_op_cls_corr": (C.c_int, [C.c_void_p, C.c_int, c_f, c_i64, C.c_int, c_f]),
+    "cald_op_pil_resize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]),
+    "cald_op_cutout_rects": (C.c_int, [C.c_uint64, C.c_int, C.c_int, C.c_int, c_f, C.c_int, c_i, c_i]),
+    "cald_op_conv2d": (C.c_int, [C.c_void_p, c_f, C.c_int, C.c_int, C.c_int, c_f, C.c_int, C.c_int, C.c_int, C.c_int,
+                                 C.c_int, c_f, c_f, c_f, c_f, C.c_int, c_f]),
+    "cald_op_transform_size": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, c_i, c_i, c_i, c_i]),
+    "cald_debug_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, c_f, C.c_int64, c_i64]),
+    "cald_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "cald_profile_read": (C.c_int, [C.c_void_p, c_d, c_d, c_i64, c_d]),
+}
+
+
+def lib():
+    """Loads libcaldhip.so.  torch is imported first so that both share one HIP runtime
+    (torch's bundled libamdhip64.so.7 satisfies the library's NEEDED entry)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libcaldhip.so is not built (%s missing): run `python -c 'import __graft_entry__ as g; "
+                               "g.build()'` or `make -C cald_amd/csrc`; there is no CPU fallback" % LIB_PATH)
+        import torch  # noqa: F401  (loads the HIP runtime)
+        L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError("libcaldhip: %s (code %d)" % (lib().cald_last_error().decode(), rc))
+
+
+def ptr(a, t=c_f):
+    return a.ctypes.data_as(t) if a is not None else None

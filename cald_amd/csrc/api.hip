@@ -1,0 +1,1018 @@
+// api.hip -- C ABI (include/cald_hip.h) and host orchestration of the CALD sweep on MI355X.
+//
+// Host-side restatements (no device work): Python `random` (MT19937) + cald_helper.cutout rectangle
+// selection (cald/cald_helper.py:88-132), Pillow's resampling coefficients (cald_helper.py:47-53),
+// the detector-transform size rule (torchvision GeneralizedRCNNTransform), np.linspace sub-sampling
+// (cald_train.py:110-113), and the float64 means of cald_train.py:225-228.
+#include "../../include/cald_hip.h"
+#include "common.h"
+#include "kernels.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+    return code;
+}
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(CALD_ERR_HIP, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+
+extern "C" const char* cald_last_error(void) { return g_err; }
+extern "C" int cald_version(void) { return 100; }
+
+// =============================================================================================
+// context
+// =============================================================================================
+struct PilCoef { int ksize; int* d_bounds; int* d_kk; };
+
+struct cald_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    char* arena = nullptr; size_t arena_cap = 0, arena_off = 0;
+    BatchPlan* d_plan = nullptr;
+    ViewDesc* d_views = nullptr;
+    // pinned host staging ring for the per-forward plan + view descriptors (keeps the source of the
+    // stream-ordered H2D copies alive without a host sync)
+    static const int NSTAGE = 8;
+    char* h_stage[NSTAGE] = {nullptr}; hipEvent_t stage_ev[NSTAGE] = {nullptr}; int stage_i = 0;
+    bool prof = false;
+    std::vector<hipEvent_t> ev0, ev1;
+    double prof_flops = 0.0;
+    hipEvent_t tot0 = nullptr, tot1 = nullptr; bool tot_open = false; double tot_ms = 0.0;
+    std::map<std::pair<int, int>, PilCoef> pil;
+};
+
+static int arena_reserve(cald_ctx* c, size_t bytes) {
+    if (bytes <= c->arena_cap) return 0;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->arena) HIPCHK(hipFree(c->arena));
+    c->arena = nullptr; c->arena_cap = 0;
+    size_t want = bytes + (bytes >> 3);
+    HIPCHK(hipMalloc((void**)&c->arena, want));
+    c->arena_cap = want;
+    return 0;
+}
+struct Bump {
+    char* base; size_t off = 0; bool dry;
+    explicit Bump(char* b, bool d) : base(b), dry(d) {}
+    template <typename T> T* get(size_t count) {
+        size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
+        T* p = dry ? nullptr : reinterpret_cast<T*>(base + off);
+        off += bytes;
+        return p;
+    }
+};
+
+extern "C" int cald_ctx_create(int device, void* stream, cald_ctx** out) {
+    if (!out) return fail(CALD_ERR_INVALID, "out is null");
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(CALD_ERR_INVALID, "device %d out of range (%d devices)", device, ndev);
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(CALD_ERR_INVALID, "libcaldhip is built for gfx950 (MI355X); device %d is %s", device, prop.gcnArchName);
+    cald_ctx* c = new cald_ctx();
+    c->device = device;
+    if (stream) c->stream = (hipStream_t)stream;
+    else { HIPCHK(hipStreamCreate(&c->stream)); c->own_stream = true; }
+    HIPCHK(hipMalloc((void**)&c->d_plan, sizeof(BatchPlan)));
+    HIPCHK(hipMalloc((void**)&c->d_views, sizeof(ViewDesc) * CALD_MAX_VIEWS));
+    for (int i = 0; i < cald_ctx::NSTAGE; i++) {
+        HIPCHK(hipHostMalloc((void**)&c->h_stage[i], sizeof(BatchPlan) + sizeof(ViewDesc) * CALD_MAX_VIEWS));
+        HIPCHK(hipEventCreateWithFlags(&c->stage_ev[i], hipEventDisableTiming));
+    }
+    *out = c;
+    return 0;
+}
+extern "C" int cald_ctx_sync(cald_ctx* c) {
+    if (!c) return fail(CALD_ERR_INVALID, "ctx is null");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+extern "C" int cald_ctx_destroy(cald_ctx* c) {
+    if (!c) return 0;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    for (auto& kv : c->pil) { hipFree(kv.second.d_bounds); hipFree(kv.second.d_kk); }
+    for (auto e : c->ev0) hipEventDestroy(e);
+    for (auto e : c->ev1) hipEventDestroy(e);
+    if (c->tot0) hipEventDestroy(c->tot0);
+    if (c->tot1) hipEventDestroy(c->tot1);
+    if (c->arena) hipFree(c->arena);
+    for (int i = 0; i < cald_ctx::NSTAGE; i++) { if (c->h_stage[i]) hipHostFree(c->h_stage[i]); if (c->stage_ev[i]) hipEventDestroy(c->stage_ev[i]); }
+    hipFree(c->d_plan); hipFree(c->d_views);
+    if (c->own_stream) hipStreamDestroy(c->stream);
+    delete c;
+    return 0;
+}
+
+extern "C" int cald_profile_enable(cald_ctx* c, int on) {
+    if (!c) return fail(CALD_ERR_INVALID, "ctx is null");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->prof = on != 0;
+    for (auto e : c->ev0) hipEventDestroy(e);
+    for (auto e : c->ev1) hipEventDestroy(e);
+    c->ev0.clear(); c->ev1.clear(); c->prof_flops = 0.0; c->tot_ms = 0.0; c->tot_open = false;
+    if (on && !c->tot0) { HIPCHK(hipEventCreate(&c->tot0)); HIPCHK(hipEventCreate(&c->tot1)); }
+    return 0;
+}
+extern "C" int cald_profile_read(cald_ctx* c, double* gemm_ms, double* gemm_flops, int64_t* launches, double* total_ms) {
+    if (!c) return fail(CALD_ERR_INVALID, "ctx is null");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    double ms = 0.0;
+    for (size_t i = 0; i < c->ev0.size(); i++) { float t = 0.f; HIPCHK(hipEventElapsedTime(&t, c->ev0[i], c->ev1[i])); ms += t; }
+    if (gemm_ms) *gemm_ms = ms;
+    if (gemm_flops) *gemm_flops = c->prof_flops;
+    if (launches) *launches = (int64_t)c->ev0.size();
+    if (total_ms) *total_ms = c->tot_ms;
+    return 0;
+}
+
+// conv launch with optional event bracketing
+static int run_conv(cald_ctx* c, const ConvArgs& a, double flops) {
+    if (c->prof) {
+        hipEvent_t e0, e1;
+        HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+        HIPCHK(hipEventRecord(e0, c->stream));
+        launch_conv(a, c->stream);
+        HIPCHK(hipEventRecord(e1, c->stream));
+        c->ev0.push_back(e0); c->ev1.push_back(e1); c->prof_flops += flops;
+    } else {
+        launch_conv(a, c->stream);
+    }
+    return 0;
+}
+
+// =============================================================================================
+// host-side restatements
+// =============================================================================================
+static void transform_size(int H, int W, int min_size, int max_size, int* Hr, int* Wr, int* Hp, int* Wp) {
+    double mn = (double)(H < W ? H : W), mx = (double)(H > W ? H : W);
+    double scale = (double)min_size / mn;
+    if (mx * scale > (double)max_size) scale = (double)max_size / mx;
+    *Hr = (int)std::floor((double)H * scale);
+    *Wr = (int)std::floor((double)W * scale);
+    *Hp = ((*Hr + 31) / 32) * 32;
+    *Wp = ((*Wr + 31) / 32) * 32;
+}
+extern "C" int cald_op_transform_size(int H, int W, int min_size, int max_size, int* Hr, int* Wr, int* Hp, int* Wp) {
+    if (H <= 0 || W <= 0 || min_size <= 0 || max_size <= 0) return fail(CALD_ERR_INVALID, "bad sizes");
+    transform_size(H, W, min_size, max_size, Hr, Wr, Hp, Wp);
+    return 0;
+}
+
+// ---- Python's random module: MT19937 + random.seed(int) + random.random() ----
+struct PyRandom {
+    uint32_t mt[624]; int idx;
+    void init_genrand(uint32_t s) {
+        mt[0] = s;
+        for (int i = 1; i < 624; i++) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+        idx = 624;
+    }
+    void seed(uint64_t a) {
+        uint32_t key[2] = {(uint32_t)(a & 0xffffffffu), (uint32_t)(a >> 32)};
+        int klen = key[1] ? 2 : 1;
+        init_genrand(19650218u);
+        int i = 1, j = 0;
+        for (int k = 624; k; k--) {
+            mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1664525u)) + key[j] + (uint32_t)j;
+            i++; j++;
+            if (i >= 624) { mt[0] = mt[623]; i = 1; }
+            if (j >= klen) j = 0;
+        }
+        for (int k = 623; k; k--) {
+            mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1566083941u)) - (uint32_t)i;
+            i++;
+            if (i >= 624) { mt[0] = mt[623]; i = 1; }
+        }
+        mt[0] = 0x80000000u;
+    }
+    uint32_t next() {
+        if (idx >= 624) {
+            for (int k = 0; k < 624; k++) {
+                uint32_t y = (mt[k] & 0x80000000u) | (mt[(k + 1) % 624] & 0x7fffffffu);
+                mt[k] = mt[(k + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+            }
+            idx = 0;
+        }
+        uint32_t y = mt[idx++];
+        y ^= (y >> 11); y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= (y >> 18);
+        return y;
+    }
+    double random() { uint32_t a = next() >> 5, b = next() >> 6; return ((double)a * 67108864.0 + (double)b) * (1.0 / 9007199254740992.0); }
+    double uniform(double a, double b) { return a + (b - a) * random(); }
+};
+
+// cald_helper.cutout (cald/cald_helper.py:88-132): rectangle selection only; the fill happens in
+// the preprocess kernel.  boxes: sub-sampled reference detections, original image coordinates.
+static int cutout_rects(uint64_t seed, int H, int W, int N, const float* boxes, int cut_num, int* rects) {
+    PyRandom rng; rng.seed(seed);
+    int count = 0;
+    for (int t = 0; t < 50; t++) {
+        double sh = rng.uniform(0.05 * H, 0.2 * H);
+        double sw = rng.uniform(0.05 * W, 0.2 * W);
+        double left = rng.uniform(0.0, (double)W - sw), right = left + sw;
+        double top = rng.uniform(0.0, (double)H - sh), bottom = top + sh;
+        int il = (int)left, it = (int)top, ir = (int)right, ib = (int)bottom;
+        float c[4] = {(float)il, (float)it, (float)ir, (float)ib};
+        float rmax = 0.0f; bool any_nan = false;
+        for (int i = 0; i < N; i++) {
+            const float* b = boxes + 4 * i;
+            float iw = std::fmin(c[2], b[2]) - std::fmax(c[0], b[0]); if (iw < 0.0f) iw = 0.0f;
+            float ih = std::fmin(c[3], b[3]) - std::fmax(c[1], b[1]); if (ih < 0.0f) ih = 0.0f;
+            float area = (b[2] - b[0]) * (b[3] - b[1]);
+            float ratio = (iw * ih) / area;
+            if (ratio != ratio) any_nan = true;
+            if (i == 0 || ratio > rmax) rmax = ratio;
+        }
+        if (!any_nan && (rmax > 0.4f || rmax < 0.1f)) continue;
+        rects[4 * count] = il; rects[4 * count + 1] = it; rects[4 * count + 2] = ir; rects[4 * count + 3] = ib;
+        if (++count >= cut_num) break;
+    }
+    return count;
+}
+extern "C" int cald_op_cutout_rects(uint64_t seed, int H, int W, int N, const float* boxes, int cut_num, int* rects_out, int* n_out) {
+    if (cut_num < 0 || cut_num > CALD_MAX_CUT) return fail(CALD_ERR_INVALID, "cut_num must be 0..%d", CALD_MAX_CUT);
+    *n_out = cutout_rects(seed, H, W, N, boxes, cut_num, rects_out);
+    return 0;
+}
+
+// np.round(np.linspace(0, n-1, 50)).astype(int)  (cald_train.py:110-113)
+static int subsample_indices(int n, int* inds) {
+    if (n <= 40) { for (int i = 0; i < n; i++) inds[i] = i; return n; }
+    double step = (double)(n - 1) / 49.0;
+    for (int i = 0; i < 50; i++) {
+        double v = (i == 49) ? (double)(n - 1) : (double)i * step;
+        inds[i] = (int)std::nearbyint(v);
+    }
+    return 50;
+}
+
+// numpy pairwise summation of float64 (np.mean over a 1-D array)
+static double np_sum(const double* a, int n) {
+    if (n < 8) { double r = 0.0; for (int i = 0; i < n; i++) r += a[i]; return r; }
+    if (n <= 128) {
+        double r[8];
+        for (int k = 0; k < 8; k++) r[k] = a[k];
+        int i;
+        for (i = 8; i < n - (n % 8); i += 8) for (int k = 0; k < 8; k++) r[k] += a[i + k];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; i++) res += a[i];
+        return res;
+    }
+    int n2 = n / 2; n2 -= n2 % 8;
+    return np_sum(a, n2) + np_sum(a + n2, n - n2);
+}
+
+// Pillow Resample.c precompute_coeffs + normalize_coeffs_8bpc for the BILINEAR filter
+static int pil_coeffs(int inSize, int outSize, std::vector<int>& bounds, std::vector<int>& kk) {
+    double scale = (double)inSize / (double)outSize, filterscale = scale;
+    if (filterscale < 1.0) filterscale = 1.0;
+    double support = 1.0 * filterscale;
+    int ksize = (int)std::ceil(support) * 2 + 1;
+    std::vector<double> pre((size_t)outSize * ksize);
+    bounds.assign((size_t)outSize * 2, 0); kk.assign((size_t)outSize * ksize, 0);
+    for (int xx = 0; xx < outSize; xx++) {
+        double center = (xx + 0.5) * scale, ww = 0.0, ss = 1.0 / filterscale;
+        int xmin = (int)(center - support + 0.5); if (xmin < 0) xmin = 0;
+        int xmax = (int)(center + support + 0.5); if (xmax > inSize) xmax = inSize;
+        xmax -= xmin;
+        double* k = &pre[(size_t)xx * ksize];
+        int x;
+        for (x = 0; x < xmax; x++) {
+            double t = (x + xmin - center + 0.5) * ss; if (t < 0) t = -t;
+            double w = t < 1.0 ? 1.0 - t : 0.0;
+            k[x] = w; ww += w;
+        }
+        for (x = 0; x < xmax; x++) if (ww != 0.0) k[x] /= ww;
+        for (; x < ksize; x++) k[x] = 0;
+        bounds[2 * xx] = xmin; bounds[2 * xx + 1] = xmax;
+    }
+    for (size_t i = 0; i < pre.size(); i++)
+        kk[i] = pre[i] < 0 ? (int)(-0.5 + pre[i] * (double)(1 << 22)) : (int)(0.5 + pre[i] * (double)(1 << 22));
+    return ksize;
+}
+static int get_pil(cald_ctx* c, int inSize, int outSize, PilCoef* out) {
+    auto key = std::make_pair(inSize, outSize);
+    auto it = c->pil.find(key);
+    if (it == c->pil.end()) {
+        std::vector<int> b, k;
+        PilCoef pc; pc.ksize = pil_coeffs(inSize, outSize, b, k);
+        HIPCHK(hipMalloc((void**)&pc.d_bounds, b.size() * sizeof(int)));
+        HIPCHK(hipMalloc((void**)&pc.d_kk, k.size() * sizeof(int)));
+        HIPCHK(hipMemcpy(pc.d_bounds, b.data(), b.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(pc.d_kk, k.data(), k.size() * sizeof(int), hipMemcpyHostToDevice));
+        it = c->pil.insert(std::make_pair(key, pc)).first;
+    }
+    *out = it->second;
+    return 0;
+}
+// dst [oh][ow][3]; tmp must hold H*ow*3 bytes
+static int pil_resize(cald_ctx* c, const uint8_t* src, int H, int W, uint8_t* dst, int oh, int ow, uint8_t* tmp) {
+    const uint8_t* cur = src;
+    if (ow != W) {
+        PilCoef pc; int rc = get_pil(c, W, ow, &pc); if (rc) return rc;
+        uint8_t* hdst = (oh != H) ? tmp : dst;
+        launch_pil_horizontal(src, H, W, hdst, ow, pc.d_bounds, pc.d_kk, pc.ksize, c->stream);
+        cur = hdst;
+    }
+    if (oh != H) {
+        PilCoef pc; int rc = get_pil(c, H, oh, &pc); if (rc) return rc;
+        launch_pil_vertical(cur, H, ow, dst, oh, pc.d_bounds, pc.d_kk, pc.ksize, c->stream);
+    } else if (ow == W) {
+        HIPCHK(hipMemcpyAsync(dst, src, (size_t)H * W * 3, hipMemcpyDeviceToDevice, c->stream));
+    }
+    return 0;
+}
+extern "C" int cald_op_pil_resize(cald_ctx* c, const uint8_t* src_dev, int H, int W, uint8_t* dst_dev, int oh, int ow) {
+    if (!c || !src_dev || !dst_dev || H <= 0 || W <= 0 || oh <= 0 || ow <= 0) return fail(CALD_ERR_INVALID, "bad arguments");
+    uint8_t* tmp = nullptr;
+    HIPCHK(hipMalloc((void**)&tmp, (size_t)H * ow * 3));
+    int rc = pil_resize(c, src_dev, H, W, dst_dev, oh, ow, tmp);
+    hipStreamSynchronize(c->stream);
+    hipFree(tmp);
+    return rc;
+}
+
+// =============================================================================================
+// model
+// =============================================================================================
+struct HostTensor { std::vector<float> data; std::vector<int64_t> shape; };
+struct ConvLayer {
+    float *w = nullptr, *bias = nullptr, *scale = nullptr, *shift = nullptr;
+    int Cin = 0, Cout = 0, CoutPad = 0, K = 0, Kpad = 0, KH = 1, KW = 1, stride = 1, pad = 0;
+};
+struct Bottleneck { ConvLayer c1, c2, c3, down; bool has_down = false; bool layer_end = false; };
+struct DebugEntry { const float* ptr; int level; int C; int kind; };  // kind 0: level tensor, 1: roi rows [cap][C]
+
+struct cald_model {
+    cald_ctx* ctx = nullptr;
+    cald_model_cfg cfg;
+    std::map<std::string, HostTensor> sd;
+    bool finalized = false;
+    ConvLayer conv1; std::vector<Bottleneck> blocks;
+    ConvLayer fpn_inner[4], fpn_layer[4], rpn_conv, rpn_head, fc6, fc7, pred;
+    float* d_anchors = nullptr;
+    std::vector<void*> owned;
+    std::map<std::string, DebugEntry> dbg;
+    BatchPlan plan; int last_V = 0;
+    std::vector<ViewDesc> last_views;
+    // batch-level detection buffers used by cald_sweep
+    DetBuffers sweep_det; int sweep_det_views = 0;
+};
+
+static int round_up(int x, int m) { return (x + m - 1) / m * m; }
+static int cout_pad(int cout) { return cout >= 128 ? round_up(cout, 128) : (cout >= 64 ? round_up(cout, 64) : round_up(cout, 32)); }
+
+extern "C" int cald_model_create(cald_ctx* ctx, const cald_model_cfg* cfg, cald_model** out) {
+    if (!ctx || !cfg || !out) return fail(CALD_ERR_INVALID, "null argument");
+    if (cfg->arch != CALD_ARCH_FRCNN) return fail(CALD_ERR_INVALID, "arch %d not supported by this build (FRCNN only)", cfg->arch);
+    if (cfg->depth != 50 && cfg->depth != 101) return fail(CALD_ERR_INVALID, "depth must be 50 or 101");
+    if (cfg->num_classes < 2 || cfg->num_classes > 256) return fail(CALD_ERR_INVALID, "num_classes out of range");
+    if (cfg->rpn_pre_nms_top_n > 1024 || cfg->rpn_post_nms_top_n > CALD_ROI_CAP || cfg->rpn_pre_nms_top_n < 1 || cfg->rpn_post_nms_top_n < 1)
+        return fail(CALD_ERR_INVALID, "rpn top-n out of range (pre <= 1024, post <= %d)", CALD_ROI_CAP);
+    if (cfg->detections_per_img < 1 || cfg->detections_per_img > 1024) return fail(CALD_ERR_INVALID, "detections_per_img out of range");
+    cald_model* m = new cald_model();
+    m->ctx = ctx; m->cfg = *cfg;
+    memset(&m->sweep_det, 0, sizeof(m->sweep_det));
+    *out = m;
+    return 0;
+}
+extern "C" int cald_model_load_tensor(cald_model* m, const char* key, const float* data, const int64_t* shape, int ndim) {
+    if (!m || !key || !data || !shape || ndim < 1 || ndim > 4) return fail(CALD_ERR_INVALID, "bad arguments");
+    if (m->finalized) return fail(CALD_ERR_STATE, "model already finalized");
+    HostTensor t; int64_t n = 1;
+    for (int i = 0; i < ndim; i++) { if (shape[i] <= 0) return fail(CALD_ERR_INVALID, "bad shape"); n *= shape[i]; t.shape.push_back(shape[i]); }
+    t.data.assign(data, data + n);
+    m->sd[key] = std::move(t);
+    return 0;
+}
+
+static int get_t(cald_model* m, const std::string& key, const HostTensor** t) {
+    auto it = m->sd.find(key);
+    if (it == m->sd.end()) return fail(CALD_ERR_MISSING_WEIGHT, "missing tensor '%s' in state dict", key.c_str());
+    *t = &it->second;
+    return 0;
+}
+template <typename T> static int upload(cald_model* m, const std::vector<T>& h, T** d) {
+    HIPCHK(hipMalloc((void**)d, h.size() * sizeof(T)));
+    HIPCHK(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    m->owned.push_back(*d);
+    return 0;
+}
+// torch conv weight [Cout][Cin][KH][KW] (optionally several tensors concatenated along Cout)
+// -> K-major [Kpad][CoutPad], k = (kh*KW + kw)*CinPad + ci
+static int make_conv(cald_model* m, ConvLayer& L, const std::vector<std::string>& wkeys, const std::vector<std::string>& bkeys,
+                     const std::string& bn_prefix, int stride, int pad, int cin_pad_to = 0) {
+    std::vector<const HostTensor*> ws;
+    int cout = 0, cin = -1, kh = -1, kw = -1;
+    for (auto& k : wkeys) {
+        const HostTensor* t; int rc = get_t(m, k, &t); if (rc) return rc;
+        if (t->shape.size() == 2) { if (cin < 0) { cin = (int)t->shape[1]; kh = kw = 1; } }
+        else if (t->shape.size() == 4) { if (cin < 0) { cin = (int)t->shape[1]; kh = (int)t->shape[2]; kw = (int)t->shape[3]; } }
+        else return fail(CALD_ERR_INVALID, "tensor '%s' has unsupported rank", k.c_str());
+        cout += (int)t->shape[0]; ws.push_back(t);
+    }
+    int cinp = cin_pad_to > cin ? cin_pad_to : cin;
+    if (cinp % 4) return fail(CALD_ERR_INVALID, "Cin must be a multiple of 4");
+    L.Cin = cinp; L.Cout = cout; L.CoutPad = cout_pad(cout); L.KH = kh; L.KW = kw; L.stride = stride; L.pad = pad;
+    L.K = kh * kw * cinp; L.Kpad = round_up(L.K, 16);
+    std::vector<float> w((size_t)L.Kpad * L.CoutPad, 0.0f);
+    int co0 = 0;
+    for (auto t : ws) {
+        int c0 = (int)t->shape[0];
+        for (int co = 0; co < c0; co++)
+            for (int ci = 0; ci < cin; ci++)
+                for (int y = 0; y < kh; y++)
+                    for (int x = 0; x < kw; x++)
+                        w[(size_t)((y * kw + x) * cinp + ci) * L.CoutPad + co0 + co] = t->data[(((size_t)co * cin + ci) * kh + y) * kw + x];
+        co0 += c0;
+    }
+    int rc = upload(m, w, &L.w); if (rc) return rc;
+    if (!bkeys.empty()) {
+        std::vector<float> b(L.CoutPad, 0.0f); int o = 0;
+        for (auto& k : bkeys) { const HostTensor* t; rc = get_t(m, k, &t); if (rc) return rc; for (float v : t->data) b[o++] = v; }
+        rc = upload(m, b, &L.bias); if (rc) return rc;
+    }
+    if (!bn_prefix.empty()) {   // FrozenBatchNorm2d: scale = w * rsqrt(var + eps); shift = b - mean * scale  (eps 1e-5)
+        const HostTensor *gw, *gb, *rm, *rv;
+        if ((rc = get_t(m, bn_prefix + ".weight", &gw)) || (rc = get_t(m, bn_prefix + ".bias", &gb)) ||
+            (rc = get_t(m, bn_prefix + ".running_mean", &rm)) || (rc = get_t(m, bn_prefix + ".running_var", &rv))) return rc;
+        std::vector<float> sc(L.CoutPad, 0.0f), sh(L.CoutPad, 0.0f);
+        for (int i = 0; i < cout; i++) {
+            float s = gw->data[i] * (1.0f / sqrtf(rv->data[i] + 1e-5f));
+            sc[i] = s; sh[i] = gb->data[i] - rm->data[i] * s;
+        }
+        if ((rc = upload(m, sc, &L.scale)) || (rc = upload(m, sh, &L.shift))) return rc;
+    }
+    return 0;
+}
+
+extern "C" int cald_model_finalize(cald_model* m) {
+    if (!m) return fail(CALD_ERR_INVALID, "model is null");
+    if (m->finalized) return 0;
+    HIPCHK(hipSetDevice(m->ctx->device));
+    int rc;
+    const std::string bb = "backbone.body.";
+    if ((rc = make_conv(m, m->conv1, {bb + "conv1.weight"}, {}, bb + "bn1", 2, 3, 4))) return rc;
+    const int nblk50[4] = {3, 4, 6, 3}, nblk101[4] = {3, 4, 23, 3};
+    const int* nb = m->cfg.depth == 50 ? nblk50 : nblk101;
+    for (int li = 0; li < 4; li++)
+        for (int bi = 0; bi < nb[li]; bi++) {
+            Bottleneck B;
+            char pre[128]; snprintf(pre, sizeof(pre), "backbone.body.layer%d.%d", li + 1, bi);
+            std::string p(pre);
+            int stride = (bi == 0 && li > 0) ? 2 : 1;
+            if ((rc = make_conv(m, B.c1, {p + ".conv1.weight"}, {}, p + ".bn1", 1, 0))) return rc;
+            if ((rc = make_conv(m, B.c2, {p + ".conv2.weight"}, {}, p + ".bn2", stride, 1))) return rc;
+            if ((rc = make_conv(m, B.c3, {p + ".conv3.weight"}, {}, p + ".bn3", 1, 0))) return rc;
+            if (m->sd.count(p + ".downsample.0.weight")) {
+                B.has_down = true;
+                if ((rc = make_conv(m, B.down, {p + ".downsample.0.weight"}, {}, p + ".downsample.1", stride, 0))) return rc;
+            }
+            B.layer_end = (bi == nb[li] - 1);
+            m->blocks.push_back(B);
+        }
+    for (int i = 0; i < 4; i++) {
+        char k[128];
+        snprintf(k, sizeof(k), "backbone.fpn.inner_blocks.%d", i);
+        if ((rc = make_conv(m, m->fpn_inner[i], {std::string(k) + ".weight"}, {std::string(k) + ".bias"}, "", 1, 0))) return rc;
+        snprintf(k, sizeof(k), "backbone.fpn.layer_blocks.%d", i);
+        if ((rc = make_conv(m, m->fpn_layer[i], {std::string(k) + ".weight"}, {std::string(k) + ".bias"}, "", 1, 1))) return rc;
+    }
+    if ((rc = make_conv(m, m->rpn_conv, {"rpn.head.conv.weight"}, {"rpn.head.conv.bias"}, "", 1, 1))) return rc;
+    if ((rc = make_conv(m, m->rpn_head, {"rpn.head.cls_logits.weight", "rpn.head.bbox_pred.weight"},
+                        {"rpn.head.cls_logits.bias", "rpn.head.bbox_pred.bias"}, "", 1, 0))) return rc;
+    {   // fc6: torch K order is (c, bin); the RoIAlign kernel writes (bin, c) -> permute the weight's K axis
+        const HostTensor* t; if ((rc = get_t(m, "roi_heads.box_head.fc6.weight", &t))) return rc;
+        if (t->shape.size() != 2 || t->shape[1] != 256 * 49) return fail(CALD_ERR_INVALID, "fc6 weight must be [N][12544]");
+        HostTensor p; p.shape = {t->shape[0], t->shape[1]}; p.data.resize(t->data.size());
+        int N = (int)t->shape[0];
+        for (int n = 0; n < N; n++)
+            for (int c = 0; c < 256; c++)
+                for (int b = 0; b < 49; b++) p.data[(size_t)n * 12544 + b * 256 + c] = t->data[(size_t)n * 12544 + c * 49 + b];
+        m->sd["__fc6_perm"] = std::move(p);
+        if ((rc = make_conv(m, m->fc6, {"__fc6_perm"}, {"roi_heads.box_head.fc6.bias"}, "", 1, 0))) return rc;
+        m->sd.erase("__fc6_perm");
+    }
+    if ((rc = make_conv(m, m->fc7, {"roi_heads.box_head.fc7.weight"}, {"roi_heads.box_head.fc7.bias"}, "", 1, 0))) return rc;
+    if ((rc = make_conv(m, m->pred, {"roi_heads.box_predictor.cls_score.weight", "roi_heads.box_predictor.bbox_pred.weight"},
+                        {"roi_heads.box_predictor.cls_score.bias", "roi_heads.box_predictor.bbox_pred.bias"}, "", 1, 0))) return rc;
+    if (m->pred.Cout != 5 * m->cfg.num_classes) return fail(CALD_ERR_INVALID, "box predictor has %d outputs, expected 5*num_classes=%d", m->pred.Cout, 5 * m->cfg.num_classes);
+    {   // AnchorGenerator base anchors: sizes (32,64,128,256,512), ratios (0.5,1,2)
+        std::vector<float> base(5 * 3 * 4);
+        const float sizes[5] = {32.f, 64.f, 128.f, 256.f, 512.f}, ratios[3] = {0.5f, 1.0f, 2.0f};
+        for (int l = 0; l < 5; l++)
+            for (int r = 0; r < 3; r++) {
+                float hr = sqrtf(ratios[r]), wr = 1.0f / hr;
+                float ws = wr * sizes[l], hs = hr * sizes[l];
+                float* b = &base[(l * 3 + r) * 4];
+                b[0] = rintf(-ws / 2.0f); b[1] = rintf(-hs / 2.0f); b[2] = rintf(ws / 2.0f); b[3] = rintf(hs / 2.0f);
+            }
+        if ((rc = upload(m, base, &m->d_anchors))) return rc;
+    }
+    m->sd.clear();
+    m->finalized = true;
+    return 0;
+}
+extern "C" int cald_model_destroy(cald_model* m) {
+    if (!m) return 0;
+    hipSetDevice(m->ctx->device);
+    hipStreamSynchronize(m->ctx->stream);
+    for (void* p : m->owned) hipFree(p);
+    delete m;
+    return 0;
+}
+
+// =============================================================================================
+// forward
+// =============================================================================================
+static void build_plan(BatchPlan& P, int V, const ViewDesc* views, const int (*hp)[2]) {
+    memset(&P, 0, sizeof(P));
+    for (int l = 0; l < CALD_MAX_LEVELS; l++) {
+        long long off = 0; int tile = 0;
+        for (int v = 0; v <= V; v++) {
+            LevelSeg& s = P.seg[l][v];
+            s.pix_off = off; s.tile_start = tile;
+            if (v == V) break;
+            int H, W;
+            if (l == 7) { H = 1; W = CALD_ROI_CAP; }
+            else if (l == 6) { H = (hp[v][0] / 32 - 1) / 2 + 1; W = (hp[v][1] / 32 - 1) / 2 + 1; }
+            else { H = hp[v][0] >> l; W = hp[v][1] >> l; }
+            s.H = H; s.W = W;
+            off += (long long)H * W;
+            tile += (H * W + 127) / 128;
+        }
+    }
+}
+static long long level_pix(const BatchPlan& P, int l, int V) { return P.seg[l][V].pix_off; }
+static int level_tiles(const BatchPlan& P, int l, int V) { return P.seg[l][V].tile_start; }
+
+struct FwdBufs {
+    float *in0, *c1, *p1, *X[2], *T1, *T2, *D, *Cf[4], *inner[4], *Pf[5], *rpn_t, *rpn_h[5];
+    unsigned long long* cand_key; float *cand_box, *sorted_box, *sorted_raw; int* sorted_count;
+    float* proposals; int* prop_count;
+    float *roi, *f6, *f7, *pr, *prob, *pmax; unsigned long long* keys; float* cbox; int* key_count;
+};
+
+static int conv_on(cald_model* m, const ConvLayer& L, const float* in, float* out, int lin, int lout, int V, bool relu,
+                   const float* residual = nullptr, const float* up = nullptr, int lup = 0, const int* dyn = nullptr) {
+    ConvArgs a;
+    const BatchPlan* dp = m->ctx->d_plan;
+    a.in = in; a.out = out; a.w = L.w; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift;
+    a.residual = residual; a.up = up;
+    a.seg_in = dp->seg[lin]; a.seg_out = dp->seg[lout]; a.seg_up = dp->seg[lup];
+    a.dyn_rows = dyn; a.V = V;
+    a.Cin = L.Cin; a.Cout = L.Cout; a.CoutPad = L.CoutPad; a.Kpad = L.Kpad;
+    a.KH = L.KH; a.KW = L.KW; a.stride = L.stride; a.pad = L.pad; a.relu = relu ? 1 : 0;
+    a.total_mtiles = level_tiles(m->plan, lout, V);
+    a.out_ld = L.Cout;
+    double flops = 2.0 * (double)level_pix(m->plan, lout, V) * (double)L.Cout * (double)(L.KH * L.KW * L.Cin);
+    return run_conv(m->ctx, a, flops);
+}
+
+static void fwd_layout(cald_model* m, Bump& B, FwdBufs& F, int V) {
+    const BatchPlan& P = m->plan;
+    const long long px[8] = {level_pix(P, 0, V), level_pix(P, 1, V), level_pix(P, 2, V), level_pix(P, 3, V),
+                             level_pix(P, 4, V), level_pix(P, 5, V), level_pix(P, 6, V), level_pix(P, 7, V)};
+    F.in0 = B.get<float>(px[0] * 4);
+    F.c1 = B.get<float>(px[1] * 64);
+    F.p1 = B.get<float>(px[2] * 64);
+    F.X[0] = B.get<float>(px[2] * 256); F.X[1] = B.get<float>(px[2] * 256);
+    F.T1 = B.get<float>(px[2] * 128); F.T2 = B.get<float>(px[2] * 64); F.D = B.get<float>(px[2] * 256);
+    const int cch[4] = {256, 512, 1024, 2048};
+    for (int i = 0; i < 4; i++) F.Cf[i] = B.get<float>(px[2 + i] * cch[i]);
+    for (int i = 0; i < 4; i++) F.inner[i] = B.get<float>(px[2 + i] * 256);
+    for (int i = 0; i < 5; i++) F.Pf[i] = B.get<float>(px[2 + i] * 256);
+    F.rpn_t = B.get<float>(px[2] * 256);
+    for (int i = 0; i < 5; i++) F.rpn_h[i] = B.get<float>(px[2 + i] * 15);
+    const int pre = m->cfg.rpn_pre_nms_top_n;
+    F.cand_key = B.get<unsigned long long>((size_t)V * 5 * pre);
+    F.cand_box = B.get<float>((size_t)V * 5 * pre * 4);
+    F.sorted_box = B.get<float>((size_t)V * 5 * pre * 4);
+    F.sorted_raw = B.get<float>((size_t)V * 5 * pre * 4);
+    F.sorted_count = B.get<int>(V);
+    F.proposals = B.get<float>((size_t)V * CALD_ROI_CAP * 4);
+    F.prop_count = B.get<int>(V);
+    F.roi = B.get<float>((size_t)V * CALD_ROI_CAP * 12544);
+    F.f6 = B.get<float>((size_t)V * CALD_ROI_CAP * 1024);
+    F.f7 = B.get<float>((size_t)V * CALD_ROI_CAP * 1024);
+    F.pr = B.get<float>((size_t)V * CALD_ROI_CAP * m->pred.Cout);
+    F.prob = B.get<float>((size_t)V * CALD_ROI_CAP * m->cfg.num_classes);
+    F.pmax = B.get<float>((size_t)V * CALD_ROI_CAP);
+    F.keys = B.get<unsigned long long>((size_t)V * 32768);
+    F.cbox = B.get<float>((size_t)V * 2 * 32768 * 4);
+    F.key_count = B.get<int>(V);
+}
+
+// views: host descriptors with src/H/W/flip/rects filled; Hr/Wr/Ho/Wo are filled here.
+static int forward_frcnn(cald_model* m, int V, ViewDesc* views, const DetBuffers& det) {
+    cald_ctx* c = m->ctx;
+    if (!m->finalized) return fail(CALD_ERR_STATE, "model not finalized (call cald_model_finalize)");
+    if (V < 1 || V > CALD_MAX_VIEWS) return fail(CALD_ERR_INVALID, "n_views must be 1..%d", CALD_MAX_VIEWS);
+    if (det.cap < m->cfg.detections_per_img) return fail(CALD_ERR_INVALID, "detection capacity %d < detections_per_img %d", det.cap, m->cfg.detections_per_img);
+    HIPCHK(hipSetDevice(c->device));
+    int hp[CALD_MAX_VIEWS][2];
+    int max_pix0 = 0, max_pix2 = 0, max_pix6 = 0;
+    for (int v = 0; v < V; v++) {
+        ViewDesc& d = views[v];
+        if (!d.src || d.H <= 0 || d.W <= 0 || d.nrect < 0 || d.nrect > CALD_MAX_CUT) return fail(CALD_ERR_INVALID, "view %d is malformed", v);
+        int Hp, Wp;
+        transform_size(d.H, d.W, m->cfg.min_size, m->cfg.max_size, &d.Hr, &d.Wr, &Hp, &Wp);
+        d.Ho = d.H; d.Wo = d.W;
+        hp[v][0] = Hp; hp[v][1] = Wp;
+        if (Hp * Wp > max_pix0) max_pix0 = Hp * Wp;
+    }
+    build_plan(m->plan, V, views, hp);
+    m->last_V = V; m->last_views.assign(views, views + V);
+    for (int v = 0; v < V; v++) {
+        int p2 = m->plan.seg[2][v].H * m->plan.seg[2][v].W; if (p2 > max_pix2) max_pix2 = p2;
+        int p6 = m->plan.seg[6][v].H * m->plan.seg[6][v].W; if (p6 > max_pix6) max_pix6 = p6;
+    }
+    FwdBufs F;
+    { Bump dry(nullptr, true); fwd_layout(m, dry, F, V); int rc = arena_reserve(c, dry.off); if (rc) return rc; }
+    { Bump real(c->arena, false); fwd_layout(m, real, F, V); }
+    {
+        const int si = c->stage_i; c->stage_i = (si + 1) % cald_ctx::NSTAGE;
+        HIPCHK(hipEventSynchronize(c->stage_ev[si]));
+        memcpy(c->h_stage[si], &m->plan, sizeof(BatchPlan));
+        memcpy(c->h_stage[si] + sizeof(BatchPlan), views, sizeof(ViewDesc) * V);
+        HIPCHK(hipMemcpyAsync(c->d_plan, c->h_stage[si], sizeof(BatchPlan), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->d_views, c->h_stage[si] + sizeof(BatchPlan), sizeof(ViewDesc) * V, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipEventRecord(c->stage_ev[si], c->stream));
+    }
+    const BatchPlan* dp = c->d_plan;
+    hipStream_t st = c->stream;
+    int rc;
+    m->dbg.clear();
+    if (c->prof && !c->tot_open) { HIPCHK(hipEventRecord(c->tot0, st)); c->tot_open = true; }
+
+    // ---- transform + ResNet body (rows A14, A15) ----
+    launch_preprocess(c->d_views, dp->seg[0], F.in0, V, max_pix0, st);
+    m->dbg["input"] = {F.in0, 0, 4, 0};
+    if ((rc = conv_on(m, m->conv1, F.in0, F.c1, 0, 1, V, true))) return rc;
+    m->dbg["conv1"] = {F.c1, 1, 64, 0};
+    launch_maxpool(F.c1, F.p1, dp->seg[1], dp->seg[2], 64, V, max_pix2, st);
+    m->dbg["pool1"] = {F.p1, 2, 64, 0};
+    const float* cur = F.p1; int lvl = 2, layer = 0, xi = 0;
+    for (size_t b = 0; b < m->blocks.size(); b++) {
+        const Bottleneck& B = m->blocks[b];
+        const int lout = lvl + (B.c2.stride == 2 ? 1 : 0);
+        const float* idn = cur;
+        if (B.has_down) { if ((rc = conv_on(m, B.down, cur, F.D, lvl, lout, V, false))) return rc; idn = F.D; }
+        if ((rc = conv_on(m, B.c1, cur, F.T1, lvl, lvl, V, true))) return rc;
+        if ((rc = conv_on(m, B.c2, F.T1, F.T2, lvl, lout, V, true))) return rc;
+        float* dst = B.layer_end ? F.Cf[layer] : F.X[xi];
+        if ((rc = conv_on(m, B.c3, F.T2, dst, lout, lout, V, true, idn))) return rc;
+        cur = dst; lvl = lout;
+        if (B.layer_end) layer++; else xi ^= 1;
+    }
+    const char* cn[4] = {"C2", "C3", "C4", "C5"};
+    const int cch[4] = {256, 512, 1024, 2048};
+    for (int i = 0; i < 4; i++) m->dbg[cn[i]] = {F.Cf[i], 2 + i, cch[i], 0};
+    // ---- FPN (row A16) ----
+    if ((rc = conv_on(m, m->fpn_inner[3], F.Cf[3], F.inner[3], 5, 5, V, false))) return rc;
+    for (int i = 2; i >= 0; i--)
+        if ((rc = conv_on(m, m->fpn_inner[i], F.Cf[i], F.inner[i], 2 + i, 2 + i, V, false, nullptr, F.inner[i + 1], 3 + i))) return rc;
+    for (int i = 0; i < 4; i++)
+        if ((rc = conv_on(m, m->fpn_layer[i], F.inner[i], F.Pf[i], 2 + i, 2 + i, V, false))) return rc;
+    launch_subsample2(F.Pf[3], F.Pf[4], dp->seg[5], dp->seg[6], 256, V, max_pix6, st);
+    const char* pn[5] = {"P2", "P3", "P4", "P5", "P6"};
+    for (int i = 0; i < 5; i++) m->dbg[pn[i]] = {F.Pf[i], 2 + i, 256, 0};
+    // ---- RPN (row A17) ----
+    const char* rn[5] = {"rpn0", "rpn1", "rpn2", "rpn3", "rpn4"};
+    for (int i = 0; i < 5; i++) {
+        if ((rc = conv_on(m, m->rpn_conv, F.Pf[i], F.rpn_t, 2 + i, 2 + i, V, true))) return rc;
+        if ((rc = conv_on(m, m->rpn_head, F.rpn_t, F.rpn_h[i], 2 + i, 2 + i, V, false))) return rc;
+        m->dbg[rn[i]] = {F.rpn_h[i], 2 + i, 15, 0};
+    }
+    RpnArgs ra;
+    for (int i = 0; i < 5; i++) { ra.head[i] = F.rpn_h[i]; ra.seg[i] = dp->seg[2 + i]; }
+    ra.seg0 = dp->seg[0]; ra.views = c->d_views; ra.base_anchors = m->d_anchors;
+    ra.head_ld = 15; ra.A = 3; ra.V = V; ra.pre_n = m->cfg.rpn_pre_nms_top_n; ra.post_n = m->cfg.rpn_post_nms_top_n;
+    ra.nms_thr = m->cfg.rpn_nms_thresh; ra.min_size = 1e-3f;
+    ra.cand_key = F.cand_key; ra.cand_box = F.cand_box; ra.sorted_box = F.sorted_box; ra.sorted_raw = F.sorted_raw;
+    ra.sorted_count = F.sorted_count; ra.proposals = F.proposals; ra.prop_count = F.prop_count;
+    launch_rpn(ra, st);
+    m->dbg["proposals"] = {F.proposals, 7, 4, 1};
+    // ---- box head (rows A18, A19, A20) ----
+    RoiArgs ro;
+    for (int i = 0; i < 4; i++) { ro.feat[i] = F.Pf[i]; ro.seg[i] = dp->seg[2 + i]; }
+    ro.C = 256; ro.V = V; ro.proposals = F.proposals; ro.prop_count = F.prop_count; ro.out = F.roi;
+    launch_roi_align(ro, st);
+    m->dbg["roi"] = {F.roi, 7, 12544, 1};
+    if ((rc = conv_on(m, m->fc6, F.roi, F.f6, 7, 7, V, true, nullptr, nullptr, 0, F.prop_count))) return rc;
+    if ((rc = conv_on(m, m->fc7, F.f6, F.f7, 7, 7, V, true, nullptr, nullptr, 0, F.prop_count))) return rc;
+    if ((rc = conv_on(m, m->pred, F.f7, F.pr, 7, 7, V, false, nullptr, nullptr, 0, F.prop_count))) return rc;
+    m->dbg["fc6"] = {F.f6, 7, 1024, 1}; m->dbg["fc7"] = {F.f7, 7, 1024, 1}; m->dbg["pred"] = {F.pr, 7, m->pred.Cout, 1};
+    PostArgs pa;
+    pa.pred = F.pr; pa.pred_ld = m->pred.Cout; pa.C = m->cfg.num_classes; pa.V = V;
+    pa.proposals = F.proposals; pa.prop_count = F.prop_count; pa.views = c->d_views;
+    pa.score_thr = m->cfg.box_score_thresh; pa.nms_thr = m->cfg.box_nms_thresh;
+    pa.prob = F.prob; pa.pmax = F.pmax; pa.keys = F.keys; pa.cbox = F.cbox; pa.key_count = F.key_count; pa.key_cap = 32768;
+    pa.det = det;
+    launch_frcnn_postprocess(pa, st);
+    HIPCHK(hipGetLastError());
+    if (c->prof) {
+        HIPCHK(hipEventRecord(c->tot1, st));
+        HIPCHK(hipEventSynchronize(c->tot1));
+        float t = 0.f; HIPCHK(hipEventElapsedTime(&t, c->tot0, c->tot1));
+        c->tot_ms += t; c->tot_open = false;
+    }
+    return 0;
+}
+
+static int fill_view(ViewDesc& d, const cald_view& v) {
+    memset(&d, 0, sizeof(d));
+    d.src = v.image_dev; d.H = v.H; d.W = v.W; d.flip = v.flip ? 1 : 0; d.nrect = v.nrect;
+    if (v.nrect < 0 || v.nrect > CALD_MAX_CUT) return fail(CALD_ERR_INVALID, "nrect must be 0..%d", CALD_MAX_CUT);
+    for (int i = 0; i < 4 * v.nrect; i++) d.rects[i] = v.rects[i];
+    return 0;
+}
+
+extern "C" int cald_forward(cald_model* m, int n_views, const cald_view* views, const cald_dets* out) {
+    if (!m || !views || !out) return fail(CALD_ERR_INVALID, "null argument");
+    if (n_views < 1 || n_views > CALD_MAX_VIEWS) return fail(CALD_ERR_INVALID, "n_views must be 1..%d", CALD_MAX_VIEWS);
+    std::vector<ViewDesc> vd(n_views);
+    for (int i = 0; i < n_views; i++) { int rc = fill_view(vd[i], views[i]); if (rc) return rc; }
+    DetBuffers det;
+    det.boxes = out->boxes_dev; det.scores = out->scores_dev; det.labels = (long long*)out->labels_dev; det.props = out->props_dev;
+    det.prob_max = out->prob_max_dev; det.scores_cls = out->scores_cls_dev; det.count = out->count_dev;
+    det.cap = out->cap; det.C = m->cfg.num_classes;
+    if (!det.boxes || !det.scores || !det.labels || !det.props || !det.prob_max || !det.scores_cls || !det.count)
+        return fail(CALD_ERR_INVALID, "output buffers must all be provided");
+    return forward_frcnn(m, n_views, vd.data(), det);
+}
+
+extern "C" int cald_debug_tensor(cald_model* m, const char* name, int view, float* host_out, int64_t capacity, int64_t* shape3) {
+    if (!m || !name || !host_out || !shape3) return fail(CALD_ERR_INVALID, "null argument");
+    auto it = m->dbg.find(name);
+    if (it == m->dbg.end()) return fail(CALD_ERR_INVALID, "no intermediate tensor named '%s'", name);
+    if (view < 0 || view >= m->last_V) return fail(CALD_ERR_INVALID, "view out of range");
+    const DebugEntry& e = it->second;
+    const LevelSeg& s = m->plan.seg[e.level][view];
+    int64_t n = (int64_t)s.H * s.W * e.C;
+    shape3[0] = s.H; shape3[1] = s.W; shape3[2] = e.C;
+    if (n > capacity) return fail(CALD_ERR_INVALID, "buffer too small: need %lld floats", (long long)n);
+    HIPCHK(hipStreamSynchronize(m->ctx->stream));
+    HIPCHK(hipMemcpy(host_out, e.ptr + s.pix_off * e.C, n * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// =============================================================================================
+// operator-level entry points
+// =============================================================================================
+extern "C" int cald_op_conv2d(cald_ctx* c, const float* in, int H, int W, int Cin, const float* weight, int Cout, int KH, int KW,
+                              int stride, int pad, const float* bias, const float* bn_scale, const float* bn_shift,
+                              const float* residual, int relu, float* out) {
+    if (!c || !in || !weight || !out) return fail(CALD_ERR_INVALID, "null argument");
+    if (Cin % 4) return fail(CALD_ERR_INVALID, "Cin must be a multiple of 4");
+    HIPCHK(hipSetDevice(c->device));
+    const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+    const int CoutPad = cout_pad(Cout), K = KH * KW * Cin, Kpad = round_up(K, 16);
+    std::vector<float> w((size_t)Kpad * CoutPad, 0.0f), b(CoutPad, 0.0f), sc(CoutPad, 0.0f), sh(CoutPad, 0.0f);
+    for (int co = 0; co < Cout; co++)
+        for (int ci = 0; ci < Cin; ci++)
+            for (int y = 0; y < KH; y++)
+                for (int x = 0; x < KW; x++)
+                    w[(size_t)((y * KW + x) * Cin + ci) * CoutPad + co] = weight[(((size_t)co * Cin + ci) * KH + y) * KW + x];
+    for (int i = 0; i < Cout; i++) { if (bias) b[i] = bias[i]; if (bn_scale) { sc[i] = bn_scale[i]; sh[i] = bn_shift[i]; } }
+    BatchPlan P; memset(&P, 0, sizeof(P));
+    P.seg[0][0].H = H; P.seg[0][0].W = W; P.seg[0][1].pix_off = (long long)H * W; P.seg[0][1].tile_start = (H * W + 127) / 128;
+    P.seg[1][0].H = Ho; P.seg[1][0].W = Wo; P.seg[1][1].pix_off = (long long)Ho * Wo; P.seg[1][1].tile_start = (Ho * Wo + 127) / 128;
+    float *d_in, *d_out, *d_w, *d_b, *d_sc, *d_sh, *d_res = nullptr; BatchPlan* d_p;
+    HIPCHK(hipMalloc((void**)&d_in, (size_t)H * W * Cin * 4)); HIPCHK(hipMalloc((void**)&d_out, (size_t)Ho * Wo * Cout * 4));
+    HIPCHK(hipMalloc((void**)&d_w, w.size() * 4)); HIPCHK(hipMalloc((void**)&d_b, b.size() * 4));
+    HIPCHK(hipMalloc((void**)&d_sc, sc.size() * 4)); HIPCHK(hipMalloc((void**)&d_sh, sh.size() * 4));
+    HIPCHK(hipMalloc((void**)&d_p, sizeof(BatchPlan)));
+    HIPCHK(hipMemcpy(d_in, in, (size_t)H * W * Cin * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_w, w.data(), w.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_b, b.data(), b.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_sc, sc.data(), sc.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_sh, sh.data(), sh.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_p, &P, sizeof(P), hipMemcpyHostToDevice));
+    if (residual) { HIPCHK(hipMalloc((void**)&d_res, (size_t)Ho * Wo * Cout * 4)); HIPCHK(hipMemcpy(d_res, residual, (size_t)Ho * Wo * Cout * 4, hipMemcpyHostToDevice)); }
+    ConvArgs a; memset(&a, 0, sizeof(a));
+    a.in = d_in; a.out = d_out; a.w = d_w; a.bias = bias ? d_b : nullptr; a.scale = bn_scale ? d_sc : nullptr; a.shift = bn_scale ? d_sh : nullptr;
+    a.residual = d_res; a.up = nullptr; a.seg_in = d_p->seg[0]; a.seg_out = d_p->seg[1]; a.seg_up = d_p->seg[1]; a.dyn_rows = nullptr;
+    a.V = 1; a.Cin = Cin; a.Cout = Cout; a.CoutPad = CoutPad; a.Kpad = Kpad; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
+    a.relu = relu; a.total_mtiles = (Ho * Wo + 127) / 128; a.out_ld = Cout;
+    launch_conv(a, c->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(out, d_out, (size_t)Ho * Wo * Cout * 4, hipMemcpyDeviceToHost));
+    hipFree(d_in); hipFree(d_out); hipFree(d_w); hipFree(d_b); hipFree(d_sc); hipFree(d_sh); hipFree(d_p); if (d_res) hipFree(d_res);
+    return 0;
+}
+
+// helper: device detection buffers
+static int alloc_det(DetBuffers& d, int V, int cap, int C) {
+    d.cap = cap; d.C = C;
+    HIPCHK(hipMalloc((void**)&d.boxes, (size_t)V * cap * 16)); HIPCHK(hipMalloc((void**)&d.scores, (size_t)V * cap * 4));
+    HIPCHK(hipMalloc((void**)&d.labels, (size_t)V * cap * 8)); HIPCHK(hipMalloc((void**)&d.props, (size_t)V * cap * 16));
+    HIPCHK(hipMalloc((void**)&d.prob_max, (size_t)V * cap * 4)); HIPCHK(hipMalloc((void**)&d.scores_cls, (size_t)V * cap * C * 4));
+    HIPCHK(hipMalloc((void**)&d.count, (size_t)V * 4));
+    return 0;
+}
+static void free_det(DetBuffers& d) {
+    hipFree(d.boxes); hipFree(d.scores); hipFree(d.labels); hipFree(d.props); hipFree(d.prob_max); hipFree(d.scores_cls); hipFree(d.count);
+    memset(&d, 0, sizeof(d));
+}
+
+extern "C" int cald_op_consistency(cald_ctx* c, int N, const float* aug_box, const float* ref_scores_cls, const float* ref_pm,
+                                   int M, const float* boxes, const float* scores_cls, const float* pm, int C, float bp,
+                                   float* consistency_out) {
+    if (!c || !consistency_out || N < 0 || M < 0 || C < 2 || C > 256) return fail(CALD_ERR_INVALID, "bad arguments");
+    if (N > 50) return fail(CALD_ERR_INVALID, "at most 50 reference boxes (cald_train.py:110-113)");
+    HIPCHK(hipSetDevice(c->device));
+    const int cap = (N > M ? N : M) > 0 ? (N > M ? N : M) : 1;
+    DetBuffers d; int rc = alloc_det(d, 2, cap, C); if (rc) return rc;
+    if (N) {
+        HIPCHK(hipMemcpy(d.boxes, aug_box, (size_t)N * 16, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d.scores_cls, ref_scores_cls, (size_t)N * C * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d.prob_max, ref_pm, (size_t)N * 4, hipMemcpyHostToDevice));
+    }
+    if (M) {
+        HIPCHK(hipMemcpy(d.boxes + (size_t)cap * 4, boxes, (size_t)M * 16, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d.scores_cls + (size_t)cap * C, scores_cls, (size_t)M * C * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d.prob_max + cap, pm, (size_t)M * 4, hipMemcpyHostToDevice));
+    }
+    int counts[2] = {N, M};
+    HIPCHK(hipMemcpy(d.count, counts, 8, hipMemcpyHostToDevice));
+    int h[4 + 50 + 1] = {0};   // ref_view, aug_view, kind, pair_img | ref_sel[50] | ref_n
+    h[0] = 0; h[1] = 1; h[2] = 0; h[3] = 0;
+    for (int i = 0; i < 50; i++) h[4 + i] = i;
+    h[54] = N;
+    int* dh; float* dpar; float* dcons;
+    HIPCHK(hipMalloc((void**)&dh, sizeof(h))); HIPCHK(hipMalloc((void**)&dpar, 4)); HIPCHK(hipMalloc((void**)&dcons, 4));
+    HIPCHK(hipMemcpy(dh, h, sizeof(h), hipMemcpyHostToDevice));
+    float zero = 0.f; HIPCHK(hipMemcpy(dpar, &zero, 4, hipMemcpyHostToDevice));
+    ScoreArgs a; a.det = d; a.ref_view = dh; a.aug_view = dh + 1; a.aug_kind = dh + 2; a.pair_img = dh + 3; a.ref_sel = dh + 4; a.ref_n = dh + 54;
+    a.aug_param = dpar; a.P = 1; a.bp = bp; a.cons = dcons;
+    launch_consistency(a, c->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(consistency_out, dcons, 4, hipMemcpyDeviceToHost));
+    hipFree(dh); hipFree(dpar); hipFree(dcons); free_det(d);
+    return 0;
+}
+
+extern "C" int cald_op_cls_corr(cald_ctx* c, int n, const float* scores, const int64_t* labels, int C, float* out) {
+    if (!c || !out || n < 0 || C < 2 || C > 256) return fail(CALD_ERR_INVALID, "bad arguments");
+    HIPCHK(hipSetDevice(c->device));
+    DetBuffers d; int rc = alloc_det(d, 1, n > 0 ? n : 1, C); if (rc) return rc;
+    if (n) { HIPCHK(hipMemcpy(d.scores, scores, (size_t)n * 4, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(d.labels, labels, (size_t)n * 8, hipMemcpyHostToDevice)); }
+    HIPCHK(hipMemcpy(d.count, &n, 4, hipMemcpyHostToDevice));
+    int h[2] = {0, 0}; int* dh; float* dout;
+    HIPCHK(hipMalloc((void**)&dh, 8)); HIPCHK(hipMalloc((void**)&dout, (size_t)(C - 1) * 4));
+    HIPCHK(hipMemcpy(dh, h, 8, hipMemcpyHostToDevice));
+    launch_cls_corr(d, nullptr, nullptr, dh, dh + 1, 1, dout, c->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(out, dout, (size_t)(C - 1) * 4, hipMemcpyDeviceToHost));
+    hipFree(dh); hipFree(dout); free_det(d);
+    return 0;
+}
+
+// =============================================================================================
+// the sweep (get_uncertainty, cald_train.py:91-231)
+// =============================================================================================
+extern "C" int cald_sweep(cald_model* m, int n_images, const uint8_t* const* images_dev, const int* H, const int* W,
+                          const int64_t* pool_pos, const cald_sweep_cfg* cfg, double* consistency_out, double* cls_corr_out) {
+    if (!m || !images_dev || !H || !W || !cfg || !consistency_out || !cls_corr_out) return fail(CALD_ERR_INVALID, "null argument");
+    if (!m->finalized) return fail(CALD_ERR_STATE, "model not finalized");
+    cald_ctx* c = m->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    const int C = m->cfg.num_classes, cap = m->cfg.detections_per_img;
+    const int A = (cfg->aug_flip ? 1 : 0) + (cfg->aug_cutout ? 1 : 0) + (cfg->aug_resize ? 1 : 0);
+    int B = cfg->batch_images > 0 ? cfg->batch_images : 16;
+    if (B > CALD_MAX_VIEWS) B = CALD_MAX_VIEWS;
+    const int VT = B * (1 + A);
+    if (m->sweep_det_views < VT) {
+        if (m->sweep_det_views) { HIPCHK(hipStreamSynchronize(c->stream)); free_det(m->sweep_det); }
+        int rc = alloc_det(m->sweep_det, VT, cap, C); if (rc) return rc;
+        m->sweep_det_views = VT;
+    }
+    DetBuffers& D = m->sweep_det;
+    // small device scratch for the scoring stage + resized images
+    int *d_ints = nullptr; float *d_par = nullptr, *d_cons = nullptr, *d_clsc = nullptr;
+    const int P_MAX = B * (A > 0 ? A : 1);
+    const size_t n_ints = (size_t)P_MAX * 4 + (size_t)B * 51 + (size_t)VT * 2;
+    HIPCHK(hipMalloc((void**)&d_ints, n_ints * 4)); HIPCHK(hipMalloc((void**)&d_par, (size_t)P_MAX * 4));
+    HIPCHK(hipMalloc((void**)&d_cons, (size_t)P_MAX * 4)); HIPCHK(hipMalloc((void**)&d_clsc, (size_t)VT * (C - 1) * 4));
+    std::vector<uint8_t*> rsz(B, nullptr); std::vector<size_t> rsz_cap(B, 0);
+    uint8_t* d_tmp = nullptr; size_t tmp_cap = 0;
+    int rc = 0;
+    std::vector<int> h_count(VT); std::vector<float> h_boxes((size_t)B * cap * 4), h_cons(P_MAX), h_clsc((size_t)VT * (C - 1));
+    auto cleanup = [&]() {
+        hipStreamSynchronize(c->stream);
+        hipFree(d_ints); hipFree(d_par); hipFree(d_cons); hipFree(d_clsc); hipFree(d_tmp);
+        for (auto p : rsz) if (p) hipFree(p);
+    };
+    for (int i0 = 0; i0 < n_images && !rc; i0 += B) {
+        const int nb = (n_images - i0 < B) ? n_images - i0 : B;
+        // ---- phase 1: reference views ----
+        std::vector<ViewDesc> views(nb);
+        for (int i = 0; i < nb; i++) {
+            memset(&views[i], 0, sizeof(ViewDesc));
+            views[i].src = images_dev[i0 + i]; views[i].H = H[i0 + i]; views[i].W = W[i0 + i];
+        }
+        DetBuffers d1 = D;
+        if ((rc = forward_frcnn(m, nb, views.data(), d1))) break;
+        if (hipMemcpyAsync(h_count.data(), D.count, (size_t)nb * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipMemcpyAsync(h_boxes.data(), D.boxes, (size_t)nb * cap * 16, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipStreamSynchronize(c->stream) != hipSuccess) { rc = fail(CALD_ERR_HIP, "D2H of reference detections failed"); break; }
+        // ---- host: sub-sample, build augmented views ----
+        std::vector<int> ref_sel((size_t)B * 50, 0), ref_n(B, 0), pair_ref, pair_aug, pair_kind, pair_img, view_img(VT, 0), view_isref(VT, 0);
+        std::vector<float> pair_par;
+        std::vector<ViewDesc> aviews;
+        for (int i = 0; i < nb; i++) {
+            view_img[i] = i; view_isref[i] = 1;
+            const int n = h_count[i];
+            ref_n[i] = subsample_indices(n, &ref_sel[(size_t)i * 50]);
+            if (n == 0) continue;
+            const int Hi = H[i0 + i], Wi = W[i0 + i];
+            float sub[50 * 4];
+            for (int k = 0; k < ref_n[i]; k++) memcpy(sub + 4 * k, &h_boxes[((size_t)i * cap + ref_sel[(size_t)i * 50 + k]) * 4], 16);
+            auto add_view = [&](const ViewDesc& vd, int kind, float par) {
+                const int vidx = nb + (int)aviews.size();
+                aviews.push_back(vd); view_img[vidx] = i; view_isref[vidx] = 0;
+                pair_ref.push_back(i); pair_aug.push_back(vidx); pair_kind.push_back(kind); pair_par.push_back(par); pair_img.push_back(i);
+            };
+            ViewDesc base; memset(&base, 0, sizeof(base)); base.src = images_dev[i0 + i]; base.H = Hi; base.W = Wi;
+            if (cfg->aug_flip) { ViewDesc v = base; v.flip = 1; add_view(v, 1, (float)Wi); }
+            if (cfg->aug_cutout) {
+                ViewDesc v = base;
+                const uint64_t seed = (uint64_t)cfg->base_seed * 1000003ull + (uint64_t)pool_pos[i0 + i];
+                v.nrect = cutout_rects(seed, Hi, Wi, ref_n[i], sub, 2, v.rects);
+                add_view(v, 0, 0.0f);
+            }
+            if (cfg->aug_resize) {
+                const int ow = (int)((double)Wi * (double)cfg->resize_ratio), oh = (int)((double)Hi * (double)cfg->resize_ratio);
+                const size_t need = (size_t)oh * ow * 3, tneed = (size_t)Hi * ow * 3;
+                if (rsz_cap[i] < need) { if (rsz[i]) hipFree(rsz[i]); if (hipMalloc((void**)&rsz[i], need) != hipSuccess) { rc = fail(CALD_ERR_HIP, "hipMalloc failed"); break; } rsz_cap[i] = need; }
+                if (tmp_cap < tneed) { hipStreamSynchronize(c->stream); if (d_tmp) hipFree(d_tmp); if (hipMalloc((void**)&d_tmp, tneed) != hipSuccess) { rc = fail(CALD_ERR_HIP, "hipMalloc failed"); break; } tmp_cap = tneed; }
+                if ((rc = pil_resize(c, images_dev[i0 + i], Hi, Wi, rsz[i], oh, ow, d_tmp))) break;
+                ViewDesc v; memset(&v, 0, sizeof(v)); v.src = rsz[i]; v.H = oh; v.W = ow;
+                add_view(v, 2, cfg->resize_ratio);
+            }
+        }
+        if (rc) break;
+        // ---- phase 2: augmented views (chunks of <= 64) ----
+        const int na = (int)aviews.size();
+        for (int a0 = 0; a0 < na && !rc; a0 += CALD_MAX_VIEWS) {
+            const int nv = (na - a0 < CALD_MAX_VIEWS) ? na - a0 : CALD_MAX_VIEWS;
+            DetBuffers d2 = D; const size_t o = (size_t)(nb + a0);
+            d2.boxes += o * cap * 4; d2.scores += o * cap; d2.labels += o * cap; d2.props += o * cap * 4;
+            d2.prob_max += o * cap; d2.scores_cls += o * cap * C; d2.count += o;
+            rc = forward_frcnn(m, nv, aviews.data() + a0, d2);
+        }
+        if (rc) break;
+        // ---- phase 3: scoring ----
+        const int P = (int)pair_ref.size(), VV = nb + na;
+        std::vector<int> ints(n_ints, 0);
+        int* p_ref = ints.data(); int* p_aug = p_ref + P_MAX; int* p_kind = p_aug + P_MAX; int* p_img = p_kind + P_MAX;
+        int* p_sel = p_img + P_MAX; int* p_n = p_sel + (size_t)B * 50; int* p_vimg = p_n + B; int* p_visref = p_vimg + VT;
+        for (int p = 0; p < P; p++) { p_ref[p] = pair_ref[p]; p_aug[p] = pair_aug[p]; p_kind[p] = pair_kind[p]; p_img[p] = pair_img[p]; }
+        memcpy(p_sel, ref_sel.data(), (size_t)B * 50 * 4); memcpy(p_n, ref_n.data(), (size_t)B * 4);
+        memcpy(p_vimg, view_img.data(), (size_t)VT * 4); memcpy(p_visref, view_isref.data(), (size_t)VT * 4);
+        if (hipMemcpyAsync(d_ints, ints.data(), n_ints * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+            (P && hipMemcpyAsync(d_par, pair_par.data(), (size_t)P * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess)) { rc = fail(CALD_ERR_HIP, "H2D failed"); break; }
+        ScoreArgs sa; sa.det = D;
+        sa.ref_view = d_ints; sa.aug_view = d_ints + P_MAX; sa.aug_kind = d_ints + 2 * P_MAX; sa.pair_img = d_ints + 3 * P_MAX;
+        sa.ref_sel = d_ints + 4 * P_MAX; sa.ref_n = sa.ref_sel + (size_t)B * 50; sa.aug_param = d_par; sa.P = P; sa.bp = cfg->bp; sa.cons = d_cons;
+        launch_consistency(sa, c->stream);
+        launch_cls_corr(D, sa.ref_sel, sa.ref_n, sa.ref_n + B, sa.ref_n + B + VT, VV, d_clsc, c->stream);
+        if ((P && hipMemcpyAsync(h_cons.data(), d_cons, (size_t)P * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess) ||
+            hipMemcpyAsync(h_clsc.data(), d_clsc, (size_t)VV * (C - 1) * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipStreamSynchronize(c->stream) != hipSuccess) { rc = fail(CALD_ERR_HIP, "scoring stage failed: %s", hipGetErrorString(hipGetLastError())); break; }
+        // ---- host: float64 means (cald_train.py:225-228) ----
+        std::vector<std::vector<int>> img_pairs(nb), img_views(nb);
+        for (int p = 0; p < P; p++) img_pairs[pair_img[p]].push_back(p);
+        for (int v = nb; v < VV; v++) img_views[view_img[v]].push_back(v);
+        for (int i = 0; i < nb; i++) {
+            double* cc = cls_corr_out + (size_t)(i0 + i) * (C - 1);
+            const int nvw = 1 + (int)img_views[i].size();
+            for (int k = 0; k < C - 1; k++) {
+                double s = (double)h_clsc[(size_t)i * (C - 1) + k];
+                for (int v : img_views[i]) s += (double)h_clsc[(size_t)v * (C - 1) + k];
+                cc[k] = s / (double)nvw;
+            }
+            if (h_count[i] == 0 || img_pairs[i].empty()) { consistency_out[i0 + i] = 0.0; continue; }
+            std::vector<double> cs;
+            for (int p : img_pairs[i]) cs.push_back((double)h_cons[p]);
+            consistency_out[i0 + i] = np_sum(cs.data(), (int)cs.size()) / (double)cs.size();
+        }
+    }
+    cleanup();
+    return rc;
+}

@@ -1,0 +1,142 @@
+// cald_amd/csrc/common.h -- shared declarations of the MI355X (gfx950) CALD hot-path library.
+// Product code: never includes or links anything under oracle/.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+#define CALD_MAX_VIEWS 64      // views (image x augmentation) per batched launch
+#define CALD_MAX_LEVELS 8      // spatial levels: 0 input, 1 /2, 2 /4 (P2) ... 6 /64 (pool), 7 roi rows
+#define CALD_ROI_CAP 1000      // rpn_post_nms_top_n: fixed row capacity per view in the roi GEMMs
+#define CALD_MAX_CUT 4
+
+// Per-view geometry of one spatial level inside a ragged batch.  Activations of level L with C
+// channels live in one buffer; view v starts at float offset pix_off * C and is [H][W][C] (NHWC).
+struct LevelSeg {
+    long long pix_off;
+    int H, W;
+    int tile_start;   // first 128-row M tile of this view at this level
+    int pad_;
+};
+
+// One batch plan = geometry of every level for every view (+ sentinel entry V for tile_start).
+struct BatchPlan {
+    LevelSeg seg[CALD_MAX_LEVELS][CALD_MAX_VIEWS + 1];
+};
+
+struct ConvArgs {
+    const float* in;
+    float* out;
+    const float* w;        // [Kpad][CoutPad], K order (kh, kw, cin)
+    const float* bias;     // [CoutPad] or null
+    const float* scale;    // FrozenBN scale/shift or null
+    const float* shift;
+    const float* residual; // same geometry as out, or null
+    const float* up;       // coarser level to nearest-upsample-add (FPN top-down), or null
+    const LevelSeg* seg_in;
+    const LevelSeg* seg_out;
+    const LevelSeg* seg_up;
+    const int* dyn_rows;   // optional per-view dynamic row count (roi GEMMs), else null
+    int V;
+    int Cin, Cout, CoutPad, Kpad;
+    int KH, KW, stride, pad;
+    int relu;
+    int total_mtiles;
+    int out_ld;            // output row stride in floats (== Cout normally)
+};
+
+// ---------------------------------------------------------------------------------------------
+// Deterministic float32 elementary functions (DESIGN.md "arithmetic contract"): fixed fmaf
+// polynomials, built with -ffp-contract=off so that every fused multiply-add is explicit.
+// They stand where the reference calls torch.exp / softmax / sigmoid / numpy.log
+// (frcnn_la.py:40, retinanet_cal.py:411, cald_train.py:214).
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ inline float det_bits2f(uint32_t u) {
+    union { uint32_t u; float f; } c; c.u = u; return c.f;
+}
+__host__ __device__ inline uint32_t det_f2bits(float f) {
+    union { uint32_t u; float f; } c; c.f = f; return c.u;
+}
+
+__host__ __device__ inline float det_expf(float x) {
+    if (x != x) return x;
+    if (x > 88.72283f) return INFINITY;
+    if (x < -87.0f) return 0.0f;
+    float n = rintf(x * 1.44269504f);
+    float r = fmaf(n, -0.693145752f, x);
+    r = fmaf(n, -1.42860677e-6f, r);
+    float p = 1.9875691500e-4f;
+    p = fmaf(p, r, 1.3981999507e-3f);
+    p = fmaf(p, r, 8.3334519073e-3f);
+    p = fmaf(p, r, 4.1665795894e-2f);
+    p = fmaf(p, r, 1.6666665459e-1f);
+    p = fmaf(p, r, 5.0000001201e-1f);
+    float r2 = r * r;
+    float y = fmaf(p, r2, r) + 1.0f;
+    int ni = (int)n;
+    int n1 = ni / 2, n2 = ni - n1;
+    y = y * det_bits2f((uint32_t)(n1 + 127) << 23);
+    y = y * det_bits2f((uint32_t)(n2 + 127) << 23);
+    return y;
+}
+
+__host__ __device__ inline float det_logf(float x) {
+    if (x != x) return x;
+    if (x < 0.0f) return NAN;
+    if (x == 0.0f) return -INFINITY;
+    if (x == INFINITY) return x;
+    int e = 0;
+    uint32_t u = det_f2bits(x);
+    if (u < 0x00800000u) { x = x * 8388608.0f; u = det_f2bits(x); e = -23; }
+    e += (int)(u >> 23) - 126;
+    float m = det_bits2f((u & 0x007fffffu) | 0x3f000000u);
+    float f;
+    if (m < 0.70710678f) { e -= 1; f = (m + m) - 1.0f; } else { f = m - 1.0f; }
+    float z = f * f;
+    float p = 7.0376836292e-2f;
+    p = fmaf(p, f, -1.1514610310e-1f);
+    p = fmaf(p, f, 1.1676998740e-1f);
+    p = fmaf(p, f, -1.2420140846e-1f);
+    p = fmaf(p, f, 1.4249322787e-1f);
+    p = fmaf(p, f, -1.6668057665e-1f);
+    p = fmaf(p, f, 2.0000714765e-1f);
+    p = fmaf(p, f, -2.4999993993e-1f);
+    p = fmaf(p, f, 3.3333331174e-1f);
+    float y = (p * f) * z;
+    float fe = (float)e;
+    y = fmaf(fe, -2.12194440e-4f, y);
+    y = fmaf(z, -0.5f, y);
+    float r = f + y;
+    r = fmaf(fe, 0.693359375f, r);
+    return r;
+}
+__host__ __device__ inline float det_log2f(float x) { return det_logf(x) * 1.44269504f; }
+__host__ __device__ inline float det_sigmoidf(float x) { return 1.0f / (1.0f + det_expf(-x)); }
+
+#define BBOX_XFORM_CLIP_F 4.135166556742356f  /* (float)math.log(1000/16) */
+
+// BoxCoder.decode_single (torchvision 0.8.2 _utils.py; weights as arguments)
+__host__ __device__ inline void det_box_decode(const float* box, const float* d, float wx, float wy, float ww,
+                                               float wh, float* o) {
+    float width = box[2] - box[0], height = box[3] - box[1];
+    float cx = box[0] + 0.5f * width, cy = box[1] + 0.5f * height;
+    float dx = d[0] / wx, dy = d[1] / wy, dw = d[2] / ww, dh = d[3] / wh;
+    if (dw > BBOX_XFORM_CLIP_F) dw = BBOX_XFORM_CLIP_F;
+    if (dh > BBOX_XFORM_CLIP_F) dh = BBOX_XFORM_CLIP_F;
+    float pcx = dx * width + cx, pcy = dy * height + cy;
+    float pw = det_expf(dw) * width, ph = det_expf(dh) * height;
+    o[0] = pcx - 0.5f * pw; o[1] = pcy - 0.5f * ph; o[2] = pcx + 0.5f * pw; o[3] = pcy + 0.5f * ph;
+}
+__host__ __device__ inline float det_clamp(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// Orderable 32-bit key of a float: larger float -> larger unsigned (NaN sorts above +inf).
+__host__ __device__ inline uint32_t det_orderable(float f) {
+    uint32_t u = det_f2bits(f);
+    if ((u << 1) == 0u) u = 0u;   // -0.0 and +0.0 compare equal
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernel launchers (implemented in the .hip files; all asynchronous on `stream`)
+// ---------------------------------------------------------------------------------------------
+void launch_conv(const ConvArgs& a, hipStream_t stream);

@@ -1,0 +1,160 @@
+// elementwise.hip -- HBM-bound kernels of the sweep front end: view construction (augmentation +
+// detector transform), PIL-exact resize for the `smaller_resize` augmentation, max-pool, and the
+// FPN 'pool' level.  All are coalesced NHWC / float4 kernels; none touches MFMA.
+//
+// Reference call sites: cald_train.py:107 (to_tensor), :124-179 (flip / cut_out / resize views),
+// cald/cald_helper.py:23-30, :47-53, :88-132; detector transform = torchvision
+// GeneralizedRCNNTransform constructed at detection/frcnn_la.py:230-234.
+#include "common.h"
+#include "kernels.h"
+
+// ---------------------------------------------------------------------------------------------
+// One view: uint8 HWC source -> (flip | cutout rectangles) -> /255 -> (x-mean)/std -> bilinear
+// resize (align_corners=False, scale=in/out) -> zero pad to a multiple of 32.  NHWC, 4 channels.
+// grid = (ceil(maxHp*maxWp/256), V)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void preprocess_kernel(const ViewDesc* views, const LevelSeg* seg0, float* out) {
+    const int v = blockIdx.y;
+    const ViewDesc vd = views[v];
+    const LevelSeg s = seg0[v];
+    const int Hp = s.H, Wp = s.W;
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= Hp * Wp) return;
+    const int y = pix / Wp, x = pix - y * Wp;
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (y < vd.Hr && x < vd.Wr) {
+        const int H = vd.H, W = vd.W;
+        const float sh = (float)H / (float)vd.Hr, sw = (float)W / (float)vd.Wr;
+        float fy = sh * ((float)y + 0.5f) - 0.5f; if (fy < 0.0f) fy = 0.0f;
+        float fx = sw * ((float)x + 0.5f) - 0.5f; if (fx < 0.0f) fx = 0.0f;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+        const float ly = fy - (float)y0, hy = 1.0f - ly, lx = fx - (float)x0, hx = 1.0f - lx;
+        const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+        float val[2][2][3];
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++) {
+                const int yy = a ? y1 : y0, xx = b ? x1 : x0;
+                bool cut = false;
+                for (int r = 0; r < vd.nrect; r++)
+                    cut |= (xx >= vd.rects[4 * r] && xx < vd.rects[4 * r + 2] && yy >= vd.rects[4 * r + 1] && yy < vd.rects[4 * r + 3]);
+                const int sx = vd.flip ? (W - 1 - xx) : xx;
+                const uint8_t* p = vd.src + ((long long)yy * W + sx) * 3;
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    float u = cut ? 0.0f : (float)p[c] / 255.0f;
+                    val[a][b][c] = (u - mean[c]) / stdv[c];
+                }
+            }
+        float r3[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+            r3[c] = hy * (hx * val[0][0][c] + lx * val[0][1][c]) + ly * (hx * val[1][0][c] + lx * val[1][1][c]);
+        o = make_float4(r3[0], r3[1], r3[2], 0.0f);
+    }
+    reinterpret_cast<float4*>(out + s.pix_off * 4)[pix] = o;
+}
+
+void launch_preprocess(const ViewDesc* views, const LevelSeg* seg0, float* out, int V, int max_pix, hipStream_t st) {
+    dim3 grid((max_pix + 255) / 256, V);
+    hipLaunchKernelGGL(preprocess_kernel, grid, dim3(256), 0, st, views, seg0, out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// PIL Image.resize(BILINEAR) on 8-bit RGB: two fixed-point passes (Pillow Resample.c algorithm).
+// Coefficients (bounds, kk) are computed on the host in double and int32, exactly as Pillow does.
+// ---------------------------------------------------------------------------------------------
+#define PIL_BITS 22
+__device__ inline uint8_t pil_clip8(int v) {
+    v >>= PIL_BITS;
+    return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+}
+// horizontal: src [H][W][3] -> dst [H][ow][3]; grid = (ceil(ow*3/256), H)
+__global__ __launch_bounds__(256) void pil_horizontal_kernel(const uint8_t* src, int H, int W, uint8_t* dst, int ow,
+                                                             const int* bounds, const int* kk, int ksize) {
+    const int y = blockIdx.y;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= ow * 3) return;
+    const int xx = e / 3, c = e - xx * 3;
+    const int xmin = bounds[2 * xx], xmax = bounds[2 * xx + 1];
+    const int* k = kk + (long long)xx * ksize;
+    int ss = 1 << (PIL_BITS - 1);
+    const uint8_t* row = src + (long long)y * W * 3;
+    for (int x = 0; x < xmax; x++) ss += (int)row[(x + xmin) * 3 + c] * k[x];
+    dst[((long long)y * ow + xx) * 3 + c] = pil_clip8(ss);
+}
+// vertical: src [H][W][3] -> dst [oh][W][3]; grid = (ceil(W*3/256), oh)
+__global__ __launch_bounds__(256) void pil_vertical_kernel(const uint8_t* src, int H, int W, uint8_t* dst, int oh,
+                                                           const int* bounds, const int* kk, int ksize) {
+    const int yy = blockIdx.y;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= W * 3) return;
+    const int ymin = bounds[2 * yy], ymax = bounds[2 * yy + 1];
+    const int* k = kk + (long long)yy * ksize;
+    int ss = 1 << (PIL_BITS - 1);
+    for (int y = 0; y < ymax; y++) ss += (int)src[(long long)(y + ymin) * W * 3 + e] * k[y];
+    dst[(long long)yy * W * 3 + e] = pil_clip8(ss);
+}
+void launch_pil_horizontal(const uint8_t* src, int H, int W, uint8_t* dst, int ow, const int* bounds, const int* kk,
+                           int ksize, hipStream_t st) {
+    dim3 grid((ow * 3 + 255) / 256, H);
+    hipLaunchKernelGGL(pil_horizontal_kernel, grid, dim3(256), 0, st, src, H, W, dst, ow, bounds, kk, ksize);
+}
+void launch_pil_vertical(const uint8_t* src, int H, int W, uint8_t* dst, int oh, const int* bounds, const int* kk,
+                         int ksize, hipStream_t st) {
+    dim3 grid((W * 3 + 255) / 256, oh);
+    hipLaunchKernelGGL(pil_vertical_kernel, grid, dim3(256), 0, st, src, H, W, dst, oh, bounds, kk, ksize);
+}
+
+// ---------------------------------------------------------------------------------------------
+// max_pool2d(3, 2, 1) NHWC, C % 4 == 0; grid = (ceil(maxHo*maxWo*C/4/256), V)
+// ---------------------------------------------------------------------------------------------
+__device__ inline float nanmax(float m, float v) { return (v > m || v != v) ? v : m; }
+__global__ __launch_bounds__(256) void maxpool_kernel(const float* in, float* out, const LevelSeg* sin, const LevelSeg* sout, int C) {
+    const int v = blockIdx.y;
+    const LevelSeg si = sin[v], so = sout[v];
+    const int C4 = C >> 2;
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long long)so.H * so.W * C4) return;
+    const int c4 = (int)(e % C4);
+    const int pix = (int)(e / C4);
+    const int oy = pix / so.W, ox = pix - oy * so.W;
+    const float4* ip = reinterpret_cast<const float4*>(in + si.pix_off * C);
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+    for (int kh = 0; kh < 3; kh++)
+#pragma unroll
+        for (int kw = 0; kw < 3; kw++) {
+            const int iy = oy * 2 - 1 + kh, ix = ox * 2 - 1 + kw;
+            if (iy < 0 || iy >= si.H || ix < 0 || ix >= si.W) continue;
+            const float4 t = ip[(long long)(iy * si.W + ix) * C4 + c4];
+            m.x = nanmax(m.x, t.x); m.y = nanmax(m.y, t.y); m.z = nanmax(m.z, t.z); m.w = nanmax(m.w, t.w);
+        }
+    reinterpret_cast<float4*>(out + so.pix_off * C)[e] = m;
+}
+void launch_maxpool(const float* in, float* out, const LevelSeg* sin, const LevelSeg* sout, int C, int V, int max_out_pix,
+                    hipStream_t st) {
+    dim3 grid((unsigned)(((long long)max_out_pix * (C / 4) + 255) / 256), V);
+    hipLaunchKernelGGL(maxpool_kernel, grid, dim3(256), 0, st, in, out, sin, sout, C);
+}
+
+// LastLevelMaxPool = max_pool2d(x, 1, 2, 0): every second pixel of P5.
+__global__ __launch_bounds__(256) void subsample2_kernel(const float* in, float* out, const LevelSeg* sin, const LevelSeg* sout, int C) {
+    const int v = blockIdx.y;
+    const LevelSeg si = sin[v], so = sout[v];
+    const int C4 = C >> 2;
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long long)so.H * so.W * C4) return;
+    const int c4 = (int)(e % C4);
+    const int pix = (int)(e / C4);
+    const int oy = pix / so.W, ox = pix - oy * so.W;
+    const float4* ip = reinterpret_cast<const float4*>(in + si.pix_off * C);
+    reinterpret_cast<float4*>(out + so.pix_off * C)[e] = ip[(long long)((oy * 2) * si.W + ox * 2) * C4 + c4];
+}
+void launch_subsample2(const float* in, float* out, const LevelSeg* sin, const LevelSeg* sout, int C, int V, int max_out_pix,
+                       hipStream_t st) {
+    dim3 grid((unsigned)(((long long)max_out_pix * (C / 4) + 255) / 256), V);
+    hipLaunchKernelGGL(subsample2_kernel, grid, dim3(256), 0, st, in, out, sin, sout, C);
+}

@@ -1,0 +1,100 @@
+// kernels.h -- launcher prototypes and device-visible descriptor structs (product code).
+#pragma once
+#include "common.h"
+
+struct ViewDesc {
+    const uint8_t* src;   // device uint8 HWC (original image, or the PIL-resized one)
+    int H, W;             // source size
+    int flip;             // HorizontalFlip view
+    int nrect;            // cutout rectangles (left, top, right, bottom)
+    int rects[4 * CALD_MAX_CUT];
+    int Hr, Wr;           // detector-transform resized size (image_sizes)
+    int Ho, Wo;           // size the detections are scaled back to (= H, W of this view's source)
+    int pad_[2];
+};
+
+// detections of one view, fixed capacity det_cap rows (frcnn_la.py:131-141 result dict)
+struct DetBuffers {
+    float* boxes;       // [V][cap][4]
+    float* scores;      // [V][cap]
+    long long* labels;  // [V][cap]
+    float* props;       // [V][cap][4]
+    float* prob_max;    // [V][cap]
+    float* scores_cls;  // [V][cap][C]
+    int* count;         // [V]
+    int cap;
+    int C;
+};
+
+// elementwise.hip
+void launch_preprocess(const ViewDesc* views, const LevelSeg* seg0, float* out, int V, int max_pix, hipStream_t st);
+void launch_pil_horizontal(const uint8_t* src, int H, int W, uint8_t* dst, int ow, const int* bounds, const int* kk, int ksize, hipStream_t st);
+void launch_pil_vertical(const uint8_t* src, int H, int W, uint8_t* dst, int oh, const int* bounds, const int* kk, int ksize, hipStream_t st);
+void launch_maxpool(const float* in, float* out, const LevelSeg* sin, const LevelSeg* sout, int C, int V, int max_out_pix, hipStream_t st);
+void launch_subsample2(const float* in, float* out, const LevelSeg* sin, const LevelSeg* sout, int C, int V, int max_out_pix, hipStream_t st);
+
+// rpn.hip
+struct RpnArgs {
+    const float* head[5];        // per level: [sum pix][head_ld], ch a = logit, ch A+4a+j = delta
+    const LevelSeg* seg[5];      // level geometry (levels 2..6 of the plan)
+    const LevelSeg* seg0;        // padded input geometry (for anchor strides)
+    const ViewDesc* views;       // Hr, Wr for clipping
+    const float* base_anchors;   // [5][A][4]
+    int head_ld, A, V;
+    int pre_n, post_n;
+    float nms_thr, min_size;
+    unsigned long long* cand_key;  // [V][5*pre_n]
+    float* cand_box;               // [V][5*pre_n][4]
+    float* sorted_box;             // [V][5*pre_n][4]  (score order, level offset applied)
+    float* sorted_raw;             // [V][5*pre_n][4]  (score order, no offset)
+    int* sorted_count;             // [V]
+    float* proposals;              // [V][post_n][4]
+    int* prop_count;               // [V]
+};
+void launch_rpn(const RpnArgs& a, hipStream_t st);
+
+// roi.hip
+struct RoiArgs {
+    const float* feat[4];
+    const LevelSeg* seg[4];
+    int C, V;
+    const float* proposals;  // [V][ROI_CAP][4]
+    const int* prop_count;   // [V]
+    float* out;              // [V][ROI_CAP][49][C]
+};
+void launch_roi_align(const RoiArgs& a, hipStream_t st);
+
+struct PostArgs {
+    const float* pred;        // [V][ROI_CAP][pred_ld]: logits C, then deltas 4C
+    int pred_ld, C, V;
+    const float* proposals;   // [V][ROI_CAP][4]
+    const int* prop_count;
+    const ViewDesc* views;
+    float score_thr, nms_thr;
+    float* prob;              // [V][ROI_CAP][C] scratch (softmax)
+    float* pmax;              // [V][ROI_CAP]
+    unsigned long long* keys; // [V][key_cap] scratch
+    float* cbox;              // [V][2*key_cap][4] scratch: decoded+clipped candidate boxes (raw, then class-offset)
+    int* key_count;           // [V] scratch counter
+    int key_cap;              // power of two >= ROI_CAP * min(C-1, 19)
+    DetBuffers det;
+};
+void launch_frcnn_postprocess(const PostArgs& a, hipStream_t st);
+
+// score.hip
+struct ScoreArgs {
+    DetBuffers det;            // detections of ALL views of the batch
+    const int* ref_view;       // [P] view index of the reference view of pair p
+    const int* aug_view;       // [P] view index of the augmented view of pair p
+    const int* aug_kind;       // [P] 0 = boxes unchanged, 1 = flip, 2 = scale by aug_scale
+    const float* aug_param;    // [P] flip: image width; scale: ratio
+    const int* ref_sel;        // [nimg][50] sub-sample indices into the reference detections
+    const int* ref_n;          // [nimg] number of (sub-sampled) reference boxes
+    const int* pair_img;       // [P] image slot of the pair
+    int P;
+    float bp;
+    float* cons;               // [P] consistency_img per pair
+};
+void launch_consistency(const ScoreArgs& a, hipStream_t st);
+void launch_cls_corr(const DetBuffers& det, const int* ref_sel, const int* ref_n, const int* view_img, const int* view_is_ref,
+                     int V, float* out /*[V][C-1]*/, hipStream_t st);

@@ -1,0 +1,193 @@
+// roi.hip -- box head front/back ends of the Faster R-CNN forward:
+//   * MultiScaleRoIAlign (7x7, sampling_ratio 2, aligned=False) over P2..P5, written directly in the
+//     A-operand layout of the fc6 GEMM: [roi][bin(49)][channel]  (reference detection/frcnn_la.py:112,
+//     :205-209; torchvision 0.8.2 roi_align semantics)
+//   * RoIHeads.postprocess_detections (detection/frcnn_la.py:32-87) + transform.postprocess
+//     (:292-315): softmax, per-class decode, clip, score threshold, class-batched NMS, top-100,
+//     gather of scores_cls / prob_max / props, rescale to the original image.
+#include "common.h"
+#include "kernels.h"
+#include "sortnms.h"
+
+__device__ inline int roi_level(const float4 b) {
+    const float area = (b.z - b.x) * (b.w - b.y);
+    const float s = sqrtf(area);
+    float k = floorf((4.0f + det_log2f(s / 224.0f)) + 1e-6f);
+    if (!(k >= 2.0f)) k = 2.0f;
+    if (k > 5.0f) k = 5.0f;
+    return (int)k - 2;
+}
+
+// grid = (ROI_CAP, V), block = C threads (256): one thread per channel, loops over the 49 bins.
+__global__ __launch_bounds__(256) void roi_align_kernel(RoiArgs a) {
+    const int r = blockIdx.x, v = blockIdx.y, c = threadIdx.x;
+    if (r >= a.prop_count[v]) return;
+    const float4 box = reinterpret_cast<const float4*>(a.proposals)[(long long)v * CALD_ROI_CAP + r];
+    const int l = roi_level(box);
+    const LevelSeg sg = a.seg[l][v];
+    const int Hf = sg.H, Wf = sg.W, C = a.C;
+    const float* f = a.feat[l] + sg.pix_off * (long long)C;
+    const float scale = 1.0f / (float)(4 << l);
+    const float x1 = box.x * scale, y1 = box.y * scale, x2 = box.z * scale, y2 = box.w * scale;
+    float rw = x2 - x1; if (!(rw >= 1.0f)) rw = 1.0f;
+    float rh = y2 - y1; if (!(rh >= 1.0f)) rh = 1.0f;
+    const float bw = rw / 7.0f, bh = rh / 7.0f;
+    float* out = a.out + ((long long)v * CALD_ROI_CAP + r) * 49 * C;
+    for (int ph = 0; ph < 7; ph++)
+        for (int pw = 0; pw < 7; pw++) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int iy = 0; iy < 2; iy++) {
+                const float y = y1 + (float)ph * bh + ((float)iy + 0.5f) * bh / 2.0f;
+#pragma unroll
+                for (int ix = 0; ix < 2; ix++) {
+                    const float x = x1 + (float)pw * bw + ((float)ix + 0.5f) * bw / 2.0f;
+                    float w1, w2, w3, w4; int yl, xl, yh, xh;
+                    if (y < -1.0f || y > (float)Hf || x < -1.0f || x > (float)Wf) {
+                        w1 = w2 = w3 = w4 = 0.0f; yl = xl = yh = xh = 0;
+                    } else {
+                        float yy = y <= 0.0f ? 0.0f : y, xx = x <= 0.0f ? 0.0f : x;
+                        yl = (int)yy; xl = (int)xx;
+                        if (yl >= Hf - 1) { yh = yl = Hf - 1; yy = (float)yl; } else yh = yl + 1;
+                        if (xl >= Wf - 1) { xh = xl = Wf - 1; xx = (float)xl; } else xh = xl + 1;
+                        const float ly = yy - (float)yl, lx = xx - (float)xl, hy = 1.0f - ly, hx = 1.0f - lx;
+                        w1 = hy * hx; w2 = hy * lx; w3 = ly * hx; w4 = ly * lx;
+                    }
+                    const float v1 = f[(long long)(yl * Wf + xl) * C + c], v2 = f[(long long)(yl * Wf + xh) * C + c];
+                    const float v3 = f[(long long)(yh * Wf + xl) * C + c], v4 = f[(long long)(yh * Wf + xh) * C + c];
+                    acc = acc + (((w1 * v1 + w2 * v2) + w3 * v3) + w4 * v4);
+                }
+            }
+            out[(ph * 7 + pw) * C + c] = acc / 4.0f;
+        }
+}
+void launch_roi_align(const RoiArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(roi_align_kernel, dim3(CALD_ROI_CAP, a.V), dim3(a.C), 0, st, a);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Post-processing kernel 1: softmax per proposal; candidate (proposal, fg class) keys above the
+// score threshold are appended to the per-view key list.  grid = (ceil(ROI_CAP/256), V)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void post_softmax_kernel(PostArgs a) {
+    int* key_count = a.key_count;
+    const int v = blockIdx.y, r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= a.prop_count[v]) return;
+    const int C = a.C;
+    const float* lg = a.pred + ((long long)v * CALD_ROI_CAP + r) * a.pred_ld;
+    float* pr = a.prob + ((long long)v * CALD_ROI_CAP + r) * C;
+    float m = lg[0];
+    for (int c = 1; c < C; c++) if (lg[c] > m) m = lg[c];
+    float s = 0.0f;
+    for (int c = 0; c < C; c++) { const float e = det_expf(lg[c] - m); pr[c] = e; s = s + e; }
+    float pm = 0.0f;
+    for (int c = 0; c < C; c++) {
+        const float p = pr[c] / s;
+        pr[c] = p;
+        if (c == 1 || (c > 1 && p > pm)) pm = p;
+        if (c >= 1 && p > a.score_thr) {
+            const int slot = atomicAdd(&key_count[v], 1);
+            if (slot < a.key_cap)
+                a.keys[(long long)v * a.key_cap + slot] =
+                    ((unsigned long long)det_orderable(p) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)(r * (C - 1) + (c - 1)));
+        }
+    }
+    a.pmax[(long long)v * CALD_ROI_CAP + r] = pm;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Post-processing kernel 2: per view: sort candidates, decode + clip their boxes, class-batched
+// NMS (coordinate offset label*(max_coord+1) in fp32), keep the first det_cap, write the outputs.
+// grid = V, block = 1024, dynamic LDS (sort buffer of up to 16384 keys; larger lists sort in place
+// in global memory).
+// ---------------------------------------------------------------------------------------------
+#define POST_LDS_KEYS 8192
+__global__ __launch_bounds__(1024) void post_nms_kernel(PostArgs a) {
+    const int* key_count = a.key_count;
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+    unsigned long long* lkeys = reinterpret_cast<unsigned long long*>(dyn);
+    const int cap = a.det.cap;
+    float4* kept_box = reinterpret_cast<float4*>(dyn + (size_t)POST_LDS_KEYS * 8);
+    float* kept_area = reinterpret_cast<float*>(kept_box + cap);
+    int* keep_idx = reinterpret_cast<int*>(kept_area + cap);
+    int* dead_or = keep_idx + cap;
+    float* red = reinterpret_cast<float*>(dead_or + 256);
+    __shared__ int s_nk;
+    const int v = blockIdx.x, tid = threadIdx.x, C = a.C;
+    int n = key_count[v];
+    if (n > a.key_cap) n = a.key_cap;
+    int NP = 1024;
+    while (NP < n) NP <<= 1;
+    unsigned long long* gkeys = a.keys + (long long)v * a.key_cap;
+    unsigned long long* keys = (NP <= POST_LDS_KEYS) ? lkeys : gkeys;
+    for (int i = tid; i < NP; i += 1024) keys[i] = (i < n) ? gkeys[i] : 0ull;
+    __syncthreads();
+    block_bitonic_sort_desc(keys, NP);
+    // decode + clip in sorted order
+    const ViewDesc vd = a.views[v];
+    const float Wr = (float)vd.Wr, Hr = (float)vd.Hr;
+    float4* cbox = reinterpret_cast<float4*>(a.cbox) + (long long)v * 2 * a.key_cap;
+    const float4* props = reinterpret_cast<const float4*>(a.proposals) + (long long)v * CALD_ROI_CAP;
+    float mx = -INFINITY;
+    for (int i = tid; i < n; i += 1024) {
+        const int pos = (int)(0xFFFFFFFFu - (unsigned)(keys[i] & 0xFFFFFFFFull));
+        const int r = pos / (C - 1), c = pos - r * (C - 1) + 1;
+        const float4 p = props[r];
+        const float pb[4] = {p.x, p.y, p.z, p.w};
+        const float* dl = a.pred + ((long long)v * CALD_ROI_CAP + r) * a.pred_ld + C + 4 * c;
+        const float d[4] = {dl[0], dl[1], dl[2], dl[3]};
+        float o[4];
+        det_box_decode(pb, d, 10.0f, 10.0f, 5.0f, 5.0f, o);
+        float4 b;
+        b.x = det_clamp(o[0], 0.0f, Wr); b.z = det_clamp(o[2], 0.0f, Wr);
+        b.y = det_clamp(o[1], 0.0f, Hr); b.w = det_clamp(o[3], 0.0f, Hr);
+        cbox[i] = b;
+        mx = fmaxf(mx, fmaxf(fmaxf(b.x, b.y), fmaxf(b.z, b.w)));
+    }
+    red[tid] = mx;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) { if (tid < s) red[tid] = fmaxf(red[tid], red[tid + s]); __syncthreads(); }
+    const float maxc = red[0];
+    // offset boxes for class-batched NMS, stored after the raw ones
+    float4* obox = cbox + n;   // cbox has 2*key_cap rows per view
+    for (int i = tid; i < n; i += 1024) {
+        const int pos = (int)(0xFFFFFFFFu - (unsigned)(keys[i] & 0xFFFFFFFFull));
+        const int c = pos % (C - 1) + 1;
+        const float off = (float)c * (maxc + 1.0f);
+        const float4 b = cbox[i];
+        obox[i] = make_float4(b.x + off, b.y + off, b.z + off, b.w + off);
+    }
+    __syncthreads();
+    block_nms_sorted(obox, n, a.nms_thr, cap, kept_box, kept_area, dead_or, keep_idx, &s_nk);
+    const int nk = s_nk;
+    const float rh = (float)((double)vd.Ho / (double)vd.Hr), rw = (float)((double)vd.Wo / (double)vd.Wr);
+    for (int i = tid; i < nk; i += 1024) {
+        const int k = keep_idx[i];
+        const unsigned long long key = keys[k];
+        const int pos = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
+        const int r = pos / (C - 1), c = pos - r * (C - 1) + 1;
+        const float4 b = cbox[k];
+        const float4 p = props[r];
+        const long long o = (long long)v * cap + i;
+        reinterpret_cast<float4*>(a.det.boxes)[o] = make_float4(b.x * rw, b.y * rh, b.z * rw, b.w * rh);
+        reinterpret_cast<float4*>(a.det.props)[o] = make_float4(p.x * rw, p.y * rh, p.z * rw, p.w * rh);
+        const float* pr = a.prob + ((long long)v * CALD_ROI_CAP + r) * C;
+        a.det.scores[o] = pr[c];
+        a.det.labels[o] = c;
+        a.det.prob_max[o] = a.pmax[(long long)v * CALD_ROI_CAP + r];
+        for (int q = 0; q < C; q++) a.det.scores_cls[o * C + q] = pr[q];
+    }
+    if (tid == 0) a.det.count[v] = nk;
+}
+
+void launch_frcnn_postprocess(const PostArgs& a, hipStream_t st) {
+    hipMemsetAsync(a.key_count, 0, sizeof(int) * a.V, st);
+    hipLaunchKernelGGL(post_softmax_kernel, dim3((CALD_ROI_CAP + 255) / 256, a.V), dim3(256), 0, st, a);
+    size_t lds = (size_t)POST_LDS_KEYS * 8 + (size_t)a.det.cap * (16 + 4 + 4) + 256 * 4 + 1024 * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(post_nms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(post_nms_kernel, dim3(a.V), dim3(1024), lds, st, a);
+}

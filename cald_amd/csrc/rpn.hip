@@ -1,0 +1,161 @@
+// rpn.hip -- region proposals: anchors, box decode, per-level top-k, clip, small-box filter,
+// level-batched NMS, post-NMS top-n.  Restates torchvision 0.8.2 RegionProposalNetwork
+// (in-repo copy: detection/frcnn_ll.py:284-321 filter_proposals, :323-374 forward; parameters
+// detection/frcnn_la.py:154-158, :185-203).  Integer / index work is exact; ties are broken by
+// (score desc, anchor index asc).
+#include "common.h"
+#include "kernels.h"
+#include "sortnms.h"
+
+// ---------------------------------------------------------------------------------------------
+// Kernel 1: per (level, view): exact top-k of the objectness logits by 8-pass radix select on
+// 64-bit keys, bitonic sort of the <=1024 survivors in LDS, anchor decode + clip + min-size test.
+// grid = (5, V), block = 1024.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void rpn_topk_kernel(RpnArgs a) {
+    __shared__ unsigned long long sel[1024];
+    __shared__ int hist[256];
+    __shared__ unsigned long long s_prefix, s_mask;
+    __shared__ int s_remaining, s_cnt;
+    const int l = blockIdx.x, v = blockIdx.y, tid = threadIdx.x;
+    const LevelSeg sg = a.seg[l][v];
+    const int A = a.A, n = sg.H * sg.W * A;
+    const int k = n < a.pre_n ? n : a.pre_n;
+    const float* head = a.head[l] + sg.pix_off * (long long)a.head_ld;
+    auto key_of = [&](int i) -> unsigned long long {
+        const int pix = i / A, an = i - pix * A;
+        const float lg = head[(long long)pix * a.head_ld + an];
+        return ((unsigned long long)det_orderable(lg) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
+    };
+    sel[tid] = 0ull;
+    if (tid == 0) { s_prefix = 0ull; s_mask = 0ull; s_remaining = k; s_cnt = 0; }
+    __syncthreads();
+    if (n > k) {
+        for (int pass = 0; pass < 8; pass++) {
+            const int shift = 56 - 8 * pass;
+            if (tid < 256) hist[tid] = 0;
+            __syncthreads();
+            const unsigned long long prefix = s_prefix, mask = s_mask;
+            for (int i = tid; i < n; i += 1024) {
+                const unsigned long long key = key_of(i);
+                if ((key & mask) == prefix) atomicAdd(&hist[(int)((key >> shift) & 255ull)], 1);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int cum = 0, rem = s_remaining;
+                for (int b = 255; b >= 0; b--) {
+                    const int h = hist[b];
+                    if (cum + h >= rem) {
+                        s_remaining = rem - cum;
+                        s_prefix = prefix | ((unsigned long long)b << shift);
+                        s_mask = mask | (255ull << shift);
+                        break;
+                    }
+                    cum += h;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const unsigned long long thresh = (n > k) ? s_prefix : 0ull;   // k-th largest key (keys are unique)
+    for (int i = tid; i < n; i += 1024) {
+        const unsigned long long key = key_of(i);
+        if (key >= thresh) { const int slot = atomicAdd(&s_cnt, 1); if (slot < 1024) sel[slot] = key; }
+    }
+    __syncthreads();
+    block_bitonic_sort_desc(sel, 1024);
+    // decode the t-th best anchor
+    const int t = tid;
+    if (t < a.pre_n) {
+        unsigned long long outkey = 0ull;
+        float4 box = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t < k) {
+            const unsigned long long key = sel[t];
+            const int i = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
+            const int pix = i / A, an = i - pix * A;
+            const int y = pix / sg.W, x = pix - y * sg.W;
+            const LevelSeg s0 = a.seg0[v];
+            const int sth = s0.H / sg.H, stw = s0.W / sg.W;
+            const float* ba = a.base_anchors + (l * A + an) * 4;
+            float anchor[4] = {(float)(x * stw) + ba[0], (float)(y * sth) + ba[1], (float)(x * stw) + ba[2], (float)(y * sth) + ba[3]};
+            const float* hp = head + (long long)pix * a.head_ld;
+            float d[4] = {hp[A + 4 * an], hp[A + 4 * an + 1], hp[A + 4 * an + 2], hp[A + 4 * an + 3]};
+            float o[4];
+            det_box_decode(anchor, d, 1.0f, 1.0f, 1.0f, 1.0f, o);
+            const float Wr = (float)a.views[v].Wr, Hr = (float)a.views[v].Hr;
+            box.x = det_clamp(o[0], 0.0f, Wr); box.z = det_clamp(o[2], 0.0f, Wr);
+            box.y = det_clamp(o[1], 0.0f, Hr); box.w = det_clamp(o[3], 0.0f, Hr);
+            const bool ok = (box.z - box.x) >= a.min_size && (box.w - box.y) >= a.min_size;
+            if (ok) outkey = (key & 0xFFFFFFFF00000000ull) | (unsigned long long)(0xFFFFFFFFu - (unsigned)(l * a.pre_n + t));
+        }
+        const long long o = (long long)v * 5 * a.pre_n + l * a.pre_n + t;
+        a.cand_key[o] = outkey;
+        reinterpret_cast<float4*>(a.cand_box)[o] = box;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Kernel 2: per view: sort the <=5*pre_n candidates by (score desc, position asc), apply the
+// batched_nms coordinate offset level*(max_coord+1) in fp32, run greedy NMS, emit <=post_n boxes.
+// grid = V, block = 1024, dynamic LDS.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void rpn_nms_kernel(RpnArgs a, int NP) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(dyn);                 // NP
+    float4* kept_box = reinterpret_cast<float4*>(dyn + (size_t)NP * 8);                    // post_n
+    float* kept_area = reinterpret_cast<float*>(dyn + (size_t)NP * 8 + (size_t)a.post_n * 16);
+    int* keep_idx = reinterpret_cast<int*>(kept_area + a.post_n);                          // post_n
+    int* dead_or = keep_idx + a.post_n;                                                    // 256
+    float* red = reinterpret_cast<float*>(dead_or + 256);                                  // 1024
+    __shared__ int s_nc, s_nk;
+    const int v = blockIdx.x, tid = threadIdx.x;
+    const int ntot = 5 * a.pre_n;
+    const unsigned long long* ck = a.cand_key + (long long)v * ntot;
+    const float4* cb = reinterpret_cast<const float4*>(a.cand_box) + (long long)v * ntot;
+    if (tid == 0) s_nc = 0;
+    float mx = -INFINITY;
+    for (int i = tid; i < NP; i += 1024) {
+        unsigned long long key = i < ntot ? ck[i] : 0ull;
+        keys[i] = key;
+        if (key) { const float4 b = cb[i]; mx = fmaxf(mx, fmaxf(fmaxf(b.x, b.y), fmaxf(b.z, b.w))); }
+    }
+    red[tid] = mx;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) { if (tid < s) red[tid] = fmaxf(red[tid], red[tid + s]); __syncthreads(); }
+    const float maxc = red[0];
+    block_bitonic_sort_desc(keys, NP);
+    int local = 0;
+    for (int i = tid; i < NP; i += 1024) local += keys[i] != 0ull;
+    if (local) atomicAdd(&s_nc, local);
+    __syncthreads();
+    const int nc = s_nc;
+    float4* sb = reinterpret_cast<float4*>(a.sorted_box) + (long long)v * ntot;
+    float4* sr = reinterpret_cast<float4*>(a.sorted_raw) + (long long)v * ntot;
+    for (int i = tid; i < nc; i += 1024) {
+        const int pos = (int)(0xFFFFFFFFu - (unsigned)(keys[i] & 0xFFFFFFFFull));
+        const int lvl = pos / a.pre_n;
+        const float off = (float)lvl * (maxc + 1.0f);
+        const float4 b = cb[pos];
+        sr[i] = b;
+        sb[i] = make_float4(b.x + off, b.y + off, b.z + off, b.w + off);
+    }
+    __syncthreads();   // global writes by this block are read back below by other threads
+    block_nms_sorted(sb, nc, a.nms_thr, a.post_n, kept_box, kept_area, dead_or, keep_idx, &s_nk);
+    const int nk = s_nk;
+    float4* pr = reinterpret_cast<float4*>(a.proposals) + (long long)v * CALD_ROI_CAP;
+    for (int i = tid; i < nk; i += 1024) pr[i] = sr[keep_idx[i]];
+    if (tid == 0) { a.prop_count[v] = nk; a.sorted_count[v] = nc; }
+}
+
+void launch_rpn(const RpnArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(rpn_topk_kernel, dim3(5, a.V), dim3(1024), 0, st, a);
+    int NP = 1024;
+    while (NP < 5 * a.pre_n) NP <<= 1;
+    size_t lds = (size_t)NP * 8 + (size_t)a.post_n * (16 + 4 + 4) + 256 * 4 + 1024 * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(rpn_nms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(rpn_nms_kernel, dim3(a.V), dim3(1024), lds, st, a, NP);
+}

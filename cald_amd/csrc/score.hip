@@ -1,0 +1,140 @@
+// score.hip -- the CALD consistency score (reference cald_train.py:189-224, hot loops 3-4 of
+// SURVEY.md section 3.2) and the per-view class-max vector (cald_train.py:114-117, :194-197).
+//
+// The reference runs ~25 tiny torch kernels + 6 host syncs per (reference box, augmentation);
+// here one workgroup scores one (image, augmentation) pair: a wavefront per reference box does the
+// IoU row + first-index argmax across lanes, then the Jensen-Shannon divergence with one class per
+// lane and 64-lane butterfly reductions (the same addition order the oracle's wave_sum uses).
+#include "common.h"
+#include "kernels.h"
+
+__device__ inline float wave_sum64(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = v + __shfl_xor(v, off, 64);
+    return v;
+}
+
+// scipy.special.rel_entr
+__device__ inline float rel_entr_f(float x, float y) {
+    if (x != x || y != y) return NAN;
+    if (x > 0.0f && y > 0.0f) return x * det_logf(x / y);
+    if (x == 0.0f && y >= 0.0f) return 0.0f;
+    return INFINITY;
+}
+
+__device__ inline float cald_iou(const float4 ab, const float4 B) {
+    float w = fminf(ab.z, B.z) - fmaxf(ab.x, B.x);
+    float h = fminf(ab.w, B.w) - fmaxf(ab.y, B.y);
+    float Aarea = (ab.z - ab.x) * (ab.w - ab.y);
+    float Barea = (B.z - B.x) * (B.w - B.y);
+    float inter = w * h;
+    float iou = inter / ((Aarea + Barea) - inter);
+    if (w < 0.0f) iou = 0.0f;
+    if (h < 0.0f) iou = 0.0f;
+    return iou;
+}
+
+// "is (v1, j1) a better argmax than (v2, j2)": torch.argmax = first maximum, NaN is maximal.
+__device__ inline bool better(float v1, int j1, float v2, int j2) {
+    const bool n1 = v1 != v1, n2 = v2 != v2;
+    if (n1 != n2) return n1;
+    if (n1) return j1 < j2;
+    return v1 > v2 || (v1 == v2 && j1 < j2);
+}
+
+__global__ __launch_bounds__(256) void consistency_kernel(ScoreArgs a) {
+    __shared__ float wmin[4];
+    const int p = blockIdx.x;
+    const int rv = a.ref_view[p], av = a.aug_view[p], img = a.pair_img[p];
+    const int N = a.ref_n[img];
+    const int M = a.det.count[av];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cap = a.det.cap, C = a.det.C;
+    if (M == 0) { if (threadIdx.x == 0) a.cons[p] = 0.0f; return; }
+    const float4* rboxes = reinterpret_cast<const float4*>(a.det.boxes) + (long long)rv * cap;
+    const float4* aboxes = reinterpret_cast<const float4*>(a.det.boxes) + (long long)av * cap;
+    const int kind = a.aug_kind[p];
+    const float prm = a.aug_param[p];
+    float cur = 1.0f;
+    for (int i = wave; i < N; i += 4) {
+        const int ri = a.ref_sel[img * 50 + i];
+        float4 ab = rboxes[ri];
+        if (kind == 1) { float x0 = prm - ab.z, x2 = prm - ab.x; ab.x = x0; ab.z = x2; }   // cald_helper.py:29
+        else if (kind == 2) { ab.x = ab.x * prm; ab.y = ab.y * prm; ab.z = ab.z * prm; ab.w = ab.w * prm; }  // :53
+        float best = -INFINITY; int bj = 0x7fffffff;
+        for (int j = lane; j < M; j += 64) {
+            float v = cald_iou(ab, aboxes[j]);
+            if (better(v, j, best, bj)) { best = v; bj = j; }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            float ov = __shfl_xor(best, off, 64); int oj = __shfl_xor(bj, off, 64);
+            if (better(ov, oj, best, bj)) { best = ov; bj = oj; }
+        }
+        // Jensen-Shannon divergence through scipy.stats.entropy semantics (float32, renormalised)
+        const float* pv = a.det.scores_cls + ((long long)rv * cap + ri) * C;
+        const float* qv = a.det.scores_cls + ((long long)av * cap + bj) * C;
+        float sp = 0.0f, sq = 0.0f, sm = 0.0f;
+        for (int k = lane; k < C; k += 64) {
+            float pk = pv[k], qk = qv[k];
+            sp = sp + pk; sq = sq + qk; sm = sm + (pk + qk) / 2.0f;
+        }
+        sp = wave_sum64(sp); sq = wave_sum64(sq); sm = wave_sum64(sm);
+        float t1 = 0.0f, t2 = 0.0f;
+        for (int k = lane; k < C; k += 64) {
+            float pk = pv[k], qk = qv[k];
+            float mk = ((pk + qk) / 2.0f) / sm;
+            t1 = t1 + rel_entr_f(pk / sp, mk);
+            t2 = t2 + rel_entr_f(qk / sq, mk);
+        }
+        t1 = wave_sum64(t1); t2 = wave_sum64(t2);
+        float js = 0.5f * t1 + 0.5f * t2;
+        if (js < 0.0f) js = 0.0f;
+        const float t = 0.5f * (1.0f - js);
+        const float u = a.det.prob_max[(long long)rv * cap + ri] + a.det.prob_max[(long long)av * cap + bj];
+        const float s = fabsf((best + t * u) - a.bp);
+        if (s < cur) cur = s;
+    }
+    if (lane == 0) wmin[wave] = cur;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float c = 1.0f;
+        for (int w = 0; w < 4; w++) if (wmin[w] < c) c = wmin[w];
+        a.cons[p] = c;
+    }
+}
+
+void launch_consistency(const ScoreArgs& a, hipStream_t st) {
+    if (a.P <= 0) return;
+    hipLaunchKernelGGL(consistency_kernel, dim3(a.P), dim3(256), 0, st, a);
+}
+
+// cls_corr[l-1] = max(cls_corr[l-1], score) with python negative indexing for label 0 (RetinaNet).
+// Reference views use only their sub-sampled detections (cald_train.py:110-117).
+__global__ __launch_bounds__(256) void cls_corr_kernel(DetBuffers det, const int* ref_sel, const int* ref_n,
+                                                       const int* view_img, const int* view_is_ref, float* out) {
+    __shared__ int smax[256];
+    const int v = blockIdx.x;
+    const int C = det.C, cap = det.cap;
+    for (int k = threadIdx.x; k < C - 1; k += 256) smax[k] = 0;
+    __syncthreads();
+    const bool is_ref = view_is_ref[v] != 0;
+    const int img = view_img[v];
+    const int n = is_ref ? ref_n[img] : det.count[v];
+    for (int d = threadIdx.x; d < n; d += 256) {
+        const int di = is_ref ? ref_sel[img * 50 + d] : d;
+        long long l = det.labels[(long long)v * cap + di] - 1;
+        if (l < 0) l += C - 1;
+        if (l < 0 || l >= C - 1) continue;
+        const float s = det.scores[(long long)v * cap + di];
+        if (s > 0.0f) atomicMax(&smax[l], __float_as_int(s));
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < C - 1; k += 256) out[(long long)v * (C - 1) + k] = __int_as_float(smax[k]);
+}
+
+void launch_cls_corr(const DetBuffers& det, const int* ref_sel, const int* ref_n, const int* view_img, const int* view_is_ref,
+                     int V, float* out, hipStream_t st) {
+    if (V <= 0) return;
+    hipLaunchKernelGGL(cls_corr_kernel, dim3(V), dim3(256), 0, st, det, ref_sel, ref_n, view_img, view_is_ref, out);
+}

@@ -1,0 +1,169 @@
+"""Drop-in detector objects behind the reference's factory signatures.
+
+``fasterrcnn_resnet50_fpn_feature(pretrained, progress, num_classes, pretrained_backbone, **kwargs)``
+mirrors detection/frcnn_la.py:278-289 (call sites cald_train.py:340-347): the returned object exposes
+``.eval() / .to() / .load_state_dict() / __call__(list[Tensor[3,H,W] float 0..1])`` and returns the
+result dicts of detection/frcnn_la.py:131-141 (``boxes, labels, scores, props, prob_max,
+scores_cls``; ``features`` is omitted, detection/engine.py:109-111 checks for its presence).
+All arithmetic runs in libcaldhip.so on the MI355X; there is no CPU path.  Training is out of
+scope: ``.train()`` raises.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _ffi
+
+_CTX = {}
+
+
+def get_ctx(device_index=None):
+    """One library context per device, bound to torch's current stream on that device."""
+    if not torch.cuda.is_available():
+        raise RuntimeError("cald_amd needs a visible MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
+    if device_index is None:
+        device_index = torch.cuda.current_device()
+    if device_index not in _CTX:
+        h = C.c_void_p()
+        stream = torch.cuda.current_stream(device_index).cuda_stream
+        _ffi.check(_ffi.lib().cald_ctx_create(device_index, C.c_void_p(stream), C.byref(h)))
+        _CTX[device_index] = h
+    return _CTX[device_index]
+
+
+class HipDetector:
+    arch = 0
+
+    def __init__(self, num_classes, depth=50, min_size=800, max_size=1333, box_score_thresh=0.05, box_nms_thresh=0.5,
+                 box_detections_per_img=100, rpn_pre_nms_top_n_test=1000, rpn_post_nms_top_n_test=1000,
+                 rpn_nms_thresh=0.7, **unused):
+        self.cfg = _ffi.ModelCfg(self.arch, depth, num_classes, int(min_size), int(max_size), box_score_thresh,
+                                 box_nms_thresh, box_detections_per_img, rpn_pre_nms_top_n_test, rpn_post_nms_top_n_test,
+                                 rpn_nms_thresh)
+        self.num_classes = num_classes
+        self.training = False
+        self._state = None
+        self._handle = None
+        self._device = None
+
+    # ---- nn.Module-like surface used by cald_train.py ----
+    def eval(self):
+        self.training = False
+        return self
+
+    def train(self, mode=True):
+        if mode:
+            raise NotImplementedError("cald_amd detectors are inference-only (training stays with stock PyTorch, SURVEY 8b)")
+        return self.eval()
+
+    def to(self, device):
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise RuntimeError("cald_amd detectors live on the MI355X only")
+        self._device = dev.index if dev.index is not None else torch.cuda.current_device()
+        return self
+
+    def cuda(self, device=None):
+        return self.to("cuda" if device is None else "cuda:%d" % device)
+
+    def state_dict(self):
+        return dict(self._state or {})
+
+    def load_state_dict(self, sd, strict=True):
+        self._state = {k: (v.detach().cpu().float().numpy() if hasattr(v, "detach") else np.asarray(v, np.float32))
+                       for k, v in sd.items() if not k.endswith("num_batches_tracked")}
+        self._destroy()
+        return self
+
+    # ---- native handle ----
+    def _destroy(self):
+        if self._handle is not None:
+            _ffi.lib().cald_model_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self._destroy()
+        except Exception:
+            pass
+
+    def handle(self):
+        if self._handle is None:
+            if self._state is None:
+                raise RuntimeError("no weights: call load_state_dict() first (cald_train.py:356)")
+            L = _ffi.lib()
+            ctx = get_ctx(self._device)
+            h = C.c_void_p()
+            _ffi.check(L.cald_model_create(ctx, C.byref(self.cfg), C.byref(h)))
+            for k, v in self._state.items():
+                a = np.ascontiguousarray(v, dtype=np.float32)
+                if a.ndim == 0:
+                    continue
+                shape = (C.c_int64 * a.ndim)(*a.shape)
+                _ffi.check(L.cald_model_load_tensor(h, k.encode(), _ffi.ptr(a), shape, a.ndim))
+            _ffi.check(L.cald_model_finalize(h))
+            self._handle = h
+        return self._handle
+
+    # ---- inference ----
+    def forward_views(self, views):
+        """views: list of (uint8 HWC cuda tensor, flip, rects).  Returns list of result dicts (device tensors)."""
+        L = _ffi.lib()
+        h = self.handle()
+        n = len(views)
+        dev = views[0][0].device
+        cap, Cn = self.cfg.detections_per_img, self.num_classes
+        out = dict(boxes=torch.empty((n, cap, 4), device=dev), scores=torch.empty((n, cap), device=dev),
+                   labels=torch.empty((n, cap), dtype=torch.int64, device=dev), props=torch.empty((n, cap, 4), device=dev),
+                   prob_max=torch.empty((n, cap), device=dev), scores_cls=torch.empty((n, cap, Cn), device=dev),
+                   count=torch.zeros((n,), dtype=torch.int32, device=dev))
+        arr = (_ffi.View * n)()
+        for i, (img, flip, rects) in enumerate(views):
+            assert img.dtype == torch.uint8 and img.is_cuda and img.is_contiguous() and img.shape[2] == 3
+            arr[i].image_dev = img.data_ptr(); arr[i].H = img.shape[0]; arr[i].W = img.shape[1]
+            arr[i].flip = int(bool(flip)); arr[i].nrect = 0 if rects is None else len(rects)
+            if rects is not None:
+                for j, r in enumerate(np.asarray(rects, np.int32).reshape(-1)):
+                    arr[i].rects[j] = int(r)
+        d = _ffi.Dets(out["boxes"].data_ptr(), out["scores"].data_ptr(), out["labels"].data_ptr(), out["props"].data_ptr(),
+                      out["prob_max"].data_ptr(), out["scores_cls"].data_ptr(), out["count"].data_ptr(), cap)
+        _ffi.check(L.cald_forward(h, n, arr, C.byref(d)))
+        counts = out["count"].cpu().tolist()
+        res = []
+        for i, k in enumerate(counts):
+            res.append({key: out[key][i, :k] for key in ("boxes", "labels", "scores", "props", "prob_max", "scores_cls")})
+        return res
+
+    def __call__(self, images, targets=None):
+        """model(list[Tensor[3,H,W] float32 in 0..1]) -> list[dict] (detection/frcnn_la.py:237-275).
+        The tensors are quantised back to the uint8 grid they came from (to_tensor, cald_train.py:107)."""
+        if self.training:
+            raise NotImplementedError("inference only")
+        views = []
+        for img in images:
+            if img.dtype == torch.uint8:
+                u8 = img if img.shape[-1] == 3 else img.permute(1, 2, 0)
+            else:
+                u8 = (img * 255.0).round().clamp(0, 255).to(torch.uint8).permute(1, 2, 0)
+            views.append((u8.contiguous().cuda(), False, None))
+        return self.forward_views(views)
+
+    def debug_tensor(self, name, view=0):
+        shape = (C.c_int64 * 3)()
+        cap = 1 << 26
+        buf = np.empty(cap, np.float32)
+        _ffi.check(_ffi.lib().cald_debug_tensor(self.handle(), name.encode(), view, _ffi.ptr(buf), cap, shape))
+        n = shape[0] * shape[1] * shape[2]
+        return buf[:n].reshape(shape[0], shape[1], shape[2]).copy()
+
+
+def fasterrcnn_resnet50_fpn_feature(pretrained=False, progress=True, num_classes=91, pretrained_backbone=True, **kwargs):
+    """detection/frcnn_la.py:278-289.  No network here: `pretrained*` cannot download anything; weights arrive
+    through load_state_dict() exactly as in cald_train.py:349-356."""
+    return HipDetector(num_classes, depth=50, **kwargs)
+
+
+def fasterrcnn_resnet101_fpn_feature(pretrained=False, progress=True, num_classes=91, pretrained_backbone=True, **kwargs):
+    """BASELINE.json config 5 (ResNet-101): same factory with torchvision's 'resnet101' body."""
+    return HipDetector(num_classes, depth=101, **kwargs)

@@ -1,0 +1,145 @@
+"""get_uncertainty / cls_kldiv with the reference's signatures (cald_train.py:91-231, :234-271).
+
+``get_uncertainty(task_model, unlabeled_loader, augs, num_cls, bp=1.3)`` returns
+``(consistency_all: list[float], cls_all: list[np.ndarray float64 [num_cls-1]])`` in loader order.
+``bp`` replaces the module-global ``args.bp`` (cald_train.py:220).  With ``world_size > 1`` each rank
+scores the strided shard ``pos % world_size == rank`` and one RCCL all-gather returns the full vectors
+on every rank.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _ffi
+
+KNOWN_AUGS = ['flip', 'multi_ga', 'color_adjust', 'color_swap', 'multi_color_adjust', 'multi_sp', 'cut_out',
+              'multi_cut_out', 'multi_resize', 'larger_resize', 'smaller_resize', 'rotation', 'ga', 'sp']
+SUPPORTED_AUGS = ('flip', 'cut_out', 'smaller_resize')
+
+
+def _to_u8_cuda(image, device):
+    if isinstance(image, torch.Tensor):
+        t = image
+        if t.dtype != torch.uint8:
+            t = (t * 255.0).round().clamp(0, 255).to(torch.uint8)
+        if t.shape[0] == 3 and t.shape[-1] != 3:
+            t = t.permute(1, 2, 0)
+    else:  # PIL image or ndarray
+        t = torch.from_numpy(np.array(image, dtype=np.uint8))
+    return t.contiguous().to(device, non_blocking=True)
+
+
+def sweep_device_images(task_model, images, positions, augs, bp=1.3, base_seed=0, batch_images=16):
+    """Scores uint8 HWC CUDA tensors already resident in HBM.  Returns (consistency [n] f64, cls_corr [n][C-1] f64)."""
+    for aug in augs:
+        if aug not in KNOWN_AUGS:
+            print('{} is not in the pre-set augmentations!'.format(aug))   # cald_train.py:92-95
+        elif aug not in SUPPORTED_AUGS:
+            raise NotImplementedError("augmentation %r is not implemented on the MI355X path yet" % aug)
+    L = _ffi.lib()
+    n = len(images)
+    Cn = task_model.num_classes
+    cons = np.zeros(n, np.float64)
+    cls = np.zeros((n, Cn - 1), np.float64)
+    if n == 0:
+        return cons, cls
+    ptrs = (C.c_void_p * n)(*[im.data_ptr() for im in images])
+    Hs = np.array([im.shape[0] for im in images], np.int32)
+    Ws = np.array([im.shape[1] for im in images], np.int32)
+    pos = np.ascontiguousarray(positions, dtype=np.int64)
+    cfg = _ffi.SweepCfg(int('flip' in augs), int('cut_out' in augs), int('smaller_resize' in augs), 0.8,
+                        int(base_seed), float(bp), int(batch_images))
+    _ffi.check(L.cald_sweep(task_model.handle(), n, ptrs, _ffi.ptr(Hs, _ffi.c_i), _ffi.ptr(Ws, _ffi.c_i),
+                            _ffi.ptr(pos, _ffi.c_i64), C.byref(cfg), _ffi.ptr(cons, _ffi.c_d), _ffi.ptr(cls, _ffi.c_d)))
+    return cons, cls
+
+
+def allgather_scores(local_pos, cons, cls, pool_size, group=None):
+    """One all-gather of (pool position, consistency, cls_corr) rows (RCCL on GPUs, gloo on CPU);
+    replaces detection/utils.py:75-115's pickled all_gather pattern.  Shards are padded to equal length."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    Cm1 = cls.shape[1]
+    rows = (pool_size + world - 1) // world
+    buf = torch.full((rows, 2 + Cm1), -1.0, dtype=torch.float64)
+    k = len(local_pos)
+    if k:
+        buf[:k, 0] = torch.from_numpy(np.asarray(local_pos, np.float64))
+        buf[:k, 1] = torch.from_numpy(cons)
+        buf[:k, 2:] = torch.from_numpy(cls)
+    backend = dist.get_backend(group)
+    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    buf = buf.to(dev)
+    out = torch.empty((world * rows, 2 + Cm1), dtype=torch.float64, device=dev)
+    dist.all_gather_into_tensor(out, buf, group=group)
+    out = out.cpu().numpy()
+    full_cons = np.zeros(pool_size, np.float64)
+    full_cls = np.zeros((pool_size, Cm1), np.float64)
+    valid = out[:, 0] >= 0
+    idx = out[valid, 0].astype(np.int64)
+    full_cons[idx] = out[valid, 1]
+    full_cls[idx] = out[valid, 2:]
+    return full_cons, full_cls
+
+
+def get_uncertainty(task_model, unlabeled_loader, augs, num_cls, bp=1.3, base_seed=0, rank=0, world_size=1,
+                    batch_images=16, group=None):
+    """Drop-in for cald_train.py:91 (same positional signature)."""
+    task_model.eval()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    images, positions = [], []
+    pool_size = 0
+    for pos, (imgs, _) in enumerate(unlabeled_loader):      # batch size 1, cald_train.py:101-104
+        pool_size += 1
+        if pos % world_size != rank:
+            continue
+        for image in imgs:
+            images.append(_to_u8_cuda(image, dev)); positions.append(pos)
+    cons, cls = sweep_device_images(task_model, images, positions, augs, bp, base_seed, batch_images)
+    if world_size > 1:
+        cons, cls = allgather_scores(positions, cons, cls, pool_size, group)
+    return [float(c) for c in cons], [cls[i] for i in range(cls.shape[0])]
+
+
+def cls_kldiv(labeled_loader, cls_corrs, budget, cycle=0, uniform=False):
+    """cald_train.py:234-271 (host side, float64; `uniform` replaces the global args.uniform)."""
+    from torch import nn
+    cls_inds, result = [], []
+    for _, targets in labeled_loader:
+        for target in targets:
+            cls_corr = [0] * cls_corrs[0].shape[0]
+            for l in target['labels']:
+                cls_corr[int(l) - 1] += 1
+            result.append(cls_corr)
+    for a in list(np.where(np.sum(cls_corrs, axis=1) == 0)[0]):
+        cls_inds.append(int(a))
+    kld = nn.KLDivLoss(reduction='none')
+    _cls = torch.tensor(np.asarray(cls_corrs))
+    _res = torch.tensor(np.mean(np.array(result), axis=0)).unsqueeze(0)
+    while len(cls_inds) < budget:
+        if uniform:
+            p = torch.nn.functional.softmax(_res + _cls, -1)
+            q = torch.nn.functional.softmax(torch.ones(_res.shape) / len(_res), -1)
+            log_mean = ((p + q) / 2).log()
+            js = torch.sum(kld(log_mean, p), dim=1) / 2 + torch.sum(kld(log_mean, q), dim=1) / 2
+            js[cls_inds] = 100
+            cls_inds.append(torch.argmin(js).item())
+        else:
+            p = torch.nn.functional.softmax(_res, -1)
+            q = torch.nn.functional.softmax(_cls, -1)
+            log_mean = ((p + q) / 2).log()
+            js = torch.sum(kld(log_mean, p), dim=1) / 2 + torch.sum(kld(log_mean, q), dim=1) / 2
+            js[cls_inds] = -1
+            cls_inds.append(torch.argmax(js).item())
+    return cls_inds
+
+
+def select(uncertainty, cls_corrs, labeled_loader, budget, mr=1.2, mutual=True, uniform=False):
+    """cald_train.py:439-447: argsort ascending, candidate cut, class-balance pick.  Returns positions into the pool."""
+    arg = np.argsort(np.asarray(uncertainty))
+    if not mutual:
+        return arg[:budget]
+    cand = arg[:int(mr * budget)]
+    tobe = cls_kldiv(labeled_loader, [cls_corrs[i] for i in cand], budget, uniform=uniform)
+    return cand[np.asarray(tobe, dtype=np.int64)]

@@ -1,0 +1,136 @@
+/* cald_hip.h -- C ABI of libcaldhip.so: the MI355X (gfx950) implementation of CALD's unlabeled-pool
+ * consistency sweep.  Plain pointers and sizes only; no torch types cross this boundary.
+ *
+ * The reference (we1pingyu/CALD) has no FFI: its boundary for this path is two in-process Python
+ * call signatures.  Each entry point below names the reference interface it stands behind; the
+ * Python shim that binds them (cald_amd/_ffi.py, ctypes) and the stub a maintainer would add to the
+ * reference are shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative code on failure; cald_last_error() gives the
+ *     thread-local message (the Python shim raises RuntimeError with it).
+ *   - pointers named *_dev are device (HBM) pointers on the context's GPU, everything else is host.
+ *   - the caller owns and allocates all outputs; the library owns only ctx / model / workspace.
+ *   - one context per device, one HIP stream per context, not thread-safe per context;
+ *     one process per GPU for multi-GPU (the pool is sharded by the caller, see cald_amd/sweep.py).
+ */
+#ifndef CALD_HIP_H
+#define CALD_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cald_ctx cald_ctx;
+typedef struct cald_model cald_model;
+
+#define CALD_OK 0
+#define CALD_ERR_INVALID (-1)
+#define CALD_ERR_HIP (-2)
+#define CALD_ERR_STATE (-3)
+#define CALD_ERR_MISSING_WEIGHT (-4)
+
+#define CALD_ARCH_FRCNN 0      /* detection/frcnn_la.py FRCNN_Feature */
+#define CALD_ARCH_RETINANET 1  /* detection/retinanet_cal.py RetinaNet */
+
+const char* cald_last_error(void);
+int cald_version(void);
+
+/* stream: a hipStream_t to launch on (e.g. torch.cuda.current_stream().cuda_stream), or NULL for
+ * a private stream.  Replaces torch.cuda.set_device(0) + default stream (cald_train.py:275). */
+int cald_ctx_create(int device, void* stream, cald_ctx** out);
+int cald_ctx_destroy(cald_ctx* ctx);
+int cald_ctx_sync(cald_ctx* ctx);
+
+/* Constructor arguments of fasterrcnn_resnet50_fpn_feature(num_classes, min_size, max_size)
+ * (detection/frcnn_la.py:148-169, :278-289; call sites cald_train.py:340-347). */
+typedef struct cald_model_cfg {
+    int arch;               /* CALD_ARCH_* */
+    int depth;              /* 50 | 101 */
+    int num_classes;        /* incl. background for FRCNN */
+    int min_size, max_size; /* 600/1000 VOC, 800/1333 COCO */
+    float box_score_thresh; /* 0.05 */
+    float box_nms_thresh;   /* 0.5 */
+    int detections_per_img; /* 100 */
+    int rpn_pre_nms_top_n;  /* 1000 */
+    int rpn_post_nms_top_n; /* 1000 */
+    float rpn_nms_thresh;   /* 0.7 */
+} cald_model_cfg;
+
+int cald_model_create(cald_ctx* ctx, const cald_model_cfg* cfg, cald_model** out);
+/* model.load_state_dict() (cald_train.py:356): one call per tensor, torchvision key layout
+ * ("backbone.body.layer1.0.conv1.weight", ...), float32 host data, row-major. */
+int cald_model_load_tensor(cald_model* m, const char* key, const float* data, const int64_t* shape, int ndim);
+/* folds FrozenBatchNorm into per-channel scale/shift, repacks weights K-major for the MFMA kernels */
+int cald_model_finalize(cald_model* m);
+int cald_model_destroy(cald_model* m);
+
+/* One detector input: task_model([tensor]) in cald_train.py:107 / :186.  The view is described by
+ * its uint8 HWC source image in HBM plus the augmentation to apply on the fly. */
+typedef struct cald_view {
+    const uint8_t* image_dev; /* [H][W][3] uint8 */
+    int H, W;
+    int flip;                 /* cald_helper.HorizontalFlip */
+    int nrect;                /* cald_helper.cutout rectangles (left, top, right, bottom), <= 4 */
+    int rects[16];
+} cald_view;
+
+/* Result dict of the detector (detection/frcnn_la.py:131-141): device buffers, `cap` rows per view. */
+typedef struct cald_dets {
+    float* boxes_dev;      /* [n_views][cap][4] */
+    float* scores_dev;     /* [n_views][cap] */
+    int64_t* labels_dev;   /* [n_views][cap] */
+    float* props_dev;      /* [n_views][cap][4] */
+    float* prob_max_dev;   /* [n_views][cap] */
+    float* scores_cls_dev; /* [n_views][cap][num_classes] */
+    int32_t* count_dev;    /* [n_views] */
+    int cap;
+} cald_dets;
+
+/* model(list_of_images) in eval mode, for up to 64 views at once (batch-1 semantics per view). */
+int cald_forward(cald_model* m, int n_views, const cald_view* views, const cald_dets* out);
+
+/* get_uncertainty(task_model, unlabeled_loader, augs, num_cls) (cald_train.py:91-231) over
+ * n_images already resident in HBM.  pool_pos[i] keys the per-image RNG (cut_out), so results do
+ * not depend on sharding.  consistency_out[n_images], cls_corr_out[n_images][num_classes-1]. */
+typedef struct cald_sweep_cfg {
+    int aug_flip;          /* 'flip' */
+    int aug_cutout;        /* 'cut_out' (cut_num 2) */
+    int aug_resize;        /* 'smaller_resize' */
+    float resize_ratio;    /* 0.8 */
+    uint64_t base_seed;
+    float bp;              /* args.bp, 1.3 */
+    int batch_images;      /* images per batched launch sequence (0 = default 16) */
+} cald_sweep_cfg;
+int cald_sweep(cald_model* m, int n_images, const uint8_t* const* images_dev, const int* H, const int* W,
+               const int64_t* pool_pos, const cald_sweep_cfg* cfg, double* consistency_out, double* cls_corr_out);
+
+/* ---- operator-level entry points (used by the parity tests; same kernels as the paths above) ---- */
+/* scoring of ONE (reference, augmentation) pair, cald_train.py:189-224 */
+int cald_op_consistency(cald_ctx* ctx, int N, const float* aug_box, const float* ref_scores_cls, const float* ref_pm,
+                        int M, const float* boxes, const float* scores_cls, const float* pm, int C, float bp,
+                        float* consistency_out);
+/* cald_train.py:114-117 */
+int cald_op_cls_corr(cald_ctx* ctx, int n, const float* scores, const int64_t* labels, int C, float* out);
+/* cald_helper.resize: PIL.Image.resize((ow, oh), BILINEAR) on uint8 RGB */
+int cald_op_pil_resize(cald_ctx* ctx, const uint8_t* src_dev, int H, int W, uint8_t* dst_dev, int oh, int ow);
+/* cald_helper.cutout rectangle selection (host side RNG = Python random seeded per image) */
+int cald_op_cutout_rects(uint64_t seed, int H, int W, int N, const float* boxes, int cut_num, int* rects_out, int* n_out);
+/* NHWC convolution on the MFMA kernel; weights in torch layout [Cout][Cin][KH][KW] (host) */
+int cald_op_conv2d(cald_ctx* ctx, const float* in, int H, int W, int Cin, const float* weight, int Cout, int KH, int KW,
+                   int stride, int pad, const float* bias, const float* bn_scale, const float* bn_shift,
+                   const float* residual, int relu, float* out);
+/* detector-transform size (GeneralizedRCNNTransform): resized and padded sizes */
+int cald_op_transform_size(int H, int W, int min_size, int max_size, int* Hr, int* Wr, int* Hp, int* Wp);
+/* intermediate tensors of the LAST cald_forward (parity debugging): name in
+ * {"input","conv1","pool1","C2".."C5","P2".."P6","rpn0".."rpn4","proposals","roi","fc6","fc7","pred"} */
+int cald_debug_tensor(cald_model* m, const char* name, int view, float* host_out, int64_t capacity, int64_t* shape3);
+
+/* ---- measurement: HIP-event timing of every conv/linear launch on the context stream ---- */
+int cald_profile_enable(cald_ctx* ctx, int on);
+int cald_profile_read(cald_ctx* ctx, double* gemm_ms, double* gemm_flops, int64_t* gemm_launches, double* total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -373,8 +373,9 @@ ORC_API void orc_preprocess_view(const uint8_t* src, int H, int W, int flip, int
  * in (kh, kw, cin) order from +0; then (+bias) -> (*bn_scale, +bn_shift as two roundings,
  * FrozenBatchNorm2d: x*scale+bias) -> (+residual) -> (+nearest-upsampled `up`) -> ReLU.
  * ------------------------------------------------------------------------------------- */
-#define CT_P 4
+#define CT_P 6
 #define CT_V 32
+__attribute__((target_clones("arch=skylake-avx512", "default")))
 ORC_API void orc_conv2d_nhwc(const float* in, int H, int W, int Cin, const float* wk, int Cout, int KH, int KW,
                              int stride, int pad, const float* bias, const float* bn_scale, const float* bn_shift,
                              const float* residual, const float* up, int upH, int upW, int relu,
@@ -382,10 +383,13 @@ ORC_API void orc_conv2d_nhwc(const float* in, int H, int W, int Cin, const float
     float* zero = (float*)calloc((size_t)Cin, sizeof(float));
     long npix = (long)Ho * Wo;
     float uph_scale = up ? (float)upH / (float)Ho : 0.0f, upw_scale = up ? (float)upW / (float)Wo : 0.0f;
-#pragma omp parallel for schedule(dynamic, 16)
-    for (long p0 = 0; p0 < npix; p0 += CT_P) {
+#pragma omp parallel for schedule(dynamic, 2)
+    for (long pb0 = 0; pb0 < npix; pb0 += CT_P * 16) {
+      /* weights chunk [K][CT_V] is reused across the 16 pixel tiles of this block */
+      for (int co0 = 0; co0 < Cout; co0 += CT_V) {
+       for (long p0 = pb0; p0 < pb0 + CT_P * 16 && p0 < npix; p0 += CT_P) {
         int np_ = (int)(npix - p0 < CT_P ? npix - p0 : CT_P);
-        for (int co0 = 0; co0 < Cout; co0 += CT_V) {
+        {
             int nv = Cout - co0 < CT_V ? Cout - co0 : CT_V;
             float acc[CT_P][CT_V];
             for (int p = 0; p < CT_P; p++) for (int v = 0; v < CT_V; v++) acc[p][v] = 0.0f;
@@ -404,6 +408,7 @@ ORC_API void orc_conv2d_nhwc(const float* in, int H, int W, int Cin, const float
                     if (nv == CT_V) {
                         for (int ci = 0; ci < Cin; ci++) {
                             const float* wr = wbase + (size_t)ci * Cout;
+#pragma GCC unroll 8
                             for (int p = 0; p < CT_P; p++) {
                                 float a = rows[p][ci];
 #pragma omp simd
@@ -441,6 +446,8 @@ ORC_API void orc_conv2d_nhwc(const float* in, int H, int W, int Cin, const float
                 }
             }
         }
+       }
+      }
     }
     free(zero);
 }

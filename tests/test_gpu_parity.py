@@ -1,0 +1,181 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the golden vectors.
+Integer / index results are compared exactly; the float arithmetic follows the same contract
+ and is compared BIT-EXACTLY as well, which is far inside BASELINE.json's 1e-4 tolerance."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SCORING = ["scoring_frcnn_F", "scoring_frcnn_FCD", "scoring_retina_FCD", "scoring_frcnn_coco_FD"]
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import torch
+    assert torch.cuda.is_available(), "these tests need an MI355X"
+    from cald_amd import _ffi, detector
+    L = _ffi.lib()
+    return dict(L=L, ffi=_ffi, ctx=detector.get_ctx(0), det=detector, torch=torch)
+
+
+def _dets(g, i, v):
+    return {k: g["det%d_%d_%s" % (i, v, k)] for k in ("boxes", "labels", "scores", "prob_max", "scores_cls")}
+
+
+def gpu_consistency(hip, aug_box, ref_scls, ref_pm, boxes, scls, pm, bp):
+    ffi, L = hip["ffi"], hip["L"]
+    f = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+    aug_box, ref_scls, ref_pm, boxes, scls, pm = map(f, (aug_box, ref_scls, ref_pm, boxes, scls, pm))
+    N, M = aug_box.reshape(-1, 4).shape[0], boxes.reshape(-1, 4).shape[0]
+    Cn = ref_scls.shape[1]
+    out = np.zeros(1, np.float32)
+    ffi.check(L.cald_op_consistency(hip["ctx"], N, ffi.ptr(aug_box), ffi.ptr(ref_scls), ffi.ptr(ref_pm), M, ffi.ptr(boxes),
+                                    ffi.ptr(scls), ffi.ptr(pm), Cn, bp, ffi.ptr(out)))
+    return float(out[0])
+
+
+@pytest.mark.parametrize("name", SCORING)
+def test_consistency_kernel_vs_reference_golden(hip, oracle, golden, name):
+    g = golden(name)
+    augs = [str(a) for a in g["augs"]]
+    Cn, bp, base_seed = int(g["C"]), float(g["bp"]), int(g["base_seed"])
+    ffi, L = hip["ffi"], hip["L"]
+    for i in range(int(g["n_images"])):
+        nviews = int(g["per_image"][i])
+        if nviews == 1:
+            continue
+        ref = oracle.subsample_ref(_dets(g, i, 0))
+        views = oracle.build_views(g["img%d" % i], augs, ref, oracle.image_seed(base_seed, i))
+        cons = []
+        for vi, v in enumerate(views):
+            d = _dets(g, i, vi + 1)
+            got = gpu_consistency(hip, v[3], ref["scores_cls"], ref["prob_max"], d["boxes"], d["scores_cls"], d["prob_max"], bp)
+            want = oracle.consistency_view(v[3], ref["scores_cls"], ref["prob_max"], d["boxes"], d["scores_cls"], d["prob_max"], bp)
+            assert np.float32(got).tobytes() == np.float32(want).tobytes(), (name, i, vi, got, want)
+            cons.append(got)
+            cc = np.zeros(Cn - 1, np.float32)
+            lab = np.ascontiguousarray(d["labels"], np.int64); sc = np.ascontiguousarray(d["scores"], np.float32)
+            ffi.check(L.cald_op_cls_corr(hip["ctx"], len(sc), ffi.ptr(sc), ffi.ptr(lab, ffi.c_i64), Cn, ffi.ptr(cc)))
+            np.testing.assert_array_equal(cc, oracle.cls_corr_view(sc, lab, Cn))
+        assert abs(float(np.mean(np.array(cons, np.float64))) - g["consistency"][i]) <= 1e-5   # vs the reference itself
+
+
+def test_pil_resize_kernel(hip, oracle):
+    torch, ffi, L = hip["torch"], hip["ffi"], hip["L"]
+    from PIL import Image
+    rs = np.random.RandomState(0)
+    for (H, W) in [(375, 500), (333, 500), (500, 375), (61, 47)]:
+        img = (rs.rand(H, W, 3) * 255).astype(np.uint8)
+        for r in (0.8, 1.2, 0.5):
+            ow, oh = int(W * r), int(H * r)
+            src = torch.from_numpy(img).cuda(); dst = torch.empty((oh, ow, 3), dtype=torch.uint8, device="cuda")
+            ffi.check(L.cald_op_pil_resize(hip["ctx"], src.data_ptr(), H, W, dst.data_ptr(), oh, ow))
+            want = np.asarray(Image.fromarray(img).resize((ow, oh), Image.BILINEAR))
+            np.testing.assert_array_equal(dst.cpu().numpy(), want)
+            np.testing.assert_array_equal(want, oracle.pil_resize_bilinear(img, oh, ow))
+
+
+def test_cutout_rects_host(hip, oracle, golden):
+    g = golden("helpers")
+    ffi, L = hip["ffi"], hip["L"]
+    for i in range(4):
+        img, boxes = g["img%d" % i], np.ascontiguousarray(g["boxes%d" % i], np.float32)
+        H, W, _ = img.shape
+        for s in (11, 12, 13):
+            rects = np.zeros(16, np.int32); n = C.c_int()
+            ffi.check(L.cald_op_cutout_rects(s, H, W, boxes.shape[0], ffi.ptr(boxes), 2, ffi.ptr(rects, ffi.c_i), C.byref(n)))
+            np.testing.assert_array_equal(rects[:4 * n.value].reshape(-1, 4), oracle.cutout_rects(s, H, W, boxes, 2))
+
+
+CONV_CASES = [
+    # H, W, Cin, Cout, K, stride, pad, bias, bn, res, relu
+    (37, 53, 4, 64, 7, 2, 3, False, True, False, True),      # conv1
+    (38, 50, 64, 64, 1, 1, 0, False, True, False, True),     # bottleneck conv1
+    (38, 50, 64, 64, 3, 1, 1, False, True, False, True),     # bottleneck conv2
+    (38, 50, 64, 256, 1, 1, 0, False, True, True, True),     # bottleneck conv3 + residual
+    (38, 50, 128, 128, 3, 2, 1, False, True, False, True),   # stride-2 3x3
+    (38, 50, 256, 512, 1, 2, 0, False, True, False, False),  # downsample
+    (19, 25, 256, 256, 3, 1, 1, True, False, False, False),  # FPN layer block
+    (19, 25, 256, 15, 1, 1, 0, True, False, False, False),   # RPN head (Cout 15 -> tile 32)
+    (1, 300, 1024, 105, 1, 1, 0, True, False, False, False), # predictor (Cout 105 -> tile 128)
+    (1, 130, 12544, 1024, 1, 1, 0, True, False, False, True) # fc6: K = 12544 chain
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_mfma_bit_exact(hip, oracle, case):
+    H, W, Cin, Cout, K, stride, pad, bias, bn, res, relu = case
+    ffi, L = hip["ffi"], hip["L"]
+    rs = np.random.RandomState(H * 1000 + Cout)
+    x = rs.randn(H, W, Cin).astype(np.float32)
+    x[rs.rand(H, W, Cin) < 0.3] = 0.0
+    w = (rs.randn(Cout, Cin, K, K) * np.sqrt(2.0 / (Cin * K * K))).astype(np.float32)
+    b = rs.randn(Cout).astype(np.float32) if bias else None
+    sc = (0.5 + rs.rand(Cout)).astype(np.float32) if bn else None
+    sh = rs.randn(Cout).astype(np.float32) if bn else None
+    Ho, Wo = (H + 2 * pad - K) // stride + 1, (W + 2 * pad - K) // stride + 1
+    r = rs.randn(Ho, Wo, Cout).astype(np.float32) if res else None
+    out = np.empty((Ho, Wo, Cout), np.float32)
+    ffi.check(L.cald_op_conv2d(hip["ctx"], ffi.ptr(x), H, W, Cin, ffi.ptr(w), Cout, K, K, stride, pad, ffi.ptr(b), ffi.ptr(sc),
+                               ffi.ptr(sh), ffi.ptr(r), int(relu), ffi.ptr(out)))
+    wk = np.ascontiguousarray(w.transpose(2, 3, 1, 0).reshape(-1, Cout))
+    want = oracle.conv2d(x, wk, K, K, stride, pad, bias=b, bn=(sc, sh) if bn else None, residual=r, relu=relu)
+    assert out.tobytes() == want.tobytes(), "max abs diff %g" % float(np.abs(out - want).max())
+
+
+@pytest.fixture(scope="module")
+def small_model(hip, oracle):
+    from cald_amd import synth
+    sd = synth.pseudo_trained_frcnn(21, 50, seed=0)
+    model = hip["det"].fasterrcnn_resnet50_fpn_feature(num_classes=21, min_size=300, max_size=500)
+    model.to("cuda").load_state_dict(sd)
+    model.eval()
+    return model, oracle.prepare_frcnn(sd, 21, 50)
+
+
+def test_forward_stagewise_bit_exact(hip, oracle, small_model):
+    """Every stage of the detector forward, one view, against the oracle (first divergence is reported)."""
+    torch = hip["torch"]
+    from cald_amd import synth
+    model, P = small_model
+    img = synth.make_pool(3, "voc", 0, scale=0.5)[1]
+    rects = np.array([[20, 30, 60, 70], [100, 10, 130, 50]], np.int32)
+    for flip, rc in ((False, None), (True, None), (False, rects)):
+        keep = {}
+        want = oracle.frcnn_forward(P, img, 300, 500, flip=flip, rects=rc, keep=keep)
+        got = model.forward_views([(torch.from_numpy(img).cuda(), flip, rc)])[0]
+        stages = [("input", keep["input"]), ("conv1", keep["conv1"]), ("pool1", keep["pool1"])]
+        stages += [("C%d" % (i + 2), keep["C"][i]) for i in range(4)]
+        stages += [("P%d" % (i + 2), keep["fpn"][i]) for i in range(5)]
+        stages += [("rpn%d" % i, keep["rpn_head"][i]) for i in range(5)]
+        for name, w in stages:
+            g = model.debug_tensor(name, 0)
+            assert g.shape == w.shape, (name, g.shape, w.shape)
+            assert g.tobytes() == w.tobytes(), "stage %s differs: max abs %g" % (name, float(np.abs(g - w).max()))
+        n = keep["proposals"].shape[0]
+        gp = model.debug_tensor("proposals", 0).reshape(-1, 4)[:n]
+        assert gp.tobytes() == keep["proposals"].tobytes(), "proposals differ"
+        for name in ("roi", "fc7", "pred"):
+            g = model.debug_tensor(name, 0).reshape(1000, -1)[:n]
+            w = keep[name].reshape(n, -1)
+            assert g.tobytes() == w.tobytes(), "stage %s differs: max abs %g" % (name, float(np.abs(g - w).max()))
+        for k in ("boxes", "scores", "labels", "props", "prob_max", "scores_cls"):
+            assert got[k].cpu().numpy().tobytes() == want[k].tobytes(), "output %s differs" % k
+
+
+def test_sweep_matches_oracle(hip, oracle, small_model):
+    """cald_sweep (batched, ragged, 3 augmentations) == oracle get_uncertainty, bit for bit, and the
+    selection (argsort) is identical."""
+    torch = hip["torch"]
+    from cald_amd import synth, sweep
+    model, P = small_model
+    pool = synth.make_pool(6, "voc", 0, scale=0.5)
+    augs = ["flip", "cut_out", "smaller_resize"]
+    imgs = [torch.from_numpy(im).cuda() for im in pool]
+    cons, cls = sweep.sweep_device_images(model, imgs, list(range(len(pool))), augs, bp=1.3, base_seed=3, batch_images=4)
+    wc, wcls = oracle.get_uncertainty(P, pool, augs, 21, bp=1.3, min_size=300, max_size=500, base_seed=3)
+    np.testing.assert_array_equal(cons, np.array(wc))
+    np.testing.assert_array_equal(cls, np.stack(wcls))
+    np.testing.assert_array_equal(np.argsort(cons), np.argsort(np.array(wc)))
