@@ -44,7 +44,7 @@ def synth_image(index, H, W):
             mask = ((yy - cy) / (hh / 2)) ** 2 + ((xx - cx) / (ww / 2)) ** 2 < 1.0
         img[mask] = col
     img += (rs.rand(H, W, 3).astype(np.float32) - 0.5) * 0.04
-    return np.clip(img * 255.0, 0, 255).astype(np.uint8)
+    return np.ascontiguousarray(np.clip(img * 255.0, 0, 255).astype(np.uint8))
 
 
 def make_pool(n, kind="voc", seed=0, scale=1.0):
