@@ -1,0 +1,143 @@
+#!/usr/bin/env python
+"""bench.py -- CALD consistency sweep throughput on MI355X (unlabeled images scored / second).
+
+A "step" is one pass of the hot path (cald_sweep: reference view + 3 augmented views per image,
+detector forward x4, consistency scoring) over one batch of synthetic VOC-shaped images that are
+already resident in HBM.  Workload = BASELINE.json configs[1]: Faster R-CNN ResNet-50 FPN, 21
+classes, min/max size 600/1000, augmentations flip / cut_out / smaller_resize, seeded pseudo-trained
+weights (cald_amd/synth.py), float32 (exact fp32 MFMA).
+
+    python bench.py --gpus N --steps K --warmup W
+For N > 1 launch with torch.distributed.run (one rank per GPU, RCCL); the pool is sharded by position
+(no data-path collective) and one all-gather of the per-image scores closes the timed region.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
+
+
+def cpu_baseline(sd, pool, augs, budget_s=12.0, max_images=3):
+    """The reference-shaped PyTorch-CPU port (oracle/torch_port.py) on a bounded sample of the same workload."""
+    import torch
+    from oracle import torch_port
+    model = torch_port.TorchFRCNN(sd, 21, 50, 600, 1000)
+    model.forward(pool[0])          # warm-up view (oneDNN primitive creation), not timed
+    n, t0 = 0, time.time()
+    while n < max_images and (n == 0 or time.time() - t0 < budget_s):
+        torch_port.get_uncertainty(model, [pool[n]], augs, 21, bp=1.3, base_seed=0, positions=[n])
+        n += 1
+    dt = time.time() - t0
+    return {"value": n / dt, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d synthetic VOC-shaped image(s) x 4 views, batch-1 sequential torch-CPU fp32 forwards + python/scipy "
+                      "scoring loop (oracle/torch_port.py), %.1f s" % (n, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch-images", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback for the product path"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from cald_amd import _ffi, detector, synth, sweep
+    B, K, Wm = args.batch_images, args.steps, args.warmup
+    augs = ["flip", "cut_out", "smaller_resize"]
+    sd = synth.pseudo_trained_frcnn(21, 50, seed=0)
+    model = detector.fasterrcnn_resnet50_fpn_feature(num_classes=21, min_size=600, max_size=1000).to("cuda:%d" % local_rank)
+    model.load_state_dict(sd)
+    model.eval()
+
+    # distinct images per rank, resident in HBM before the timed region; rank r owns pool positions p % world == r
+    n_local = B * min(K + Wm, 4)
+    sizes = synth.pool_sizes(n_local * world, "voc", 0)
+    positions = [rank + world * i for i in range(n_local)]
+    host_pool = [synth.synth_image(p, *sizes[p]) for p in positions]
+    dev_pool = [torch.from_numpy(im).cuda() for im in host_pool]
+    torch.cuda.synchronize()
+
+    def step(s):
+        lo = (s * B) % n_local
+        idx = [(lo + j) % n_local for j in range(B)]
+        return sweep.sweep_device_images(model, [dev_pool[i] for i in idx], [positions[i] for i in idx], augs,
+                                         bp=1.3, base_seed=0, batch_images=B)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for s in range(Wm):
+        step(s)
+    L, ctx = _ffi.lib(), detector.get_ctx(local_rank)
+    _ffi.check(L.cald_profile_enable(ctx, 1))     # HIP events around every conv/linear launch on the launch stream
+    barrier()
+    t0 = time.time()
+    last = None
+    for s in range(K):
+        last = step(Wm + s)
+    if world > 1:   # the one RCCL all-gather of (position, consistency, cls_corr) rows
+        idx = [(((Wm + K - 1) * B) % n_local + j) % n_local for j in range(B)]
+        sweep.allgather_scores([positions[i] for i in idx], last[0], last[1], world * n_local)
+    barrier()
+    dt = time.time() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    import ctypes as C
+    gm, gf, tot = C.c_double(), C.c_double(), C.c_double()
+    nl = C.c_int64()
+    _ffi.check(L.cald_profile_read(ctx, C.byref(gm), C.byref(gf), C.byref(nl), C.byref(tot)))
+    _ffi.check(L.cald_profile_enable(ctx, 0))
+
+    if rank == 0:
+        images = world * K * B
+        achieved = gf.value / (gm.value * 1e-3) / 1e12 if gm.value > 0 else 0.0
+        out = {
+            "metric": "unlabeled images scored/sec (CALD consistency sweep)", "value": images / dt, "unit": "images/s",
+            "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": dt / K * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: Faster R-CNN ResNet-50 FPN, VOC2012-shaped synthetic pool, "
+                                   "3 augs (flip/cut_out/smaller_resize), 21 classes, min/max 600/1000, seeded pseudo-trained weights",
+                       "images_per_step_per_gpu": B, "views_per_image": 4, "parallelism": "pool sharded by position, dp%d" % world},
+            "roofline": {"bound": "mfma", "kernel": "conv_mfma_f32_kernel (implicit-GEMM conv + linear, v_mfma_f32_32x32x2_f32)",
+                         "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "launches": int(nl.value), "avg_launch_ms": gm.value / max(1, nl.value),
+                         "gemm_ms_per_step": gm.value / K, "algorithmic_gflop_per_launch": gf.value / max(1, nl.value) / 1e9},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sd, host_pool, augs)
+            out["cpu_baseline"]["host_cpus"] = os.cpu_count()
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -654,7 +654,6 @@ static int forward_frcnn(cald_model* m, int V, ViewDesc* views, const DetBuffers
     hipStream_t st = c->stream;
     int rc;
     m->dbg.clear();
-    if (c->prof && !c->tot_open) { HIPCHK(hipEventRecord(c->tot0, st)); c->tot_open = true; }
 
     // ---- transform + ResNet body (rows A14, A15) ----
     launch_preprocess(c->d_views, dp->seg[0], F.in0, V, max_pix0, st);
@@ -722,12 +721,6 @@ static int forward_frcnn(cald_model* m, int V, ViewDesc* views, const DetBuffers
     pa.det = det;
     launch_frcnn_postprocess(pa, st);
     HIPCHK(hipGetLastError());
-    if (c->prof) {
-        HIPCHK(hipEventRecord(c->tot1, st));
-        HIPCHK(hipEventSynchronize(c->tot1));
-        float t = 0.f; HIPCHK(hipEventElapsedTime(&t, c->tot0, c->tot1));
-        c->tot_ms += t; c->tot_open = false;
-    }
     return 0;
 }
 
