@@ -44,9 +44,9 @@ def cpu_baseline(sd, pool, augs, budget_s=12.0, max_images=3):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch-images", type=int, default=16)
+    ap.add_argument("--batch-images", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -73,7 +73,7 @@ def main():
     model.eval()
 
     # distinct images per rank, resident in HBM before the timed region; rank r owns pool positions p % world == r
-    n_local = B * min(K + Wm, 4)
+    n_local = B * min(K + Wm, 2)
     sizes = synth.pool_sizes(n_local * world, "voc", 0)
     positions = [rank + world * i for i in range(n_local)]
     host_pool = [synth.synth_image(p, *sizes[p]) for p in positions]
@@ -113,6 +113,8 @@ def main():
     gm, gf, tot = C.c_double(), C.c_double(), C.c_double()
     nl = C.c_int64()
     _ffi.check(L.cald_profile_read(ctx, C.byref(gm), C.byref(gf), C.byref(nl), C.byref(tot)))
+    if os.environ.get("CALD_PROFILE_DUMP"):
+        _ffi.check(L.cald_profile_dump(ctx, os.environ["CALD_PROFILE_DUMP"].encode()))
     _ffi.check(L.cald_profile_enable(ctx, 0))
 
     if rank == 0:

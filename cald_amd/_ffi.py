@@ -64,6 +64,7 @@ SIGNATURES = {
     "cald_debug_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, c_f, C.c_int64, c_i64]),
     "cald_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "cald_profile_read": (C.c_int, [C.c_void_p, c_d, c_d, c_i64, c_d]),
+    "cald_profile_dump": (C.c_int, [C.c_void_p, C.c_char_p]),
 }
 
 

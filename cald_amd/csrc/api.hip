@@ -45,6 +45,7 @@ struct cald_ctx {
     bool prof = false;
     std::vector<hipEvent_t> ev0, ev1;
     double prof_flops = 0.0;
+    std::vector<std::string> prof_desc; std::vector<double> prof_fl;
     hipEvent_t tot0 = nullptr, tot1 = nullptr; bool tot_open = false; double tot_ms = 0.0;
     std::map<std::pair<int, int>, PilCoef> pil;
 };
@@ -121,7 +122,7 @@ extern "C" int cald_profile_enable(cald_ctx* c, int on) {
     c->prof = on != 0;
     for (auto e : c->ev0) hipEventDestroy(e);
     for (auto e : c->ev1) hipEventDestroy(e);
-    c->ev0.clear(); c->ev1.clear(); c->prof_flops = 0.0; c->tot_ms = 0.0; c->tot_open = false;
+    c->ev0.clear(); c->ev1.clear(); c->prof_flops = 0.0; c->tot_ms = 0.0; c->tot_open = false; c->prof_desc.clear(); c->prof_fl.clear();
     if (on && !c->tot0) { HIPCHK(hipEventCreate(&c->tot0)); HIPCHK(hipEventCreate(&c->tot1)); }
     return 0;
 }
@@ -137,6 +138,20 @@ extern "C" int cald_profile_read(cald_ctx* c, double* gemm_ms, double* gemm_flop
     return 0;
 }
 
+extern "C" int cald_profile_dump(cald_ctx* c, const char* path) {
+    if (!c || !path) return fail(CALD_ERR_INVALID, "null argument");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    FILE* f = fopen(path, "w");
+    if (!f) return fail(CALD_ERR_INVALID, "cannot open %s", path);
+    fprintf(f, "launch,desc,gflop,ms,tflops\n");
+    for (size_t i = 0; i < c->ev0.size(); i++) {
+        float t = 0.f; hipEventElapsedTime(&t, c->ev0[i], c->ev1[i]);
+        fprintf(f, "%zu,\"%s\",%.3f,%.4f,%.2f\n", i, c->prof_desc[i].c_str(), c->prof_fl[i] / 1e9, t, c->prof_fl[i] / (t * 1e-3) / 1e12);
+    }
+    fclose(f);
+    return 0;
+}
+
 // conv launch with optional event bracketing
 static int run_conv(cald_ctx* c, const ConvArgs& a, double flops) {
     if (c->prof) {
@@ -146,6 +161,8 @@ static int run_conv(cald_ctx* c, const ConvArgs& a, double flops) {
         launch_conv(a, c->stream);
         HIPCHK(hipEventRecord(e1, c->stream));
         c->ev0.push_back(e0); c->ev1.push_back(e1); c->prof_flops += flops;
+        char d[160]; snprintf(d, sizeof(d), "mt=%d,Cin=%d,Cout=%d,k=%dx%d,s=%d", a.total_mtiles, a.Cin, a.Cout, a.KH, a.KW, a.stride);
+        c->prof_desc.push_back(d); c->prof_fl.push_back(flops);
     } else {
         launch_conv(a, c->stream);
     }
@@ -350,6 +367,7 @@ struct HostTensor { std::vector<float> data; std::vector<int64_t> shape; };
 struct ConvLayer {
     float *w = nullptr, *bias = nullptr, *scale = nullptr, *shift = nullptr;
     int Cin = 0, Cout = 0, CoutPad = 0, K = 0, Kpad = 0, KH = 1, KW = 1, stride = 1, pad = 0;
+    int CinTrue = 0;   // un-padded input channels (algorithmic FLOP accounting)
 };
 struct Bottleneck { ConvLayer c1, c2, c3, down; bool has_down = false; bool layer_end = false; };
 struct DebugEntry { const float* ptr; int level; int C; int kind; };  // kind 0: level tensor, 1: roi rows [cap][C]
@@ -424,7 +442,7 @@ static int make_conv(cald_model* m, ConvLayer& L, const std::vector<std::string>
     }
     int cinp = cin_pad_to > cin ? cin_pad_to : cin;
     if (cinp % 4) return fail(CALD_ERR_INVALID, "Cin must be a multiple of 4");
-    L.Cin = cinp; L.Cout = cout; L.CoutPad = cout_pad(cout); L.KH = kh; L.KW = kw; L.stride = stride; L.pad = pad;
+    L.Cin = cinp; L.CinTrue = cin; L.Cout = cout; L.CoutPad = cout_pad(cout); L.KH = kh; L.KW = kw; L.stride = stride; L.pad = pad;
     L.K = kh * kw * cinp; L.Kpad = round_up(L.K, 16);
     std::vector<float> w((size_t)L.Kpad * L.CoutPad, 0.0f);
     int co0 = 0;
@@ -576,7 +594,7 @@ static int conv_on(cald_model* m, const ConvLayer& L, const float* in, float* ou
     a.KH = L.KH; a.KW = L.KW; a.stride = L.stride; a.pad = L.pad; a.relu = relu ? 1 : 0;
     a.total_mtiles = level_tiles(m->plan, lout, V);
     a.out_ld = L.Cout;
-    double flops = 2.0 * (double)level_pix(m->plan, lout, V) * (double)L.Cout * (double)(L.KH * L.KW * L.Cin);
+    double flops = 2.0 * (double)level_pix(m->plan, lout, V) * (double)L.Cout * (double)(L.KH * L.KW * L.CinTrue);
     return run_conv(m->ctx, a, flops);
 }
 
@@ -887,7 +905,7 @@ extern "C" int cald_sweep(cald_model* m, int n_images, const uint8_t* const* ima
     HIPCHK(hipSetDevice(c->device));
     const int C = m->cfg.num_classes, cap = m->cfg.detections_per_img;
     const int A = (cfg->aug_flip ? 1 : 0) + (cfg->aug_cutout ? 1 : 0) + (cfg->aug_resize ? 1 : 0);
-    int B = cfg->batch_images > 0 ? cfg->batch_images : 16;
+    int B = cfg->batch_images > 0 ? cfg->batch_images : 64;
     if (B > CALD_MAX_VIEWS) B = CALD_MAX_VIEWS;
     const int VT = B * (1 + A);
     if (m->sweep_det_views < VT) {

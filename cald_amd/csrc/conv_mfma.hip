@@ -11,29 +11,44 @@
 //   Tile:       128 x BN x 16, 256 threads = 4 waves; each wave owns TM x TN 32x32 accumulators.
 //   LDS:        A staged k-major [16][130] (stride 130 makes the transposing ds_write_b32 of the
 //               im2col gather conflict-free), B [16][BN]; double buffered, one barrier per k-tile.
+//   Pipeline:   global loads of k-tile t+1 are issued (unconditionally, clamped address + select)
+//               before the MFMAs of tile t and land in registers while they run; LDS fragments of
+//               k-step s+1 are read while the MFMAs of step s issue.
+//   Mapping:    blocks that share an A tile (same M tile, different N tile) are placed on one XCD
+//               (block b runs on XCD b % 8) so the im2col gather is fetched into one L2 only.
 //   Epilogue:   (+bias) -> (*bn_scale, +bn_shift) -> (+residual) -> (+nearest-upsampled top-down)
-//               -> ReLU, fused; NHWC stores are 128 B contiguous per half-wave.
+//               -> ReLU, fused; residual rows are loaded as a batch before the stores.
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int WM, int WN, int TM, int TN>
-__global__ __launch_bounds__(256) void conv_mfma_f32_kernel(ConvArgs a) {
+template <int WM, int WN, int TM, int TN, int EPI>
+__global__ __launch_bounds__(256, 3) void conv_mfma_f32_kernel(const ConvArgs a) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, BK = 16;
     constexpr int SA = BM + 2;
     constexpr int SB = BN;
-    constexpr int PA = BM / 64;                       // float4 A loads per thread per k-tile
-    constexpr int B_F4 = BK * BN / 4;                 // float4 in one B tile
+    constexpr int B_F4 = BK * BN / 4;                 // float4 in one B tile: 512 / 256 / 128
     constexpr int PB = (B_F4 + 255) / 256;
-    static_assert(WM * WN == 4, "4 waves");
+    static_assert(WM * WN == 4 && BM == 128, "4 waves, 128-row tile");
     __shared__ __attribute__((aligned(16))) float smem[2 * BK * SA + 2 * BK * SB];
-    float* sA = smem;
-    float* sB = smem + 2 * BK * SA;
+    float* const sA = smem;
+    float* const sB = smem + 2 * BK * SA;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int NT = a.CoutPad / BN;
-    const int nt = blockIdx.x % NT, mt = blockIdx.x / NT;
+    // ---- XCD-aware block -> (M tile, N tile) map ----
+    int mt, nt;
+    {
+        const int b = blockIdx.x, MT = a.total_mtiles, MT8 = MT & ~7;
+        if (b < MT8 * NT) {
+            const int xcd = b & 7, idx = b >> 3;
+            mt = (idx / NT) * 8 + xcd; nt = idx % NT;
+        } else {
+            const int r = b - MT8 * NT;
+            mt = MT8 + r / NT; nt = r % NT;
+        }
+    }
     const int n0 = nt * BN;
 
     // ---- which view does this M tile belong to (wave-uniform scan of the plan) ----
@@ -43,71 +58,57 @@ __global__ __launch_bounds__(256) void conv_mfma_f32_kernel(ConvArgs a) {
     const LevelSeg si = a.seg_in[v];
     const int Ho = so.H, Wo = so.W, Hi = si.H, Wi = si.W;
     int Mv = Ho * Wo;
-    if (a.dyn_rows) { int d = a.dyn_rows[v]; Mv = d < Mv ? d : Mv; }
+    if (a.dyn_rows) { const int d = a.dyn_rows[v]; Mv = d < Mv ? d : Mv; }
     const int m0 = (mt - so.tile_start) * BM;
     if (m0 >= Mv) return;
-    const float* in_v = a.in + si.pix_off * (long long)a.Cin;
-    const int Cin = a.Cin, KW = a.KW, KH = a.KH;
+    const float* __restrict__ in_v = a.in + si.pix_off * (long long)a.Cin;
+    const float* __restrict__ wgt = a.w;
+    const int Cin = a.Cin, KW = a.KW, KH = a.KH, CoutPad = a.CoutPad;
 
-    // ---- per-thread A gather state: rows (tid>>2) + 64*p, k group g = tid&3 (4 consecutive k) ----
-    const int g = tid & 3;
-    int iy0[PA], ix0[PA];
-    bool rvalid[PA];
-#pragma unroll
-    for (int p = 0; p < PA; p++) {
-        int m = m0 + (tid >> 2) + 64 * p;
-        rvalid[p] = m < Mv;
-        int oy = m / Wo, ox = m - oy * Wo;
-        iy0[p] = oy * a.stride - a.pad;
-        ix0[p] = ox * a.stride - a.pad;
-    }
-    int ci = (4 * g) % Cin, tap = (4 * g) / Cin;
-    int kh = tap / KW, kw = tap - kh * KW;
+    // ---- per-thread A gather state: rows (tid>>2) and (tid>>2)+64, k group g = tid&3 ----
+    const int g = tid & 3, arow = tid >> 2;
+    const int mA0 = m0 + arow, mA1 = mA0 + 64;
+    const bool rv0 = mA0 < Mv, rv1 = mA1 < Mv;
+    const int oyA0 = mA0 / Wo, oxA0 = mA0 - oyA0 * Wo;
+    const int oyA1 = mA1 / Wo, oxA1 = mA1 - oyA1 * Wo;
+    const int iy00 = oyA0 * a.stride - a.pad, ix00 = oxA0 * a.stride - a.pad;
+    const int iy01 = oyA1 * a.stride - a.pad, ix01 = oxA1 * a.stride - a.pad;
+    int ci = (4 * g) % Cin;
+    int kh, kw;
+    { const int tap = (4 * g) / Cin; kh = tap / KW; kw = tap - kh * KW; }
+    // B tile mapping
+    const int bk0 = tid / (BN / 4), bc0 = tid % (BN / 4);            // first float4
+    const int bk1 = (tid + 256) / (BN / 4), bc1 = (tid + 256) % (BN / 4);
+    const bool b0ok = (B_F4 >= 256) || (tid < B_F4);
 
-    float4 ra[PA], rb[PB];
+    float4 ra0, ra1, rb0, rb1;
     const int KT = a.Kpad / BK;
 
-    auto load_tile = [&](int kt) {
-#pragma unroll
-        for (int p = 0; p < PA; p++) {
-            int iy = iy0[p] + kh, ix = ix0[p] + kw;
-            bool ok = rvalid[p] && kh < KH && iy >= 0 && iy < Hi && ix >= 0 && ix < Wi;
-            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok) val = *reinterpret_cast<const float4*>(in_v + ((long long)(iy * Wi + ix) * Cin + ci));
-            ra[p] = val;
-        }
-#pragma unroll
-        for (int p = 0; p < PB; p++) {
-            int f = tid + 256 * p;
-            if (B_F4 >= 256 || f < B_F4) {
-                int krow = f / (BN / 4), c4 = f % (BN / 4);
-                rb[p] = *reinterpret_cast<const float4*>(a.w + (long long)(kt * BK + krow) * a.CoutPad + n0 + 4 * c4);
-            }
-        }
-        // advance the (kh, kw, ci) cursor by one k-tile
-        ci += BK;
-        while (ci >= Cin) { ci -= Cin; kw++; if (kw == KW) { kw = 0; kh++; } }
-    };
-    auto store_tile = [&](int buf) {
-        float* dA = sA + buf * BK * SA;
-        float* dB = sB + buf * BK * SB;
-#pragma unroll
-        for (int p = 0; p < PA; p++) {
-            int r = (tid >> 2) + 64 * p;
-            dA[(4 * g + 0) * SA + r] = ra[p].x;
-            dA[(4 * g + 1) * SA + r] = ra[p].y;
-            dA[(4 * g + 2) * SA + r] = ra[p].z;
-            dA[(4 * g + 3) * SA + r] = ra[p].w;
-        }
-#pragma unroll
-        for (int p = 0; p < PB; p++) {
-            int f = tid + 256 * p;
-            if (B_F4 >= 256 || f < B_F4) {
-                int krow = f / (BN / 4), c4 = f % (BN / 4);
-                *reinterpret_cast<float4*>(dB + krow * SB + 4 * c4) = rb[p];
-            }
-        }
-    };
+#define LOAD_TILE(KTI)                                                                                     \
+    {                                                                                                      \
+        const int iy0 = iy00 + kh, ix0 = ix00 + kw, iy1 = iy01 + kh, ix1 = ix01 + kw;                      \
+        const bool ok0 = rv0 && kh < KH && iy0 >= 0 && iy0 < Hi && ix0 >= 0 && ix0 < Wi;                   \
+        const bool ok1 = rv1 && kh < KH && iy1 >= 0 && iy1 < Hi && ix1 >= 0 && ix1 < Wi;                   \
+        const long long o0 = ok0 ? ((long long)(iy0 * Wi + ix0) * Cin + ci) : 0ll;                         \
+        const long long o1 = ok1 ? ((long long)(iy1 * Wi + ix1) * Cin + ci) : 0ll;                         \
+        const float4 t0 = *reinterpret_cast<const float4*>(in_v + o0);                                     \
+        const float4 t1 = *reinterpret_cast<const float4*>(in_v + o1);                                     \
+        ra0.x = ok0 ? t0.x : 0.0f; ra0.y = ok0 ? t0.y : 0.0f; ra0.z = ok0 ? t0.z : 0.0f; ra0.w = ok0 ? t0.w : 0.0f; \
+        ra1.x = ok1 ? t1.x : 0.0f; ra1.y = ok1 ? t1.y : 0.0f; ra1.z = ok1 ? t1.z : 0.0f; ra1.w = ok1 ? t1.w : 0.0f; \
+        if (b0ok) rb0 = *reinterpret_cast<const float4*>(wgt + (long long)((KTI) * BK + bk0) * CoutPad + n0 + 4 * bc0); \
+        if (PB > 1) rb1 = *reinterpret_cast<const float4*>(wgt + (long long)((KTI) * BK + bk1) * CoutPad + n0 + 4 * bc1); \
+        ci += BK;                                                                                          \
+        while (ci >= Cin) { ci -= Cin; kw++; if (kw == KW) { kw = 0; kh++; } }                             \
+    }
+#define STORE_TILE(BUF)                                                                                    \
+    {                                                                                                      \
+        float* dA = sA + (BUF) * BK * SA + (4 * g) * SA + arow;                                            \
+        dA[0] = ra0.x; dA[SA] = ra0.y; dA[2 * SA] = ra0.z; dA[3 * SA] = ra0.w;                             \
+        dA[64] = ra1.x; dA[SA + 64] = ra1.y; dA[2 * SA + 64] = ra1.z; dA[3 * SA + 64] = ra1.w;             \
+        float* dB = sB + (BUF) * BK * SB;                                                                  \
+        if (b0ok) *reinterpret_cast<float4*>(dB + bk0 * SB + 4 * bc0) = rb0;                               \
+        if (PB > 1) *reinterpret_cast<float4*>(dB + bk1 * SB + 4 * bc1) = rb1;                             \
+    }
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -117,87 +118,111 @@ __global__ __launch_bounds__(256) void conv_mfma_f32_kernel(ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
 
-    load_tile(0);
-    store_tile(0);
+    LOAD_TILE(0);
+    STORE_TILE(0);
     __syncthreads();
     const int kh_lane = lane >> 5, l31 = lane & 31;
     for (int kt = 0; kt < KT; kt++) {
         const int buf = kt & 1;
-        if (kt + 1 < KT) load_tile(kt + 1);
-        const float* cA = sA + buf * BK * SA + wm * TM * 32 + l31;
-        const float* cB = sB + buf * BK * SB + wn * TN * 32 + l31;
+        const bool more = kt + 1 < KT;
+        if (more) LOAD_TILE(kt + 1);
+        const float* cA = sA + buf * BK * SA + kh_lane * SA + wm * TM * 32 + l31;
+        const float* cB = sB + buf * BK * SB + kh_lane * SB + wn * TN * 32 + l31;
+        float av[2][TM], bv[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; i++) av[0][i] = cA[i * 32];
+#pragma unroll
+        for (int j = 0; j < TN; j++) bv[0][j] = cB[j * 32];
 #pragma unroll
         for (int ks = 0; ks < BK / 2; ks++) {
-            float av[TM], bv[TN];
+            const int cur = ks & 1, nxt = cur ^ 1;
+            if (ks + 1 < BK / 2) {
 #pragma unroll
-            for (int i = 0; i < TM; i++) av[i] = cA[(2 * ks + kh_lane) * SA + i * 32];
+                for (int i = 0; i < TM; i++) av[nxt][i] = cA[(2 * ks + 2) * SA + i * 32];
 #pragma unroll
-            for (int j = 0; j < TN; j++) bv[j] = cB[(2 * ks + kh_lane) * SB + j * 32];
+                for (int j = 0; j < TN; j++) bv[nxt][j] = cB[(2 * ks + 2) * SB + j * 32];
+            }
 #pragma unroll
             for (int i = 0; i < TM; i++)
 #pragma unroll
                 for (int j = 0; j < TN; j++)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i], bv[cur][j], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < KT) store_tile(buf ^ 1);
+        if (more) STORE_TILE(buf ^ 1);
         __syncthreads();
     }
+#undef LOAD_TILE
+#undef STORE_TILE
 
-    // ---- fused epilogue ----
-    float* out_v = a.out + so.pix_off * (long long)a.out_ld;
-    const float* res_v = a.residual ? a.residual + so.pix_off * (long long)a.out_ld : nullptr;
-    const float* up_v = nullptr;
-    int upH = 0, upW = 0;
+    // ---- fused epilogue (EPI: 0 = plain, 1 = +residual, 2 = +nearest-upsampled top-down) ----
+    // bias / FrozenBN are applied unconditionally with neutral constants when absent: acc is never
+    // -0.0 (the chain starts from +0), so x + 0.0f and x * 1.0f + 0.0f are exact identities.
+    const int out_ld = a.out_ld;
+    float* __restrict__ out_v = a.out + so.pix_off * (long long)out_ld;
+    const float* __restrict__ ex_v = nullptr;
+    int upH = 1, upW = 1;
     float uph_s = 0.f, upw_s = 0.f;
-    if (a.up) {
+    if (EPI == 1) ex_v = a.residual + so.pix_off * (long long)out_ld;
+    if (EPI == 2) {
         const LevelSeg su = a.seg_up[v];
-        up_v = a.up + su.pix_off * (long long)a.out_ld;
+        ex_v = a.up + su.pix_off * (long long)out_ld;
         upH = su.H; upW = su.W;
         uph_s = (float)upH / (float)Ho; upw_s = (float)upW / (float)Wo;
     }
+    const bool relu = a.relu != 0;
+    const int Mlast = Mv - 1;
 #pragma unroll
     for (int j = 0; j < TN; j++) {
         const int n = n0 + wn * TN * 32 + j * 32 + l31;
         const bool nok = n < a.Cout;
-        const float bs = (a.bias && nok) ? a.bias[n] : 0.0f;
-        const float sc = (a.scale && nok) ? a.scale[n] : 1.0f;
-        const float sh = (a.shift && nok) ? a.shift[n] : 0.0f;
+        const int nc = nok ? n : 0;
+        const float bs = a.bias ? a.bias[nc] : 0.0f;
+        const float sc = a.scale ? a.scale[nc] : 1.0f;
+        const float sh = a.scale ? a.shift[nc] : 0.0f;
 #pragma unroll
         for (int i = 0; i < TM; i++) {
+            const int mbase = m0 + wm * TM * 32 + i * 32 + 4 * kh_lane;
+            float extra[16];
+            if (EPI != 0) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) {   // all 16 loads of this 32x32 tile in flight together
+                    int m = mbase + (r & 3) + 8 * (r >> 2);
+                    m = m < Mlast ? m : Mlast;
+                    if (EPI == 1) {
+                        extra[r] = ex_v[(long long)m * out_ld + nc];
+                    } else {
+                        const int oy = m / Wo, ox = m - oy * Wo;
+                        int sy = (int)floorf((float)oy * uph_s); sy = sy > upH - 1 ? upH - 1 : sy;
+                        int sx = (int)floorf((float)ox * upw_s); sx = sx > upW - 1 ? upW - 1 : sx;
+                        extra[r] = ex_v[(long long)(sy * upW + sx) * out_ld + nc];
+                    }
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * kh_lane;
-                const int m = m0 + wm * TM * 32 + i * 32 + row;
-                if (m < Mv && nok) {
-                    float val = acc[i][j][r];
-                    if (a.bias) val = val + bs;
-                    if (a.scale) { val = val * sc; val = val + sh; }
-                    const long long o = (long long)m * a.out_ld + n;
-                    if (res_v) val = val + res_v[o];
-                    if (up_v) {
-                        int oy = m / Wo, ox = m - oy * Wo;
-                        int sy = (int)floorf((float)oy * uph_s); if (sy > upH - 1) sy = upH - 1;
-                        int sx = (int)floorf((float)ox * upw_s); if (sx > upW - 1) sx = upW - 1;
-                        val = val + up_v[(long long)(sy * upW + sx) * a.out_ld + n];
-                    }
-                    if (a.relu) val = val > 0.0f ? val : 0.0f;
-                    out_v[o] = val;
-                }
+                const int m = mbase + (r & 3) + 8 * (r >> 2);
+                float val = acc[i][j][r];
+                val = val + bs;
+                val = val * sc;
+                val = val + sh;
+                if (EPI != 0) val = val + extra[r];
+                if (relu) val = val > 0.0f ? val : 0.0f;
+                if (m < Mv && nok) out_v[(long long)m * out_ld + n] = val;
             }
         }
     }
 }
 
+template <int WM, int WN, int TM, int TN>
+static void launch_cfg(const ConvArgs& a, int bn, hipStream_t stream) {
+    dim3 grid((unsigned)(a.total_mtiles * (a.CoutPad / bn))), block(256);
+    if (a.residual) hipLaunchKernelGGL((conv_mfma_f32_kernel<WM, WN, TM, TN, 1>), grid, block, 0, stream, a);
+    else if (a.up) hipLaunchKernelGGL((conv_mfma_f32_kernel<WM, WN, TM, TN, 2>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((conv_mfma_f32_kernel<WM, WN, TM, TN, 0>), grid, block, 0, stream, a);
+}
+
 void launch_conv(const ConvArgs& a, hipStream_t stream) {
-    dim3 block(256);
-    if (a.CoutPad % 128 == 0) {
-        dim3 grid((unsigned)(a.total_mtiles * (a.CoutPad / 128)));
-        hipLaunchKernelGGL((conv_mfma_f32_kernel<2, 2, 2, 2>), grid, block, 0, stream, a);
-    } else if (a.CoutPad % 64 == 0) {
-        dim3 grid((unsigned)(a.total_mtiles * (a.CoutPad / 64)));
-        hipLaunchKernelGGL((conv_mfma_f32_kernel<2, 2, 2, 1>), grid, block, 0, stream, a);
-    } else {
-        dim3 grid((unsigned)(a.total_mtiles * (a.CoutPad / 32)));
-        hipLaunchKernelGGL((conv_mfma_f32_kernel<4, 1, 1, 1>), grid, block, 0, stream, a);
-    }
+    if (a.CoutPad % 128 == 0) launch_cfg<2, 2, 2, 2>(a, 128, stream);
+    else if (a.CoutPad % 64 == 0) launch_cfg<2, 2, 2, 1>(a, 64, stream);
+    else launch_cfg<4, 1, 1, 1>(a, 32, stream);
 }

@@ -30,7 +30,7 @@ def _to_u8_cuda(image, device):
     return t.contiguous().to(device, non_blocking=True)
 
 
-def sweep_device_images(task_model, images, positions, augs, bp=1.3, base_seed=0, batch_images=16):
+def sweep_device_images(task_model, images, positions, augs, bp=1.3, base_seed=0, batch_images=64):
     """Scores uint8 HWC CUDA tensors already resident in HBM.  Returns (consistency [n] f64, cls_corr [n][C-1] f64)."""
     for aug in augs:
         if aug not in KNOWN_AUGS:
@@ -84,7 +84,7 @@ def allgather_scores(local_pos, cons, cls, pool_size, group=None):
 
 
 def get_uncertainty(task_model, unlabeled_loader, augs, num_cls, bp=1.3, base_seed=0, rank=0, world_size=1,
-                    batch_images=16, group=None):
+                    batch_images=64, group=None):
     """Drop-in for cald_train.py:91 (same positional signature)."""
     task_model.eval()
     dev = torch.device("cuda", torch.cuda.current_device())

@@ -100,7 +100,7 @@ typedef struct cald_sweep_cfg {
     float resize_ratio;    /* 0.8 */
     uint64_t base_seed;
     float bp;              /* args.bp, 1.3 */
-    int batch_images;      /* images per batched launch sequence (0 = default 16) */
+    int batch_images;      /* images per batched launch sequence (0 = default 64, max 64) */
 } cald_sweep_cfg;
 int cald_sweep(cald_model* m, int n_images, const uint8_t* const* images_dev, const int* H, const int* W,
                const int64_t* pool_pos, const cald_sweep_cfg* cfg, double* consistency_out, double* cls_corr_out);
@@ -129,6 +129,8 @@ int cald_debug_tensor(cald_model* m, const char* name, int view, float* host_out
 /* ---- measurement: HIP-event timing of every conv/linear launch on the context stream ---- */
 int cald_profile_enable(cald_ctx* ctx, int on);
 int cald_profile_read(cald_ctx* ctx, double* gemm_ms, double* gemm_flops, int64_t* gemm_launches, double* total_ms);
+/* per-launch CSV (shape, algorithmic GFLOP, ms, TFLOP/s) of the launches recorded since cald_profile_enable */
+int cald_profile_dump(cald_ctx* ctx, const char* path);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,157 @@
+"""CPU-only tests: C-ABI surface, host-side logic of the product, selection stage, the sharded
+all-gather (gloo, world_size 2) and the oracle's float cross-checks against plain torch fp32."""
+import ctypes as C
+import os
+import re
+import socket
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    hdr = open(os.path.join(ROOT, "include", "cald_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(cald_[a-z_0-9]+)\s*\(", hdr)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from cald_amd import _ffi
+    L = _ffi.lib()
+    names = _header_functions()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(L, n), "libcaldhip.so does not export %s" % n
+    assert sorted(_ffi.SIGNATURES) == names, "cald_amd/_ffi.py must bind exactly the symbols of include/cald_hip.h"
+    assert L.cald_version() >= 100
+
+
+def test_product_never_touches_the_oracle():
+    for dp, _, files in os.walk(os.path.join(ROOT, "cald_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", txt, flags=re.M), f
+                assert "cald_oracle" not in txt and "#include \"../../oracle" not in txt, f
+
+
+def test_compute_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from cald_amd import detector
+    with pytest.raises(RuntimeError):
+        detector.get_ctx()
+
+
+def test_host_cutout_and_transform_size_match_oracle_and_reference(oracle, golden):
+    from cald_amd import _ffi
+    L = _ffi.lib()
+    g = golden("helpers")
+    for i in range(4):
+        img, boxes = g["img%d" % i], np.ascontiguousarray(g["boxes%d" % i], np.float32)
+        H, W, _ = img.shape
+        for s in (11, 12, 13):
+            rects = np.zeros(16, np.int32); n = C.c_int()
+            _ffi.check(L.cald_op_cutout_rects(s, H, W, boxes.shape[0], _ffi.ptr(boxes), 2, _ffi.ptr(rects, _ffi.c_i), C.byref(n)))
+            got = img.copy()
+            for (l, t, r, b) in rects[:4 * n.value].reshape(-1, 4):
+                got[t:b, l:r] = 0
+            np.testing.assert_array_equal(got, g["cutout%d_%d_img" % (i, s)])      # the reference's own output
+    for (H, W) in [(375, 500), (500, 375), (333, 500), (500, 334), (480, 640), (427, 640), (100, 3000), (31, 37)]:
+        for (mn, mx) in [(600, 1000), (800, 1333)]:
+            v = [C.c_int() for _ in range(4)]
+            _ffi.check(L.cald_op_transform_size(H, W, mn, mx, *[C.byref(x) for x in v]))
+            assert tuple(x.value for x in v) == oracle.transform_size(H, W, mn, mx)
+    assert L.cald_op_transform_size(0, 5, 600, 1000, *[C.byref(C.c_int()) for _ in range(4)]) != 0
+    assert b"bad sizes" in L.cald_last_error()
+
+
+def test_selection_matches_reference_golden(golden):
+    from cald_amd import sweep
+    import torch
+    g = golden("selection")
+    for case in range(4):
+        cls_corrs = g["cls_corrs%d" % case]
+        labels = g["labels%d" % case]
+        loader = [(None, [{"labels": torch.from_numpy(row[row >= 0])}]) for row in labels]
+        sel = sweep.cls_kldiv(loader, list(cls_corrs), int(g["budget%d" % case]), 0, uniform=bool(g["uniform%d" % case]))
+        np.testing.assert_array_equal(np.array(sel), g["sel%d" % case])
+    np.testing.assert_array_equal(np.argsort(g["argsort_in"]), g["argsort_out"])
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _gather_worker(rank, world, port, pool_size, q):
+    import torch.distributed as dist
+    from cald_amd import sweep
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    pos = [p for p in range(pool_size) if p % world == rank]
+    cons = np.array([0.25 + p * 0.5 for p in pos], np.float64)
+    cls = np.stack([np.arange(20, dtype=np.float64) * 0.01 + p for p in pos]) if pos else np.zeros((0, 20))
+    fc, fcl = sweep.allgather_scores(pos, cons, cls, pool_size)
+    q.put((rank, fc, fcl))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("pool_size", [7, 8, 1])
+def test_sharded_allgather_is_rank_count_invariant(pool_size):
+    """world_size-2 gloo run of the N>1 path: every rank ends with the full, correctly ordered vectors."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, pool_size, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    want_c = np.array([0.25 + p * 0.5 for p in range(pool_size)])
+    want_cls = np.stack([np.arange(20, dtype=np.float64) * 0.01 + p for p in range(pool_size)])
+    for _, fc, fcl in res:
+        np.testing.assert_array_equal(fc, want_c)
+        np.testing.assert_array_equal(fcl, want_cls)
+
+
+def test_oracle_conv_chain_vs_torch_fp32(oracle):
+    import torch
+    import torch.nn.functional as F
+    rs = np.random.RandomState(0)
+    for (H, W, Cin, Cout, K, stride, pad) in [(23, 31, 4, 64, 7, 2, 3), (20, 26, 64, 64, 3, 1, 1), (20, 26, 128, 128, 3, 2, 1),
+                                              (17, 19, 256, 512, 1, 2, 0), (9, 11, 256, 15, 1, 1, 0)]:
+        x = rs.randn(H, W, Cin).astype(np.float32)
+        w = (rs.randn(Cout, Cin, K, K) * np.sqrt(2.0 / (Cin * K * K))).astype(np.float32)
+        b = rs.randn(Cout).astype(np.float32)
+        wk = np.ascontiguousarray(w.transpose(2, 3, 1, 0).reshape(-1, Cout))
+        got = oracle.conv2d(x, wk, K, K, stride, pad, bias=b, relu=True)
+        want = F.relu(F.conv2d(torch.from_numpy(x).permute(2, 0, 1)[None], torch.from_numpy(w), torch.from_numpy(b), stride, pad))
+        np.testing.assert_allclose(got, want[0].permute(1, 2, 0).numpy(), rtol=1e-4, atol=1e-4)   # tolerance of BASELINE.json
+    x = rs.randn(11, 13, 64).astype(np.float32)
+    np.testing.assert_array_equal(oracle.maxpool3x3s2(x), F.max_pool2d(torch.from_numpy(x).permute(2, 0, 1)[None], 3, 2, 1)[0].permute(1, 2, 0).numpy())
+
+
+def test_oracle_detector_vs_torch_port_small(oracle):
+    """The C oracle's full forward against the plain-torch fp32 port (float tolerance 1e-4; same detections)."""
+    from cald_amd import synth
+    from oracle import torch_port
+    sd = synth.pseudo_trained_frcnn(21, 50, seed=0)
+    P = oracle.prepare_frcnn(sd, 21, 50)
+    tm = torch_port.TorchFRCNN(sd, 21, 50, 160, 256)
+    img = synth.make_pool(2, "voc", 0, scale=0.3)[1]
+    k1, k2 = {}, {}
+    a = tm.forward(img, keep=k1)
+    b = oracle.frcnn_forward(P, img, 160, 256, keep=k2)
+    np.testing.assert_allclose(k1["input"][..., :3], k2["input"][..., :3], atol=1e-5)
+    for i in range(5):
+        scale = float(np.abs(k2["fpn"][i]).max())
+        assert float(np.abs(k1["fpn"][i] - k2["fpn"][i]).max()) <= 1e-4 * max(1.0, scale)
+    assert a["boxes"].shape == b["boxes"].shape
+    np.testing.assert_allclose(a["scores"], b["scores"], atol=1e-4)
+    np.testing.assert_array_equal(a["labels"], b["labels"])
+    np.testing.assert_allclose(a["boxes"], b["boxes"], atol=2e-2)
