@@ -118,6 +118,15 @@ def main():
     _ffi.check(L.cald_profile_enable(ctx, 0))
 
     if rank == 0:
+        # HBM bytes per GEMM launch from the rocprofv3 PMC passes of this same command (tools/profile_gpu.sh ->
+        # tools/summarize_profile.py -> profiles/*_pmc.json; FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, KB units)
+        traffic = None
+        try:
+            cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc.json"))
+            if cands:
+                traffic = json.load(open(os.path.join(ROOT, "profiles", cands[-1])))["conv_mfma"]["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
         images = world * K * B
         achieved = gf.value / (gm.value * 1e-3) / 1e12 if gm.value > 0 else 0.0
         out = {
@@ -129,7 +138,7 @@ def main():
                        "images_per_step_per_gpu": B, "views_per_image": 4, "parallelism": "pool sharded by position, dp%d" % world},
             "roofline": {"bound": "mfma", "kernel": "conv_mfma_f32_kernel (implicit-GEMM conv + linear, v_mfma_f32_32x32x2_f32)",
                          "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
                          "launches": int(nl.value), "avg_launch_ms": gm.value / max(1, nl.value),
                          "gemm_ms_per_step": gm.value / K, "algorithmic_gflop_per_launch": gf.value / max(1, nl.value) / 1e9},
         }

@@ -1,0 +1,54 @@
+#!/usr/bin/env python
+"""Condenses gpurun_out/prof_<tag>/ (rocprofv3 CSVs) into profiles/<tag>_*.{csv,json} (tracked)."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+tag = sys.argv[1]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", "prof_" + tag)
+dst = os.path.join(root, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+
+def find(pattern):
+    g = glob.glob(os.path.join(src, pattern), recursive=True)
+    return g[0] if g else None
+
+
+stats = find("stats/**/*kernel_stats.csv")
+if stats:
+    rows = list(csv.DictReader(open(stats)))
+    with open(os.path.join(dst, "%s_kernel_stats.csv" % tag), "w") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+        for r in rows:
+            w.writerow([r["Name"], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
+    print("kernel stats ->", os.path.join(dst, "%s_kernel_stats.csv" % tag))
+
+summary = {}
+for key, pat in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write"), ("MFMA", "pmc_mfma")):
+    f = find(pat + "/**/*counter_collection.csv")
+    if not f:
+        continue
+    agg = defaultdict(lambda: defaultdict(float)); cnt = defaultdict(lambda: defaultdict(int))
+    for r in csv.DictReader(open(f)):
+        name = r["Kernel_Name"].split("(")[0]
+        agg[name][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[name][r["Counter_Name"]] += 1
+    for name in agg:
+        for c in agg[name]:
+            summary.setdefault(name, {})[c] = {"sum": agg[name][c], "dispatches": cnt[name][c], "avg": agg[name][c] / cnt[name][c]}
+if summary:
+    conv = {k: v for k, v in summary.items() if "conv_mfma" in k}
+    tot_f = sum(v.get("FETCH_SIZE", {}).get("sum", 0) for v in conv.values())
+    tot_w = sum(v.get("WRITE_SIZE", {}).get("sum", 0) for v in conv.values())
+    n = sum(v.get("FETCH_SIZE", {}).get("dispatches", 0) for v in conv.values())
+    out = {"per_kernel": summary,
+           "conv_mfma": {"dispatches": n, "FETCH_SIZE_KB_sum": tot_f, "WRITE_SIZE_KB_sum": tot_w,
+                         # MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports 1/2 of wide coalesced reads -> x2; unit KB
+                         "hbm_bytes_per_launch": ((2.0 * tot_f + tot_w) * 1024.0 / n) if n else None}}
+    json.dump(out, open(os.path.join(dst, "%s_pmc.json" % tag), "w"), indent=1)
+    print("pmc ->", os.path.join(dst, "%s_pmc.json" % tag), out["conv_mfma"])
