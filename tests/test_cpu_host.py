@@ -155,3 +155,19 @@ def test_oracle_detector_vs_torch_port_small(oracle):
     np.testing.assert_allclose(a["scores"], b["scores"], atol=1e-4)
     np.testing.assert_array_equal(a["labels"], b["labels"])
     np.testing.assert_allclose(a["boxes"], b["boxes"], atol=2e-2)
+
+
+def test_helper_api_mirror_matches_reference_golden(golden):
+    """cald_amd.cald_helper keeps the reference's helper names/signatures (CPU-computable parts)."""
+    import torch
+    from cald_amd import cald_helper as ch
+    g = golden("helpers")
+    for i in range(4):
+        img, boxes = g["img%d" % i], torch.from_numpy(g["boxes%d" % i])
+        fi, fb = ch.HorizontalFlip(torch.from_numpy(img), boxes)
+        np.testing.assert_array_equal(fb.numpy(), g["flip_boxes%d" % i])
+        np.testing.assert_array_equal((fi * 255).round().to(torch.uint8).permute(1, 2, 0).numpy(), g["flip_img%d" % i])
+        np.testing.assert_array_equal(ch.intersect(boxes, torch.from_numpy(g["boxes_b%d" % i])).numpy(), g["intersect%d" % i])
+        for s in (11, 12, 13):
+            ci = ch.cutout(torch.from_numpy(img), boxes, None, 2, seed=s)
+            np.testing.assert_array_equal((ci * 255).round().to(torch.uint8).permute(1, 2, 0).numpy(), g["cutout%d_%d_img" % (i, s)])
