@@ -379,6 +379,8 @@ struct cald_model {
     bool finalized = false;
     ConvLayer conv1; std::vector<Bottleneck> blocks;
     ConvLayer fpn_inner[4], fpn_layer[4], rpn_conv, rpn_head, fc6, fc7, pred;
+    ConvLayer p6, p7, cls_tower[4], reg_tower[4], cls_out, reg_out;   // RetinaNet
+    int det_cap() const { return cfg.arch == CALD_ARCH_RETINANET ? cfg.num_classes * cfg.detections_per_img : cfg.detections_per_img; }
     float* d_anchors = nullptr;
     std::vector<void*> owned;
     std::map<std::string, DebugEntry> dbg;
@@ -393,7 +395,7 @@ static int cout_pad(int cout) { return cout >= 128 ? round_up(cout, 128) : (cout
 
 extern "C" int cald_model_create(cald_ctx* ctx, const cald_model_cfg* cfg, cald_model** out) {
     if (!ctx || !cfg || !out) return fail(CALD_ERR_INVALID, "null argument");
-    if (cfg->arch != CALD_ARCH_FRCNN) return fail(CALD_ERR_INVALID, "arch %d not supported by this build (FRCNN only)", cfg->arch);
+    if (cfg->arch != CALD_ARCH_FRCNN && cfg->arch != CALD_ARCH_RETINANET) return fail(CALD_ERR_INVALID, "unknown arch %d", cfg->arch);
     if (cfg->depth != 50 && cfg->depth != 101) return fail(CALD_ERR_INVALID, "depth must be 50 or 101");
     if (cfg->num_classes < 2 || cfg->num_classes > 256) return fail(CALD_ERR_INVALID, "num_classes out of range");
     if (cfg->rpn_pre_nms_top_n > 1024 || cfg->rpn_post_nms_top_n > CALD_ROI_CAP || cfg->rpn_pre_nms_top_n < 1 || cfg->rpn_post_nms_top_n < 1)
@@ -500,42 +502,82 @@ extern "C" int cald_model_finalize(cald_model* m) {
             B.layer_end = (bi == nb[li] - 1);
             m->blocks.push_back(B);
         }
+    const bool retina = m->cfg.arch == CALD_ARCH_RETINANET;
+    if (!retina) {
     for (int i = 0; i < 4; i++) {
-        char k[128];
-        snprintf(k, sizeof(k), "backbone.fpn.inner_blocks.%d", i);
-        if ((rc = make_conv(m, m->fpn_inner[i], {std::string(k) + ".weight"}, {std::string(k) + ".bias"}, "", 1, 0))) return rc;
-        snprintf(k, sizeof(k), "backbone.fpn.layer_blocks.%d", i);
-        if ((rc = make_conv(m, m->fpn_layer[i], {std::string(k) + ".weight"}, {std::string(k) + ".bias"}, "", 1, 1))) return rc;
-    }
-    if ((rc = make_conv(m, m->rpn_conv, {"rpn.head.conv.weight"}, {"rpn.head.conv.bias"}, "", 1, 1))) return rc;
-    if ((rc = make_conv(m, m->rpn_head, {"rpn.head.cls_logits.weight", "rpn.head.bbox_pred.weight"},
-                        {"rpn.head.cls_logits.bias", "rpn.head.bbox_pred.bias"}, "", 1, 0))) return rc;
-    {   // fc6: torch K order is (c, bin); the RoIAlign kernel writes (bin, c) -> permute the weight's K axis
-        const HostTensor* t; if ((rc = get_t(m, "roi_heads.box_head.fc6.weight", &t))) return rc;
-        if (t->shape.size() != 2 || t->shape[1] != 256 * 49) return fail(CALD_ERR_INVALID, "fc6 weight must be [N][12544]");
-        HostTensor p; p.shape = {t->shape[0], t->shape[1]}; p.data.resize(t->data.size());
-        int N = (int)t->shape[0];
-        for (int n = 0; n < N; n++)
-            for (int c = 0; c < 256; c++)
-                for (int b = 0; b < 49; b++) p.data[(size_t)n * 12544 + b * 256 + c] = t->data[(size_t)n * 12544 + c * 49 + b];
-        m->sd["__fc6_perm"] = std::move(p);
-        if ((rc = make_conv(m, m->fc6, {"__fc6_perm"}, {"roi_heads.box_head.fc6.bias"}, "", 1, 0))) return rc;
-        m->sd.erase("__fc6_perm");
-    }
-    if ((rc = make_conv(m, m->fc7, {"roi_heads.box_head.fc7.weight"}, {"roi_heads.box_head.fc7.bias"}, "", 1, 0))) return rc;
-    if ((rc = make_conv(m, m->pred, {"roi_heads.box_predictor.cls_score.weight", "roi_heads.box_predictor.bbox_pred.weight"},
-                        {"roi_heads.box_predictor.cls_score.bias", "roi_heads.box_predictor.bbox_pred.bias"}, "", 1, 0))) return rc;
-    if (m->pred.Cout != 5 * m->cfg.num_classes) return fail(CALD_ERR_INVALID, "box predictor has %d outputs, expected 5*num_classes=%d", m->pred.Cout, 5 * m->cfg.num_classes);
-    {   // AnchorGenerator base anchors: sizes (32,64,128,256,512), ratios (0.5,1,2)
-        std::vector<float> base(5 * 3 * 4);
-        const float sizes[5] = {32.f, 64.f, 128.f, 256.f, 512.f}, ratios[3] = {0.5f, 1.0f, 2.0f};
-        for (int l = 0; l < 5; l++)
+            char k[128];
+            snprintf(k, sizeof(k), "backbone.fpn.inner_blocks.%d", i);
+            if ((rc = make_conv(m, m->fpn_inner[i], {std::string(k) + ".weight"}, {std::string(k) + ".bias"}, "", 1, 0))) return rc;
+            snprintf(k, sizeof(k), "backbone.fpn.layer_blocks.%d", i);
+            if ((rc = make_conv(m, m->fpn_layer[i], {std::string(k) + ".weight"}, {std::string(k) + ".bias"}, "", 1, 1))) return rc;
+        }
+        if ((rc = make_conv(m, m->rpn_conv, {"rpn.head.conv.weight"}, {"rpn.head.conv.bias"}, "", 1, 1))) return rc;
+        if ((rc = make_conv(m, m->rpn_head, {"rpn.head.cls_logits.weight", "rpn.head.bbox_pred.weight"},
+                            {"rpn.head.cls_logits.bias", "rpn.head.bbox_pred.bias"}, "", 1, 0))) return rc;
+        {   // fc6: torch K order is (c, bin); the RoIAlign kernel writes (bin, c) -> permute the weight's K axis
+            const HostTensor* t; if ((rc = get_t(m, "roi_heads.box_head.fc6.weight", &t))) return rc;
+            if (t->shape.size() != 2 || t->shape[1] != 256 * 49) return fail(CALD_ERR_INVALID, "fc6 weight must be [N][12544]");
+            HostTensor p; p.shape = {t->shape[0], t->shape[1]}; p.data.resize(t->data.size());
+            int N = (int)t->shape[0];
+            for (int n = 0; n < N; n++)
+                for (int c = 0; c < 256; c++)
+                    for (int b = 0; b < 49; b++) p.data[(size_t)n * 12544 + b * 256 + c] = t->data[(size_t)n * 12544 + c * 49 + b];
+            m->sd["__fc6_perm"] = std::move(p);
+            if ((rc = make_conv(m, m->fc6, {"__fc6_perm"}, {"roi_heads.box_head.fc6.bias"}, "", 1, 0))) return rc;
+            m->sd.erase("__fc6_perm");
+        }
+        if ((rc = make_conv(m, m->fc7, {"roi_heads.box_head.fc7.weight"}, {"roi_heads.box_head.fc7.bias"}, "", 1, 0))) return rc;
+        if ((rc = make_conv(m, m->pred, {"roi_heads.box_predictor.cls_score.weight", "roi_heads.box_predictor.bbox_pred.weight"},
+                            {"roi_heads.box_predictor.cls_score.bias", "roi_heads.box_predictor.bbox_pred.bias"}, "", 1, 0))) return rc;
+        if (m->pred.Cout != 5 * m->cfg.num_classes) return fail(CALD_ERR_INVALID, "box predictor has %d outputs, expected 5*num_classes=%d", m->pred.Cout, 5 * m->cfg.num_classes);
+        {   // AnchorGenerator base anchors: sizes (32,64,128,256,512), ratios (0.5,1,2)
+            std::vector<float> base(5 * 3 * 4);
+            const float sizes[5] = {32.f, 64.f, 128.f, 256.f, 512.f}, ratios[3] = {0.5f, 1.0f, 2.0f};
+            for (int l = 0; l < 5; l++)
+                for (int r = 0; r < 3; r++) {
+                    float hr = sqrtf(ratios[r]), wr = 1.0f / hr;
+                    float ws = wr * sizes[l], hs = hr * sizes[l];
+                    float* b = &base[(l * 3 + r) * 4];
+                    b[0] = rintf(-ws / 2.0f); b[1] = rintf(-hs / 2.0f); b[2] = rintf(ws / 2.0f); b[3] = rintf(hs / 2.0f);
+                }
+            if ((rc = upload(m, base, &m->d_anchors))) return rc;
+        }
+    } else {
+        for (int i = 0; i < 3; i++) {
+            char k[128];
+            snprintf(k, sizeof(k), "backbone.fpn.inner_blocks.%d", i);
+            if ((rc = make_conv(m, m->fpn_inner[i], {std::string(k) + ".weight"}, {std::string(k) + ".bias"}, "", 1, 0))) return rc;
+            snprintf(k, sizeof(k), "backbone.fpn.layer_blocks.%d", i);
+            if ((rc = make_conv(m, m->fpn_layer[i], {std::string(k) + ".weight"}, {std::string(k) + ".bias"}, "", 1, 1))) return rc;
+        }
+        if ((rc = make_conv(m, m->p6, {"backbone.fpn.extra_blocks.p6.weight"}, {"backbone.fpn.extra_blocks.p6.bias"}, "", 2, 1))) return rc;
+        if ((rc = make_conv(m, m->p7, {"backbone.fpn.extra_blocks.p7.weight"}, {"backbone.fpn.extra_blocks.p7.bias"}, "", 2, 1))) return rc;
+        for (int i = 0; i < 4; i++) {
+            char k[128];
+            snprintf(k, sizeof(k), "head.classification_head.conv.%d", 2 * i);
+            if ((rc = make_conv(m, m->cls_tower[i], {std::string(k) + ".weight"}, {std::string(k) + ".bias"}, "", 1, 1))) return rc;
+            snprintf(k, sizeof(k), "head.regression_head.conv.%d", 2 * i);
+            if ((rc = make_conv(m, m->reg_tower[i], {std::string(k) + ".weight"}, {std::string(k) + ".bias"}, "", 1, 1))) return rc;
+        }
+        if ((rc = make_conv(m, m->cls_out, {"head.classification_head.cls_logits.weight"}, {"head.classification_head.cls_logits.bias"}, "", 1, 1))) return rc;
+        if ((rc = make_conv(m, m->reg_out, {"head.regression_head.bbox_reg.weight"}, {"head.regression_head.bbox_reg.bias"}, "", 1, 1))) return rc;
+        if (m->cls_out.Cout != 9 * m->cfg.num_classes || m->reg_out.Cout != 36)
+            return fail(CALD_ERR_INVALID, "RetinaNet heads must have 9*num_classes / 36 outputs (got %d / %d)", m->cls_out.Cout, m->reg_out.Cout);
+        // anchors: sizes (x, int(x*2^(1/3)), int(x*2^(2/3))) x ratios (0.5, 1, 2), index = ratio*3 + size (retinanet_cal.py:346-351)
+        std::vector<float> base(5 * 9 * 4);
+        const float ratios[3] = {0.5f, 1.0f, 2.0f};
+        for (int l = 0; l < 5; l++) {
+            const int x = 32 << l;
+            const float sizes[3] = {(float)x, (float)(int)((double)x * pow(2.0, 1.0 / 3)), (float)(int)((double)x * pow(2.0, 2.0 / 3))};
             for (int r = 0; r < 3; r++) {
                 float hr = sqrtf(ratios[r]), wr = 1.0f / hr;
-                float ws = wr * sizes[l], hs = hr * sizes[l];
-                float* b = &base[(l * 3 + r) * 4];
-                b[0] = rintf(-ws / 2.0f); b[1] = rintf(-hs / 2.0f); b[2] = rintf(ws / 2.0f); b[3] = rintf(hs / 2.0f);
+                for (int sidx = 0; sidx < 3; sidx++) {
+                    float ws = wr * sizes[sidx], hs = hr * sizes[sidx];
+                    float* b = &base[((l * 9) + r * 3 + sidx) * 4];
+                    b[0] = rintf(-ws / 2.0f); b[1] = rintf(-hs / 2.0f); b[2] = rintf(ws / 2.0f); b[3] = rintf(hs / 2.0f);
+                }
             }
+        }
         if ((rc = upload(m, base, &m->d_anchors))) return rc;
     }
     m->sd.clear();
@@ -554,7 +596,7 @@ extern "C" int cald_model_destroy(cald_model* m) {
 // =============================================================================================
 // forward
 // =============================================================================================
-static void build_plan(BatchPlan& P, int V, const ViewDesc* views, const int (*hp)[2]) {
+static void build_plan(BatchPlan& P, int V, const ViewDesc* views, const int (*hp)[2], bool retina) {
     memset(&P, 0, sizeof(P));
     for (int l = 0; l < CALD_MAX_LEVELS; l++) {
         long long off = 0; int tile = 0;
@@ -563,7 +605,8 @@ static void build_plan(BatchPlan& P, int V, const ViewDesc* views, const int (*h
             s.pix_off = off; s.tile_start = tile;
             if (v == V) break;
             int H, W;
-            if (l == 7) { H = 1; W = CALD_ROI_CAP; }
+            if (l == 7 && retina) { int h6 = (hp[v][0] / 32 - 1) / 2 + 1, w6 = (hp[v][1] / 32 - 1) / 2 + 1; H = (h6 - 1) / 2 + 1; W = (w6 - 1) / 2 + 1; }
+            else if (l == 7) { H = 1; W = CALD_ROI_CAP; }
             else if (l == 6) { H = (hp[v][0] / 32 - 1) / 2 + 1; W = (hp[v][1] / 32 - 1) / 2 + 1; }
             else { H = hp[v][0] >> l; W = hp[v][1] >> l; }
             s.H = H; s.W = W;
@@ -580,10 +623,14 @@ struct FwdBufs {
     unsigned long long* cand_key; float *cand_box, *sorted_box, *sorted_raw; int* sorted_count;
     float* proposals; int* prop_count;
     float *roi, *f6, *f7, *pr, *prob, *pmax; unsigned long long* keys; float* cbox; int* key_count;
+    // RetinaNet
+    float *ret_ta, *ret_tb, *cls_h[5], *reg_h[5], *rcand_box, *kept_box; unsigned long long* rcand_key;
+    int *cand_count, *kept_anchor, *kept_count; int cand_cap; int max_anchors;
 };
 
 static int conv_on(cald_model* m, const ConvLayer& L, const float* in, float* out, int lin, int lout, int V, bool relu,
-                   const float* residual = nullptr, const float* up = nullptr, int lup = 0, const int* dyn = nullptr) {
+                   const float* residual = nullptr, const float* up = nullptr, int lup = 0, const int* dyn = nullptr,
+                   bool in_relu = false) {
     ConvArgs a;
     const BatchPlan* dp = m->ctx->d_plan;
     a.in = in; a.out = out; a.w = L.w; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift;
@@ -593,7 +640,7 @@ static int conv_on(cald_model* m, const ConvLayer& L, const float* in, float* ou
     a.Cin = L.Cin; a.Cout = L.Cout; a.CoutPad = L.CoutPad; a.Kpad = L.Kpad;
     a.KH = L.KH; a.KW = L.KW; a.stride = L.stride; a.pad = L.pad; a.relu = relu ? 1 : 0;
     a.total_mtiles = level_tiles(m->plan, lout, V);
-    a.out_ld = L.Cout;
+    a.out_ld = L.Cout; a.in_relu = in_relu ? 1 : 0;
     double flops = 2.0 * (double)level_pix(m->plan, lout, V) * (double)L.Cout * (double)(L.KH * L.KW * L.CinTrue);
     return run_conv(m->ctx, a, flops);
 }
@@ -609,6 +656,24 @@ static void fwd_layout(cald_model* m, Bump& B, FwdBufs& F, int V) {
     F.T1 = B.get<float>(px[2] * 128); F.T2 = B.get<float>(px[2] * 64); F.D = B.get<float>(px[2] * 256);
     const int cch[4] = {256, 512, 1024, 2048};
     for (int i = 0; i < 4; i++) F.Cf[i] = B.get<float>(px[2 + i] * cch[i]);
+    if (m->cfg.arch == CALD_ARCH_RETINANET) {
+        const int K = m->cfg.num_classes, per = m->cfg.detections_per_img;
+        for (int i = 0; i < 3; i++) F.inner[i] = B.get<float>(px[3 + i] * 256);
+        for (int i = 0; i < 5; i++) F.Pf[i] = B.get<float>(px[3 + i] * 256);
+        F.ret_ta = B.get<float>(px[3] * 256); F.ret_tb = B.get<float>(px[3] * 256);
+        for (int i = 0; i < 5; i++) { F.cls_h[i] = B.get<float>(px[3 + i] * m->cls_out.Cout); F.reg_h[i] = B.get<float>(px[3 + i] * 36); }
+        int maxa = 0;
+        for (int v = 0; v < V; v++) { int t = 0; for (int l = 3; l < 8; l++) t += P.seg[l][v].H * P.seg[l][v].W * 9; if (t > maxa) maxa = t; }
+        int cap = 1024; while (cap < maxa) cap <<= 1;
+        F.max_anchors = maxa; F.cand_cap = cap;
+        F.cand_count = B.get<int>((size_t)V * K);
+        F.rcand_key = B.get<unsigned long long>((size_t)V * K * cap);
+        F.rcand_box = B.get<float>((size_t)V * K * cap * 4);
+        F.kept_anchor = B.get<int>((size_t)V * K * per);
+        F.kept_box = B.get<float>((size_t)V * K * per * 4);
+        F.kept_count = B.get<int>((size_t)V * K);
+        return;
+    }
     for (int i = 0; i < 4; i++) F.inner[i] = B.get<float>(px[2 + i] * 256);
     for (int i = 0; i < 5; i++) F.Pf[i] = B.get<float>(px[2 + i] * 256);
     F.rpn_t = B.get<float>(px[2] * 256);
@@ -633,11 +698,11 @@ static void fwd_layout(cald_model* m, Bump& B, FwdBufs& F, int V) {
 }
 
 // views: host descriptors with src/H/W/flip/rects filled; Hr/Wr/Ho/Wo are filled here.
-static int forward_frcnn(cald_model* m, int V, ViewDesc* views, const DetBuffers& det) {
+static int forward_model(cald_model* m, int V, ViewDesc* views, const DetBuffers& det) {
     cald_ctx* c = m->ctx;
     if (!m->finalized) return fail(CALD_ERR_STATE, "model not finalized (call cald_model_finalize)");
     if (V < 1 || V > CALD_MAX_VIEWS) return fail(CALD_ERR_INVALID, "n_views must be 1..%d", CALD_MAX_VIEWS);
-    if (det.cap < m->cfg.detections_per_img) return fail(CALD_ERR_INVALID, "detection capacity %d < detections_per_img %d", det.cap, m->cfg.detections_per_img);
+    if (det.cap < m->det_cap()) return fail(CALD_ERR_INVALID, "detection capacity %d < required %d", det.cap, m->det_cap());
     HIPCHK(hipSetDevice(c->device));
     int hp[CALD_MAX_VIEWS][2];
     int max_pix0 = 0, max_pix2 = 0, max_pix6 = 0;
@@ -650,7 +715,8 @@ static int forward_frcnn(cald_model* m, int V, ViewDesc* views, const DetBuffers
         hp[v][0] = Hp; hp[v][1] = Wp;
         if (Hp * Wp > max_pix0) max_pix0 = Hp * Wp;
     }
-    build_plan(m->plan, V, views, hp);
+    const bool retina = m->cfg.arch == CALD_ARCH_RETINANET;
+    build_plan(m->plan, V, views, hp, retina);
     m->last_V = V; m->last_views.assign(views, views + V);
     for (int v = 0; v < V; v++) {
         int p2 = m->plan.seg[2][v].H * m->plan.seg[2][v].W; if (p2 > max_pix2) max_pix2 = p2;
@@ -696,6 +762,47 @@ static int forward_frcnn(cald_model* m, int V, ViewDesc* views, const DetBuffers
     const char* cn[4] = {"C2", "C3", "C4", "C5"};
     const int cch[4] = {256, 512, 1024, 2048};
     for (int i = 0; i < 4; i++) m->dbg[cn[i]] = {F.Cf[i], 2 + i, cch[i], 0};
+    if (retina) {
+        // ---- FPN on C3..C5 + LastLevelP6P7 (retinanet_cal.py:618-619) ----
+        if ((rc = conv_on(m, m->fpn_inner[2], F.Cf[3], F.inner[2], 5, 5, V, false))) return rc;
+        for (int i = 1; i >= 0; i--)
+            if ((rc = conv_on(m, m->fpn_inner[i], F.Cf[1 + i], F.inner[i], 3 + i, 3 + i, V, false, nullptr, F.inner[i + 1], 4 + i))) return rc;
+        for (int i = 0; i < 3; i++)
+            if ((rc = conv_on(m, m->fpn_layer[i], F.inner[i], F.Pf[i], 3 + i, 3 + i, V, false))) return rc;
+        if ((rc = conv_on(m, m->p6, F.Pf[2], F.Pf[3], 5, 6, V, false))) return rc;
+        if ((rc = conv_on(m, m->p7, F.Pf[3], F.Pf[4], 6, 7, V, false, nullptr, nullptr, 0, nullptr, true))) return rc;
+        const char* pn[5] = {"P3", "P4", "P5", "P6", "P7"};
+        const char* cnm[5] = {"cls0", "cls1", "cls2", "cls3", "cls4"};
+        const char* rnm[5] = {"reg0", "reg1", "reg2", "reg3", "reg4"};
+        for (int i = 0; i < 5; i++) m->dbg[pn[i]] = {F.Pf[i], 3 + i, 256, 0};
+        // ---- heads (retinanet_cal.py:36-241): 4 x (3x3 conv + ReLU) + 3x3 output conv, per level ----
+        for (int i = 0; i < 5; i++) {
+            const int l = 3 + i;
+            for (int hsel = 0; hsel < 2; hsel++) {
+                const ConvLayer* tw = hsel == 0 ? m->cls_tower : m->reg_tower;
+                const float* src = F.Pf[i];
+                for (int t = 0; t < 4; t++) {
+                    float* dst = (t & 1) ? F.ret_tb : F.ret_ta;
+                    if ((rc = conv_on(m, tw[t], src, dst, l, l, V, true))) return rc;
+                    src = dst;
+                }
+                if ((rc = conv_on(m, hsel == 0 ? m->cls_out : m->reg_out, src, hsel == 0 ? F.cls_h[i] : F.reg_h[i], l, l, V, false))) return rc;
+            }
+            m->dbg[cnm[i]] = {F.cls_h[i], l, m->cls_out.Cout, 0};
+            m->dbg[rnm[i]] = {F.reg_h[i], l, 36, 0};
+        }
+        RetinaArgs ra;
+        for (int i = 0; i < 5; i++) { ra.cls[i] = F.cls_h[i]; ra.reg[i] = F.reg_h[i]; ra.seg[i] = dp->seg[3 + i]; }
+        ra.seg0 = dp->seg[0]; ra.views = c->d_views; ra.base_anchors = m->d_anchors;
+        ra.cls_ld = m->cls_out.Cout; ra.reg_ld = 36; ra.A = 9; ra.K = m->cfg.num_classes; ra.V = V;
+        ra.score_thr = m->cfg.box_score_thresh; ra.nms_thr = m->cfg.box_nms_thresh; ra.min_box = 1e-2f;
+        ra.per_class = m->cfg.detections_per_img; ra.cand_cap = F.cand_cap;
+        ra.cand_count = F.cand_count; ra.cand_key = F.rcand_key; ra.cand_box = F.rcand_box;
+        ra.kept_anchor = F.kept_anchor; ra.kept_box = F.kept_box; ra.kept_count = F.kept_count; ra.det = det;
+        launch_retina_postprocess(ra, F.max_anchors, st);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     // ---- FPN (row A16) ----
     if ((rc = conv_on(m, m->fpn_inner[3], F.Cf[3], F.inner[3], 5, 5, V, false))) return rc;
     for (int i = 2; i >= 0; i--)
@@ -761,7 +868,7 @@ extern "C" int cald_forward(cald_model* m, int n_views, const cald_view* views, 
     det.cap = out->cap; det.C = m->cfg.num_classes;
     if (!det.boxes || !det.scores || !det.labels || !det.props || !det.prob_max || !det.scores_cls || !det.count)
         return fail(CALD_ERR_INVALID, "output buffers must all be provided");
-    return forward_frcnn(m, n_views, vd.data(), det);
+    return forward_model(m, n_views, vd.data(), det);
 }
 
 extern "C" int cald_debug_tensor(cald_model* m, const char* name, int view, float* host_out, int64_t capacity, int64_t* shape3) {
@@ -816,7 +923,7 @@ extern "C" int cald_op_conv2d(cald_ctx* c, const float* in, int H, int W, int Ci
     a.in = d_in; a.out = d_out; a.w = d_w; a.bias = bias ? d_b : nullptr; a.scale = bn_scale ? d_sc : nullptr; a.shift = bn_scale ? d_sh : nullptr;
     a.residual = d_res; a.up = nullptr; a.seg_in = d_p->seg[0]; a.seg_out = d_p->seg[1]; a.seg_up = d_p->seg[1]; a.dyn_rows = nullptr;
     a.V = 1; a.Cin = Cin; a.Cout = Cout; a.CoutPad = CoutPad; a.Kpad = Kpad; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
-    a.relu = relu; a.total_mtiles = (Ho * Wo + 127) / 128; a.out_ld = Cout;
+    a.relu = relu; a.total_mtiles = (Ho * Wo + 127) / 128; a.out_ld = Cout; a.in_relu = 0;
     launch_conv(a, c->stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -903,7 +1010,7 @@ extern "C" int cald_sweep(cald_model* m, int n_images, const uint8_t* const* ima
     if (!m->finalized) return fail(CALD_ERR_STATE, "model not finalized");
     cald_ctx* c = m->ctx;
     HIPCHK(hipSetDevice(c->device));
-    const int C = m->cfg.num_classes, cap = m->cfg.detections_per_img;
+    const int C = m->cfg.num_classes, cap = m->det_cap();
     const int A = (cfg->aug_flip ? 1 : 0) + (cfg->aug_cutout ? 1 : 0) + (cfg->aug_resize ? 1 : 0);
     int B = cfg->batch_images > 0 ? cfg->batch_images : 64;
     if (B > CALD_MAX_VIEWS) B = CALD_MAX_VIEWS;
@@ -938,7 +1045,7 @@ extern "C" int cald_sweep(cald_model* m, int n_images, const uint8_t* const* ima
             views[i].src = images_dev[i0 + i]; views[i].H = H[i0 + i]; views[i].W = W[i0 + i];
         }
         DetBuffers d1 = D;
-        if ((rc = forward_frcnn(m, nb, views.data(), d1))) break;
+        if ((rc = forward_model(m, nb, views.data(), d1))) break;
         if (hipMemcpyAsync(h_count.data(), D.count, (size_t)nb * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
             hipMemcpyAsync(h_boxes.data(), D.boxes, (size_t)nb * cap * 16, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
             hipStreamSynchronize(c->stream) != hipSuccess) { rc = fail(CALD_ERR_HIP, "D2H of reference detections failed"); break; }
@@ -985,7 +1092,7 @@ extern "C" int cald_sweep(cald_model* m, int n_images, const uint8_t* const* ima
             DetBuffers d2 = D; const size_t o = (size_t)(nb + a0);
             d2.boxes += o * cap * 4; d2.scores += o * cap; d2.labels += o * cap; d2.props += o * cap * 4;
             d2.prob_max += o * cap; d2.scores_cls += o * cap * C; d2.count += o;
-            rc = forward_frcnn(m, nv, aviews.data() + a0, d2);
+            rc = forward_model(m, nv, aviews.data() + a0, d2);
         }
         if (rc) break;
         // ---- phase 3: scoring ----

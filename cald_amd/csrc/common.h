@@ -43,6 +43,7 @@ struct ConvArgs {
     int relu;
     int total_mtiles;
     int out_ld;            // output row stride in floats (== Cout normally)
+    int in_relu;           // apply ReLU to the input while gathering (LastLevelP6P7: p7(relu(p6)))
 };
 
 // ---------------------------------------------------------------------------------------------

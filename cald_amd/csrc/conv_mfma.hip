@@ -64,6 +64,7 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_f32_kernel(const ConvArgs a)
     const float* __restrict__ in_v = a.in + si.pix_off * (long long)a.Cin;
     const float* __restrict__ wgt = a.w;
     const int Cin = a.Cin, KW = a.KW, KH = a.KH, CoutPad = a.CoutPad;
+    const bool in_relu = a.in_relu != 0;
 
     // ---- per-thread A gather state: rows (tid>>2) and (tid>>2)+64, k group g = tid&3 ----
     const int g = tid & 3, arow = tid >> 2;
@@ -95,6 +96,10 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_f32_kernel(const ConvArgs a)
         const float4 t1 = *reinterpret_cast<const float4*>(in_v + o1);                                     \
         ra0.x = ok0 ? t0.x : 0.0f; ra0.y = ok0 ? t0.y : 0.0f; ra0.z = ok0 ? t0.z : 0.0f; ra0.w = ok0 ? t0.w : 0.0f; \
         ra1.x = ok1 ? t1.x : 0.0f; ra1.y = ok1 ? t1.y : 0.0f; ra1.z = ok1 ? t1.z : 0.0f; ra1.w = ok1 ? t1.w : 0.0f; \
+        if (in_relu) {                                                                                     \
+            ra0.x = ra0.x < 0.0f ? 0.0f : ra0.x; ra0.y = ra0.y < 0.0f ? 0.0f : ra0.y; ra0.z = ra0.z < 0.0f ? 0.0f : ra0.z; ra0.w = ra0.w < 0.0f ? 0.0f : ra0.w; \
+            ra1.x = ra1.x < 0.0f ? 0.0f : ra1.x; ra1.y = ra1.y < 0.0f ? 0.0f : ra1.y; ra1.z = ra1.z < 0.0f ? 0.0f : ra1.z; ra1.w = ra1.w < 0.0f ? 0.0f : ra1.w; \
+        }                                                                                                  \
         if (b0ok) rb0 = *reinterpret_cast<const float4*>(wgt + (long long)((KTI) * BK + bk0) * CoutPad + n0 + 4 * bc0); \
         if (PB > 1) rb1 = *reinterpret_cast<const float4*>(wgt + (long long)((KTI) * BK + bk1) * CoutPad + n0 + 4 * bc1); \
         ci += BK;                                                                                          \

@@ -98,3 +98,25 @@ struct ScoreArgs {
 void launch_consistency(const ScoreArgs& a, hipStream_t st);
 void launch_cls_corr(const DetBuffers& det, const int* ref_sel, const int* ref_n, const int* view_img, const int* view_is_ref,
                      int V, float* out /*[V][C-1]*/, hipStream_t st);
+
+// retina.hip
+struct RetinaArgs {
+    const float* cls[5];          // per level [sum pix][cls_ld], channel a*K + k
+    const float* reg[5];          // per level [sum pix][reg_ld], channel a*4 + j
+    const LevelSeg* seg[5];       // P3..P7 geometry
+    const LevelSeg* seg0;
+    const ViewDesc* views;
+    const float* base_anchors;    // [5][A][4]
+    int cls_ld, reg_ld, A, K, V;
+    float score_thr, nms_thr, min_box;
+    int per_class;                // detections_per_img (300), applied per class
+    int cand_cap;                 // power of two >= anchors per view
+    int* cand_count;              // [V][K]
+    unsigned long long* cand_key; // [V][K][cand_cap]
+    float* cand_box;              // [V][K][cand_cap][4]
+    int* kept_anchor;             // [V][K][per_class]
+    float* kept_box;              // [V][K][per_class][4]
+    int* kept_count;              // [V][K]
+    DetBuffers det;               // cap >= K * per_class
+};
+void launch_retina_postprocess(const RetinaArgs& a, int max_anchors, hipStream_t st);

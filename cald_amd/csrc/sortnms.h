@@ -50,7 +50,7 @@ __device__ inline void block_nms_sorted(const float4* boxes, int n, float thr, i
         bool dead = true;
         if (wave < 4) {
             dead = !(j < n);
-            if (!dead) b = boxes[j];
+            if (!dead) { b = boxes[j]; if (b.x != b.x) dead = true; }   // NaN x1 marks a filtered-out box
             // phase A: this wave tests kept[t], t = wave, wave+4, ...
             if (!dead) {
                 for (int t = wave; t < nk; t += 4)

@@ -33,11 +33,10 @@ def get_ctx(device_index=None):
 
 
 class HipDetector:
-    arch = 0
-
     def __init__(self, num_classes, depth=50, min_size=800, max_size=1333, box_score_thresh=0.05, box_nms_thresh=0.5,
                  box_detections_per_img=100, rpn_pre_nms_top_n_test=1000, rpn_post_nms_top_n_test=1000,
-                 rpn_nms_thresh=0.7, **unused):
+                 rpn_nms_thresh=0.7, arch=0, **unused):
+        self.arch = arch
         self.cfg = _ffi.ModelCfg(self.arch, depth, num_classes, int(min_size), int(max_size), box_score_thresh,
                                  box_nms_thresh, box_detections_per_img, rpn_pre_nms_top_n_test, rpn_post_nms_top_n_test,
                                  rpn_nms_thresh)
@@ -113,7 +112,8 @@ class HipDetector:
         h = self.handle()
         n = len(views)
         dev = views[0][0].device
-        cap, Cn = self.cfg.detections_per_img, self.num_classes
+        Cn = self.num_classes
+        cap = self.cfg.detections_per_img * (Cn if self.arch == 1 else 1)
         out = dict(boxes=torch.empty((n, cap, 4), device=dev), scores=torch.empty((n, cap), device=dev),
                    labels=torch.empty((n, cap), dtype=torch.int64, device=dev), props=torch.empty((n, cap, 4), device=dev),
                    prob_max=torch.empty((n, cap), device=dev), scores_cls=torch.empty((n, cap, Cn), device=dev),
@@ -132,7 +132,9 @@ class HipDetector:
         counts = out["count"].cpu().tolist()
         res = []
         for i, k in enumerate(counts):
-            res.append({key: out[key][i, :k] for key in ("boxes", "labels", "scores", "props", "prob_max", "scores_cls")})
+            keys = ("boxes", "labels", "scores", "props", "prob_max", "scores_cls") if self.arch == 0 else \
+                   ("boxes", "scores", "labels", "scores_cls", "prob_max")
+            res.append({key: out[key][i, :k] for key in keys})
         return res
 
     def __call__(self, images, targets=None):
@@ -167,3 +169,10 @@ def fasterrcnn_resnet50_fpn_feature(pretrained=False, progress=True, num_classes
 def fasterrcnn_resnet101_fpn_feature(pretrained=False, progress=True, num_classes=91, pretrained_backbone=True, **kwargs):
     """BASELINE.json config 5 (ResNet-101): same factory with torchvision's 'resnet101' body."""
     return HipDetector(num_classes, depth=101, **kwargs)
+
+
+def retinanet_resnet50_fpn_cal(pretrained=False, progress=True, num_classes=91, pretrained_backbone=True,
+                               score_thresh=0.05, nms_thresh=0.5, detections_per_img=300, **kwargs):
+    """detection/retinanet_cal.py:584-625 (constructor defaults :322-333).  Result dict keys of :479-485."""
+    return HipDetector(num_classes, depth=50, box_score_thresh=score_thresh, box_nms_thresh=nms_thresh,
+                       box_detections_per_img=detections_per_img, arch=1, **kwargs)

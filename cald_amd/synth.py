@@ -110,3 +110,29 @@ def pseudo_trained_frcnn(num_classes=21, depth=50, seed=0, cls_gain=1.0, rpn_gai
     sd["roi_heads.box_predictor.bbox_pred.weight"] = (wd - wd.mean(axis=1, keepdims=True)).astype(np.float32)
     sd["roi_heads.box_predictor.bbox_pred.bias"] = (0.05 * rs.randn(4 * num_classes)).astype(np.float32)
     return sd
+
+
+def pseudo_trained_retinanet(num_classes=21, depth=50, seed=0):
+    """torchvision-layout RetinaNet ResNet-FPN state dict (detection/retinanet_cal.py key layout), seeded."""
+    rs = np.random.RandomState(seed)
+    full = pseudo_trained_frcnn(num_classes, depth, seed)
+    sd = {k: v for k, v in full.items() if k.startswith("backbone.body.")}
+    for i, cin in enumerate([512, 1024, 2048]):
+        sd["backbone.fpn.inner_blocks.%d.weight" % i] = _he(rs, (256, cin, 1, 1), gain=1.0)
+        sd["backbone.fpn.inner_blocks.%d.bias" % i] = (0.05 * rs.randn(256)).astype(np.float32)
+        sd["backbone.fpn.layer_blocks.%d.weight" % i] = _he(rs, (256, 256, 3, 3), gain=1.0)
+        sd["backbone.fpn.layer_blocks.%d.bias" % i] = (0.05 * rs.randn(256)).astype(np.float32)
+    for p in ("p6", "p7"):
+        sd["backbone.fpn.extra_blocks.%s.weight" % p] = _he(rs, (256, 256, 3, 3), gain=1.0)
+        sd["backbone.fpn.extra_blocks.%s.bias" % p] = (0.05 * rs.randn(256)).astype(np.float32)
+    for head in ("classification_head", "regression_head"):
+        for i in range(4):
+            sd["head.%s.conv.%d.weight" % (head, 2 * i)] = _he(rs, (256, 256, 3, 3))
+            sd["head.%s.conv.%d.bias" % (head, 2 * i)] = (0.02 * rs.randn(256)).astype(np.float32)
+    wc = _he(rs, (9 * num_classes, 256, 3, 3), gain=1.0) * 0.17
+    sd["head.classification_head.cls_logits.weight"] = (wc - wc.mean(axis=(1, 2, 3), keepdims=True)).astype(np.float32)
+    sd["head.classification_head.cls_logits.bias"] = (-5.0 + 0.3 * rs.randn(9 * num_classes)).astype(np.float32)
+    wb = _he(rs, (36, 256, 3, 3), gain=1.0) * 0.05
+    sd["head.regression_head.bbox_reg.weight"] = (wb - wb.mean(axis=(1, 2, 3), keepdims=True)).astype(np.float32)
+    sd["head.regression_head.bbox_reg.bias"] = (0.02 * rs.randn(36)).astype(np.float32)
+    return sd

@@ -26,6 +26,9 @@
 #include "orc_math.h"
 
 #define ORC_API __attribute__((visibility("default")))
+/* OpenMP team size of the oracle loops (a 256-thread host makes tiny test convolutions crawl) */
+static int orc_threads = 16;
+ORC_API void orc_set_threads(int n) { orc_threads = n < 1 ? 1 : n; }
 static inline float fminf_(float a, float b) { return a < b ? a : b; }
 static inline float fmaxf_(float a, float b) { return a > b ? a : b; }
 
@@ -339,7 +342,7 @@ ORC_API void orc_preprocess_view(const uint8_t* src, int H, int W, int flip, int
                                  int Hr, int Wr, int Hp, int Wp, float* out) {
     memset(out, 0, sizeof(float) * (size_t)Hp * Wp * 4);
     float sh = (float)H / (float)Hr, sw = (float)W / (float)Wr;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(orc_threads)
     for (int y = 0; y < Hr; y++) {
         float fy = sh * ((float)y + 0.5f) - 0.5f; if (fy < 0.0f) fy = 0.0f;
         int y0 = (int)fy; int y1 = y0 + (y0 < H - 1 ? 1 : 0);
@@ -383,7 +386,7 @@ ORC_API void orc_conv2d_nhwc(const float* in, int H, int W, int Cin, const float
     float* zero = (float*)calloc((size_t)Cin, sizeof(float));
     long npix = (long)Ho * Wo;
     float uph_scale = up ? (float)upH / (float)Ho : 0.0f, upw_scale = up ? (float)upW / (float)Wo : 0.0f;
-#pragma omp parallel for schedule(dynamic, 2)
+#pragma omp parallel for schedule(dynamic, 2) num_threads(orc_threads)
     for (long pb0 = 0; pb0 < npix; pb0 += CT_P * 16) {
       /* weights chunk [K][CT_V] is reused across the 16 pixel tiles of this block */
       for (int co0 = 0; co0 < Cout; co0 += CT_V) {
@@ -459,7 +462,7 @@ ORC_API void orc_linear(const float* in, int M, int K, const float* wk, int N, c
 
 /* max_pool2d(k=3, s=2, p=1), NHWC */
 ORC_API void orc_maxpool3x3s2(const float* in, int H, int W, int C, float* out, int Ho, int Wo) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(orc_threads)
     for (int oy = 0; oy < Ho; oy++)
         for (int ox = 0; ox < Wo; ox++)
             for (int c = 0; c < C; c++) {
@@ -626,7 +629,7 @@ ORC_API int orc_roi_level(const float* box) {
 ORC_API void orc_roi_align(int L, const float* const* feat, const int* fh, const int* fw, int C,
                            const float* rois, int R, float* out) {
     const int PH = 7, PW = 7, SR = 2;
-#pragma omp parallel for schedule(dynamic, 4)
+#pragma omp parallel for schedule(dynamic, 4) num_threads(orc_threads)
     for (int r = 0; r < R; r++) {
         const float* box = rois + 4 * r;
         int l = orc_roi_level(box); if (l > L - 1) l = L - 1;
@@ -722,4 +725,71 @@ ORC_API int orc_frcnn_postprocess(int R, int C, const float* logits, const float
     }
     free(prob); free(pmax); free(cb); free(cs); free(cg); free(cr); free(keep);
     return nk;
+}
+
+/* -------------------------------------------------------------------------------------
+ * RetinaNet.postprocess_detections (detection/retinanet_cal.py:402-490) + the stock
+ * GeneralizedRCNNTransform.postprocess (boxes only, float32 tensor ratios).
+ * cls[l]: NHWC [h][w][A*K] logits (channel a*K+k), reg[l]: [h][w][A*4] (channel a*4+j).
+ * Outputs hold up to K*per_class rows, grouped by class in class order (NOT globally sorted).
+ * ------------------------------------------------------------------------------------- */
+ORC_API int orc_retina_postprocess(int L, const float* const* cls, const float* const* reg, const int* fh, const int* fw,
+                                   int A, int K, const float* base_anchors /*[L][A][4]*/, int Hp, int Wp, int Hr, int Wr,
+                                   int Ho, int Wo, float score_thr, float nms_thr, int per_class, float min_box,
+                                   float* o_boxes, float* o_scores, int64_t* o_labels, float* o_pm, float* o_scls) {
+    long total = 0;
+    for (int l = 0; l < L; l++) total += (long)fh[l] * fw[l] * A;
+    float* sc = (float*)malloc(sizeof(float) * (size_t)total * K);
+    float* bx = (float*)malloc(sizeof(float) * (size_t)total * 4);
+    float* pm = (float*)malloc(sizeof(float) * (size_t)total);
+    long base = 0;
+    for (int l = 0; l < L; l++) {
+        int sth = Hp / fh[l], stw = Wp / fw[l];
+        long n = (long)fh[l] * fw[l] * A;
+#pragma omp parallel for schedule(static) num_threads(orc_threads)
+        for (long i = 0; i < n; i++) {
+            int a = (int)(i % A); long pix = i / A; int y = (int)(pix / fw[l]), x = (int)(pix % fw[l]);
+            const float* lg = cls[l] + (size_t)pix * A * K + (size_t)a * K;
+            float m = 0.0f;
+            for (int k = 0; k < K; k++) { float s = orc_sigmoidf(lg[k]); sc[(size_t)(base + i) * K + k] = s; if (k == 0 || s > m) m = s; }
+            pm[base + i] = m;
+            const float* ba = base_anchors + ((size_t)l * A + a) * 4;
+            float anchor[4] = {(float)(x * stw) + ba[0], (float)(y * sth) + ba[1], (float)(x * stw) + ba[2], (float)(y * sth) + ba[3]};
+            float b[4];
+            box_decode(anchor, reg[l] + (size_t)pix * A * 4 + (size_t)a * 4, 1.0f, 1.0f, 1.0f, 1.0f, (float)BBOX_XFORM_CLIP, b);
+            b[0] = clampf(b[0], 0.0f, (float)Wr); b[2] = clampf(b[2], 0.0f, (float)Wr);
+            b[1] = clampf(b[1], 0.0f, (float)Hr); b[3] = clampf(b[3], 0.0f, (float)Hr);
+            memcpy(bx + 4 * (size_t)(base + i), b, sizeof(b));
+        }
+        base += n;
+    }
+    float rh = (float)Ho / (float)Hr, rw = (float)Wo / (float)Wr;   /* stock resize_boxes: float32 tensor division */
+    orc_kv* kv = (orc_kv*)malloc(sizeof(orc_kv) * (size_t)total);
+    float* sb = (float*)malloc(sizeof(float) * 4 * (size_t)total);
+    int* keep = (int*)malloc(sizeof(int) * ((size_t)total + 1));
+    int nout = 0;
+    for (int k = 0; k < K; k++) {
+        int nc = 0;
+        for (long i = 0; i < total; i++) {
+            float s = sc[(size_t)i * K + k];
+            if (!(s > score_thr)) continue;
+            const float* b = bx + 4 * (size_t)i;
+            if (!((b[2] - b[0]) >= min_box && (b[3] - b[1]) >= min_box)) continue;
+            kv[nc].key = s; kv[nc].idx = (int)i; nc++;
+        }
+        qsort(kv, nc, sizeof(orc_kv), kv_cmp);
+        for (int i = 0; i < nc; i++) memcpy(sb + 4 * (size_t)i, bx + 4 * (size_t)kv[i].idx, 4 * sizeof(float));
+        int nk = nms_sorted(sb, nc, nms_thr, per_class, keep);
+        for (int i = 0; i < nk; i++) {
+            int ai = kv[keep[i]].idx;
+            const float* b = bx + 4 * (size_t)ai;
+            o_boxes[4 * (size_t)nout + 0] = b[0] * rw; o_boxes[4 * (size_t)nout + 1] = b[1] * rh;
+            o_boxes[4 * (size_t)nout + 2] = b[2] * rw; o_boxes[4 * (size_t)nout + 3] = b[3] * rh;
+            o_scores[nout] = sc[(size_t)ai * K + k]; o_labels[nout] = k; o_pm[nout] = pm[ai];
+            memcpy(o_scls + (size_t)nout * K, sc + (size_t)ai * K, sizeof(float) * K);
+            nout++;
+        }
+    }
+    free(sc); free(bx); free(pm); free(kv); free(sb); free(keep);
+    return nout;
 }

@@ -42,6 +42,7 @@ def lib():
         _LIB.orc_log.argtypes = [C.c_float]
         _LIB.orc_js_divergence.restype = C.c_float
         _LIB.orc_consistency_view.restype = C.c_float
+        _LIB.orc_set_threads(C.c_int(min(32, os.cpu_count() or 1)))
     return _LIB
 
 
@@ -372,6 +373,110 @@ def frcnn_forward(P, img, min_size, max_size, flip=False, rects=None, keep=None,
     return frcnn_postprocess(pred[:, :Cn], pred[:, Cn:], props, Hr, Wr, H, W, score_thr, nms_thr, det_max)
 
 
+# ----------------------------------------------------------------------------- RetinaNet (rows A21, A22)
+def retina_anchor_sizes():
+    """retinanet_cal.py:346-347"""
+    return [(x, int(x * 2 ** (1.0 / 3)), int(x * 2 ** (2.0 / 3))) for x in [32, 64, 128, 256, 512]]
+
+
+def prepare_retinanet(sd, num_classes, depth=50):
+    """torchvision-layout RetinaNet state dict (SURVEY section 8b key layout) -> oracle weights."""
+    sd = {k: (v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)) for k, v in sd.items()}
+    P = {"num_classes": num_classes, "depth": depth, "arch": "retinanet"}
+    w1 = f32(sd["backbone.body.conv1.weight"])
+    w1p = np.zeros((64, 4, 7, 7), np.float32); w1p[:, :3] = w1
+    P["conv1"] = (_kmajor_conv(w1p), _frozen_bn(sd, "backbone.body.bn1"))
+    blocks = []
+    for li, nb in enumerate(RESNET_LAYERS[depth]):
+        for bi in range(nb):
+            pre = "backbone.body.layer%d.%d" % (li + 1, bi)
+            blk = {"stride": 2 if (bi == 0 and li > 0) else 1}
+            for ci in (1, 2, 3):
+                blk["conv%d" % ci] = (_kmajor_conv(sd[pre + ".conv%d.weight" % ci]), _frozen_bn(sd, pre + ".bn%d" % ci))
+            if pre + ".downsample.0.weight" in sd:
+                blk["down"] = (_kmajor_conv(sd[pre + ".downsample.0.weight"]), _frozen_bn(sd, pre + ".downsample.1"))
+            blk["layer_end"] = (bi == nb - 1)
+            blocks.append(blk)
+    P["blocks"] = blocks
+    P["fpn_inner"] = [(_kmajor_conv(sd["backbone.fpn.inner_blocks.%d.weight" % i]), f32(sd["backbone.fpn.inner_blocks.%d.bias" % i])) for i in range(3)]
+    P["fpn_layer"] = [(_kmajor_conv(sd["backbone.fpn.layer_blocks.%d.weight" % i]), f32(sd["backbone.fpn.layer_blocks.%d.bias" % i])) for i in range(3)]
+    P["p6"] = (_kmajor_conv(sd["backbone.fpn.extra_blocks.p6.weight"]), f32(sd["backbone.fpn.extra_blocks.p6.bias"]))
+    P["p7"] = (_kmajor_conv(sd["backbone.fpn.extra_blocks.p7.weight"]), f32(sd["backbone.fpn.extra_blocks.p7.bias"]))
+    for head, last in (("classification_head", "cls_logits"), ("regression_head", "bbox_reg")):
+        P[head] = [(_kmajor_conv(sd["head.%s.conv.%d.weight" % (head, 2 * i)]), f32(sd["head.%s.conv.%d.bias" % (head, 2 * i)])) for i in range(4)]
+        P[head + "_out"] = (_kmajor_conv(sd["head.%s.%s.weight" % (head, last)]), f32(sd["head.%s.%s.bias" % (head, last)]))
+    P["anchors"] = np.stack([base_anchors(list(s), [0.5, 1.0, 2.0]) for s in retina_anchor_sizes()])  # [5][9][4]
+    return P
+
+
+def retina_backbone(P, x, keep=None):
+    """ResNet body (C3..C5) + FPN + LastLevelP6P7(256, 256) (retinanet_cal.py:618-619)."""
+    wk, bn = P["conv1"]
+    y = maxpool3x3s2(conv2d(x, wk, 7, 7, 2, 3, bn=bn, relu=True))
+    feats = []
+    for blk in P["blocks"]:
+        idn = y
+        if "down" in blk:
+            idn = conv2d(y, blk["down"][0], 1, 1, blk["stride"], 0, bn=blk["down"][1])
+        o = conv2d(y, blk["conv1"][0], 1, 1, 1, 0, bn=blk["conv1"][1], relu=True)
+        o = conv2d(o, blk["conv2"][0], 3, 3, blk["stride"], 1, bn=blk["conv2"][1], relu=True)
+        y = conv2d(o, blk["conv3"][0], 1, 1, 1, 0, bn=blk["conv3"][1], residual=idn, relu=True)
+        if blk["layer_end"]:
+            feats.append(y)
+    feats = feats[1:]   # returned_layers=[2, 3, 4]
+    if keep is not None: keep["C"] = feats
+    inner = [None] * 3
+    inner[2] = conv2d(feats[2], P["fpn_inner"][2][0], 1, 1, 1, 0, bias=P["fpn_inner"][2][1])
+    for i in (1, 0):
+        inner[i] = conv2d(feats[i], P["fpn_inner"][i][0], 1, 1, 1, 0, bias=P["fpn_inner"][i][1], up=inner[i + 1])
+    outs = [conv2d(inner[i], P["fpn_layer"][i][0], 3, 3, 1, 1, bias=P["fpn_layer"][i][1]) for i in range(3)]
+    p6 = conv2d(outs[2], P["p6"][0], 3, 3, 2, 1, bias=P["p6"][1])
+    p7 = conv2d(np.maximum(p6, np.float32(0.0)), P["p7"][0], 3, 3, 2, 1, bias=P["p7"][1])
+    return outs + [p6, p7]
+
+
+def retina_postprocess(cls, reg, anchors, Hp, Wp, Hr, Wr, Ho, Wo, K, A=9, score_thr=0.05, nms_thr=0.5, per_class=300):
+    L = len(cls)
+    cls = [f32(c) for c in cls]; reg = [f32(r) for r in reg]
+    cp = (c_f * L)(*[_p(c) for c in cls]); rp = (c_f * L)(*[_p(r) for r in reg])
+    fh = np.array([c.shape[0] for c in cls], np.int32); fw = np.array([c.shape[1] for c in cls], np.int32)
+    cap = K * per_class
+    ob = np.empty((cap, 4), np.float32); os_ = np.empty(cap, np.float32); ol = np.empty(cap, np.int64)
+    opm = np.empty(cap, np.float32); osc = np.empty((cap, K), np.float32)
+    anchors = f32(anchors)
+    n = lib().orc_retina_postprocess(C.c_int(L), cp, rp, _p(fh, c_i), _p(fw, c_i), C.c_int(A), C.c_int(K), _p(anchors),
+                                     C.c_int(Hp), C.c_int(Wp), C.c_int(Hr), C.c_int(Wr), C.c_int(Ho), C.c_int(Wo),
+                                     C.c_float(score_thr), C.c_float(nms_thr), C.c_int(per_class), C.c_float(1e-2),
+                                     _p(ob), _p(os_), ol.ctypes.data_as(C.POINTER(C.c_int64)), _p(opm), _p(osc))
+    return dict(boxes=ob[:n].copy(), scores=os_[:n].copy(), labels=ol[:n].copy(), prob_max=opm[:n].copy(), scores_cls=osc[:n].copy())
+
+
+def retina_forward(P, img, min_size, max_size, flip=False, rects=None, keep=None, score_thr=0.05, nms_thr=0.5, per_class=300):
+    """retinanet_cal.py:492-575 for ONE view."""
+    H, W, _ = img.shape
+    x, (Hr, Wr, Hp, Wp) = preprocess_view(img, min_size, max_size, flip, rects)
+    feats = retina_backbone(P, x, keep)
+    if keep is not None: keep["fpn"] = feats; keep["sizes"] = (Hr, Wr, Hp, Wp)
+    cls, reg = [], []
+    for f in feats:
+        t = f
+        for (wk, b) in P["classification_head"]:
+            t = conv2d(t, wk, 3, 3, 1, 1, bias=b, relu=True)
+        cls.append(conv2d(t, P["classification_head_out"][0], 3, 3, 1, 1, bias=P["classification_head_out"][1]))
+        t = f
+        for (wk, b) in P["regression_head"]:
+            t = conv2d(t, wk, 3, 3, 1, 1, bias=b, relu=True)
+        reg.append(conv2d(t, P["regression_head_out"][0], 3, 3, 1, 1, bias=P["regression_head_out"][1]))
+    if keep is not None: keep["cls"] = cls; keep["reg"] = reg
+    return retina_postprocess(cls, reg, P["anchors"], Hp, Wp, Hr, Wr, H, W, P["num_classes"], 9, score_thr, nms_thr, per_class)
+
+
+def detector_forward(P, img, min_size, max_size, flip=False, rects=None, keep=None):
+    if P.get("arch") == "retinanet":
+        return retina_forward(P, img, min_size, max_size, flip, rects, keep)
+    return frcnn_forward(P, img, min_size, max_size, flip, rects, keep)
+
+
 # ----------------------------------------------------------------------------- the sweep (A1)
 def image_seed(base_seed, pool_pos):
     return (int(base_seed) * 1000003 + int(pool_pos)) & 0xFFFFFFFFFFFFFFFF
@@ -419,12 +524,12 @@ def get_uncertainty(P, images, augs, num_cls, bp=1.3, min_size=600, max_size=100
     consistency_all, cls_all = [], []
     for pos, img in enumerate(images):
         gpos = pos if positions is None else positions[pos]
-        ref = subsample_ref(frcnn_forward(P, img, min_size, max_size))
+        ref = subsample_ref(detector_forward(P, img, min_size, max_size))
         if ref["boxes"].shape[0] == 0:
             c, cc = score_image(ref, [], [], num_cls, bp)
         else:
             views = build_views(img, augs, ref, image_seed(base_seed, gpos))
-            outs = [frcnn_forward(P, v[0], min_size, max_size, v[1], v[2]) for v in views]
+            outs = [detector_forward(P, v[0], min_size, max_size, v[1], v[2]) for v in views]
             c, cc = score_image(ref, outs, [v[3] for v in views], num_cls, bp)
         consistency_all.append(c); cls_all.append(cc)
     return consistency_all, cls_all

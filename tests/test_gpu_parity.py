@@ -179,3 +179,46 @@ def test_sweep_matches_oracle(hip, oracle, small_model):
     np.testing.assert_array_equal(cons, np.array(wc))
     np.testing.assert_array_equal(cls, np.stack(wcls))
     np.testing.assert_array_equal(np.argsort(cons), np.argsort(np.array(wc)))
+
+
+@pytest.fixture(scope="module")
+def small_retina(hip, oracle):
+    from cald_amd import synth
+    sd = synth.pseudo_trained_retinanet(21, 50, seed=0)
+    model = hip["det"].retinanet_resnet50_fpn_cal(num_classes=21, min_size=300, max_size=500)
+    model.to("cuda").load_state_dict(sd)
+    model.eval()
+    return model, oracle.prepare_retinanet(sd, 21, 50)
+
+
+def test_retinanet_forward_bit_exact(hip, oracle, small_retina):
+    """RetinaNet rows A21/A22: FPN+P6/P7, towers, per-class post-processing (label 0 included)."""
+    torch = hip["torch"]
+    from cald_amd import synth
+    model, P = small_retina
+    for idx, flip in ((1, False), (2, True)):
+        img = synth.make_pool(3, "voc", 0, scale=0.5)[idx]
+        keep = {}
+        want = oracle.retina_forward(P, img, 300, 500, flip=flip, keep=keep)
+        got = model.forward_views([(torch.from_numpy(img).cuda(), flip, None)])[0]
+        for i in range(5):
+            for name, w in (("P%d" % (i + 3), keep["fpn"][i]), ("cls%d" % i, keep["cls"][i]), ("reg%d" % i, keep["reg"][i])):
+                g = model.debug_tensor(name, 0)
+                assert g.shape == w.shape, (name, g.shape, w.shape)
+                assert g.tobytes() == w.tobytes(), "stage %s differs: max abs %g" % (name, float(np.abs(g - w).max()))
+        assert want["boxes"].shape[0] > 0 and (want["labels"] == 0).any()
+        for k in ("boxes", "scores", "labels", "prob_max", "scores_cls"):
+            assert got[k].cpu().numpy().tobytes() == want[k].tobytes(), "output %s differs" % k
+
+
+def test_retinanet_sweep_matches_oracle(hip, oracle, small_retina):
+    torch = hip["torch"]
+    from cald_amd import synth, sweep
+    model, P = small_retina
+    pool = synth.make_pool(4, "voc", 0, scale=0.5)
+    augs = ["flip", "cut_out", "smaller_resize"]
+    cons, cls = sweep.sweep_device_images(model, [torch.from_numpy(im).cuda() for im in pool], list(range(len(pool))), augs,
+                                          bp=1.3, base_seed=5, batch_images=4)
+    wc, wcls = oracle.get_uncertainty(P, pool, augs, 21, bp=1.3, min_size=300, max_size=500, base_seed=5)
+    np.testing.assert_array_equal(cons, np.array(wc))
+    np.testing.assert_array_equal(cls, np.stack(wcls))
