@@ -38,6 +38,7 @@ struct cald_ctx {
     char* arena = nullptr; size_t arena_cap = 0, arena_off = 0;
     BatchPlan* d_plan = nullptr;
     ViewDesc* d_views = nullptr;
+    float* d_zeros = nullptr;
     // pinned host staging ring for the per-forward plan + view descriptors (keeps the source of the
     // stream-ordered H2D copies alive without a host sync)
     static const int NSTAGE = 8;
@@ -87,6 +88,8 @@ extern "C" int cald_ctx_create(int device, void* stream, cald_ctx** out) {
     else { HIPCHK(hipStreamCreate(&c->stream)); c->own_stream = true; }
     HIPCHK(hipMalloc((void**)&c->d_plan, sizeof(BatchPlan)));
     HIPCHK(hipMalloc((void**)&c->d_views, sizeof(ViewDesc) * CALD_MAX_VIEWS));
+    HIPCHK(hipMalloc((void**)&c->d_zeros, 256));
+    HIPCHK(hipMemset(c->d_zeros, 0, 256));
     for (int i = 0; i < cald_ctx::NSTAGE; i++) {
         HIPCHK(hipHostMalloc((void**)&c->h_stage[i], sizeof(BatchPlan) + sizeof(ViewDesc) * CALD_MAX_VIEWS));
         HIPCHK(hipEventCreateWithFlags(&c->stage_ev[i], hipEventDisableTiming));
@@ -110,7 +113,7 @@ extern "C" int cald_ctx_destroy(cald_ctx* c) {
     if (c->tot1) hipEventDestroy(c->tot1);
     if (c->arena) hipFree(c->arena);
     for (int i = 0; i < cald_ctx::NSTAGE; i++) { if (c->h_stage[i]) hipHostFree(c->h_stage[i]); if (c->stage_ev[i]) hipEventDestroy(c->stage_ev[i]); }
-    hipFree(c->d_plan); hipFree(c->d_views);
+    hipFree(c->d_plan); hipFree(c->d_views); hipFree(c->d_zeros);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
     return 0;
@@ -445,7 +448,7 @@ static int make_conv(cald_model* m, ConvLayer& L, const std::vector<std::string>
     int cinp = cin_pad_to > cin ? cin_pad_to : cin;
     if (cinp % 4) return fail(CALD_ERR_INVALID, "Cin must be a multiple of 4");
     L.Cin = cinp; L.CinTrue = cin; L.Cout = cout; L.CoutPad = cout_pad(cout); L.KH = kh; L.KW = kw; L.stride = stride; L.pad = pad;
-    L.K = kh * kw * cinp; L.Kpad = round_up(L.K, 16);
+    L.K = kh * kw * cinp; L.Kpad = round_up(L.K, 32);
     std::vector<float> w((size_t)L.Kpad * L.CoutPad, 0.0f);
     int co0 = 0;
     for (auto t : ws) {
@@ -640,7 +643,7 @@ static int conv_on(cald_model* m, const ConvLayer& L, const float* in, float* ou
     a.Cin = L.Cin; a.Cout = L.Cout; a.CoutPad = L.CoutPad; a.Kpad = L.Kpad;
     a.KH = L.KH; a.KW = L.KW; a.stride = L.stride; a.pad = L.pad; a.relu = relu ? 1 : 0;
     a.total_mtiles = level_tiles(m->plan, lout, V);
-    a.out_ld = L.Cout; a.in_relu = in_relu ? 1 : 0;
+    a.out_ld = L.Cout; a.in_relu = in_relu ? 1 : 0; a.zeros = m->ctx->d_zeros;
     double flops = 2.0 * (double)level_pix(m->plan, lout, V) * (double)L.Cout * (double)(L.KH * L.KW * L.CinTrue);
     return run_conv(m->ctx, a, flops);
 }
@@ -896,7 +899,7 @@ extern "C" int cald_op_conv2d(cald_ctx* c, const float* in, int H, int W, int Ci
     if (Cin % 4) return fail(CALD_ERR_INVALID, "Cin must be a multiple of 4");
     HIPCHK(hipSetDevice(c->device));
     const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
-    const int CoutPad = cout_pad(Cout), K = KH * KW * Cin, Kpad = round_up(K, 16);
+    const int CoutPad = cout_pad(Cout), K = KH * KW * Cin, Kpad = round_up(K, 32);
     std::vector<float> w((size_t)Kpad * CoutPad, 0.0f), b(CoutPad, 0.0f), sc(CoutPad, 0.0f), sh(CoutPad, 0.0f);
     for (int co = 0; co < Cout; co++)
         for (int ci = 0; ci < Cin; ci++)
@@ -923,7 +926,7 @@ extern "C" int cald_op_conv2d(cald_ctx* c, const float* in, int H, int W, int Ci
     a.in = d_in; a.out = d_out; a.w = d_w; a.bias = bias ? d_b : nullptr; a.scale = bn_scale ? d_sc : nullptr; a.shift = bn_scale ? d_sh : nullptr;
     a.residual = d_res; a.up = nullptr; a.seg_in = d_p->seg[0]; a.seg_out = d_p->seg[1]; a.seg_up = d_p->seg[1]; a.dyn_rows = nullptr;
     a.V = 1; a.Cin = Cin; a.Cout = Cout; a.CoutPad = CoutPad; a.Kpad = Kpad; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
-    a.relu = relu; a.total_mtiles = (Ho * Wo + 127) / 128; a.out_ld = Cout; a.in_relu = 0;
+    a.relu = relu; a.total_mtiles = (Ho * Wo + 127) / 128; a.out_ld = Cout; a.in_relu = 0; a.zeros = c->d_zeros;
     launch_conv(a, c->stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));

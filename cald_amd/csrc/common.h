@@ -43,6 +43,7 @@ struct ConvArgs {
     int relu;
     int total_mtiles;
     int out_ld;            // output row stride in floats (== Cout normally)
+    const float* zeros;    // >= 16 bytes of zeros, 16-byte aligned (source of out-of-image taps)
     int in_relu;           // apply ReLU to the input while gathering (LastLevelP6P7: p7(relu(p6)))
 };
 

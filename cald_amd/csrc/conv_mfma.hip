@@ -19,15 +19,19 @@
 //   Epilogue:   (+bias) -> (*bn_scale, +bn_shift) -> (+residual) -> (+nearest-upsampled top-down)
 //               -> ReLU, fused; residual rows are loaded as a batch before the stores.
 #include "common.h"
+#include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int WM, int WN, int TM, int TN, int EPI>
-__global__ __launch_bounds__(256, 3) void conv_mfma_f32_kernel(const ConvArgs a) {
-    constexpr int BM = WM * TM * 32, BN = WN * TN * 32, BK = 16;
-    constexpr int SA = BM + 2;
+template <int WM, int WN, int TM, int TN, int EPI, int BK, bool FAST>
+__global__ __launch_bounds__(256, (BK == 32 ? 2 : 3)) void conv_mfma_f32_kernel(const ConvArgs a) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int SA = BM + (BK == 16 ? 2 : 1);       // makes the transposing ds_write_b32 conflict-free
     constexpr int SB = BN;
-    constexpr int B_F4 = BK * BN / 4;                 // float4 in one B tile: 512 / 256 / 128
+    constexpr int KG = BK / 4;                        // float4 k-groups per A row
+    constexpr int RP = 256 / KG;                      // A rows loaded per pass
+    constexpr int PA = BM / RP;                       // A float4 per thread per k-tile
+    constexpr int B_F4 = BK * BN / 4;                 // float4 in one B tile
     constexpr int PB = (B_F4 + 255) / 256;
     static_assert(WM * WN == 4 && BM == 128, "4 waves, 128-row tile");
     __shared__ __attribute__((aligned(16))) float smem[2 * BK * SA + 2 * BK * SB];
@@ -65,54 +69,97 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_f32_kernel(const ConvArgs a)
     const float* __restrict__ wgt = a.w;
     const int Cin = a.Cin, KW = a.KW, KH = a.KH, CoutPad = a.CoutPad;
     const bool in_relu = a.in_relu != 0;
+    const float* __restrict__ zpage = a.zeros;
 
-    // ---- per-thread A gather state: rows (tid>>2) and (tid>>2)+64, k group g = tid&3 ----
-    const int g = tid & 3, arow = tid >> 2;
-    const int mA0 = m0 + arow, mA1 = mA0 + 64;
-    const bool rv0 = mA0 < Mv, rv1 = mA1 < Mv;
-    const int oyA0 = mA0 / Wo, oxA0 = mA0 - oyA0 * Wo;
-    const int oyA1 = mA1 / Wo, oxA1 = mA1 - oyA1 * Wo;
-    const int iy00 = oyA0 * a.stride - a.pad, ix00 = oxA0 * a.stride - a.pad;
-    const int iy01 = oyA1 * a.stride - a.pad, ix01 = oxA1 * a.stride - a.pad;
+    // ---- per-thread A gather state: rows arow + RP*p, k group g (4 consecutive k) ----
+    const int g = tid % KG, arow = tid / KG;
+    int iy0[PA], ix0[PA];
+    bool rvalid[PA];
+#pragma unroll
+    for (int p = 0; p < PA; p++) {
+        const int m = m0 + arow + RP * p;
+        rvalid[p] = m < Mv;
+        const int oy = m / Wo, ox = m - oy * Wo;
+        iy0[p] = oy * a.stride - a.pad;
+        ix0[p] = ox * a.stride - a.pad;
+    }
     int ci = (4 * g) % Cin;
     int kh, kw;
     { const int tap = (4 * g) / Cin; kh = tap / KW; kw = tap - kh * KW; }
-    // B tile mapping
-    const int bk0 = tid / (BN / 4), bc0 = tid % (BN / 4);            // first float4
-    const int bk1 = (tid + 256) / (BN / 4), bc1 = (tid + 256) % (BN / 4);
-    const bool b0ok = (B_F4 >= 256) || (tid < B_F4);
+    // FAST path (Cin % BK == 0: a k-tile lies inside one tap): per-row tap-validity bit mask and element
+    // offset are computed once; per k-tile only a wave-uniform offset is added (VALU instructions steal
+    // issue cycles from the fp32 MFMA pipe, so the main loop keeps them to a minimum).
+    unsigned rowmask[PA];
+    int rowoff[PA];
+    int u_kh = 0, u_kw = 0, u_ci = 0;                 // wave-uniform cursor
+    if (FAST) {
+#pragma unroll
+        for (int p = 0; p < PA; p++) {
+            unsigned msk = 0;
+            if (rvalid[p])
+                for (int t = 0; t < KH * KW; t++) {
+                    const int th = t / KW, tw = t - th * KW;
+                    const int iy = iy0[p] + th, ix = ix0[p] + tw;
+                    if (iy >= 0 && iy < Hi && ix >= 0 && ix < Wi) msk |= 1u << t;
+                }
+            rowmask[p] = msk;
+            rowoff[p] = (iy0[p] * Wi + ix0[p]) * Cin + 4 * g;
+        }
+    }
 
-    float4 ra0, ra1, rb0, rb1;
+    float rax[PA], ray[PA], raz[PA], raw[PA];
+    float rbx[PB], rby[PB], rbz[PB], rbw[PB];
     const int KT = a.Kpad / BK;
 
 #define LOAD_TILE(KTI)                                                                                     \
     {                                                                                                      \
-        const int iy0 = iy00 + kh, ix0 = ix00 + kw, iy1 = iy01 + kh, ix1 = ix01 + kw;                      \
-        const bool ok0 = rv0 && kh < KH && iy0 >= 0 && iy0 < Hi && ix0 >= 0 && ix0 < Wi;                   \
-        const bool ok1 = rv1 && kh < KH && iy1 >= 0 && iy1 < Hi && ix1 >= 0 && ix1 < Wi;                   \
-        const long long o0 = ok0 ? ((long long)(iy0 * Wi + ix0) * Cin + ci) : 0ll;                         \
-        const long long o1 = ok1 ? ((long long)(iy1 * Wi + ix1) * Cin + ci) : 0ll;                         \
-        const float4 t0 = *reinterpret_cast<const float4*>(in_v + o0);                                     \
-        const float4 t1 = *reinterpret_cast<const float4*>(in_v + o1);                                     \
-        ra0.x = ok0 ? t0.x : 0.0f; ra0.y = ok0 ? t0.y : 0.0f; ra0.z = ok0 ? t0.z : 0.0f; ra0.w = ok0 ? t0.w : 0.0f; \
-        ra1.x = ok1 ? t1.x : 0.0f; ra1.y = ok1 ? t1.y : 0.0f; ra1.z = ok1 ? t1.z : 0.0f; ra1.w = ok1 ? t1.w : 0.0f; \
-        if (in_relu) {                                                                                     \
-            ra0.x = ra0.x < 0.0f ? 0.0f : ra0.x; ra0.y = ra0.y < 0.0f ? 0.0f : ra0.y; ra0.z = ra0.z < 0.0f ? 0.0f : ra0.z; ra0.w = ra0.w < 0.0f ? 0.0f : ra0.w; \
-            ra1.x = ra1.x < 0.0f ? 0.0f : ra1.x; ra1.y = ra1.y < 0.0f ? 0.0f : ra1.y; ra1.z = ra1.z < 0.0f ? 0.0f : ra1.z; ra1.w = ra1.w < 0.0f ? 0.0f : ra1.w; \
+        const int u_tap = u_kh * KW + u_kw;                                                                \
+        const int u_off = (u_kh * Wi + u_kw) * Cin + u_ci;                                                 \
+        _Pragma("unroll") for (int p = 0; p < PA; p++) {                                                   \
+            /* out-of-image taps read a zero page: no select after the load, so it stays in flight */     \
+            const float* src;                                                                              \
+            if (FAST) {                                                                                    \
+                const bool ok = (rowmask[p] >> u_tap) & 1u;                                                \
+                src = ok ? (in_v + (rowoff[p] + u_off)) : zpage;                                           \
+            } else {                                                                                       \
+                const int iy = iy0[p] + kh, ix = ix0[p] + kw;                                              \
+                const bool ok = rvalid[p] && kh < KH && iy >= 0 && iy < Hi && ix >= 0 && ix < Wi;          \
+                src = ok ? (in_v + ((long long)(iy * Wi + ix) * Cin + ci)) : zpage;                        \
+            }                                                                                              \
+            const float4 t = *reinterpret_cast<const float4*>(src);                                        \
+            rax[p] = t.x; ray[p] = t.y; raz[p] = t.z; raw[p] = t.w;                                        \
         }                                                                                                  \
-        if (b0ok) rb0 = *reinterpret_cast<const float4*>(wgt + (long long)((KTI) * BK + bk0) * CoutPad + n0 + 4 * bc0); \
-        if (PB > 1) rb1 = *reinterpret_cast<const float4*>(wgt + (long long)((KTI) * BK + bk1) * CoutPad + n0 + 4 * bc1); \
-        ci += BK;                                                                                          \
-        while (ci >= Cin) { ci -= Cin; kw++; if (kw == KW) { kw = 0; kh++; } }                             \
+        _Pragma("unroll") for (int p = 0; p < PB; p++) {                                                   \
+            const int f = tid + 256 * p;                                                                   \
+            if (B_F4 >= 256 * (p + 1) || f < B_F4) {                                                       \
+                const float4 t = *reinterpret_cast<const float4*>(wgt + (long long)((KTI) * BK + f / (BN / 4)) * CoutPad + n0 + 4 * (f % (BN / 4))); \
+                rbx[p] = t.x; rby[p] = t.y; rbz[p] = t.z; rbw[p] = t.w;                                    \
+            }                                                                                              \
+        }                                                                                                  \
+        if (FAST) {                                                                                        \
+            u_ci += BK;                                                                                    \
+            if (u_ci >= Cin) { u_ci = 0; u_kw++; if (u_kw == KW) { u_kw = 0; u_kh++; } }                   \
+        } else {                                                                                           \
+            ci += BK;                                                                                      \
+            while (ci >= Cin) { ci -= Cin; kw++; if (kw == KW) { kw = 0; kh++; } }                         \
+        }                                                                                                  \
     }
 #define STORE_TILE(BUF)                                                                                    \
     {                                                                                                      \
         float* dA = sA + (BUF) * BK * SA + (4 * g) * SA + arow;                                            \
-        dA[0] = ra0.x; dA[SA] = ra0.y; dA[2 * SA] = ra0.z; dA[3 * SA] = ra0.w;                             \
-        dA[64] = ra1.x; dA[SA + 64] = ra1.y; dA[2 * SA + 64] = ra1.z; dA[3 * SA + 64] = ra1.w;             \
+        _Pragma("unroll") for (int p = 0; p < PA; p++) {                                                   \
+            if (in_relu) {                                                                                 \
+                rax[p] = rax[p] < 0.0f ? 0.0f : rax[p]; ray[p] = ray[p] < 0.0f ? 0.0f : ray[p];            \
+                raz[p] = raz[p] < 0.0f ? 0.0f : raz[p]; raw[p] = raw[p] < 0.0f ? 0.0f : raw[p];            \
+            }                                                                                              \
+            dA[RP * p] = rax[p]; dA[SA + RP * p] = ray[p]; dA[2 * SA + RP * p] = raz[p]; dA[3 * SA + RP * p] = raw[p]; \
+        }                                                                                                  \
         float* dB = sB + (BUF) * BK * SB;                                                                  \
-        if (b0ok) *reinterpret_cast<float4*>(dB + bk0 * SB + 4 * bc0) = rb0;                               \
-        if (PB > 1) *reinterpret_cast<float4*>(dB + bk1 * SB + 4 * bc1) = rb1;                             \
+        _Pragma("unroll") for (int p = 0; p < PB; p++) {                                                   \
+            const int f = tid + 256 * p;                                                                   \
+            if (B_F4 >= 256 * (p + 1) || f < B_F4)                                                         \
+                *reinterpret_cast<float4*>(dB + (f / (BN / 4)) * SB + 4 * (f % (BN / 4))) = make_float4(rbx[p], rby[p], rbz[p], rbw[p]); \
+        }                                                                                                  \
     }
 
     f32x16 acc[TM][TN];
@@ -218,16 +265,26 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_f32_kernel(const ConvArgs a)
     }
 }
 
-template <int WM, int WN, int TM, int TN>
+static int conv_env(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+template <int WM, int WN, int TM, int TN, int BK>
 static void launch_cfg(const ConvArgs& a, int bn, hipStream_t stream) {
     dim3 grid((unsigned)(a.total_mtiles * (a.CoutPad / bn))), block(256);
-    if (a.residual) hipLaunchKernelGGL((conv_mfma_f32_kernel<WM, WN, TM, TN, 1>), grid, block, 0, stream, a);
-    else if (a.up) hipLaunchKernelGGL((conv_mfma_f32_kernel<WM, WN, TM, TN, 2>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((conv_mfma_f32_kernel<WM, WN, TM, TN, 0>), grid, block, 0, stream, a);
+    static const int dl = conv_env("CALD_CONV_DYNLDS", 0);   // extra dynamic LDS (experiments): caps workgroups per CU
+    const bool fast = (a.Cin % BK == 0) && (a.KH * a.KW <= 32);
+    if (!fast) { hipLaunchKernelGGL((conv_mfma_f32_kernel<WM, WN, TM, TN, 0, BK, false>), grid, block, dl, stream, a); return; }
+    if (a.residual) hipLaunchKernelGGL((conv_mfma_f32_kernel<WM, WN, TM, TN, 1, BK, true>), grid, block, dl, stream, a);
+    else if (a.up) hipLaunchKernelGGL((conv_mfma_f32_kernel<WM, WN, TM, TN, 2, BK, true>), grid, block, dl, stream, a);
+    else hipLaunchKernelGGL((conv_mfma_f32_kernel<WM, WN, TM, TN, 0, BK, true>), grid, block, dl, stream, a);
 }
 
 void launch_conv(const ConvArgs& a, hipStream_t stream) {
-    if (a.CoutPad % 128 == 0) launch_cfg<2, 2, 2, 2>(a, 128, stream);
-    else if (a.CoutPad % 64 == 0) launch_cfg<2, 2, 2, 1>(a, 64, stream);
-    else launch_cfg<4, 1, 1, 1>(a, 32, stream);
+    static const int bk32 = conv_env("CALD_CONV_BK32", 0);
+    if (a.CoutPad % 128 == 0) {
+        if (bk32 && a.Kpad % 32 == 0) launch_cfg<2, 2, 2, 2, 32>(a, 128, stream);
+        else launch_cfg<2, 2, 2, 2, 16>(a, 128, stream);
+    } else if (a.CoutPad % 64 == 0) launch_cfg<2, 2, 2, 1, 16>(a, 64, stream);
+    else launch_cfg<4, 1, 1, 1, 16>(a, 32, stream);
 }
