@@ -30,6 +30,7 @@ extern "C" int cald_version(void) { return 100; }
 // context
 // =============================================================================================
 struct PilCoef { int ksize; int* d_bounds; int* d_kk; };
+struct PilKey { int in, out, fid; bool operator<(const PilKey& o) const { return in != o.in ? in < o.in : (out != o.out ? out < o.out : fid < o.fid); } };
 
 struct cald_ctx {
     int device = 0;
@@ -48,7 +49,7 @@ struct cald_ctx {
     double prof_flops = 0.0;
     std::vector<std::string> prof_desc; std::vector<double> prof_fl;
     hipEvent_t tot0 = nullptr, tot1 = nullptr; bool tot_open = false; double tot_ms = 0.0;
-    std::map<std::pair<int, int>, PilCoef> pil;
+    std::map<PilKey, PilCoef> pil;
 };
 
 static int arena_reserve(cald_ctx* c, size_t bytes) {
@@ -293,11 +294,18 @@ static double np_sum(const double* a, int n) {
     return np_sum(a, n2) + np_sum(a + n2, n - n2);
 }
 
-// Pillow Resample.c precompute_coeffs + normalize_coeffs_8bpc for the BILINEAR filter
-static int pil_coeffs(int inSize, int outSize, std::vector<int>& bounds, std::vector<int>& kk) {
+// Pillow Resample.c precompute_coeffs + normalize_coeffs_8bpc; fid 0 = BILINEAR (support 1), 1 = BICUBIC (support 2, a = -0.5)
+static double pil_filter(int fid, double x) {
+    if (x < 0.0) x = -x;
+    if (fid == 0) return x < 1.0 ? 1.0 - x : 0.0;
+    if (x < 1.0) return ((-0.5 + 2.0) * x - (-0.5 + 3.0)) * x * x + 1;
+    if (x < 2.0) return (((x - 5) * x + 8) * x - 4) * -0.5;
+    return 0.0;
+}
+static int pil_coeffs(int inSize, int outSize, int fid, std::vector<int>& bounds, std::vector<int>& kk) {
     double scale = (double)inSize / (double)outSize, filterscale = scale;
     if (filterscale < 1.0) filterscale = 1.0;
-    double support = 1.0 * filterscale;
+    double support = (fid == 0 ? 1.0 : 2.0) * filterscale;
     int ksize = (int)std::ceil(support) * 2 + 1;
     std::vector<double> pre((size_t)outSize * ksize);
     bounds.assign((size_t)outSize * 2, 0); kk.assign((size_t)outSize * ksize, 0);
@@ -309,8 +317,7 @@ static int pil_coeffs(int inSize, int outSize, std::vector<int>& bounds, std::ve
         double* k = &pre[(size_t)xx * ksize];
         int x;
         for (x = 0; x < xmax; x++) {
-            double t = (x + xmin - center + 0.5) * ss; if (t < 0) t = -t;
-            double w = t < 1.0 ? 1.0 - t : 0.0;
+            double w = pil_filter(fid, (x + xmin - center + 0.5) * ss);
             k[x] = w; ww += w;
         }
         for (x = 0; x < xmax; x++) if (ww != 0.0) k[x] /= ww;
@@ -321,12 +328,12 @@ static int pil_coeffs(int inSize, int outSize, std::vector<int>& bounds, std::ve
         kk[i] = pre[i] < 0 ? (int)(-0.5 + pre[i] * (double)(1 << 22)) : (int)(0.5 + pre[i] * (double)(1 << 22));
     return ksize;
 }
-static int get_pil(cald_ctx* c, int inSize, int outSize, PilCoef* out) {
-    auto key = std::make_pair(inSize, outSize);
+static int get_pil(cald_ctx* c, int inSize, int outSize, int fid, PilCoef* out) {
+    PilKey key{inSize, outSize, fid};
     auto it = c->pil.find(key);
     if (it == c->pil.end()) {
         std::vector<int> b, k;
-        PilCoef pc; pc.ksize = pil_coeffs(inSize, outSize, b, k);
+        PilCoef pc; pc.ksize = pil_coeffs(inSize, outSize, fid, b, k);
         HIPCHK(hipMalloc((void**)&pc.d_bounds, b.size() * sizeof(int)));
         HIPCHK(hipMalloc((void**)&pc.d_kk, k.size() * sizeof(int)));
         HIPCHK(hipMemcpy(pc.d_bounds, b.data(), b.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -337,22 +344,61 @@ static int get_pil(cald_ctx* c, int inSize, int outSize, PilCoef* out) {
     return 0;
 }
 // dst [oh][ow][3]; tmp must hold H*ow*3 bytes
-static int pil_resize(cald_ctx* c, const uint8_t* src, int H, int W, uint8_t* dst, int oh, int ow, uint8_t* tmp) {
+static int pil_resize(cald_ctx* c, const uint8_t* src, int H, int W, uint8_t* dst, int oh, int ow, uint8_t* tmp, int fid = 0) {
     const uint8_t* cur = src;
     if (ow != W) {
-        PilCoef pc; int rc = get_pil(c, W, ow, &pc); if (rc) return rc;
+        PilCoef pc; int rc = get_pil(c, W, ow, fid, &pc); if (rc) return rc;
         uint8_t* hdst = (oh != H) ? tmp : dst;
         launch_pil_horizontal(src, H, W, hdst, ow, pc.d_bounds, pc.d_kk, pc.ksize, c->stream);
         cur = hdst;
     }
     if (oh != H) {
-        PilCoef pc; int rc = get_pil(c, H, oh, &pc); if (rc) return rc;
+        PilCoef pc; int rc = get_pil(c, H, oh, fid, &pc); if (rc) return rc;
         launch_pil_vertical(cur, H, ow, dst, oh, pc.d_bounds, pc.d_kk, pc.ksize, c->stream);
     } else if (ow == W) {
         HIPCHK(hipMemcpyAsync(dst, src, (size_t)H * W * 3, hipMemcpyDeviceToDevice, c->stream));
     }
     return 0;
 }
+// PIL Image.rotate(angle, expand=True): matrix arithmetic of Image.rotate (python floats, round(., 15)),
+// then the FIX()ed 16.16 coefficients of Geometry.c affine_fixed.  (cald_helper.py:153)
+static double py_round15(double v) { char buf[64]; snprintf(buf, sizeof(buf), "%.15f", v); return strtod(buf, nullptr); }
+static int pil_fix(double v) { double t = v * 65536.0 + 0.5; return t < 0.0 ? (int)std::floor(t) : (int)t; }
+static void pil_rotate_setup(int H, int W, double angle_deg, int fix[6], int* nH, int* nW) {
+    double angle = std::fmod(angle_deg, 360.0); if (angle < 0) angle += 360.0;
+    const double w = (double)W, h = (double)H, cx = w / 2.0, cy = h / 2.0;
+    const double ang = -(angle * (3.141592653589793 / 180.0));
+    double m[6] = {py_round15(std::cos(ang)), py_round15(std::sin(ang)), 0.0, py_round15(-std::sin(ang)), py_round15(std::cos(ang)), 0.0};
+    double m2 = m[0] * -cx + m[1] * -cy + m[2], m5 = m[3] * -cx + m[4] * -cy + m[5];
+    m[2] = m2 + cx; m[5] = m5 + cy;
+    const double xs[4] = {0, w, w, 0}, ys[4] = {0, 0, h, h};
+    double xmin = 0, xmax = 0, ymin = 0, ymax = 0;
+    for (int i = 0; i < 4; i++) {
+        const double X = m[0] * xs[i] + m[1] * ys[i] + m[2], Y = m[3] * xs[i] + m[4] * ys[i] + m[5];
+        if (i == 0 || X < xmin) xmin = X; if (i == 0 || X > xmax) xmax = X;
+        if (i == 0 || Y < ymin) ymin = Y; if (i == 0 || Y > ymax) ymax = Y;
+    }
+    const int nw = (int)std::ceil(xmax) - (int)std::floor(xmin), nh = (int)std::ceil(ymax) - (int)std::floor(ymin);
+    const double px = -(nw - W) / 2.0, py = -(nh - H) / 2.0;
+    m2 = m[0] * px + m[1] * py + m[2]; m5 = m[3] * px + m[4] * py + m[5];
+    m[2] = m2; m[5] = m5;
+    fix[0] = pil_fix(m[0]); fix[1] = pil_fix(m[1]); fix[3] = pil_fix(m[3]); fix[4] = pil_fix(m[4]);
+    fix[2] = pil_fix(m[2] + m[0] * 0.5 + m[1] * 0.5); fix[5] = pil_fix(m[5] + m[3] * 0.5 + m[4] * 0.5);
+    *nH = nh; *nW = nw;
+}
+// cald_helper.rotate box transform constants (cald_helper.py:135-222): float32 affine matrix, scale, clamp bounds
+static void rotate_box_params(int H, int W, double angle_deg, int pilW, int pilH, float* p /*12*/) {
+    const double ang = angle_deg * (3.141592653589793 / 180.0);
+    const double alpha = std::cos(ang), beta = std::sin(ang), cx = W / 2.0, cy = H / 2.0;
+    double m02 = (1 - alpha) * cx - beta * cy, m12 = beta * cx + (1 - alpha) * cy;
+    const double c_ = std::fabs(alpha), s_ = std::fabs(beta);
+    const int nW = (int)((H * s_) + (W * c_)), nH = (int)((H * c_) + (W * s_));
+    m02 += (nW / 2.0) - cx; m12 += (nH / 2.0) - cy;
+    p[0] = (float)alpha; p[1] = (float)beta; p[2] = (float)m02; p[3] = (float)(-beta); p[4] = (float)alpha; p[5] = (float)m12;
+    p[6] = (float)((double)pilW / (double)W); p[7] = (float)((double)pilH / (double)H); p[8] = (float)W; p[9] = (float)H;
+    p[10] = p[11] = 0.0f;
+}
+
 extern "C" int cald_op_pil_resize(cald_ctx* c, const uint8_t* src_dev, int H, int W, uint8_t* dst_dev, int oh, int ow) {
     if (!c || !src_dev || !dst_dev || H <= 0 || W <= 0 || oh <= 0 || ow <= 0) return fail(CALD_ERR_INVALID, "bad arguments");
     uint8_t* tmp = nullptr;
@@ -974,9 +1020,9 @@ extern "C" int cald_op_consistency(cald_ctx* c, int N, const float* aug_box, con
     for (int i = 0; i < 50; i++) h[4 + i] = i;
     h[54] = N;
     int* dh; float* dpar; float* dcons;
-    HIPCHK(hipMalloc((void**)&dh, sizeof(h))); HIPCHK(hipMalloc((void**)&dpar, 4)); HIPCHK(hipMalloc((void**)&dcons, 4));
+    HIPCHK(hipMalloc((void**)&dh, sizeof(h))); HIPCHK(hipMalloc((void**)&dpar, 48)); HIPCHK(hipMalloc((void**)&dcons, 4));
     HIPCHK(hipMemcpy(dh, h, sizeof(h), hipMemcpyHostToDevice));
-    float zero = 0.f; HIPCHK(hipMemcpy(dpar, &zero, 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(dpar, 0, 48));
     ScoreArgs a; a.det = d; a.ref_view = dh; a.aug_view = dh + 1; a.aug_kind = dh + 2; a.pair_img = dh + 3; a.ref_sel = dh + 4; a.ref_n = dh + 54;
     a.aug_param = dpar; a.P = 1; a.bp = bp; a.cons = dcons;
     launch_consistency(a, c->stream);
@@ -1014,7 +1060,8 @@ extern "C" int cald_sweep(cald_model* m, int n_images, const uint8_t* const* ima
     cald_ctx* c = m->ctx;
     HIPCHK(hipSetDevice(c->device));
     const int C = m->cfg.num_classes, cap = m->det_cap();
-    const int A = (cfg->aug_flip ? 1 : 0) + (cfg->aug_cutout ? 1 : 0) + (cfg->aug_resize ? 1 : 0);
+    const int A = (cfg->aug_flip ? 1 : 0) + (cfg->aug_sp ? 1 : 0) + (cfg->aug_cutout ? 1 : 0) + (cfg->aug_resize ? 1 : 0) +
+                  (cfg->aug_rotate ? 1 : 0);
     int B = cfg->batch_images > 0 ? cfg->batch_images : 64;
     if (B > CALD_MAX_VIEWS) B = CALD_MAX_VIEWS;
     const int VT = B * (1 + A);
@@ -1024,21 +1071,22 @@ extern "C" int cald_sweep(cald_model* m, int n_images, const uint8_t* const* ima
         m->sweep_det_views = VT;
     }
     DetBuffers& D = m->sweep_det;
-    // small device scratch for the scoring stage + resized images
+    // small device scratch for the scoring stage + an arena for augmented uint8 images
     int *d_ints = nullptr; float *d_par = nullptr, *d_cons = nullptr, *d_clsc = nullptr;
+    SaltPepperJob* d_jobs = nullptr;
     const int P_MAX = B * (A > 0 ? A : 1);
     const size_t n_ints = (size_t)P_MAX * 4 + (size_t)B * 51 + (size_t)VT * 2;
-    HIPCHK(hipMalloc((void**)&d_ints, n_ints * 4)); HIPCHK(hipMalloc((void**)&d_par, (size_t)P_MAX * 4));
+    HIPCHK(hipMalloc((void**)&d_ints, n_ints * 4)); HIPCHK(hipMalloc((void**)&d_par, (size_t)P_MAX * 12 * 4));
     HIPCHK(hipMalloc((void**)&d_cons, (size_t)P_MAX * 4)); HIPCHK(hipMalloc((void**)&d_clsc, (size_t)VT * (C - 1) * 4));
-    std::vector<uint8_t*> rsz(B, nullptr); std::vector<size_t> rsz_cap(B, 0);
-    uint8_t* d_tmp = nullptr; size_t tmp_cap = 0;
+    HIPCHK(hipMalloc((void**)&d_jobs, sizeof(SaltPepperJob) * B));
+    uint8_t* d_aug = nullptr; size_t aug_cap = 0;
     int rc = 0;
     std::vector<int> h_count(VT); std::vector<float> h_boxes((size_t)B * cap * 4), h_cons(P_MAX), h_clsc((size_t)VT * (C - 1));
     auto cleanup = [&]() {
         hipStreamSynchronize(c->stream);
-        hipFree(d_ints); hipFree(d_par); hipFree(d_cons); hipFree(d_clsc); hipFree(d_tmp);
-        for (auto p : rsz) if (p) hipFree(p);
+        hipFree(d_ints); hipFree(d_par); hipFree(d_cons); hipFree(d_clsc); hipFree(d_jobs); hipFree(d_aug);
     };
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     for (int i0 = 0; i0 < n_images && !rc; i0 += B) {
         const int nb = (n_images - i0 < B) ? n_images - i0 : B;
         // ---- phase 1: reference views ----
@@ -1052,40 +1100,85 @@ extern "C" int cald_sweep(cald_model* m, int n_images, const uint8_t* const* ima
         if (hipMemcpyAsync(h_count.data(), D.count, (size_t)nb * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
             hipMemcpyAsync(h_boxes.data(), D.boxes, (size_t)nb * cap * 16, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
             hipStreamSynchronize(c->stream) != hipSuccess) { rc = fail(CALD_ERR_HIP, "D2H of reference detections failed"); break; }
-        // ---- host: sub-sample, build augmented views ----
+        // ---- host: sub-sample, size the augmented-image arena ----
         std::vector<int> ref_sel((size_t)B * 50, 0), ref_n(B, 0), pair_ref, pair_aug, pair_kind, pair_img, view_img(VT, 0), view_isref(VT, 0);
         std::vector<float> pair_par;
         std::vector<ViewDesc> aviews;
+        std::vector<SaltPepperJob> jobs;
+        size_t need = 0;
+        for (int i = 0; i < nb; i++) {
+            if (h_count[i] == 0) continue;
+            const int Hi = H[i0 + i], Wi = W[i0 + i];
+            if (cfg->aug_sp) need += al((size_t)Hi * Wi * 3);
+            if (cfg->aug_resize) {
+                const int ow = (int)((double)Wi * (double)cfg->resize_ratio), oh = (int)((double)Hi * (double)cfg->resize_ratio);
+                need += al((size_t)oh * ow * 3) + al((size_t)Hi * ow * 3);
+            }
+            if (cfg->aug_rotate) {
+                int fx[6], nh, nw; pil_rotate_setup(Hi, Wi, (double)cfg->rotate_angle, fx, &nh, &nw);
+                need += al((size_t)nh * nw * 3) + al((size_t)nh * Wi * 3) + al((size_t)Hi * Wi * 3);
+            }
+        }
+        if (need > aug_cap) {
+            if (d_aug) hipFree(d_aug);
+            d_aug = nullptr; aug_cap = 0;
+            if (hipMalloc((void**)&d_aug, need + (need >> 2)) != hipSuccess) { rc = fail(CALD_ERR_HIP, "hipMalloc of the augmentation arena failed"); break; }
+            aug_cap = need + (need >> 2);
+        }
+        size_t aug_off = 0;
+        auto take = [&](size_t bytes) { uint8_t* p = d_aug + aug_off; aug_off += al(bytes); return p; };
+        // ---- host: build augmented views in the reference's order (cald_train.py:124-183) ----
         for (int i = 0; i < nb; i++) {
             view_img[i] = i; view_isref[i] = 1;
             const int n = h_count[i];
             ref_n[i] = subsample_indices(n, &ref_sel[(size_t)i * 50]);
             if (n == 0) continue;
             const int Hi = H[i0 + i], Wi = W[i0 + i];
+            const uint64_t seed = (uint64_t)cfg->base_seed * 1000003ull + (uint64_t)pool_pos[i0 + i];
             float sub[50 * 4];
             for (int k = 0; k < ref_n[i]; k++) memcpy(sub + 4 * k, &h_boxes[((size_t)i * cap + ref_sel[(size_t)i * 50 + k]) * 4], 16);
-            auto add_view = [&](const ViewDesc& vd, int kind, float par) {
+            auto add_view = [&](const ViewDesc& vd, int kind, const float* par) {
                 const int vidx = nb + (int)aviews.size();
                 aviews.push_back(vd); view_img[vidx] = i; view_isref[vidx] = 0;
-                pair_ref.push_back(i); pair_aug.push_back(vidx); pair_kind.push_back(kind); pair_par.push_back(par); pair_img.push_back(i);
+                pair_ref.push_back(i); pair_aug.push_back(vidx); pair_kind.push_back(kind); pair_img.push_back(i);
+                for (int q = 0; q < 12; q++) pair_par.push_back(par ? par[q] : 0.0f);
             };
             ViewDesc base; memset(&base, 0, sizeof(base)); base.src = images_dev[i0 + i]; base.H = Hi; base.W = Wi;
-            if (cfg->aug_flip) { ViewDesc v = base; v.flip = 1; add_view(v, 1, (float)Wi); }
+            float par[12] = {0};
+            if (cfg->aug_flip) { ViewDesc v = base; v.flip = 1; par[0] = (float)Wi; add_view(v, 1, par); }
+            if (cfg->aug_sp) {     // SaltPepperNoise(image, 0.1), cald_train.py:150-153; torch.rand stream re-seeded per image
+                SaltPepperJob j; j.src = images_dev[i0 + i]; j.dst = take((size_t)Hi * Wi * 3); j.H = Hi; j.W = Wi; j.seed = seed;
+                j.lo = (float)((double)cfg->sp_prob / 2.0); j.hi = (float)(1.0 - (double)cfg->sp_prob / 2.0);
+                jobs.push_back(j);
+                ViewDesc v = base; v.src = j.dst; add_view(v, 0, nullptr);
+            }
             if (cfg->aug_cutout) {
                 ViewDesc v = base;
-                const uint64_t seed = (uint64_t)cfg->base_seed * 1000003ull + (uint64_t)pool_pos[i0 + i];
                 v.nrect = cutout_rects(seed, Hi, Wi, ref_n[i], sub, 2, v.rects);
-                add_view(v, 0, 0.0f);
+                add_view(v, 0, nullptr);
             }
             if (cfg->aug_resize) {
                 const int ow = (int)((double)Wi * (double)cfg->resize_ratio), oh = (int)((double)Hi * (double)cfg->resize_ratio);
-                const size_t need = (size_t)oh * ow * 3, tneed = (size_t)Hi * ow * 3;
-                if (rsz_cap[i] < need) { if (rsz[i]) hipFree(rsz[i]); if (hipMalloc((void**)&rsz[i], need) != hipSuccess) { rc = fail(CALD_ERR_HIP, "hipMalloc failed"); break; } rsz_cap[i] = need; }
-                if (tmp_cap < tneed) { hipStreamSynchronize(c->stream); if (d_tmp) hipFree(d_tmp); if (hipMalloc((void**)&d_tmp, tneed) != hipSuccess) { rc = fail(CALD_ERR_HIP, "hipMalloc failed"); break; } tmp_cap = tneed; }
-                if ((rc = pil_resize(c, images_dev[i0 + i], Hi, Wi, rsz[i], oh, ow, d_tmp))) break;
-                ViewDesc v; memset(&v, 0, sizeof(v)); v.src = rsz[i]; v.H = oh; v.W = ow;
-                add_view(v, 2, cfg->resize_ratio);
+                uint8_t* dst = take((size_t)oh * ow * 3); uint8_t* tmp = take((size_t)Hi * ow * 3);
+                if ((rc = pil_resize(c, images_dev[i0 + i], Hi, Wi, dst, oh, ow, tmp, 0))) break;
+                ViewDesc v; memset(&v, 0, sizeof(v)); v.src = dst; v.H = oh; v.W = ow;
+                par[0] = cfg->resize_ratio; add_view(v, 2, par);
             }
+            if (cfg->aug_rotate) {   // rotate(image, ref_boxes, 5), cald_train.py:180-183
+                int fx[6], nh, nw; pil_rotate_setup(Hi, Wi, (double)cfg->rotate_angle, fx, &nh, &nw);
+                uint8_t* rot = take((size_t)nh * nw * 3); uint8_t* tmp = take((size_t)nh * Wi * 3); uint8_t* dst = take((size_t)Hi * Wi * 3);
+                launch_affine_nearest(images_dev[i0 + i], Hi, Wi, rot, nh, nw, fx, c->stream);
+                if ((rc = pil_resize(c, rot, nh, nw, dst, Hi, Wi, tmp, 1))) break;      // new_image.resize((w, h)): BICUBIC default
+                ViewDesc v = base; v.src = dst;
+                rotate_box_params(Hi, Wi, (double)cfg->rotate_angle, nw, nh, par);
+                add_view(v, 3, par);
+            }
+        }
+        if (rc) break;
+        if (!jobs.empty()) {
+            if (hipMemcpyAsync(d_jobs, jobs.data(), sizeof(SaltPepperJob) * jobs.size(), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+                hipStreamSynchronize(c->stream) != hipSuccess) { rc = fail(CALD_ERR_HIP, "H2D of salt-pepper jobs failed"); break; }
+            launch_salt_pepper(d_jobs, (int)jobs.size(), c->stream);
         }
         if (rc) break;
         // ---- phase 2: augmented views (chunks of <= 64) ----
@@ -1107,7 +1200,7 @@ extern "C" int cald_sweep(cald_model* m, int n_images, const uint8_t* const* ima
         memcpy(p_sel, ref_sel.data(), (size_t)B * 50 * 4); memcpy(p_n, ref_n.data(), (size_t)B * 4);
         memcpy(p_vimg, view_img.data(), (size_t)VT * 4); memcpy(p_visref, view_isref.data(), (size_t)VT * 4);
         if (hipMemcpyAsync(d_ints, ints.data(), n_ints * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
-            (P && hipMemcpyAsync(d_par, pair_par.data(), (size_t)P * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess)) { rc = fail(CALD_ERR_HIP, "H2D failed"); break; }
+            (P && hipMemcpyAsync(d_par, pair_par.data(), (size_t)P * 12 * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess)) { rc = fail(CALD_ERR_HIP, "H2D failed"); break; }
         ScoreArgs sa; sa.det = D;
         sa.ref_view = d_ints; sa.aug_view = d_ints + P_MAX; sa.aug_kind = d_ints + 2 * P_MAX; sa.pair_img = d_ints + 3 * P_MAX;
         sa.ref_sel = d_ints + 4 * P_MAX; sa.ref_n = sa.ref_sel + (size_t)B * 50; sa.aug_param = d_par; sa.P = P; sa.bp = cfg->bp; sa.cons = d_cons;

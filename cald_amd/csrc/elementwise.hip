@@ -158,3 +158,85 @@ void launch_subsample2(const float* in, float* out, const LevelSeg* sin, const L
     dim3 grid((unsigned)(((long long)max_out_pix * (C / 4) + 255) / 256), V);
     hipLaunchKernelGGL(subsample2_kernel, grid, dim3(256), 0, st, in, out, sin, sout, C);
 }
+
+// ---------------------------------------------------------------------------------------------
+// PIL Image.rotate(expand=True, NEAREST): Pillow's 16.16 fixed-point affine loop (Geometry.c
+// affine_fixed), one thread per output pixel.  a[6] = FIX()ed coefficients computed on the host.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void affine_nearest_kernel(const uint8_t* src, int H, int W, uint8_t* dst, int oh, int ow,
+                                                             int a0, int a1, int a2, int a3, int a4, int a5) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= ow) return;
+    const int xx = a2 + a1 * y + a0 * x, yy = a5 + a4 * y + a3 * x;
+    const int xin = xx >> 16, yin = yy >> 16;
+    uint8_t r = 0, g = 0, b = 0;
+    if (xin >= 0 && xin < W && yin >= 0 && yin < H) {
+        const uint8_t* p = src + ((long long)yin * W + xin) * 3;
+        r = p[0]; g = p[1]; b = p[2];
+    }
+    uint8_t* o = dst + ((long long)y * ow + x) * 3;
+    o[0] = r; o[1] = g; o[2] = b;
+}
+void launch_affine_nearest(const uint8_t* src, int H, int W, uint8_t* dst, int oh, int ow, const int* a, hipStream_t st) {
+    dim3 grid((ow + 255) / 256, oh);
+    hipLaunchKernelGGL(affine_nearest_kernel, grid, dim3(256), 0, st, src, H, W, dst, oh, ow, a[0], a[1], a[2], a[3], a[4], a[5]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// cald_helper.SaltPepperNoise on the uint8 image, with torch's CPU random stream reproduced on the
+// device: one workgroup per image runs MT19937 (seeded like torch.manual_seed: init_genrand(seed))
+// in LDS -- the 624-word twist is done in three dependency-free phases (k < 227, < 454, < 624) --
+// and applies  u < prob/2 -> max(image),  u > 1 - prob/2 -> min(image)  in to_tensor's CHW order.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void salt_pepper_kernel(const SaltPepperJob* jobs) {
+    __shared__ unsigned mt[624];
+    __shared__ int s_mx, s_mn;
+    const SaltPepperJob j = jobs[blockIdx.x];
+    const int tid = threadIdx.x;
+    const long long n = (long long)j.H * j.W * 3;
+    if (tid == 0) { s_mx = 0; s_mn = 255; }
+    __syncthreads();
+    int mx = 0, mn = 255;
+    for (long long i = tid; i < n; i += 256) { const int v = j.src[i]; mx = v > mx ? v : mx; mn = v < mn ? v : mn; }
+    atomicMax(&s_mx, mx); atomicMin(&s_mn, mn);
+    if (tid == 0) {
+        unsigned x = (unsigned)(j.seed & 0xffffffffull);
+        mt[0] = x;
+        for (int i = 1; i < 624; i++) { x = 1812433253u * (x ^ (x >> 30)) + (unsigned)i; mt[i] = x; }
+    }
+    __syncthreads();
+    const uint8_t vmax = (uint8_t)s_mx, vmin = (uint8_t)s_mn;
+    const long long plane = (long long)j.H * j.W;
+    for (long long base = 0; base < n; base += 624) {
+        // twist: new[k] = old[k+397 mod 624] ^ f(old[k], old[k+1]); phases keep every read well-defined
+        for (int ph = 0; ph < 3; ph++) {
+            const int lo = ph == 0 ? 0 : (ph == 1 ? 227 : 454), hi = ph == 0 ? 227 : (ph == 1 ? 454 : 624);
+            unsigned nv = 0; int k = lo + tid;
+            if (k < hi) {
+                const unsigned y = (mt[k] & 0x80000000u) | (mt[(k + 1) % 624] & 0x7fffffffu);
+                nv = mt[(k + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+            }
+            __syncthreads();
+            if (k < hi) mt[k] = nv;
+            __syncthreads();
+        }
+        for (int t = tid; t < 624; t += 256) {
+            const long long e = base + t;
+            if (e >= n) break;
+            unsigned y = mt[t];
+            y ^= (y >> 11); y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= (y >> 18);
+            const float u = (float)((double)(y & 0xffffffu) * (1.0 / 16777216.0));
+            const int c = (int)(e / plane);
+            const long long pix = e - (long long)c * plane;
+            const long long o = pix * 3 + c;
+            uint8_t v = j.src[o];
+            if (u < j.lo) v = vmax;
+            if (u > j.hi) v = vmin;
+            j.dst[o] = v;
+        }
+        __syncthreads();
+    }
+}
+void launch_salt_pepper(const SaltPepperJob* jobs, int n, hipStream_t st) {
+    if (n > 0) hipLaunchKernelGGL(salt_pepper_kernel, dim3(n), dim3(256), 0, st, jobs);
+}

@@ -33,6 +33,10 @@ void launch_pil_vertical(const uint8_t* src, int H, int W, uint8_t* dst, int oh,
 void launch_maxpool(const float* in, float* out, const LevelSeg* sin, const LevelSeg* sout, int C, int V, int max_out_pix, hipStream_t st);
 void launch_subsample2(const float* in, float* out, const LevelSeg* sin, const LevelSeg* sout, int C, int V, int max_out_pix, hipStream_t st);
 
+struct SaltPepperJob { const uint8_t* src; uint8_t* dst; int H, W; unsigned long long seed; float lo, hi; };
+void launch_affine_nearest(const uint8_t* src, int H, int W, uint8_t* dst, int oh, int ow, const int* a, hipStream_t st);
+void launch_salt_pepper(const SaltPepperJob* jobs, int n, hipStream_t st);
+
 // rpn.hip
 struct RpnArgs {
     const float* head[5];        // per level: [sum pix][head_ld], ch a = logit, ch A+4a+j = delta
@@ -86,8 +90,8 @@ struct ScoreArgs {
     DetBuffers det;            // detections of ALL views of the batch
     const int* ref_view;       // [P] view index of the reference view of pair p
     const int* aug_view;       // [P] view index of the augmented view of pair p
-    const int* aug_kind;       // [P] 0 = boxes unchanged, 1 = flip, 2 = scale by aug_scale
-    const float* aug_param;    // [P] flip: image width; scale: ratio
+    const int* aug_kind;       // [P] 0 = boxes unchanged, 1 = flip, 2 = scale, 3 = rotate
+    const float* aug_param;    // [P][12] flip: {W}; scale: {ratio}; rotate: {a00,a01,a02,a10,a11,a12,sx,sy,W,H}
     const int* ref_sel;        // [nimg][50] sub-sample indices into the reference detections
     const int* ref_n;          // [nimg] number of (sub-sampled) reference boxes
     const int* pair_img;       // [P] image slot of the pair

@@ -54,13 +54,28 @@ __global__ __launch_bounds__(256) void consistency_kernel(ScoreArgs a) {
     const float4* rboxes = reinterpret_cast<const float4*>(a.det.boxes) + (long long)rv * cap;
     const float4* aboxes = reinterpret_cast<const float4*>(a.det.boxes) + (long long)av * cap;
     const int kind = a.aug_kind[p];
-    const float prm = a.aug_param[p];
+    const float* prmv = a.aug_param + (long long)p * 12;
+    const float prm = prmv[0];
     float cur = 1.0f;
     for (int i = wave; i < N; i += 4) {
         const int ri = a.ref_sel[img * 50 + i];
         float4 ab = rboxes[ri];
         if (kind == 1) { float x0 = prm - ab.z, x2 = prm - ab.x; ab.x = x0; ab.z = x2; }   // cald_helper.py:29
         else if (kind == 2) { ab.x = ab.x * prm; ab.y = ab.y * prm; ab.z = ab.z * prm; ab.w = ab.w * prm; }  // :53
+        else if (kind == 3) {   // cald_helper.rotate box transform, cald_helper.py:160-222
+            const float bw = ab.z - ab.x, bh = ab.w - ab.y;
+            const float xs[4] = {ab.x, ab.x + bw, ab.x, ab.z}, ys[4] = {ab.y, ab.y, ab.y + bh, ab.w};
+            float xmin = 0.f, xmax = 0.f, ymin = 0.f, ymax = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float X = (prmv[0] * xs[q] + prmv[1] * ys[q]) + prmv[2] * 1.0f;
+                const float Y = (prmv[3] * xs[q] + prmv[4] * ys[q]) + prmv[5] * 1.0f;
+                if (q == 0 || X < xmin) xmin = X; if (q == 0 || X > xmax) xmax = X;
+                if (q == 0 || Y < ymin) ymin = Y; if (q == 0 || Y > ymax) ymax = Y;
+            }
+            ab.x = det_clamp(xmin / prmv[6], 0.0f, prmv[8]); ab.y = det_clamp(ymin / prmv[7], 0.0f, prmv[9]);
+            ab.z = det_clamp(xmax / prmv[6], 0.0f, prmv[8]); ab.w = det_clamp(ymax / prmv[7], 0.0f, prmv[9]);
+        }
         float best = -INFINITY; int bj = 0x7fffffff;
         for (int j = lane; j < M; j += 64) {
             float v = cald_iou(ab, aboxes[j]);

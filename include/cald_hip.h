@@ -101,6 +101,10 @@ typedef struct cald_sweep_cfg {
     uint64_t base_seed;
     float bp;              /* args.bp, 1.3 */
     int batch_images;      /* images per batched launch sequence (0 = default 64, max 64) */
+    int aug_sp;            /* 'sp': SaltPepperNoise(image, sp_prob), torch.rand stream re-seeded per image */
+    float sp_prob;         /* 0.1 */
+    int aug_rotate;        /* 'rotation': rotate(image, ref_boxes, rotate_angle) */
+    float rotate_angle;    /* 5 */
 } cald_sweep_cfg;
 int cald_sweep(cald_model* m, int n_images, const uint8_t* const* images_dev, const int* H, const int* W,
                const int64_t* pool_pos, const cald_sweep_cfg* cfg, double* consistency_out, double* cls_corr_out);

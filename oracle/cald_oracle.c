@@ -238,10 +238,20 @@ ORC_API int orc_cutout_rects(uint64_t seed, int H, int W, int N, const float* bo
  * antialiased fixed-point resampler (published algorithm, src/libImaging/Resample.c).
  * ------------------------------------------------------------------------------------- */
 #define PIL_PRECISION_BITS (32 - 8 - 2)
-static int pil_coeffs(int inSize, int outSize, int** bounds_out, int32_t** kk_out) {
+static double pil_filter(int fid, double x) {
+    if (x < 0.0) x = -x;
+    if (fid == 0) return x < 1.0 ? 1.0 - x : 0.0;
+    /* bicubic, a = -0.5 (Pillow Resample.c bicubic_filter) */
+    if (x < 1.0) return ((-0.5 + 2.0) * x - (-0.5 + 3.0)) * x * x + 1;
+    if (x < 2.0) return (((x - 5) * x + 8) * x - 4) * -0.5;
+    return 0.0;
+}
+static int pil_coeffs_f(int inSize, int outSize, int fid, int** bounds_out, int32_t** kk_out);
+static int pil_coeffs(int inSize, int outSize, int** bounds_out, int32_t** kk_out) { return pil_coeffs_f(inSize, outSize, 0, bounds_out, kk_out); }
+static int pil_coeffs_f(int inSize, int outSize, int fid, int** bounds_out, int32_t** kk_out) {
     double scale = (double)inSize / (double)outSize, filterscale = scale;
     if (filterscale < 1.0) filterscale = 1.0;
-    double support = 1.0 * filterscale;
+    double support = (fid == 0 ? 1.0 : 2.0) * filterscale;
     int ksize = (int)ceil(support) * 2 + 1;
     double* pre = (double*)malloc(sizeof(double) * (size_t)outSize * ksize);
     int* bounds = (int*)malloc(sizeof(int) * 2 * (size_t)outSize);
@@ -254,8 +264,7 @@ static int pil_coeffs(int inSize, int outSize, int** bounds_out, int32_t** kk_ou
         double* k = pre + (size_t)xx * ksize;
         int x;
         for (x = 0; x < xmax; x++) {
-            double a = (x + xmin - center + 0.5) * ss; if (a < 0) a = -a;
-            double w = a < 1.0 ? 1.0 - a : 0.0;
+            double w = pil_filter(fid, (x + xmin - center + 0.5) * ss);
             k[x] = w; ww += w;
         }
         for (x = 0; x < xmax; x++) if (ww != 0.0) k[x] /= ww;
@@ -281,11 +290,14 @@ ORC_API void orc_pil_coeffs(int inSize, int outSize, int* ksize_out, int* bounds
     if (kk) memcpy(kk, k, sizeof(int32_t) * (size_t)outSize * ks);
     free(b); free(k);
 }
-ORC_API void orc_pil_resize_bilinear(const uint8_t* src, int H, int W, uint8_t* dst, int oh, int ow) {
+static void pil_resize_f(const uint8_t* src, int H, int W, uint8_t* dst, int oh, int ow, int fid);
+ORC_API void orc_pil_resize_bilinear(const uint8_t* src, int H, int W, uint8_t* dst, int oh, int ow) { pil_resize_f(src, H, W, dst, oh, ow, 0); }
+ORC_API void orc_pil_resize_bicubic(const uint8_t* src, int H, int W, uint8_t* dst, int oh, int ow) { pil_resize_f(src, H, W, dst, oh, ow, 1); }
+static void pil_resize_f(const uint8_t* src, int H, int W, uint8_t* dst, int oh, int ow, int fid) {
     int *bh, *bv; int32_t *kh, *kv;
     const uint8_t* cur = src; int curW = W; uint8_t* tmp = NULL;
     if (ow != W) {
-        int ks = pil_coeffs(W, ow, &bh, &kh);
+        int ks = pil_coeffs_f(W, ow, fid, &bh, &kh);
         tmp = (uint8_t*)malloc((size_t)H * ow * 3);
         for (int y = 0; y < H; y++)
             for (int xx = 0; xx < ow; xx++) {
@@ -301,7 +313,7 @@ ORC_API void orc_pil_resize_bilinear(const uint8_t* src, int H, int W, uint8_t* 
         cur = tmp; curW = ow;
     }
     if (oh != H) {
-        int ks = pil_coeffs(H, oh, &bv, &kv);
+        int ks = pil_coeffs_f(H, oh, fid, &bv, &kv);
         for (int yy = 0; yy < oh; yy++) {
             int ymin = bv[2 * yy], ymax = bv[2 * yy + 1];
             const int32_t* k = kv + (size_t)yy * ks;
@@ -792,4 +804,109 @@ ORC_API int orc_retina_postprocess(int L, const float* const* cls, const float* 
     }
     free(sc); free(bx); free(pm); free(kv); free(sb); free(keep);
     return nout;
+}
+
+
+/* -------------------------------------------------------------------------------------
+ * PIL Image.rotate(angle, expand=True) with the default NEAREST resampling
+ * (cald_helper.py:153): Image.rotate's matrix arithmetic (python floats, round(.,15)) followed
+ * by Pillow's 16.16 fixed-point nearest-neighbour affine loop (Geometry.c affine_fixed).
+ * ------------------------------------------------------------------------------------- */
+#include <stdio.h>
+static double py_round15(double v) { char buf[64]; snprintf(buf, sizeof(buf), "%.15f", v); return strtod(buf, NULL); }
+static int pil_floor_(double v) { return v < 0.0 ? (int)floor(v) : (int)v; }
+static int pil_fix(double v) { return pil_floor_(v * 65536.0 + 0.5); }
+ORC_API void orc_pil_rotate_matrix(int H, int W, double angle_deg, double* m /*6*/, int* nH, int* nW) {
+    double angle = fmod(angle_deg, 360.0); if (angle < 0) angle += 360.0;
+    double w = (double)W, h = (double)H, cx = w / 2.0, cy = h / 2.0;
+    double ang = -(angle * (3.141592653589793 / 180.0));
+    m[0] = py_round15(cos(ang)); m[1] = py_round15(sin(ang)); m[2] = 0.0;
+    m[3] = py_round15(-sin(ang)); m[4] = py_round15(cos(ang)); m[5] = 0.0;
+    double tx = -cx, ty = -cy;
+    double m2 = m[0] * tx + m[1] * ty + m[2], m5 = m[3] * tx + m[4] * ty + m[5];
+    m[2] = m2 + cx; m[5] = m5 + cy;
+    double xs[4] = {0, w, w, 0}, ys[4] = {0, 0, h, h}, xmin = 0, xmax = 0, ymin = 0, ymax = 0;
+    for (int i = 0; i < 4; i++) {
+        double X = m[0] * xs[i] + m[1] * ys[i] + m[2], Y = m[3] * xs[i] + m[4] * ys[i] + m[5];
+        if (i == 0 || X < xmin) xmin = X; if (i == 0 || X > xmax) xmax = X;
+        if (i == 0 || Y < ymin) ymin = Y; if (i == 0 || Y > ymax) ymax = Y;
+    }
+    int nw = (int)ceil(xmax) - (int)floor(xmin), nh = (int)ceil(ymax) - (int)floor(ymin);
+    double px = -(nw - W) / 2.0, py = -(nh - H) / 2.0;
+    m2 = m[0] * px + m[1] * py + m[2]; m5 = m[3] * px + m[4] * py + m[5];
+    m[2] = m2; m[5] = m5;
+    *nH = nh; *nW = nw;
+}
+ORC_API void orc_pil_affine_nearest(const uint8_t* src, int H, int W, const double* a, uint8_t* dst, int oh, int ow) {
+    int a0 = pil_fix(a[0]), a1 = pil_fix(a[1]), a3 = pil_fix(a[3]), a4 = pil_fix(a[4]);
+    int a2 = pil_fix(a[2] + a[0] * 0.5 + a[1] * 0.5), a5 = pil_fix(a[5] + a[3] * 0.5 + a[4] * 0.5);
+    memset(dst, 0, (size_t)oh * ow * 3);
+    for (int y = 0; y < oh; y++) {
+        int xx = a2, yy = a5;
+        for (int x = 0; x < ow; x++) {
+            int xin = xx >> 16;
+            if (xin >= 0 && xin < W) {
+                int yin = yy >> 16;
+                if (yin >= 0 && yin < H) memcpy(dst + ((size_t)y * ow + x) * 3, src + ((size_t)yin * W + xin) * 3, 3);
+            }
+            xx += a0; yy += a3;
+        }
+        a2 += a1; a5 += a4;
+    }
+}
+
+
+/* -------------------------------------------------------------------------------------
+ * torch.rand on the CPU generator after torch.manual_seed(seed): MT19937 seeded with
+ * init_genrand(seed & 0xffffffff), one 32-bit draw per element, value = (r & 0xffffff) * 2^-24.
+ * SaltPepperNoise (cald_helper.py:78-85) on a uint8 image: noise has the CHW layout of
+ * to_tensor(image); salt / pepper are the image's global max / min.
+ * ------------------------------------------------------------------------------------- */
+ORC_API void orc_torch_rand(uint64_t seed, int n, float* out) {
+    orc_mt s; mt_init_genrand(&s, (uint32_t)(seed & 0xffffffffu));
+    for (int i = 0; i < n; i++) out[i] = (float)((double)(mt_next(&s) & 0xffffffu) * (1.0 / 16777216.0));
+}
+ORC_API void orc_salt_pepper(const uint8_t* src, int H, int W, float prob, uint64_t seed, uint8_t* dst) {
+    orc_mt s; mt_init_genrand(&s, (uint32_t)(seed & 0xffffffffu));
+    uint8_t mx = src[0], mn = src[0];
+    for (size_t i = 0; i < (size_t)H * W * 3; i++) { if (src[i] > mx) mx = src[i]; if (src[i] < mn) mn = src[i]; }
+    const float lo = (float)((double)prob / 2.0), hi = (float)(1.0 - (double)prob / 2.0);
+    memcpy(dst, src, (size_t)H * W * 3);
+    for (int c = 0; c < 3; c++)
+        for (int y = 0; y < H; y++)
+            for (int x = 0; x < W; x++) {
+                float u = (float)((double)(mt_next(&s) & 0xffffffu) * (1.0 / 16777216.0));
+                size_t o = ((size_t)y * W + x) * 3 + c;
+                if (u < lo) dst[o] = mx;
+                if (u > hi) dst[o] = mn;
+            }
+}
+
+/* cald_helper.py:135-223 rotate(): box corners through the affine matrix (float32 after
+ * .float()), axis-aligned hull, rescale by (rotated size / original size), clamp.
+ * nW2/nH2 are the PIL-expanded image sizes (new_image.width/height). */
+ORC_API void orc_rotate_boxes(const float* boxes, int N, int H, int W, double angle_deg, int pilW, int pilH, float* out) {
+    double ang = angle_deg * (3.141592653589793 / 180.0);      /* np.radians */
+    double alpha = cos(ang), beta = sin(ang), cx = W / 2.0, cy = H / 2.0;
+    double m02 = (1 - alpha) * cx - beta * cy, m12 = beta * cx + (1 - alpha) * cy;
+    double c_ = fabs(alpha), s_ = fabs(beta);
+    int nW = (int)((H * s_) + (W * c_)), nH = (int)((H * c_) + (W * s_));
+    m02 += (nW / 2.0) - cx; m12 += (nH / 2.0) - cy;
+    float a00 = (float)alpha, a01 = (float)beta, a02 = (float)m02, a10 = (float)(-beta), a11 = (float)alpha, a12 = (float)m12;
+    float sx = (float)((double)pilW / (double)W), sy = (float)((double)pilH / (double)H);
+    for (int i = 0; i < N; i++) {
+        const float* b = boxes + 4 * i;
+        float bw = b[2] - b[0], bh = b[3] - b[1];
+        float xs[4] = {b[0], b[0] + bw, b[0], b[2]}, ys[4] = {b[1], b[1], b[1] + bh, b[3]};
+        float xmin = 0, xmax = 0, ymin = 0, ymax = 0;
+        for (int k = 0; k < 4; k++) {
+            float X = (a00 * xs[k] + a01 * ys[k]) + a02 * 1.0f;
+            float Y = (a10 * xs[k] + a11 * ys[k]) + a12 * 1.0f;
+            if (k == 0 || X < xmin) xmin = X; if (k == 0 || X > xmax) xmax = X;
+            if (k == 0 || Y < ymin) ymin = Y; if (k == 0 || Y > ymax) ymax = Y;
+        }
+        float r[4] = {xmin / sx, ymin / sy, xmax / sx, ymax / sy};
+        out[4 * i + 0] = clampf(r[0], 0.0f, (float)W); out[4 * i + 1] = clampf(r[1], 0.0f, (float)H);
+        out[4 * i + 2] = clampf(r[2], 0.0f, (float)W); out[4 * i + 3] = clampf(r[3], 0.0f, (float)H);
+    }
 }

@@ -85,6 +85,7 @@ class SeededLoader:
         from PIL import Image
         for pos, img in enumerate(self.images):
             random.seed(image_seed(self.base_seed, pos))
+            torch.manual_seed(image_seed(self.base_seed, pos))
             yield (Image.fromarray(img),), (None,)
 
 
@@ -146,6 +147,12 @@ def gen_helpers(ch):
             random.seed(s)
             ci = ch.cutout(Image.fromarray(img), torch.from_numpy(boxes), None, 2)
             blob["cutout%d_%d_img" % (i, s)] = (ci * 255).round().to(torch.uint8).permute(1, 2, 0).numpy()
+        ri, rb = ch.rotate(Image.fromarray(img), torch.from_numpy(boxes), 5)
+        blob["rotate%d_img" % i] = (ri * 255).round().to(torch.uint8).permute(1, 2, 0).numpy(); blob["rotate%d_boxes" % i] = rb.numpy()
+        for s in (21, 22):
+            torch.manual_seed(s)
+            si = ch.SaltPepperNoise(Image.fromarray(img), 0.1)
+            blob["sp%d_%d_img" % (i, s)] = (si * 255).round().to(torch.uint8).permute(1, 2, 0).numpy()
         b2 = fake_dets(rs, 4, H, W, 21, "softmax")["boxes"]
         blob["boxes_b%d" % i] = b2
         blob["intersect%d" % i] = ch.intersect(torch.from_numpy(boxes), torch.from_numpy(b2)).numpy()
@@ -210,6 +217,8 @@ def main():
                 [3, 0, 41, 49, 50, 51, 100, 1, 12, 7], [5, 0, 100, 1, 17, 33], 2)
     gen_scoring(ct, "scoring_retina_FCD", "sigmoid", 21, ["flip", "cut_out", "smaller_resize"],
                 [6, 0, 45, 300, 2, 80], [9, 0, 600, 3, 40], 3)
+    gen_scoring(ct, "scoring_frcnn_FSCDR", "softmax", 21, ["flip", "sp", "cut_out", "smaller_resize", "rotation"],
+                [5, 0, 44, 9], [7, 0, 100, 2, 30], 6)
     gen_scoring(ct, "scoring_frcnn_coco_FD", "softmax", 91, ["flip", "smaller_resize"], [10, 60, 0, 2], [20, 3, 100], 4)
     gen_helpers(ch)
     gen_js()

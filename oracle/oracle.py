@@ -139,6 +139,54 @@ def pil_resize_bilinear(img, oh, ow):
     return out
 
 
+def pil_resize_bicubic(img, oh, ow):
+    """PIL.Image.resize((ow, oh)) with the default filter (BICUBIC), cald_helper.py:215."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    H, W, _ = img.shape
+    out = np.empty((oh, ow, 3), np.uint8)
+    lib().orc_pil_resize_bicubic(_p(img, c_u8), C.c_int(H), C.c_int(W), _p(out, c_u8), C.c_int(oh), C.c_int(ow))
+    return out
+
+
+def pil_rotate_expand(img, angle):
+    """PIL.Image.rotate(angle, expand=True) (NEAREST), cald_helper.py:153.  Returns the rotated uint8 image."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    H, W, _ = img.shape
+    m = np.zeros(6, np.float64); nh, nw = C.c_int(), C.c_int()
+    lib().orc_pil_rotate_matrix(C.c_int(H), C.c_int(W), C.c_double(angle), m.ctypes.data_as(C.POINTER(C.c_double)), C.byref(nh), C.byref(nw))
+    out = np.empty((nh.value, nw.value, 3), np.uint8)
+    lib().orc_pil_affine_nearest(_p(img, c_u8), C.c_int(H), C.c_int(W), m.ctypes.data_as(C.POINTER(C.c_double)), _p(out, c_u8),
+                                 C.c_int(nh.value), C.c_int(nw.value))
+    return out
+
+
+def torch_rand(seed, n):
+    out = np.empty(n, np.float32)
+    lib().orc_torch_rand(C.c_uint64(seed), C.c_int(n), _p(out))
+    return out
+
+
+def salt_pepper(img, prob, seed):
+    """cald_helper.py:78-85 on the uint8 image (torch.rand stream re-seeded with `seed`)."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    H, W, _ = img.shape
+    out = np.empty_like(img)
+    lib().orc_salt_pepper(_p(img, c_u8), C.c_int(H), C.c_int(W), C.c_float(prob), C.c_uint64(seed), _p(out, c_u8))
+    return out
+
+
+def rotate_aug(img, boxes, angle):
+    """cald_helper.py:135-223: returns (uint8 image of the original size, rotated boxes)."""
+    H, W, _ = img.shape
+    rot = pil_rotate_expand(img, angle)
+    back = pil_resize_bicubic(rot, H, W)
+    b = f32(boxes).reshape(-1, 4)
+    out = np.empty_like(b)
+    lib().orc_rotate_boxes(_p(b), C.c_int(b.shape[0]), C.c_int(H), C.c_int(W), C.c_double(angle), C.c_int(rot.shape[1]),
+                           C.c_int(rot.shape[0]), _p(out))
+    return back, out
+
+
 def resize_aug(img, ratio):
     H, W, _ = img.shape
     ow, oh = int(W * ratio), int(H * ratio)
@@ -490,10 +538,15 @@ def build_views(img, augs, ref, seed):
     rb = ref["boxes"]
     if "flip" in augs:
         views.append((img, True, None, flip_boxes(rb, W)))
+    if "sp" in augs:
+        views.append((salt_pepper(img, 0.1, seed), False, None, rb))
     if "cut_out" in augs:
         views.append((img, False, cutout_rects(seed, H, W, rb, 2), rb))
     if "smaller_resize" in augs:
         views.append((resize_aug(img, 0.8), False, None, (f32(rb) * np.float32(0.8)).astype(np.float32)))
+    if "rotation" in augs:
+        ri, rbx = rotate_aug(img, rb, 5)
+        views.append((ri, False, None, rbx))
     return views
 
 

@@ -8,7 +8,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-SCORING = ["scoring_frcnn_F", "scoring_frcnn_FCD", "scoring_retina_FCD", "scoring_frcnn_coco_FD"]
+SCORING = ["scoring_frcnn_F", "scoring_frcnn_FCD", "scoring_retina_FCD", "scoring_frcnn_coco_FD", "scoring_frcnn_FSCDR"]
 
 
 @pytest.fixture(scope="module")
@@ -220,5 +220,20 @@ def test_retinanet_sweep_matches_oracle(hip, oracle, small_retina):
     cons, cls = sweep.sweep_device_images(model, [torch.from_numpy(im).cuda() for im in pool], list(range(len(pool))), augs,
                                           bp=1.3, base_seed=5, batch_images=4)
     wc, wcls = oracle.get_uncertainty(P, pool, augs, 21, bp=1.3, min_size=300, max_size=500, base_seed=5)
+    np.testing.assert_array_equal(cons, np.array(wc))
+    np.testing.assert_array_equal(cls, np.stack(wcls))
+
+
+def test_sweep_five_augs_matches_oracle(hip, oracle, small_model):
+    """Reference default --augs FCDR plus S: flip, sp (torch.rand stream on the device), cut_out,
+    smaller_resize, rotation (PIL rotate + bicubic resize on the device)."""
+    torch = hip["torch"]
+    from cald_amd import synth, sweep
+    model, P = small_model
+    pool = synth.make_pool(5, "voc", 0, scale=0.5)
+    augs = ["flip", "sp", "cut_out", "smaller_resize", "rotation"]
+    cons, cls = sweep.sweep_device_images(model, [torch.from_numpy(im).cuda() for im in pool], list(range(len(pool))), augs,
+                                          bp=1.3, base_seed=11, batch_images=3)
+    wc, wcls = oracle.get_uncertainty(P, pool, augs, 21, bp=1.3, min_size=300, max_size=500, base_seed=11)
     np.testing.assert_array_equal(cons, np.array(wc))
     np.testing.assert_array_equal(cls, np.stack(wcls))

@@ -3,7 +3,7 @@
 import numpy as np
 import pytest
 
-SCORING = ["scoring_frcnn_F", "scoring_frcnn_FCD", "scoring_retina_FCD", "scoring_frcnn_coco_FD"]
+SCORING = ["scoring_frcnn_F", "scoring_frcnn_FCD", "scoring_retina_FCD", "scoring_frcnn_coco_FD", "scoring_frcnn_FSCDR"]
 
 
 def _dets(g, i, v):
@@ -62,6 +62,11 @@ def test_helpers_match_reference(oracle, golden):
         for s in (11, 12, 13):
             rects = oracle.cutout_rects(s, H, W, boxes, 2)
             np.testing.assert_array_equal(materialize(oracle, img, False, rects), g["cutout%d_%d_img" % (i, s)])
+        ri, rb = oracle.rotate_aug(img, boxes, 5)
+        np.testing.assert_array_equal(ri, g["rotate%d_img" % i])                      # PIL rotate(expand) + default resize
+        np.testing.assert_allclose(rb, g["rotate%d_boxes" % i], rtol=0, atol=1e-4)    # float tolerance of BASELINE.json
+        for s in (21, 22):
+            np.testing.assert_array_equal(oracle.salt_pepper(img, 0.1, s), g["sp%d_%d_img" % (i, s)])
     for s in (0, 1, 12345, (1 << 40) + 17):
         np.testing.assert_array_equal(oracle.py_random(s, 8), g["pyrandom_%d" % s])
 
