@@ -87,7 +87,8 @@ def get_uncertainty(task_model, unlabeled_loader, augs, num_cls, bp=1.3, base_se
                     batch_images=64, group=None):
     """Drop-in for cald_train.py:91 (same positional signature)."""
     task_model.eval()
-    dev = torch.device("cuda", torch.cuda.current_device())
+    # without a GPU the upload below is a no-op and sweep_device_images() raises (no CPU fallback)
+    dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
     images, positions = [], []
     pool_size = 0
     for pos, (imgs, _) in enumerate(unlabeled_loader):      # batch size 1, cald_train.py:101-104

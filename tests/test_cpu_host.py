@@ -171,3 +171,58 @@ def test_helper_api_mirror_matches_reference_golden(golden):
         for s in (11, 12, 13):
             ci = ch.cutout(torch.from_numpy(img), boxes, None, 2, seed=s)
             np.testing.assert_array_equal((ci * 255).round().to(torch.uint8).permute(1, 2, 0).numpy(), g["cutout%d_%d_img" % (i, s)])
+
+
+class _FakeModel:
+    num_classes = 21
+
+    def eval(self):
+        return self
+
+
+def _fake_sweep(task_model, images, positions, augs, bp=1.3, base_seed=0, batch_images=64):
+    """Stands in for the GPU sweep: a deterministic function of (pool position, image bytes)."""
+    cons = np.array([p * 0.125 + float(im.float().mean()) / 255.0 for p, im in zip(positions, images)], np.float64)
+    cls = np.stack([np.full(20, p, np.float64) for p in positions]) if positions else np.zeros((0, 20))
+    return cons, cls
+
+
+def _sharded_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    from cald_amd import sweep
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    sweep.sweep_device_images = _fake_sweep
+    rs = np.random.RandomState(0)
+    loader = [((torch.from_numpy((rs.rand(8, 9, 3) * 255).astype(np.uint8)),), (None,)) for _ in range(11)]
+    cons, cls = sweep.get_uncertainty(_FakeModel(), loader, ["flip"], 21, rank=rank, world_size=world)
+    q.put((rank, np.array(cons), np.stack(cls)))
+    dist.destroy_process_group()
+
+
+def test_get_uncertainty_sharded_equals_single_rank():
+    """The N>1 path of get_uncertainty (strided shard + one all-gather) returns, on every rank, exactly
+    what the 1-rank run returns, in loader order."""
+    import torch
+    import torch.multiprocessing as mp
+    from cald_amd import sweep
+    rs = np.random.RandomState(0)
+    loader = [((torch.from_numpy((rs.rand(8, 9, 3) * 255).astype(np.uint8)),), (None,)) for _ in range(11)]
+    orig = sweep.sweep_device_images
+    try:
+        sweep.sweep_device_images = _fake_sweep
+        c1, k1 = sweep.get_uncertainty(_FakeModel(), loader, ["flip"], 21)
+    finally:
+        sweep.sweep_device_images = orig
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for _, cons, cls in res:
+        np.testing.assert_array_equal(cons, np.array(c1))
+        np.testing.assert_array_equal(cls, np.stack(k1))

@@ -237,3 +237,41 @@ def test_sweep_five_augs_matches_oracle(hip, oracle, small_model):
     wc, wcls = oracle.get_uncertainty(P, pool, augs, 21, bp=1.3, min_size=300, max_size=500, base_seed=11)
     np.testing.assert_array_equal(cons, np.array(wc))
     np.testing.assert_array_equal(cls, np.stack(wcls))
+
+
+def test_resnet101_coco_classes_forward(hip, oracle):
+    """BASELINE config 5 shape: ResNet-101 body, 91 classes (COCO) -- one view, bit-exact vs the oracle."""
+    torch = hip["torch"]
+    from cald_amd import synth
+    sd = synth.pseudo_trained_frcnn(91, 101, seed=1)
+    model = hip["det"].fasterrcnn_resnet101_fpn_feature(num_classes=91, min_size=256, max_size=400).to("cuda")
+    model.load_state_dict(sd)
+    P = oracle.prepare_frcnn(sd, 91, 101)
+    img = synth.make_pool(2, "coco", 0, scale=0.4)[1]
+    want = oracle.frcnn_forward(P, img, 256, 400)
+    got = model.forward_views([(torch.from_numpy(img).cuda(), False, None)])[0]
+    assert want["boxes"].shape[0] > 0
+    for k in ("boxes", "scores", "labels", "props", "prob_max", "scores_cls"):
+        assert got[k].cpu().numpy().tobytes() == want[k].tobytes(), "output %s differs" % k
+
+
+def test_empty_reference_and_error_paths(hip, oracle, small_model):
+    """Images without reference detections score 0.0 (cald_train.py:118-121); malformed calls fail loudly."""
+    torch, ffi, L = hip["torch"], hip["ffi"], hip["L"]
+    from cald_amd import synth, sweep
+    import ctypes as C
+    model, P = small_model
+    black = np.zeros((150, 200, 3), np.uint8)
+    pool = [black, synth.make_pool(2, "voc", 0, scale=0.5)[1]]
+    augs = ["flip", "cut_out", "smaller_resize"]
+    model.cfg.box_score_thresh = 0.9999999          # nothing survives on the first image ...
+    strict = hip["det"].fasterrcnn_resnet50_fpn_feature(num_classes=21, min_size=300, max_size=500, box_score_thresh=1.1)
+    strict.to("cuda").load_state_dict(model.state_dict())
+    model.cfg.box_score_thresh = 0.05
+    cons, cls = sweep.sweep_device_images(strict, [torch.from_numpy(im).cuda() for im in pool], [0, 1], augs)
+    np.testing.assert_array_equal(cons, np.zeros(2))
+    np.testing.assert_array_equal(cls, np.zeros((2, 20)))
+    with pytest.raises(RuntimeError):
+        model.forward_views([(torch.zeros((0, 0, 3), dtype=torch.uint8, device="cuda"), False, None)])
+    with pytest.raises(NotImplementedError):
+        sweep.sweep_device_images(model, [torch.from_numpy(pool[1]).cuda()], [0], ["ga"])
