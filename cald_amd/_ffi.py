@@ -39,7 +39,7 @@ class Dets(C.Structure):
 class SweepCfg(C.Structure):
     _fields_ = [("aug_flip", C.c_int), ("aug_cutout", C.c_int), ("aug_resize", C.c_int), ("resize_ratio", C.c_float),
                 ("base_seed", C.c_uint64), ("bp", C.c_float), ("batch_images", C.c_int), ("aug_sp", C.c_int), ("sp_prob", C.c_float),
-                ("aug_rotate", C.c_int), ("rotate_angle", C.c_float)]
+                ("aug_rotate", C.c_int), ("rotate_angle", C.c_float), ("aug_ga", C.c_int), ("ga_std", C.c_float)]
 
 
 # name -> (restype, argtypes): must list every symbol of include/cald_hip.h

@@ -1060,7 +1060,7 @@ extern "C" int cald_sweep(cald_model* m, int n_images, const uint8_t* const* ima
     cald_ctx* c = m->ctx;
     HIPCHK(hipSetDevice(c->device));
     const int C = m->cfg.num_classes, cap = m->det_cap();
-    const int A = (cfg->aug_flip ? 1 : 0) + (cfg->aug_sp ? 1 : 0) + (cfg->aug_cutout ? 1 : 0) + (cfg->aug_resize ? 1 : 0) +
+    const int A = (cfg->aug_flip ? 1 : 0) + (cfg->aug_ga ? 1 : 0) + (cfg->aug_sp ? 1 : 0) + (cfg->aug_cutout ? 1 : 0) + (cfg->aug_resize ? 1 : 0) +
                   (cfg->aug_rotate ? 1 : 0);
     int B = cfg->batch_images > 0 ? cfg->batch_images : 64;
     if (B > CALD_MAX_VIEWS) B = CALD_MAX_VIEWS;
@@ -1073,18 +1073,18 @@ extern "C" int cald_sweep(cald_model* m, int n_images, const uint8_t* const* ima
     DetBuffers& D = m->sweep_det;
     // small device scratch for the scoring stage + an arena for augmented uint8 images
     int *d_ints = nullptr; float *d_par = nullptr, *d_cons = nullptr, *d_clsc = nullptr;
-    SaltPepperJob* d_jobs = nullptr;
+    SaltPepperJob* d_jobs = nullptr; GaussJob* d_gjobs = nullptr;
     const int P_MAX = B * (A > 0 ? A : 1);
     const size_t n_ints = (size_t)P_MAX * 4 + (size_t)B * 51 + (size_t)VT * 2;
     HIPCHK(hipMalloc((void**)&d_ints, n_ints * 4)); HIPCHK(hipMalloc((void**)&d_par, (size_t)P_MAX * 12 * 4));
     HIPCHK(hipMalloc((void**)&d_cons, (size_t)P_MAX * 4)); HIPCHK(hipMalloc((void**)&d_clsc, (size_t)VT * (C - 1) * 4));
-    HIPCHK(hipMalloc((void**)&d_jobs, sizeof(SaltPepperJob) * B));
+    HIPCHK(hipMalloc((void**)&d_jobs, sizeof(SaltPepperJob) * B)); HIPCHK(hipMalloc((void**)&d_gjobs, sizeof(GaussJob) * B));
     uint8_t* d_aug = nullptr; size_t aug_cap = 0;
     int rc = 0;
     std::vector<int> h_count(VT); std::vector<float> h_boxes((size_t)B * cap * 4), h_cons(P_MAX), h_clsc((size_t)VT * (C - 1));
     auto cleanup = [&]() {
         hipStreamSynchronize(c->stream);
-        hipFree(d_ints); hipFree(d_par); hipFree(d_cons); hipFree(d_clsc); hipFree(d_jobs); hipFree(d_aug);
+        hipFree(d_ints); hipFree(d_par); hipFree(d_cons); hipFree(d_clsc); hipFree(d_jobs); hipFree(d_gjobs); hipFree(d_aug);
     };
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     for (int i0 = 0; i0 < n_images && !rc; i0 += B) {
@@ -1104,12 +1104,13 @@ extern "C" int cald_sweep(cald_model* m, int n_images, const uint8_t* const* ima
         std::vector<int> ref_sel((size_t)B * 50, 0), ref_n(B, 0), pair_ref, pair_aug, pair_kind, pair_img, view_img(VT, 0), view_isref(VT, 0);
         std::vector<float> pair_par;
         std::vector<ViewDesc> aviews;
-        std::vector<SaltPepperJob> jobs;
+        std::vector<SaltPepperJob> jobs; std::vector<GaussJob> gjobs;
         size_t need = 0;
         for (int i = 0; i < nb; i++) {
             if (h_count[i] == 0) continue;
             const int Hi = H[i0 + i], Wi = W[i0 + i];
             if (cfg->aug_sp) need += al((size_t)Hi * Wi * 3);
+            if (cfg->aug_ga) need += al((size_t)Hi * Wi * 3 * sizeof(float));
             if (cfg->aug_resize) {
                 const int ow = (int)((double)Wi * (double)cfg->resize_ratio), oh = (int)((double)Hi * (double)cfg->resize_ratio);
                 need += al((size_t)oh * ow * 3) + al((size_t)Hi * ow * 3);
@@ -1146,6 +1147,11 @@ extern "C" int cald_sweep(cald_model* m, int n_images, const uint8_t* const* ima
             ViewDesc base; memset(&base, 0, sizeof(base)); base.src = images_dev[i0 + i]; base.H = Hi; base.W = Wi;
             float par[12] = {0};
             if (cfg->aug_flip) { ViewDesc v = base; v.flip = 1; par[0] = (float)Wi; add_view(v, 1, par); }
+            if (cfg->aug_ga) {     // GaussianNoise(image, 16), cald_train.py:128-131; torch.randn stream re-seeded per image
+                GaussJob gj; gj.dst = reinterpret_cast<float*>(take((size_t)Hi * Wi * 3 * sizeof(float))); gj.n = Hi * Wi * 3; gj.seed = seed; gj.std = cfg->ga_std;
+                gjobs.push_back(gj);
+                ViewDesc v = base; v.noise = gj.dst; add_view(v, 0, nullptr);
+            }
             if (cfg->aug_sp) {     // SaltPepperNoise(image, 0.1), cald_train.py:150-153; torch.rand stream re-seeded per image
                 SaltPepperJob j; j.src = images_dev[i0 + i]; j.dst = take((size_t)Hi * Wi * 3); j.H = Hi; j.W = Wi; j.seed = seed;
                 j.lo = (float)((double)cfg->sp_prob / 2.0); j.hi = (float)(1.0 - (double)cfg->sp_prob / 2.0);
@@ -1179,6 +1185,11 @@ extern "C" int cald_sweep(cald_model* m, int n_images, const uint8_t* const* ima
             if (hipMemcpyAsync(d_jobs, jobs.data(), sizeof(SaltPepperJob) * jobs.size(), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
                 hipStreamSynchronize(c->stream) != hipSuccess) { rc = fail(CALD_ERR_HIP, "H2D of salt-pepper jobs failed"); break; }
             launch_salt_pepper(d_jobs, (int)jobs.size(), c->stream);
+        }
+        if (!gjobs.empty()) {
+            if (hipMemcpyAsync(d_gjobs, gjobs.data(), sizeof(GaussJob) * gjobs.size(), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+                hipStreamSynchronize(c->stream) != hipSuccess) { rc = fail(CALD_ERR_HIP, "H2D of gaussian-noise jobs failed"); break; }
+            launch_gauss_noise(d_gjobs, (int)gjobs.size(), c->stream);
         }
         if (rc) break;
         // ---- phase 2: augmented views (chunks of <= 64) ----

@@ -45,6 +45,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const ViewDesc* views, 
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
                     float u = cut ? 0.0f : (float)p[c] / 255.0f;
+                    if (vd.noise) u = u + vd.noise[((long long)c * H + yy) * W + sx];
                     val[a][b][c] = (u - mean[c]) / stdv[c];
                 }
             }
@@ -239,4 +240,79 @@ __global__ __launch_bounds__(256) void salt_pepper_kernel(const SaltPepperJob* j
 }
 void launch_salt_pepper(const SaltPepperJob* jobs, int n, hipStream_t st) {
     if (n > 0) hipLaunchKernelGGL(salt_pepper_kernel, dim3(n), dim3(256), 0, st, jobs);
+}
+
+// ---------------------------------------------------------------------------------------------
+// cald_helper.GaussianNoise: the additive term torch.randn(3, H, W) * std / 255.0, generated on the
+// device from torch's CPU stream: MT19937 uniforms, Box-Muller per 16-chunk (elements j, j+8 pair
+// up; 624 = 39 * 16 so chunks never straddle a twist), and the "last 16 from 16 NEW uniforms" tail
+// when the size is not a multiple of 16.  One workgroup per image.
+// ---------------------------------------------------------------------------------------------
+__device__ inline unsigned mt_temper(unsigned y) {
+    y ^= (y >> 11); y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= (y >> 18);
+    return y;
+}
+__device__ inline float mt_u24(unsigned y) { return (float)((double)(y & 0xffffffu) * (1.0 / 16777216.0)); }
+__device__ inline void box_muller_pair(float ua, float ub, float std, float* oa, float* ob) {
+    const float u1 = 1.0f - ua;
+    const float radius = sqrtf(-2.0f * det_logf(u1));
+    float sn, cs;
+    det_sincosf(6.283185307179586f * ub, &sn, &cs);
+    *oa = ((radius * cs) * std) / 255.0f;
+    *ob = ((radius * sn) * std) / 255.0f;
+}
+__global__ __launch_bounds__(256) void gauss_noise_kernel(const GaussJob* jobs) {
+    __shared__ unsigned mt[624];
+    __shared__ float tail_u[16];
+    const GaussJob j = jobs[blockIdx.x];
+    const int tid = threadIdx.x;
+    const long long n = j.n;
+    if (tid == 0) {
+        unsigned x = (unsigned)(j.seed & 0xffffffffull);
+        mt[0] = x;
+        for (int i = 1; i < 624; i++) { x = 1812433253u * (x ^ (x >> 30)) + (unsigned)i; mt[i] = x; }
+    }
+    __syncthreads();
+    const long long rem = n % 16, n_full = n - rem;                 // elements covered by whole 16-chunks
+    const long long draws = n + (rem ? 16 : 0);
+    for (long long base = 0; base < draws; base += 624) {
+        for (int ph = 0; ph < 3; ph++) {
+            const int lo = ph == 0 ? 0 : (ph == 1 ? 227 : 454), hi = ph == 0 ? 227 : (ph == 1 ? 454 : 624);
+            unsigned nv = 0; const int k = lo + tid;
+            if (k < hi) {
+                const unsigned y = (mt[k] & 0x80000000u) | (mt[(k + 1) % 624] & 0x7fffffffu);
+                nv = mt[(k + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+            }
+            __syncthreads();
+            if (k < hi) mt[k] = nv;
+            __syncthreads();
+        }
+        // 39 chunks x 8 pairs per twist
+        for (int t = tid; t < 312; t += 256) {
+            const int ch = t >> 3, jj = t & 7;
+            const long long e = base + ch * 16 + jj;
+            if (e + 8 < n_full + 0 && e < n_full) {
+                float oa, ob;
+                box_muller_pair(mt_u24(mt_temper(mt[ch * 16 + jj])), mt_u24(mt_temper(mt[ch * 16 + jj + 8])), j.std, &oa, &ob);
+                // the tail (if any) overwrites [n-16, n): skip those here
+                if (!rem || e < n - 16) j.dst[e] = oa;
+                if (!rem || e + 8 < n - 16) j.dst[e + 8] = ob;
+            }
+        }
+        if (rem) {   // collect the 16 fresh uniforms n .. n+15 (may straddle two twists)
+            for (int t = tid; t < 624; t += 256) {
+                const long long d = base + t;
+                if (d >= n && d < n + 16) tail_u[d - n] = mt_u24(mt_temper(mt[t]));
+            }
+        }
+        __syncthreads();
+    }
+    if (rem && n >= 16 && tid < 8) {
+        float oa, ob;
+        box_muller_pair(tail_u[tid], tail_u[tid + 8], j.std, &oa, &ob);
+        j.dst[n - 16 + tid] = oa; j.dst[n - 16 + tid + 8] = ob;
+    }
+}
+void launch_gauss_noise(const GaussJob* jobs, int n, hipStream_t st) {
+    if (n > 0) hipLaunchKernelGGL(gauss_noise_kernel, dim3(n), dim3(256), 0, st, jobs);
 }

@@ -10,7 +10,7 @@ struct ViewDesc {
     int rects[4 * CALD_MAX_CUT];
     int Hr, Wr;           // detector-transform resized size (image_sizes)
     int Ho, Wo;           // size the detections are scaled back to (= H, W of this view's source)
-    int pad_[2];
+    const float* noise;   // optional additive noise, CHW float32 (GaussianNoise view), else null
 };
 
 // detections of one view, fixed capacity det_cap rows (frcnn_la.py:131-141 result dict)
@@ -36,6 +36,8 @@ void launch_subsample2(const float* in, float* out, const LevelSeg* sin, const L
 struct SaltPepperJob { const uint8_t* src; uint8_t* dst; int H, W; unsigned long long seed; float lo, hi; };
 void launch_affine_nearest(const uint8_t* src, int H, int W, uint8_t* dst, int oh, int ow, const int* a, hipStream_t st);
 void launch_salt_pepper(const SaltPepperJob* jobs, int n, hipStream_t st);
+struct GaussJob { float* dst; int n; unsigned long long seed; float std; };
+void launch_gauss_noise(const GaussJob* jobs, int n, hipStream_t st);
 
 // rpn.hip
 struct RpnArgs {

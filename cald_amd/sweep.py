@@ -15,7 +15,7 @@ from . import _ffi
 
 KNOWN_AUGS = ['flip', 'multi_ga', 'color_adjust', 'color_swap', 'multi_color_adjust', 'multi_sp', 'cut_out',
               'multi_cut_out', 'multi_resize', 'larger_resize', 'smaller_resize', 'rotation', 'ga', 'sp']
-SUPPORTED_AUGS = ('flip', 'sp', 'cut_out', 'smaller_resize', 'rotation')
+SUPPORTED_AUGS = ('flip', 'ga', 'sp', 'cut_out', 'smaller_resize', 'rotation')
 
 
 def _to_u8_cuda(image, device):
@@ -49,7 +49,7 @@ def sweep_device_images(task_model, images, positions, augs, bp=1.3, base_seed=0
     Ws = np.array([im.shape[1] for im in images], np.int32)
     pos = np.ascontiguousarray(positions, dtype=np.int64)
     cfg = _ffi.SweepCfg(int('flip' in augs), int('cut_out' in augs), int('smaller_resize' in augs), 0.8,
-                        int(base_seed), float(bp), int(batch_images), int('sp' in augs), 0.1, int('rotation' in augs), 5.0)
+                        int(base_seed), float(bp), int(batch_images), int('sp' in augs), 0.1, int('rotation' in augs), 5.0, int('ga' in augs), 16.0)
     _ffi.check(L.cald_sweep(task_model.handle(), n, ptrs, _ffi.ptr(Hs, _ffi.c_i), _ffi.ptr(Ws, _ffi.c_i),
                             _ffi.ptr(pos, _ffi.c_i64), C.byref(cfg), _ffi.ptr(cons, _ffi.c_d), _ffi.ptr(cls, _ffi.c_d)))
     return cons, cls

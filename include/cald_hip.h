@@ -105,6 +105,8 @@ typedef struct cald_sweep_cfg {
     float sp_prob;         /* 0.1 */
     int aug_rotate;        /* 'rotation': rotate(image, ref_boxes, rotate_angle) */
     float rotate_angle;    /* 5 */
+    int aug_ga;            /* 'ga': GaussianNoise(image, ga_std), torch.randn stream re-seeded per image */
+    float ga_std;          /* 16 */
 } cald_sweep_cfg;
 int cald_sweep(cald_model* m, int n_images, const uint8_t* const* images_dev, const int* H, const int* W,
                const int64_t* pool_pos, const cald_sweep_cfg* cfg, double* consistency_out, double* cls_corr_out);

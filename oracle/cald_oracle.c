@@ -351,7 +351,7 @@ static const float ORC_STD[3] = {0.229f, 0.224f, 0.225f};
  * resize (align_corners=False, scale = in/out) -> zero pad.  Output NHWC with 4 channels
  * (4th = 0), [Hp][Wp][4].  rects are (left, top, right, bottom) in view coordinates. */
 ORC_API void orc_preprocess_view(const uint8_t* src, int H, int W, int flip, int nrect, const int* rects,
-                                 int Hr, int Wr, int Hp, int Wp, float* out) {
+                                 int Hr, int Wr, int Hp, int Wp, float* out, const float* noise /* CHW or NULL */) {
     memset(out, 0, sizeof(float) * (size_t)Hp * Wp * 4);
     float sh = (float)H / (float)Hr, sw = (float)W / (float)Wr;
 #pragma omp parallel for schedule(static) num_threads(orc_threads)
@@ -373,6 +373,7 @@ ORC_API void orc_preprocess_view(const uint8_t* src, int H, int W, int flip, int
                     int sx = flip ? (W - 1 - xx) : xx;
                     for (int c = 0; c < 3; c++) {
                         float u = cut ? 0.0f : (float)src[((size_t)yy * W + sx) * 3 + c] / 255.0f;
+                        if (noise) u = u + noise[((size_t)c * H + yy) * W + sx];
                         v[a][b][c] = (u - ORC_MEAN[c]) / ORC_STD[c];
                     }
                 }
@@ -909,4 +910,36 @@ ORC_API void orc_rotate_boxes(const float* boxes, int N, int H, int W, double an
         out[4 * i + 0] = clampf(r[0], 0.0f, (float)W); out[4 * i + 1] = clampf(r[1], 0.0f, (float)H);
         out[4 * i + 2] = clampf(r[2], 0.0f, (float)W); out[4 * i + 3] = clampf(r[3], 0.0f, (float)H);
     }
+}
+
+
+/* -------------------------------------------------------------------------------------
+ * GaussianNoise (cald_helper.py:72-75): image + torch.randn(size) * std / 255.0.
+ * torch.randn on the CPU generator (>= 16 elements): the tensor is first filled with uniforms from
+ * the MT19937 stream, then every 16-chunk is transformed by Box-Muller (elements j and j+8 pair
+ * up); if the size is not a multiple of 16 the last 16 entries are refilled from 16 NEW uniforms and
+ * transformed.  log / sin / cos are the oracle's deterministic float32 versions (torch uses its
+ * vector math library; agreement ~1e-6).  out[i] = (randn[i] * std) / 255.
+ * ------------------------------------------------------------------------------------- */
+static void normal_fill_16(const float* u, float* o, float std) {
+    for (int j = 0; j < 8; j++) {
+        float u1 = 1.0f - u[j], u2 = u[j + 8];
+        float radius = sqrtf(-2.0f * orc_logf(u1));
+        float theta = 6.283185307179586f * u2, sn, cs;
+        orc_sincosf(theta, &sn, &cs);
+        o[j] = ((radius * cs) * std) / 255.0f;
+        o[j + 8] = ((radius * sn) * std) / 255.0f;
+    }
+}
+ORC_API void orc_gaussian_noise(uint64_t seed, int n, float std, float* out) {
+    orc_mt s; mt_init_genrand(&s, (uint32_t)(seed & 0xffffffffu));
+    float* u = (float*)malloc(sizeof(float) * ((size_t)n + 16));
+    for (int i = 0; i < n; i++) u[i] = (float)((double)(mt_next(&s) & 0xffffffu) * (1.0 / 16777216.0));
+    for (int i = 0; i + 15 < n; i += 16) normal_fill_16(u + i, out + i, std);
+    if (n % 16 != 0 && n >= 16) {
+        float v[16];
+        for (int i = 0; i < 16; i++) v[i] = (float)((double)(mt_next(&s) & 0xffffffu) * (1.0 / 16777216.0));
+        normal_fill_16(v, out + n - 16, std);
+    }
+    free(u);
 }

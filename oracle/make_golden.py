@@ -149,6 +149,9 @@ def gen_helpers(ch):
             blob["cutout%d_%d_img" % (i, s)] = (ci * 255).round().to(torch.uint8).permute(1, 2, 0).numpy()
         ri, rb = ch.rotate(Image.fromarray(img), torch.from_numpy(boxes), 5)
         blob["rotate%d_img" % i] = (ri * 255).round().to(torch.uint8).permute(1, 2, 0).numpy(); blob["rotate%d_boxes" % i] = rb.numpy()
+        if i >= 2:
+            torch.manual_seed(31 + i)
+            blob["ga%d_img" % i] = ch.GaussianNoise(Image.fromarray(img), 16).permute(1, 2, 0).numpy()    # float32 HWC
         for s in (21, 22):
             torch.manual_seed(s)
             si = ch.SaltPepperNoise(Image.fromarray(img), 0.1)

@@ -187,6 +187,13 @@ def rotate_aug(img, boxes, angle):
     return back, out
 
 
+def gaussian_noise(seed, H, W, std=16):
+    """cald_helper.py:72-75: the additive term torch.randn(3, H, W) * std / 255.0 (CHW float32)."""
+    out = np.empty(3 * H * W, np.float32)
+    lib().orc_gaussian_noise(C.c_uint64(seed), C.c_int(3 * H * W), C.c_float(std), _p(out))
+    return out.reshape(3, H, W)
+
+
 def resize_aug(img, ratio):
     H, W, _ = img.shape
     ow, oh = int(W * ratio), int(H * ratio)
@@ -200,7 +207,7 @@ def transform_size(H, W, min_size, max_size):
     return tuple(x.value for x in v)  # Hr, Wr, Hp, Wp
 
 
-def preprocess_view(img, min_size, max_size, flip=False, rects=None):
+def preprocess_view(img, min_size, max_size, flip=False, rects=None, noise=None):
     img = np.ascontiguousarray(img, dtype=np.uint8)
     H, W, _ = img.shape
     Hr, Wr, Hp, Wp = transform_size(H, W, min_size, max_size)
@@ -208,7 +215,7 @@ def preprocess_view(img, min_size, max_size, flip=False, rects=None):
     r = np.ascontiguousarray(rects, dtype=np.int32).reshape(-1, 4) if rects is not None and len(rects) else None
     lib().orc_preprocess_view(_p(img, c_u8), C.c_int(H), C.c_int(W), C.c_int(int(flip)),
                               C.c_int(0 if r is None else r.shape[0]), _p(r, c_i) if r is not None else None,
-                              C.c_int(Hr), C.c_int(Wr), C.c_int(Hp), C.c_int(Wp), _p(out))
+                              C.c_int(Hr), C.c_int(Wr), C.c_int(Hp), C.c_int(Wp), _p(out), _p(f32(noise)) if noise is not None else None)
     return out, (Hr, Wr, Hp, Wp)
 
 
@@ -393,10 +400,10 @@ def frcnn_backbone(P, x, keep=None):
 
 
 def frcnn_forward(P, img, min_size, max_size, flip=False, rects=None, keep=None,
-                  score_thr=0.05, nms_thr=0.5, det_max=100):
+                  score_thr=0.05, nms_thr=0.5, det_max=100, noise=None):
     """frcnn_la.py:237-275 for ONE view (batch 1, like the reference)."""
     H, W, _ = img.shape
-    x, (Hr, Wr, Hp, Wp) = preprocess_view(img, min_size, max_size, flip, rects)
+    x, (Hr, Wr, Hp, Wp) = preprocess_view(img, min_size, max_size, flip, rects, noise)
     if keep is not None: keep["input"] = x; keep["sizes"] = (Hr, Wr, Hp, Wp)
     feats = frcnn_backbone(P, x, keep)
     if keep is not None: keep["fpn"] = feats
@@ -499,10 +506,10 @@ def retina_postprocess(cls, reg, anchors, Hp, Wp, Hr, Wr, Ho, Wo, K, A=9, score_
     return dict(boxes=ob[:n].copy(), scores=os_[:n].copy(), labels=ol[:n].copy(), prob_max=opm[:n].copy(), scores_cls=osc[:n].copy())
 
 
-def retina_forward(P, img, min_size, max_size, flip=False, rects=None, keep=None, score_thr=0.05, nms_thr=0.5, per_class=300):
+def retina_forward(P, img, min_size, max_size, flip=False, rects=None, keep=None, score_thr=0.05, nms_thr=0.5, per_class=300, noise=None):
     """retinanet_cal.py:492-575 for ONE view."""
     H, W, _ = img.shape
-    x, (Hr, Wr, Hp, Wp) = preprocess_view(img, min_size, max_size, flip, rects)
+    x, (Hr, Wr, Hp, Wp) = preprocess_view(img, min_size, max_size, flip, rects, noise)
     feats = retina_backbone(P, x, keep)
     if keep is not None: keep["fpn"] = feats; keep["sizes"] = (Hr, Wr, Hp, Wp)
     cls, reg = [], []
@@ -519,10 +526,10 @@ def retina_forward(P, img, min_size, max_size, flip=False, rects=None, keep=None
     return retina_postprocess(cls, reg, P["anchors"], Hp, Wp, Hr, Wr, H, W, P["num_classes"], 9, score_thr, nms_thr, per_class)
 
 
-def detector_forward(P, img, min_size, max_size, flip=False, rects=None, keep=None):
+def detector_forward(P, img, min_size, max_size, flip=False, rects=None, keep=None, noise=None):
     if P.get("arch") == "retinanet":
-        return retina_forward(P, img, min_size, max_size, flip, rects, keep)
-    return frcnn_forward(P, img, min_size, max_size, flip, rects, keep)
+        return retina_forward(P, img, min_size, max_size, flip, rects, keep, noise=noise)
+    return frcnn_forward(P, img, min_size, max_size, flip, rects, keep, noise=noise)
 
 
 # ----------------------------------------------------------------------------- the sweep (A1)
@@ -538,6 +545,8 @@ def build_views(img, augs, ref, seed):
     rb = ref["boxes"]
     if "flip" in augs:
         views.append((img, True, None, flip_boxes(rb, W)))
+    if "ga" in augs:
+        views.append((img, False, None, rb, gaussian_noise(seed, H, W, 16)))
     if "sp" in augs:
         views.append((salt_pepper(img, 0.1, seed), False, None, rb))
     if "cut_out" in augs:
@@ -582,7 +591,7 @@ def get_uncertainty(P, images, augs, num_cls, bp=1.3, min_size=600, max_size=100
             c, cc = score_image(ref, [], [], num_cls, bp)
         else:
             views = build_views(img, augs, ref, image_seed(base_seed, gpos))
-            outs = [detector_forward(P, v[0], min_size, max_size, v[1], v[2]) for v in views]
+            outs = [detector_forward(P, v[0], min_size, max_size, v[1], v[2], noise=(v[4] if len(v) > 4 else None)) for v in views]
             c, cc = score_image(ref, outs, [v[3] for v in views], num_cls, bp)
         consistency_all.append(c); cls_all.append(cc)
     return consistency_all, cls_all

@@ -74,6 +74,27 @@ static inline float orc_logf(float x) {
     return r;
 }
 
+/* sin and cos for x in [0, 2*pi] (Box-Muller angle): quadrant reduction + Cephes minimax polynomials */
+static inline void orc_sincosf(float x, float* s, float* c) {
+    float q = rintf(x * 0.636619772f);                 /* 2/pi */
+    float r = fmaf(q, -1.5703125f, x);
+    r = fmaf(q, -4.837512969970703125e-4f, r);
+    r = fmaf(q, -7.54978995489188216e-8f, r);
+    float z = r * r;
+    float ps = -1.9515295891e-4f;
+    ps = fmaf(ps, z, 8.3321608736e-3f);
+    ps = fmaf(ps, z, -1.6666654611e-1f);
+    float sn = fmaf(ps * z, r, r);
+    float pc = 2.443315711809948e-5f;
+    pc = fmaf(pc, z, -1.388731625493765e-3f);
+    pc = fmaf(pc, z, 4.166664568298827e-2f);
+    float cs = fmaf(pc * z, z, fmaf(z, -0.5f, 1.0f));
+    int qi = ((int)q) & 3;
+    float ss = (qi & 1) ? cs : sn, cc = (qi & 1) ? sn : cs;
+    if (qi == 2 || qi == 3) ss = -ss;
+    if (qi == 1 || qi == 2) cc = -cc;
+    *s = ss; *c = cc;
+}
 static inline float orc_sigmoidf(float x) { return 1.0f / (1.0f + orc_expf(-x)); }
 static inline float orc_log2f(float x) { return orc_logf(x) * 1.44269504f; }
 

@@ -158,7 +158,7 @@ def get_uncertainty(model, images, augs, num_cls, bp=1.3, base_seed=0, positions
             c, cc = score_image_python(ref, [], [], num_cls, bp)
         else:
             views = orc.build_views(img, augs, ref, orc.image_seed(base_seed, gpos))
-            outs = [model.forward(v[0], v[1], v[2]) for v in views]
+            outs = [model.forward(v[0], v[1], v[2]) for v in views]   # (the port is only timed on flip / cut_out / resize)
             c, cc = score_image_python(ref, outs, [v[3] for v in views], num_cls, bp)
         cons.append(c); cls.append(cc)
     return cons, cls

@@ -231,7 +231,7 @@ def test_sweep_five_augs_matches_oracle(hip, oracle, small_model):
     from cald_amd import synth, sweep
     model, P = small_model
     pool = synth.make_pool(5, "voc", 0, scale=0.5)
-    augs = ["flip", "sp", "cut_out", "smaller_resize", "rotation"]
+    augs = ["flip", "ga", "sp", "cut_out", "smaller_resize", "rotation"]
     cons, cls = sweep.sweep_device_images(model, [torch.from_numpy(im).cuda() for im in pool], list(range(len(pool))), augs,
                                           bp=1.3, base_seed=11, batch_images=3)
     wc, wcls = oracle.get_uncertainty(P, pool, augs, 21, bp=1.3, min_size=300, max_size=500, base_seed=11)
@@ -274,4 +274,4 @@ def test_empty_reference_and_error_paths(hip, oracle, small_model):
     with pytest.raises(RuntimeError):
         model.forward_views([(torch.zeros((0, 0, 3), dtype=torch.uint8, device="cuda"), False, None)])
     with pytest.raises(NotImplementedError):
-        sweep.sweep_device_images(model, [torch.from_numpy(pool[1]).cuda()], [0], ["ga"])
+        sweep.sweep_device_images(model, [torch.from_numpy(pool[1]).cuda()], [0], ["multi_ga"])

@@ -67,6 +67,10 @@ def test_helpers_match_reference(oracle, golden):
         np.testing.assert_allclose(rb, g["rotate%d_boxes" % i], rtol=0, atol=1e-4)    # float tolerance of BASELINE.json
         for s in (21, 22):
             np.testing.assert_array_equal(oracle.salt_pepper(img, 0.1, s), g["sp%d_%d_img" % (i, s)])
+        if i >= 2:   # GaussianNoise: torch.randn's stream structure, float tolerance 1e-4 (measured ~1e-7)
+            noise = oracle.gaussian_noise(31 + i, H, W, 16)
+            got = img.astype(np.float32) / np.float32(255) + noise.transpose(1, 2, 0)
+            np.testing.assert_allclose(got, g["ga%d_img" % i], rtol=0, atol=1e-6)
     for s in (0, 1, 12345, (1 << 40) + 17):
         np.testing.assert_array_equal(oracle.py_random(s, 8), g["pyrandom_%d" % s])
 
