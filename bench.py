@@ -48,6 +48,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch-images", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--model", default="frcnn", choices=["frcnn", "frcnn101", "retinanet"],
+                    help="frcnn = the headline workload (BASELINE configs[1]); others are informational runs of configs[2]/[4]")
+    ap.add_argument("--shape", default="voc", choices=["voc", "coco"])
+    ap.add_argument("--augs", default="FCD", help="letters of cald_train.py --augs (F C D R G S)")
     args = ap.parse_args()
 
     import numpy as np
@@ -59,22 +63,40 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
     assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback for the product path"
+    # dry-run aid for 1-GPU boxes: CALD_BENCH_SHARE_GPU=1 puts every rank on cuda:0 with the gloo backend
+    share = os.environ.get("CALD_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from cald_amd import _ffi, detector, synth, sweep
     B, K, Wm = args.batch_images, args.steps, args.warmup
-    augs = ["flip", "cut_out", "smaller_resize"]
-    sd = synth.pseudo_trained_frcnn(21, 50, seed=0)
-    model = detector.fasterrcnn_resnet50_fpn_feature(num_classes=21, min_size=600, max_size=1000).to("cuda:%d" % local_rank)
+    letters = {"F": "flip", "C": "cut_out", "D": "smaller_resize", "R": "rotation", "G": "ga", "S": "sp"}
+    augs = [letters[ch] for ch in args.augs]
+    ncls = 21 if args.shape == "voc" else 91
+    mn, mx = (600, 1000) if args.shape == "voc" else (800, 1333)
+    headline = (args.model == "frcnn" and args.shape == "voc" and args.augs == "FCD")
+    if args.model == "retinanet":
+        sd = synth.pseudo_trained_retinanet(ncls, 50, seed=0)
+        model = detector.retinanet_resnet50_fpn_cal(num_classes=ncls, min_size=mn, max_size=mx)
+    else:
+        depth = 101 if args.model == "frcnn101" else 50
+        sd = synth.pseudo_trained_frcnn(ncls, depth, seed=0)
+        model = (detector.fasterrcnn_resnet101_fpn_feature if depth == 101 else detector.fasterrcnn_resnet50_fpn_feature)(
+            num_classes=ncls, min_size=mn, max_size=mx)
+    model = model.to("cuda:%d" % local_rank)
     model.load_state_dict(sd)
     model.eval()
 
     # distinct images per rank, resident in HBM before the timed region; rank r owns pool positions p % world == r
     n_local = B * min(K + Wm, 2)
-    sizes = synth.pool_sizes(n_local * world, "voc", 0)
+    sizes = synth.pool_sizes(n_local * world, args.shape, 0)
     positions = [rank + world * i for i in range(n_local)]
     host_pool = [synth.synth_image(p, *sizes[p]) for p in positions]
     dev_pool = [torch.from_numpy(im).cuda() for im in host_pool]
@@ -106,7 +128,7 @@ def main():
     barrier()
     dt = time.time() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if share else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     import ctypes as C
@@ -133,16 +155,17 @@ def main():
             "metric": "unlabeled images scored/sec (CALD consistency sweep)", "value": images / dt, "unit": "images/s",
             "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": dt / K * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: Faster R-CNN ResNet-50 FPN, VOC2012-shaped synthetic pool, "
-                                   "3 augs (flip/cut_out/smaller_resize), 21 classes, min/max 600/1000, seeded pseudo-trained weights",
-                       "images_per_step_per_gpu": B, "views_per_image": 4, "parallelism": "pool sharded by position, dp%d" % world},
+            "config": {"workload": ("BASELINE.json configs[1]: Faster R-CNN ResNet-50 FPN, VOC2012-shaped synthetic pool, "
+                                    "3 augs (flip/cut_out/smaller_resize), 21 classes, min/max 600/1000, seeded pseudo-trained weights")
+                       if headline else "informational: model=%s shape=%s augs=%s classes=%d min/max %d/%d" % (args.model, args.shape, args.augs, ncls, mn, mx),
+                       "images_per_step_per_gpu": B, "views_per_image": 1 + len(augs), "parallelism": "pool sharded by position, dp%d" % world},
             "roofline": {"bound": "mfma", "kernel": "conv_mfma_f32_kernel (implicit-GEMM conv + linear, v_mfma_f32_32x32x2_f32)",
                          "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
                          "launches": int(nl.value), "avg_launch_ms": gm.value / max(1, nl.value),
                          "gemm_ms_per_step": gm.value / K, "algorithmic_gflop_per_launch": gf.value / max(1, nl.value) / 1e9},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and headline:
             out["cpu_baseline"] = cpu_baseline(sd, host_pool, augs)
             out["cpu_baseline"]["host_cpus"] = os.cpu_count()
         print(json.dumps(out))

@@ -280,7 +280,11 @@ static void launch_cfg(const ConvArgs& a, int bn, hipStream_t stream) {
     else hipLaunchKernelGGL((conv_mfma_f32_kernel<WM, WN, TM, TN, 0, BK, true>), grid, block, dl, stream, a);
 }
 
+bool launch_conv_p3(const ConvArgs& a, hipStream_t stream);   // conv_p3.hip
+
 void launch_conv(const ConvArgs& a, hipStream_t stream) {
+    static const int p3 = conv_env("CALD_CONV_P3", 0);
+    if (p3 && launch_conv_p3(a, stream)) return;
     static const int bk32 = conv_env("CALD_CONV_BK32", 0);
     if (a.CoutPad % 128 == 0) {
         if (bk32 && a.Kpad % 32 == 0) launch_cfg<2, 2, 2, 2, 32>(a, 128, stream);
