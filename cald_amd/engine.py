@@ -1,0 +1,70 @@
+"""Evaluation-side consumer of the same detector forward.
+
+``voc_detections`` is the forward half of detection/engine.py:86-141 (``voc_evaluate``): it walks the test
+loader, runs the HIP detector -- batched, up to 64 images per launch sequence instead of the reference's
+batch-1 loop with a ``torch.cuda.synchronize()`` per image -- and returns ``(all_boxes, image_index)`` in the
+reference's structure.  ``write_voc_results_file`` emits the wire format of detection/voc_eval.py:188-222
+(``/tmp/{path}/det_test_{cls}.txt``: ``image_id score x1+1 y1+1 x2+1 y2+1``), which the reference's own
+``_do_python_eval`` then consumes.  AP computation itself stays with the reference (host code, needs the VOC
+annotation files).
+"""
+import os
+import shutil
+
+import torch
+
+
+def voc_detections(model, data_loader, num_classes=21, batch_views=64):
+    model.eval()
+    all_boxes = [[] for _ in range(num_classes)]
+    image_index = []
+    pending = []
+
+    def flush():
+        if not pending:
+            return
+        outs = model([im for im, _ in pending])
+        for (_, name), o in zip(pending, outs):
+            image_index.append(name)
+            o = {k: v.cpu() for k, v in o.items()}
+            per_cls = [[] for _ in range(num_classes)]
+            for i in range(o['boxes'].shape[0]):
+                per_cls[int(o['labels'][i])].append(torch.cat([o['boxes'][i], o['scores'][i].unsqueeze(0)], dim=0))
+            for c in range(num_classes):
+                all_boxes[c].append([torch.stack(per_cls[c])] if per_cls[c] else [])
+        pending.clear()
+
+    for images, targets in data_loader:
+        for img, t in zip(images, targets):
+            name = ''.join(chr(int(i)) for i in t['name'].tolist()) if 'name' in t else str(len(image_index) + len(pending))
+            pending.append((img, name))
+            if len(pending) >= batch_views:
+                flush()
+    flush()
+    return all_boxes, image_index
+
+
+def write_voc_results_file(all_boxes, image_index, path, classes, root='/tmp'):
+    out_dir = os.path.join(root, path)
+    if os.path.exists(out_dir):
+        shutil.rmtree(out_dir)
+    os.makedirs(out_dir)
+    all_boxes = [list(b) for b in all_boxes]
+    for cls_ind, cls in enumerate(classes):
+        pairs = sorted(zip(image_index, all_boxes[cls_ind]), key=lambda x: x[0])
+        if cls == '__background__':
+            continue
+        with open(os.path.join(out_dir, 'det_test_{:s}.txt'.format(cls)), 'wt') as f:
+            prev = ''
+            for index, dets in pairs:
+                if prev == index:       # repeated inputs (DistributedSampler padding) are discarded
+                    continue
+                prev = index
+                if dets == []:
+                    continue
+                dets = dets[0]
+                for k in range(dets.shape[0]):
+                    f.write('{:s} {:.3f} {:.1f} {:.1f} {:.1f} {:.1f}\n'.format(
+                        index, float(dets[k, -1]), float(dets[k, 0]) + 1, float(dets[k, 1]) + 1,
+                        float(dets[k, 2]) + 1, float(dets[k, 3]) + 1))
+    return out_dir

@@ -212,6 +212,30 @@ def gen_selection(ct):
     print("selection ok")
 
 
+def gen_voc_results():
+    """detection/voc_eval.py:188-222 _write_voc_results_file on synthetic detections -> text fixture."""
+    import importlib, glob
+    ve = importlib.import_module("detection.voc_eval")
+    rs = np.random.RandomState(4)
+    classes = ('__background__', 'aeroplane', 'bicycle', 'bird')
+    names = ["2008_%06d" % i for i in (12, 3, 7, 3)]          # one repeated index
+    all_boxes = [[] for _ in classes]
+    blob = {"names": np.array(names), "classes": np.array(classes)}
+    for ii, n in enumerate(names):
+        for c in range(len(classes)):
+            k = rs.randint(0, 3)
+            if k:
+                d = torch.from_numpy((rs.rand(k, 5) * 300).astype(np.float32)); d[:, 4] = torch.from_numpy(rs.rand(k).astype(np.float32))
+                all_boxes[c].append([d]); blob["d%d_%d" % (ii, c)] = d.numpy()
+            else:
+                all_boxes[c].append([])
+    ve._write_voc_results_file([list(b) for b in all_boxes], list(names), "cald_golden_voc", classes)
+    for f in sorted(glob.glob("/tmp/cald_golden_voc/det_test_*.txt")):
+        blob["file_" + os.path.basename(f)] = np.array(open(f).read())
+    np.savez_compressed(os.path.join(OUT, "voc_results.npz"), **blob)
+    print("voc_results ok")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ct, ch = ref_harness.load_reference()
@@ -226,6 +250,7 @@ def main():
     gen_helpers(ch)
     gen_js()
     gen_selection(ct)
+    gen_voc_results()
 
 
 if __name__ == "__main__":

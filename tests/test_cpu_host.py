@@ -226,3 +226,20 @@ def test_get_uncertainty_sharded_equals_single_rank():
     for _, cons, cls in res:
         np.testing.assert_array_equal(cons, np.array(c1))
         np.testing.assert_array_equal(cls, np.stack(k1))
+
+
+def test_voc_results_wire_format_matches_reference(golden, tmp_path):
+    """engine.write_voc_results_file == detection/voc_eval.py:188-222 on the same detections."""
+    import torch
+    from cald_amd import engine
+    g = golden("voc_results")
+    names, classes = [str(n) for n in g["names"]], [str(c) for c in g["classes"]]
+    all_boxes = [[] for _ in classes]
+    for ii in range(len(names)):
+        for c in range(len(classes)):
+            key = "d%d_%d" % (ii, c)
+            all_boxes[c].append([torch.from_numpy(g[key])] if key in g.files else [])
+    out = engine.write_voc_results_file(all_boxes, names, "res", classes, root=str(tmp_path))
+    for key in g.files:
+        if key.startswith("file_"):
+            assert open(os.path.join(out, key[5:])).read() == str(g[key]), key

@@ -275,3 +275,23 @@ def test_empty_reference_and_error_paths(hip, oracle, small_model):
         model.forward_views([(torch.zeros((0, 0, 3), dtype=torch.uint8, device="cuda"), False, None)])
     with pytest.raises(NotImplementedError):
         sweep.sweep_device_images(model, [torch.from_numpy(pool[1]).cuda()], [0], ["multi_ga"])
+
+
+def test_ragged_batch_equals_batch1_and_eval_consumer(hip, small_model):
+    """A batched launch (views of different sizes) returns exactly what one-by-one calls return (the reference
+    is batch-1); the evaluation consumer (engine.voc_detections) sees the same detections."""
+    torch = hip["torch"]
+    from cald_amd import synth, engine
+    model, _ = small_model
+    pool = synth.make_pool(5, "voc", 0, scale=0.5)
+    imgs = [torch.from_numpy(im).permute(2, 0, 1).float().div(255).cuda() for im in pool]     # ToTensor-style inputs
+    together = model(imgs)
+    for i, im in enumerate(imgs):
+        alone = model([im])[0]
+        for k in ("boxes", "scores", "labels", "prob_max", "scores_cls", "props"):
+            assert torch.equal(alone[k], together[i][k]), (i, k)
+    loader = [((im,), ({"name": torch.tensor([ord(ch) for ch in "img%03d" % i])},)) for i, im in enumerate(imgs)]
+    all_boxes, index = engine.voc_detections(model, loader, 21, batch_views=2)
+    assert index == ["img%03d" % i for i in range(5)]
+    n = sum(b[0].shape[0] for c in all_boxes for b in c if b != [])
+    assert n == sum(int(o["boxes"].shape[0]) for o in together)
