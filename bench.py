@@ -25,20 +25,32 @@ if ROOT not in sys.path:
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
 
 
-def cpu_baseline(sd, pool, augs, budget_s=12.0, max_images=3):
+def cpu_baseline(sd, pool, augs, budget_s=12.0, max_images=24):
     """The reference-shaped PyTorch-CPU port (oracle/torch_port.py) on a bounded sample of the same workload."""
     import torch
     from oracle import torch_port
     model = torch_port.TorchFRCNN(sd, 21, 50, 600, 1000)
     model.forward(pool[0])          # warm-up view (oneDNN primitive creation), not timed
+    # batch-1 convolutions do not scale to every core of a big host: use the thread count that is fastest here
+    default_threads = torch.get_num_threads()
+    best = (None, 1e30)
+    for nt in sorted({default_threads, max(1, default_threads // 2), max(1, default_threads // 4), max(1, default_threads // 8)}, reverse=True):
+        torch.set_num_threads(nt)
+        model.forward(pool[0])
+        t = time.time(); model.forward(pool[0]); t = time.time() - t
+        if t < best[1]:
+            best = (nt, t)
+    torch.set_num_threads(best[0])
     n, t0 = 0, time.time()
     while n < max_images and (n == 0 or time.time() - t0 < budget_s):
         torch_port.get_uncertainty(model, [pool[n]], augs, 21, bp=1.3, base_seed=0, positions=[n])
         n += 1
     dt = time.time() - t0
-    return {"value": n / dt, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+    used = torch.get_num_threads()
+    torch.set_num_threads(default_threads)
+    return {"value": n / dt, "unit": "images/s", "cores": used, "kind": "port",
             "sample": "%d synthetic VOC-shaped image(s) x 4 views, batch-1 sequential torch-CPU fp32 forwards + python/scipy "
-                      "scoring loop (oracle/torch_port.py), %.1f s" % (n, dt)}
+                      "scoring loop (oracle/torch_port.py), %.1f s; thread count chosen as the fastest of {T, T/2, T/4, T/8}" % (n, dt)}
 
 
 def main():
@@ -113,6 +125,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if Wm == 0:
+        step(0)       # one-time initialisation (code objects, workspace arena) is model build, not a step
     for s in range(Wm):
         step(s)
     L, ctx = _ffi.lib(), detector.get_ctx(local_rank)
