@@ -17,6 +17,8 @@
 #include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int EPI>
 __global__ __launch_bounds__(256, 3) void conv_p3_kernel(const ConvArgs a) {
@@ -45,14 +47,16 @@ __global__ __launch_bounds__(256, 3) void conv_p3_kernel(const ConvArgs a) {
     if (m0 >= Mv) return;
     const float* __restrict__ in_v = a.in + si.pix_off * (long long)a.Cin;
     const float* __restrict__ wgt = a.w;
-    const float* __restrict__ zpage = a.zeros;
     const int Cin = a.Cin, KW = a.KW, KH = a.KH, CoutPad = a.CoutPad;
     const bool in_relu = a.in_relu != 0;
 
-    // A gather: rows arow, arow+64; k group g.  Tap-validity masks + element offsets precomputed.
+    // A gather through a buffer resource (SRSRC + 32-bit voffset + wave-uniform soffset): the per-tile address
+    // work is 3 VALU per row (tap-valid test -> voffset or an out-of-range offset that the hardware returns as
+    // zeros) instead of 64-bit pointer arithmetic; the B (weights) loads need no VALU at all.
+    // The resource base is shifted by -pad rows/cols so that voffset and soffset are both non-negative.
     const int g = tid & 3, arow = tid >> 2;
     unsigned rowmask[2];
-    int rowoff[2];
+    int rowvoff[2];
 #pragma unroll
     for (int p = 0; p < 2; p++) {
         const int m = m0 + arow + 64 * p;
@@ -66,26 +70,30 @@ __global__ __launch_bounds__(256, 3) void conv_p3_kernel(const ConvArgs a) {
                 if (iy >= 0 && iy < Hi && ix >= 0 && ix < Wi) msk |= 1u << t;
             }
         rowmask[p] = msk;
-        rowoff[p] = (iy0 * Wi + ix0) * Cin + 4 * g;
+        rowvoff[p] = (((oy * a.stride) * Wi + ox * a.stride) * Cin + 4 * g) * 4;       // bytes, >= 0
     }
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(in_v - (long long)a.pad * (Wi + 1) * Cin), 0, 0x7FFE0000, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(wgt + n0), 0, 0x7FFE0000, 0x00020000);
     int u_kh = 0, u_kw = 0, u_ci = 0, u_kt = 0;      // wave-uniform cursor of the NEXT tile to load
     const int bk0 = tid >> 5, bc0 = tid & 31;        // B: rows bk0 and bk0+8, float4 column bc0
+    const int bvoff0 = (bk0 * CoutPad + 4 * bc0) * 4, bvoff1 = bvoff0 + 8 * CoutPad * 4;
 
     float ax0, ay0, az0, aw0, ax1, ay1, az1, aw1, bx0, by0, bz0, bw0, bx1, by1, bz1, bw1;
 
 #define P3_LOAD()                                                                                          \
     {                                                                                                      \
-        const int u_tap = u_kh * KW + u_kw;                                                                \
-        const int u_off = (u_kh * Wi + u_kw) * Cin + u_ci;                                                 \
-        const float* s0 = ((rowmask[0] >> u_tap) & 1u) ? (in_v + (rowoff[0] + u_off)) : zpage;             \
-        const float* s1 = ((rowmask[1] >> u_tap) & 1u) ? (in_v + (rowoff[1] + u_off)) : zpage;             \
-        const float4 t0 = *reinterpret_cast<const float4*>(s0);                                            \
-        const float4 t1 = *reinterpret_cast<const float4*>(s1);                                            \
-        const float* wrow = wgt + (long long)(u_kt * BK + bk0) * CoutPad + n0 + 4 * bc0;                   \
-        const float4 t2 = *reinterpret_cast<const float4*>(wrow);                                          \
-        const float4 t3 = *reinterpret_cast<const float4*>(wrow + 8ll * CoutPad);                          \
-        ax0 = t0.x; ay0 = t0.y; az0 = t0.z; aw0 = t0.w; ax1 = t1.x; ay1 = t1.y; az1 = t1.z; aw1 = t1.w;    \
-        bx0 = t2.x; by0 = t2.y; bz0 = t2.z; bw0 = t2.w; bx1 = t3.x; by1 = t3.y; bz1 = t3.z; bw1 = t3.w;    \
+        const unsigned u_bit = 1u << (u_kh * KW + u_kw);                                                   \
+        const int soffA = ((u_kh * Wi + u_kw) * Cin + u_ci) * 4;                                           \
+        const int soffB = u_kt * BK * CoutPad * 4;                                                         \
+        const int v0 = (rowmask[0] & u_bit) ? rowvoff[0] : 0x7FFF0000;                                     \
+        const int v1 = (rowmask[1] & u_bit) ? rowvoff[1] : 0x7FFF0000;                                     \
+        const f32x4 t0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, v0, soffA, 0)); \
+        const f32x4 t1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, v1, soffA, 0)); \
+        const f32x4 t2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, bvoff0, soffB, 0)); \
+        const f32x4 t3 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, bvoff1, soffB, 0)); \
+        ax0 = t0[0]; ay0 = t0[1]; az0 = t0[2]; aw0 = t0[3]; ax1 = t1[0]; ay1 = t1[1]; az1 = t1[2]; aw1 = t1[3]; \
+        bx0 = t2[0]; by0 = t2[1]; bz0 = t2[2]; bw0 = t2[3]; bx1 = t3[0]; by1 = t3[1]; bz1 = t3[2]; bw1 = t3[3]; \
         u_kt++; u_ci += BK;                                                                                \
         if (u_ci >= Cin) { u_ci = 0; u_kw++; if (u_kw == KW) { u_kw = 0; u_kh++; } }                       \
     }
