@@ -295,3 +295,34 @@ def test_ragged_batch_equals_batch1_and_eval_consumer(hip, small_model):
     assert index == ["img%03d" % i for i in range(5)]
     n = sum(b[0].shape[0] for c in all_boxes for b in c if b != [])
     assert n == sum(int(o["boxes"].shape[0]) for o in together)
+
+
+def test_full_size_properties_and_oracle_spot_check(hip, oracle):
+    """BASELINE.json's full VOC sizes (600/1000): determinism, batch-size invariance and rank-count invariance of
+    the sweep over 12 images, plus one image checked against the oracle bit for bit."""
+    torch = hip["torch"]
+    from cald_amd import synth, sweep
+    sd = synth.pseudo_trained_frcnn(21, 50, seed=0)
+    model = hip["det"].fasterrcnn_resnet50_fpn_feature(num_classes=21, min_size=600, max_size=1000).to("cuda")
+    model.load_state_dict(sd)
+    pool = synth.make_pool(12, "voc", 0)
+    dev = [torch.from_numpy(im).cuda() for im in pool]
+    augs = ["flip", "cut_out", "smaller_resize"]
+    pos = list(range(12))
+    c1, k1 = sweep.sweep_device_images(model, dev, pos, augs, base_seed=2, batch_images=64)
+    c2, k2 = sweep.sweep_device_images(model, dev, pos, augs, base_seed=2, batch_images=64)
+    np.testing.assert_array_equal(c1, c2); np.testing.assert_array_equal(k1, k2)                  # deterministic
+    c3, k3 = sweep.sweep_device_images(model, dev, pos, augs, base_seed=2, batch_images=5)
+    np.testing.assert_array_equal(c1, c3); np.testing.assert_array_equal(k1, k3)                  # batch-size invariant
+    for world in (2, 3):                                                                          # shard invariant
+        cw = np.zeros(12); kw = np.zeros((12, 20))
+        for r in range(world):
+            idx = [p for p in pos if p % world == r]
+            cr, kr = sweep.sweep_device_images(model, [dev[i] for i in idx], idx, augs, base_seed=2)
+            cw[idx] = cr; kw[idx] = kr
+        np.testing.assert_array_equal(c1, cw); np.testing.assert_array_equal(k1, kw)
+    assert np.all(c1 >= 0) and np.all(c1 <= 1.0) and len(np.unique(np.round(c1, 6))) > 6
+    P = oracle.prepare_frcnn(sd, 21, 50)
+    wc, wk = oracle.get_uncertainty(P, [pool[3]], augs, 21, bp=1.3, min_size=600, max_size=1000, base_seed=2, positions=[3])
+    assert c1[3] == wc[0]
+    np.testing.assert_array_equal(k1[3], wk[0])
