@@ -326,3 +326,32 @@ def test_full_size_properties_and_oracle_spot_check(hip, oracle):
     wc, wk = oracle.get_uncertainty(P, [pool[3]], augs, 21, bp=1.3, min_size=600, max_size=1000, base_seed=2, positions=[3])
     assert c1[3] == wc[0]
     np.testing.assert_array_equal(k1[3], wk[0])
+
+
+@pytest.mark.parametrize("shape", [(333, 500), (32, 40), (60, 400), (401, 97)])
+def test_odd_image_sizes_forward(hip, oracle, small_model, shape):
+    """Ragged / extreme sizes: the 333-row floor case, tiny, very wide, very tall (max_size clamp)."""
+    torch = hip["torch"]
+    from cald_amd import synth
+    model, P = small_model
+    img = synth.synth_image(77, *shape)
+    want = oracle.frcnn_forward(P, img, 300, 500)
+    got = model.forward_views([(torch.from_numpy(img).cuda(), False, None)])[0]
+    for k in ("boxes", "scores", "labels", "props", "prob_max", "scores_cls"):
+        assert got[k].cpu().numpy().tobytes() == want[k].tobytes(), "output %s differs for %s" % (k, shape)
+
+
+def test_retinanet_coco_classes_small(hip, oracle):
+    """RetinaNet with 91 classes (cls_logits 819 channels, per-class lists for 91 classes)."""
+    torch = hip["torch"]
+    from cald_amd import synth
+    sd = synth.pseudo_trained_retinanet(91, 50, seed=2)
+    model = hip["det"].retinanet_resnet50_fpn_cal(num_classes=91, min_size=200, max_size=320).to("cuda")
+    model.load_state_dict(sd)
+    P = oracle.prepare_retinanet(sd, 91, 50)
+    img = synth.make_pool(2, "coco", 0, scale=0.35)[0]
+    want = oracle.retina_forward(P, img, 200, 320)
+    got = model.forward_views([(torch.from_numpy(img).cuda(), False, None)])[0]
+    assert want["boxes"].shape[0] > 0
+    for k in ("boxes", "scores", "labels", "prob_max", "scores_cls"):
+        assert got[k].cpu().numpy().tobytes() == want[k].tobytes(), "output %s differs" % k
