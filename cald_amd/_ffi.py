@@ -55,6 +55,8 @@ SIGNATURES = {
     "cald_model_destroy": (C.c_int, [C.c_void_p]),
     "cald_forward": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(View), C.POINTER(Dets)]),
     "cald_sweep": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), c_i, c_i, c_i64, C.POINTER(SweepCfg), c_d, c_d]),
+    "cald_sweep_ltc": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), c_i, c_i, C.c_int, c_d]),
+    "cald_sweep_lsc": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), c_i, c_i, c_i64, C.c_uint64, C.c_int, c_d]),
     "cald_op_consistency": (C.c_int, [C.c_void_p, C.c_int, c_f, c_f, c_f, C.c_int, c_f, c_f, c_f, C.c_int, C.c_float, c_f]),
     "cald_op_cls_corr": (C.c_int, [C.c_void_p, C.c_int, c_f, c_i64, C.c_int, c_f]),
     "cald_op_pil_resize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]),

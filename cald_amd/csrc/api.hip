@@ -12,6 +12,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -1148,7 +1149,7 @@ extern "C" int cald_sweep(cald_model* m, int n_images, const uint8_t* const* ima
             float par[12] = {0};
             if (cfg->aug_flip) { ViewDesc v = base; v.flip = 1; par[0] = (float)Wi; add_view(v, 1, par); }
             if (cfg->aug_ga) {     // GaussianNoise(image, 16), cald_train.py:128-131; torch.randn stream re-seeded per image
-                GaussJob gj; gj.dst = reinterpret_cast<float*>(take((size_t)Hi * Wi * 3 * sizeof(float))); gj.n = Hi * Wi * 3; gj.seed = seed; gj.std = cfg->ga_std;
+                GaussJob gj; gj.dst = reinterpret_cast<float*>(take((size_t)Hi * Wi * 3 * sizeof(float))); gj.n = Hi * Wi * 3; gj.nseg = 1; gj.seed = seed; memset(gj.stds, 0, sizeof(gj.stds)); gj.stds[0] = cfg->ga_std;
                 gjobs.push_back(gj);
                 ViewDesc v = base; v.noise = gj.dst; add_view(v, 0, nullptr);
             }
@@ -1239,5 +1240,170 @@ extern "C" int cald_sweep(cald_model* m, int n_images, const uint8_t* const* ima
         }
     }
     cleanup();
+    return rc;
+}
+
+
+// =============================================================================================
+// baseline sweeps on the same detector forward
+// =============================================================================================
+// numpy pairwise summation of float32 (np.sum over a 1-D float32 array)
+static float np_sum_f32(const float* a, int n) {
+    if (n < 8) { float r = 0.0f; for (int i = 0; i < n; i++) r += a[i]; return r; }
+    if (n <= 128) {
+        float r[8];
+        for (int k = 0; k < 8; k++) r[k] = a[k];
+        int i;
+        for (i = 8; i < n - (n % 8); i += 8) for (int k = 0; k < 8; k++) r[k] += a[i + k];
+        float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; i++) res += a[i];
+        return res;
+    }
+    int n2 = n / 2; n2 -= n2 % 8;
+    return np_sum_f32(a, n2) + np_sum_f32(a + n2, n - n2);
+}
+
+// lt_c_train.py:105-121 get_uncertainty: one forward per image, min over detections of |IoU(box, prop) + prob_max - 1|
+extern "C" int cald_sweep_ltc(cald_model* m, int n_images, const uint8_t* const* images_dev, const int* H, const int* W,
+                              int batch_images, double* uncertainty_out) {
+    if (!m || !images_dev || !H || !W || !uncertainty_out) return fail(CALD_ERR_INVALID, "null argument");
+    if (!m->finalized) return fail(CALD_ERR_STATE, "model not finalized");
+    if (m->cfg.arch != CALD_ARCH_FRCNN) return fail(CALD_ERR_INVALID, "lt_c needs the Faster R-CNN outputs (props)");
+    cald_ctx* c = m->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    int B = batch_images > 0 ? batch_images : 64; if (B > CALD_MAX_VIEWS) B = CALD_MAX_VIEWS;
+    const int C = m->cfg.num_classes, cap = m->det_cap();
+    if (m->sweep_det_views < B) {
+        if (m->sweep_det_views) { HIPCHK(hipStreamSynchronize(c->stream)); free_det(m->sweep_det); }
+        int rc = alloc_det(m->sweep_det, B, cap, C); if (rc) return rc;
+        m->sweep_det_views = B;
+    }
+    float* d_out = nullptr; HIPCHK(hipMalloc((void**)&d_out, (size_t)B * 4));
+    std::vector<float> h(B);
+    int rc = 0;
+    for (int i0 = 0; i0 < n_images && !rc; i0 += B) {
+        const int nb = (n_images - i0 < B) ? n_images - i0 : B;
+        std::vector<ViewDesc> views(nb);
+        for (int i = 0; i < nb; i++) { memset(&views[i], 0, sizeof(ViewDesc)); views[i].src = images_dev[i0 + i]; views[i].H = H[i0 + i]; views[i].W = W[i0 + i]; }
+        if ((rc = forward_model(m, nb, views.data(), m->sweep_det))) break;
+        launch_lt_uncertainty(m->sweep_det, nb, d_out, c->stream);
+        if (hipMemcpyAsync(h.data(), d_out, (size_t)nb * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipStreamSynchronize(c->stream) != hipSuccess) { rc = fail(CALD_ERR_HIP, "lt_c scoring failed: %s", hipGetErrorString(hipGetLastError())); break; }
+        for (int i = 0; i < nb; i++) uncertainty_out[i0 + i] = (double)h[i];
+    }
+    hipStreamSynchronize(c->stream); hipFree(d_out);
+    return rc;
+}
+
+// ls_c_train.py:108-155 get_uncertainty: reference view + GaussianNoise(image, 8 i), i = 1..6 (six consecutive torch.randn
+// draws on the per-image re-seeded generator), top-30 reference boxes by prob_max, IoU stability weighted by prob_max, minus
+// U = max(1 - prob_max).
+extern "C" int cald_sweep_lsc(cald_model* m, int n_images, const uint8_t* const* images_dev, const int* H, const int* W,
+                              const int64_t* pool_pos, uint64_t base_seed, int batch_images, double* stability_out) {
+    if (!m || !images_dev || !H || !W || !pool_pos || !stability_out) return fail(CALD_ERR_INVALID, "null argument");
+    if (!m->finalized) return fail(CALD_ERR_STATE, "model not finalized");
+    cald_ctx* c = m->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    const int A = 6;
+    int B = batch_images > 0 ? batch_images : 32; if (B > CALD_MAX_VIEWS) B = CALD_MAX_VIEWS;
+    const int C = m->cfg.num_classes, cap = m->det_cap(), VT = B * (1 + A), P_MAX = B * A;
+    if (m->sweep_det_views < VT) {
+        if (m->sweep_det_views) { HIPCHK(hipStreamSynchronize(c->stream)); free_det(m->sweep_det); }
+        int rc = alloc_det(m->sweep_det, VT, cap, C); if (rc) return rc;
+        m->sweep_det_views = VT;
+    }
+    DetBuffers& D = m->sweep_det;
+    int* d_ints = nullptr; float *d_par = nullptr, *d_rows = nullptr; GaussJob* d_gjobs = nullptr; float* d_noise = nullptr; size_t noise_cap = 0;
+    const size_t n_ints = (size_t)P_MAX * 4 + (size_t)B * 51;
+    HIPCHK(hipMalloc((void**)&d_ints, n_ints * 4)); HIPCHK(hipMalloc((void**)&d_par, (size_t)P_MAX * 12 * 4));
+    HIPCHK(hipMalloc((void**)&d_rows, (size_t)P_MAX * 50 * 4)); HIPCHK(hipMalloc((void**)&d_gjobs, sizeof(GaussJob) * B));
+    HIPCHK(hipMemset(d_par, 0, (size_t)P_MAX * 12 * 4));
+    std::vector<int> h_count(VT); std::vector<float> h_pm((size_t)B * cap), h_rows((size_t)P_MAX * 50);
+    int rc = 0;
+    for (int i0 = 0; i0 < n_images && !rc; i0 += B) {
+        const int nb = (n_images - i0 < B) ? n_images - i0 : B;
+        std::vector<ViewDesc> views(nb);
+        for (int i = 0; i < nb; i++) { memset(&views[i], 0, sizeof(ViewDesc)); views[i].src = images_dev[i0 + i]; views[i].H = H[i0 + i]; views[i].W = W[i0 + i]; }
+        if ((rc = forward_model(m, nb, views.data(), D))) break;
+        if (hipMemcpyAsync(h_count.data(), D.count, (size_t)nb * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipMemcpyAsync(h_pm.data(), D.prob_max, (size_t)nb * cap * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipStreamSynchronize(c->stream) != hipSuccess) { rc = fail(CALD_ERR_HIP, "D2H of reference detections failed"); break; }
+        // host: top-30 by prob_max (value desc, index asc), noise jobs, views
+        std::vector<int> ref_sel((size_t)B * 50, 0), ref_n(B, 0), pair_ref, pair_aug, pair_img;
+        std::vector<ViewDesc> aviews; std::vector<GaussJob> gjobs;
+        size_t need = 0;
+        for (int i = 0; i < nb; i++) if (h_count[i] > 0) need += ((size_t)H[i0 + i] * W[i0 + i] * 3 * A * 4 + 255) & ~(size_t)255;
+        if (need > noise_cap) { if (d_noise) hipFree(d_noise); d_noise = nullptr; noise_cap = 0;
+            if (hipMalloc((void**)&d_noise, need + (need >> 2)) != hipSuccess) { rc = fail(CALD_ERR_HIP, "hipMalloc of the noise arena failed"); break; } noise_cap = need + (need >> 2); }
+        size_t noff = 0;
+        for (int i = 0; i < nb; i++) {
+            const int n = h_count[i];
+            if (n == 0) continue;
+            const float* pm = &h_pm[(size_t)i * cap];
+            std::vector<int> idx(n); for (int k = 0; k < n; k++) idx[k] = k;
+            if (n > 30) {
+                std::stable_sort(idx.begin(), idx.end(), [&](int x, int y) { return pm[x] > pm[y]; });
+                idx.resize(30);
+            }
+            ref_n[i] = (int)idx.size();
+            for (size_t k = 0; k < idx.size(); k++) ref_sel[(size_t)i * 50 + k] = idx[k];
+            const int Hi = H[i0 + i], Wi = W[i0 + i], ne = Hi * Wi * 3;
+            GaussJob gj; gj.dst = reinterpret_cast<float*>(reinterpret_cast<char*>(d_noise) + noff); noff += ((size_t)ne * A * 4 + 255) & ~(size_t)255;
+            gj.n = ne; gj.nseg = A; gj.seed = (uint64_t)base_seed * 1000003ull + (uint64_t)pool_pos[i0 + i];
+            memset(gj.stds, 0, sizeof(gj.stds)); for (int k = 0; k < A; k++) gj.stds[k] = 8.0f * (float)(k + 1);
+            gjobs.push_back(gj);
+            for (int k = 0; k < A; k++) {
+                ViewDesc v; memset(&v, 0, sizeof(v)); v.src = images_dev[i0 + i]; v.H = Hi; v.W = Wi; v.noise = gj.dst + (size_t)k * ne;
+                pair_ref.push_back(i); pair_aug.push_back(nb + (int)aviews.size()); pair_img.push_back(i);
+                aviews.push_back(v);
+            }
+        }
+        if (!gjobs.empty()) {
+            if (hipMemcpyAsync(d_gjobs, gjobs.data(), sizeof(GaussJob) * gjobs.size(), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+                hipStreamSynchronize(c->stream) != hipSuccess) { rc = fail(CALD_ERR_HIP, "H2D of gaussian-noise jobs failed"); break; }
+            launch_gauss_noise(d_gjobs, (int)gjobs.size(), c->stream);
+        }
+        const int na = (int)aviews.size();
+        for (int a0 = 0; a0 < na && !rc; a0 += CALD_MAX_VIEWS) {
+            const int nv = (na - a0 < CALD_MAX_VIEWS) ? na - a0 : CALD_MAX_VIEWS;
+            DetBuffers d2 = D; const size_t o = (size_t)(nb + a0);
+            d2.boxes += o * cap * 4; d2.scores += o * cap; d2.labels += o * cap; d2.props += o * cap * 4;
+            d2.prob_max += o * cap; d2.scores_cls += o * cap * C; d2.count += o;
+            rc = forward_model(m, nv, aviews.data() + a0, d2);
+        }
+        if (rc) break;
+        const int P = (int)pair_ref.size();
+        std::vector<int> ints(n_ints, 0);
+        int* p_ref = ints.data(); int* p_aug = p_ref + P_MAX; int* p_kind = p_aug + P_MAX; int* p_img = p_kind + P_MAX;
+        int* p_sel = p_img + P_MAX; int* p_n = p_sel + (size_t)B * 50;
+        for (int p = 0; p < P; p++) { p_ref[p] = pair_ref[p]; p_aug[p] = pair_aug[p]; p_kind[p] = 0; p_img[p] = pair_img[p]; }
+        memcpy(p_sel, ref_sel.data(), (size_t)B * 50 * 4); memcpy(p_n, ref_n.data(), (size_t)B * 4);
+        if (hipMemcpyAsync(d_ints, ints.data(), n_ints * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = fail(CALD_ERR_HIP, "H2D failed"); break; }
+        ScoreArgs sa; sa.det = D;
+        sa.ref_view = d_ints; sa.aug_view = d_ints + P_MAX; sa.aug_kind = d_ints + 2 * P_MAX; sa.pair_img = d_ints + 3 * P_MAX;
+        sa.ref_sel = d_ints + 4 * P_MAX; sa.ref_n = sa.ref_sel + (size_t)B * 50; sa.aug_param = d_par; sa.P = P; sa.bp = 0.f; sa.cons = nullptr;
+        launch_max_iou(sa, d_rows, c->stream);
+        if ((P && hipMemcpyAsync(h_rows.data(), d_rows, (size_t)P * 50 * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess) ||
+            hipStreamSynchronize(c->stream) != hipSuccess) { rc = fail(CALD_ERR_HIP, "ls_c scoring failed: %s", hipGetErrorString(hipGetLastError())); break; }
+        // host: float64 / float32 numpy arithmetic of ls_c_train.py:151-153
+        std::vector<std::vector<int>> img_pairs(nb);
+        for (int p = 0; p < P; p++) img_pairs[pair_img[p]].push_back(p);
+        for (int i = 0; i < nb; i++) {
+            if (h_count[i] == 0) { stability_out[i0 + i] = 0.0; continue; }
+            const int N = ref_n[i];
+            std::vector<float> pm(N); std::vector<double> st(N, 0.0), prod(N);
+            float U = 0.0f;
+            for (int k = 0; k < N; k++) {
+                pm[k] = h_pm[(size_t)i * cap + ref_sel[(size_t)i * 50 + k]];
+                const float u = 1.0f - pm[k];
+                if (k == 0 || u > U) U = u;
+            }
+            for (int p : img_pairs[i]) for (int k = 0; k < N; k++) st[k] += (double)h_rows[(size_t)p * 50 + k];
+            for (int k = 0; k < N; k++) { st[k] = st[k] / 6.0; prod[k] = (double)pm[k] * st[k]; }
+            stability_out[i0 + i] = np_sum(prod.data(), N) / (double)np_sum_f32(pm.data(), N) - (double)U;
+        }
+    }
+    hipStreamSynchronize(c->stream);
+    hipFree(d_ints); hipFree(d_par); hipFree(d_rows); hipFree(d_gjobs); if (d_noise) hipFree(d_noise);
     return rc;
 }

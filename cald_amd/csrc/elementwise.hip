@@ -262,8 +262,11 @@ __device__ inline void box_muller_pair(float ua, float ub, float std, float* oa,
     *ob = ((radius * sn) * std) / 255.0f;
 }
 __global__ __launch_bounds__(256) void gauss_noise_kernel(const GaussJob* jobs) {
+    // nseg consecutive torch.randn(n) calls on one generator: the draw stream of segment g starts at
+    // g * (n + (n % 16 ? 16 : 0)).  Tempered uniforms of the last two twists are kept in an LDS ring, and a
+    // 16-draw chunk is transformed as soon as the twist holding its last draw is available.
     __shared__ unsigned mt[624];
-    __shared__ float tail_u[16];
+    __shared__ float ring[2][624];
     const GaussJob j = jobs[blockIdx.x];
     const int tid = threadIdx.x;
     const long long n = j.n;
@@ -273,9 +276,11 @@ __global__ __launch_bounds__(256) void gauss_noise_kernel(const GaussJob* jobs) 
         for (int i = 1; i < 624; i++) { x = 1812433253u * (x ^ (x >> 30)) + (unsigned)i; mt[i] = x; }
     }
     __syncthreads();
-    const long long rem = n % 16, n_full = n - rem;                 // elements covered by whole 16-chunks
-    const long long draws = n + (rem ? 16 : 0);
-    for (long long base = 0; base < draws; base += 624) {
+    const long long rem = n % 16, ncs = n / 16;                       // standard chunks per segment
+    const long long seg_draws = n + ((rem && n >= 16) ? 16 : 0);
+    const long long total = seg_draws * j.nseg;
+    const long long nblk = (total + 623) / 624;
+    for (long long blk = 0; blk < nblk; blk++) {
         for (int ph = 0; ph < 3; ph++) {
             const int lo = ph == 0 ? 0 : (ph == 1 ? 227 : 454), hi = ph == 0 ? 227 : (ph == 1 ? 454 : 624);
             unsigned nv = 0; const int k = lo + tid;
@@ -287,30 +292,38 @@ __global__ __launch_bounds__(256) void gauss_noise_kernel(const GaussJob* jobs) 
             if (k < hi) mt[k] = nv;
             __syncthreads();
         }
-        // 39 chunks x 8 pairs per twist
-        for (int t = tid; t < 312; t += 256) {
-            const int ch = t >> 3, jj = t & 7;
-            const long long e = base + ch * 16 + jj;
-            if (e + 8 < n_full + 0 && e < n_full) {
+        for (int t = tid; t < 624; t += 256) ring[blk & 1][t] = mt_u24(mt_temper(mt[t]));
+        __syncthreads();
+        const long long d_lo = blk * 624 - 15, d_hi = blk * 624 + 608;   // chunk starts whose last draw is in this twist
+        for (int g = 0; g < j.nseg; g++) {
+            const long long base = seg_draws * g;
+            if (base > d_hi || base + seg_draws - 16 < d_lo) continue;
+            // chunk ids: 0 .. ncs-1 standard (start base + 16c), id ncs = tail (start base + n) when rem
+            long long c_lo = d_lo - base; c_lo = c_lo <= 0 ? 0 : (c_lo + 15) / 16;
+            long long c_hi = d_hi - base; c_hi = c_hi < 0 ? -1 : c_hi / 16;
+            if (c_hi > ncs - 1) c_hi = ncs - 1;
+            float* dst = j.dst + (long long)g * n;
+            const float std = j.stds[g];
+            for (long long w = c_lo * 8 + tid; w < (c_hi + 1) * 8; w += 256) {
+                const long long c = w >> 3; const int jj = (int)(w & 7);
+                const long long s = base + 16 * c + jj, s8 = s + 8;
                 float oa, ob;
-                box_muller_pair(mt_u24(mt_temper(mt[ch * 16 + jj])), mt_u24(mt_temper(mt[ch * 16 + jj + 8])), j.std, &oa, &ob);
-                // the tail (if any) overwrites [n-16, n): skip those here
-                if (!rem || e < n - 16) j.dst[e] = oa;
-                if (!rem || e + 8 < n - 16) j.dst[e + 8] = ob;
+                box_muller_pair(ring[(s / 624) & 1][s % 624], ring[(s8 / 624) & 1][s8 % 624], std, &oa, &ob);
+                const long long e0 = 16 * c + jj;
+                if (!rem || e0 < n - 16) dst[e0] = oa;
+                if (!rem || e0 + 8 < n - 16) dst[e0 + 8] = ob;
             }
-        }
-        if (rem) {   // collect the 16 fresh uniforms n .. n+15 (may straddle two twists)
-            for (int t = tid; t < 624; t += 256) {
-                const long long d = base + t;
-                if (d >= n && d < n + 16) tail_u[d - n] = mt_u24(mt_temper(mt[t]));
+            if (rem && n >= 16) {
+                const long long ts = base + n;                          // tail chunk start
+                if (ts >= d_lo && ts <= d_hi && tid < 8) {
+                    const long long s = ts + tid, s8 = s + 8;
+                    float oa, ob;
+                    box_muller_pair(ring[(s / 624) & 1][s % 624], ring[(s8 / 624) & 1][s8 % 624], std, &oa, &ob);
+                    dst[n - 16 + tid] = oa; dst[n - 16 + tid + 8] = ob;
+                }
             }
         }
         __syncthreads();
-    }
-    if (rem && n >= 16 && tid < 8) {
-        float oa, ob;
-        box_muller_pair(tail_u[tid], tail_u[tid + 8], j.std, &oa, &ob);
-        j.dst[n - 16 + tid] = oa; j.dst[n - 16 + tid + 8] = ob;
     }
 }
 void launch_gauss_noise(const GaussJob* jobs, int n, hipStream_t st) {

@@ -36,7 +36,7 @@ void launch_subsample2(const float* in, float* out, const LevelSeg* sin, const L
 struct SaltPepperJob { const uint8_t* src; uint8_t* dst; int H, W; unsigned long long seed; float lo, hi; };
 void launch_affine_nearest(const uint8_t* src, int H, int W, uint8_t* dst, int oh, int ow, const int* a, hipStream_t st);
 void launch_salt_pepper(const SaltPepperJob* jobs, int n, hipStream_t st);
-struct GaussJob { float* dst; int n; unsigned long long seed; float std; };
+struct GaussJob { float* dst; int n; int nseg; unsigned long long seed; float stds[8]; };   // dst: [nseg][n]
 void launch_gauss_noise(const GaussJob* jobs, int n, hipStream_t st);
 
 // rpn.hip
@@ -126,3 +126,7 @@ struct RetinaArgs {
     DetBuffers det;               // cap >= K * per_class
 };
 void launch_retina_postprocess(const RetinaArgs& a, int max_anchors, hipStream_t st);
+
+// baseline sweeps
+void launch_lt_uncertainty(const DetBuffers& det, int V, float* out, hipStream_t st);
+void launch_max_iou(const ScoreArgs& a, float* out /*[P][50]*/, hipStream_t st);

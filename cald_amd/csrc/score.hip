@@ -153,3 +153,64 @@ void launch_cls_corr(const DetBuffers& det, const int* ref_sel, const int* ref_n
     if (V <= 0) return;
     hipLaunchKernelGGL(cls_corr_kernel, dim3(V), dim3(256), 0, st, det, ref_sel, ref_n, view_img, view_is_ref, out);
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// scoring kernels of the baseline sweeps that share the detector forward.
+// lt_c_train.py:92-121: min over detections of |calcu_iou(box, prop) + prob_max - 1| (init 1.0).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lt_uncertainty_kernel(DetBuffers det, float* out) {
+    __shared__ float red[256];
+    const int v = blockIdx.x, n = det.count[v], cap = det.cap;
+    const float4* boxes = reinterpret_cast<const float4*>(det.boxes) + (long long)v * cap;
+    const float4* props = reinterpret_cast<const float4*>(det.props) + (long long)v * cap;
+    float unc = 1.0f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float4 A = boxes[i], B = props[i];
+        const float width = (fminf(A.z, B.z) - fmaxf(A.x, B.x)) + 1.0f;
+        const float height = (fminf(A.w, B.w) - fmaxf(A.y, B.y)) + 1.0f;
+        float iou = 0.0f;
+        if (!(width <= 0.0f || height <= 0.0f)) {
+            const float Aarea = (A.z - A.x) * ((A.w - A.y) + 1.0f);
+            const float Barea = (B.z - B.x) * ((B.w - B.y) + 1.0f);
+            const float iner = width * height;
+            iou = iner / ((Aarea + Barea) - iner);
+        }
+        const float u = fabsf((iou + det.prob_max[(long long)v * cap + i]) - 1.0f);
+        if (u < unc) unc = u;
+    }
+    red[threadIdx.x] = unc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s && red[threadIdx.x + s] < red[threadIdx.x]) red[threadIdx.x] = red[threadIdx.x + s]; __syncthreads(); }
+    if (threadIdx.x == 0) out[v] = red[0];
+}
+void launch_lt_uncertainty(const DetBuffers& det, int V, float* out, hipStream_t st) {
+    if (V > 0) hipLaunchKernelGGL(lt_uncertainty_kernel, dim3(V), dim3(256), 0, st, det, out);
+}
+
+// ls_c_train.py:136-150: for every selected reference box the maximum IoU against one noisy view's detections.
+__global__ __launch_bounds__(256) void max_iou_kernel(ScoreArgs a, float* out) {
+    const int p = blockIdx.x;
+    const int rv = a.ref_view[p], av = a.aug_view[p], img = a.pair_img[p];
+    const int N = a.ref_n[img], M = a.det.count[av], cap = a.det.cap;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float4* rboxes = reinterpret_cast<const float4*>(a.det.boxes) + (long long)rv * cap;
+    const float4* aboxes = reinterpret_cast<const float4*>(a.det.boxes) + (long long)av * cap;
+    for (int i = wave; i < N; i += 4) {
+        const float4 ab = rboxes[a.ref_sel[img * 50 + i]];
+        float best = -INFINITY; int bj = 0x7fffffff;
+        for (int j = lane; j < M; j += 64) {
+            const float v = cald_iou(ab, aboxes[j]);
+            if (better(v, j, best, bj)) { best = v; bj = j; }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float ov = __shfl_xor(best, off, 64); const int oj = __shfl_xor(bj, off, 64);
+            if (better(ov, oj, best, bj)) { best = ov; bj = oj; }
+        }
+        if (lane == 0) out[(long long)p * 50 + i] = M > 0 ? best : 0.0f;
+    }
+}
+void launch_max_iou(const ScoreArgs& a, float* out, hipStream_t st) {
+    if (a.P > 0) hipLaunchKernelGGL(max_iou_kernel, dim3(a.P), dim3(256), 0, st, a, out);
+}

@@ -111,6 +111,14 @@ typedef struct cald_sweep_cfg {
 int cald_sweep(cald_model* m, int n_images, const uint8_t* const* images_dev, const int* H, const int* W,
                const int64_t* pool_pos, const cald_sweep_cfg* cfg, double* consistency_out, double* cls_corr_out);
 
+/* ---- the baseline sweeps of the same repo that share the detector forward ---- */
+/* lt_c_train.py:105-121 get_uncertainty(task_model, unlabeled_loader) -> one float per image */
+int cald_sweep_ltc(cald_model* m, int n_images, const uint8_t* const* images_dev, const int* H, const int* W,
+                   int batch_images, double* uncertainty_out);
+/* ls_c_train.py:108-155 get_uncertainty(task_model, unlabeled_loader) -> one float per image (six GaussianNoise views) */
+int cald_sweep_lsc(cald_model* m, int n_images, const uint8_t* const* images_dev, const int* H, const int* W,
+                   const int64_t* pool_pos, uint64_t base_seed, int batch_images, double* stability_out);
+
 /* ---- operator-level entry points (used by the parity tests; same kernels as the paths above) ---- */
 /* scoring of ONE (reference, augmentation) pair, cald_train.py:189-224 */
 int cald_op_consistency(cald_ctx* ctx, int N, const float* aug_box, const float* ref_scores_cls, const float* ref_pm,

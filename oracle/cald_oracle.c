@@ -943,3 +943,59 @@ ORC_API void orc_gaussian_noise(uint64_t seed, int n, float std, float* out) {
     }
     free(u);
 }
+
+
+/* -------------------------------------------------------------------------------------
+ * the baseline sweeps that share the detector forward.
+ * lt_c_train.py:92-121  uncertainty = min(1, |calcu_iou(box, prop) + prob_max - 1|) over detections
+ * (calcu_iou's +1 convention incl. its asymmetric area, lt_c_train.py:92-103).
+ * ------------------------------------------------------------------------------------- */
+ORC_API float orc_lt_uncertainty(int n, const float* boxes, const float* props, const float* pm) {
+    float unc = 1.0f;
+    for (int i = 0; i < n; i++) {
+        const float *A = boxes + 4 * i, *B = props + 4 * i;
+        float width = (fminf_(A[2], B[2]) - fmaxf_(A[0], B[0])) + 1.0f;
+        float height = (fminf_(A[3], B[3]) - fmaxf_(A[1], B[1])) + 1.0f;
+        float iou = 0.0f;
+        if (!(width <= 0.0f || height <= 0.0f)) {
+            float Aarea = (A[2] - A[0]) * ((A[3] - A[1]) + 1.0f);
+            float Barea = (B[2] - B[0]) * ((B[3] - B[1]) + 1.0f);
+            float iner = width * height;
+            iou = iner / ((Aarea + Barea) - iner);
+        }
+        float u = fabsf((iou + pm[i]) - 1.0f);
+        if (u < unc) unc = u;
+    }
+    return unc;
+}
+
+/* ls_c_train.py:136-150: max IoU of each reference box against one view's detections (0 when the view is empty) */
+ORC_API void orc_max_iou_rows(int N, const float* ref_boxes, int M, const float* boxes, float* out) {
+    for (int i = 0; i < N; i++) {
+        float best = 0.0f;
+        for (int k = 0; k < M; k++) {
+            float v = cald_iou(ref_boxes + 4 * i, boxes + 4 * k);
+            if (k == 0 || v > best || v != v) best = v;
+            if (best != best) break;
+        }
+        out[i] = best;
+    }
+}
+
+/* torch.randn called nseg times in a row on the same generator (ls_c_train.py:129-131: GaussianNoise(image, i*8),
+ * i = 1..6): the MT19937 stream simply continues from one call to the next. */
+ORC_API void orc_gaussian_noise_seq(uint64_t seed, int n, int nseg, const float* stds, float* out /*[nseg][n]*/) {
+    orc_mt s; mt_init_genrand(&s, (uint32_t)(seed & 0xffffffffu));
+    float* u = (float*)malloc(sizeof(float) * ((size_t)n + 16));
+    for (int g = 0; g < nseg; g++) {
+        float* o = out + (size_t)g * n;
+        for (int i = 0; i < n; i++) u[i] = (float)((double)(mt_next(&s) & 0xffffffu) * (1.0 / 16777216.0));
+        for (int i = 0; i + 15 < n; i += 16) normal_fill_16(u + i, o + i, stds[g]);
+        if (n % 16 != 0 && n >= 16) {
+            float v[16];
+            for (int i = 0; i < 16; i++) v[i] = (float)((double)(mt_next(&s) & 0xffffffu) * (1.0 / 16777216.0));
+            normal_fill_16(v, o + n - 16, stds[g]);
+        }
+    }
+    free(u);
+}

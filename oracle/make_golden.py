@@ -236,6 +236,63 @@ def gen_voc_results():
     print("voc_results ok")
 
 
+def gen_baselines():
+    lt, ls = ref_harness.load_baselines()
+    rs = np.random.RandomState(8)
+    blob = {}
+    # ---- lt_c: detections with props ----
+    lt_outs = []
+    for i, n in enumerate([0, 1, 7, 100]):
+        d = fake_dets(rs, n, 120, 160, 21, "softmax")
+        d["props"] = (d["boxes"] + rs.randn(n, 4).astype(np.float32) * 6).astype(np.float32)
+        if n > 3:
+            d["props"][2] = d["props"][2] + np.float32(5000)      # disjoint -> calcu_iou returns 0
+        lt_outs.append(d)
+        for k, v in d.items():
+            blob["lt%d_%s" % (i, k)] = v
+
+    class LtModel:
+        def eval(self): return self
+        def __call__(self, images): return [{k: torch.from_numpy(v.copy()) for k, v in lt_outs[self.i].items()}]
+    m = LtModel(); res = []
+    for i in range(len(lt_outs)):
+        m.i = i
+        res += lt.get_uncertainty(m, [((torch.zeros(3, 8, 8),), (None,))])
+    blob["lt_unc"] = np.array(res, np.float64)
+    # ---- ls_c: reference view + six noisy views ----
+    images, outputs, per = [], [], []
+    for i, nref in enumerate([4, 0, 35, 12]):
+        H, W = [(60, 80), (75, 50)][i % 2]
+        images.append(synth_image(rs, H, W))
+        outs = [fake_dets(rs, nref, H, W, 21, "softmax")]
+        if nref:
+            for k in range(6):
+                outs.append(fake_dets(rs, [9, 0, 40, 3, 17, 1][(i + k) % 6], H, W, 21, "softmax"))
+        outputs.extend(outs); per.append(len(outs))
+    model = FakeModel(outputs)
+    model_seen_float = []
+    orig_call = model.__call__
+
+    class Rec(FakeModel):
+        def __call__(self, imgs):
+            model_seen_float.append(imgs[0].detach().clone().permute(1, 2, 0).numpy())
+            return FakeModel.__call__(self, imgs)
+    model = Rec(outputs)
+    stab = ls.get_uncertainty(model, SeededLoader(images, 5))
+    blob["ls_unc"] = np.array(stab, np.float64); blob["ls_per"] = np.array(per); blob["ls_n"] = len(images)
+    k = 0
+    for i, img in enumerate(images):
+        blob["ls_img%d" % i] = img
+        for v in range(per[i]):
+            for key in ("boxes", "prob_max", "labels"):
+                blob["ls%d_%d_%s" % (i, v, key)] = outputs[k][key]
+            if i == 0:
+                blob["ls_seen%d_%d" % (i, v)] = model_seen_float[k]
+            k += 1
+    np.savez_compressed(os.path.join(OUT, "baselines.npz"), **blob)
+    print("baselines ok", res, stab)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ct, ch = ref_harness.load_reference()
@@ -251,6 +308,7 @@ def main():
     gen_js()
     gen_selection(ct)
     gen_voc_results()
+    gen_baselines()
 
 
 if __name__ == "__main__":

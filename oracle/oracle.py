@@ -595,3 +595,65 @@ def get_uncertainty(P, images, augs, num_cls, bp=1.3, min_size=600, max_size=100
             c, cc = score_image(ref, outs, [v[3] for v in views], num_cls, bp)
         consistency_all.append(c); cls_all.append(cc)
     return consistency_all, cls_all
+
+
+# ----------------------------------------------------------------------------- baseline sweeps
+def lt_uncertainty(out):
+    """lt_c_train.py:105-121 for one image's detections."""
+    b = f32(out["boxes"]).reshape(-1, 4); p = f32(out["props"]).reshape(-1, 4); pm = f32(out["prob_max"])
+    lib().orc_lt_uncertainty.restype = C.c_float
+    return float(lib().orc_lt_uncertainty(C.c_int(b.shape[0]), _p(b), _p(p), _p(pm)))
+
+
+def lt_get_uncertainty(P, images, min_size=600, max_size=1000):
+    return [lt_uncertainty(detector_forward(P, img, min_size, max_size)) for img in images]
+
+
+def gaussian_noise_seq(seed, H, W, stds):
+    stds = f32(stds)
+    out = np.empty((len(stds), 3 * H * W), np.float32)
+    lib().orc_gaussian_noise_seq(C.c_uint64(seed), C.c_int(3 * H * W), C.c_int(len(stds)), _p(stds), _p(out))
+    return out.reshape(len(stds), 3, H, W)
+
+
+def topk_indices(values, k):
+    """torch.topk(values, k)[1] with the contract's tie rule (value desc, index asc)."""
+    v = f32(values)
+    return np.array(sorted(range(v.size), key=lambda i: (-v[i], i))[:k], np.int64)
+
+
+def ls_score_image(ref, aug_outs):
+    """ls_c_train.py:118-153 given the detector outputs of the reference view and the six noisy views."""
+    if ref["boxes"].shape[0] == 0:
+        return 0.0
+    rb, pm = f32(ref["boxes"]), f32(ref["prob_max"])
+    if rb.shape[0] > 30:
+        inds = topk_indices(pm, 30)
+        rb, pm = rb[inds], pm[inds]
+    U = float(np.max(np.float32(1) - pm))
+    stab = [0.0] * rb.shape[0]
+    for o in aug_outs:
+        M = o["boxes"].shape[0]
+        if M == 0:
+            continue
+        row = np.empty(rb.shape[0], np.float32)
+        lib().orc_max_iou_rows(C.c_int(rb.shape[0]), _p(rb), C.c_int(M), _p(f32(o["boxes"]).reshape(-1, 4)), _p(row))
+        for i in range(rb.shape[0]):
+            stab[i] += float(row[i])
+    st = np.array(stab) / 6.0
+    return float(np.sum(pm * st) / np.sum(pm) - U)
+
+
+def ls_get_uncertainty(P, images, min_size=600, max_size=1000, base_seed=0, positions=None):
+    res = []
+    for pos, img in enumerate(images):
+        gpos = pos if positions is None else positions[pos]
+        ref = detector_forward(P, img, min_size, max_size)
+        if ref["boxes"].shape[0] == 0:
+            res.append(0.0)
+            continue
+        H, W, _ = img.shape
+        noise = gaussian_noise_seq(image_seed(base_seed, gpos), H, W, [8.0 * i for i in range(1, 7)])
+        outs = [detector_forward(P, img, min_size, max_size, noise=noise[k]) for k in range(6)]
+        res.append(ls_score_image(ref, outs))
+    return res

@@ -123,3 +123,19 @@ def load_reference(bp=1.3, uniform=False):
     cald_helper = importlib.import_module("cald.cald_helper")
     cald_train.args = Namespace(bp=bp, uniform=uniform)
     return cald_train, cald_helper
+
+
+def load_baselines():
+    """lt_c_train / ls_c_train.  ls_c_train.py:52 imports `cal4od.cal4od_helper`, a module
+    that does not exist in the reference tree (the script is broken as shipped); the
+    harness aliases it to cald.cald_helper, which defines the same helper names (GaussianNoise, ...)."""
+    install_stubs()
+    if REF_ROOT not in sys.path:
+        sys.path.insert(0, REF_ROOT)
+    import matplotlib
+    matplotlib.use("Agg")
+    helper = importlib.import_module("cald.cald_helper")
+    pkg = types.ModuleType("cal4od"); pkg.__path__ = []
+    sys.modules["cal4od"] = pkg
+    sys.modules["cal4od.cal4od_helper"] = helper
+    return importlib.import_module("lt_c_train"), importlib.import_module("ls_c_train")

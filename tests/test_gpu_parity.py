@@ -355,3 +355,18 @@ def test_retinanet_coco_classes_small(hip, oracle):
     assert want["boxes"].shape[0] > 0
     for k in ("boxes", "scores", "labels", "prob_max", "scores_cls"):
         assert got[k].cpu().numpy().tobytes() == want[k].tobytes(), "output %s differs" % k
+
+
+def test_baseline_sweeps_lt_c_ls_c(hip, oracle, small_model):
+    """SURVEY 8f rank 3 on the GPU: lt_c (tightness) and ls_c (six sequential GaussianNoise views) vs the oracle."""
+    torch = hip["torch"]
+    from cald_amd import synth, baselines
+    model, P = small_model
+    pool = synth.make_pool(5, "voc", 0, scale=0.5)
+    loader = [((torch.from_numpy(im),), (None,)) for im in pool]
+    got = baselines.lt_c_get_uncertainty(model, loader, batch_images=3)
+    want = oracle.lt_get_uncertainty(P, pool, 300, 500)
+    np.testing.assert_array_equal(np.array(got), np.array(want, np.float64))
+    got = baselines.ls_c_get_uncertainty(model, loader[:3], base_seed=4, batch_images=2)
+    want = oracle.ls_get_uncertainty(P, pool[:3], 300, 500, base_seed=4)
+    np.testing.assert_allclose(np.array(got), np.array(want), rtol=0, atol=1e-12)

@@ -99,3 +99,22 @@ def test_det_math_accuracy(oracle):
     y = np.concatenate([np.logspace(-30, 30, 20001), np.linspace(0.5, 2, 5001)]).astype(np.float32)
     l = oracle.log_array(y)
     np.testing.assert_allclose(l, np.log(y.astype(np.float64)), rtol=3e-7, atol=2e-7)
+
+
+def test_baseline_sweeps_match_reference(oracle, golden):
+    """lt_c_train.py:105-121 and ls_c_train.py:108-155 scoring against the imported reference."""
+    g = golden("baselines")
+    for i in range(4):
+        out = {k: g["lt%d_%s" % (i, k)] for k in ("boxes", "props", "prob_max")}
+        assert abs(oracle.lt_uncertainty(out) - g["lt_unc"][i]) <= 1e-6
+    for i in range(int(g["ls_n"])):
+        per = int(g["ls_per"][i])
+        ref = {k: g["ls%d_0_%s" % (i, k)] for k in ("boxes", "prob_max")}
+        outs = [{"boxes": g["ls%d_%d_boxes" % (i, v)]} for v in range(1, per)]
+        assert abs(oracle.ls_score_image(ref, outs) - g["ls_unc"][i]) <= 1e-6, i
+    img = g["ls_img0"]
+    H, W, _ = img.shape
+    noise = oracle.gaussian_noise_seq(oracle.image_seed(5, 0), H, W, [8.0 * k for k in range(1, 7)])
+    for v in range(1, 7):    # the six sequential GaussianNoise views exactly as the reference's detector saw them
+        got = img.astype(np.float32) / np.float32(255) + noise[v - 1].transpose(1, 2, 0)
+        np.testing.assert_allclose(got, g["ls_seen0_%d" % v], rtol=0, atol=2e-6)
