@@ -634,11 +634,13 @@ extern "C" int cald_model_finalize(cald_model* m) {
     m->finalized = true;
     return 0;
 }
+static void free_det(DetBuffers& d);
 extern "C" int cald_model_destroy(cald_model* m) {
     if (!m) return 0;
     hipSetDevice(m->ctx->device);
     hipStreamSynchronize(m->ctx->stream);
     for (void* p : m->owned) hipFree(p);
+    if (m->sweep_det_views) free_det(m->sweep_det);
     delete m;
     return 0;
 }

@@ -176,3 +176,34 @@ def retinanet_resnet50_fpn_cal(pretrained=False, progress=True, num_classes=91, 
     """detection/retinanet_cal.py:584-625 (constructor defaults :322-333).  Result dict keys of :479-485."""
     return HipDetector(num_classes, depth=50, box_score_thresh=score_thresh, box_nms_thresh=nms_thresh,
                        box_detections_per_img=detections_per_img, arch=1, **kwargs)
+
+
+def from_torch_module(task_model):
+    """Builds the HIP detector that mirrors a reference torch model (detection/frcnn_la.py FRCNN_Feature or
+    detection/retinanet_cal.py RetinaNet): constructor arguments are read off the module's attributes
+    (transform.min_size / max_size, roi_heads.*, rpn.*), the weights off ``state_dict()`` -- so
+    ``get_uncertainty(task_model, ...)`` accepts the model cald_train.py already has (cald_train.py:436)."""
+    sd = task_model.state_dict()
+    tr = getattr(task_model, "transform", None)
+    min_size = getattr(tr, "min_size", 800)
+    min_size = int(min_size[0] if isinstance(min_size, (tuple, list)) else min_size)
+    max_size = int(getattr(tr, "max_size", 1333))
+    depth = 101 if any(k.startswith("backbone.body.layer3.22.") for k in sd) else 50
+    if any(k.startswith("head.classification_head.") for k in sd):
+        ncls = int(sd["head.classification_head.cls_logits.weight"].shape[0]) // 9
+        m = HipDetector(ncls, depth=depth, min_size=min_size, max_size=max_size, arch=1,
+                        box_score_thresh=float(getattr(task_model, "score_thresh", 0.05)),
+                        box_nms_thresh=float(getattr(task_model, "nms_thresh", 0.5)),
+                        box_detections_per_img=int(getattr(task_model, "detections_per_img", 300)))
+    else:
+        ncls = int(sd["roi_heads.box_predictor.cls_score.weight"].shape[0])
+        rh, rpn = getattr(task_model, "roi_heads", None), getattr(task_model, "rpn", None)
+        pre = getattr(rpn, "_pre_nms_top_n", {"testing": 1000}); post = getattr(rpn, "_post_nms_top_n", {"testing": 1000})
+        m = HipDetector(ncls, depth=depth, min_size=min_size, max_size=max_size,
+                        box_score_thresh=float(getattr(rh, "score_thresh", 0.05)), box_nms_thresh=float(getattr(rh, "nms_thresh", 0.5)),
+                        box_detections_per_img=int(getattr(rh, "detections_per_img", 100)),
+                        rpn_pre_nms_top_n_test=int(pre["testing"]), rpn_post_nms_top_n_test=int(post["testing"]),
+                        rpn_nms_thresh=float(getattr(rpn, "nms_thresh", 0.7)))
+    m.to("cuda:%d" % torch.cuda.current_device() if torch.cuda.is_available() else "cuda")
+    m.load_state_dict(sd)
+    return m.eval()

@@ -86,6 +86,9 @@ def allgather_scores(local_pos, cons, cls, pool_size, group=None):
 def get_uncertainty(task_model, unlabeled_loader, augs, num_cls, bp=1.3, base_seed=0, rank=0, world_size=1,
                     batch_images=64, group=None):
     """Drop-in for cald_train.py:91 (same positional signature)."""
+    if not hasattr(task_model, "handle"):          # the reference's torch model: mirror it on the HIP side
+        from .detector import from_torch_module
+        task_model = from_torch_module(task_model)
     task_model.eval()
     # without a GPU the upload below is a no-op and sweep_device_images() raises (no CPU fallback)
     dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")

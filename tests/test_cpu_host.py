@@ -179,6 +179,9 @@ class _FakeModel:
     def eval(self):
         return self
 
+    def handle(self):
+        return None
+
 
 def _fake_sweep(task_model, images, positions, augs, bp=1.3, base_seed=0, batch_images=64):
     """Stands in for the GPU sweep: a deterministic function of (pool position, image bytes)."""
@@ -243,3 +246,43 @@ def test_voc_results_wire_format_matches_reference(golden, tmp_path):
     for key in g.files:
         if key.startswith("file_"):
             assert open(os.path.join(out, key[5:])).read() == str(g[key]), key
+
+
+def test_wrapping_a_reference_torch_model_reads_its_configuration():
+    """get_uncertainty() accepts the torch model cald_train.py already holds: constructor arguments come from
+    the module attributes torchvision exposes, weights from state_dict()."""
+    import torch
+    from types import SimpleNamespace
+    from cald_amd import detector, synth
+
+    class FakeTorchFRCNN:
+        transform = SimpleNamespace(min_size=(600,), max_size=1000)
+        roi_heads = SimpleNamespace(score_thresh=0.05, nms_thresh=0.5, detections_per_img=100)
+        rpn = SimpleNamespace(_pre_nms_top_n={"training": 2000, "testing": 1000}, _post_nms_top_n={"training": 2000, "testing": 1000}, nms_thresh=0.7)
+
+        def __init__(self, sd):
+            self._sd = {k: torch.from_numpy(v) for k, v in sd.items()}
+
+        def state_dict(self):
+            return self._sd
+    m = detector.from_torch_module(FakeTorchFRCNN(synth.pseudo_trained_frcnn(21, 50, 0)))
+    assert (m.cfg.arch, m.cfg.depth, m.cfg.num_classes, m.cfg.min_size, m.cfg.max_size) == (0, 50, 21, 600, 1000)
+    assert (m.cfg.detections_per_img, m.cfg.rpn_pre_nms_top_n, m.cfg.rpn_post_nms_top_n) == (100, 1000, 1000)
+
+    class FakeTorchRetina(FakeTorchFRCNN):
+        score_thresh, nms_thresh, detections_per_img = 0.05, 0.5, 300
+    r = detector.from_torch_module(FakeTorchRetina(synth.pseudo_trained_retinanet(21, 50, 0)))
+    assert (r.cfg.arch, r.cfg.num_classes, r.cfg.detections_per_img) == (1, 21, 300)
+
+
+def test_c_abi_rejects_bad_arguments_without_touching_the_gpu():
+    import ctypes as C
+    from cald_amd import _ffi
+    L = _ffi.lib()
+    assert L.cald_ctx_create(0, None, None) != 0 and b"null" in L.cald_last_error()
+    assert L.cald_model_create(None, None, None) != 0
+    assert L.cald_ctx_sync(None) != 0
+    n = C.c_int()
+    rects = (C.c_int * 16)()
+    assert L.cald_op_cutout_rects(1, 10, 10, 0, None, 9, rects, C.byref(n)) != 0      # cut_num > 4
+    assert L.cald_ctx_destroy(None) == 0 and L.cald_model_destroy(None) == 0

@@ -370,3 +370,28 @@ def test_baseline_sweeps_lt_c_ls_c(hip, oracle, small_model):
     got = baselines.ls_c_get_uncertainty(model, loader[:3], base_seed=4, batch_images=2)
     want = oracle.ls_get_uncertainty(P, pool[:3], 300, 500, base_seed=4)
     np.testing.assert_allclose(np.array(got), np.array(want), rtol=0, atol=1e-12)
+
+
+def test_drop_in_selection_stage(hip, oracle, small_model):
+    """The selection stage of cald_train.py:434-447 with the drop-in modules: a reference-style torch model object goes
+    into get_uncertainty(); argsort + cls_kldiv pick the same images as the oracle-driven flow."""
+    torch = hip["torch"]
+    from types import SimpleNamespace
+    from cald_amd import synth, sweep
+    model, P = small_model
+
+    class RefStyleModel:            # what cald_train.py holds: a torch module with state_dict() and torchvision attributes
+        transform = SimpleNamespace(min_size=(300,), max_size=500)
+
+        def state_dict(self):
+            return {k: torch.from_numpy(v) for k, v in model.state_dict().items()}
+    pool = synth.make_pool(8, "voc", 0, scale=0.5)
+    loader = [((torch.from_numpy(im),), (None,)) for im in pool]
+    augs = ["flip", "cut_out", "smaller_resize"]
+    unc, cls = sweep.get_uncertainty(RefStyleModel(), loader, augs, 21, bp=1.3, base_seed=1)
+    wc, wcls = oracle.get_uncertainty(P, pool, augs, 21, bp=1.3, min_size=300, max_size=500, base_seed=1)
+    assert unc == wc
+    labeled = [(None, [{"labels": torch.tensor([1, 5, 5, 7])}]), (None, [{"labels": torch.tensor([2])}])]
+    got = sweep.select(unc, cls, labeled, budget=3, mr=1.2)
+    want = sweep.select(wc, wcls, labeled, budget=3, mr=1.2)
+    np.testing.assert_array_equal(got, want)
