@@ -60,7 +60,7 @@ class HipDetector:
         dev = torch.device(device)
         if dev.type != "cuda":
             raise RuntimeError("cald_amd detectors live on the MI355X only")
-        self._device = dev.index if dev.index is not None else torch.cuda.current_device()
+        self._device = dev.index if dev.index is not None else (torch.cuda.current_device() if torch.cuda.is_available() else 0)
         return self
 
     def cuda(self, device=None):
