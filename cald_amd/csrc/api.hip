@@ -677,7 +677,7 @@ struct FwdBufs {
     float *roi, *f6, *f7, *pr, *prob, *pmax; unsigned long long* keys; float* cbox; int* key_count;
     // RetinaNet
     float *ret_ta, *ret_tb, *cls_h[5], *reg_h[5], *rcand_box, *kept_box; unsigned long long* rcand_key;
-    int *cand_count, *kept_anchor, *kept_count; int cand_cap; int max_anchors;
+    int *cand_count, *kept_anchor, *kept_count; int cand_cap; int max_anchors; unsigned char* cand_skip;
 };
 
 static int conv_on(cald_model* m, const ConvLayer& L, const float* in, float* out, int lin, int lout, int V, bool relu,
@@ -721,6 +721,7 @@ static void fwd_layout(cald_model* m, Bump& B, FwdBufs& F, int V) {
         F.cand_count = B.get<int>((size_t)V * K);
         F.rcand_key = B.get<unsigned long long>((size_t)V * K * cap);
         F.rcand_box = B.get<float>((size_t)V * K * cap * 4);
+        F.cand_skip = B.get<unsigned char>((size_t)V * K * cap);
         F.kept_anchor = B.get<int>((size_t)V * K * per);
         F.kept_box = B.get<float>((size_t)V * K * per * 4);
         F.kept_count = B.get<int>((size_t)V * K);
@@ -849,7 +850,7 @@ static int forward_model(cald_model* m, int V, ViewDesc* views, const DetBuffers
         ra.cls_ld = m->cls_out.Cout; ra.reg_ld = 36; ra.A = 9; ra.K = m->cfg.num_classes; ra.V = V;
         ra.score_thr = m->cfg.box_score_thresh; ra.nms_thr = m->cfg.box_nms_thresh; ra.min_box = 1e-2f;
         ra.per_class = m->cfg.detections_per_img; ra.cand_cap = F.cand_cap;
-        ra.cand_count = F.cand_count; ra.cand_key = F.rcand_key; ra.cand_box = F.rcand_box;
+        ra.cand_count = F.cand_count; ra.cand_key = F.rcand_key; ra.cand_box = F.rcand_box; ra.cand_skip = F.cand_skip;
         ra.kept_anchor = F.kept_anchor; ra.kept_box = F.kept_box; ra.kept_count = F.kept_count; ra.det = det;
         launch_retina_postprocess(ra, F.max_anchors, st);
         HIPCHK(hipGetLastError());

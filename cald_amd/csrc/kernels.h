@@ -120,6 +120,7 @@ struct RetinaArgs {
     int* cand_count;              // [V][K]
     unsigned long long* cand_key; // [V][K][cand_cap]
     float* cand_box;              // [V][K][cand_cap][4]
+    unsigned char* cand_skip;     // [V][K][cand_cap] 1 = removed by remove_small_boxes
     int* kept_anchor;             // [V][K][per_class]
     float* kept_box;              // [V][K][per_class][4]
     int* kept_count;              // [V][K]

@@ -89,14 +89,15 @@ __global__ __launch_bounds__(1024) void retina_class_nms_kernel(RetinaArgs a) {
     const ViewDesc vd = a.views[v];
     const float Wr = (float)vd.Wr, Hr = (float)vd.Hr;
     float4* cbox = reinterpret_cast<float4*>(a.cand_box) + slot * a.cand_cap;
+    unsigned char* cskip = a.cand_skip + slot * a.cand_cap;
     for (int i = tid; i < n; i += 1024) {
         const int ai = (int)(0xFFFFFFFFu - (unsigned)(keys[i] & 0xFFFFFFFFull));
         float4 b = retina_decode(a, v, ai, Wr, Hr);
-        if (!((b.z - b.x) >= a.min_box && (b.w - b.y) >= a.min_box)) b.x = NAN;   // remove_small_boxes
+        cskip[i] = ((b.z - b.x) >= a.min_box && (b.w - b.y) >= a.min_box) ? 0 : 1;   // remove_small_boxes
         cbox[i] = b;
     }
     __syncthreads();
-    block_nms_sorted(cbox, n, a.nms_thr, per, kept_box, kept_area, dead_or, keep_idx, &s_nk);
+    block_nms_sorted(cbox, n, a.nms_thr, per, kept_box, kept_area, dead_or, keep_idx, &s_nk, cskip);
     const int nk = s_nk;
     for (int i = tid; i < nk; i += 1024) {
         const int ci = keep_idx[i];

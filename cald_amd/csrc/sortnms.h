@@ -35,9 +35,11 @@ __device__ inline bool nms_overlaps(const float4 bi, const float ai, const float
 // Greedy NMS over n score-sorted boxes, executed by the first 256 threads (4 waves) of the block.
 // kept_box / kept_area: LDS scratch of max_keep entries; dead_or: LDS scratch of 4*64 ints.
 // keep_out (LDS or global): indices (into the sorted order) of kept boxes.  Returns count via *nk_out.
+// skip (optional, global): 1 = the box takes no part in NMS (neither kept nor suppressing).
 // Must be called by ALL threads of the block (contains __syncthreads).
 __device__ inline void block_nms_sorted(const float4* boxes, int n, float thr, int max_keep, float4* kept_box,
-                                        float* kept_area, int* dead_or, int* keep_out, int* nk_out) {
+                                        float* kept_area, int* dead_or, int* keep_out, int* nk_out,
+                                        const unsigned char* skip = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     __shared__ int s_nk;
     if (tid == 0) s_nk = 0;
@@ -50,7 +52,7 @@ __device__ inline void block_nms_sorted(const float4* boxes, int n, float thr, i
         bool dead = true;
         if (wave < 4) {
             dead = !(j < n);
-            if (!dead) { b = boxes[j]; if (b.x != b.x) dead = true; }   // NaN x1 marks a filtered-out box
+            if (!dead) { b = boxes[j]; if (skip && skip[j]) dead = true; }   // skip[]: boxes filtered out before NMS (remove_small_boxes)
             // phase A: this wave tests kept[t], t = wave, wave+4, ...
             if (!dead) {
                 for (int t = wave; t < nk; t += 4)
