@@ -395,3 +395,21 @@ def test_drop_in_selection_stage(hip, oracle, small_model):
     got = sweep.select(unc, cls, labeled, budget=3, mr=1.2)
     want = sweep.select(wc, wcls, labeled, budget=3, mr=1.2)
     np.testing.assert_array_equal(got, want)
+
+
+def test_gpu_sweep_vs_independent_torch_cpu_path(hip, small_model):
+    """BASELINE.json's bar against a path that does NOT share the arithmetic contract: the torch-CPU fp32 port
+    (oneDNN conv/linear summation order).  Floats within 1e-4, identical top-k selection indices."""
+    torch = hip["torch"]
+    from cald_amd import synth, sweep
+    from oracle import torch_port
+    model, _ = small_model
+    pool = synth.make_pool(12, "voc", 0, scale=0.5)
+    augs = ["flip", "cut_out", "smaller_resize"]
+    cons, cls = sweep.sweep_device_images(model, [torch.from_numpy(im).cuda() for im in pool], list(range(12)), augs, base_seed=0)
+    tm = torch_port.TorchFRCNN(model.state_dict(), 21, 50, 300, 500)
+    ref, rcls = torch_port.get_uncertainty(tm, pool, augs, 21, bp=1.3, base_seed=0)
+    np.testing.assert_allclose(cons, np.array(ref), rtol=0, atol=1e-4)       # tolerance stated by BASELINE.json north_star
+    np.testing.assert_allclose(cls, np.stack(rcls), rtol=0, atol=1e-4)
+    k = 4
+    np.testing.assert_array_equal(np.argsort(cons)[:k], np.argsort(np.array(ref))[:k])
