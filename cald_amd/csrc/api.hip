@@ -237,7 +237,7 @@ extern "C" int cald_op_pil_resize(cald_ctx* c, const uint8_t* src_dev, int H, in
 // =============================================================================================
 struct HostTensor { std::vector<float> data; std::vector<int64_t> shape; };
 struct ConvLayer {
-    float *w = nullptr, *bias = nullptr, *scale = nullptr, *shift = nullptr;
+    float *w = nullptr, *w4 = nullptr, *bias = nullptr, *scale = nullptr, *shift = nullptr;
     int Cin = 0, Cout = 0, CoutPad = 0, K = 0, Kpad = 0, KH = 1, KW = 1, stride = 1, pad = 0;
     int CinTrue = 0;   // un-padded input channels (algorithmic FLOP accounting)
 };
@@ -289,6 +289,17 @@ extern "C" int cald_model_load_tensor(cald_model* m, const char* key, const floa
     return 0;
 }
 
+// K-major [Kpad][CoutPad] -> [Kpad/16][2][CoutPad][2][4], k = 16 kt + 8 kq + 2 j + h  (conv_p4.hip)
+static std::vector<float> pack_w4(const std::vector<float>& w, int Kpad, int CoutPad) {
+    std::vector<float> o(w.size());
+    for (int k = 0; k < Kpad; k++) {
+        const int kt = k >> 4, kk = k & 15, kq = kk >> 3, j = (kk & 7) >> 1, h = kk & 1;
+        for (int n = 0; n < CoutPad; n++)
+            o[(((size_t)(kt * 2 + kq) * CoutPad + n) * 2 + h) * 4 + j] = w[(size_t)k * CoutPad + n];
+    }
+    return o;
+}
+
 static int get_t(cald_model* m, const std::string& key, const HostTensor** t) {
     auto it = m->sd.find(key);
     if (it == m->sd.end()) return fail(CALD_ERR_MISSING_WEIGHT, "missing tensor '%s' in state dict", key.c_str());
@@ -330,6 +341,10 @@ static int make_conv(cald_model* m, ConvLayer& L, const std::vector<std::string>
         co0 += c0;
     }
     int rc = upload(m, w, &L.w); if (rc) return rc;
+    if (L.CoutPad % 128 == 0 && L.Cin % 16 == 0 && kh * kw <= 32) {   // conv_p4.hip layout
+        std::vector<float> w4 = pack_w4(w, L.Kpad, L.CoutPad);
+        if ((rc = upload(m, w4, &L.w4))) return rc;
+    }
     if (!bkeys.empty()) {
         std::vector<float> b(L.CoutPad, 0.0f); int o = 0;
         for (auto& k : bkeys) { const HostTensor* t; rc = get_t(m, k, &t); if (rc) return rc; for (float v : t->data) b[o++] = v; }
@@ -507,7 +522,7 @@ static int conv_on(cald_model* m, const ConvLayer& L, const float* in, float* ou
                    bool in_relu = false) {
     ConvArgs a;
     const BatchPlan* dp = m->ctx->d_plan;
-    a.in = in; a.out = out; a.w = L.w; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift;
+    a.in = in; a.out = out; a.w = L.w; a.w4 = L.w4; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift;
     a.residual = residual; a.up = up;
     a.seg_in = dp->seg[lin]; a.seg_out = dp->seg[lout]; a.seg_up = dp->seg[lup];
     a.dyn_rows = dyn; a.V = V;
@@ -789,13 +804,19 @@ extern "C" int cald_op_conv2d(cald_ctx* c, const float* in, int H, int W, int Ci
     HIPCHK(hipMalloc((void**)&d_p, sizeof(BatchPlan)));
     HIPCHK(hipMemcpy(d_in, in, (size_t)H * W * Cin * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_w, w.data(), w.size() * 4, hipMemcpyHostToDevice));
+    float* d_w4 = nullptr;
+    if (CoutPad % 128 == 0 && Cin % 16 == 0 && KH * KW <= 32) {
+        std::vector<float> w4 = pack_w4(w, Kpad, CoutPad);
+        HIPCHK(hipMalloc((void**)&d_w4, w4.size() * 4));
+        HIPCHK(hipMemcpy(d_w4, w4.data(), w4.size() * 4, hipMemcpyHostToDevice));
+    }
     HIPCHK(hipMemcpy(d_b, b.data(), b.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_sc, sc.data(), sc.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_sh, sh.data(), sh.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_p, &P, sizeof(P), hipMemcpyHostToDevice));
     if (residual) { HIPCHK(hipMalloc((void**)&d_res, (size_t)Ho * Wo * Cout * 4)); HIPCHK(hipMemcpy(d_res, residual, (size_t)Ho * Wo * Cout * 4, hipMemcpyHostToDevice)); }
     ConvArgs a; memset(&a, 0, sizeof(a));
-    a.in = d_in; a.out = d_out; a.w = d_w; a.bias = bias ? d_b : nullptr; a.scale = bn_scale ? d_sc : nullptr; a.shift = bn_scale ? d_sh : nullptr;
+    a.in = d_in; a.out = d_out; a.w = d_w; a.w4 = d_w4; a.bias = bias ? d_b : nullptr; a.scale = bn_scale ? d_sc : nullptr; a.shift = bn_scale ? d_sh : nullptr;
     a.residual = d_res; a.up = nullptr; a.seg_in = d_p->seg[0]; a.seg_out = d_p->seg[1]; a.seg_up = d_p->seg[1]; a.dyn_rows = nullptr;
     a.V = 1; a.Cin = Cin; a.Cout = Cout; a.CoutPad = CoutPad; a.Kpad = Kpad; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
     a.relu = relu; a.total_mtiles = (Ho * Wo + 127) / 128; a.out_ld = Cout; a.in_relu = 0; a.zeros = c->d_zeros;
@@ -803,6 +824,7 @@ extern "C" int cald_op_conv2d(cald_ctx* c, const float* in, int H, int W, int Ci
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemcpy(out, d_out, (size_t)Ho * Wo * Cout * 4, hipMemcpyDeviceToHost));
+    if (d_w4) hipFree(d_w4);
     hipFree(d_in); hipFree(d_out); hipFree(d_w); hipFree(d_b); hipFree(d_sc); hipFree(d_sh); hipFree(d_p); if (d_res) hipFree(d_res);
     return 0;
 }

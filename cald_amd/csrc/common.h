@@ -28,6 +28,7 @@ struct ConvArgs {
     const float* in;
     float* out;
     const float* w;        // [Kpad][CoutPad], K order (kh, kw, cin)
+    const float* w4;       // same weights packed [Kpad/16][2][CoutPad][2][4] for conv_p4.hip (k = 16 kt + 8 kq + 2 j + h), or null
     const float* bias;     // [CoutPad] or null
     const float* scale;    // FrozenBN scale/shift or null
     const float* shift;

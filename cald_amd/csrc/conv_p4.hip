@@ -1,0 +1,246 @@
+// conv_p4.hip -- conv_p3's schedule with 128-bit LDS fragment reads.
+//
+// Same arithmetic and bit-identical results (one k-ordered fma chain per output).  Differences from conv_p3.hip:
+//   * LDS tile layout [kq][row][h][j] (k = 8*kq + 2*j + h): the four A (or B) values a lane feeds into four
+//     consecutive v_mfma_f32_32x32x2_f32 are one aligned 16-byte word -> one ds_read_b128 per (sub-tile, kq)
+//     instead of four ds_read_b32; h is XOR-swizzled with bit 3 of the row so the 16-lane b128 groups are
+//     conflict-free.  Weights are pre-packed in that order at model finalize (ConvArgs::w4), so B is staged with
+//     coalesced 16-byte loads + ds_write_b128; A is staged with two ds_write_b64 per gathered float4.
+//   Per k-tile and wave: 32 MFMA, 8 ds_read_b128, 6 LDS writes, 4 buffer loads, ~10 VALU.
+#include "common.h"
+#include <cstdlib>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int EPI>
+__global__ __launch_bounds__(256, 3) void conv_p4_kernel(const ConvArgs a) {
+    constexpr int BM = 128, BN = 128, BK = 16, TM = 2, TN = 2, WN = 2;
+    constexpr int TILE_A = 2 * BM * 8, TILE_F = TILE_A + 2 * BN * 8;      // floats: 2048 + 2048
+    __shared__ __attribute__((aligned(16))) float smem[3 * TILE_F];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int NT = a.CoutPad / BN;
+    int mt, nt;
+    {
+        const int b = blockIdx.x, MT = a.total_mtiles, MT8 = MT & ~7;
+        if (b < MT8 * NT) { const int xcd = b & 7, idx = b >> 3; mt = (idx / NT) * 8 + xcd; nt = idx % NT; }
+        else { const int r = b - MT8 * NT; mt = MT8 + r / NT; nt = r % NT; }
+    }
+    const int n0 = nt * BN;
+    int v = 0;
+    while (v + 1 < a.V && a.seg_out[v + 1].tile_start <= mt) v++;
+    const LevelSeg so = a.seg_out[v];
+    const LevelSeg si = a.seg_in[v];
+    const int Ho = so.H, Wo = so.W, Hi = si.H, Wi = si.W;
+    int Mv = Ho * Wo;
+    if (a.dyn_rows) { const int d = a.dyn_rows[v]; Mv = d < Mv ? d : Mv; }
+    const int m0 = (mt - so.tile_start) * BM;
+    if (m0 >= Mv) return;
+    const float* __restrict__ in_v = a.in + si.pix_off * (long long)a.Cin;
+    const int Cin = a.Cin, KW = a.KW, KH = a.KH, CoutPad = a.CoutPad;
+    const bool in_relu = a.in_relu != 0;
+
+    // ---- A gather (buffer resource, tap masks) : rows arow, arow + 64; k group g = 4 consecutive k ----
+    const int g = tid & 3, arow = tid >> 2;
+    unsigned rowmask[2];
+    int rowvoff[2];
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        const int m = m0 + arow + 64 * p;
+        const int oy = m / Wo, ox = m - oy * Wo;
+        const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
+        unsigned msk = 0;
+        if (m < Mv)
+            for (int t = 0; t < KH * KW; t++) {
+                const int th = t / KW, tw = t - th * KW;
+                const int iy = iy0 + th, ix = ix0 + tw;
+                if (iy >= 0 && iy < Hi && ix >= 0 && ix < Wi) msk |= 1u << t;
+            }
+        rowmask[p] = msk;
+        rowvoff[p] = (((oy * a.stride) * Wi + ox * a.stride) * Cin + 4 * g) * 4;
+    }
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(in_v - (long long)a.pad * (Wi + 1) * Cin), 0, 0x7FFE0000, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(a.w4 + (long long)n0 * 8), 0, 0x7FFE0000, 0x00020000);
+    int u_kh = 0, u_kw = 0, u_ci = 0, u_kt = 0;
+    // A LDS write offsets (floats): k = 4g + t -> kq = g >> 1, j = 2 (g & 1) + (t >> 1), h = t & 1
+    const int a_kq = g >> 1, a_j = 2 * (g & 1);
+    int aw_off[2][2];
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        const int r = arow + 64 * p;
+#pragma unroll
+        for (int h = 0; h < 2; h++) aw_off[p][h] = ((a_kq * BM + r) * 2 + (h ^ ((r >> 3) & 1))) * 4 + a_j;
+    }
+    // B: float4 f = tid + 256 p  ->  kq = p, n_l = tid >> 1, h = tid & 1
+    const int b_nl = tid >> 1, b_h = tid & 1;
+    const int bvoff0 = (b_nl * 8 + b_h * 4) * 4, bvoff1 = bvoff0 + CoutPad * 8 * 4;
+    const int bw_off0 = TILE_A + ((0 * BN + b_nl) * 2 + (b_h ^ ((b_nl >> 3) & 1))) * 4, bw_off1 = bw_off0 + BN * 8;
+
+    f32x4 ra0, ra1, rb0, rb1;
+
+#define P4_LOAD()                                                                                          \
+    {                                                                                                      \
+        const unsigned u_bit = 1u << (u_kh * KW + u_kw);                                                   \
+        const int soffA = ((u_kh * Wi + u_kw) * Cin + u_ci) * 4;                                           \
+        const int soffB = u_kt * 2 * CoutPad * 8 * 4;                                                      \
+        const int v0 = (rowmask[0] & u_bit) ? rowvoff[0] : 0x7FFF0000;                                     \
+        const int v1 = (rowmask[1] & u_bit) ? rowvoff[1] : 0x7FFF0000;                                     \
+        ra0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, v0, soffA, 0));         \
+        ra1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, v1, soffA, 0));         \
+        rb0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, bvoff0, soffB, 0));     \
+        rb1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, bvoff1, soffB, 0));     \
+        u_kt++; u_ci += BK;                                                                                \
+        if (u_ci >= Cin) { u_ci = 0; u_kw++; if (u_kw == KW) { u_kw = 0; u_kh++; } }                       \
+    }
+#define P4_STORE(BUF)                                                                                      \
+    {                                                                                                      \
+        if (in_relu) {                                                                                     \
+            _Pragma("unroll") for (int q = 0; q < 4; q++) { ra0[q] = ra0[q] < 0.f ? 0.f : ra0[q]; ra1[q] = ra1[q] < 0.f ? 0.f : ra1[q]; } \
+        }                                                                                                  \
+        float* tb = smem + (BUF) * TILE_F;                                                                 \
+        *reinterpret_cast<float2*>(tb + aw_off[0][0]) = make_float2(ra0[0], ra0[2]);                       \
+        *reinterpret_cast<float2*>(tb + aw_off[0][1]) = make_float2(ra0[1], ra0[3]);                       \
+        *reinterpret_cast<float2*>(tb + aw_off[1][0]) = make_float2(ra1[0], ra1[2]);                       \
+        *reinterpret_cast<float2*>(tb + aw_off[1][1]) = make_float2(ra1[1], ra1[3]);                       \
+        *reinterpret_cast<f32x4*>(tb + bw_off0) = rb0;                                                     \
+        *reinterpret_cast<f32x4*>(tb + bw_off1) = rb1;                                                     \
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+
+    const int KT = a.Kpad / BK;
+    P4_LOAD();
+    P4_STORE(0);
+    if (KT > 1) P4_LOAD();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // fragment read offsets (floats) inside a tile buffer, kq = 0; kq = 1 adds BM*8 (A) / BN*8 (B)
+    const int kh_lane = lane >> 5, l31 = lane & 31;
+    int fo_a[TM], fo_b[TN];
+#pragma unroll
+    for (int t = 0; t < TM; t++) { const int m = wm * 64 + t * 32 + l31; fo_a[t] = (m * 2 + (kh_lane ^ ((m >> 3) & 1))) * 4; }
+#pragma unroll
+    for (int t = 0; t < TN; t++) { const int n = wn * 64 + t * 32 + l31; fo_b[t] = TILE_A + (n * 2 + (kh_lane ^ ((n >> 3) & 1))) * 4; }
+    f32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+#pragma unroll
+    for (int t = 0; t < TM; t++) fa0[t] = *reinterpret_cast<const f32x4*>(smem + fo_a[t]);
+#pragma unroll
+    for (int t = 0; t < TN; t++) fb0[t] = *reinterpret_cast<const f32x4*>(smem + fo_b[t]);
+
+#define P4_MFMA(FA, FB, Q)                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < TM; i++)                                                         \
+        _Pragma("unroll") for (int j = 0; j < TN; j++)                                                     \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[i][Q], FB[j][Q], acc[i][j], 0, 0, 0);
+#define P4_TILE(CUR, NXT)                                                                                  \
+    {                                                                                                      \
+        const float* tc = smem + (CUR) * TILE_F;                                                           \
+        const float* tn = smem + (NXT) * TILE_F;                                                           \
+        const bool has1 = kt + 1 < KT, has2 = kt + 2 < KT;                                                 \
+        _Pragma("unroll") for (int t = 0; t < TM; t++) fa1[t] = *reinterpret_cast<const f32x4*>(tc + fo_a[t] + BM * 8); \
+        _Pragma("unroll") for (int t = 0; t < TN; t++) fb1[t] = *reinterpret_cast<const f32x4*>(tc + fo_b[t] + BN * 8); \
+        P4_MFMA(fa0, fb0, 0)                                                                               \
+        P4_MFMA(fa0, fb0, 1)                                                                               \
+        if (has1) P4_STORE(NXT)                                                                            \
+        P4_MFMA(fa0, fb0, 2)                                                                               \
+        if (has2) P4_LOAD()                                                                                \
+        P4_MFMA(fa0, fb0, 3)                                                                               \
+        P4_MFMA(fa1, fb1, 0)                                                                               \
+        P4_MFMA(fa1, fb1, 1)                                                                               \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                 \
+        __builtin_amdgcn_s_barrier();                                                                      \
+        if (has1) {                                                                                        \
+            _Pragma("unroll") for (int t = 0; t < TM; t++) fa0[t] = *reinterpret_cast<const f32x4*>(tn + fo_a[t]); \
+            _Pragma("unroll") for (int t = 0; t < TN; t++) fb0[t] = *reinterpret_cast<const f32x4*>(tn + fo_b[t]); \
+        }                                                                                                  \
+        P4_MFMA(fa1, fb1, 2)                                                                               \
+        P4_MFMA(fa1, fb1, 3)                                                                               \
+    }
+
+    int cur = 0;
+    for (int kt = 0; kt < KT; kt++) {
+        const int nxtb = cur == 2 ? 0 : cur + 1;
+        P4_TILE(cur, nxtb);
+        cur = nxtb;
+    }
+#undef P4_LOAD
+#undef P4_STORE
+#undef P4_MFMA
+#undef P4_TILE
+
+    // ---- fused epilogue: identical to conv_mfma.hip ----
+    const int out_ld = a.out_ld;
+    float* __restrict__ out_v = a.out + so.pix_off * (long long)out_ld;
+    const float* __restrict__ ex_v = nullptr;
+    int upH = 1, upW = 1;
+    float uph_s = 0.f, upw_s = 0.f;
+    if (EPI == 1) ex_v = a.residual + so.pix_off * (long long)out_ld;
+    if (EPI == 2) {
+        const LevelSeg su = a.seg_up[v];
+        ex_v = a.up + su.pix_off * (long long)out_ld;
+        upH = su.H; upW = su.W;
+        uph_s = (float)upH / (float)Ho; upw_s = (float)upW / (float)Wo;
+    }
+    const bool relu = a.relu != 0;
+    const int Mlast = Mv - 1;
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+        const int n = n0 + wn * TN * 32 + j * 32 + l31;
+        const bool nok = n < a.Cout;
+        const int nc = nok ? n : 0;
+        const float bs = a.bias ? a.bias[nc] : 0.0f;
+        const float sc = a.scale ? a.scale[nc] : 1.0f;
+        const float sh = a.scale ? a.shift[nc] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+            const int mbase = m0 + wm * TM * 32 + i * 32 + 4 * kh_lane;
+            float extra[16];
+            if (EPI != 0) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    int m = mbase + (r & 3) + 8 * (r >> 2);
+                    m = m < Mlast ? m : Mlast;
+                    if (EPI == 1) {
+                        extra[r] = ex_v[(long long)m * out_ld + nc];
+                    } else {
+                        const int oy = m / Wo, ox = m - oy * Wo;
+                        int sy = (int)floorf((float)oy * uph_s); sy = sy > upH - 1 ? upH - 1 : sy;
+                        int sx = (int)floorf((float)ox * upw_s); sx = sx > upW - 1 ? upW - 1 : sx;
+                        extra[r] = ex_v[(long long)(sy * upW + sx) * out_ld + nc];
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int m = mbase + (r & 3) + 8 * (r >> 2);
+                float val = acc[i][j][r];
+                val = val + bs;
+                val = val * sc;
+                val = val + sh;
+                if (EPI != 0) val = val + extra[r];
+                if (relu) val = val > 0.0f ? val : 0.0f;
+                if (m < Mv && nok) out_v[(long long)m * out_ld + n] = val;
+            }
+        }
+    }
+}
+
+// returns true if this variant handled the launch
+bool launch_conv_p4(const ConvArgs& a, hipStream_t stream) {
+    if (!a.w4 || a.CoutPad % 128 != 0 || a.Cin % 16 != 0 || a.KH * a.KW > 32) return false;
+    dim3 grid((unsigned)(a.total_mtiles * (a.CoutPad / 128))), block(256);
+    if (a.residual) hipLaunchKernelGGL((conv_p4_kernel<1>), grid, block, 0, stream, a);
+    else if (a.up) hipLaunchKernelGGL((conv_p4_kernel<2>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((conv_p4_kernel<0>), grid, block, 0, stream, a);
+    return true;
+}

@@ -42,7 +42,7 @@ for key, pat in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write"), ("MFM
         for c in agg[name]:
             summary.setdefault(name, {})[c] = {"sum": agg[name][c], "dispatches": cnt[name][c], "avg": agg[name][c] / cnt[name][c]}
 if summary:
-    conv = {k: v for k, v in summary.items() if "conv_mfma" in k or "conv_p3" in k}
+    conv = {k: v for k, v in summary.items() if "conv_mfma" in k or "conv_p3" in k or "conv_p4" in k}
     tot_f = sum(v.get("FETCH_SIZE", {}).get("sum", 0) for v in conv.values())
     tot_w = sum(v.get("WRITE_SIZE", {}).get("sum", 0) for v in conv.values())
     n = sum(v.get("FETCH_SIZE", {}).get("dispatches", 0) for v in conv.values())
