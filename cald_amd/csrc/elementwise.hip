@@ -15,7 +15,7 @@
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void preprocess_kernel(const ViewDesc* views, const LevelSeg* seg0, float* out) {
     const int v = blockIdx.y;
-    const ViewDesc vd = views[v];
+    const ViewDesc& vd = views[v];   // by reference: a by-value copy puts rects[] (dynamically indexed) in scratch
     const LevelSeg s = seg0[v];
     const int Hp = s.H, Wp = s.W;
     const int pix = blockIdx.x * 256 + threadIdx.x;
@@ -38,8 +38,11 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const ViewDesc* views, 
             for (int b = 0; b < 2; b++) {
                 const int yy = a ? y1 : y0, xx = b ? x1 : x0;
                 bool cut = false;
-                for (int r = 0; r < vd.nrect; r++)
-                    cut |= (xx >= vd.rects[4 * r] && xx < vd.rects[4 * r + 2] && yy >= vd.rects[4 * r + 1] && yy < vd.rects[4 * r + 3]);
+                const int nrect = vd.nrect;
+                for (int r = 0; r < nrect; r++) {
+                    const int* q = vd.rects + 4 * r;
+                    cut |= (xx >= q[0] && xx < q[2] && yy >= q[1] && yy < q[3]);
+                }
                 const int sx = vd.flip ? (W - 1 - xx) : xx;
                 const uint8_t* p = vd.src + ((long long)yy * W + sx) * 3;
 #pragma unroll

@@ -18,51 +18,70 @@ __device__ inline int roi_level(const float4 b) {
     return (int)k - 2;
 }
 
-// grid = (ROI_CAP, V), block = C threads (256): one thread per channel, loops over the 49 bins.
+// grid = (ROI_CAP, V), block = 256.  The 14 sample rows and 14 sample columns of the RoI (7 bins x 2 samples,
+// separable) are set up once per workgroup in LDS; then a thread owns (bin, 4 consecutive channels): 16 float4
+// gathers in flight per bin and one float4 store, 1 KB contiguous per wavefront.  Arithmetic order per channel is
+// the oracle's: acc += ((w1*v1 + w2*v2) + w3*v3) + w4*v4 over samples (iy, ix), then / 4.
+struct RoiSample { int lo, hi; float l, h; int valid; };
+__device__ inline RoiSample roi_sample(float start, float bin, int p, int i, int size) {
+    RoiSample s;
+    const float t = start + (float)p * bin + ((float)i + 0.5f) * bin / 2.0f;
+    s.valid = !(t < -1.0f || t > (float)size);
+    float tt = t <= 0.0f ? 0.0f : t;
+    int lo = (int)tt, hi;
+    if (lo >= size - 1) { hi = lo = size - 1; tt = (float)lo; } else hi = lo + 1;
+    s.lo = lo; s.hi = hi;
+    s.l = tt - (float)lo; s.h = 1.0f - s.l;
+    if (!s.valid) { s.lo = s.hi = 0; }
+    return s;
+}
 __global__ __launch_bounds__(256) void roi_align_kernel(RoiArgs a) {
-    const int r = blockIdx.x, v = blockIdx.y, c = threadIdx.x;
+    __shared__ RoiSample sy[14], sx[14];
+    const int r = blockIdx.x, v = blockIdx.y, tid = threadIdx.x;
     if (r >= a.prop_count[v]) return;
     const float4 box = reinterpret_cast<const float4*>(a.proposals)[(long long)v * CALD_ROI_CAP + r];
     const int l = roi_level(box);
     const LevelSeg sg = a.seg[l][v];
-    const int Hf = sg.H, Wf = sg.W, C = a.C;
-    const float* f = a.feat[l] + sg.pix_off * (long long)C;
-    const float scale = 1.0f / (float)(4 << l);
-    const float x1 = box.x * scale, y1 = box.y * scale, x2 = box.z * scale, y2 = box.w * scale;
-    float rw = x2 - x1; if (!(rw >= 1.0f)) rw = 1.0f;
-    float rh = y2 - y1; if (!(rh >= 1.0f)) rh = 1.0f;
-    const float bw = rw / 7.0f, bh = rh / 7.0f;
-    float* out = a.out + ((long long)v * CALD_ROI_CAP + r) * 49 * C;
-    for (int ph = 0; ph < 7; ph++)
-        for (int pw = 0; pw < 7; pw++) {
-            float acc = 0.0f;
+    const int Hf = sg.H, Wf = sg.W, C = a.C, Cq = C >> 2;
+    const float4* f = reinterpret_cast<const float4*>(a.feat[l] + sg.pix_off * (long long)C);
+    if (tid < 28) {
+        const float scale = 1.0f / (float)(4 << l);
+        const float x1 = box.x * scale, y1 = box.y * scale, x2 = box.z * scale, y2 = box.w * scale;
+        float rw = x2 - x1; if (!(rw >= 1.0f)) rw = 1.0f;
+        float rh = y2 - y1; if (!(rh >= 1.0f)) rh = 1.0f;
+        const float bw = rw / 7.0f, bh = rh / 7.0f;
+        if (tid < 14) sy[tid] = roi_sample(y1, bh, tid >> 1, tid & 1, Hf);
+        else sx[tid - 14] = roi_sample(x1, bw, (tid - 14) >> 1, (tid - 14) & 1, Wf);
+    }
+    __syncthreads();
+    float4* out = reinterpret_cast<float4*>(a.out + ((long long)v * CALD_ROI_CAP + r) * 49 * C);
+    for (int idx = tid; idx < 49 * Cq; idx += 256) {
+        const int bin = idx / Cq, q = idx - bin * Cq;
+        const int ph = bin / 7, pw = bin - ph * 7;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int iy = 0; iy < 2; iy++) {
-                const float y = y1 + (float)ph * bh + ((float)iy + 0.5f) * bh / 2.0f;
+        for (int iy = 0; iy < 2; iy++) {
+            const RoiSample Y = sy[ph * 2 + iy];
 #pragma unroll
-                for (int ix = 0; ix < 2; ix++) {
-                    const float x = x1 + (float)pw * bw + ((float)ix + 0.5f) * bw / 2.0f;
-                    float w1, w2, w3, w4; int yl, xl, yh, xh;
-                    if (y < -1.0f || y > (float)Hf || x < -1.0f || x > (float)Wf) {
-                        w1 = w2 = w3 = w4 = 0.0f; yl = xl = yh = xh = 0;
-                    } else {
-                        float yy = y <= 0.0f ? 0.0f : y, xx = x <= 0.0f ? 0.0f : x;
-                        yl = (int)yy; xl = (int)xx;
-                        if (yl >= Hf - 1) { yh = yl = Hf - 1; yy = (float)yl; } else yh = yl + 1;
-                        if (xl >= Wf - 1) { xh = xl = Wf - 1; xx = (float)xl; } else xh = xl + 1;
-                        const float ly = yy - (float)yl, lx = xx - (float)xl, hy = 1.0f - ly, hx = 1.0f - lx;
-                        w1 = hy * hx; w2 = hy * lx; w3 = ly * hx; w4 = ly * lx;
-                    }
-                    const float v1 = f[(long long)(yl * Wf + xl) * C + c], v2 = f[(long long)(yl * Wf + xh) * C + c];
-                    const float v3 = f[(long long)(yh * Wf + xl) * C + c], v4 = f[(long long)(yh * Wf + xh) * C + c];
-                    acc = acc + (((w1 * v1 + w2 * v2) + w3 * v3) + w4 * v4);
-                }
+            for (int ix = 0; ix < 2; ix++) {
+                const RoiSample X = sx[pw * 2 + ix];
+                const bool ok = Y.valid && X.valid;
+                const int yl = ok ? Y.lo : 0, yh = ok ? Y.hi : 0, xl = ok ? X.lo : 0, xh = ok ? X.hi : 0;
+                const float w1 = ok ? Y.h * X.h : 0.0f, w2 = ok ? Y.h * X.l : 0.0f;
+                const float w3 = ok ? Y.l * X.h : 0.0f, w4 = ok ? Y.l * X.l : 0.0f;
+                const float4 v1 = f[(long long)(yl * Wf + xl) * Cq + q], v2 = f[(long long)(yl * Wf + xh) * Cq + q];
+                const float4 v3 = f[(long long)(yh * Wf + xl) * Cq + q], v4 = f[(long long)(yh * Wf + xh) * Cq + q];
+                acc.x = acc.x + (((w1 * v1.x + w2 * v2.x) + w3 * v3.x) + w4 * v4.x);
+                acc.y = acc.y + (((w1 * v1.y + w2 * v2.y) + w3 * v3.y) + w4 * v4.y);
+                acc.z = acc.z + (((w1 * v1.z + w2 * v2.z) + w3 * v3.z) + w4 * v4.z);
+                acc.w = acc.w + (((w1 * v1.w + w2 * v2.w) + w3 * v3.w) + w4 * v4.w);
             }
-            out[(ph * 7 + pw) * C + c] = acc / 4.0f;
         }
+        out[idx] = make_float4(acc.x / 4.0f, acc.y / 4.0f, acc.z / 4.0f, acc.w / 4.0f);
+    }
 }
 void launch_roi_align(const RoiArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(roi_align_kernel, dim3(CALD_ROI_CAP, a.V), dim3(a.C), 0, st, a);
+    hipLaunchKernelGGL(roi_align_kernel, dim3(CALD_ROI_CAP, a.V), dim3(256), 0, st, a);
 }
 
 // ---------------------------------------------------------------------------------------------
