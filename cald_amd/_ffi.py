@@ -65,6 +65,8 @@ SIGNATURES = {
                                  C.c_int, c_f, c_f, c_f, c_f, C.c_int, c_f]),
     "cald_op_transform_size": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, c_i, c_i, c_i, c_i]),
     "cald_debug_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, c_f, C.c_int64, c_i64]),
+    "cald_jpeg_info": (C.c_int, [C.c_void_p, C.c_size_t, c_i, c_i, c_i]),
+    "cald_jpeg_decode_batch": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p)]),
     "cald_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "cald_profile_read": (C.c_int, [C.c_void_p, c_d, c_d, c_i64, c_d]),
     "cald_profile_dump": (C.c_int, [C.c_void_p, C.c_char_p]),
@@ -89,7 +91,12 @@ def lib():
     return _lib
 
 
+ERR_UNSUPPORTED = -5
+
+
 def check(rc):
+    if rc == ERR_UNSUPPORTED:
+        raise NotImplementedError("libcaldhip: %s (code %d)" % (lib().cald_last_error().decode(), rc))
     if rc != 0:
         raise RuntimeError("libcaldhip: %s (code %d)" % (lib().cald_last_error().decode(), rc))
 

@@ -25,6 +25,13 @@ static int fail(int code, const char* fmt, ...) {
 }
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(CALD_ERR_HIP, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
 
+// shared with jpeg.hip (internal, not part of the C ABI)
+int cald_internal_fail(int code, const char* fmt, ...) {
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+    return code;
+}
+hipStream_t cald_internal_stream(cald_ctx* c);
+
 extern "C" const char* cald_last_error(void) { return g_err; }
 extern "C" int cald_version(void) { return 100; }
 
@@ -53,6 +60,8 @@ struct cald_ctx {
     hipEvent_t tot0 = nullptr, tot1 = nullptr; bool tot_open = false; double tot_ms = 0.0;
     std::map<PilKey, PilCoef> pil;
 };
+
+hipStream_t cald_internal_stream(cald_ctx* c) { return c->stream; }
 
 static int arena_reserve(cald_ctx* c, size_t bytes) {
     if (bytes <= c->arena_cap) return 0;

@@ -16,6 +16,7 @@
  */
 #ifndef CALD_HIP_H
 #define CALD_HIP_H
+#include <stddef.h>
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
@@ -29,6 +30,7 @@ typedef struct cald_model cald_model;
 #define CALD_ERR_HIP (-2)
 #define CALD_ERR_STATE (-3)
 #define CALD_ERR_MISSING_WEIGHT (-4)
+#define CALD_ERR_UNSUPPORTED (-5)   /* input outside the supported set (e.g. progressive JPEG) */
 
 #define CALD_ARCH_FRCNN 0      /* detection/frcnn_la.py FRCNN_Feature */
 #define CALD_ARCH_RETINANET 1  /* detection/retinanet_cal.py RetinaNet */
@@ -139,6 +141,16 @@ int cald_op_transform_size(int H, int W, int min_size, int max_size, int* Hr, in
 /* intermediate tensors of the LAST cald_forward (parity debugging): name in
  * {"input","conv1","pool1","C2".."C5","P2".."P6","rpn0".."rpn4","proposals","roi","fc6","fc7","pred"} */
 int cald_debug_tensor(cald_model* m, const char* name, int view, float* host_out, int64_t capacity, int64_t* shape3);
+
+/* ---- input side: PIL.Image.open(path).convert('RGB') of torchvision's VOCDetection /
+ * CocoDetection __getitem__ (detection/voc_utils.py:47-58, detection/coco_utils.py; DataLoader at cald_train.py:434).
+ * Bit-identical to Pillow / libjpeg-turbo defaults (ISLOW IDCT, fancy upsampling) for 8-bit baseline Huffman JPEGs:
+ * grayscale or YCbCr 4:4:4 / 4:2:2 / 4:2:0, one interleaved scan, restart intervals allowed.  Other flavours
+ * (progressive, CMYK, ...) return CALD_ERR_UNSUPPORTED -- nothing is decoded on the CPU. ---- */
+/* host-only header parse: image size and component count */
+int cald_jpeg_info(const uint8_t* data, size_t size, int* H, int* W, int* ncomp);
+/* decodes n JPEG files (host bytes) into caller-allocated device images out_dev[i] = uint8 [H][W][3] (RGB) */
+int cald_jpeg_decode_batch(cald_ctx* ctx, int n, const uint8_t* const* data, const size_t* sizes, uint8_t* const* out_dev);
 
 /* ---- measurement: HIP-event timing of every conv/linear launch on the context stream ---- */
 int cald_profile_enable(cald_ctx* ctx, int on);

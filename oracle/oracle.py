@@ -23,8 +23,8 @@ c_u8 = C.POINTER(C.c_uint8)
 
 def build(force=False):
     so = os.path.join(_HERE, "libcald_oracle.so")
-    src = os.path.join(_HERE, "cald_oracle.c")
-    if force or not os.path.exists(so) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(so)):
+    srcs = [os.path.join(_HERE, f) for f in ("cald_oracle.c", "jpeg_oracle.c", "orc_math.h")]
+    if force or not os.path.exists(so) or any(os.path.exists(f) and os.path.getmtime(f) > os.path.getmtime(so) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "libcald_oracle.so"], stdout=subprocess.DEVNULL)
     return so
 
@@ -657,3 +657,29 @@ def ls_get_uncertainty(P, images, min_size=600, max_size=1000, base_seed=0, posi
         outs = [detector_forward(P, img, min_size, max_size, noise=noise[k]) for k in range(6)]
         res.append(ls_score_image(ref, outs))
     return res
+
+
+# ---------------------------------------------------------------------------------------------
+# JPEG decode (oracle/jpeg_oracle.c).  Returns uint8 [H][W][3] like
+# PIL.Image.open(...).convert('RGB'); raises NotImplementedError for JPEG flavours outside the
+# supported set (progressive, CMYK, 4:4:0, ...), ValueError for broken files.
+# ---------------------------------------------------------------------------------------------
+def jpeg_info(data):
+    buf = np.frombuffer(bytes(data), np.uint8)
+    H, W, nc = C.c_int(), C.c_int(), C.c_int()
+    rc = lib().orc_jpeg_info(buf.ctypes.data_as(c_u8), C.c_size_t(buf.size), C.byref(H), C.byref(W), C.byref(nc))
+    if rc == -2:
+        raise NotImplementedError("unsupported JPEG flavour")
+    if rc:
+        raise ValueError("not a decodable JPEG")
+    return H.value, W.value, nc.value
+
+
+def jpeg_decode(data):
+    H, W, _ = jpeg_info(data)
+    buf = np.frombuffer(bytes(data), np.uint8)
+    out = np.empty((H, W, 3), np.uint8)
+    rc = lib().orc_jpeg_decode(buf.ctypes.data_as(c_u8), C.c_size_t(buf.size), out.ctypes.data_as(c_u8))
+    if rc:
+        raise ValueError("JPEG decode failed (%d)" % rc)
+    return out
