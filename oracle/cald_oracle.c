@@ -202,16 +202,15 @@ ORC_API void orc_py_random(uint64_t seed, int n, double* out) {
 /* cald_helper.py:88-132 cutout: selects up to cut_num rectangles (left, top, right, bottom
  * ints).  boxes are the (sub-sampled) reference detections in ORIGINAL image coordinates.
  * Returns the number of rectangles accepted. */
-ORC_API int orc_cutout_rects(uint64_t seed, int H, int W, int N, const float* boxes, int cut_num,
-                             float remove_thres, float min_thres, int* rects) {
-    orc_mt s; mt_seed_py(&s, seed);
+static int cutout_impl(orc_mt* sp, int H, int W, int N, const float* boxes, int cut_num,
+                       float remove_thres, float min_thres, int* rects) {
     int count = 0;
     for (int t = 0; t < 50; t++) {
-        double sh = mt_uniform(&s, 0.05 * H, 0.2 * H);
-        double sw = mt_uniform(&s, 0.05 * W, 0.2 * W);
-        double left = mt_uniform(&s, 0.0, (double)W - sw);
+        double sh = mt_uniform(sp, 0.05 * H, 0.2 * H);
+        double sw = mt_uniform(sp, 0.05 * W, 0.2 * W);
+        double left = mt_uniform(sp, 0.0, (double)W - sw);
         double right = left + sw;
-        double top = mt_uniform(&s, 0.0, (double)H - sh);
+        double top = mt_uniform(sp, 0.0, (double)H - sh);
         double bottom = top + sh;
         int il = (int)left, it = (int)top, ir = (int)right, ib = (int)bottom;
         float c[4] = {(float)il, (float)it, (float)ir, (float)ib};
@@ -231,6 +230,32 @@ ORC_API int orc_cutout_rects(uint64_t seed, int H, int W, int N, const float* bo
         if (count >= cut_num) break;
     }
     return count;
+}
+ORC_API int orc_cutout_rects(uint64_t seed, int H, int W, int N, const float* boxes, int cut_num,
+                             float remove_thres, float min_thres, int* rects) {
+    orc_mt s; mt_seed_py(&s, seed);
+    return cutout_impl(&s, H, W, N, boxes, cut_num, remove_thres, min_thres, rects);
+}
+/* One Python `random` generator kept across several draws of one image (get_uncertainty calls ColorSwap's
+ * random.randint and cutout's random.uniform on the same global generator, cald_train.py:140-166). */
+ORC_API void* orc_pyrandom_new(uint64_t seed) {
+    orc_mt* s = (orc_mt*)malloc(sizeof(orc_mt));
+    mt_seed_py(s, seed);
+    return s;
+}
+ORC_API void orc_pyrandom_free(void* st) { free(st); }
+/* random.randint(0, n - 1) == randrange(n): _randbelow_with_getrandbits (k = n.bit_length(), rejection) */
+ORC_API int orc_pyrandom_randbelow(void* st, int n) {
+    int k = 0;
+    for (int t = n; t; t >>= 1) k++;
+    for (;;) {
+        const uint32_t r = mt_next((orc_mt*)st) >> (32 - k);
+        if ((int)r < n) return (int)r;
+    }
+}
+ORC_API int orc_cutout_rects_st(void* st, int H, int W, int N, const float* boxes, int cut_num,
+                                float remove_thres, float min_thres, int* rects) {
+    return cutout_impl((orc_mt*)st, H, W, N, boxes, cut_num, remove_thres, min_thres, rects);
 }
 
 /* -------------------------------------------------------------------------------------
@@ -998,4 +1023,65 @@ ORC_API void orc_gaussian_noise_seq(uint64_t seed, int n, int nseg, const float*
         }
     }
     free(u);
+}
+
+
+/* One torch CPU generator consumed by a sequence of torch.randn(n) (kind 0, scaled: * std / 255) and
+ * torch.rand(n) (kind 1) calls: get_uncertainty draws GaussianNoise and SaltPepperNoise views of one image from
+ * the same global generator, in call order (cald_train.py:127-157). */
+ORC_API void orc_torch_stream(uint64_t seed, int nops, const int* kinds, int n, const float* stds, float* out /*[nops][n]*/) {
+    orc_mt s; mt_init_genrand(&s, (uint32_t)(seed & 0xffffffffu));
+    float* u = (float*)malloc(sizeof(float) * ((size_t)n + 16));
+    for (int g = 0; g < nops; g++) {
+        float* o = out + (size_t)g * n;
+        if (kinds[g] == 1) {
+            for (int i = 0; i < n; i++) o[i] = (float)((double)(mt_next(&s) & 0xffffffu) * (1.0 / 16777216.0));
+            continue;
+        }
+        for (int i = 0; i < n; i++) u[i] = (float)((double)(mt_next(&s) & 0xffffffu) * (1.0 / 16777216.0));
+        for (int i = 0; i + 15 < n; i += 16) normal_fill_16(u + i, o + i, stds[g]);
+        if (n % 16 != 0 && n >= 16) {
+            float v[16];
+            for (int i = 0; i < 16; i++) v[i] = (float)((double)(mt_next(&s) & 0xffffffu) * (1.0 / 16777216.0));
+            normal_fill_16(v, o + n - 16, stds[g]);
+        }
+    }
+    free(u);
+}
+
+/* cald_helper.ColorAdjust (cald_helper.py:65-69): torchvision F.adjust_brightness / _contrast / _saturation on a
+ * PIL image = PIL.ImageEnhance.{Brightness, Contrast, Color}(img).enhance(factor) = Image.blend(degenerate, img,
+ * factor).  Pillow's ImagingBlend for alpha outside [0, 1]: temp = (float)(in1 + alpha * (in2 - in1)) in C float
+ * arithmetic, clipped to [0, 255] and truncated; inside [0, 1] the same expression truncated without clipping.
+ * Degenerates: black; the rounded mean of convert('L') (L = (19595 R + 38470 G + 7471 B + 0x8000) >> 16);
+ * convert('L') of the image itself. */
+static uint8_t pil_blend1(int in1, int in2, float alpha) {
+    volatile float prod = alpha * (float)(in2 - in1);
+    float temp = (float)in1 + prod;
+    if (alpha >= 0.0f && alpha <= 1.0f) return (uint8_t)temp;
+    if (temp <= 0.0f) return 0;
+    if (temp >= 255.0f) return 255;
+    return (uint8_t)temp;
+}
+static int pil_l(const uint8_t* p) { return (p[0] * 19595 + p[1] * 38470 + p[2] * 7471 + 0x8000) >> 16; }
+ORC_API void orc_color_adjust(const uint8_t* src, int H, int W, float factor, uint8_t* dst) {
+    const size_t npx = (size_t)H * W;
+    uint8_t* a = (uint8_t*)malloc(npx * 3);
+    uint8_t* b = (uint8_t*)malloc(npx * 3);
+    /* brightness */
+    if (factor == 1.0f) memcpy(a, src, npx * 3);
+    else for (size_t i = 0; i < npx * 3; i++) a[i] = factor == 0.0f ? 0 : pil_blend1(0, src[i], factor);
+    /* contrast */
+    double sum = 0.0;
+    for (size_t i = 0; i < npx; i++) sum += (double)pil_l(a + 3 * i);
+    const int mean = (int)(sum / (double)npx + 0.5);
+    if (factor == 1.0f) memcpy(b, a, npx * 3);
+    else for (size_t i = 0; i < npx * 3; i++) b[i] = factor == 0.0f ? (uint8_t)mean : pil_blend1(mean, a[i], factor);
+    /* saturation */
+    for (size_t i = 0; i < npx; i++) {
+        const int l = pil_l(b + 3 * i);
+        for (int c = 0; c < 3; c++)
+            dst[3 * i + c] = factor == 1.0f ? b[3 * i + c] : (factor == 0.0f ? (uint8_t)l : pil_blend1(l, b[3 * i + c], factor));
+    }
+    free(a); free(b);
 }

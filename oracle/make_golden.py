@@ -64,12 +64,14 @@ class FakeModel:
         self.outputs = outputs
         self.calls = 0
         self.seen = []
+        self.seen_float = []
 
     def eval(self):
         return self
 
     def __call__(self, imgs):
         self.seen.append((imgs[0].detach().clone() * 255).round().to(torch.uint8).permute(1, 2, 0).numpy())
+        self.seen_float.append(imgs[0].detach().clone().permute(1, 2, 0).numpy())
         o = self.outputs[self.calls]
         self.calls += 1
         return [{k: torch.from_numpy(v.copy()) for k, v in o.items()}]
@@ -89,17 +91,19 @@ class SeededLoader:
             yield (Image.fromarray(img),), (None,)
 
 
-def gen_scoring(ct, name, kind, C, augs, ref_counts, aug_counts, seed):
+def gen_scoring(ct, name, kind, C, augs, ref_counts, aug_counts, seed, n_views=None, sizes=((96, 128), (120, 90), (75, 100)),
+                seen_images=3, float_views=()):
     rs = np.random.RandomState(seed)
     images, outputs, per_image = [], [], []
+    n_views = len(augs) if n_views is None else n_views
     for i, nref in enumerate(ref_counts):
-        H, W = [(96, 128), (120, 90), (75, 100)][i % 3]
+        H, W = sizes[i % len(sizes)]
         img = synth_image(rs, H, W)
         images.append(img)
         ref = fake_dets(rs, nref, H, W, C, kind)
         outs = [ref]
         if nref > 0:
-            for a in range(len(augs)):
+            for a in range(n_views):
                 m = aug_counts[(i + a) % len(aug_counts)]
                 d = fake_dets(rs, m, H, W, C, kind)
                 if m and (i + a) % 4 == 1:           # an all-zero IoU row: push detections far away
@@ -122,8 +126,10 @@ def gen_scoring(ct, name, kind, C, augs, ref_counts, aug_counts, seed):
         for v in range(per_image[i]):
             for key, val in outputs[k].items():
                 blob["det%d_%d_%s" % (i, v, key)] = val
-            if i < 3:
+            if i < seen_images:
                 blob["seen%d_%d" % (i, v)] = model.seen[k]
+                if v in float_views:
+                    blob["seenf%d_%d" % (i, v)] = model.seen_float[k]
             k += 1
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **blob)
     print(name, "consistency", np.round(cons, 4))
@@ -303,6 +309,12 @@ def main():
                 [6, 0, 45, 300, 2, 80], [9, 0, 600, 3, 40], 3)
     gen_scoring(ct, "scoring_frcnn_FSCDR", "softmax", 21, ["flip", "sp", "cut_out", "smaller_resize", "rotation"],
                 [5, 0, 44, 9], [7, 0, 100, 2, 30], 6)
+    # every augmentation branch of get_uncertainty that runs in the reference (multi_color_adjust raises NameError there):
+    # 28 views per image, in the reference's order; views 1..7 are GaussianNoise (kept as float for image 0)
+    all_augs = ["flip", "ga", "multi_ga", "color_adjust", "color_swap", "sp", "multi_sp", "cut_out", "multi_cut_out",
+                "multi_resize", "larger_resize", "smaller_resize", "rotation"]
+    gen_scoring(ct, "scoring_frcnn_ALL", "softmax", 21, all_augs, [6, 0, 43], [7, 0, 60, 2, 25], 11, n_views=28,
+                sizes=((48, 64), (60, 44)), seen_images=1, float_views=tuple(range(1, 8)))
     gen_scoring(ct, "scoring_frcnn_coco_FD", "softmax", 91, ["flip", "smaller_resize"], [10, 60, 0, 2], [20, 3, 100], 4)
     gen_helpers(ch)
     gen_js()

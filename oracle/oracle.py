@@ -537,25 +537,111 @@ def image_seed(base_seed, pool_pos):
     return (int(base_seed) * 1000003 + int(pool_pos)) & 0xFFFFFFFFFFFFFFFF
 
 
-def build_views(img, augs, ref, seed):
-    """cald_train.py:123-183 for the augmentations reachable from --augs F, C, D.
-    Returns list of (src_image, flip, rects, aug_boxes)."""
-    H, W, _ = img.shape
-    views = []
-    rb = ref["boxes"]
+AUG_KINDS = ("flip", "gauss", "color_adjust", "color_swap", "salt_pepper", "cutout", "resize", "rotate")
+COLOR_PERMS = ((0, 1, 2), (0, 2, 1), (1, 0, 2), (1, 2, 0), (2, 0, 1), (2, 1, 0))     # cald_helper.py:57-58
+
+
+def expand_augs(augs):
+    """The augmented views get_uncertainty builds for a list of aug names, in ITS order (cald_train.py:123-183;
+    the order of `augs` itself is irrelevant there).  Returns [(kind, param)]."""
+    out = []
     if "flip" in augs:
-        views.append((img, True, None, flip_boxes(rb, W)))
+        out.append(("flip", 0.0))
     if "ga" in augs:
-        views.append((img, False, None, rb, gaussian_noise(seed, H, W, 16)))
+        out.append(("gauss", 16.0))
+    if "multi_ga" in augs:
+        out += [("gauss", float(i * 8)) for i in range(1, 7)]
+    if "color_adjust" in augs:
+        out.append(("color_adjust", 1.5))
+    if "color_swap" in augs:
+        out.append(("color_swap", 0.0))
+    if "multi_color_adjust" in augs:
+        raise NameError("name 'reference_boxes' is not defined")          # cald_train.py:148, as the reference does
     if "sp" in augs:
-        views.append((salt_pepper(img, 0.1, seed), False, None, rb))
+        out.append(("salt_pepper", 0.1))
+    if "multi_sp" in augs:
+        out += [("salt_pepper", i * 0.05) for i in range(1, 7)]
     if "cut_out" in augs:
-        views.append((img, False, cutout_rects(seed, H, W, rb, 2), rb))
+        out.append(("cutout", 2.0))
+    if "multi_cut_out" in augs:
+        out += [("cutout", float(i)) for i in range(1, 5)]
+    if "multi_resize" in augs:
+        out += [("resize", i * 0.1) for i in range(7, 10)]
+    if "larger_resize" in augs:
+        out.append(("resize", 1.2))
     if "smaller_resize" in augs:
-        views.append((resize_aug(img, 0.8), False, None, (f32(rb) * np.float32(0.8)).astype(np.float32)))
+        out.append(("resize", 0.8))
     if "rotation" in augs:
-        ri, rbx = rotate_aug(img, rb, 5)
-        views.append((ri, False, None, rbx))
+        out.append(("rotate", 5.0))
+    return out
+
+
+def color_adjust(img, factor):
+    """cald_helper.py:65-69 ColorAdjust on the uint8 image (PIL ImageEnhance Brightness -> Contrast -> Color)."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    out = np.empty_like(img)
+    lib().orc_color_adjust(_p(img, c_u8), C.c_int(img.shape[0]), C.c_int(img.shape[1]), C.c_float(factor), _p(out, c_u8))
+    return out
+
+
+def torch_stream(seed, n, ops):
+    """ops: [(kind 0 randn*std/255 | 1 rand, std)] drawn in order from one torch CPU generator seeded with `seed`."""
+    kinds = np.array([k for k, _ in ops], np.int32)
+    stds = f32([p for _, p in ops])
+    out = np.empty((len(ops), n), np.float32)
+    if len(ops):
+        lib().orc_torch_stream(C.c_uint64(seed), C.c_int(len(ops)), _p(kinds, c_i), C.c_int(n), _p(stds), _p(out))
+    return out
+
+
+def salt_pepper_from_uniforms(img, prob, u):
+    """cald_helper.py:78-85 given the torch.rand(3, H, W) draws `u` (CHW order)."""
+    H, W, _ = img.shape
+    noise = u.reshape(3, H, W).transpose(1, 2, 0)
+    lo, hi = np.float32(prob / 2.0), np.float32(1.0 - prob / 2.0)
+    out = img.copy()
+    mx, mn = img.max(), img.min()
+    out[noise < lo] = mx
+    out[noise > hi] = mn
+    return out
+
+
+def build_views(img, augs, ref, seed):
+    """cald_train.py:123-183.  One torch generator (GaussianNoise / SaltPepperNoise draws) and one Python `random`
+    generator (ColorSwap / cutout draws) per image, both seeded with `seed` and consumed in call order.
+    Returns list of (src_image, flip, rects, aug_boxes[, noise])."""
+    H, W, _ = img.shape
+    rb = ref["boxes"]
+    specs = expand_augs(augs)
+    ops = [((0, p) if k == "gauss" else (1, 0.0)) for k, p in specs if k in ("gauss", "salt_pepper")]
+    draws = torch_stream(seed, 3 * H * W, ops)
+    lib().orc_pyrandom_new.restype = C.c_void_p
+    st = C.c_void_p(lib().orc_pyrandom_new(C.c_uint64(seed)))
+    views, d = [], 0
+    for kind, p in specs:
+        if kind == "flip":
+            views.append((img, True, None, flip_boxes(rb, W)))
+        elif kind == "gauss":
+            views.append((img, False, None, rb, draws[d].reshape(3, H, W))); d += 1
+        elif kind == "color_adjust":
+            views.append((color_adjust(img, p), False, None, rb))
+        elif kind == "color_swap":
+            perm = COLOR_PERMS[lib().orc_pyrandom_randbelow(st, C.c_int(6))]
+            views.append((np.ascontiguousarray(img[:, :, list(perm)]), False, None, rb))
+        elif kind == "salt_pepper":
+            views.append((salt_pepper_from_uniforms(img, p, draws[d]), False, None, rb)); d += 1
+        elif kind == "cutout":
+            b = f32(rb).reshape(-1, 4)
+            rects = np.zeros((4, 4), np.int32)
+            n = lib().orc_cutout_rects_st(st, C.c_int(H), C.c_int(W), C.c_int(b.shape[0]), _p(b), C.c_int(int(p)),
+                                          C.c_float(0.4), C.c_float(0.1), _p(rects, c_i))
+            views.append((img, False, rects[:n].copy(), rb))
+        elif kind == "resize":
+            views.append((resize_aug(img, p), False, None, (f32(rb) * np.float32(p)).astype(np.float32)))
+        elif kind == "rotate":
+            ri, rbx = rotate_aug(img, rb, p)
+            views.append((ri, False, None, rbx))
+    lib().orc_pyrandom_free(st)
     return views
 
 

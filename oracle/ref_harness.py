@@ -55,6 +55,15 @@ def _to_pil_image(t):
     return Image.fromarray(np.ascontiguousarray(arr))
 
 
+def _adjust(kind):
+    """torchvision.transforms.functional.adjust_{brightness,contrast,saturation} for PIL input are one-liners over
+    PIL.ImageEnhance (functional_pil.py); restated here because torchvision is not installed."""
+    def f(img, factor):
+        from PIL import ImageEnhance
+        return getattr(ImageEnhance, kind)(img).enhance(factor)
+    return f
+
+
 def install_stubs():
     import torch
 
@@ -103,6 +112,9 @@ def install_stubs():
     mods["torchvision.datasets.coco"].CocoDetection = object
     mods["torchvision.transforms.functional"].to_tensor = _to_tensor
     mods["torchvision.transforms.functional"].to_pil_image = _to_pil_image
+    mods["torchvision.transforms.functional"].adjust_brightness = _adjust("Brightness")
+    mods["torchvision.transforms.functional"].adjust_contrast = _adjust("Contrast")
+    mods["torchvision.transforms.functional"].adjust_saturation = _adjust("Color")
     mods["torch._six"].string_classes = (str,)
     mods["torch._six"].container_abcs = importlib.import_module("collections.abc")
     mods["torch._six"].int_classes = (int,)
