@@ -172,7 +172,7 @@ def main():
             "config": {"workload": ("BASELINE.json configs[1]: Faster R-CNN ResNet-50 FPN, VOC2012-shaped synthetic pool, "
                                     "3 augs (flip/cut_out/smaller_resize), 21 classes, min/max 600/1000, seeded pseudo-trained weights")
                        if headline else "informational: model=%s shape=%s augs=%s classes=%d min/max %d/%d" % (args.model, args.shape, args.augs, ncls, mn, mx),
-                       "images_per_step_per_gpu": B, "views_per_image": 1 + len(augs), "parallelism": "pool sharded by position, dp%d" % world},
+                       "images_per_step_per_gpu": B, "views_per_image": 1 + len(sweep.expand_augs(augs)), "parallelism": "pool sharded by position, dp%d" % world},
             "roofline": {"bound": "mfma", "kernel": "conv_p4_kernel + conv_mfma_f32_kernel (implicit-GEMM conv + linear, v_mfma_f32_32x32x2_f32)",
                          "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,

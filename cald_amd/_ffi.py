@@ -36,10 +36,17 @@ class Dets(C.Structure):
                 ("count_dev", C.c_void_p), ("cap", C.c_int)]
 
 
+MAX_AUGS = 32
+AUG_FLIP, AUG_GAUSS, AUG_COLOR_ADJUST, AUG_COLOR_SWAP, AUG_SALT_PEPPER, AUG_CUTOUT, AUG_RESIZE, AUG_ROTATE = range(1, 9)
+
+
+class AugSpec(C.Structure):
+    _fields_ = [("kind", C.c_int), ("param", C.c_double)]
+
+
 class SweepCfg(C.Structure):
-    _fields_ = [("aug_flip", C.c_int), ("aug_cutout", C.c_int), ("aug_resize", C.c_int), ("resize_ratio", C.c_float),
-                ("base_seed", C.c_uint64), ("bp", C.c_float), ("batch_images", C.c_int), ("aug_sp", C.c_int), ("sp_prob", C.c_float),
-                ("aug_rotate", C.c_int), ("rotate_angle", C.c_float), ("aug_ga", C.c_int), ("ga_std", C.c_float)]
+    _fields_ = [("base_seed", C.c_uint64), ("bp", C.c_float), ("batch_images", C.c_int), ("n_augs", C.c_int),
+                ("augs", AugSpec * MAX_AUGS)]
 
 
 # name -> (restype, argtypes): must list every symbol of include/cald_hip.h

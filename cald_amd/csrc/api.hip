@@ -917,8 +917,18 @@ extern "C" int cald_sweep(cald_model* m, int n_images, const uint8_t* const* ima
     cald_ctx* c = m->ctx;
     HIPCHK(hipSetDevice(c->device));
     const int C = m->cfg.num_classes, cap = m->det_cap();
-    const int A = (cfg->aug_flip ? 1 : 0) + (cfg->aug_ga ? 1 : 0) + (cfg->aug_sp ? 1 : 0) + (cfg->aug_cutout ? 1 : 0) + (cfg->aug_resize ? 1 : 0) +
-                  (cfg->aug_rotate ? 1 : 0);
+    const int A = cfg->n_augs;
+    if (A < 0 || A > CALD_MAX_AUGS) return fail(CALD_ERR_INVALID, "n_augs %d outside [0, %d]", A, CALD_MAX_AUGS);
+    int n_noise = 0;
+    for (int a = 0; a < A; a++) {
+        const int k = cfg->augs[a].kind;
+        if (k < CALD_AUG_FLIP || k > CALD_AUG_ROTATE) return fail(CALD_ERR_INVALID, "augmentation %d: unknown kind %d", a, k);
+        if (k == CALD_AUG_CUTOUT && (cfg->augs[a].param < 1.0 || cfg->augs[a].param > (double)CALD_MAX_CUT))
+            return fail(CALD_ERR_INVALID, "cutout: cut_num must be in [1, %d]", CALD_MAX_CUT);
+        if (k == CALD_AUG_RESIZE && !(cfg->augs[a].param > 0.0)) return fail(CALD_ERR_INVALID, "resize: ratio must be positive");
+        n_noise += (k == CALD_AUG_GAUSS || k == CALD_AUG_SALT_PEPPER);
+    }
+    if (n_noise > CALD_MAX_NOISE_SEG) return fail(CALD_ERR_INVALID, "at most %d GaussianNoise / SaltPepperNoise views per image", CALD_MAX_NOISE_SEG);
     int B = cfg->batch_images > 0 ? cfg->batch_images : 64;
     if (B > CALD_MAX_VIEWS) B = CALD_MAX_VIEWS;
     const int VT = B * (1 + A);
@@ -930,18 +940,18 @@ extern "C" int cald_sweep(cald_model* m, int n_images, const uint8_t* const* ima
     DetBuffers& D = m->sweep_det;
     // small device scratch for the scoring stage + an arena for augmented uint8 images
     int *d_ints = nullptr; float *d_par = nullptr, *d_cons = nullptr, *d_clsc = nullptr;
-    SaltPepperJob* d_jobs = nullptr; GaussJob* d_gjobs = nullptr;
+    NoiseJob* d_jobs = nullptr; unsigned long long* d_lsum = nullptr;
     const int P_MAX = B * (A > 0 ? A : 1);
     const size_t n_ints = (size_t)P_MAX * 4 + (size_t)B * 51 + (size_t)VT * 2;
     HIPCHK(hipMalloc((void**)&d_ints, n_ints * 4)); HIPCHK(hipMalloc((void**)&d_par, (size_t)P_MAX * 12 * 4));
     HIPCHK(hipMalloc((void**)&d_cons, (size_t)P_MAX * 4)); HIPCHK(hipMalloc((void**)&d_clsc, (size_t)VT * (C - 1) * 4));
-    HIPCHK(hipMalloc((void**)&d_jobs, sizeof(SaltPepperJob) * B)); HIPCHK(hipMalloc((void**)&d_gjobs, sizeof(GaussJob) * B));
+    HIPCHK(hipMalloc((void**)&d_jobs, sizeof(NoiseJob) * B)); HIPCHK(hipMalloc((void**)&d_lsum, sizeof(unsigned long long) * P_MAX));
     uint8_t* d_aug = nullptr; size_t aug_cap = 0;
     int rc = 0;
     std::vector<int> h_count(VT); std::vector<float> h_boxes((size_t)B * cap * 4), h_cons(P_MAX), h_clsc((size_t)VT * (C - 1));
     auto cleanup = [&]() {
         hipStreamSynchronize(c->stream);
-        hipFree(d_ints); hipFree(d_par); hipFree(d_cons); hipFree(d_clsc); hipFree(d_jobs); hipFree(d_gjobs); hipFree(d_aug);
+        hipFree(d_ints); hipFree(d_par); hipFree(d_cons); hipFree(d_clsc); hipFree(d_jobs); hipFree(d_lsum); hipFree(d_aug);
     };
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     for (int i0 = 0; i0 < n_images && !rc; i0 += B) {
@@ -961,22 +971,28 @@ extern "C" int cald_sweep(cald_model* m, int n_images, const uint8_t* const* ima
         std::vector<int> ref_sel((size_t)B * 50, 0), ref_n(B, 0), pair_ref, pair_aug, pair_kind, pair_img, view_img(VT, 0), view_isref(VT, 0);
         std::vector<float> pair_par;
         std::vector<ViewDesc> aviews;
-        std::vector<SaltPepperJob> jobs; std::vector<GaussJob> gjobs;
+        std::vector<NoiseJob> jobs;
         size_t need = 0;
         for (int i = 0; i < nb; i++) {
             if (h_count[i] == 0) continue;
             const int Hi = H[i0 + i], Wi = W[i0 + i];
-            if (cfg->aug_sp) need += al((size_t)Hi * Wi * 3);
-            if (cfg->aug_ga) need += al((size_t)Hi * Wi * 3 * sizeof(float));
-            if (cfg->aug_resize) {
-                const int ow = (int)((double)Wi * (double)cfg->resize_ratio), oh = (int)((double)Hi * (double)cfg->resize_ratio);
-                need += al((size_t)oh * ow * 3) + al((size_t)Hi * ow * 3);
+            for (int a = 0; a < A; a++) {
+                const int k = cfg->augs[a].kind; const double prm = cfg->augs[a].param;
+                if (k == CALD_AUG_SALT_PEPPER) need += al((size_t)Hi * Wi * 3);
+                else if (k == CALD_AUG_GAUSS) need += al((size_t)Hi * Wi * 3 * sizeof(float));
+                else if (k == CALD_AUG_COLOR_ADJUST) need += 2 * al((size_t)Hi * Wi * 3);
+                else if (k == CALD_AUG_RESIZE) {
+                    const int ow = (int)((double)Wi * prm), oh = (int)((double)Hi * prm);
+                    if (ow < 1 || oh < 1) { rc = fail(CALD_ERR_INVALID, "resize ratio %g empties a %dx%d image", prm, Hi, Wi); break; }
+                    need += al((size_t)oh * ow * 3) + al((size_t)Hi * ow * 3);
+                } else if (k == CALD_AUG_ROTATE) {
+                    int fx[6], nh, nw; pil_rotate_setup(Hi, Wi, prm, fx, &nh, &nw);
+                    need += al((size_t)nh * nw * 3) + al((size_t)nh * Wi * 3) + al((size_t)Hi * Wi * 3);
+                }
             }
-            if (cfg->aug_rotate) {
-                int fx[6], nh, nw; pil_rotate_setup(Hi, Wi, (double)cfg->rotate_angle, fx, &nh, &nw);
-                need += al((size_t)nh * nw * 3) + al((size_t)nh * Wi * 3) + al((size_t)Hi * Wi * 3);
-            }
+            if (rc) break;
         }
+        if (rc) break;
         if (need > aug_cap) {
             if (d_aug) hipFree(d_aug);
             d_aug = nullptr; aug_cap = 0;
@@ -1002,51 +1018,54 @@ extern "C" int cald_sweep(cald_model* m, int n_images, const uint8_t* const* ima
                 for (int q = 0; q < 12; q++) pair_par.push_back(par ? par[q] : 0.0f);
             };
             ViewDesc base; memset(&base, 0, sizeof(base)); base.src = images_dev[i0 + i]; base.H = Hi; base.W = Wi;
-            float par[12] = {0};
-            if (cfg->aug_flip) { ViewDesc v = base; v.flip = 1; par[0] = (float)Wi; add_view(v, 1, par); }
-            if (cfg->aug_ga) {     // GaussianNoise(image, 16), cald_train.py:128-131; torch.randn stream re-seeded per image
-                GaussJob gj; gj.dst = reinterpret_cast<float*>(take((size_t)Hi * Wi * 3 * sizeof(float))); gj.n = Hi * Wi * 3; gj.nseg = 1; gj.seed = seed; memset(gj.stds, 0, sizeof(gj.stds)); gj.stds[0] = cfg->ga_std;
-                gjobs.push_back(gj);
-                ViewDesc v = base; v.noise = gj.dst; add_view(v, 0, nullptr);
+            PyRandom pyrng; pyrng.seed(seed);          // ColorSwap's randint and every cutout of this image, in call order
+            NoiseJob nj; memset(&nj, 0, sizeof(nj)); nj.seed = seed; nj.src = images_dev[i0 + i]; nj.H = Hi; nj.W = Wi;
+            for (int a = 0; a < A && !rc; a++) {
+                const int k = cfg->augs[a].kind; const double prm = cfg->augs[a].param;
+                float par[12] = {0};
+                if (k == CALD_AUG_FLIP) { ViewDesc v = base; v.flip = 1; par[0] = (float)Wi; add_view(v, 1, par); }
+                else if (k == CALD_AUG_GAUSS) {            // image + torch.randn(size) * std / 255.0
+                    NoiseSeg& sg = nj.seg[nj.nseg++]; sg.kind = 0; sg.p0 = (float)prm; sg.p1 = 0.0f;
+                    sg.dst = take((size_t)Hi * Wi * 3 * sizeof(float));
+                    ViewDesc v = base; v.noise = reinterpret_cast<const float*>(sg.dst); add_view(v, 0, nullptr);
+                } else if (k == CALD_AUG_SALT_PEPPER) {    // noise = torch.rand(size); < prob/2 -> max, > 1 - prob/2 -> min
+                    NoiseSeg& sg = nj.seg[nj.nseg++]; sg.kind = 1; sg.p0 = (float)(prm / 2.0); sg.p1 = (float)(1.0 - prm / 2.0);
+                    sg.dst = take((size_t)Hi * Wi * 3);
+                    ViewDesc v = base; v.src = reinterpret_cast<const uint8_t*>(sg.dst); add_view(v, 0, nullptr);
+                } else if (k == CALD_AUG_COLOR_ADJUST) {
+                    uint8_t* tmp = take((size_t)Hi * Wi * 3); uint8_t* dst = take((size_t)Hi * Wi * 3);
+                    launch_color_adjust(images_dev[i0 + i], Hi, Wi, (float)prm, tmp, d_lsum + pair_ref.size(), dst, c->stream);
+                    ViewDesc v = base; v.src = dst; add_view(v, 0, nullptr);
+                } else if (k == CALD_AUG_COLOR_SWAP) {
+                    ViewDesc v = base; v.swap = pyrng.randbelow(6); add_view(v, 0, nullptr);
+                } else if (k == CALD_AUG_CUTOUT) {
+                    ViewDesc v = base;
+                    v.nrect = cutout_rects(pyrng, Hi, Wi, ref_n[i], sub, (int)prm, v.rects);
+                    add_view(v, 0, nullptr);
+                } else if (k == CALD_AUG_RESIZE) {
+                    const int ow = (int)((double)Wi * prm), oh = (int)((double)Hi * prm);
+                    uint8_t* dst = take((size_t)oh * ow * 3); uint8_t* tmp = take((size_t)Hi * ow * 3);
+                    if ((rc = pil_resize(c, images_dev[i0 + i], Hi, Wi, dst, oh, ow, tmp, 0))) break;
+                    ViewDesc v; memset(&v, 0, sizeof(v)); v.src = dst; v.H = oh; v.W = ow;
+                    par[0] = (float)prm; add_view(v, 2, par);          // boxes * ratio: float32 tensor times the scalar
+                } else if (k == CALD_AUG_ROTATE) {
+                    int fx[6], nh, nw; pil_rotate_setup(Hi, Wi, prm, fx, &nh, &nw);
+                    uint8_t* rot = take((size_t)nh * nw * 3); uint8_t* tmp = take((size_t)nh * Wi * 3); uint8_t* dst = take((size_t)Hi * Wi * 3);
+                    launch_affine_nearest(images_dev[i0 + i], Hi, Wi, rot, nh, nw, fx, c->stream);
+                    if ((rc = pil_resize(c, rot, nh, nw, dst, Hi, Wi, tmp, 1))) break;      // new_image.resize((w, h)): BICUBIC default
+                    ViewDesc v = base; v.src = dst;
+                    rotate_box_params(Hi, Wi, prm, nw, nh, par);
+                    add_view(v, 3, par);
+                }
             }
-            if (cfg->aug_sp) {     // SaltPepperNoise(image, 0.1), cald_train.py:150-153; torch.rand stream re-seeded per image
-                SaltPepperJob j; j.src = images_dev[i0 + i]; j.dst = take((size_t)Hi * Wi * 3); j.H = Hi; j.W = Wi; j.seed = seed;
-                j.lo = (float)((double)cfg->sp_prob / 2.0); j.hi = (float)(1.0 - (double)cfg->sp_prob / 2.0);
-                jobs.push_back(j);
-                ViewDesc v = base; v.src = j.dst; add_view(v, 0, nullptr);
-            }
-            if (cfg->aug_cutout) {
-                ViewDesc v = base;
-                v.nrect = cutout_rects(seed, Hi, Wi, ref_n[i], sub, 2, v.rects);
-                add_view(v, 0, nullptr);
-            }
-            if (cfg->aug_resize) {
-                const int ow = (int)((double)Wi * (double)cfg->resize_ratio), oh = (int)((double)Hi * (double)cfg->resize_ratio);
-                uint8_t* dst = take((size_t)oh * ow * 3); uint8_t* tmp = take((size_t)Hi * ow * 3);
-                if ((rc = pil_resize(c, images_dev[i0 + i], Hi, Wi, dst, oh, ow, tmp, 0))) break;
-                ViewDesc v; memset(&v, 0, sizeof(v)); v.src = dst; v.H = oh; v.W = ow;
-                par[0] = cfg->resize_ratio; add_view(v, 2, par);
-            }
-            if (cfg->aug_rotate) {   // rotate(image, ref_boxes, 5), cald_train.py:180-183
-                int fx[6], nh, nw; pil_rotate_setup(Hi, Wi, (double)cfg->rotate_angle, fx, &nh, &nw);
-                uint8_t* rot = take((size_t)nh * nw * 3); uint8_t* tmp = take((size_t)nh * Wi * 3); uint8_t* dst = take((size_t)Hi * Wi * 3);
-                launch_affine_nearest(images_dev[i0 + i], Hi, Wi, rot, nh, nw, fx, c->stream);
-                if ((rc = pil_resize(c, rot, nh, nw, dst, Hi, Wi, tmp, 1))) break;      // new_image.resize((w, h)): BICUBIC default
-                ViewDesc v = base; v.src = dst;
-                rotate_box_params(Hi, Wi, (double)cfg->rotate_angle, nw, nh, par);
-                add_view(v, 3, par);
-            }
+            if (rc) break;
+            if (nj.nseg) jobs.push_back(nj);
         }
         if (rc) break;
         if (!jobs.empty()) {
-            if (hipMemcpyAsync(d_jobs, jobs.data(), sizeof(SaltPepperJob) * jobs.size(), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
-                hipStreamSynchronize(c->stream) != hipSuccess) { rc = fail(CALD_ERR_HIP, "H2D of salt-pepper jobs failed"); break; }
-            launch_salt_pepper(d_jobs, (int)jobs.size(), c->stream);
-        }
-        if (!gjobs.empty()) {
-            if (hipMemcpyAsync(d_gjobs, gjobs.data(), sizeof(GaussJob) * gjobs.size(), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
-                hipStreamSynchronize(c->stream) != hipSuccess) { rc = fail(CALD_ERR_HIP, "H2D of gaussian-noise jobs failed"); break; }
-            launch_gauss_noise(d_gjobs, (int)gjobs.size(), c->stream);
+            if (hipMemcpyAsync(d_jobs, jobs.data(), sizeof(NoiseJob) * jobs.size(), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+                hipStreamSynchronize(c->stream) != hipSuccess) { rc = fail(CALD_ERR_HIP, "H2D of noise jobs failed"); break; }
+            launch_noise_stream(d_jobs, (int)jobs.size(), c->stream);
         }
         if (rc) break;
         // ---- phase 2: augmented views (chunks of <= 64) ----
@@ -1153,10 +1172,10 @@ extern "C" int cald_sweep_lsc(cald_model* m, int n_images, const uint8_t* const*
         m->sweep_det_views = VT;
     }
     DetBuffers& D = m->sweep_det;
-    int* d_ints = nullptr; float *d_par = nullptr, *d_rows = nullptr; GaussJob* d_gjobs = nullptr; float* d_noise = nullptr; size_t noise_cap = 0;
+    int* d_ints = nullptr; float *d_par = nullptr, *d_rows = nullptr; NoiseJob* d_gjobs = nullptr; float* d_noise = nullptr; size_t noise_cap = 0;
     const size_t n_ints = (size_t)P_MAX * 4 + (size_t)B * 51;
     HIPCHK(hipMalloc((void**)&d_ints, n_ints * 4)); HIPCHK(hipMalloc((void**)&d_par, (size_t)P_MAX * 12 * 4));
-    HIPCHK(hipMalloc((void**)&d_rows, (size_t)P_MAX * 50 * 4)); HIPCHK(hipMalloc((void**)&d_gjobs, sizeof(GaussJob) * B));
+    HIPCHK(hipMalloc((void**)&d_rows, (size_t)P_MAX * 50 * 4)); HIPCHK(hipMalloc((void**)&d_gjobs, sizeof(NoiseJob) * B));
     HIPCHK(hipMemset(d_par, 0, (size_t)P_MAX * 12 * 4));
     std::vector<int> h_count(VT); std::vector<float> h_pm((size_t)B * cap), h_rows((size_t)P_MAX * 50);
     int rc = 0;
@@ -1170,7 +1189,7 @@ extern "C" int cald_sweep_lsc(cald_model* m, int n_images, const uint8_t* const*
             hipStreamSynchronize(c->stream) != hipSuccess) { rc = fail(CALD_ERR_HIP, "D2H of reference detections failed"); break; }
         // host: top-30 by prob_max (value desc, index asc), noise jobs, views
         std::vector<int> ref_sel((size_t)B * 50, 0), ref_n(B, 0), pair_ref, pair_aug, pair_img;
-        std::vector<ViewDesc> aviews; std::vector<GaussJob> gjobs;
+        std::vector<ViewDesc> aviews; std::vector<NoiseJob> gjobs;
         size_t need = 0;
         for (int i = 0; i < nb; i++) if (h_count[i] > 0) need += ((size_t)H[i0 + i] * W[i0 + i] * 3 * A * 4 + 255) & ~(size_t)255;
         if (need > noise_cap) { if (d_noise) hipFree(d_noise); d_noise = nullptr; noise_cap = 0;
@@ -1188,20 +1207,21 @@ extern "C" int cald_sweep_lsc(cald_model* m, int n_images, const uint8_t* const*
             ref_n[i] = (int)idx.size();
             for (size_t k = 0; k < idx.size(); k++) ref_sel[(size_t)i * 50 + k] = idx[k];
             const int Hi = H[i0 + i], Wi = W[i0 + i], ne = Hi * Wi * 3;
-            GaussJob gj; gj.dst = reinterpret_cast<float*>(reinterpret_cast<char*>(d_noise) + noff); noff += ((size_t)ne * A * 4 + 255) & ~(size_t)255;
-            gj.n = ne; gj.nseg = A; gj.seed = (uint64_t)base_seed * 1000003ull + (uint64_t)pool_pos[i0 + i];
-            memset(gj.stds, 0, sizeof(gj.stds)); for (int k = 0; k < A; k++) gj.stds[k] = 8.0f * (float)(k + 1);
+            float* nbase = reinterpret_cast<float*>(reinterpret_cast<char*>(d_noise) + noff); noff += ((size_t)ne * A * 4 + 255) & ~(size_t)255;
+            NoiseJob gj; memset(&gj, 0, sizeof(gj));
+            gj.src = images_dev[i0 + i]; gj.H = Hi; gj.W = Wi; gj.nseg = A; gj.seed = (uint64_t)base_seed * 1000003ull + (uint64_t)pool_pos[i0 + i];
+            for (int k = 0; k < A; k++) { gj.seg[k].kind = 0; gj.seg[k].p0 = 8.0f * (float)(k + 1); gj.seg[k].dst = nbase + (size_t)k * ne; }
             gjobs.push_back(gj);
             for (int k = 0; k < A; k++) {
-                ViewDesc v; memset(&v, 0, sizeof(v)); v.src = images_dev[i0 + i]; v.H = Hi; v.W = Wi; v.noise = gj.dst + (size_t)k * ne;
+                ViewDesc v; memset(&v, 0, sizeof(v)); v.src = images_dev[i0 + i]; v.H = Hi; v.W = Wi; v.noise = nbase + (size_t)k * ne;
                 pair_ref.push_back(i); pair_aug.push_back(nb + (int)aviews.size()); pair_img.push_back(i);
                 aviews.push_back(v);
             }
         }
         if (!gjobs.empty()) {
-            if (hipMemcpyAsync(d_gjobs, gjobs.data(), sizeof(GaussJob) * gjobs.size(), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+            if (hipMemcpyAsync(d_gjobs, gjobs.data(), sizeof(NoiseJob) * gjobs.size(), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
                 hipStreamSynchronize(c->stream) != hipSuccess) { rc = fail(CALD_ERR_HIP, "H2D of gaussian-noise jobs failed"); break; }
-            launch_gauss_noise(d_gjobs, (int)gjobs.size(), c->stream);
+            launch_noise_stream(d_gjobs, (int)gjobs.size(), c->stream);
         }
         const int na = (int)aviews.size();
         for (int a0 = 0; a0 < na && !rc; a0 += CALD_MAX_VIEWS) {

@@ -13,6 +13,13 @@
 // resize (align_corners=False, scale=in/out) -> zero pad to a multiple of 32.  NHWC, 4 channels.
 // grid = (ceil(maxHp*maxWp/256), V)
 // ---------------------------------------------------------------------------------------------
+// cald_helper.ColorSwap (cald_helper.py:56-62): image[perms[k]] -> output channel c reads source channel perms[k][c]
+__device__ inline int color_perm(int k, int c) {
+    // perms = ((0,1,2), (0,2,1), (1,0,2), (1,2,0), (2,0,1), (2,1,0)), packed 2 bits per entry
+    const unsigned packed[6] = {0u | (1u << 2) | (2u << 4), 0u | (2u << 2) | (1u << 4), 1u | (0u << 2) | (2u << 4),
+                                1u | (2u << 2) | (0u << 4), 2u | (0u << 2) | (1u << 4), 2u | (1u << 2) | (0u << 4)};
+    return (int)((packed[k] >> (2 * c)) & 3u);
+}
 __global__ __launch_bounds__(256) void preprocess_kernel(const ViewDesc* views, const LevelSeg* seg0, float* out) {
     const int v = blockIdx.y;
     const ViewDesc& vd = views[v];   // by reference: a by-value copy puts rects[] (dynamically indexed) in scratch
@@ -23,7 +30,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const ViewDesc* views, 
     const int y = pix / Wp, x = pix - y * Wp;
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
     if (y < vd.Hr && x < vd.Wr) {
-        const int H = vd.H, W = vd.W;
+        const int H = vd.H, W = vd.W, swap = vd.swap;
         const float sh = (float)H / (float)vd.Hr, sw = (float)W / (float)vd.Wr;
         float fy = sh * ((float)y + 0.5f) - 0.5f; if (fy < 0.0f) fy = 0.0f;
         float fx = sw * ((float)x + 0.5f) - 0.5f; if (fx < 0.0f) fx = 0.0f;
@@ -47,7 +54,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const ViewDesc* views, 
                 const uint8_t* p = vd.src + ((long long)yy * W + sx) * 3;
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
-                    float u = cut ? 0.0f : (float)p[c] / 255.0f;
+                    float u = cut ? 0.0f : (float)p[color_perm(swap, c)] / 255.0f;
                     if (vd.noise) u = u + vd.noise[((long long)c * H + yy) * W + sx];
                     val[a][b][c] = (u - mean[c]) / stdv[c];
                 }
@@ -187,69 +194,15 @@ void launch_affine_nearest(const uint8_t* src, int H, int W, uint8_t* dst, int o
 }
 
 // ---------------------------------------------------------------------------------------------
-// cald_helper.SaltPepperNoise on the uint8 image, with torch's CPU random stream reproduced on the
-// device: one workgroup per image runs MT19937 (seeded like torch.manual_seed: init_genrand(seed))
-// in LDS -- the 624-word twist is done in three dependency-free phases (k < 227, < 454, < 624) --
-// and applies  u < prob/2 -> max(image),  u > 1 - prob/2 -> min(image)  in to_tensor's CHW order.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void salt_pepper_kernel(const SaltPepperJob* jobs) {
-    __shared__ unsigned mt[624];
-    __shared__ int s_mx, s_mn;
-    const SaltPepperJob j = jobs[blockIdx.x];
-    const int tid = threadIdx.x;
-    const long long n = (long long)j.H * j.W * 3;
-    if (tid == 0) { s_mx = 0; s_mn = 255; }
-    __syncthreads();
-    int mx = 0, mn = 255;
-    for (long long i = tid; i < n; i += 256) { const int v = j.src[i]; mx = v > mx ? v : mx; mn = v < mn ? v : mn; }
-    atomicMax(&s_mx, mx); atomicMin(&s_mn, mn);
-    if (tid == 0) {
-        unsigned x = (unsigned)(j.seed & 0xffffffffull);
-        mt[0] = x;
-        for (int i = 1; i < 624; i++) { x = 1812433253u * (x ^ (x >> 30)) + (unsigned)i; mt[i] = x; }
-    }
-    __syncthreads();
-    const uint8_t vmax = (uint8_t)s_mx, vmin = (uint8_t)s_mn;
-    const long long plane = (long long)j.H * j.W;
-    for (long long base = 0; base < n; base += 624) {
-        // twist: new[k] = old[k+397 mod 624] ^ f(old[k], old[k+1]); phases keep every read well-defined
-        for (int ph = 0; ph < 3; ph++) {
-            const int lo = ph == 0 ? 0 : (ph == 1 ? 227 : 454), hi = ph == 0 ? 227 : (ph == 1 ? 454 : 624);
-            unsigned nv = 0; int k = lo + tid;
-            if (k < hi) {
-                const unsigned y = (mt[k] & 0x80000000u) | (mt[(k + 1) % 624] & 0x7fffffffu);
-                nv = mt[(k + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-            }
-            __syncthreads();
-            if (k < hi) mt[k] = nv;
-            __syncthreads();
-        }
-        for (int t = tid; t < 624; t += 256) {
-            const long long e = base + t;
-            if (e >= n) break;
-            unsigned y = mt[t];
-            y ^= (y >> 11); y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= (y >> 18);
-            const float u = (float)((double)(y & 0xffffffu) * (1.0 / 16777216.0));
-            const int c = (int)(e / plane);
-            const long long pix = e - (long long)c * plane;
-            const long long o = pix * 3 + c;
-            uint8_t v = j.src[o];
-            if (u < j.lo) v = vmax;
-            if (u > j.hi) v = vmin;
-            j.dst[o] = v;
-        }
-        __syncthreads();
-    }
-}
-void launch_salt_pepper(const SaltPepperJob* jobs, int n, hipStream_t st) {
-    if (n > 0) hipLaunchKernelGGL(salt_pepper_kernel, dim3(n), dim3(256), 0, st, jobs);
-}
-
-// ---------------------------------------------------------------------------------------------
-// cald_helper.GaussianNoise: the additive term torch.randn(3, H, W) * std / 255.0, generated on the
-// device from torch's CPU stream: MT19937 uniforms, Box-Muller per 16-chunk (elements j, j+8 pair
-// up; 624 = 39 * 16 so chunks never straddle a twist), and the "last 16 from 16 NEW uniforms" tail
-// when the size is not a multiple of 16.  One workgroup per image.
+// cald_helper.GaussianNoise / SaltPepperNoise views of ONE image, drawn from ONE torch CPU generator in call order
+// (get_uncertainty, cald_train.py:127-157; ls_c_train.py:129-131).  One workgroup per image runs MT19937 (seeded like
+// torch.manual_seed: init_genrand(seed)) in LDS -- the 624-word twist is done in three dependency-free phases
+// (k < 227, < 454, < 624) -- and keeps the tempered 24-bit uniforms of the last two twists in an LDS ring.
+//   kind 0  torch.randn(3, H, W) * std / 255.0 (additive term, CHW float): uniforms -> Box-Muller per 16-chunk
+//           (elements j, j + 8 pair up), and the "last 16 from 16 NEW uniforms" tail when the size is not a multiple
+//           of 16; consumes n (+16) draws.  A chunk is transformed as soon as the twist holding its last draw exists.
+//   kind 1  torch.rand(3, H, W) (CHW): u < prob/2 -> max(image), u > 1 - prob/2 -> min(image) on the uint8 image;
+//           consumes n draws.
 // ---------------------------------------------------------------------------------------------
 __device__ inline unsigned mt_temper(unsigned y) {
     y ^= (y >> 11); y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= (y >> 18);
@@ -264,26 +217,39 @@ __device__ inline void box_muller_pair(float ua, float ub, float std, float* oa,
     *oa = ((radius * cs) * std) / 255.0f;
     *ob = ((radius * sn) * std) / 255.0f;
 }
-__global__ __launch_bounds__(256) void gauss_noise_kernel(const GaussJob* jobs) {
-    // nseg consecutive torch.randn(n) calls on one generator: the draw stream of segment g starts at
-    // g * (n + (n % 16 ? 16 : 0)).  Tempered uniforms of the last two twists are kept in an LDS ring, and a
-    // 16-draw chunk is transformed as soon as the twist holding its last draw is available.
+__global__ __launch_bounds__(256) void noise_stream_kernel(const NoiseJob* jobs) {
     __shared__ unsigned mt[624];
     __shared__ float ring[2][624];
-    const GaussJob j = jobs[blockIdx.x];
+    __shared__ long long seg_start[CALD_MAX_NOISE_SEG + 1];
+    __shared__ int s_mx, s_mn;
+    const NoiseJob& j = jobs[blockIdx.x];
     const int tid = threadIdx.x;
-    const long long n = j.n;
+    const long long n = (long long)j.H * j.W * 3, plane = (long long)j.H * j.W;
+    const long long rem = n % 16, ncs = n / 16;                       // standard chunks per randn segment
+    const int nseg = j.nseg;
     if (tid == 0) {
         unsigned x = (unsigned)(j.seed & 0xffffffffull);
         mt[0] = x;
         for (int i = 1; i < 624; i++) { x = 1812433253u * (x ^ (x >> 30)) + (unsigned)i; mt[i] = x; }
+        long long d = 0;
+        for (int g = 0; g < nseg; g++) { seg_start[g] = d; d += n + ((j.seg[g].kind == 0 && rem && n >= 16) ? 16 : 0); }
+        seg_start[nseg] = d;
+        s_mx = 0; s_mn = 255;
     }
     __syncthreads();
-    const long long rem = n % 16, ncs = n / 16;                       // standard chunks per segment
-    const long long seg_draws = n + ((rem && n >= 16) ? 16 : 0);
-    const long long total = seg_draws * j.nseg;
+    bool any_sp = false;
+    for (int g = 0; g < nseg; g++) any_sp |= j.seg[g].kind == 1;
+    if (any_sp) {
+        int mx = 0, mn = 255;
+        for (long long i = tid; i < n; i += 256) { const int v = j.src[i]; mx = v > mx ? v : mx; mn = v < mn ? v : mn; }
+        atomicMax(&s_mx, mx); atomicMin(&s_mn, mn);
+        __syncthreads();
+    }
+    const unsigned char vmax = (unsigned char)s_mx, vmin = (unsigned char)s_mn;
+    const long long total = seg_start[nseg];
     const long long nblk = (total + 623) / 624;
     for (long long blk = 0; blk < nblk; blk++) {
+        // twist: new[k] = old[k+397 mod 624] ^ f(old[k], old[k+1]); phases keep every read well-defined
         for (int ph = 0; ph < 3; ph++) {
             const int lo = ph == 0 ? 0 : (ph == 1 ? 227 : 454), hi = ph == 0 ? 227 : (ph == 1 ? 454 : 624);
             unsigned nv = 0; const int k = lo + tid;
@@ -297,16 +263,35 @@ __global__ __launch_bounds__(256) void gauss_noise_kernel(const GaussJob* jobs) 
         }
         for (int t = tid; t < 624; t += 256) ring[blk & 1][t] = mt_u24(mt_temper(mt[t]));
         __syncthreads();
-        const long long d_lo = blk * 624 - 15, d_hi = blk * 624 + 608;   // chunk starts whose last draw is in this twist
-        for (int g = 0; g < j.nseg; g++) {
-            const long long base = seg_draws * g;
+        const long long b0 = blk * 624;
+        const long long d_lo = b0 - 15, d_hi = b0 + 608;                 // chunk starts whose last draw is in this twist
+        for (int g = 0; g < nseg; g++) {
+            const long long base = seg_start[g];
+            if (j.seg[g].kind == 1) {
+                // draws [base, base + n) intersected with this twist
+                const long long lo = base > b0 ? base : b0, hi = (base + n < b0 + 624) ? base + n : b0 + 624;
+                unsigned char* dst = reinterpret_cast<unsigned char*>(j.seg[g].dst);
+                const float plo = j.seg[g].p0, phi = j.seg[g].p1;
+                for (long long d = lo + tid; d < hi; d += 256) {
+                    const float u = ring[blk & 1][d - b0];
+                    const long long e = d - base;
+                    const int c = (int)(e / plane);
+                    const long long o = (e - (long long)c * plane) * 3 + c;
+                    unsigned char v = j.src[o];
+                    if (u < plo) v = vmax;
+                    if (u > phi) v = vmin;
+                    dst[o] = v;
+                }
+                continue;
+            }
+            const long long seg_draws = seg_start[g + 1] - base;
             if (base > d_hi || base + seg_draws - 16 < d_lo) continue;
             // chunk ids: 0 .. ncs-1 standard (start base + 16c), id ncs = tail (start base + n) when rem
             long long c_lo = d_lo - base; c_lo = c_lo <= 0 ? 0 : (c_lo + 15) / 16;
             long long c_hi = d_hi - base; c_hi = c_hi < 0 ? -1 : c_hi / 16;
             if (c_hi > ncs - 1) c_hi = ncs - 1;
-            float* dst = j.dst + (long long)g * n;
-            const float std = j.stds[g];
+            float* dst = reinterpret_cast<float*>(j.seg[g].dst);
+            const float std = j.seg[g].p0;
             for (long long w = c_lo * 8 + tid; w < (c_hi + 1) * 8; w += 256) {
                 const long long c = w >> 3; const int jj = (int)(w & 7);
                 const long long s = base + 16 * c + jj, s8 = s + 8;
@@ -329,6 +314,64 @@ __global__ __launch_bounds__(256) void gauss_noise_kernel(const GaussJob* jobs) 
         __syncthreads();
     }
 }
-void launch_gauss_noise(const GaussJob* jobs, int n, hipStream_t st) {
-    if (n > 0) hipLaunchKernelGGL(gauss_noise_kernel, dim3(n), dim3(256), 0, st, jobs);
+void launch_noise_stream(const NoiseJob* jobs, int n, hipStream_t st) {
+    if (n > 0) hipLaunchKernelGGL(noise_stream_kernel, dim3(n), dim3(256), 0, st, jobs);
+}
+
+// ---------------------------------------------------------------------------------------------
+// cald_helper.ColorAdjust (cald_helper.py:65-69) = PIL.ImageEnhance Brightness -> Contrast -> Color, each
+// Image.blend(degenerate, image, factor): temp = (float)(in1 + alpha * (in2 - in1)) in C float arithmetic (one float
+// multiply, one float add), clipped to [0, 255] and truncated when alpha is outside [0, 1].
+//   pass 1 (grid over pixels): brightness (degenerate = black) -> tmp; sum of L = (19595 R + 38470 G + 7471 B + 0x8000) >> 16
+//   pass 2: contrast against the rounded mean of L, then saturation against the pixel's own L -> dst
+// ---------------------------------------------------------------------------------------------
+__device__ inline unsigned char pil_blend1(int in1, int in2, float alpha) {
+    const float temp = (float)in1 + alpha * (float)(in2 - in1);
+    if (alpha >= 0.0f && alpha <= 1.0f) return (unsigned char)temp;
+    if (temp <= 0.0f) return 0;
+    if (temp >= 255.0f) return 255;
+    return (unsigned char)temp;
+}
+__device__ inline int pil_l(int r, int g, int b) { return (r * 19595 + g * 38470 + b * 7471 + 0x8000) >> 16; }
+__global__ __launch_bounds__(256) void color_brightness_kernel(const uint8_t* src, long long npx, float f, uint8_t* tmp,
+                                                               unsigned long long* lsum) {
+    __shared__ unsigned long long red[256];
+    unsigned long long acc = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < npx; i += (long long)gridDim.x * 256) {
+        int c[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int v = src[3 * i + k];
+            c[k] = f == 1.0f ? v : (f == 0.0f ? 0 : pil_blend1(0, v, f));
+            tmp[3 * i + k] = (uint8_t)c[k];
+        }
+        acc += (unsigned long long)pil_l(c[0], c[1], c[2]);
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
+    if (threadIdx.x == 0) atomicAdd(lsum, red[0]);
+}
+__global__ __launch_bounds__(256) void color_contrast_saturation_kernel(const uint8_t* tmp, long long npx, float f,
+                                                                        const unsigned long long* lsum, uint8_t* dst) {
+    const int mean = (int)((double)(*lsum) / (double)npx + 0.5);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < npx; i += (long long)gridDim.x * 256) {
+        int c[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int v = tmp[3 * i + k];
+            c[k] = f == 1.0f ? v : (f == 0.0f ? mean : pil_blend1(mean, v, f));
+        }
+        const int l = pil_l(c[0], c[1], c[2]);
+#pragma unroll
+        for (int k = 0; k < 3; k++) dst[3 * i + k] = (uint8_t)(f == 1.0f ? c[k] : (f == 0.0f ? l : pil_blend1(l, c[k], f)));
+    }
+}
+void launch_color_adjust(const uint8_t* src, int H, int W, float factor, uint8_t* tmp, unsigned long long* lsum, uint8_t* dst,
+                         hipStream_t st) {
+    const long long npx = (long long)H * W;
+    const int grid = (int)((npx + 255) / 256 < 1024 ? (npx + 255) / 256 : 1024);
+    hipMemsetAsync(lsum, 0, sizeof(unsigned long long), st);
+    hipLaunchKernelGGL(color_brightness_kernel, dim3(grid), dim3(256), 0, st, src, npx, factor, tmp, lsum);
+    hipLaunchKernelGGL(color_contrast_saturation_kernel, dim3(grid), dim3(256), 0, st, tmp, npx, factor, lsum, dst);
 }

@@ -64,12 +64,19 @@ struct PyRandom {
     }
     double random() { uint32_t a = next() >> 5, b = next() >> 6; return ((double)a * 67108864.0 + (double)b) * (1.0 / 9007199254740992.0); }
     double uniform(double a, double b) { return a + (b - a) * random(); }
+    // random.randint(0, n - 1) == randrange(n): _randbelow_with_getrandbits (k = n.bit_length(), rejection sampling)
+    int randbelow(int n) {
+        int k = 0;
+        for (int t = n; t; t >>= 1) k++;
+        for (;;) { const uint32_t r = next() >> (32 - k); if ((int)r < n) return (int)r; }
+    }
 };
 
 // cald_helper.cutout (cald/cald_helper.py:88-132): rectangle selection only; the fill happens in
 // the preprocess kernel.  boxes: sub-sampled reference detections, original image coordinates.
-static inline int cutout_rects(uint64_t seed, int H, int W, int N, const float* boxes, int cut_num, int* rects) {
-    PyRandom rng; rng.seed(seed);
+// The generator is the caller's: get_uncertainty draws ColorSwap's randint and every cutout call of one image from the
+// same global Python generator, in call order (cald_train.py:140-166).
+static inline int cutout_rects(PyRandom& rng, int H, int W, int N, const float* boxes, int cut_num, int* rects) {
     int count = 0;
     for (int t = 0; t < 50; t++) {
         double sh = rng.uniform(0.05 * H, 0.2 * H);
@@ -93,6 +100,10 @@ static inline int cutout_rects(uint64_t seed, int H, int W, int N, const float* 
         if (++count >= cut_num) break;
     }
     return count;
+}
+static inline int cutout_rects(uint64_t seed, int H, int W, int N, const float* boxes, int cut_num, int* rects) {
+    PyRandom rng; rng.seed(seed);
+    return cutout_rects(rng, H, W, N, boxes, cut_num, rects);
 }
 
 // np.round(np.linspace(0, n-1, 50)).astype(int)  (cald_train.py:110-113)

@@ -11,6 +11,7 @@ struct ViewDesc {
     int Hr, Wr;           // detector-transform resized size (image_sizes)
     int Ho, Wo;           // size the detections are scaled back to (= H, W of this view's source)
     const float* noise;   // optional additive noise, CHW float32 (GaussianNoise view), else null
+    int swap;             // ColorSwap view: index into cald_helper.ColorSwap's permutation table (0 = identity)
 };
 
 // detections of one view, fixed capacity det_cap rows (frcnn_la.py:131-141 result dict)
@@ -33,11 +34,16 @@ void launch_pil_vertical(const uint8_t* src, int H, int W, uint8_t* dst, int oh,
 void launch_maxpool(const float* in, float* out, const LevelSeg* sin, const LevelSeg* sout, int C, int V, int max_out_pix, hipStream_t st);
 void launch_subsample2(const float* in, float* out, const LevelSeg* sin, const LevelSeg* sout, int C, int V, int max_out_pix, hipStream_t st);
 
-struct SaltPepperJob { const uint8_t* src; uint8_t* dst; int H, W; unsigned long long seed; float lo, hi; };
 void launch_affine_nearest(const uint8_t* src, int H, int W, uint8_t* dst, int oh, int ow, const int* a, hipStream_t st);
-void launch_salt_pepper(const SaltPepperJob* jobs, int n, hipStream_t st);
-struct GaussJob { float* dst; int n; int nseg; unsigned long long seed; float stds[8]; };   // dst: [nseg][n]
-void launch_gauss_noise(const GaussJob* jobs, int n, hipStream_t st);
+// all torch-generator views of one image, in draw order: kind 0 = randn * p0 / 255 -> float dst[3*H*W] (CHW),
+// kind 1 = rand -> salt (u < p0) / pepper (u > p1) on src -> uint8 dst[H*W*3] (HWC)
+#define CALD_MAX_NOISE_SEG 16
+struct NoiseSeg { int kind; float p0, p1; void* dst; };
+struct NoiseJob { unsigned long long seed; const uint8_t* src; int H, W, nseg; NoiseSeg seg[CALD_MAX_NOISE_SEG]; };
+void launch_noise_stream(const NoiseJob* jobs, int n, hipStream_t st);
+// ColorAdjust (PIL ImageEnhance Brightness -> Contrast -> Color); tmp: H*W*3 bytes, lsum: one u64
+void launch_color_adjust(const uint8_t* src, int H, int W, float factor, uint8_t* tmp, unsigned long long* lsum, uint8_t* dst,
+                         hipStream_t st);
 
 // rpn.hip
 struct RpnArgs {

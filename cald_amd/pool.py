@@ -104,7 +104,7 @@ class DevicePool:
     def from_arrays(cls, arrays, device=None):
         """Already-decoded uint8 HWC arrays (e.g. files in a format other than baseline JPEG, decoded by the caller)."""
         dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
-        arrays = [np.ascontiguousarray(a, dtype=np.uint8) for a in arrays]
+        arrays = [np.array(a, dtype=np.uint8, order="C") for a in arrays]
         shapes = [a.shape[:2] for a in arrays]
         offsets, total = cls._layout(shapes)
         arena = torch.empty(max(total, 1), dtype=torch.uint8, device=dev)

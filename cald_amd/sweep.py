@@ -15,7 +15,55 @@ from . import _ffi
 
 KNOWN_AUGS = ['flip', 'multi_ga', 'color_adjust', 'color_swap', 'multi_color_adjust', 'multi_sp', 'cut_out',
               'multi_cut_out', 'multi_resize', 'larger_resize', 'smaller_resize', 'rotation', 'ga', 'sp']
-SUPPORTED_AUGS = ('flip', 'ga', 'sp', 'cut_out', 'smaller_resize', 'rotation')
+SUPPORTED_AUGS = tuple(a for a in KNOWN_AUGS if a != 'multi_color_adjust')
+
+
+def expand_augs(augs):
+    """The augmented views get_uncertainty builds for a list of aug names, in ITS order (cald_train.py:123-183 tests
+    `name in augs` in a fixed sequence).  Returns [(kind, param)] for cald_sweep_cfg.augs."""
+    F = _ffi
+    out = []
+    if 'flip' in augs:
+        out.append((F.AUG_FLIP, 0.0))
+    if 'ga' in augs:
+        out.append((F.AUG_GAUSS, 16))
+    if 'multi_ga' in augs:
+        out += [(F.AUG_GAUSS, i * 8) for i in range(1, 7)]
+    if 'color_adjust' in augs:
+        out.append((F.AUG_COLOR_ADJUST, 1.5))
+    if 'color_swap' in augs:
+        out.append((F.AUG_COLOR_SWAP, 0.0))
+    if 'multi_color_adjust' in augs:
+        # cald_train.py:148 appends an undefined name: the reference raises NameError on the first image with detections
+        raise NameError("name 'reference_boxes' is not defined (multi_color_adjust is broken in the reference, cald_train.py:148)")
+    if 'sp' in augs:
+        out.append((F.AUG_SALT_PEPPER, 0.1))
+    if 'multi_sp' in augs:
+        out += [(F.AUG_SALT_PEPPER, i * 0.05) for i in range(1, 7)]
+    if 'cut_out' in augs:
+        out.append((F.AUG_CUTOUT, 2))
+    if 'multi_cut_out' in augs:
+        out += [(F.AUG_CUTOUT, i) for i in range(1, 5)]
+    if 'multi_resize' in augs:
+        out += [(F.AUG_RESIZE, i * 0.1) for i in range(7, 10)]
+    if 'larger_resize' in augs:
+        out.append((F.AUG_RESIZE, 1.2))
+    if 'smaller_resize' in augs:
+        out.append((F.AUG_RESIZE, 0.8))
+    if 'rotation' in augs:
+        out.append((F.AUG_ROTATE, 5))
+    return out
+
+
+def make_sweep_cfg(augs, bp=1.3, base_seed=0, batch_images=64):
+    specs = expand_augs(augs)
+    if len(specs) > _ffi.MAX_AUGS:
+        raise ValueError("more than %d augmented views per image" % _ffi.MAX_AUGS)
+    cfg = _ffi.SweepCfg()
+    cfg.base_seed, cfg.bp, cfg.batch_images, cfg.n_augs = int(base_seed), float(bp), int(batch_images), len(specs)
+    for k, (kind, param) in enumerate(specs):
+        cfg.augs[k].kind, cfg.augs[k].param = kind, float(param)
+    return cfg
 
 
 def _to_u8_cuda(image, device):
@@ -35,8 +83,6 @@ def sweep_device_images(task_model, images, positions, augs, bp=1.3, base_seed=0
     for aug in augs:
         if aug not in KNOWN_AUGS:
             print('{} is not in the pre-set augmentations!'.format(aug))   # cald_train.py:92-95
-        elif aug not in SUPPORTED_AUGS:
-            raise NotImplementedError("augmentation %r is not implemented on the MI355X path yet" % aug)
     L = _ffi.lib()
     n = len(images)
     Cn = task_model.num_classes
@@ -48,8 +94,7 @@ def sweep_device_images(task_model, images, positions, augs, bp=1.3, base_seed=0
     Hs = np.array([im.shape[0] for im in images], np.int32)
     Ws = np.array([im.shape[1] for im in images], np.int32)
     pos = np.ascontiguousarray(positions, dtype=np.int64)
-    cfg = _ffi.SweepCfg(int('flip' in augs), int('cut_out' in augs), int('smaller_resize' in augs), 0.8,
-                        int(base_seed), float(bp), int(batch_images), int('sp' in augs), 0.1, int('rotation' in augs), 5.0, int('ga' in augs), 16.0)
+    cfg = make_sweep_cfg(augs, bp, base_seed, batch_images)
     _ffi.check(L.cald_sweep(task_model.handle(), n, ptrs, _ffi.ptr(Hs, _ffi.c_i), _ffi.ptr(Ws, _ffi.c_i),
                             _ffi.ptr(pos, _ffi.c_i64), C.byref(cfg), _ffi.ptr(cons, _ffi.c_d), _ffi.ptr(cls, _ffi.c_d)))
     return cons, cls

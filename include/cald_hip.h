@@ -93,22 +93,32 @@ typedef struct cald_dets {
 int cald_forward(cald_model* m, int n_views, const cald_view* views, const cald_dets* out);
 
 /* get_uncertainty(task_model, unlabeled_loader, augs, num_cls) (cald_train.py:91-231) over
- * n_images already resident in HBM.  pool_pos[i] keys the per-image RNG (cut_out), so results do
- * not depend on sharding.  consistency_out[n_images], cls_corr_out[n_images][num_classes-1]. */
+ * n_images already resident in HBM.  consistency_out[n_images], cls_corr_out[n_images][num_classes-1].
+ *
+ * The augmented views of an image are given as an ordered list (the Python shim expands the reference's aug names
+ * in the reference's order, cald_train.py:123-183).  Randomness: the reference draws GaussianNoise / SaltPepperNoise
+ * from torch's global CPU generator and ColorSwap / cutout from Python's global `random`, in call order; here both
+ * generators are re-seeded per image with base_seed * 1000003 + pool_pos[i] and consumed in list order, so results
+ * do not depend on sharding or batching. */
+#define CALD_AUG_FLIP 1          /* HorizontalFlip(image, boxes)            cald_train.py:123-126 */
+#define CALD_AUG_GAUSS 2         /* GaussianNoise(image, std = param)       :127-135 ('ga' 16; 'multi_ga' 8..48) */
+#define CALD_AUG_COLOR_ADJUST 3  /* ColorAdjust(image, factor = param)      :136-139 ('color_adjust' 1.5) */
+#define CALD_AUG_COLOR_SWAP 4    /* ColorSwap(image)                        :140-143 */
+#define CALD_AUG_SALT_PEPPER 5   /* SaltPepperNoise(image, prob = param)    :149-157 ('sp' 0.1; 'multi_sp' 0.05..0.3) */
+#define CALD_AUG_CUTOUT 6        /* cutout(image, boxes, labels, cut_num = param) :158-166 ('cut_out' 2; 'multi_cut_out' 1..4) */
+#define CALD_AUG_RESIZE 7        /* resize(image, boxes, ratio = param)     :167-179 ('smaller_resize' .8, 'larger_resize' 1.2, 'multi_resize' .7 .8 .9) */
+#define CALD_AUG_ROTATE 8        /* rotate(image, boxes, angle = param)     :180-183 ('rotation' 5) */
+#define CALD_MAX_AUGS 32
+typedef struct cald_aug_spec {
+    int kind;
+    double param;          /* a Python float in the reference (e.g. 7 * 0.1 for multi_resize): kept in double */
+} cald_aug_spec;
 typedef struct cald_sweep_cfg {
-    int aug_flip;          /* 'flip' */
-    int aug_cutout;        /* 'cut_out' (cut_num 2) */
-    int aug_resize;        /* 'smaller_resize' */
-    float resize_ratio;    /* 0.8 */
     uint64_t base_seed;
     float bp;              /* args.bp, 1.3 */
     int batch_images;      /* images per batched launch sequence (0 = default 64, max 64) */
-    int aug_sp;            /* 'sp': SaltPepperNoise(image, sp_prob), torch.rand stream re-seeded per image */
-    float sp_prob;         /* 0.1 */
-    int aug_rotate;        /* 'rotation': rotate(image, ref_boxes, rotate_angle) */
-    float rotate_angle;    /* 5 */
-    int aug_ga;            /* 'ga': GaussianNoise(image, ga_std), torch.randn stream re-seeded per image */
-    float ga_std;          /* 16 */
+    int n_augs;
+    cald_aug_spec augs[CALD_MAX_AUGS];
 } cald_sweep_cfg;
 int cald_sweep(cald_model* m, int n_images, const uint8_t* const* images_dev, const int* H, const int* W,
                const int64_t* pool_pos, const cald_sweep_cfg* cfg, double* consistency_out, double* cls_corr_out);

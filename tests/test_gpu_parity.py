@@ -239,6 +239,25 @@ def test_sweep_five_augs_matches_oracle(hip, oracle, small_model):
     np.testing.assert_array_equal(cls, np.stack(wcls))
 
 
+def test_sweep_every_augmentation_branch_matches_oracle(hip, oracle, small_model):
+    """All 13 augmentation names get_uncertainty can run (cald_train.py:123-183; multi_color_adjust raises NameError in
+    the reference): 28 views per image in the reference's order, GaussianNoise / SaltPepperNoise views sharing one
+    torch generator stream, ColorSwap / cutout sharing one Python `random` stream.  The oracle's views are pinned to
+    the reference by tests/golden/scoring_frcnn_ALL.npz."""
+    torch = hip["torch"]
+    from cald_amd import synth, sweep
+    model, P = small_model
+    pool = [np.ascontiguousarray(im[:120, :150]) for im in synth.make_pool(2, "voc", 3, scale=0.5)]
+    augs = ["rotation", "flip", "ga", "multi_ga", "color_adjust", "color_swap", "sp", "multi_sp", "cut_out", "multi_cut_out",
+            "multi_resize", "larger_resize", "smaller_resize"]
+    assert len(sweep.expand_augs(augs)) == 28
+    cons, cls = sweep.sweep_device_images(model, [torch.from_numpy(im).cuda() for im in pool], [4, 9], augs,
+                                          bp=1.3, base_seed=3, batch_images=2)
+    wc, wcls = oracle.get_uncertainty(P, pool, augs, 21, bp=1.3, min_size=300, max_size=500, base_seed=3, positions=[4, 9])
+    np.testing.assert_array_equal(cons, np.array(wc))
+    np.testing.assert_array_equal(cls, np.stack(wcls))
+
+
 def test_resnet101_coco_classes_forward(hip, oracle):
     """BASELINE config 5 shape: ResNet-101 body, 91 classes (COCO) -- one view, bit-exact vs the oracle."""
     torch = hip["torch"]
@@ -273,8 +292,8 @@ def test_empty_reference_and_error_paths(hip, oracle, small_model):
     np.testing.assert_array_equal(cls, np.zeros((2, 20)))
     with pytest.raises(RuntimeError):
         model.forward_views([(torch.zeros((0, 0, 3), dtype=torch.uint8, device="cuda"), False, None)])
-    with pytest.raises(NotImplementedError):
-        sweep.sweep_device_images(model, [torch.from_numpy(pool[1]).cuda()], [0], ["multi_ga"])
+    with pytest.raises(NameError):            # the reference raises NameError for this one (cald_train.py:148)
+        sweep.sweep_device_images(model, [torch.from_numpy(pool[1]).cuda()], [0], ["multi_color_adjust"])
 
 
 def test_ragged_batch_equals_batch1_and_eval_consumer(hip, small_model):
