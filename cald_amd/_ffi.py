@@ -68,6 +68,8 @@ SIGNATURES = {
     "cald_op_cls_corr": (C.c_int, [C.c_void_p, C.c_int, c_f, c_i64, C.c_int, c_f]),
     "cald_op_pil_resize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]),
     "cald_op_cutout_rects": (C.c_int, [C.c_uint64, C.c_int, C.c_int, C.c_int, c_f, C.c_int, c_i, c_i]),
+    "cald_op_augment": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_uint64, C.c_void_p, C.c_int, C.c_int, C.c_int, c_f,
+                                  C.c_void_p, c_f, c_i]),
     "cald_op_conv2d": (C.c_int, [C.c_void_p, c_f, C.c_int, C.c_int, C.c_int, c_f, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_int, c_f, c_f, c_f, c_f, C.c_int, c_f]),
     "cald_op_transform_size": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, c_i, c_i, c_i, c_i]),

@@ -241,6 +241,62 @@ extern "C" int cald_op_pil_resize(cald_ctx* c, const uint8_t* src_dev, int H, in
     return rc;
 }
 
+// One augmented view of one image, outside the sweep (the helper API of cald/cald_helper.py and the parity tests).
+// A fresh generator is seeded with `seed` (torch's for GAUSS / SALT_PEPPER, Python's for COLOR_SWAP).
+extern "C" int cald_op_augment(cald_ctx* c, int kind, double param, uint64_t seed, const uint8_t* src_dev, int H, int W,
+                               int n_boxes, const float* boxes, void* dst_dev, float* boxes_out, int* aux_out) {
+    if (!c || H <= 0 || W <= 0) return fail(CALD_ERR_INVALID, "bad arguments");
+    if (kind == CALD_AUG_COLOR_SWAP) {
+        if (!aux_out) return fail(CALD_ERR_INVALID, "color_swap: aux_out is null");
+        PyRandom r; r.seed(seed);
+        aux_out[0] = r.randbelow(6);
+        return CALD_OK;
+    }
+    if (!src_dev || !dst_dev) return fail(CALD_ERR_INVALID, "null image pointer");
+    HIPCHK(hipSetDevice(c->device));
+    const size_t nbytes = (size_t)H * W * 3;
+    if (kind == CALD_AUG_GAUSS || kind == CALD_AUG_SALT_PEPPER) {
+        NoiseJob nj; memset(&nj, 0, sizeof(nj));
+        nj.seed = seed; nj.src = src_dev; nj.H = H; nj.W = W; nj.nseg = 1; nj.seg[0].dst = dst_dev;
+        if (kind == CALD_AUG_GAUSS) { nj.seg[0].kind = 0; nj.seg[0].p0 = (float)param; }
+        else { nj.seg[0].kind = 1; nj.seg[0].p0 = (float)(param / 2.0); nj.seg[0].p1 = (float)(1.0 - param / 2.0); }
+        NoiseJob* d = nullptr;
+        HIPCHK(hipMalloc((void**)&d, sizeof(NoiseJob)));
+        hipError_t e = hipMemcpyAsync(d, &nj, sizeof(nj), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) { launch_noise_stream(d, 1, c->stream); e = hipStreamSynchronize(c->stream); }
+        hipFree(d);
+        if (e != hipSuccess) return fail(CALD_ERR_HIP, "noise stream failed: %s", hipGetErrorString(e));
+        return CALD_OK;
+    }
+    if (kind == CALD_AUG_COLOR_ADJUST) {
+        uint8_t* tmp = nullptr;
+        HIPCHK(hipMalloc((void**)&tmp, nbytes + 256));
+        unsigned long long* lsum = reinterpret_cast<unsigned long long*>(tmp + ((nbytes + 7) & ~(size_t)7));
+        launch_color_adjust(src_dev, H, W, (float)param, tmp, lsum, reinterpret_cast<uint8_t*>(dst_dev), c->stream);
+        hipError_t e = hipStreamSynchronize(c->stream);
+        hipFree(tmp);
+        if (e != hipSuccess) return fail(CALD_ERR_HIP, "color adjust failed: %s", hipGetErrorString(e));
+        return CALD_OK;
+    }
+    if (kind == CALD_AUG_ROTATE) {
+        if (n_boxes < 0 || (n_boxes && (!boxes || !boxes_out))) return fail(CALD_ERR_INVALID, "rotate: null boxes");
+        int fx[6], nh, nw; pil_rotate_setup(H, W, param, fx, &nh, &nw);
+        uint8_t* ws = nullptr;
+        const size_t a = ((size_t)nh * nw * 3 + 255) & ~(size_t)255;
+        HIPCHK(hipMalloc((void**)&ws, a + (size_t)nh * W * 3));
+        launch_affine_nearest(src_dev, H, W, ws, nh, nw, fx, c->stream);
+        int rc = pil_resize(c, ws, nh, nw, reinterpret_cast<uint8_t*>(dst_dev), H, W, ws + a, 1);
+        hipError_t e = hipStreamSynchronize(c->stream);
+        hipFree(ws);
+        if (rc) return rc;
+        if (e != hipSuccess) return fail(CALD_ERR_HIP, "rotate failed: %s", hipGetErrorString(e));
+        float par[12]; rotate_box_params(H, W, param, nw, nh, par);
+        rotate_boxes_host(par, boxes, n_boxes, boxes_out);
+        return CALD_OK;
+    }
+    return fail(CALD_ERR_INVALID, "cald_op_augment: kind %d has its own entry point or needs no device work", kind);
+}
+
 // =============================================================================================
 // model
 // =============================================================================================

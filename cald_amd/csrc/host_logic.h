@@ -207,6 +207,24 @@ static inline void rotate_box_params(int H, int W, double angle_deg, int pilW, i
     p[10] = p[11] = 0.0f;
 }
 
+// cald_helper.rotate box transform (cald_helper.py:160-222) on the host, same float32 arithmetic as score.hip kind 3
+static inline void rotate_boxes_host(const float* p /*rotate_box_params*/, const float* boxes, int N, float* out) {
+    for (int i = 0; i < N; i++) {
+        const float* b = boxes + 4 * i;
+        const float bw = b[2] - b[0], bh = b[3] - b[1];
+        const float xs[4] = {b[0], b[0] + bw, b[0], b[2]}, ys[4] = {b[1], b[1], b[1] + bh, b[3]};
+        float xmin = 0.f, xmax = 0.f, ymin = 0.f, ymax = 0.f;
+        for (int q = 0; q < 4; q++) {
+            const float X = (p[0] * xs[q] + p[1] * ys[q]) + p[2] * 1.0f;
+            const float Y = (p[3] * xs[q] + p[4] * ys[q]) + p[5] * 1.0f;
+            if (q == 0 || X < xmin) xmin = X; if (q == 0 || X > xmax) xmax = X;
+            if (q == 0 || Y < ymin) ymin = Y; if (q == 0 || Y > ymax) ymax = Y;
+        }
+        auto cl = [](float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); };
+        out[4 * i] = cl(xmin / p[6], 0.0f, p[8]); out[4 * i + 1] = cl(ymin / p[7], 0.0f, p[9]);
+        out[4 * i + 2] = cl(xmax / p[6], 0.0f, p[8]); out[4 * i + 3] = cl(ymax / p[7], 0.0f, p[9]);
+    }
+}
 
 // numpy pairwise summation of float32 (np.sum over a 1-D float32 array)
 static inline float np_sum_f32(const float* a, int n) {

@@ -142,6 +142,15 @@ int cald_op_cls_corr(cald_ctx* ctx, int n, const float* scores, const int64_t* l
 int cald_op_pil_resize(cald_ctx* ctx, const uint8_t* src_dev, int H, int W, uint8_t* dst_dev, int oh, int ow);
 /* cald_helper.cutout rectangle selection (host side RNG = Python random seeded per image) */
 int cald_op_cutout_rects(uint64_t seed, int H, int W, int N, const float* boxes, int cut_num, int* rects_out, int* n_out);
+/* one augmented view outside the sweep (helper API of cald/cald_helper.py; same kernels as inside cald_sweep).  A fresh
+ * generator is seeded with `seed` (torch's CPU generator for GAUSS / SALT_PEPPER, Python's `random` for COLOR_SWAP).
+ *   CALD_AUG_GAUSS        GaussianNoise :72-75    dst_dev = float [3][H][W], the additive term randn * param / 255
+ *   CALD_AUG_SALT_PEPPER  SaltPepperNoise :78-85  dst_dev = uint8 [H][W][3]
+ *   CALD_AUG_COLOR_ADJUST ColorAdjust :65-69      dst_dev = uint8 [H][W][3]
+ *   CALD_AUG_COLOR_SWAP   ColorSwap :56-62        aux_out[0] = index of the drawn channel permutation (no device work)
+ *   CALD_AUG_ROTATE       rotate :135-223         dst_dev = uint8 [H][W][3], boxes_out[n_boxes][4] (host) */
+int cald_op_augment(cald_ctx* ctx, int kind, double param, uint64_t seed, const uint8_t* src_dev, int H, int W,
+                    int n_boxes, const float* boxes, void* dst_dev, float* boxes_out, int* aux_out);
 /* NHWC convolution on the MFMA kernel; weights in torch layout [Cout][Cin][KH][KW] (host) */
 int cald_op_conv2d(cald_ctx* ctx, const float* in, int H, int W, int Cin, const float* weight, int Cout, int KH, int KW,
                    int stride, int pad, const float* bias, const float* bn_scale, const float* bn_shift,

@@ -89,6 +89,36 @@ def test_cutout_rects_host(hip, oracle, golden):
             np.testing.assert_array_equal(rects[:4 * n.value].reshape(-1, 4), oracle.cutout_rects(s, H, W, boxes, 2))
 
 
+def test_helper_api_mirror_gpu_ops_match_reference_golden(hip, oracle, golden):
+    """cald_amd.cald_helper's GPU-backed helpers (resize, rotate, GaussianNoise, SaltPepperNoise, ColorAdjust, ColorSwap)
+    against what the IMPORTED reference helpers produced (tests/golden/helpers.npz, scoring_frcnn_ALL.npz)."""
+    torch = hip["torch"]
+    from cald_amd import cald_helper as ch
+    g = golden("helpers")
+    u8 = lambda t: (t * 255).round().to(torch.uint8).permute(1, 2, 0).cpu().numpy()
+    for i in range(4):
+        img, boxes = torch.from_numpy(g["img%d" % i]), torch.from_numpy(g["boxes%d" % i])
+        for r in (0.8, 1.2, 0.7):
+            ri, rb = ch.resize(img, boxes, r)
+            np.testing.assert_array_equal(u8(ri), g["resize%d_%d_img" % (i, int(r * 10))])
+            np.testing.assert_array_equal(rb.numpy(), g["resize%d_%d_boxes" % (i, int(r * 10))])
+        ri, rb = ch.rotate(img, boxes, 5)
+        np.testing.assert_array_equal(u8(ri), g["rotate%d_img" % i])
+        np.testing.assert_allclose(rb.numpy(), g["rotate%d_boxes" % i], rtol=0, atol=1e-4)   # torch.mm vs the contract's op order
+        np.testing.assert_array_equal(rb.numpy(), oracle.rotate_aug(g["img%d" % i], g["boxes%d" % i], 5)[1])
+        for s in (21, 22):
+            np.testing.assert_array_equal(u8(ch.SaltPepperNoise(img, 0.1, seed=s)), g["sp%d_%d_img" % (i, s)])
+        if i >= 2:
+            got = ch.GaussianNoise(img, 16, seed=31 + i).permute(1, 2, 0).cpu().numpy()
+            np.testing.assert_allclose(got, g["ga%d_img" % i], rtol=0, atol=2e-6)      # torch's libm vs det_logf / det_sincosf
+    a = golden("scoring_frcnn_ALL")      # image 0: view 9 = ColorAdjust(image, 1.5), view 10 = ColorSwap(image)
+    img0 = torch.from_numpy(a["img0"])
+    np.testing.assert_array_equal(u8(ch.ColorAdjust(img0, 1.5)), a["seen0_9"])
+    np.testing.assert_array_equal(u8(ch.ColorSwap(img0, seed=oracle.image_seed(int(a["base_seed"]), 0))), a["seen0_10"])
+    for f in (2, 3, 0.5, 0.0, 1.0):      # the other factors of multi_color_adjust, against the oracle (pinned to PIL)
+        np.testing.assert_array_equal(u8(ch.ColorAdjust(img0, f)), oracle.color_adjust(a["img0"], f))
+
+
 CONV_CASES = [
     # H, W, Cin, Cout, K, stride, pad, bias, bn, res, relu
     (37, 53, 4, 64, 7, 2, 3, False, True, False, True),      # conv1
