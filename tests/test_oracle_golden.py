@@ -124,3 +124,32 @@ def test_baseline_sweeps_match_reference(oracle, golden):
     for v in range(1, 7):    # the six sequential GaussianNoise views exactly as the reference's detector saw them
         got = img.astype(np.float32) / np.float32(255) + noise[v - 1].transpose(1, 2, 0)
         np.testing.assert_allclose(got, g["ls_seen0_%d" % v], rtol=0, atol=2e-6)
+
+
+def test_postprocess_bookkeeping_matches_reference_bodies(oracle, golden):
+    """A19 / A22: the oracle's postprocess against the outputs of the reference's OWN method bodies
+    (frcnn_la.py:32-87, retinanet_cal.py:402-490 run under the stub harness, oracle/make_golden_postprocess.py).
+    Index bookkeeping must agree exactly (count, labels, order); floats within 1e-4 (torch's exp / softmax / sigmoid vs
+    the arithmetic contract's polynomials)."""
+    g = golden("postprocess")
+    for k in range(int(g["f_n"])):
+        H, W = [int(v) for v in g["f%d_hw" % k]]
+        got = oracle.frcnn_postprocess(g["f%d_logits" % k], g["f%d_deltas" % k], g["f%d_props" % k], H, W, H, W)
+        want = {n: g["f%d_out_%s" % (k, n)] for n in ("boxes", "scores", "labels", "props", "prob_max", "scores_cls")}
+        assert got["labels"].shape == want["labels"].shape, (k, got["labels"].shape, want["labels"].shape)
+        np.testing.assert_array_equal(got["labels"], want["labels"])
+        np.testing.assert_array_equal(got["props"], want["props"])
+        for n in ("scores", "prob_max", "scores_cls"):
+            np.testing.assert_allclose(got[n], want[n].reshape(got[n].shape), rtol=0, atol=1e-5)
+        np.testing.assert_allclose(got["boxes"], want["boxes"].reshape(-1, 4), rtol=0, atol=1e-3)
+    base = g["r_base"]
+    for k in range(int(g["r_n"])):
+        K = int(g["r%d_K" % k]); Hp, Wp, Hr, Wr = [int(v) for v in g["r%d_sizes" % k]]
+        cls = [g["r%d_cls%d" % (k, l)] for l in range(5)]; reg = [g["r%d_reg%d" % (k, l)] for l in range(5)]
+        got = oracle.retina_postprocess(cls, reg, base, Hp, Wp, Hr, Wr, Hr, Wr, K)
+        want = {n: g["r%d_out_%s" % (k, n)] for n in ("boxes", "scores", "labels", "scores_cls", "prob_max")}
+        assert got["labels"].shape == want["labels"].shape, (k, got["labels"].shape, want["labels"].shape)
+        np.testing.assert_array_equal(got["labels"], want["labels"])
+        for n in ("scores", "prob_max", "scores_cls"):
+            np.testing.assert_allclose(got[n], want[n].reshape(got[n].shape), rtol=0, atol=1e-5)
+        np.testing.assert_allclose(got["boxes"], want["boxes"], rtol=0, atol=1e-3)
