@@ -23,6 +23,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
+F16_MFMA_PEAK_TFLOPS = 2516.6  # v_mfma_f32_32x32x16_f16: 32 cycles / SIMD -> 16 x the f32-input rate (dense)
 
 
 def cpu_baseline(sd, pool, augs, budget_s=12.0, max_images=24):
@@ -64,6 +65,8 @@ def main():
                     help="frcnn = the headline workload (BASELINE configs[1]); others are informational runs of configs[2]/[4]")
     ap.add_argument("--shape", default="voc", choices=["voc", "coco"])
     ap.add_argument("--augs", default="FCD", help="letters of cald_train.py --augs (F C D R G S)")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "f16x3"],
+                    help="fp32 = exact (headline, bit-identical to the oracle); f16x3 = informational split-fp16 MFMA path")
     args = ap.parse_args()
 
     import numpy as np
@@ -93,15 +96,15 @@ def main():
     augs = [letters[ch] for ch in args.augs]
     ncls = 21 if args.shape == "voc" else 91
     mn, mx = (600, 1000) if args.shape == "voc" else (800, 1333)
-    headline = (args.model == "frcnn" and args.shape == "voc" and args.augs == "FCD")
+    headline = (args.model == "frcnn" and args.shape == "voc" and args.augs == "FCD" and args.precision == "fp32")
     if args.model == "retinanet":
         sd = synth.pseudo_trained_retinanet(ncls, 50, seed=0)
-        model = detector.retinanet_resnet50_fpn_cal(num_classes=ncls, min_size=mn, max_size=mx)
+        model = detector.retinanet_resnet50_fpn_cal(num_classes=ncls, min_size=mn, max_size=mx, precision=args.precision)
     else:
         depth = 101 if args.model == "frcnn101" else 50
         sd = synth.pseudo_trained_frcnn(ncls, depth, seed=0)
         model = (detector.fasterrcnn_resnet101_fpn_feature if depth == 101 else detector.fasterrcnn_resnet50_fpn_feature)(
-            num_classes=ncls, min_size=mn, max_size=mx)
+            num_classes=ncls, min_size=mn, max_size=mx, precision=args.precision)
     model = model.to("cuda:%d" % local_rank)
     model.load_state_dict(sd)
     model.eval()
@@ -165,23 +168,46 @@ def main():
             traffic = None
         images = world * K * B
         achieved = gf.value / (gm.value * 1e-3) / 1e12 if gm.value > 0 else 0.0
+        peak = F32_MFMA_PEAK_TFLOPS if args.precision == "fp32" else F16_MFMA_PEAK_TFLOPS
         out = {
             "metric": "unlabeled images scored/sec (CALD consistency sweep)", "value": images / dt, "unit": "images/s",
             "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": dt / K * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "f16x3 (fp16 hi+lo split operands, fp32 accumulate)",
+            "data": "synthetic",
             "config": {"workload": ("BASELINE.json configs[1]: Faster R-CNN ResNet-50 FPN, VOC2012-shaped synthetic pool, "
                                     "3 augs (flip/cut_out/smaller_resize), 21 classes, min/max 600/1000, seeded pseudo-trained weights")
-                       if headline else "informational: model=%s shape=%s augs=%s classes=%d min/max %d/%d" % (args.model, args.shape, args.augs, ncls, mn, mx),
+                       if headline else "informational: model=%s shape=%s augs=%s classes=%d min/max %d/%d precision=%s" % (args.model, args.shape, args.augs, ncls, mn, mx, args.precision),
                        "images_per_step_per_gpu": B, "views_per_image": 1 + len(sweep.expand_augs(augs)), "parallelism": "pool sharded by position, dp%d" % world},
-            "roofline": {"bound": "mfma", "kernel": "conv_p4_kernel + conv_mfma_f32_kernel (implicit-GEMM conv + linear, v_mfma_f32_32x32x2_f32)",
-                         "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+            "roofline": {"bound": "mfma",
+                         "kernel": ("conv_p4_kernel + conv_mfma_f32_kernel (implicit-GEMM conv + linear, v_mfma_f32_32x32x2_f32)" if args.precision == "fp32"
+                                    else "conv_h3_kernel (3 x v_mfma_f32_32x32x16_f16 per product; algorithmic flops counted once) + exact kernels for uncovered shapes"),
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": traffic if args.precision == "fp32" else None,
                          "launches": int(nl.value), "avg_launch_ms": gm.value / max(1, nl.value),
                          "gemm_ms_per_step": gm.value / K, "algorithmic_gflop_per_launch": gf.value / max(1, nl.value) / 1e9},
         }
         if world == 1 and not args.no_cpu_baseline and headline:
             out["cpu_baseline"] = cpu_baseline(sd, host_pool, augs)
             out["cpu_baseline"]["host_cpus"] = os.cpu_count()
+            # informational second line, NOT the headline: the opt-in split-fp16 MFMA mode (BASELINE configs[4]'s
+            # "fp16 MFMA path") on the same workload.  Parity bar of that mode: 1e-4 / identical ranking, not bit-exact.
+            fast = (detector.fasterrcnn_resnet50_fpn_feature(num_classes=ncls, min_size=mn, max_size=mx, precision="f16x3")
+                    .to("cuda:%d" % local_rank))
+            fast.load_state_dict(sd)
+            fast.eval()
+            idx = list(range(B))
+            run = lambda: sweep.sweep_device_images(fast, [dev_pool[i] for i in idx], [positions[i] for i in idx], augs,
+                                                    bp=1.3, base_seed=0, batch_images=B)
+            fc, _ = run()
+            torch.cuda.synchronize(); tf = time.time()
+            for _ in range(2):
+                run()
+            torch.cuda.synchronize(); tf = time.time() - tf
+            ec, _ = sweep.sweep_device_images(model, [dev_pool[i] for i in idx], [positions[i] for i in idx], augs,
+                                              bp=1.3, base_seed=0, batch_images=B)
+            out["f16x3_mode"] = {"value": 2 * B / tf, "unit": "images/s", "dtype": "fp16 hi+lo split operands, 3 x v_mfma_f32_32x32x16_f16 per product, fp32 accumulate",
+                                 "headline": False, "max_abs_consistency_diff_vs_exact": float(np.abs(fc - ec).max()),
+                                 "same_ranking_as_exact": bool(np.array_equal(np.argsort(fc, kind="stable"), np.argsort(ec, kind="stable")))}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -22,7 +22,10 @@ class ModelCfg(C.Structure):
     _fields_ = [("arch", C.c_int), ("depth", C.c_int), ("num_classes", C.c_int), ("min_size", C.c_int),
                 ("max_size", C.c_int), ("box_score_thresh", C.c_float), ("box_nms_thresh", C.c_float),
                 ("detections_per_img", C.c_int), ("rpn_pre_nms_top_n", C.c_int), ("rpn_post_nms_top_n", C.c_int),
-                ("rpn_nms_thresh", C.c_float)]
+                ("rpn_nms_thresh", C.c_float), ("precision", C.c_int)]
+
+
+PRECISION = {"fp32": 0, "f16x3": 1}
 
 
 class View(C.Structure):
@@ -72,6 +75,8 @@ SIGNATURES = {
                                   C.c_void_p, c_f, c_i]),
     "cald_op_conv2d": (C.c_int, [C.c_void_p, c_f, C.c_int, C.c_int, C.c_int, c_f, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_int, c_f, c_f, c_f, c_f, C.c_int, c_f]),
+    "cald_op_conv2d_f16x3": (C.c_int, [C.c_void_p, c_f, C.c_int, C.c_int, C.c_int, c_f, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_int, c_f, c_f, c_f, c_f, C.c_int, c_f]),
     "cald_op_transform_size": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, c_i, c_i, c_i, c_i]),
     "cald_debug_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, c_f, C.c_int64, c_i64]),
     "cald_jpeg_info": (C.c_int, [C.c_void_p, C.c_size_t, c_i, c_i, c_i]),

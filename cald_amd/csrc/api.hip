@@ -303,6 +303,7 @@ extern "C" int cald_op_augment(cald_ctx* c, int kind, double param, uint64_t see
 struct HostTensor { std::vector<float> data; std::vector<int64_t> shape; };
 struct ConvLayer {
     float *w = nullptr, *w4 = nullptr, *bias = nullptr, *scale = nullptr, *shift = nullptr;
+    uint16_t* w16 = nullptr; float w16_unscale = 1.0f;   // CALD_PRECISION_F16X3 only
     int Cin = 0, Cout = 0, CoutPad = 0, K = 0, Kpad = 0, KH = 1, KW = 1, stride = 1, pad = 0;
     int CinTrue = 0;   // un-padded input channels (algorithmic FLOP accounting)
 };
@@ -338,6 +339,7 @@ extern "C" int cald_model_create(cald_ctx* ctx, const cald_model_cfg* cfg, cald_
     if (cfg->rpn_pre_nms_top_n > 1024 || cfg->rpn_post_nms_top_n > CALD_ROI_CAP || cfg->rpn_pre_nms_top_n < 1 || cfg->rpn_post_nms_top_n < 1)
         return fail(CALD_ERR_INVALID, "rpn top-n out of range (pre <= 1024, post <= %d)", CALD_ROI_CAP);
     if (cfg->detections_per_img < 1 || cfg->detections_per_img > 1024) return fail(CALD_ERR_INVALID, "detections_per_img out of range");
+    if (cfg->precision != CALD_PRECISION_FP32 && cfg->precision != CALD_PRECISION_F16X3) return fail(CALD_ERR_INVALID, "unknown precision %d", cfg->precision);
     cald_model* m = new cald_model();
     m->ctx = ctx; m->cfg = *cfg;
     memset(&m->sweep_det, 0, sizeof(m->sweep_det));
@@ -361,6 +363,32 @@ static std::vector<float> pack_w4(const std::vector<float>& w, int Kpad, int Cou
         const int kt = k >> 4, kk = k & 15, kq = kk >> 3, j = (kk & 7) >> 1, h = kk & 1;
         for (int n = 0; n < CoutPad; n++)
             o[(((size_t)(kt * 2 + kq) * CoutPad + n) * 2 + h) * 4 + j] = w[(size_t)k * CoutPad + n];
+    }
+    return o;
+}
+
+// K-major [Kpad][CoutPad] -> fp16 hi / lo planes [Kpad/16][2][CoutPad][16]  (conv_h3.hip): w * 2^S = hi + lo,
+// hi = fp16(w * 2^S), lo = fp16(w * 2^S - hi); S = largest power with max |w| * 2^S <= 2^14 keeps the lo parts of all but
+// negligible weights out of fp16's subnormal range.  *unscale = 2^-(S + 4) (4 = the kernel's activation scale).
+static std::vector<uint16_t> pack_w16(const std::vector<float>& w, int Kpad, int CoutPad, float* unscale) {
+    std::vector<uint16_t> o(w.size() * 2);
+    float mx = 0.0f;
+    for (float x : w) { const float ax = std::fabs(x); if (ax > mx) mx = ax; }
+    int S = 0;
+    if (mx > 0.0f && std::isfinite(mx)) { int e; std::frexp(mx, &e); S = 14 - e; }     // mx = f * 2^e, f in [0.5, 1)
+    if (S > 40) S = 40;
+    if (S < -40) S = -40;
+    *unscale = std::ldexp(1.0f, -(S + 4));
+    for (int k = 0; k < Kpad; k++) {
+        const int kt = k >> 4, kk = k & 15;
+        for (int n = 0; n < CoutPad; n++) {
+            const float x = std::ldexp(w[(size_t)k * CoutPad + n], S);
+            const _Float16 hi = (_Float16)x;
+            const _Float16 lo = (_Float16)(x - (float)hi);
+            uint16_t hb, lb; memcpy(&hb, &hi, 2); memcpy(&lb, &lo, 2);
+            o[(((size_t)kt * 2 + 0) * CoutPad + n) * 16 + kk] = hb;
+            o[(((size_t)kt * 2 + 1) * CoutPad + n) * 16 + kk] = lb;
+        }
     }
     return o;
 }
@@ -409,6 +437,10 @@ static int make_conv(cald_model* m, ConvLayer& L, const std::vector<std::string>
     if (L.CoutPad % 128 == 0 && L.Cin % 16 == 0 && kh * kw <= 32) {   // conv_p4.hip layout
         std::vector<float> w4 = pack_w4(w, L.Kpad, L.CoutPad);
         if ((rc = upload(m, w4, &L.w4))) return rc;
+    }
+    if (m->cfg.precision == CALD_PRECISION_F16X3 && L.CoutPad % 64 == 0 && ((L.Cin % 16 == 0 && kh * kw <= 32) || L.Cin == 4)) {   // conv_h3.hip layout
+        std::vector<uint16_t> w16 = pack_w16(w, L.Kpad, L.CoutPad, &L.w16_unscale);
+        if ((rc = upload(m, w16, &L.w16))) return rc;
     }
     if (!bkeys.empty()) {
         std::vector<float> b(L.CoutPad, 0.0f); int o = 0;
@@ -587,7 +619,7 @@ static int conv_on(cald_model* m, const ConvLayer& L, const float* in, float* ou
                    bool in_relu = false) {
     ConvArgs a;
     const BatchPlan* dp = m->ctx->d_plan;
-    a.in = in; a.out = out; a.w = L.w; a.w4 = L.w4; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift;
+    a.in = in; a.out = out; a.w = L.w; a.w4 = L.w4; a.w16 = L.w16; a.w16_unscale = L.w16_unscale; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift;
     a.residual = residual; a.up = up;
     a.seg_in = dp->seg[lin]; a.seg_out = dp->seg[lout]; a.seg_up = dp->seg[lup];
     a.dyn_rows = dyn; a.V = V;
@@ -844,9 +876,9 @@ extern "C" int cald_debug_tensor(cald_model* m, const char* name, int view, floa
 // =============================================================================================
 // operator-level entry points
 // =============================================================================================
-extern "C" int cald_op_conv2d(cald_ctx* c, const float* in, int H, int W, int Cin, const float* weight, int Cout, int KH, int KW,
-                              int stride, int pad, const float* bias, const float* bn_scale, const float* bn_shift,
-                              const float* residual, int relu, float* out) {
+static int op_conv2d(cald_ctx* c, int precision, const float* in, int H, int W, int Cin, const float* weight, int Cout, int KH, int KW,
+                     int stride, int pad, const float* bias, const float* bn_scale, const float* bn_shift,
+                     const float* residual, int relu, float* out) {
     if (!c || !in || !weight || !out) return fail(CALD_ERR_INVALID, "null argument");
     if (Cin % 4) return fail(CALD_ERR_INVALID, "Cin must be a multiple of 4");
     HIPCHK(hipSetDevice(c->device));
@@ -875,13 +907,19 @@ extern "C" int cald_op_conv2d(cald_ctx* c, const float* in, int H, int W, int Ci
         HIPCHK(hipMalloc((void**)&d_w4, w4.size() * 4));
         HIPCHK(hipMemcpy(d_w4, w4.data(), w4.size() * 4, hipMemcpyHostToDevice));
     }
+    uint16_t* d_w16 = nullptr; float w16_unscale = 1.0f;
+    if (precision == CALD_PRECISION_F16X3 && CoutPad % 64 == 0 && ((Cin % 16 == 0 && KH * KW <= 32) || Cin == 4)) {
+        std::vector<uint16_t> w16 = pack_w16(w, Kpad, CoutPad, &w16_unscale);
+        HIPCHK(hipMalloc((void**)&d_w16, w16.size() * 2));
+        HIPCHK(hipMemcpy(d_w16, w16.data(), w16.size() * 2, hipMemcpyHostToDevice));
+    }
     HIPCHK(hipMemcpy(d_b, b.data(), b.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_sc, sc.data(), sc.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_sh, sh.data(), sh.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_p, &P, sizeof(P), hipMemcpyHostToDevice));
     if (residual) { HIPCHK(hipMalloc((void**)&d_res, (size_t)Ho * Wo * Cout * 4)); HIPCHK(hipMemcpy(d_res, residual, (size_t)Ho * Wo * Cout * 4, hipMemcpyHostToDevice)); }
     ConvArgs a; memset(&a, 0, sizeof(a));
-    a.in = d_in; a.out = d_out; a.w = d_w; a.w4 = d_w4; a.bias = bias ? d_b : nullptr; a.scale = bn_scale ? d_sc : nullptr; a.shift = bn_scale ? d_sh : nullptr;
+    a.in = d_in; a.out = d_out; a.w = d_w; a.w4 = d_w4; a.w16 = d_w16; a.w16_unscale = w16_unscale; a.bias = bias ? d_b : nullptr; a.scale = bn_scale ? d_sc : nullptr; a.shift = bn_scale ? d_sh : nullptr;
     a.residual = d_res; a.up = nullptr; a.seg_in = d_p->seg[0]; a.seg_out = d_p->seg[1]; a.seg_up = d_p->seg[1]; a.dyn_rows = nullptr;
     a.V = 1; a.Cin = Cin; a.Cout = Cout; a.CoutPad = CoutPad; a.Kpad = Kpad; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
     a.relu = relu; a.total_mtiles = (Ho * Wo + 127) / 128; a.out_ld = Cout; a.in_relu = 0; a.zeros = c->d_zeros;
@@ -890,8 +928,19 @@ extern "C" int cald_op_conv2d(cald_ctx* c, const float* in, int H, int W, int Ci
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemcpy(out, d_out, (size_t)Ho * Wo * Cout * 4, hipMemcpyDeviceToHost));
     if (d_w4) hipFree(d_w4);
+    if (d_w16) hipFree(d_w16);
     hipFree(d_in); hipFree(d_out); hipFree(d_w); hipFree(d_b); hipFree(d_sc); hipFree(d_sh); hipFree(d_p); if (d_res) hipFree(d_res);
     return 0;
+}
+extern "C" int cald_op_conv2d(cald_ctx* c, const float* in, int H, int W, int Cin, const float* weight, int Cout, int KH, int KW,
+                              int stride, int pad, const float* bias, const float* bn_scale, const float* bn_shift,
+                              const float* residual, int relu, float* out) {
+    return op_conv2d(c, CALD_PRECISION_FP32, in, H, W, Cin, weight, Cout, KH, KW, stride, pad, bias, bn_scale, bn_shift, residual, relu, out);
+}
+extern "C" int cald_op_conv2d_f16x3(cald_ctx* c, const float* in, int H, int W, int Cin, const float* weight, int Cout, int KH, int KW,
+                                    int stride, int pad, const float* bias, const float* bn_scale, const float* bn_shift,
+                                    const float* residual, int relu, float* out) {
+    return op_conv2d(c, CALD_PRECISION_F16X3, in, H, W, Cin, weight, Cout, KH, KW, stride, pad, bias, bn_scale, bn_shift, residual, relu, out);
 }
 
 // helper: device detection buffers

@@ -29,6 +29,8 @@ struct ConvArgs {
     float* out;
     const float* w;        // [Kpad][CoutPad], K order (kh, kw, cin)
     const float* w4;       // same weights packed [Kpad/16][2][CoutPad][2][4] for conv_p4.hip (k = 16 kt + 8 kq + 2 j + h), or null
+    const void* w16;       // fp16 hi/lo split of the same weights * 2^S, [Kpad/16][2 (hi, lo)][CoutPad][16] (conv_h3.hip), or null
+    float w16_unscale;     // 2^-(S + 4): undoes the weight scale 2^S and conv_h3's activation scale 2^4 (exact powers of two)
     const float* bias;     // [CoutPad] or null
     const float* scale;    // FrozenBN scale/shift or null
     const float* shift;

@@ -1,0 +1,296 @@
+// conv_h3.hip -- the "fp16 MFMA path" of BASELINE.json configs[4], built so that it still meets the fp32 parity bar
+// (consistency within 1e-4, identical top-k): every fp32 operand is split into two fp16 values,
+//     x = hi + lo,  hi = fp16(x),  lo = fp16(x - hi)                      (22 significant bits)
+// and a product a*b is evaluated as  a_lo*b_hi + a_hi*b_lo + a_hi*b_hi  with three v_mfma_f32_32x32x16_f16 into
+// the same fp32 accumulator (the a_lo*b_lo term, 2^-22 relative, is dropped).  The fp16 matrix pipe is 16x the
+// fp32-input one (32 cycles per 32x32x16 vs 64 cycles per 32x32x2), so three passes are ~5x faster than
+// conv_p4.hip's exact v_mfma_f32_32x32x2_f32 chain.  NOT bit-identical to the oracle (different rounding, ~1e-7
+// relative like any other fp32 implementation) -- this mode is opt-in (cald_model_cfg.precision = 1) and is checked
+// against the oracle to the tolerance, not bit for bit; the default mode stays the exact one.
+// fp16 has a narrow exponent range: the lo part of a small operand would be subnormal (absolute step 2^-24, e.g.
+// only ~1e-6 relative for a weight of 0.03).  Both operands are therefore scaled by exact powers of two before the
+// split -- weights by 2^S per layer at finalize (max |w| * 2^S <= 2^14), activations by 2^4 while staging -- and the
+// accumulator is multiplied by 2^-(S+4) first thing in the epilogue (exact).  Range: |activation| < 4094.
+//
+// Same implicit-GEMM structure as conv_p4.hip: 128 x 128 x 16 tiles, 4 waves (64 x 64 each), buffer loads with
+// hardware zero fill for out-of-image taps, XCD-aware tile map, fused fp32 epilogue.  Activations stay fp32 in HBM
+// (split while staging into LDS); weights are split and packed at model finalize (ConvArgs::w16).
+// LDS tile (16 KB): planes A_hi, A_lo, B_hi, B_lo of [128][16] fp16; a lane's MFMA operand (8 consecutive k of one
+// row) is one ds_read_b128, 16-byte halves XOR-swizzled with bit 3 of the row (conflict-free).  Two tile buffers,
+// one barrier per k-tile: the fragments of tile t+1 are read right after the barrier of tile t, under the
+// a_hi*b_hi MFMAs of tile t.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+// TN = 2: 128 x 128 tiles (64 x 64 per wave); TN = 1: 128 x 64 tiles (64 x 32 per wave) for 64-wide layers.
+// C4: Cin == 4 (the stem conv on the NHWC4 input): a thread's four consecutive k are one filter tap, so the tap
+// (kh, kw) and its validity are per-thread quantities instead of wave-uniform ones.
+template <int EPI, int TN, bool C4>
+__global__ __launch_bounds__(256, 3) void conv_h3_kernel(const ConvArgs a) {
+    constexpr int BM = 128, BN = 64 * TN, BK = 16, TM = 2, WN = 2;
+    constexpr int PLANE = BM * 32, PLANE_B = BN * 32, TILE_B = 2 * PLANE + 2 * PLANE_B;       // bytes
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE_B];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int NT = a.CoutPad / BN;
+    int mt, nt;
+    {
+        const int b = blockIdx.x, MT = a.total_mtiles, MT8 = MT & ~7;
+        if (b < MT8 * NT) { const int xcd = b & 7, idx = b >> 3; mt = (idx / NT) * 8 + xcd; nt = idx % NT; }
+        else { const int r = b - MT8 * NT; mt = MT8 + r / NT; nt = r % NT; }
+    }
+    const int n0 = nt * BN;
+    int v = 0;
+    while (v + 1 < a.V && a.seg_out[v + 1].tile_start <= mt) v++;
+    const LevelSeg so = a.seg_out[v];
+    const LevelSeg si = a.seg_in[v];
+    const int Ho = so.H, Wo = so.W, Hi = si.H, Wi = si.W;
+    int Mv = Ho * Wo;
+    if (a.dyn_rows) { const int d = a.dyn_rows[v]; Mv = d < Mv ? d : Mv; }
+    const int m0 = (mt - so.tile_start) * BM;
+    if (m0 >= Mv) return;
+    const float* __restrict__ in_v = a.in + si.pix_off * (long long)a.Cin;
+    const int Cin = a.Cin, KW = a.KW, KH = a.KH, CoutPad = a.CoutPad;
+    const bool in_relu = a.in_relu != 0;
+
+    // ---- A gather: rows arow, arow + 64; k group g = 4 consecutive k ----
+    const int g = tid & 3, arow = tid >> 2;
+    unsigned rowmask[2];
+    int rowvoff[2], riy0[2], rix0[2];
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        const int m = m0 + arow + 64 * p;
+        const int oy = m / Wo, ox = m - oy * Wo;
+        const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
+        unsigned msk = 0;
+        if (!C4 && m < Mv)
+            for (int t = 0; t < KH * KW; t++) {
+                const int th = t / KW, tw = t - th * KW;
+                const int iy = iy0 + th, ix = ix0 + tw;
+                if (iy >= 0 && iy < Hi && ix >= 0 && ix < Wi) msk |= 1u << t;
+            }
+        rowmask[p] = msk;
+        rowvoff[p] = (((oy * a.stride) * Wi + ox * a.stride) * Cin + (C4 ? 0 : 4 * g)) * 4;
+        riy0[p] = m < Mv ? iy0 : -0x40000000; rix0[p] = ix0;
+    }
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(in_v - (long long)a.pad * (Wi + 1) * Cin), 0, 0x7FFE0000, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(reinterpret_cast<const unsigned char*>(a.w16) + (long long)n0 * 32), 0, 0x7FFE0000, 0x00020000);
+    int u_kh = 0, u_kw = 0, u_ci = 0, u_kt = 0;
+    // A LDS write offsets (bytes, hi plane): k = 4g .. 4g+3 -> 16-byte half g >> 1, 8-byte slot g & 1
+    int aw_off[2];
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        const int r = arow + 64 * p;
+        aw_off[p] = r * 32 + (((g >> 1) ^ ((r >> 3) & 1)) * 16) + (g & 1) * 8;
+    }
+    // B: plane p (hi, lo) x n_l x 16-byte half.  TN = 2: two 16-byte pieces per thread (plane 0 and 1);
+    // TN = 1: one piece per thread (plane = tid >> 7)
+    const int b_t = TN == 2 ? tid : (tid & 127), b_p = TN == 2 ? 0 : (tid >> 7);
+    const int b_nl = b_t >> 1, b_h = b_t & 1;
+    const int bvoff0 = b_p * CoutPad * 32 + b_nl * 32 + b_h * 16, bvoff1 = bvoff0 + CoutPad * 32;
+    const int bw_off0 = 2 * PLANE + b_p * PLANE_B + b_nl * 32 + ((b_h ^ ((b_nl >> 3) & 1)) * 16), bw_off1 = bw_off0 + PLANE_B;
+
+    f32x4 ra0, ra1;
+    i32x4 rb0, rb1 = {0, 0, 0, 0};
+
+#define H3_LOAD()                                                                                          \
+    {                                                                                                      \
+        const int soffB = u_kt * 2 * CoutPad * 32;                                                         \
+        int soffA, v0, v1;                                                                                 \
+        if (C4) {                                                                                          \
+            const int tap = u_kt * 4 + g, th = tap / KW, tw = tap - th * KW;                               \
+            const int toff = (th * Wi + tw) * 16;                                                          \
+            const bool ok0 = th < KH && (unsigned)(riy0[0] + th) < (unsigned)Hi && (unsigned)(rix0[0] + tw) < (unsigned)Wi; \
+            const bool ok1 = th < KH && (unsigned)(riy0[1] + th) < (unsigned)Hi && (unsigned)(rix0[1] + tw) < (unsigned)Wi; \
+            soffA = 0;                                                                                     \
+            v0 = ok0 ? rowvoff[0] + toff : 0x7FFF0000;                                                     \
+            v1 = ok1 ? rowvoff[1] + toff : 0x7FFF0000;                                                     \
+        } else {                                                                                           \
+            const unsigned u_bit = 1u << (u_kh * KW + u_kw);                                               \
+            soffA = ((u_kh * Wi + u_kw) * Cin + u_ci) * 4;                                                 \
+            v0 = (rowmask[0] & u_bit) ? rowvoff[0] : 0x7FFF0000;                                           \
+            v1 = (rowmask[1] & u_bit) ? rowvoff[1] : 0x7FFF0000;                                           \
+        }                                                                                                  \
+        ra0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, v0, soffA, 0));         \
+        ra1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, v1, soffA, 0));         \
+        rb0 = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, bvoff0, soffB, 0));     \
+        if (TN == 2) rb1 = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, bvoff1, soffB, 0)); \
+        u_kt++; u_ci += BK;                                                                                \
+        if (u_ci >= Cin) { u_ci = 0; u_kw++; if (u_kw == KW) { u_kw = 0; u_kh++; } }                       \
+    }
+#define H3_STORE(BUF)                                                                                      \
+    {                                                                                                      \
+        if (in_relu) {                                                                                     \
+            _Pragma("unroll") for (int q = 0; q < 4; q++) { ra0[q] = ra0[q] < 0.f ? 0.f : ra0[q]; ra1[q] = ra1[q] < 0.f ? 0.f : ra1[q]; } \
+        }                                                                                                  \
+        unsigned char* tb = smem + (BUF) * TILE_B;                                                         \
+        ra0 = ra0 * 16.0f; ra1 = ra1 * 16.0f;                                                              \
+        const h4 hi0 = __builtin_convertvector(ra0, h4), hi1 = __builtin_convertvector(ra1, h4);           \
+        const h4 lo0 = __builtin_convertvector(ra0 - __builtin_convertvector(hi0, f32x4), h4);             \
+        const h4 lo1 = __builtin_convertvector(ra1 - __builtin_convertvector(hi1, f32x4), h4);             \
+        *reinterpret_cast<h4*>(tb + aw_off[0]) = hi0;                                                      \
+        *reinterpret_cast<h4*>(tb + PLANE + aw_off[0]) = lo0;                                              \
+        *reinterpret_cast<h4*>(tb + aw_off[1]) = hi1;                                                      \
+        *reinterpret_cast<h4*>(tb + PLANE + aw_off[1]) = lo1;                                              \
+        *reinterpret_cast<i32x4*>(tb + bw_off0) = rb0;                                                     \
+        if (TN == 2) *reinterpret_cast<i32x4*>(tb + bw_off1) = rb1;                                        \
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+
+    const int KT = a.Kpad / BK;
+    H3_LOAD();
+    H3_STORE(0);
+    if (KT > 1) H3_LOAD();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // fragment read offsets (bytes) inside a tile buffer: hi plane; lo plane = + PLANE
+    const int kh_lane = lane >> 5, l31 = lane & 31;
+    int fo_a[TM], fo_b[TN];
+#pragma unroll
+    for (int t = 0; t < TM; t++) { const int m = wm * 64 + t * 32 + l31; fo_a[t] = m * 32 + ((kh_lane ^ ((m >> 3) & 1)) * 16); }
+#pragma unroll
+    for (int t = 0; t < TN; t++) { const int n = wn * 32 * TN + t * 32 + l31; fo_b[t] = 2 * PLANE + n * 32 + ((kh_lane ^ ((n >> 3) & 1)) * 16); }
+    h8 ah0[TM], al0[TM], bh0[TN], bl0[TN], ah1[TM], al1[TM], bh1[TN], bl1[TN];
+
+#define H3_READ(AH, AL, BH, BL, TB)                                                                        \
+    {                                                                                                      \
+        _Pragma("unroll") for (int t = 0; t < TM; t++) {                                                   \
+            AH[t] = *reinterpret_cast<const h8*>((TB) + fo_a[t]);                                          \
+            AL[t] = *reinterpret_cast<const h8*>((TB) + PLANE + fo_a[t]);                                  \
+        }                                                                                                  \
+        _Pragma("unroll") for (int t = 0; t < TN; t++) {                                                   \
+            BH[t] = *reinterpret_cast<const h8*>((TB) + fo_b[t]);                                          \
+            BL[t] = *reinterpret_cast<const h8*>((TB) + PLANE_B + fo_b[t]);                                \
+        }                                                                                                  \
+    }
+#define H3_MFMA(FA, FB)                                                                                    \
+    _Pragma("unroll") for (int i = 0; i < TM; i++)                                                         \
+        _Pragma("unroll") for (int j = 0; j < TN; j++)                                                     \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(FA[i], FB[j], acc[i][j], 0, 0, 0);
+    // one k-tile: operands in (AH, AL, BH, BL); the next tile's operands are read into (NAH, ...)
+#define H3_TILE(AH, AL, BH, BL, NAH, NAL, NBH, NBL)                                                        \
+    {                                                                                                      \
+        const int nxt = cur ^ 1;                                                                           \
+        const bool has1 = kt + 1 < KT, has2 = kt + 2 < KT;                                                 \
+        H3_MFMA(AL, BH)                                                                                    \
+        if (has1) H3_STORE(nxt)                                                                            \
+        H3_MFMA(AH, BL)                                                                                    \
+        if (has2) H3_LOAD()                                                                                \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                 \
+        __builtin_amdgcn_s_barrier();                                                                      \
+        if (has1) H3_READ(NAH, NAL, NBH, NBL, smem + nxt * TILE_B)                                         \
+        H3_MFMA(AH, BH)                                                                                    \
+        cur = nxt; kt++;                                                                                   \
+    }
+
+    H3_READ(ah0, al0, bh0, bl0, smem)
+    int cur = 0, kt = 0;
+    while (kt + 1 < KT) {
+        H3_TILE(ah0, al0, bh0, bl0, ah1, al1, bh1, bl1)
+        H3_TILE(ah1, al1, bh1, bl1, ah0, al0, bh0, bl0)
+    }
+    if (kt < KT) H3_TILE(ah0, al0, bh0, bl0, ah1, al1, bh1, bl1)
+#undef H3_LOAD
+#undef H3_STORE
+#undef H3_READ
+#undef H3_MFMA
+#undef H3_TILE
+
+    // ---- fused fp32 epilogue: the same operations as conv_p4.hip ----
+    const int out_ld = a.out_ld;
+    float* __restrict__ out_v = a.out + so.pix_off * (long long)out_ld;
+    const float* __restrict__ ex_v = nullptr;
+    int upH = 1, upW = 1;
+    float uph_s = 0.f, upw_s = 0.f;
+    if (EPI == 1) ex_v = a.residual + so.pix_off * (long long)out_ld;
+    if (EPI == 2) {
+        const LevelSeg su = a.seg_up[v];
+        ex_v = a.up + su.pix_off * (long long)out_ld;
+        upH = su.H; upW = su.W;
+        uph_s = (float)upH / (float)Ho; upw_s = (float)upW / (float)Wo;
+    }
+    const bool relu = a.relu != 0;
+    const int Mlast = Mv - 1;
+    const float unscale = a.w16_unscale;
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+        const int n = n0 + wn * TN * 32 + j * 32 + l31;
+        const bool nok = n < a.Cout;
+        const int nc = nok ? n : 0;
+        const float bs = a.bias ? a.bias[nc] : 0.0f;
+        const float sc = a.scale ? a.scale[nc] : 1.0f;
+        const float sh = a.scale ? a.shift[nc] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+            const int mbase = m0 + wm * TM * 32 + i * 32 + 4 * kh_lane;
+            float extra[16];
+            if (EPI != 0) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    int m = mbase + (r & 3) + 8 * (r >> 2);
+                    m = m < Mlast ? m : Mlast;
+                    if (EPI == 1) {
+                        extra[r] = ex_v[(long long)m * out_ld + nc];
+                    } else {
+                        const int oy = m / Wo, ox = m - oy * Wo;
+                        int sy = (int)floorf((float)oy * uph_s); sy = sy > upH - 1 ? upH - 1 : sy;
+                        int sx = (int)floorf((float)ox * upw_s); sx = sx > upW - 1 ? upW - 1 : sx;
+                        extra[r] = ex_v[(long long)(sy * upW + sx) * out_ld + nc];
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int m = mbase + (r & 3) + 8 * (r >> 2);
+                float val = acc[i][j][r] * unscale;
+                val = val + bs;
+                val = val * sc;
+                val = val + sh;
+                if (EPI != 0) val = val + extra[r];
+                if (relu) val = val > 0.0f ? val : 0.0f;
+                if (m < Mv && nok) out_v[(long long)m * out_ld + n] = val;
+            }
+        }
+    }
+}
+
+// returns true if this variant handled the launch
+bool launch_conv_h3(const ConvArgs& a, hipStream_t stream) {
+    if (!a.w16 || a.CoutPad % 64 != 0) return false;
+    dim3 block(256);
+    if (a.Cin == 4) {      // stem conv (7 x 7, NHWC4 input): per-thread taps
+        if (a.residual || a.up || a.in_relu) return false;
+        if (a.CoutPad % 128 == 0) hipLaunchKernelGGL((conv_h3_kernel<0, 2, true>), dim3((unsigned)(a.total_mtiles * (a.CoutPad / 128))), block, 0, stream, a);
+        else hipLaunchKernelGGL((conv_h3_kernel<0, 1, true>), dim3((unsigned)(a.total_mtiles * (a.CoutPad / 64))), block, 0, stream, a);
+        return true;
+    }
+    if (a.Cin % 16 != 0 || a.KH * a.KW > 32) return false;
+    if (a.CoutPad % 128 == 0) {
+        dim3 grid((unsigned)(a.total_mtiles * (a.CoutPad / 128)));
+        if (a.residual) hipLaunchKernelGGL((conv_h3_kernel<1, 2, false>), grid, block, 0, stream, a);
+        else if (a.up) hipLaunchKernelGGL((conv_h3_kernel<2, 2, false>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((conv_h3_kernel<0, 2, false>), grid, block, 0, stream, a);
+    } else {
+        dim3 grid((unsigned)(a.total_mtiles * (a.CoutPad / 64)));
+        if (a.residual) hipLaunchKernelGGL((conv_h3_kernel<1, 1, false>), grid, block, 0, stream, a);
+        else if (a.up) hipLaunchKernelGGL((conv_h3_kernel<2, 1, false>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((conv_h3_kernel<0, 1, false>), grid, block, 0, stream, a);
+    }
+    return true;
+}

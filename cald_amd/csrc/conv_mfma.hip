@@ -282,10 +282,12 @@ static void launch_cfg(const ConvArgs& a, int bn, hipStream_t stream) {
 
 bool launch_conv_p3(const ConvArgs& a, hipStream_t stream);   // conv_p3.hip
 bool launch_conv_p4(const ConvArgs& a, hipStream_t stream);   // conv_p4.hip
+bool launch_conv_h3(const ConvArgs& a, hipStream_t stream);   // conv_h3.hip (opt-in split-fp16 mode: only when a.w16 is set)
 
 void launch_conv(const ConvArgs& a, hipStream_t stream) {
     static const int p3 = conv_env("CALD_CONV_P3", 1);   // pipelined 3-buffer schedule for 128-wide tiles (conv_p3.hip); 0 = this file only
     static const int p4 = conv_env("CALD_CONV_P4", 1);   // conv_p4.hip: p3 + 128-bit LDS fragment reads
+    if (a.w16 && launch_conv_h3(a, stream)) return;
     if (p3 && p4 && launch_conv_p4(a, stream)) return;
     if (p3 && launch_conv_p3(a, stream)) return;
     static const int bk32 = conv_env("CALD_CONV_BK32", 0);

@@ -32,6 +32,14 @@ typedef struct cald_model cald_model;
 #define CALD_ERR_MISSING_WEIGHT (-4)
 #define CALD_ERR_UNSUPPORTED (-5)   /* input outside the supported set (e.g. progressive JPEG) */
 
+/* arithmetic of the conv / linear GEMMs.
+ *   FP32   exact: one k-ordered fp32 fma chain per output (v_mfma_f32_32x32x2_f32), bit-identical to the oracle.
+ *   F16X3  the "fp16 MFMA path" of BASELINE.json configs[4]: operands split into fp16 hi + lo, three
+ *          v_mfma_f32_32x32x16_f16 per product into fp32 accumulators (~22-bit operands, ~1e-7 relative): meets the
+ *          1e-4 / identical-top-k bar but is NOT bit-identical; |activations| must stay below 65504. */
+#define CALD_PRECISION_FP32 0
+#define CALD_PRECISION_F16X3 1
+
 #define CALD_ARCH_FRCNN 0      /* detection/frcnn_la.py FRCNN_Feature */
 #define CALD_ARCH_RETINANET 1  /* detection/retinanet_cal.py RetinaNet */
 
@@ -57,6 +65,7 @@ typedef struct cald_model_cfg {
     int rpn_pre_nms_top_n;  /* 1000 */
     int rpn_post_nms_top_n; /* 1000 */
     float rpn_nms_thresh;   /* 0.7 */
+    int precision;          /* CALD_PRECISION_* (0 = exact fp32, the default and the parity contract) */
 } cald_model_cfg;
 
 int cald_model_create(cald_ctx* ctx, const cald_model_cfg* cfg, cald_model** out);
@@ -155,6 +164,11 @@ int cald_op_augment(cald_ctx* ctx, int kind, double param, uint64_t seed, const 
 int cald_op_conv2d(cald_ctx* ctx, const float* in, int H, int W, int Cin, const float* weight, int Cout, int KH, int KW,
                    int stride, int pad, const float* bias, const float* bn_scale, const float* bn_shift,
                    const float* residual, int relu, float* out);
+/* the same convolution in CALD_PRECISION_F16X3 (conv_h3.hip); falls back to the exact kernels for shapes it does not
+ * cover (Cin % 16 != 0 or Cout not tiled by 128), exactly as inside a model */
+int cald_op_conv2d_f16x3(cald_ctx* ctx, const float* in, int H, int W, int Cin, const float* weight, int Cout, int KH, int KW,
+                         int stride, int pad, const float* bias, const float* bn_scale, const float* bn_shift,
+                         const float* residual, int relu, float* out);
 /* detector-transform size (GeneralizedRCNNTransform): resized and padded sizes */
 int cald_op_transform_size(int H, int W, int min_size, int max_size, int* Hr, int* Wr, int* Hp, int* Wp);
 /* intermediate tensors of the LAST cald_forward (parity debugging): name in

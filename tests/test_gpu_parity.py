@@ -155,6 +155,33 @@ def test_conv_mfma_bit_exact(hip, oracle, case):
     assert out.tobytes() == want.tobytes(), "max abs diff %g" % float(np.abs(out - want).max())
 
 
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_f16x3_within_split_precision_of_exact(hip, oracle, case):
+    """CALD_PRECISION_F16X3 (conv_h3.hip): operands split into fp16 hi + lo (22 bits), three fp16 MFMAs per product.
+    Error bound per output: 2^-20 * sum_k |a_k| |w_k| (dropped lo*lo term + operand truncation), plus fp32 accumulation
+    noise -- checked against the exact oracle chain.  Shapes the kernel does not cover run on the exact kernels."""
+    H, W, Cin, Cout, K, stride, pad, bias, bn, res, relu = case
+    ffi, L = hip["ffi"], hip["L"]
+    rs = np.random.RandomState(H * 1000 + Cout)
+    x = rs.randn(H, W, Cin).astype(np.float32)
+    x[rs.rand(H, W, Cin) < 0.3] = 0.0
+    w = (rs.randn(Cout, Cin, K, K) * np.sqrt(2.0 / (Cin * K * K))).astype(np.float32)
+    b = rs.randn(Cout).astype(np.float32) if bias else None
+    sc = (0.5 + rs.rand(Cout)).astype(np.float32) if bn else None
+    sh = rs.randn(Cout).astype(np.float32) if bn else None
+    Ho, Wo = (H + 2 * pad - K) // stride + 1, (W + 2 * pad - K) // stride + 1
+    r = rs.randn(Ho, Wo, Cout).astype(np.float32) if res else None
+    out = np.empty((Ho, Wo, Cout), np.float32)
+    ffi.check(L.cald_op_conv2d_f16x3(hip["ctx"], ffi.ptr(x), H, W, Cin, ffi.ptr(w), Cout, K, K, stride, pad, ffi.ptr(b), ffi.ptr(sc),
+                                     ffi.ptr(sh), ffi.ptr(r), int(relu), ffi.ptr(out)))
+    wk = np.ascontiguousarray(w.transpose(2, 3, 1, 0).reshape(-1, Cout))
+    want = oracle.conv2d(x, wk, K, K, stride, pad, bias=b, bn=(sc, sh) if bn else None, residual=r, relu=relu)
+    mag = oracle.conv2d(np.abs(x), np.abs(wk), K, K, stride, pad)                # sum_k |a_k| |w_k|
+    bound = (mag * (np.abs(sc) if bn else 1.0)) * 2.0 ** -20 + 1e-6
+    err = np.abs(out - want)
+    assert np.all(err <= bound), "max err %g, max err/bound %g" % (float(err.max()), float((err / bound).max()))
+
+
 @pytest.fixture(scope="module")
 def small_model(hip, oracle):
     from cald_amd import synth
@@ -286,6 +313,36 @@ def test_sweep_every_augmentation_branch_matches_oracle(hip, oracle, small_model
     wc, wcls = oracle.get_uncertainty(P, pool, augs, 21, bp=1.3, min_size=300, max_size=500, base_seed=3, positions=[4, 9])
     np.testing.assert_array_equal(cons, np.array(wc))
     np.testing.assert_array_equal(cls, np.stack(wcls))
+
+
+def test_f16x3_mode_meets_the_parity_bar_against_the_exact_mode(hip):
+    """CALD_PRECISION_F16X3 (BASELINE configs[4]'s "fp16 MFMA path", conv_h3.hip) is not bit-identical by design; the bar
+    it has to meet is north_star's: consistency within 1e-4 and identical selection order.  The exact mode is
+    bit-identical to the oracle (tests above), so it stands in for the oracle here: 96 full-size VOC-shaped images."""
+    torch = hip["torch"]
+    from cald_amd import synth, sweep
+    sd = synth.pseudo_trained_frcnn(21, 50, seed=0)
+    models = {}
+    for prec in ("fp32", "f16x3"):
+        m = hip["det"].fasterrcnn_resnet50_fpn_feature(num_classes=21, min_size=600, max_size=1000, precision=prec).to("cuda")
+        m.load_state_dict(sd)
+        models[prec] = m.eval()
+    pool = [torch.from_numpy(im).cuda() for im in synth.make_pool(96, "voc", 0)]
+    pos = list(range(len(pool)))
+    augs = ["flip", "cut_out", "smaller_resize"]
+    ce, le = sweep.sweep_device_images(models["fp32"], pool, pos, augs, bp=1.3, base_seed=0)
+    ch, lh = sweep.sweep_device_images(models["f16x3"], pool, pos, augs, bp=1.3, base_seed=0)
+    print("f16x3 vs exact: max |d consistency| %.3g, median |d cls_corr| %.3g, max %.3g" % (
+        np.abs(ce - ch).max(), np.median(np.abs(le - lh)[le > 0]), np.abs(le - lh).max()))
+    assert float(np.abs(ce - ch).max()) <= 1e-4, float(np.abs(ce - ch).max())          # the ranking quantity
+    np.testing.assert_array_equal(np.argsort(ce, kind="stable"), np.argsort(ch, kind="stable"))
+    # cls_corr = per-class max detection score: a borderline NMS / threshold decision that flips between two
+    # non-identical fp32-grade implementations shows up as a whole score; such flips must stay rare
+    d = np.abs(le - lh)
+    assert float(np.median(d[le > 0])) <= 1e-5
+    assert float((d > 1e-4).mean()) <= 0.005, float((d > 1e-4).mean())
+    print("f16x3 vs exact: max |d consistency| %.3g, median |d cls_corr| %.3g, max %.3g" % (
+        np.abs(ce - ch).max(), np.median(np.abs(le - lh)[le > 0]), np.abs(le - lh).max()))
 
 
 def test_resnet101_coco_classes_forward(hip, oracle):
