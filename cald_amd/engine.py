@@ -68,3 +68,43 @@ def write_voc_results_file(all_boxes, image_index, path, classes, root='/tmp'):
                         index, float(dets[k, -1]), float(dets[k, 0]) + 1, float(dets[k, 1]) + 1,
                         float(dets[k, 2]) + 1, float(dets[k, 3]) + 1))
     return out_dir
+
+
+def coco_predictions(model, data_loader, batch_views=64):
+    """Forward half of detection/engine.py:178-205 (``coco_evaluate``): ``{image_id: output dict on the CPU}`` for the
+    whole loader, which is what ``CocoEvaluator.update`` receives there one image at a time.  Batched on the GPU."""
+    model.eval()
+    res, pending = {}, []
+
+    def flush():
+        if not pending:
+            return
+        outs = model([im for im, _ in pending])
+        for (_, image_id), o in zip(pending, outs):
+            res[image_id] = {k: v.cpu() for k, v in o.items() if k != 'features'}
+        pending.clear()
+
+    for images, targets in data_loader:
+        for img, t in zip(images, targets):
+            image_id = t["image_id"].item() if hasattr(t["image_id"], "item") else t["image_id"]
+            pending.append((img, image_id))
+            if len(pending) >= batch_views:
+                flush()
+    flush()
+    return res
+
+
+def coco_results(predictions):
+    """detection/coco_eval.py:76-98 ``prepare_for_coco_detection`` (+ ``convert_to_xywh`` :162-164): the list of
+    ``{"image_id", "category_id", "bbox": [x, y, w, h], "score"}`` records pycocotools' ``loadRes`` consumes."""
+    out = []
+    for original_id, prediction in predictions.items():
+        if len(prediction) == 0:
+            continue
+        xmin, ymin, xmax, ymax = prediction["boxes"].unbind(1)
+        boxes = torch.stack((xmin, ymin, xmax - xmin, ymax - ymin), dim=1).tolist()
+        scores = prediction["scores"].tolist()
+        labels = prediction["labels"].tolist()
+        out.extend({"image_id": original_id, "category_id": labels[k], "bbox": box, "score": scores[k]}
+                   for k, box in enumerate(boxes))
+    return out

@@ -242,6 +242,26 @@ def gen_voc_results():
     print("voc_results ok")
 
 
+def gen_coco_results():
+    """detection/coco_eval.py:76-98 CocoEvaluator.prepare_for_coco_detection on synthetic predictions."""
+    import importlib, json
+    ce = importlib.import_module("detection.coco_eval")
+    rs = np.random.RandomState(6)
+    preds, blob = {}, {}
+    for image_id, n in ((139, 3), (285, 0), (632, 7)):
+        d = {"boxes": torch.from_numpy((rs.rand(n, 4) * 300).astype(np.float32)), "scores": torch.from_numpy(rs.rand(n).astype(np.float32)),
+             "labels": torch.from_numpy(rs.randint(1, 91, n).astype(np.int64))}
+        d["boxes"][:, 2:] += d["boxes"][:, :2]
+        preds[image_id] = d
+        for k, v in d.items():
+            blob["p%d_%s" % (image_id, k)] = v.numpy()
+    ev = ce.CocoEvaluator.__new__(ce.CocoEvaluator)
+    blob["ids"] = np.array(list(preds.keys()))
+    blob["json"] = np.array(json.dumps(ev.prepare_for_coco_detection(preds)))
+    np.savez_compressed(os.path.join(OUT, "coco_results.npz"), **blob)
+    print("coco_results ok")
+
+
 def gen_baselines():
     lt, ls = ref_harness.load_baselines()
     rs = np.random.RandomState(8)
@@ -320,6 +340,7 @@ def main():
     gen_js()
     gen_selection(ct)
     gen_voc_results()
+    gen_coco_results()
     gen_baselines()
 
 

@@ -248,6 +248,25 @@ def test_voc_results_wire_format_matches_reference(golden, tmp_path):
             assert open(os.path.join(out, key[5:])).read() == str(g[key]), key
 
 
+def test_coco_results_wire_format_matches_reference(golden):
+    """engine.coco_results == CocoEvaluator.prepare_for_coco_detection (detection/coco_eval.py:76-98) and
+    engine.coco_predictions builds the {image_id: output} dict coco_evaluate feeds it (detection/engine.py:199-205)."""
+    import json
+    import torch
+    from cald_amd import engine
+    g = golden("coco_results")
+    preds = {int(i): {k: torch.from_numpy(g["p%d_%s" % (i, k)]) for k in ("boxes", "scores", "labels")} for i in g["ids"]}
+    assert json.dumps(engine.coco_results(preds)) == str(g["json"])
+
+    class Model:                       # stands in for the HIP detector: returns the stored dicts in call order
+        def eval(self): return self
+        def __call__(self, images): return [dict(preds[int(im[0, 0, 0])], features=None) for im in images]
+    loader = [((torch.full((3, 4, 4), float(i)),), ({"image_id": torch.tensor(int(i))},)) for i in g["ids"]]
+    got = engine.coco_predictions(Model(), loader, batch_views=2)
+    assert list(got.keys()) == [int(i) for i in g["ids"]] and all("features" not in o for o in got.values())
+    assert json.dumps(engine.coco_results(got)) == str(g["json"])
+
+
 def test_wrapping_a_reference_torch_model_reads_its_configuration():
     """get_uncertainty() accepts the torch model cald_train.py already holds: constructor arguments come from
     the module attributes torchvision exposes, weights from state_dict()."""
