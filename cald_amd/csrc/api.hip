@@ -370,7 +370,7 @@ static std::vector<float> pack_w4(const std::vector<float>& w, int Kpad, int Cou
 // K-major [Kpad][CoutPad] -> fp16 hi / lo planes [Kpad/16][2][CoutPad][16]  (conv_h3.hip): w * 2^S = hi + lo,
 // hi = fp16(w * 2^S), lo = fp16(w * 2^S - hi); S = largest power with max |w| * 2^S <= 2^14 keeps the lo parts of all but
 // negligible weights out of fp16's subnormal range.  *unscale = 2^-(S + 4) (4 = the kernel's activation scale).
-static std::vector<uint16_t> pack_w16(const std::vector<float>& w, int Kpad, int CoutPad, float* unscale) {
+static std::vector<uint16_t> pack_w16(const std::vector<float>& w, int Kpad, int CoutPad, float* unscale, int KH, int KW, int Cin) {
     std::vector<uint16_t> o(w.size() * 2);
     float mx = 0.0f;
     for (float x : w) { const float ax = std::fabs(x); if (ax > mx) mx = ax; }
@@ -379,8 +379,15 @@ static std::vector<uint16_t> pack_w16(const std::vector<float>& w, int Kpad, int
     if (S > 40) S = 40;
     if (S < -40) S = -40;
     *unscale = std::ldexp(1.0f, -(S + 4));
+    // k-tile order of conv_h3.hip: (kh, cin chunk of 16, kw) when Cin % 16 == 0; the stem (Cin == 4) keeps (kh, kw, cin)
+    const bool reorder = Cin % 16 == 0 && KH * KW > 1;
+    const int K = KH * KW * Cin, CC = Cin / 16;
     for (int k = 0; k < Kpad; k++) {
-        const int kt = k >> 4, kk = k & 15;
+        int kt = k >> 4; const int kk = k & 15;
+        if (reorder && k < K) {
+            const int tap = k / Cin, ci = k - tap * Cin, kh = tap / KW, kw = tap - kh * KW;
+            kt = (kh * CC + (ci >> 4)) * KW + kw;
+        }
         for (int n = 0; n < CoutPad; n++) {
             const float x = std::ldexp(w[(size_t)k * CoutPad + n], S);
             const _Float16 hi = (_Float16)x;
@@ -439,7 +446,7 @@ static int make_conv(cald_model* m, ConvLayer& L, const std::vector<std::string>
         if ((rc = upload(m, w4, &L.w4))) return rc;
     }
     if (m->cfg.precision == CALD_PRECISION_F16X3 && L.CoutPad % 64 == 0 && ((L.Cin % 16 == 0 && kh * kw <= 32) || L.Cin == 4)) {   // conv_h3.hip layout
-        std::vector<uint16_t> w16 = pack_w16(w, L.Kpad, L.CoutPad, &L.w16_unscale);
+        std::vector<uint16_t> w16 = pack_w16(w, L.Kpad, L.CoutPad, &L.w16_unscale, kh, kw, L.Cin);
         if ((rc = upload(m, w16, &L.w16))) return rc;
     }
     if (!bkeys.empty()) {
@@ -909,7 +916,7 @@ static int op_conv2d(cald_ctx* c, int precision, const float* in, int H, int W, 
     }
     uint16_t* d_w16 = nullptr; float w16_unscale = 1.0f;
     if (precision == CALD_PRECISION_F16X3 && CoutPad % 64 == 0 && ((Cin % 16 == 0 && KH * KW <= 32) || Cin == 4)) {
-        std::vector<uint16_t> w16 = pack_w16(w, Kpad, CoutPad, &w16_unscale);
+        std::vector<uint16_t> w16 = pack_w16(w, Kpad, CoutPad, &w16_unscale, KH, KW, Cin);
         HIPCHK(hipMalloc((void**)&d_w16, w16.size() * 2));
         HIPCHK(hipMemcpy(d_w16, w16.data(), w16.size() * 2, hipMemcpyHostToDevice));
     }

@@ -12,6 +12,11 @@
 // split -- weights by 2^S per layer at finalize (max |w| * 2^S <= 2^14), activations by 2^4 while staging -- and the
 // accumulator is multiplied by 2^-(S+4) first thing in the epilogue (exact).  Range: |activation| < 4094.
 //
+// k order.  This mode is not tied to the exact mode's (kh, kw, cin) summation order, so the k-tiles run (kh, cin-chunk, kw):
+// the three kw taps of a 16-channel chunk read the same 64-byte pixel segments shifted by one pixel, which turns two of
+// every three A-tile fetches into L1 hits -- the kernel is L2-bandwidth-bound otherwise (at 128 x 128 tiles the 3x3
+// 256->256 layer on P2 moves 74 GB per launch from L2, 10.6 TB/s).  Weights are packed in the same order (api.hip).
+//
 // Same implicit-GEMM structure as conv_p4.hip: 128 x 128 x 16 tiles, 4 waves (64 x 64 each), buffer loads with
 // hardware zero fill for out-of-image taps, XCD-aware tile map, fused fp32 epilogue.  Activations stay fp32 in HBM
 // (split while staging into LDS); weights are split and packed at model finalize (ConvArgs::w16).
@@ -123,8 +128,9 @@ __global__ __launch_bounds__(256, 3) void conv_h3_kernel(const ConvArgs a) {
         ra1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, v1, soffA, 0));         \
         rb0 = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, bvoff0, soffB, 0));     \
         if (TN == 2) rb1 = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, bvoff1, soffB, 0)); \
-        u_kt++; u_ci += BK;                                                                                \
-        if (u_ci >= Cin) { u_ci = 0; u_kw++; if (u_kw == KW) { u_kw = 0; u_kh++; } }                       \
+        u_kt++;                                                                                            \
+        if (C4) { u_ci += BK; if (u_ci >= Cin) { u_ci = 0; u_kw++; if (u_kw == KW) { u_kw = 0; u_kh++; } } } \
+        else { u_kw++; if (u_kw == KW) { u_kw = 0; u_ci += BK; if (u_ci >= Cin) { u_ci = 0; u_kh++; } } }  \
     }
 #define H3_STORE(BUF)                                                                                      \
     {                                                                                                      \
