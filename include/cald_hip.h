@@ -35,8 +35,9 @@ typedef struct cald_model cald_model;
 /* arithmetic of the conv / linear GEMMs.
  *   FP32   exact: one k-ordered fp32 fma chain per output (v_mfma_f32_32x32x2_f32), bit-identical to the oracle.
  *   F16X3  the "fp16 MFMA path" of BASELINE.json configs[4]: operands split into fp16 hi + lo, three
- *          v_mfma_f32_32x32x16_f16 per product into fp32 accumulators (~22-bit operands, ~1e-7 relative): meets the
- *          1e-4 / identical-top-k bar but is NOT bit-identical; |activations| must stay below 65504. */
+ *          v_mfma_f32_32x32x16_f16 per product into fp32 accumulators (22-bit operands, ~1e-6 end to end): fp32-grade but
+ *          NOT bit-identical -- ~1 % of images change through a flipped borderline detection, so the identical-top-k
+ *          bar is met only by FP32; |activations| must stay below 4094. */
 #define CALD_PRECISION_FP32 0
 #define CALD_PRECISION_F16X3 1
 
