@@ -1,12 +1,12 @@
-// conv_h3.hip -- the "fp16 MFMA path" of BASELINE.json configs[4], built so that it still meets the fp32 parity bar
-// (consistency within 1e-4, identical top-k): every fp32 operand is split into two fp16 values,
+// conv_h3.hip -- the "fp16 MFMA path" of BASELINE.json configs[4], built to stay fp32-grade (a plain fp16 / bf16 pass
+// is ~1e-3): every fp32 operand is split into two fp16 values,
 //     x = hi + lo,  hi = fp16(x),  lo = fp16(x - hi)                      (22 significant bits)
 // and a product a*b is evaluated as  a_lo*b_hi + a_hi*b_lo + a_hi*b_hi  with three v_mfma_f32_32x32x16_f16 into
 // the same fp32 accumulator (the a_lo*b_lo term, 2^-22 relative, is dropped).  The fp16 matrix pipe is 16x the
 // fp32-input one (32 cycles per 32x32x16 vs 64 cycles per 32x32x2), so three passes are ~5x faster than
-// conv_p4.hip's exact v_mfma_f32_32x32x2_f32 chain.  NOT bit-identical to the oracle (different rounding, ~1e-7
-// relative like any other fp32 implementation) -- this mode is opt-in (cald_model_cfg.precision = 1) and is checked
-// against the oracle to the tolerance, not bit for bit; the default mode stays the exact one.
+// conv_p4.hip's exact v_mfma_f32_32x32x2_f32 chain.  NOT bit-identical to the oracle (different rounding, ~1e-6
+// end to end like any other fp32 implementation, so ~1 % of images change through a flipped borderline detection;
+// DESIGN.md section 4b) -- this mode is opt-in (cald_model_cfg.precision = 1); the default mode stays the exact one.
 // fp16 has a narrow exponent range: the lo part of a small operand would be subnormal (absolute step 2^-24, e.g.
 // only ~1e-6 relative for a weight of 0.03).  Both operands are therefore scaled by exact powers of two before the
 // split -- weights by 2^S per layer at finalize (max |w| * 2^S <= 2^14), activations by 2^4 while staging -- and the

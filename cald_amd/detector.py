@@ -36,8 +36,9 @@ class HipDetector:
     def __init__(self, num_classes, depth=50, min_size=800, max_size=1333, box_score_thresh=0.05, box_nms_thresh=0.5,
                  box_detections_per_img=100, rpn_pre_nms_top_n_test=1000, rpn_post_nms_top_n_test=1000,
                  rpn_nms_thresh=0.7, arch=0, precision="fp32", **unused):
-        """precision: "fp32" (exact, bit-identical to the oracle; default) or "f16x3" (split-fp16 MFMA path, ~1e-7
-        relative per GEMM, meets the 1e-4 / identical-top-k bar, not bit-identical; include/cald_hip.h)."""
+        """precision: "fp32" (exact, bit-identical to the oracle; default) or "f16x3" (split-fp16 MFMA path, 2x faster,
+        fp32-grade but not bit-identical: ~1 % of images change through a flipped borderline detection; include/cald_hip.h,
+        DESIGN.md section 4b)."""
         self.arch = arch
         self.cfg = _ffi.ModelCfg(self.arch, depth, num_classes, int(min_size), int(max_size), box_score_thresh,
                                  box_nms_thresh, box_detections_per_img, rpn_pre_nms_top_n_test, rpn_post_nms_top_n_test,
