@@ -441,7 +441,7 @@ static int make_conv(cald_model* m, ConvLayer& L, const std::vector<std::string>
         co0 += c0;
     }
     int rc = upload(m, w, &L.w); if (rc) return rc;
-    if (L.CoutPad % 128 == 0 && L.Cin % 16 == 0 && kh * kw <= 32) {   // conv_p4.hip layout
+    if (L.CoutPad % 64 == 0 && ((L.Cin % 16 == 0 && kh * kw <= 32) || L.Cin == 4)) {   // conv_p4.hip layout
         std::vector<float> w4 = pack_w4(w, L.Kpad, L.CoutPad);
         if ((rc = upload(m, w4, &L.w4))) return rc;
     }
@@ -909,7 +909,7 @@ static int op_conv2d(cald_ctx* c, int precision, const float* in, int H, int W, 
     HIPCHK(hipMemcpy(d_in, in, (size_t)H * W * Cin * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_w, w.data(), w.size() * 4, hipMemcpyHostToDevice));
     float* d_w4 = nullptr;
-    if (CoutPad % 128 == 0 && Cin % 16 == 0 && KH * KW <= 32) {
+    if (CoutPad % 64 == 0 && ((Cin % 16 == 0 && KH * KW <= 32) || Cin == 4)) {
         std::vector<float> w4 = pack_w4(w, Kpad, CoutPad);
         HIPCHK(hipMalloc((void**)&d_w4, w4.size() * 4));
         HIPCHK(hipMemcpy(d_w4, w4.data(), w4.size() * 4, hipMemcpyHostToDevice));

@@ -14,10 +14,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int EPI>
+// C4: Cin == 4 (the stem conv on the NHWC4 input).  A thread's four consecutive k are one filter tap, so the tap and its
+// validity are per-thread quantities; the k order (tap, channel) is the contract's (kh, kw, cin) order unchanged.
+// TN = 2: 128 x 128 tiles; TN = 1: 128 x 64 tiles (64 x 32 per wave) for the 64-wide layers.
+template <int EPI, bool C4 = false, int TN = 2>
 __global__ __launch_bounds__(256, 3) void conv_p4_kernel(const ConvArgs a) {
-    constexpr int BM = 128, BN = 128, BK = 16, TM = 2, TN = 2, WN = 2;
-    constexpr int TILE_A = 2 * BM * 8, TILE_F = TILE_A + 2 * BN * 8;      // floats: 2048 + 2048
+    constexpr int BM = 128, BN = 64 * TN, BK = 16, TM = 2, WN = 2;
+    constexpr int TILE_A = 2 * BM * 8, TILE_F = TILE_A + 2 * BN * 8;      // floats: 2048 + 2048 (TN = 2)
     __shared__ __attribute__((aligned(16))) float smem[3 * TILE_F];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -46,21 +49,22 @@ __global__ __launch_bounds__(256, 3) void conv_p4_kernel(const ConvArgs a) {
     // ---- A gather (buffer resource, tap masks) : rows arow, arow + 64; k group g = 4 consecutive k ----
     const int g = tid & 3, arow = tid >> 2;
     unsigned rowmask[2];
-    int rowvoff[2];
+    int rowvoff[2], riy0[2], rix0[2];
 #pragma unroll
     for (int p = 0; p < 2; p++) {
         const int m = m0 + arow + 64 * p;
         const int oy = m / Wo, ox = m - oy * Wo;
         const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
         unsigned msk = 0;
-        if (m < Mv)
+        if (!C4 && m < Mv)
             for (int t = 0; t < KH * KW; t++) {
                 const int th = t / KW, tw = t - th * KW;
                 const int iy = iy0 + th, ix = ix0 + tw;
                 if (iy >= 0 && iy < Hi && ix >= 0 && ix < Wi) msk |= 1u << t;
             }
         rowmask[p] = msk;
-        rowvoff[p] = (((oy * a.stride) * Wi + ox * a.stride) * Cin + 4 * g) * 4;
+        rowvoff[p] = (((oy * a.stride) * Wi + ox * a.stride) * Cin + (C4 ? 0 : 4 * g)) * 4;
+        riy0[p] = m < Mv ? iy0 : -0x40000000; rix0[p] = ix0;
     }
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(in_v - (long long)a.pad * (Wi + 1) * Cin), 0, 0x7FFE0000, 0x00020000);
@@ -75,24 +79,37 @@ __global__ __launch_bounds__(256, 3) void conv_p4_kernel(const ConvArgs a) {
 #pragma unroll
         for (int h = 0; h < 2; h++) aw_off[p][h] = ((a_kq * BM + r) * 2 + (h ^ ((r >> 3) & 1))) * 4 + a_j;
     }
-    // B: float4 f = tid + 256 p  ->  kq = p, n_l = tid >> 1, h = tid & 1
-    const int b_nl = tid >> 1, b_h = tid & 1;
-    const int bvoff0 = (b_nl * 8 + b_h * 4) * 4, bvoff1 = bvoff0 + CoutPad * 8 * 4;
-    const int bw_off0 = TILE_A + ((0 * BN + b_nl) * 2 + (b_h ^ ((b_nl >> 3) & 1))) * 4, bw_off1 = bw_off0 + BN * 8;
+    // B: TN = 2: float4 f = tid + 256 p -> kq = p, n_l = tid >> 1, h = tid & 1 (two pieces per thread);
+    //    TN = 1: one piece per thread, kq = tid >> 7
+    const int b_t = TN == 2 ? tid : (tid & 127), b_kq = TN == 2 ? 0 : (tid >> 7);
+    const int b_nl = b_t >> 1, b_h = b_t & 1;
+    const int bvoff0 = (b_kq * CoutPad * 8 + b_nl * 8 + b_h * 4) * 4, bvoff1 = bvoff0 + CoutPad * 8 * 4;
+    const int bw_off0 = TILE_A + ((b_kq * BN + b_nl) * 2 + (b_h ^ ((b_nl >> 3) & 1))) * 4, bw_off1 = bw_off0 + BN * 8;
 
-    f32x4 ra0, ra1, rb0, rb1;
+    f32x4 ra0, ra1, rb0, rb1 = {0.f, 0.f, 0.f, 0.f};
 
 #define P4_LOAD()                                                                                          \
     {                                                                                                      \
-        const unsigned u_bit = 1u << (u_kh * KW + u_kw);                                                   \
-        const int soffA = ((u_kh * Wi + u_kw) * Cin + u_ci) * 4;                                           \
         const int soffB = u_kt * 2 * CoutPad * 8 * 4;                                                      \
-        const int v0 = (rowmask[0] & u_bit) ? rowvoff[0] : 0x7FFF0000;                                     \
-        const int v1 = (rowmask[1] & u_bit) ? rowvoff[1] : 0x7FFF0000;                                     \
+        int soffA, v0, v1;                                                                                 \
+        if (C4) {                                                                                          \
+            const int tap = u_kt * 4 + g, th = tap / KW, tw = tap - th * KW;                               \
+            const int toff = (th * Wi + tw) * 16;                                                          \
+            const bool ok0 = th < KH && (unsigned)(riy0[0] + th) < (unsigned)Hi && (unsigned)(rix0[0] + tw) < (unsigned)Wi; \
+            const bool ok1 = th < KH && (unsigned)(riy0[1] + th) < (unsigned)Hi && (unsigned)(rix0[1] + tw) < (unsigned)Wi; \
+            soffA = 0;                                                                                     \
+            v0 = ok0 ? rowvoff[0] + toff : 0x7FFF0000;                                                     \
+            v1 = ok1 ? rowvoff[1] + toff : 0x7FFF0000;                                                     \
+        } else {                                                                                           \
+            const unsigned u_bit = 1u << (u_kh * KW + u_kw);                                               \
+            soffA = ((u_kh * Wi + u_kw) * Cin + u_ci) * 4;                                                 \
+            v0 = (rowmask[0] & u_bit) ? rowvoff[0] : 0x7FFF0000;                                           \
+            v1 = (rowmask[1] & u_bit) ? rowvoff[1] : 0x7FFF0000;                                           \
+        }                                                                                                  \
         ra0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, v0, soffA, 0));         \
         ra1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, v1, soffA, 0));         \
         rb0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, bvoff0, soffB, 0));     \
-        rb1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, bvoff1, soffB, 0));     \
+        if (TN == 2) rb1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, bvoff1, soffB, 0)); \
         u_kt++; u_ci += BK;                                                                                \
         if (u_ci >= Cin) { u_ci = 0; u_kw++; if (u_kw == KW) { u_kw = 0; u_kh++; } }                       \
     }
@@ -107,7 +124,7 @@ __global__ __launch_bounds__(256, 3) void conv_p4_kernel(const ConvArgs a) {
         *reinterpret_cast<float2*>(tb + aw_off[1][0]) = make_float2(ra1[0], ra1[2]);                       \
         *reinterpret_cast<float2*>(tb + aw_off[1][1]) = make_float2(ra1[1], ra1[3]);                       \
         *reinterpret_cast<f32x4*>(tb + bw_off0) = rb0;                                                     \
-        *reinterpret_cast<f32x4*>(tb + bw_off1) = rb1;                                                     \
+        if (TN == 2) *reinterpret_cast<f32x4*>(tb + bw_off1) = rb1;                                        \
     }
 
     f32x16 acc[TM][TN];
@@ -131,7 +148,7 @@ __global__ __launch_bounds__(256, 3) void conv_p4_kernel(const ConvArgs a) {
 #pragma unroll
     for (int t = 0; t < TM; t++) { const int m = wm * 64 + t * 32 + l31; fo_a[t] = (m * 2 + (kh_lane ^ ((m >> 3) & 1))) * 4; }
 #pragma unroll
-    for (int t = 0; t < TN; t++) { const int n = wn * 64 + t * 32 + l31; fo_b[t] = TILE_A + (n * 2 + (kh_lane ^ ((n >> 3) & 1))) * 4; }
+    for (int t = 0; t < TN; t++) { const int n = wn * 32 * TN + t * 32 + l31; fo_b[t] = TILE_A + (n * 2 + (kh_lane ^ ((n >> 3) & 1))) * 4; }
     f32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
 #pragma unroll
     for (int t = 0; t < TM; t++) fa0[t] = *reinterpret_cast<const f32x4*>(smem + fo_a[t]);
@@ -237,10 +254,24 @@ __global__ __launch_bounds__(256, 3) void conv_p4_kernel(const ConvArgs a) {
 
 // returns true if this variant handled the launch
 bool launch_conv_p4(const ConvArgs& a, hipStream_t stream) {
-    if (!a.w4 || a.CoutPad % 128 != 0 || a.Cin % 16 != 0 || a.KH * a.KW > 32) return false;
-    dim3 grid((unsigned)(a.total_mtiles * (a.CoutPad / 128))), block(256);
-    if (a.residual) hipLaunchKernelGGL((conv_p4_kernel<1>), grid, block, 0, stream, a);
-    else if (a.up) hipLaunchKernelGGL((conv_p4_kernel<2>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((conv_p4_kernel<0>), grid, block, 0, stream, a);
+    if (!a.w4 || a.CoutPad % 64 != 0) return false;
+    const bool wide = a.CoutPad % 128 == 0;
+    dim3 grid((unsigned)(a.total_mtiles * (a.CoutPad / (wide ? 128 : 64)))), block(256);
+    if (a.Cin == 4) {
+        if (a.residual || a.up || a.in_relu) return false;
+        if (wide) hipLaunchKernelGGL((conv_p4_kernel<0, true, 2>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((conv_p4_kernel<0, true, 1>), grid, block, 0, stream, a);
+        return true;
+    }
+    if (a.Cin % 16 != 0 || a.KH * a.KW > 32) return false;
+    if (wide) {
+        if (a.residual) hipLaunchKernelGGL((conv_p4_kernel<1, false, 2>), grid, block, 0, stream, a);
+        else if (a.up) hipLaunchKernelGGL((conv_p4_kernel<2, false, 2>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((conv_p4_kernel<0, false, 2>), grid, block, 0, stream, a);
+    } else {
+        if (a.residual) hipLaunchKernelGGL((conv_p4_kernel<1, false, 1>), grid, block, 0, stream, a);
+        else if (a.up) hipLaunchKernelGGL((conv_p4_kernel<2, false, 1>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((conv_p4_kernel<0, false, 1>), grid, block, 0, stream, a);
+    }
     return true;
 }
