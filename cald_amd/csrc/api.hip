@@ -428,7 +428,7 @@ static int make_conv(cald_model* m, ConvLayer& L, const std::vector<std::string>
     int cinp = cin_pad_to > cin ? cin_pad_to : cin;
     if (cinp % 4) return fail(CALD_ERR_INVALID, "Cin must be a multiple of 4");
     L.Cin = cinp; L.CinTrue = cin; L.Cout = cout; L.CoutPad = cout_pad(cout); L.KH = kh; L.KW = kw; L.stride = stride; L.pad = pad;
-    L.K = kh * kw * cinp; L.Kpad = round_up(L.K, 32);
+    L.K = kh * kw * cinp; L.Kpad = round_up(L.K, 16);
     std::vector<float> w((size_t)L.Kpad * L.CoutPad, 0.0f);
     int co0 = 0;
     for (auto t : ws) {
@@ -890,7 +890,7 @@ static int op_conv2d(cald_ctx* c, int precision, const float* in, int H, int W, 
     if (Cin % 4) return fail(CALD_ERR_INVALID, "Cin must be a multiple of 4");
     HIPCHK(hipSetDevice(c->device));
     const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
-    const int CoutPad = cout_pad(Cout), K = KH * KW * Cin, Kpad = round_up(K, 32);
+    const int CoutPad = cout_pad(Cout), K = KH * KW * Cin, Kpad = round_up(K, 16);
     std::vector<float> w((size_t)Kpad * CoutPad, 0.0f), b(CoutPad, 0.0f), sc(CoutPad, 0.0f), sh(CoutPad, 0.0f);
     for (int co = 0; co < Cout; co++)
         for (int ci = 0; ci < Cin; ci++)
