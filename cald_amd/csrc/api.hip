@@ -617,14 +617,14 @@ struct FwdBufs {
     float* proposals; int* prop_count;
     float *roi, *f6, *f7, *pr, *prob, *pmax; unsigned long long* keys; float* cbox; int* key_count;
     // RetinaNet
-    float *ret_ta, *ret_tb, *cls_h[5], *reg_h[5], *rcand_box, *kept_box; unsigned long long* rcand_key;
+    float *ret_t[2][2][5], *cls_h[5], *reg_h[5], *rcand_box, *kept_box; unsigned long long* rcand_key;   // ret_t[tower][ping-pong][level]
+    float* rpn_tl[5];
     int *cand_count, *kept_anchor, *kept_count; int cand_cap; int max_anchors; unsigned char* cand_skip;
 };
 
-static int conv_on(cald_model* m, const ConvLayer& L, const float* in, float* out, int lin, int lout, int V, bool relu,
-                   const float* residual = nullptr, const float* up = nullptr, int lup = 0, const int* dyn = nullptr,
-                   bool in_relu = false) {
-    ConvArgs a;
+static double fill_conv_args(cald_model* m, ConvArgs& a, const ConvLayer& L, const float* in, float* out, int lin, int lout, int V, bool relu,
+                             const float* residual = nullptr, const float* up = nullptr, int lup = 0, const int* dyn = nullptr,
+                             bool in_relu = false) {
     const BatchPlan* dp = m->ctx->d_plan;
     a.in = in; a.out = out; a.w = L.w; a.w4 = L.w4; a.w16 = L.w16; a.w16_unscale = L.w16_unscale; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift;
     a.residual = residual; a.up = up;
@@ -634,8 +634,35 @@ static int conv_on(cald_model* m, const ConvLayer& L, const float* in, float* ou
     a.KH = L.KH; a.KW = L.KW; a.stride = L.stride; a.pad = L.pad; a.relu = relu ? 1 : 0;
     a.total_mtiles = level_tiles(m->plan, lout, V);
     a.out_ld = L.Cout; a.in_relu = in_relu ? 1 : 0; a.zeros = m->ctx->d_zeros;
-    double flops = 2.0 * (double)level_pix(m->plan, lout, V) * (double)L.Cout * (double)(L.KH * L.KW * L.CinTrue);
+    return 2.0 * (double)level_pix(m->plan, lout, V) * (double)L.Cout * (double)(L.KH * L.KW * L.CinTrue);
+}
+static int conv_on(cald_model* m, const ConvLayer& L, const float* in, float* out, int lin, int lout, int V, bool relu,
+                   const float* residual = nullptr, const float* up = nullptr, int lup = 0, const int* dyn = nullptr,
+                   bool in_relu = false) {
+    ConvArgs a;
+    const double flops = fill_conv_args(m, a, L, in, out, lin, lout, V, relu, residual, up, lup, dyn, in_relu);
     return run_conv(m->ctx, a, flops);
+}
+// independent convolutions (bias / BN / ReLU epilogue only) issued as ONE launch when they fit the same tiled kernel
+struct ConvSpec { const ConvLayer* L; const float* in; float* out; int level; bool relu; };
+static int conv_group_on(cald_model* m, const ConvSpec* sp, int n, int V) {
+    ConvArgs a[CALD_MAX_GROUP];
+    double flops = 0.0; int tiles = 0;
+    for (int i = 0; i < n; i++) { flops += fill_conv_args(m, a[i], *sp[i].L, sp[i].in, sp[i].out, sp[i].level, sp[i].level, V, sp[i].relu); tiles += a[i].total_mtiles; }
+    cald_ctx* c = m->ctx;
+    if (c->prof) {
+        hipEvent_t e0, e1;
+        HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+        HIPCHK(hipEventRecord(e0, c->stream));
+        launch_conv_group(a, n, c->stream);
+        HIPCHK(hipEventRecord(e1, c->stream));
+        c->ev0.push_back(e0); c->ev1.push_back(e1); c->prof_flops += flops;
+        char d[160]; snprintf(d, sizeof(d), "mt=%d,Cin=%d,Cout=%d,k=%dx%d,s=%d,group=%d", tiles, a[0].Cin, a[0].Cout, a[0].KH, a[0].KW, a[0].stride, n);
+        c->prof_desc.push_back(d); c->prof_fl.push_back(flops);
+    } else {
+        launch_conv_group(a, n, c->stream);
+    }
+    return 0;
 }
 
 static void fwd_layout(cald_model* m, Bump& B, FwdBufs& F, int V) {
@@ -653,7 +680,7 @@ static void fwd_layout(cald_model* m, Bump& B, FwdBufs& F, int V) {
         const int K = m->cfg.num_classes, per = m->cfg.detections_per_img;
         for (int i = 0; i < 3; i++) F.inner[i] = B.get<float>(px[3 + i] * 256);
         for (int i = 0; i < 5; i++) F.Pf[i] = B.get<float>(px[3 + i] * 256);
-        F.ret_ta = B.get<float>(px[3] * 256); F.ret_tb = B.get<float>(px[3] * 256);
+        for (int h = 0; h < 2; h++) for (int q = 0; q < 2; q++) for (int i = 0; i < 5; i++) F.ret_t[h][q][i] = B.get<float>(px[3 + i] * 256);
         for (int i = 0; i < 5; i++) { F.cls_h[i] = B.get<float>(px[3 + i] * m->cls_out.Cout); F.reg_h[i] = B.get<float>(px[3 + i] * 36); }
         int maxa = 0;
         for (int v = 0; v < V; v++) { int t = 0; for (int l = 3; l < 8; l++) t += P.seg[l][v].H * P.seg[l][v].W * 9; if (t > maxa) maxa = t; }
@@ -670,7 +697,8 @@ static void fwd_layout(cald_model* m, Bump& B, FwdBufs& F, int V) {
     }
     for (int i = 0; i < 4; i++) F.inner[i] = B.get<float>(px[2 + i] * 256);
     for (int i = 0; i < 5; i++) F.Pf[i] = B.get<float>(px[2 + i] * 256);
-    F.rpn_t = B.get<float>(px[2] * 256);
+    F.rpn_t = nullptr;
+    for (int i = 0; i < 5; i++) F.rpn_tl[i] = B.get<float>(px[2 + i] * 256);
     for (int i = 0; i < 5; i++) F.rpn_h[i] = B.get<float>(px[2 + i] * 15);
     const int pre = m->cfg.rpn_pre_nms_top_n;
     F.cand_key = B.get<unsigned long long>((size_t)V * 5 * pre);
@@ -761,8 +789,11 @@ static int forward_model(cald_model* m, int V, ViewDesc* views, const DetBuffers
         if ((rc = conv_on(m, m->fpn_inner[2], F.Cf[3], F.inner[2], 5, 5, V, false))) return rc;
         for (int i = 1; i >= 0; i--)
             if ((rc = conv_on(m, m->fpn_inner[i], F.Cf[1 + i], F.inner[i], 3 + i, 3 + i, V, false, nullptr, F.inner[i + 1], 4 + i))) return rc;
-        for (int i = 0; i < 3; i++)
-            if ((rc = conv_on(m, m->fpn_layer[i], F.inner[i], F.Pf[i], 3 + i, 3 + i, V, false))) return rc;
+        {
+            ConvSpec sp[3];
+            for (int i = 0; i < 3; i++) sp[i] = {&m->fpn_layer[i], F.inner[i], F.Pf[i], 3 + i, false};
+            if ((rc = conv_group_on(m, sp, 3, V))) return rc;
+        }
         if ((rc = conv_on(m, m->p6, F.Pf[2], F.Pf[3], 5, 6, V, false))) return rc;
         if ((rc = conv_on(m, m->p7, F.Pf[3], F.Pf[4], 6, 7, V, false, nullptr, nullptr, 0, nullptr, true))) return rc;
         const char* pn[5] = {"P3", "P4", "P5", "P6", "P7"};
@@ -770,20 +801,23 @@ static int forward_model(cald_model* m, int V, ViewDesc* views, const DetBuffers
         const char* rnm[5] = {"reg0", "reg1", "reg2", "reg3", "reg4"};
         for (int i = 0; i < 5; i++) m->dbg[pn[i]] = {F.Pf[i], 3 + i, 256, 0};
         // ---- heads (retinanet_cal.py:36-241): 4 x (3x3 conv + ReLU) + 3x3 output conv, per level ----
+        // both towers x five levels share one launch per tower depth (10 independent problems, weights shared across levels)
+        for (int t = 0; t < 4; t++) {
+            ConvSpec sp[10];
+            for (int hsel = 0; hsel < 2; hsel++)
+                for (int i = 0; i < 5; i++)
+                    sp[hsel * 5 + i] = {&(hsel == 0 ? m->cls_tower : m->reg_tower)[t], t == 0 ? F.Pf[i] : F.ret_t[hsel][(t - 1) & 1][i],
+                                        F.ret_t[hsel][t & 1][i], 3 + i, true};
+            if ((rc = conv_group_on(m, sp, 10, V))) return rc;
+        }
+        for (int hsel = 0; hsel < 2; hsel++) {
+            ConvSpec sp[5];
+            for (int i = 0; i < 5; i++) sp[i] = {hsel == 0 ? &m->cls_out : &m->reg_out, F.ret_t[hsel][1][i], hsel == 0 ? F.cls_h[i] : F.reg_h[i], 3 + i, false};
+            if ((rc = conv_group_on(m, sp, 5, V))) return rc;
+        }
         for (int i = 0; i < 5; i++) {
-            const int l = 3 + i;
-            for (int hsel = 0; hsel < 2; hsel++) {
-                const ConvLayer* tw = hsel == 0 ? m->cls_tower : m->reg_tower;
-                const float* src = F.Pf[i];
-                for (int t = 0; t < 4; t++) {
-                    float* dst = (t & 1) ? F.ret_tb : F.ret_ta;
-                    if ((rc = conv_on(m, tw[t], src, dst, l, l, V, true))) return rc;
-                    src = dst;
-                }
-                if ((rc = conv_on(m, hsel == 0 ? m->cls_out : m->reg_out, src, hsel == 0 ? F.cls_h[i] : F.reg_h[i], l, l, V, false))) return rc;
-            }
-            m->dbg[cnm[i]] = {F.cls_h[i], l, m->cls_out.Cout, 0};
-            m->dbg[rnm[i]] = {F.reg_h[i], l, 36, 0};
+            m->dbg[cnm[i]] = {F.cls_h[i], 3 + i, m->cls_out.Cout, 0};
+            m->dbg[rnm[i]] = {F.reg_h[i], 3 + i, 36, 0};
         }
         RetinaArgs ra;
         for (int i = 0; i < 5; i++) { ra.cls[i] = F.cls_h[i]; ra.reg[i] = F.reg_h[i]; ra.seg[i] = dp->seg[3 + i]; }
@@ -801,17 +835,23 @@ static int forward_model(cald_model* m, int V, ViewDesc* views, const DetBuffers
     if ((rc = conv_on(m, m->fpn_inner[3], F.Cf[3], F.inner[3], 5, 5, V, false))) return rc;
     for (int i = 2; i >= 0; i--)
         if ((rc = conv_on(m, m->fpn_inner[i], F.Cf[i], F.inner[i], 2 + i, 2 + i, V, false, nullptr, F.inner[i + 1], 3 + i))) return rc;
-    for (int i = 0; i < 4; i++)
-        if ((rc = conv_on(m, m->fpn_layer[i], F.inner[i], F.Pf[i], 2 + i, 2 + i, V, false))) return rc;
+    {
+        ConvSpec sp[4];
+        for (int i = 0; i < 4; i++) sp[i] = {&m->fpn_layer[i], F.inner[i], F.Pf[i], 2 + i, false};
+        if ((rc = conv_group_on(m, sp, 4, V))) return rc;
+    }
     launch_subsample2(F.Pf[3], F.Pf[4], dp->seg[5], dp->seg[6], 256, V, max_pix6, st);
     const char* pn[5] = {"P2", "P3", "P4", "P5", "P6"};
     for (int i = 0; i < 5; i++) m->dbg[pn[i]] = {F.Pf[i], 2 + i, 256, 0};
     // ---- RPN (row A17) ----
     const char* rn[5] = {"rpn0", "rpn1", "rpn2", "rpn3", "rpn4"};
-    for (int i = 0; i < 5; i++) {
-        if ((rc = conv_on(m, m->rpn_conv, F.Pf[i], F.rpn_t, 2 + i, 2 + i, V, true))) return rc;
-        if ((rc = conv_on(m, m->rpn_head, F.rpn_t, F.rpn_h[i], 2 + i, 2 + i, V, false))) return rc;
-        m->dbg[rn[i]] = {F.rpn_h[i], 2 + i, 15, 0};
+    {   // the shared-weight RPN head over the five levels: one launch for the 3x3 conv, one for the fused 1x1 heads
+        ConvSpec sp[5];
+        for (int i = 0; i < 5; i++) sp[i] = {&m->rpn_conv, F.Pf[i], F.rpn_tl[i], 2 + i, true};
+        if ((rc = conv_group_on(m, sp, 5, V))) return rc;
+        for (int i = 0; i < 5; i++) sp[i] = {&m->rpn_head, F.rpn_tl[i], F.rpn_h[i], 2 + i, false};
+        if ((rc = conv_group_on(m, sp, 5, V))) return rc;
+        for (int i = 0; i < 5; i++) m->dbg[rn[i]] = {F.rpn_h[i], 2 + i, 15, 0};
     }
     RpnArgs ra;
     for (int i = 0; i < 5; i++) { ra.head[i] = F.rpn_h[i]; ra.seg[i] = dp->seg[2 + i]; }

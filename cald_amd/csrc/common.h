@@ -50,6 +50,16 @@ struct ConvArgs {
     int in_relu;           // apply ReLU to the input while gathering (LastLevelP6P7: p7(relu(p6)))
 };
 
+// Several independent conv problems in ONE launch (the five FPN levels under the shared-weight RPN / RetinaNet heads, the
+// FPN output convs): workgroups [blk0[i], blk0[i + 1]) belong to problem i.  Small levels then fill the tail of the large
+// ones instead of running as under-filled launches of their own.
+#define CALD_MAX_GROUP 10
+struct ConvGroup {
+    int n;
+    int blk0[CALD_MAX_GROUP + 1];
+    ConvArgs p[CALD_MAX_GROUP];
+};
+
 // ---------------------------------------------------------------------------------------------
 // Deterministic float32 elementary functions (DESIGN.md "arithmetic contract"): fixed fmaf
 // polynomials, built with -ffp-contract=off so that every fused multiply-add is explicit.
@@ -166,3 +176,5 @@ __host__ __device__ inline uint32_t det_orderable(float f) {
 // kernel launchers (implemented in the .hip files; all asynchronous on `stream`)
 // ---------------------------------------------------------------------------------------------
 void launch_conv(const ConvArgs& a, hipStream_t stream);
+// all problems in one launch when they qualify for the same tiled kernel variant, else one launch each
+void launch_conv_group(const ConvArgs* probs, int n, hipStream_t stream);

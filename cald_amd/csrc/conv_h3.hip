@@ -36,7 +36,7 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 // C4: Cin == 4 (the stem conv on the NHWC4 input): a thread's four consecutive k are one filter tap, so the tap
 // (kh, kw) and its validity are per-thread quantities instead of wave-uniform ones.
 template <int EPI, int TN, bool C4>
-__global__ __launch_bounds__(256, 3) void conv_h3_kernel(const ConvArgs a) {
+__device__ __forceinline__ void conv_h3_body(const ConvArgs& a, const int blk) {
     constexpr int BM = 128, BN = 64 * TN, BK = 16, TM = 2, WN = 2;
     constexpr int PLANE = BM * 32, PLANE_B = BN * 32, TILE_B = 2 * PLANE + 2 * PLANE_B;       // bytes
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE_B];
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256, 3) void conv_h3_kernel(const ConvArgs a) {
     const int NT = a.CoutPad / BN;
     int mt, nt;
     {
-        const int b = blockIdx.x, MT = a.total_mtiles, MT8 = MT & ~7;
+        const int b = blk, MT = a.total_mtiles, MT8 = MT & ~7;
         if (b < MT8 * NT) { const int xcd = b & 7, idx = b >> 3; mt = (idx / NT) * 8 + xcd; nt = idx % NT; }
         else { const int r = b - MT8 * NT; mt = MT8 + r / NT; nt = r % NT; }
     }
@@ -274,6 +274,30 @@ __global__ __launch_bounds__(256, 3) void conv_h3_kernel(const ConvArgs a) {
             }
         }
     }
+}
+
+template <int EPI, int TN, bool C4>
+__global__ __launch_bounds__(256, 3) void conv_h3_kernel(const ConvArgs a) { conv_h3_body<EPI, TN, C4>(a, blockIdx.x); }
+template <int EPI, int TN, bool C4>
+__global__ __launch_bounds__(256, 3) void conv_h3_group_kernel(const ConvGroup g) {
+    int i = 0;
+    while (i + 1 < g.n && g.blk0[i + 1] <= (int)blockIdx.x) i++;
+    conv_h3_body<EPI, TN, C4>(g.p[i], (int)blockIdx.x - g.blk0[i]);
+}
+
+bool launch_conv_h3_group(const ConvArgs* p, int n, hipStream_t stream) {
+    if (n < 1 || n > CALD_MAX_GROUP) return false;
+    const bool wide = p[0].CoutPad % 128 == 0;
+    ConvGroup g; g.n = n; int blk = 0;
+    for (int i = 0; i < n; i++) {
+        const ConvArgs& a = p[i];
+        if (!a.w16 || a.CoutPad % 64 != 0 || (a.CoutPad % 128 == 0) != wide || a.Cin % 16 != 0 || a.KH * a.KW > 32 || a.residual || a.up) return false;
+        g.blk0[i] = blk; blk += a.total_mtiles * (a.CoutPad / (wide ? 128 : 64)); g.p[i] = a;
+    }
+    g.blk0[n] = blk;
+    if (wide) hipLaunchKernelGGL((conv_h3_group_kernel<0, 2, false>), dim3((unsigned)blk), dim3(256), 0, stream, g);
+    else hipLaunchKernelGGL((conv_h3_group_kernel<0, 1, false>), dim3((unsigned)blk), dim3(256), 0, stream, g);
+    return true;
 }
 
 // returns true if this variant handled the launch

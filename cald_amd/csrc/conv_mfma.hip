@@ -284,6 +284,19 @@ bool launch_conv_p3(const ConvArgs& a, hipStream_t stream);   // conv_p3.hip
 bool launch_conv_p4(const ConvArgs& a, hipStream_t stream);   // conv_p4.hip
 bool launch_conv_h3(const ConvArgs& a, hipStream_t stream);   // conv_h3.hip (opt-in split-fp16 mode: only when a.w16 is set)
 
+bool launch_conv_p4_group(const ConvArgs* p, int n, hipStream_t stream);
+bool launch_conv_h3_group(const ConvArgs* p, int n, hipStream_t stream);
+void launch_conv(const ConvArgs& a, hipStream_t stream);
+void launch_conv_group(const ConvArgs* probs, int n, hipStream_t stream) {
+    static const int grp = conv_env("CALD_CONV_GROUP", 1);
+    static const int p4 = conv_env("CALD_CONV_P4", 1), p3 = conv_env("CALD_CONV_P3", 1);
+    if (grp && n > 1) {
+        if (probs[0].w16 && launch_conv_h3_group(probs, n, stream)) return;
+        if (!probs[0].w16 && p3 && p4 && launch_conv_p4_group(probs, n, stream)) return;
+    }
+    for (int i = 0; i < n; i++) launch_conv(probs[i], stream);
+}
+
 void launch_conv(const ConvArgs& a, hipStream_t stream) {
     static const int p3 = conv_env("CALD_CONV_P3", 1);   // pipelined 3-buffer schedule for 128-wide tiles (conv_p3.hip); 0 = this file only
     static const int p4 = conv_env("CALD_CONV_P4", 1);   // conv_p4.hip: p3 + 128-bit LDS fragment reads

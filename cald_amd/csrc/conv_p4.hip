@@ -17,8 +17,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // C4: Cin == 4 (the stem conv on the NHWC4 input).  A thread's four consecutive k are one filter tap, so the tap and its
 // validity are per-thread quantities; the k order (tap, channel) is the contract's (kh, kw, cin) order unchanged.
 // TN = 2: 128 x 128 tiles; TN = 1: 128 x 64 tiles (64 x 32 per wave) for the 64-wide layers.
-template <int EPI, bool C4 = false, int TN = 2>
-__global__ __launch_bounds__(256, 3) void conv_p4_kernel(const ConvArgs a) {
+template <int EPI, bool C4, int TN>
+__device__ __forceinline__ void conv_p4_body(const ConvArgs& a, const int blk) {
     constexpr int BM = 128, BN = 64 * TN, BK = 16, TM = 2, WN = 2;
     constexpr int TILE_A = 2 * BM * 8, TILE_F = TILE_A + 2 * BN * 8;      // floats: 2048 + 2048 (TN = 2)
     __shared__ __attribute__((aligned(16))) float smem[3 * TILE_F];
@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256, 3) void conv_p4_kernel(const ConvArgs a) {
     const int NT = a.CoutPad / BN;
     int mt, nt;
     {
-        const int b = blockIdx.x, MT = a.total_mtiles, MT8 = MT & ~7;
+        const int b = blk, MT = a.total_mtiles, MT8 = MT & ~7;
         if (b < MT8 * NT) { const int xcd = b & 7, idx = b >> 3; mt = (idx / NT) * 8 + xcd; nt = idx % NT; }
         else { const int r = b - MT8 * NT; mt = MT8 + r / NT; nt = r % NT; }
     }
@@ -250,6 +250,31 @@ __global__ __launch_bounds__(256, 3) void conv_p4_kernel(const ConvArgs a) {
             }
         }
     }
+}
+
+template <int EPI, bool C4 = false, int TN = 2>
+__global__ __launch_bounds__(256, 3) void conv_p4_kernel(const ConvArgs a) { conv_p4_body<EPI, C4, TN>(a, blockIdx.x); }
+template <int EPI, bool C4, int TN>
+__global__ __launch_bounds__(256, 3) void conv_p4_group_kernel(const ConvGroup g) {
+    int i = 0;
+    while (i + 1 < g.n && g.blk0[i + 1] <= (int)blockIdx.x) i++;
+    conv_p4_body<EPI, C4, TN>(g.p[i], (int)blockIdx.x - g.blk0[i]);
+}
+
+// grouped launch (EPI 0 only): returns true if every problem qualifies for the same variant
+bool launch_conv_p4_group(const ConvArgs* p, int n, hipStream_t stream) {
+    if (n < 1 || n > CALD_MAX_GROUP) return false;
+    const bool wide = p[0].CoutPad % 128 == 0;
+    ConvGroup g; g.n = n; int blk = 0;
+    for (int i = 0; i < n; i++) {
+        const ConvArgs& a = p[i];
+        if (!a.w4 || a.w16 || a.CoutPad % 64 != 0 || (a.CoutPad % 128 == 0) != wide || a.Cin % 16 != 0 || a.KH * a.KW > 32 || a.residual || a.up) return false;
+        g.blk0[i] = blk; blk += a.total_mtiles * (a.CoutPad / (wide ? 128 : 64)); g.p[i] = a;
+    }
+    g.blk0[n] = blk;
+    if (wide) hipLaunchKernelGGL((conv_p4_group_kernel<0, false, 2>), dim3((unsigned)blk), dim3(256), 0, stream, g);
+    else hipLaunchKernelGGL((conv_p4_group_kernel<0, false, 1>), dim3((unsigned)blk), dim3(256), 0, stream, g);
+    return true;
 }
 
 // returns true if this variant handled the launch
