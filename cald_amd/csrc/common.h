@@ -177,4 +177,4 @@ __host__ __device__ inline uint32_t det_orderable(float f) {
 // ---------------------------------------------------------------------------------------------
 void launch_conv(const ConvArgs& a, hipStream_t stream);
 // all problems in one launch when they qualify for the same tiled kernel variant, else one launch each
-void launch_conv_group(const ConvArgs* probs, int n, hipStream_t stream);
+int launch_conv_group(const ConvArgs* probs, int n, hipStream_t stream);   // returns the number of kernel launches issued

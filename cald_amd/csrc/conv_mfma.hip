@@ -287,14 +287,15 @@ bool launch_conv_h3(const ConvArgs& a, hipStream_t stream);   // conv_h3.hip (op
 bool launch_conv_p4_group(const ConvArgs* p, int n, hipStream_t stream);
 bool launch_conv_h3_group(const ConvArgs* p, int n, hipStream_t stream);
 void launch_conv(const ConvArgs& a, hipStream_t stream);
-void launch_conv_group(const ConvArgs* probs, int n, hipStream_t stream) {
+int launch_conv_group(const ConvArgs* probs, int n, hipStream_t stream) {   // returns the number of kernel launches issued
     static const int grp = conv_env("CALD_CONV_GROUP", 1);
     static const int p4 = conv_env("CALD_CONV_P4", 1), p3 = conv_env("CALD_CONV_P3", 1);
     if (grp && n > 1) {
-        if (probs[0].w16 && launch_conv_h3_group(probs, n, stream)) return;
-        if (!probs[0].w16 && p3 && p4 && launch_conv_p4_group(probs, n, stream)) return;
+        if (probs[0].w16 && launch_conv_h3_group(probs, n, stream)) return 1;
+        if (!probs[0].w16 && p3 && p4 && launch_conv_p4_group(probs, n, stream)) return 1;
     }
     for (int i = 0; i < n; i++) launch_conv(probs[i], stream);
+    return n;
 }
 
 void launch_conv(const ConvArgs& a, hipStream_t stream) {
