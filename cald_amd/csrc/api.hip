@@ -612,7 +612,7 @@ static long long level_pix(const BatchPlan& P, int l, int V) { return P.seg[l][V
 static int level_tiles(const BatchPlan& P, int l, int V) { return P.seg[l][V].tile_start; }
 
 struct FwdBufs {
-    float *in0, *c1, *p1, *X[2], *T1, *T2, *D, *Cf[4], *inner[4], *Pf[5], *rpn_t, *rpn_h[5];
+    float *in0, *c1, *p1, *X[2], *T1, *T2, *D, *Cf[4], *inner[4], *Pf[5], *rpn_h[5];
     unsigned long long* cand_key; float *cand_box, *sorted_box, *sorted_raw; int* sorted_count;
     float* proposals; int* prop_count;
     float *roi, *f6, *f7, *pr, *prob, *pmax; unsigned long long* keys; float* cbox; int* key_count;
@@ -697,7 +697,6 @@ static void fwd_layout(cald_model* m, Bump& B, FwdBufs& F, int V) {
     }
     for (int i = 0; i < 4; i++) F.inner[i] = B.get<float>(px[2 + i] * 256);
     for (int i = 0; i < 5; i++) F.Pf[i] = B.get<float>(px[2 + i] * 256);
-    F.rpn_t = nullptr;
     for (int i = 0; i < 5; i++) F.rpn_tl[i] = B.get<float>(px[2 + i] * 256);
     for (int i = 0; i < 5; i++) F.rpn_h[i] = B.get<float>(px[2 + i] * 15);
     const int pre = m->cfg.rpn_pre_nms_top_n;
