@@ -27,10 +27,14 @@ P = orc.prepare_frcnn(sd, 21, 50)
 spots = sorted(int(i) for i in rs.choice(n, size=min(6, n), replace=False))
 wc, wk = orc.get_uncertainty(P, [pool[i] for i in spots], augs, 21, 1.3, 600, 1000, 0, positions=spots)
 ok = all(cons[i] == wc[j] and np.array_equal(cls[i], wk[j]) for j, i in enumerate(spots))
+srt = np.sort(cons); kq = int(1.2 * min(500, n // 4))
+gaps = np.diff(srt[:kq + 1])
 res = {"config": "BASELINE.json configs[1] full pool", "pool": n, "sweep_s": t_sweep, "images_per_s": n / t_sweep,
        "selection_s": t_sel, "images_per_s_incl_selection": n / (t_sweep + t_sel), "upload_s": t_up, "synth_gen_s": t_gen,
        "zero_score_images": int((cons == 0).sum()), "consistency_min_max": [float(cons.min()), float(cons.max())],
        "selected_sha1": hashlib.sha1(np.asarray(picked, np.int64).tobytes()).hexdigest(), "n_selected": int(len(picked)),
+       "rank_gap_first_%d_candidates" % kq: {"min": float(gaps.min()), "median": float(np.median(gaps)), "exact_ties": int((gaps == 0).sum()),
+                                              "gap_at_cut": float(srt[kq] - srt[kq - 1])},
        "oracle_spot_check_positions": spots, "oracle_spot_check_bit_exact": bool(ok)}
 print(json.dumps(res))
 if out_path:
