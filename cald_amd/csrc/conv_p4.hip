@@ -280,7 +280,15 @@ bool launch_conv_p4_group(const ConvArgs* p, int n, hipStream_t stream) {
 // returns true if this variant handled the launch
 bool launch_conv_p4(const ConvArgs& a, hipStream_t stream) {
     if (!a.w4 || a.CoutPad % 64 != 0) return false;
-    const bool wide = a.CoutPad % 128 == 0;
+    bool wide = a.CoutPad % 128 == 0;
+    if (wide) {
+        // tail quantisation: a launch of B equal workgroups on 768 slots (256 CUs x 3) runs at B / (ceil(B / 768) * 768); the
+        // 128 x 64 tile doubles B at ~0.88 of the 128 x 128 tile's per-workgroup efficiency -- use it where that wins
+        static const int narrow_env = getenv("CALD_CONV_NARROW") ? atoi(getenv("CALD_CONV_NARROW")) : 1;
+        const long long b2 = (long long)a.total_mtiles * (a.CoutPad / 128), b1 = 2 * b2;
+        const double e2 = (double)b2 / (double)(((b2 + 767) / 768) * 768), e1 = 0.88 * (double)b1 / (double)(((b1 + 767) / 768) * 768);
+        if (narrow_env && e1 > e2 && !a.dyn_rows) wide = false;
+    }
     dim3 grid((unsigned)(a.total_mtiles * (a.CoutPad / (wide ? 128 : 64)))), block(256);
     if (a.Cin == 4) {
         if (a.residual || a.up || a.in_relu) return false;
