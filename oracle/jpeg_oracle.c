@@ -1,4 +1,4 @@
-/* jpeg_oracle.c -- TEST INFRASTRUCTURE ONLY (see oracle/README in cald_oracle.c's header).
+/* jpeg_oracle.c -- TEST INFRASTRUCTURE ONLY: nothing under cald_amd/ includes, links or calls this file.
  *
  * CPU restatement of the JPEG decode the reference's input side performs:
  * torchvision.datasets.VOCDetection.__getitem__ -> PIL.Image.open(path).convert('RGB')
