@@ -129,25 +129,38 @@ def allgather_scores(local_pos, cons, cls, pool_size, group=None):
 
 
 def get_uncertainty(task_model, unlabeled_loader, augs, num_cls, bp=1.3, base_seed=0, rank=0, world_size=1,
-                    batch_images=64, group=None):
-    """Drop-in for cald_train.py:91 (same positional signature)."""
+                    batch_images=64, group=None, chunk_images=4096):
+    """Drop-in for cald_train.py:91 (same positional signature).  Images are uploaded and swept ``chunk_images`` at a
+    time, so a loader-fed sweep never holds more than that many decoded images in HBM (a DevicePool holds them all by
+    design); results do not depend on the chunking."""
     if not hasattr(task_model, "handle"):          # the reference's torch model: mirror it on the HIP side
         from .detector import from_torch_module
         task_model = from_torch_module(task_model)
     task_model.eval()
     # without a GPU the upload below is a no-op and sweep_device_images() raises (no CPU fallback)
     dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
-    images, positions = [], []
+    images, positions, all_pos, cons_parts, cls_parts = [], [], [], [], []
     pool_size = 0
+
+    def flush():
+        if images:
+            c, k = sweep_device_images(task_model, images, positions, augs, bp, base_seed, batch_images)
+            cons_parts.append(c); cls_parts.append(k); all_pos.extend(positions)
+            images.clear(); positions.clear()
+
     for pos, (imgs, _) in enumerate(unlabeled_loader):      # batch size 1, cald_train.py:101-104
         pool_size += 1
         if pos % world_size != rank:
             continue
         for image in imgs:
             images.append(_to_u8_cuda(image, dev)); positions.append(pos)
-    cons, cls = sweep_device_images(task_model, images, positions, augs, bp, base_seed, batch_images)
+        if len(images) >= chunk_images:
+            flush()
+    flush()
+    cons = np.concatenate(cons_parts) if cons_parts else np.zeros(0, np.float64)
+    cls = np.concatenate(cls_parts) if cls_parts else np.zeros((0, num_cls - 1), np.float64)
     if world_size > 1:
-        cons, cls = allgather_scores(positions, cons, cls, pool_size, group)
+        cons, cls = allgather_scores(all_pos, cons, cls, pool_size, group)
     return [float(c) for c in cons], [cls[i] for i in range(cls.shape[0])]
 
 

@@ -203,6 +203,19 @@ def _sharded_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def test_get_uncertainty_chunked_upload_is_invisible(monkeypatch):
+    """Loader-fed sweeps upload and score `chunk_images` at a time; the returned lists do not depend on the chunking."""
+    import torch
+    from cald_amd import sweep
+    monkeypatch.setattr(sweep, "sweep_device_images", _fake_sweep)
+    rs = np.random.RandomState(1)
+    loader = [((torch.from_numpy((rs.rand(6, 7, 3) * 255).astype(np.uint8)),), (None,)) for _ in range(11)]
+    a = sweep.get_uncertainty(_FakeModel(), loader, ["flip"], 21)
+    b = sweep.get_uncertainty(_FakeModel(), loader, ["flip"], 21, chunk_images=3)
+    assert a[0] == b[0] and all(np.array_equal(x, y) for x, y in zip(a[1], b[1])) and len(a[0]) == 11
+    assert sweep.get_uncertainty(_FakeModel(), [], ["flip"], 21) == ([], [])
+
+
 def test_get_uncertainty_sharded_equals_single_rank():
     """The N>1 path of get_uncertainty (strided shard + one all-gather) returns, on every rank, exactly
     what the 1-rank run returns, in loader order."""
