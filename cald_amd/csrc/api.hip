@@ -73,6 +73,18 @@ static int arena_reserve(cald_ctx* c, size_t bytes) {
     c->arena_cap = want;
     return 0;
 }
+// device scratch that lives for one API call: everything is released when the call returns, on every path
+struct ScopedDev {
+    std::vector<void*> ptrs;
+    hipStream_t st;
+    explicit ScopedDev(hipStream_t s) : st(s) {}
+    ~ScopedDev() { if (!ptrs.empty()) { hipStreamSynchronize(st); for (void* p : ptrs) hipFree(p); } }
+    template <typename T> int alloc(T** out, size_t bytes) {
+        HIPCHK(hipMalloc((void**)out, bytes ? bytes : 1));
+        ptrs.push_back(*out);
+        return 0;
+    }
+};
 struct Bump {
     char* base; size_t off = 0; bool dry;
     explicit Bump(char* b, bool d) : base(b), dry(d) {}
@@ -1094,15 +1106,16 @@ extern "C" int cald_sweep(cald_model* m, int n_images, const uint8_t* const* ima
     NoiseJob* d_jobs = nullptr; unsigned long long* d_lsum = nullptr;
     const int P_MAX = B * (A > 0 ? A : 1);
     const size_t n_ints = (size_t)P_MAX * 4 + (size_t)B * 51 + (size_t)VT * 2;
-    HIPCHK(hipMalloc((void**)&d_ints, n_ints * 4)); HIPCHK(hipMalloc((void**)&d_par, (size_t)P_MAX * 12 * 4));
-    HIPCHK(hipMalloc((void**)&d_cons, (size_t)P_MAX * 4)); HIPCHK(hipMalloc((void**)&d_clsc, (size_t)VT * (C - 1) * 4));
-    HIPCHK(hipMalloc((void**)&d_jobs, sizeof(NoiseJob) * B)); HIPCHK(hipMalloc((void**)&d_lsum, sizeof(unsigned long long) * P_MAX));
-    uint8_t* d_aug = nullptr; size_t aug_cap = 0;
+    ScopedDev scratch(c->stream);
     int rc = 0;
+    if ((rc = scratch.alloc(&d_ints, n_ints * 4)) || (rc = scratch.alloc(&d_par, (size_t)P_MAX * 12 * 4)) ||
+        (rc = scratch.alloc(&d_cons, (size_t)P_MAX * 4)) || (rc = scratch.alloc(&d_clsc, (size_t)VT * (C - 1) * 4)) ||
+        (rc = scratch.alloc(&d_jobs, sizeof(NoiseJob) * B)) || (rc = scratch.alloc(&d_lsum, sizeof(unsigned long long) * P_MAX))) return rc;
+    uint8_t* d_aug = nullptr; size_t aug_cap = 0;
     std::vector<int> h_count(VT); std::vector<float> h_boxes((size_t)B * cap * 4), h_cons(P_MAX), h_clsc((size_t)VT * (C - 1));
     auto cleanup = [&]() {
         hipStreamSynchronize(c->stream);
-        hipFree(d_ints); hipFree(d_par); hipFree(d_cons); hipFree(d_clsc); hipFree(d_jobs); hipFree(d_lsum); hipFree(d_aug);
+        hipFree(d_aug);          // the fixed scratch belongs to `scratch`
     };
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     for (int i0 = 0; i0 < n_images && !rc; i0 += B) {
@@ -1325,8 +1338,12 @@ extern "C" int cald_sweep_lsc(cald_model* m, int n_images, const uint8_t* const*
     DetBuffers& D = m->sweep_det;
     int* d_ints = nullptr; float *d_par = nullptr, *d_rows = nullptr; NoiseJob* d_gjobs = nullptr; float* d_noise = nullptr; size_t noise_cap = 0;
     const size_t n_ints = (size_t)P_MAX * 4 + (size_t)B * 51;
-    HIPCHK(hipMalloc((void**)&d_ints, n_ints * 4)); HIPCHK(hipMalloc((void**)&d_par, (size_t)P_MAX * 12 * 4));
-    HIPCHK(hipMalloc((void**)&d_rows, (size_t)P_MAX * 50 * 4)); HIPCHK(hipMalloc((void**)&d_gjobs, sizeof(NoiseJob) * B));
+    ScopedDev scratch(c->stream);
+    {
+        int rc0;
+        if ((rc0 = scratch.alloc(&d_ints, n_ints * 4)) || (rc0 = scratch.alloc(&d_par, (size_t)P_MAX * 12 * 4)) ||
+            (rc0 = scratch.alloc(&d_rows, (size_t)P_MAX * 50 * 4)) || (rc0 = scratch.alloc(&d_gjobs, sizeof(NoiseJob) * B))) return rc0;
+    }
     HIPCHK(hipMemset(d_par, 0, (size_t)P_MAX * 12 * 4));
     std::vector<int> h_count(VT); std::vector<float> h_pm((size_t)B * cap), h_rows((size_t)P_MAX * 50);
     int rc = 0;
@@ -1415,6 +1432,6 @@ extern "C" int cald_sweep_lsc(cald_model* m, int n_images, const uint8_t* const*
         }
     }
     hipStreamSynchronize(c->stream);
-    hipFree(d_ints); hipFree(d_par); hipFree(d_rows); hipFree(d_gjobs); if (d_noise) hipFree(d_noise);
+    if (d_noise) hipFree(d_noise);          // the fixed scratch belongs to `scratch`
     return rc;
 }
