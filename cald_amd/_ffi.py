@@ -30,7 +30,7 @@ PRECISION = {"fp32": 0, "f16x3": 1}
 
 class View(C.Structure):
     _fields_ = [("image_dev", C.c_void_p), ("H", C.c_int), ("W", C.c_int), ("flip", C.c_int), ("nrect", C.c_int),
-                ("rects", C.c_int * 16)]
+                ("rects", C.c_int * 16), ("noise_dev", C.c_void_p)]
 
 
 class Dets(C.Structure):

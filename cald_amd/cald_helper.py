@@ -133,8 +133,8 @@ def cutout(image, boxes, labels, cut_num=2, fill_val=0, bbox_remove_thres=0.4, b
 
 
 def intersect(boxes1, boxes2):
-    n1, n2 = boxes1.size(0), boxes2.size(0)
-    max_xy = torch.min(boxes1[:, 2:].unsqueeze(1).expand(n1, n2, 2), boxes2[:, 2:].unsqueeze(0).expand(n1, n2, 2))
-    min_xy = torch.max(boxes1[:, :2].unsqueeze(1).expand(n1, n2, 2), boxes2[:, :2].unsqueeze(0).expand(n1, n2, 2))
-    inter = torch.clamp(max_xy - min_xy, min=0)
-    return inter[:, :, 0] * inter[:, :, 1]
+    """Pairwise intersection areas [n1, n2] of two (x1, y1, x2, y2) box sets (cald_helper.py:226-243)."""
+    a, b = boxes1[:, None, :], boxes2[None, :, :]
+    w = (torch.minimum(a[..., 2], b[..., 2]) - torch.maximum(a[..., 0], b[..., 0])).clamp(min=0)
+    h = (torch.minimum(a[..., 3], b[..., 3]) - torch.maximum(a[..., 1], b[..., 1])).clamp(min=0)
+    return w * h

@@ -338,6 +338,7 @@ struct cald_model {
     std::vector<ViewDesc> last_views;
     // batch-level detection buffers used by cald_sweep
     DetBuffers sweep_det; int sweep_det_views = 0;
+    int key_cap = 32768;   // FRCNN candidate (proposal, class) list capacity per view, sized from box_score_thresh at create
 };
 
 static int round_up(int x, int m) { return (x + m - 1) / m * m; }
@@ -354,6 +355,15 @@ extern "C" int cald_model_create(cald_ctx* ctx, const cald_model_cfg* cfg, cald_
     if (cfg->precision != CALD_PRECISION_FP32 && cfg->precision != CALD_PRECISION_F16X3) return fail(CALD_ERR_INVALID, "unknown precision %d", cfg->precision);
     cald_model* m = new cald_model();
     m->ctx = ctx; m->cfg = *cfg;
+    {   // softmax rows sum to 1, so fewer than 1/thr classes of one proposal can pass `score > thr` (frcnn_la.py:72):
+        // the candidate list never exceeds ROI_CAP * min(C - 1, ceil(1/thr) - 1) entries -- size it so nothing is ever dropped
+        const float thr = cfg->box_score_thresh;
+        long long per = cfg->num_classes - 1;
+        if (thr > 0.0f && std::isfinite(thr)) { const long long lim = (long long)std::ceil(1.0 / (double)thr) - 1; if (lim < per) per = lim < 1 ? 1 : lim; }
+        long long need = (long long)CALD_ROI_CAP * per;
+        int kc = 1024; while (kc < need) kc <<= 1;
+        m->key_cap = kc;
+    }
     memset(&m->sweep_det, 0, sizeof(m->sweep_det));
     *out = m;
     return 0;
@@ -725,8 +735,8 @@ static void fwd_layout(cald_model* m, Bump& B, FwdBufs& F, int V) {
     F.pr = B.get<float>((size_t)V * CALD_ROI_CAP * m->pred.Cout);
     F.prob = B.get<float>((size_t)V * CALD_ROI_CAP * m->cfg.num_classes);
     F.pmax = B.get<float>((size_t)V * CALD_ROI_CAP);
-    F.keys = B.get<unsigned long long>((size_t)V * 32768);
-    F.cbox = B.get<float>((size_t)V * 2 * 32768 * 4);
+    F.keys = B.get<unsigned long long>((size_t)V * m->key_cap);
+    F.cbox = B.get<float>((size_t)V * 2 * m->key_cap * 4);
     F.key_count = B.get<int>(V);
 }
 
@@ -887,7 +897,7 @@ static int forward_model(cald_model* m, int V, ViewDesc* views, const DetBuffers
     pa.pred = F.pr; pa.pred_ld = m->pred.Cout; pa.C = m->cfg.num_classes; pa.V = V;
     pa.proposals = F.proposals; pa.prop_count = F.prop_count; pa.views = c->d_views;
     pa.score_thr = m->cfg.box_score_thresh; pa.nms_thr = m->cfg.box_nms_thresh;
-    pa.prob = F.prob; pa.pmax = F.pmax; pa.keys = F.keys; pa.cbox = F.cbox; pa.key_count = F.key_count; pa.key_cap = 32768;
+    pa.prob = F.prob; pa.pmax = F.pmax; pa.keys = F.keys; pa.cbox = F.cbox; pa.key_count = F.key_count; pa.key_cap = m->key_cap;
     pa.det = det;
     launch_frcnn_postprocess(pa, st);
     HIPCHK(hipGetLastError());
@@ -896,7 +906,7 @@ static int forward_model(cald_model* m, int V, ViewDesc* views, const DetBuffers
 
 static int fill_view(ViewDesc& d, const cald_view& v) {
     memset(&d, 0, sizeof(d));
-    d.src = v.image_dev; d.H = v.H; d.W = v.W; d.flip = v.flip ? 1 : 0; d.nrect = v.nrect;
+    d.src = v.image_dev; d.H = v.H; d.W = v.W; d.flip = v.flip ? 1 : 0; d.nrect = v.nrect; d.noise = v.noise_dev;
     if (v.nrect < 0 || v.nrect > CALD_MAX_CUT) return fail(CALD_ERR_INVALID, "nrect must be 0..%d", CALD_MAX_CUT);
     for (int i = 0; i < 4 * v.nrect; i++) d.rects[i] = v.rects[i];
     return 0;
@@ -1002,17 +1012,42 @@ extern "C" int cald_op_conv2d_f16x3(cald_ctx* c, const float* in, int H, int W, 
 }
 
 // helper: device detection buffers
-static int alloc_det(DetBuffers& d, int V, int cap, int C) {
-    d.cap = cap; d.C = C;
-    HIPCHK(hipMalloc((void**)&d.boxes, (size_t)V * cap * 16)); HIPCHK(hipMalloc((void**)&d.scores, (size_t)V * cap * 4));
-    HIPCHK(hipMalloc((void**)&d.labels, (size_t)V * cap * 8)); HIPCHK(hipMalloc((void**)&d.props, (size_t)V * cap * 16));
-    HIPCHK(hipMalloc((void**)&d.prob_max, (size_t)V * cap * 4)); HIPCHK(hipMalloc((void**)&d.scores_cls, (size_t)V * cap * C * 4));
-    HIPCHK(hipMalloc((void**)&d.count, (size_t)V * 4));
-    return 0;
-}
 static void free_det(DetBuffers& d) {
     hipFree(d.boxes); hipFree(d.scores); hipFree(d.labels); hipFree(d.props); hipFree(d.prob_max); hipFree(d.scores_cls); hipFree(d.count);
     memset(&d, 0, sizeof(d));
+}
+// all-or-nothing: on any failed hipMalloc everything already allocated is released and `d` is left zeroed
+static int alloc_det(DetBuffers& d, int V, int cap, int C) {
+    memset(&d, 0, sizeof(d));
+    d.cap = cap; d.C = C;
+    const hipError_t e = [&]() {
+        hipError_t r;
+        if ((r = hipMalloc((void**)&d.boxes, (size_t)V * cap * 16)) != hipSuccess) return r;
+        if ((r = hipMalloc((void**)&d.scores, (size_t)V * cap * 4)) != hipSuccess) return r;
+        if ((r = hipMalloc((void**)&d.labels, (size_t)V * cap * 8)) != hipSuccess) return r;
+        if ((r = hipMalloc((void**)&d.props, (size_t)V * cap * 16)) != hipSuccess) return r;
+        if ((r = hipMalloc((void**)&d.prob_max, (size_t)V * cap * 4)) != hipSuccess) return r;
+        if ((r = hipMalloc((void**)&d.scores_cls, (size_t)V * cap * C * 4)) != hipSuccess) return r;
+        return hipMalloc((void**)&d.count, (size_t)V * 4);
+    }();
+    if (e != hipSuccess) {
+        free_det(d);
+        return fail(CALD_ERR_HIP, "hipMalloc of detection buffers (%d views x %d rows x %d classes) failed: %s", V, cap, C, hipGetErrorString(e));
+    }
+    return 0;
+}
+// the model's batch-level detection buffers hold at least VT views; after a failed growth the model owns none
+static int ensure_sweep_det(cald_model* m, int VT) {
+    if (m->sweep_det_views >= VT) return 0;
+    if (m->sweep_det_views) {
+        HIPCHK(hipStreamSynchronize(m->ctx->stream));
+        free_det(m->sweep_det);
+        m->sweep_det_views = 0;
+    }
+    int rc = alloc_det(m->sweep_det, VT, m->det_cap(), m->cfg.num_classes);
+    if (rc) return rc;
+    m->sweep_det_views = VT;
+    return 0;
 }
 
 extern "C" int cald_op_consistency(cald_ctx* c, int N, const float* aug_box, const float* ref_scores_cls, const float* ref_pm,
@@ -1075,7 +1110,7 @@ extern "C" int cald_op_cls_corr(cald_ctx* c, int n, const float* scores, const i
 // =============================================================================================
 extern "C" int cald_sweep(cald_model* m, int n_images, const uint8_t* const* images_dev, const int* H, const int* W,
                           const int64_t* pool_pos, const cald_sweep_cfg* cfg, double* consistency_out, double* cls_corr_out) {
-    if (!m || !images_dev || !H || !W || !cfg || !consistency_out || !cls_corr_out) return fail(CALD_ERR_INVALID, "null argument");
+    if (!m || !images_dev || !H || !W || !pool_pos || !cfg || !consistency_out || !cls_corr_out) return fail(CALD_ERR_INVALID, "null argument");
     if (!m->finalized) return fail(CALD_ERR_STATE, "model not finalized");
     cald_ctx* c = m->ctx;
     HIPCHK(hipSetDevice(c->device));
@@ -1095,11 +1130,7 @@ extern "C" int cald_sweep(cald_model* m, int n_images, const uint8_t* const* ima
     int B = cfg->batch_images > 0 ? cfg->batch_images : 64;
     if (B > CALD_MAX_VIEWS) B = CALD_MAX_VIEWS;
     const int VT = B * (1 + A);
-    if (m->sweep_det_views < VT) {
-        if (m->sweep_det_views) { HIPCHK(hipStreamSynchronize(c->stream)); free_det(m->sweep_det); }
-        int rc = alloc_det(m->sweep_det, VT, cap, C); if (rc) return rc;
-        m->sweep_det_views = VT;
-    }
+    { int rc0 = ensure_sweep_det(m, VT); if (rc0) return rc0; }
     DetBuffers& D = m->sweep_det;
     // small device scratch for the scoring stage + an arena for augmented uint8 images
     int *d_ints = nullptr; float *d_par = nullptr, *d_cons = nullptr, *d_clsc = nullptr;
@@ -1296,11 +1327,7 @@ extern "C" int cald_sweep_ltc(cald_model* m, int n_images, const uint8_t* const*
     HIPCHK(hipSetDevice(c->device));
     int B = batch_images > 0 ? batch_images : 64; if (B > CALD_MAX_VIEWS) B = CALD_MAX_VIEWS;
     const int C = m->cfg.num_classes, cap = m->det_cap();
-    if (m->sweep_det_views < B) {
-        if (m->sweep_det_views) { HIPCHK(hipStreamSynchronize(c->stream)); free_det(m->sweep_det); }
-        int rc = alloc_det(m->sweep_det, B, cap, C); if (rc) return rc;
-        m->sweep_det_views = B;
-    }
+    { int rc0 = ensure_sweep_det(m, B); if (rc0) return rc0; }
     float* d_out = nullptr; HIPCHK(hipMalloc((void**)&d_out, (size_t)B * 4));
     std::vector<float> h(B);
     int rc = 0;
@@ -1330,11 +1357,7 @@ extern "C" int cald_sweep_lsc(cald_model* m, int n_images, const uint8_t* const*
     const int A = 6;
     int B = batch_images > 0 ? batch_images : 32; if (B > CALD_MAX_VIEWS) B = CALD_MAX_VIEWS;
     const int C = m->cfg.num_classes, cap = m->det_cap(), VT = B * (1 + A), P_MAX = B * A;
-    if (m->sweep_det_views < VT) {
-        if (m->sweep_det_views) { HIPCHK(hipStreamSynchronize(c->stream)); free_det(m->sweep_det); }
-        int rc = alloc_det(m->sweep_det, VT, cap, C); if (rc) return rc;
-        m->sweep_det_views = VT;
-    }
+    { int rc0 = ensure_sweep_det(m, VT); if (rc0) return rc0; }
     DetBuffers& D = m->sweep_det;
     int* d_ints = nullptr; float *d_par = nullptr, *d_rows = nullptr; NoiseJob* d_gjobs = nullptr; float* d_noise = nullptr; size_t noise_cap = 0;
     const size_t n_ints = (size_t)P_MAX * 4 + (size_t)B * 51;

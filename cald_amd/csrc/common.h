@@ -172,6 +172,23 @@ __host__ __device__ inline uint32_t det_orderable(float f) {
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE function attribute: raise it once for every device a
+// kernel is launched on (one context per device may live in the same process), thread-safely.
+#include <atomic>
+struct PerDeviceOnce {
+    std::atomic<bool> done[64];
+    PerDeviceOnce() { for (auto& d : done) d.store(false); }
+    bool first() {   // true exactly once per current device
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+        return !done[dev].exchange(true);
+    }
+};
+template <typename K> static inline void allow_big_lds(PerDeviceOnce& once, K kernel) {
+    if (once.first())
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+}
+
 // ---------------------------------------------------------------------------------------------
 // kernel launchers (implemented in the .hip files; all asynchronous on `stream`)
 // ---------------------------------------------------------------------------------------------

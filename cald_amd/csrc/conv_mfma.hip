@@ -280,7 +280,6 @@ static void launch_cfg(const ConvArgs& a, int bn, hipStream_t stream) {
     else hipLaunchKernelGGL((conv_mfma_f32_kernel<WM, WN, TM, TN, 0, BK, true>), grid, block, dl, stream, a);
 }
 
-bool launch_conv_p3(const ConvArgs& a, hipStream_t stream);   // conv_p3.hip
 bool launch_conv_p4(const ConvArgs& a, hipStream_t stream);   // conv_p4.hip
 bool launch_conv_h3(const ConvArgs& a, hipStream_t stream);   // conv_h3.hip (opt-in split-fp16 mode: only when a.w16 is set)
 
@@ -289,21 +288,19 @@ bool launch_conv_h3_group(const ConvArgs* p, int n, hipStream_t stream);
 void launch_conv(const ConvArgs& a, hipStream_t stream);
 int launch_conv_group(const ConvArgs* probs, int n, hipStream_t stream) {   // returns the number of kernel launches issued
     static const int grp = conv_env("CALD_CONV_GROUP", 1);
-    static const int p4 = conv_env("CALD_CONV_P4", 1), p3 = conv_env("CALD_CONV_P3", 1);
+    static const int p4 = conv_env("CALD_CONV_P4", 1);
     if (grp && n > 1) {
         if (probs[0].w16 && launch_conv_h3_group(probs, n, stream)) return 1;
-        if (!probs[0].w16 && p3 && p4 && launch_conv_p4_group(probs, n, stream)) return 1;
+        if (!probs[0].w16 && p4 && launch_conv_p4_group(probs, n, stream)) return 1;
     }
     for (int i = 0; i < n; i++) launch_conv(probs[i], stream);
     return n;
 }
 
 void launch_conv(const ConvArgs& a, hipStream_t stream) {
-    static const int p3 = conv_env("CALD_CONV_P3", 1);   // pipelined 3-buffer schedule for 128-wide tiles (conv_p3.hip); 0 = this file only
-    static const int p4 = conv_env("CALD_CONV_P4", 1);   // conv_p4.hip: p3 + 128-bit LDS fragment reads
+    static const int p4 = conv_env("CALD_CONV_P4", 1);   // conv_p4.hip: 3-buffer pipelined schedule, 128-bit LDS fragment reads; 0 = this file only
     if (a.w16 && launch_conv_h3(a, stream)) return;
-    if (p3 && p4 && launch_conv_p4(a, stream)) return;
-    if (p3 && launch_conv_p3(a, stream)) return;
+    if (p4 && launch_conv_p4(a, stream)) return;
     static const int bk32 = conv_env("CALD_CONV_BK32", 0);
     if (a.CoutPad % 128 == 0) {
         if (bk32 && a.Kpad % 32 == 0) launch_cfg<2, 2, 2, 2, 32>(a, 128, stream);

@@ -1,6 +1,8 @@
-// conv_p4.hip -- conv_p3's schedule with 128-bit LDS fragment reads.
+// conv_p4.hip -- the default implicit-GEMM conv / linear kernel: three LDS buffers, one raw s_barrier per k-tile placed
+// inside the MFMA burst, LDS writes / global loads / next-tile fragment prefetch interleaved with the MFMAs, SRSRC buffer
+// loads with hardware zero-fill for out-of-image taps, 128-bit LDS fragment reads.
 //
-// Same arithmetic and bit-identical results (one k-ordered fma chain per output).  Differences from conv_p3.hip:
+// Same arithmetic as conv_mfma.hip and bit-identical results (one k-ordered fma chain per output):
 //   * LDS tile layout [kq][row][h][j] (k = 8*kq + 2*j + h): the four A (or B) values a lane feeds into four
 //     consecutive v_mfma_f32_32x32x2_f32 are one aligned 16-byte word -> one ds_read_b128 per (sub-tile, kq)
 //     instead of four ds_read_b32; h is XOR-swizzled with bit 3 of the row so the 16-lane b128 groups are

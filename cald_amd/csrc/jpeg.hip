@@ -50,18 +50,19 @@ struct JImg {                 // one image, device-visible
 
 struct HostHuff { bool set = false; uint8_t bits[17]; uint8_t vals[256]; };
 
-const uint8_t* zigzag_table() {
-    static uint8_t zz[64];
-    static bool init = false;
-    if (!init) {
+struct ZigZag {
+    uint8_t zz[64];
+    ZigZag() {
         int k = 0;
         for (int s = 0; s < 15; s++) {
             if (s & 1) { for (int r = 0; r < 8; r++) { int c = s - r; if (c >= 0 && c < 8) zz[k++] = (uint8_t)(r * 8 + c); } }
             else       { for (int c = 0; c < 8; c++) { int r = s - c; if (r >= 0 && r < 8) zz[k++] = (uint8_t)(r * 8 + c); } }
         }
-        init = true;
     }
-    return zz;
+};
+const uint8_t* zigzag_table() {
+    static const ZigZag t;     // function-local static: initialised once, thread-safely
+    return t.zz;
 }
 
 void build_jtab(const HostHuff& h, JTab* t) {

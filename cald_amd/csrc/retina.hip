@@ -145,11 +145,8 @@ void launch_retina_postprocess(const RetinaArgs& a, int max_anchors, hipStream_t
     hipMemsetAsync(a.cand_count, 0, sizeof(int) * a.V * a.K, st);
     hipLaunchKernelGGL(retina_cand_kernel, dim3((max_anchors + 255) / 256, a.V), dim3(256), 0, st, a);
     size_t lds = (size_t)RET_LDS_KEYS * 8 + (size_t)a.per_class * (16 + 4 + 4) + 256 * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(retina_class_nms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
-        attr_set = true;
-    }
+    static PerDeviceOnce once;
+    allow_big_lds(once, retina_class_nms_kernel);
     hipLaunchKernelGGL(retina_class_nms_kernel, dim3(a.K, a.V), dim3(1024), lds, st, a);
     hipLaunchKernelGGL(retina_emit_kernel, dim3(a.K, a.V), dim3(256), 0, st, a);
 }

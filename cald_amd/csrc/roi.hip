@@ -203,10 +203,7 @@ void launch_frcnn_postprocess(const PostArgs& a, hipStream_t st) {
     hipMemsetAsync(a.key_count, 0, sizeof(int) * a.V, st);
     hipLaunchKernelGGL(post_softmax_kernel, dim3((CALD_ROI_CAP + 255) / 256, a.V), dim3(256), 0, st, a);
     size_t lds = (size_t)POST_LDS_KEYS * 8 + (size_t)a.det.cap * (16 + 4 + 4) + 256 * 4 + 1024 * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(post_nms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
-        attr_set = true;
-    }
+    static PerDeviceOnce once;
+    allow_big_lds(once, post_nms_kernel);
     hipLaunchKernelGGL(post_nms_kernel, dim3(a.V), dim3(1024), lds, st, a);
 }

@@ -152,10 +152,7 @@ void launch_rpn(const RpnArgs& a, hipStream_t st) {
     int NP = 1024;
     while (NP < 5 * a.pre_n) NP <<= 1;
     size_t lds = (size_t)NP * 8 + (size_t)a.post_n * (16 + 4 + 4) + 256 * 4 + 1024 * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(rpn_nms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
-        attr_set = true;
-    }
+    static PerDeviceOnce once;
+    allow_big_lds(once, rpn_nms_kernel);
     hipLaunchKernelGGL(rpn_nms_kernel, dim3(a.V), dim3(1024), lds, st, a, NP);
 }

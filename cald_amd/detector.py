@@ -32,6 +32,17 @@ def get_ctx(device_index=None):
     return _CTX[device_index]
 
 
+_U8_TABLE = {}
+
+
+def _u8_over_255(device):
+    """float32 table k / 255 (numpy: correctly rounded division, the same values as the kernel's `(float)u8 / 255.0f`)."""
+    key = str(device)
+    if key not in _U8_TABLE:
+        _U8_TABLE[key] = torch.from_numpy(np.arange(256, dtype=np.float32) / np.float32(255.0)).to(device)
+    return _U8_TABLE[key]
+
+
 class HipDetector:
     def __init__(self, num_classes, depth=50, min_size=800, max_size=1333, box_score_thresh=0.05, box_nms_thresh=0.5,
                  box_detections_per_img=100, rpn_pre_nms_top_n_test=1000, rpn_post_nms_top_n_test=1000,
@@ -110,7 +121,8 @@ class HipDetector:
 
     # ---- inference ----
     def forward_views(self, views):
-        """views: list of (uint8 HWC cuda tensor, flip, rects).  Returns list of result dicts (device tensors)."""
+        """views: list of (uint8 HWC cuda tensor, flip, rects[, noise]) -- noise: optional float32 CHW cuda tensor added to
+        image/255 (cald_view.noise_dev).  Returns list of result dicts (device tensors)."""
         L = _ffi.lib()
         h = self.handle()
         n = len(views)
@@ -122,9 +134,14 @@ class HipDetector:
                    prob_max=torch.empty((n, cap), device=dev), scores_cls=torch.empty((n, cap, Cn), device=dev),
                    count=torch.zeros((n,), dtype=torch.int32, device=dev))
         arr = (_ffi.View * n)()
-        for i, (img, flip, rects) in enumerate(views):
+        for i, view in enumerate(views):
+            img, flip, rects = view[:3]
+            noise = view[3] if len(view) > 3 else None
             assert img.dtype == torch.uint8 and img.is_cuda and img.is_contiguous() and img.shape[2] == 3
             arr[i].image_dev = img.data_ptr(); arr[i].H = img.shape[0]; arr[i].W = img.shape[1]
+            if noise is not None:
+                assert noise.dtype == torch.float32 and noise.is_cuda and noise.is_contiguous() and tuple(noise.shape) == (3, img.shape[0], img.shape[1])
+                arr[i].noise_dev = noise.data_ptr()
             arr[i].flip = int(bool(flip)); arr[i].nrect = 0 if rects is None else len(rects)
             if rects is not None:
                 for j, r in enumerate(np.asarray(rects, np.int32).reshape(-1)):
@@ -141,17 +158,28 @@ class HipDetector:
         return res
 
     def __call__(self, images, targets=None):
-        """model(list[Tensor[3,H,W] float32 in 0..1]) -> list[dict] (detection/frcnn_la.py:237-275).
-        The tensors are quantised back to the uint8 grid they came from (to_tensor, cald_train.py:107)."""
+        """model(list[Tensor[3,H,W] float32]) -> list[dict] (detection/frcnn_la.py:237-275).
+        A float tensor is split EXACTLY into the nearest uint8 grid image g and the float32 remainder x - g/255 (Sterbenz:
+        the subtraction is exact and fl(g/255 + (x - g/255)) == x), so to_tensor outputs (remainder all zero, no extra
+        traffic) and arbitrary floats -- e.g. a caller-made GaussianNoise image -- both reach the kernels bit for bit."""
         if self.training:
             raise NotImplementedError("inference only")
         views = []
         for img in images:
             if img.dtype == torch.uint8:
                 u8 = img if img.shape[-1] == 3 else img.permute(1, 2, 0)
-            else:
-                u8 = (img * 255.0).round().clamp(0, 255).to(torch.uint8).permute(1, 2, 0)
-            views.append((u8.contiguous().cuda(), False, None))
+                views.append((u8.contiguous().cuda(), False, None))
+                continue
+            x = img.detach().to(torch.float32).cuda().contiguous()
+            if not bool(torch.isfinite(x).all()):
+                raise ValueError("non-finite pixel values in the input image")
+            g = (x * 255.0).round().clamp(0, 255).to(torch.uint8)
+            base = _u8_over_255(x.device)[g.long()]            # the kernel's (float)u8 / 255.0f, IEEE division
+            rem = x - base
+            if not bool(torch.equal(base + rem, x)):             # cannot happen for finite inputs; fail loudly rather than drift
+                raise RuntimeError("float input is not representable as uint8 grid + float32 remainder")
+            noise = rem.contiguous() if bool((rem != 0).any()) else None
+            views.append((g.permute(1, 2, 0).contiguous(), False, None, noise))
         return self.forward_views(views)
 
     def debug_tensor(self, name, view=0):

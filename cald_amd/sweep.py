@@ -164,37 +164,46 @@ def get_uncertainty(task_model, unlabeled_loader, augs, num_cls, bp=1.3, base_se
     return [float(c) for c in cons], [cls[i] for i in range(cls.shape[0])]
 
 
-def cls_kldiv(labeled_loader, cls_corrs, budget, cycle=0, uniform=False):
-    """cald_train.py:234-271 (host side, float64; `uniform` replaces the global args.uniform)."""
-    from torch import nn
-    cls_inds, result = [], []
+def _labeled_class_histogram(labeled_loader, width):
+    """Mean per-image class count vector of the labeled set (cald_train.py:237-242, :253); labels are 1-based."""
+    rows = []
     for _, targets in labeled_loader:
         for target in targets:
-            cls_corr = [0] * cls_corrs[0].shape[0]
-            for l in target['labels']:
-                cls_corr[int(l) - 1] += 1
-            result.append(cls_corr)
-    for a in list(np.where(np.sum(cls_corrs, axis=1) == 0)[0]):
-        cls_inds.append(int(a))
-    kld = nn.KLDivLoss(reduction='none')
-    _cls = torch.tensor(np.asarray(cls_corrs))
-    _res = torch.tensor(np.mean(np.array(result), axis=0)).unsqueeze(0)
-    while len(cls_inds) < budget:
-        if uniform:
-            p = torch.nn.functional.softmax(_res + _cls, -1)
-            q = torch.nn.functional.softmax(torch.ones(_res.shape) / len(_res), -1)
-            log_mean = ((p + q) / 2).log()
-            js = torch.sum(kld(log_mean, p), dim=1) / 2 + torch.sum(kld(log_mean, q), dim=1) / 2
-            js[cls_inds] = 100
-            cls_inds.append(torch.argmin(js).item())
-        else:
-            p = torch.nn.functional.softmax(_res, -1)
-            q = torch.nn.functional.softmax(_cls, -1)
-            log_mean = ((p + q) / 2).log()
-            js = torch.sum(kld(log_mean, p), dim=1) / 2 + torch.sum(kld(log_mean, q), dim=1) / 2
-            js[cls_inds] = -1
-            cls_inds.append(torch.argmax(js).item())
-    return cls_inds
+            lab = np.asarray([int(l) for l in target['labels']], dtype=np.int64) - 1
+            lab[lab < 0] += width                     # Python's negative indexing (label 0 lands in the last slot)
+            rows.append(np.bincount(lab, minlength=width)[:width])
+    return np.mean(np.array(rows), axis=0)
+
+
+def cls_kldiv(labeled_loader, cls_corrs, budget, cycle=0, uniform=False):
+    """Second-stage class-balance pick of cald_train.py:234-271 (host side, float64; `uniform` replaces the global
+    args.uniform).  Candidates whose cls_corr is all zero come first (:246-247, possibly more than `budget` of them).
+    The reference then recomputes the same JS vector in every iteration (its `result` is never updated, :270 is
+    commented out) and takes the arg-max of the not-yet-picked entries -- i.e. it walks the candidates in descending
+    JS order, first index first on ties (ascending for --uniform).  Here the vector is computed ONCE, with the
+    reference's own torch float64 operations so the order is index-exact, and walked."""
+    corr = np.asarray(cls_corrs, dtype=np.float64)
+    picked = [int(i) for i in np.flatnonzero(corr.sum(axis=1) == 0)]
+    if len(picked) >= budget:
+        return picked
+    hist = torch.from_numpy(_labeled_class_histogram(labeled_loader, corr.shape[1])).unsqueeze(0)
+    cand = torch.from_numpy(corr)
+    if uniform:
+        p = torch.softmax(hist + cand, -1)
+        q = torch.softmax(torch.ones(hist.shape) / len(hist), -1)
+    else:
+        p = torch.softmax(hist, -1)
+        q = torch.softmax(cand, -1)
+    log_mean = ((p + q) / 2).log()
+    kl = torch.nn.functional.kl_div
+    js = (kl(log_mean, p, reduction='none').sum(dim=1) / 2 + kl(log_mean, q, reduction='none').sum(dim=1) / 2).numpy()
+    free = np.ones(len(js), dtype=bool)
+    free[picked] = False
+    order = np.argsort(js if uniform else -js, kind='stable')
+    picked += [int(i) for i in order if free[i]][:budget - len(picked)]
+    # budget larger than the candidate list: every entry is masked, so the reference's arg-max/arg-min returns 0 from then on
+    picked += [0] * (budget - len(picked))
+    return picked
 
 
 def select(uncertainty, cls_corrs, labeled_loader, budget, mr=1.2, mutual=True, uniform=False):

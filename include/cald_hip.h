@@ -85,6 +85,9 @@ typedef struct cald_view {
     int flip;                 /* cald_helper.HorizontalFlip */
     int nrect;                /* cald_helper.cutout rectangles (left, top, right, bottom), <= 4 */
     int rects[16];
+    const float* noise_dev;   /* optional float32 [3][H][W] (CHW) added to image/255 before normalisation, or NULL.  With it a
+                               * view carries ANY float input tensor exactly (the reference model accepts arbitrary floats,
+                               * e.g. a caller-made GaussianNoise image): image = rounded uint8 grid, noise = x - image/255. */
 } cald_view;
 
 /* Result dict of the detector (detection/frcnn_la.py:131-141): device buffers, `cap` rows per view. */

@@ -13,6 +13,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 
 
+@pytest.fixture(autouse=True)
+def _gpu_tests_need_a_gpu(request):
+    """`-m gpu` tests are the parity tests proper and run on a GPU box; a plain `pytest` on a CPU box skips them
+    (the product path itself has no CPU fallback and raises)."""
+    if request.node.get_closest_marker("gpu") is not None:
+        import torch
+        if not torch.cuda.is_available():
+            pytest.skip("needs an MI355X")
+
+
 @pytest.fixture(scope="session")
 def oracle():
     """The CPU oracle (test infrastructure).  Built on demand with gcc."""

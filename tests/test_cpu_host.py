@@ -82,6 +82,19 @@ def test_selection_matches_reference_golden(golden):
     np.testing.assert_array_equal(np.argsort(g["argsort_in"]), g["argsort_out"])
 
 
+def test_selection_edge_cases_match_reference_golden(golden):
+    """Ties in the JS vector, zero-sum candidates beyond the budget, budget > candidates, 90-wide vectors, --uniform:
+    cls_kldiv as executed from /root/reference (oracle/make_golden_selection.py) vs the product's computed-once form."""
+    from cald_amd import sweep
+    import torch
+    g = golden("selection_more")
+    for case in range(int(g["n_cases"])):
+        labels = g["labels%d" % case]
+        loader = [(None, [{"labels": torch.from_numpy(row[row >= 0])}]) for row in labels]
+        sel = sweep.cls_kldiv(loader, list(g["cls_corrs%d" % case]), int(g["budget%d" % case]), 0, uniform=bool(g["uniform%d" % case]))
+        np.testing.assert_array_equal(np.array(sel, np.int64), g["sel%d" % case])
+
+
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
     return p

@@ -14,7 +14,8 @@ SCORING = ["scoring_frcnn_F", "scoring_frcnn_FCD", "scoring_retina_FCD", "scorin
 @pytest.fixture(scope="module")
 def hip():
     import torch
-    assert torch.cuda.is_available(), "these tests need an MI355X"
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X (run with -m gpu on a GPU box); no CPU fallback exists for the product path")
     from cald_amd import _ffi, detector
     L = _ffi.lib()
     return dict(L=L, ffi=_ffi, ctx=detector.get_ctx(0), det=detector, torch=torch)
