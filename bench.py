@@ -1,18 +1,27 @@
 #!/usr/bin/env python
 """bench.py -- CALD consistency sweep throughput on MI355X (unlabeled images scored / second).
 
-A "step" is one pass of the hot path (cald_sweep: reference view + 3 augmented views per image,
-detector forward x4, consistency scoring) over one batch of synthetic VOC-shaped images that are
-already resident in HBM.  Workload = BASELINE.json configs[1]: Faster R-CNN ResNet-50 FPN, 21
-classes, min/max size 600/1000, augmentations flip / cut_out / smaller_resize, seeded pseudo-trained
-weights (cald_amd/synth.py), float32 (exact fp32 MFMA).
+Workload = BASELINE.json configs[1]: Faster R-CNN ResNet-50 FPN, 21 classes, min/max size 600/1000, augmentations flip /
+cut_out / smaller_resize, seeded pseudo-trained weights (cald_amd/synth.py), float32 (exact fp32 MFMA), on a pool of
+synthetic VOC2012-shaped baseline-JPEG files.
 
-    python bench.py --gpus N --steps K --warmup W
-For N > 1 launch with torch.distributed.run (one rank per GPU, RCCL); the pool is sharded by position
-(no data-path collective) and one all-gather of the per-image scores closes the timed region.
-Prints ONE JSON line on rank 0.
+A "step" is one pass of the hot path (cald_sweep: reference view + 3 augmented views per image, detector forward x4,
+consistency scoring) over one batch of 64 pool images.  The timed region (SURVEY.md section 8d metric) is
+    K steps over a pool of K x 64 images per GPU that is resident in HBM (decoded once on the GPU from the JPEG bytes,
+    cald_amd/pool.py)  ->  one all-gather of the per-image score rows (N > 1)  ->  argsort + cls_kldiv selection on the
+    host  ->  selected indices available,
+bracketed by barrier + synchronize; `value` = images of all ranks / max-over-ranks time.  The JPEG decode + H2D of the
+same pool is timed right before it and reported as `from_host_jpeg_bytes` (PCIe- and decode-inclusive rate; never
+`value`).  At N = 1 the headline run additionally sweeps the FULL configs[1] pool (5 217 images: host JPEG bytes ->
+selected 500 indices, everything inside one clock) and reports it as `full_pool`.
+
+    python bench.py --gpus N --steps K --warmup W [--scaling weak|strong]
+For N > 1 launch with torch.distributed.run (one rank per GPU, RCCL); the pool is sharded by position (rank-local inputs,
+no data-path collective) and one all-gather of the score rows closes the timed region.  Prints ONE JSON line on rank 0.
 """
 import argparse
+import hashlib
+import io
 import json
 import os
 import sys
@@ -24,12 +33,47 @@ if ROOT not in sys.path:
 
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
 F16_MFMA_PEAK_TFLOPS = 2516.6  # v_mfma_f32_32x32x16_f16: 32 cycles / SIMD -> 16 x the f32-input rate (dense)
+FULL_POOL = 5217               # VOC2012 train 5 717 - 500 initially labeled (cald_train.py:299-300)
+FULL_BUDGET = 500
 
 
-def cpu_baseline(sd, pool, augs, budget_s=12.0, max_images=24):
-    """The reference-shaped PyTorch-CPU port (oracle/torch_port.py) on a bounded sample of the same workload."""
+def _jpeg_of(args):
+    """(pool position, (H, W)) -> baseline JPEG bytes of the synthetic image (runs in forked host workers)."""
+    pos, (H, W) = args
+    from PIL import Image
+    from cald_amd import synth
+    b = io.BytesIO()
+    Image.fromarray(synth.synth_image(pos, H, W)).save(b, format="JPEG", quality=90)
+    return b.getvalue()
+
+
+def make_jpeg_pool(positions, sizes):
+    """Synthetic pool as JPEG byte strings, generated on the host cores BEFORE anything touches the GPU (fork is only
+    safe then).  Not timed: stands for the files of the dataset directory."""
+    import multiprocessing as mp
+    jobs = [(p, sizes[p]) for p in positions]
+    nproc = max(1, min(64, (os.cpu_count() or 1) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))))
+    if nproc == 1 or len(jobs) < 8:
+        return [_jpeg_of(j) for j in jobs]
+    with mp.get_context("fork").Pool(nproc) as pool:
+        return pool.map(_jpeg_of, jobs, chunksize=8)
+
+
+def synthetic_labeled_set(n=500, num_cls=21, seed=0):
+    """Class labels of the initially labeled images (what cls_kldiv reads from labeled_loader, cald_train.py:237-242)."""
+    import numpy as np
     import torch
+    rs = np.random.RandomState(seed)
+    return [(None, [{"labels": torch.from_numpy(rs.randint(1, num_cls, rs.randint(1, 6)))}]) for _ in range(n)]
+
+
+def cpu_baseline(sd, blobs, augs, budget_s=12.0, max_images=24):
+    """The reference-shaped PyTorch-CPU port (oracle/torch_port.py) on a bounded sample of the same workload."""
+    import numpy as np
+    import torch
+    from PIL import Image
     from oracle import torch_port
+    pool = [np.asarray(Image.open(io.BytesIO(b)).convert("RGB")) for b in blobs[:max_images]]
     model = torch_port.TorchFRCNN(sd, 21, 50, 600, 1000)
     model.forward(pool[0])          # warm-up view (oneDNN primitive creation), not timed
     # batch-1 convolutions do not scale to every core of a big host: use the thread count that is fastest here
@@ -43,24 +87,43 @@ def cpu_baseline(sd, pool, augs, budget_s=12.0, max_images=24):
             best = (nt, t)
     torch.set_num_threads(best[0])
     n, t0 = 0, time.time()
-    while n < max_images and (n == 0 or time.time() - t0 < budget_s):
+    while n < len(pool) and (n == 0 or time.time() - t0 < budget_s):
         torch_port.get_uncertainty(model, [pool[n]], augs, 21, bp=1.3, base_seed=0, positions=[n])
         n += 1
     dt = time.time() - t0
     used = torch.get_num_threads()
     torch.set_num_threads(default_threads)
-    return {"value": n / dt, "unit": "images/s", "cores": used, "kind": "port",
+    return {"value": n / dt, "unit": "images/s", "cores": used,
+            "kind": "port (torch-CPU fp32 convs / linears; top-k, NMS, RoIAlign and post-processing in the OpenMP C oracle -- "
+                    "stronger than the reference's pure-PyTorch CPU path)",
             "sample": "%d synthetic VOC-shaped image(s) x 4 views, batch-1 sequential torch-CPU fp32 forwards + python/scipy "
                       "scoring loop (oracle/torch_port.py), %.1f s; thread count chosen as the fastest of {T, T/2, T/4, T/8}" % (n, dt)}
+
+
+def latest_pmc():
+    """HBM bytes per GEMM launch from the rocprofv3 PMC passes of this same command (tools/profile_gpu.sh ->
+    tools/summarize_profile.py -> profiles/*_pmc.json; FETCH_SIZE x2 gfx950 correction + WRITE_SIZE).  Not measured in
+    this process (a process cannot attach rocprofv3 to itself): the source file is named next to the number."""
+    try:
+        cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc.json"))
+        if cands:
+            return json.load(open(os.path.join(ROOT, "profiles", cands[-1])))["conv_mfma"]["hbm_bytes_per_launch"], "profiles/" + cands[-1]
+    except Exception:
+        pass
+    return None, None
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch-images", type=int, default=64)
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: K x 64 images per GPU (pool grows with N); strong: K x 64 images in total, split over the N GPUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-full-pool", action="store_true", help="skip the 5 217-image end-to-end run (N = 1 headline only)")
+    ap.add_argument("--no-f16x3", action="store_true")
     ap.add_argument("--model", default="frcnn", choices=["frcnn", "frcnn101", "retinanet"],
                     help="frcnn = the headline workload (BASELINE configs[1]); others are informational runs of configs[2]/[4]")
     ap.add_argument("--shape", default="voc", choices=["voc", "coco"])
@@ -69,20 +132,45 @@ def main():
                     help="fp32 = exact (headline, bit-identical to the oracle); f16x3 = informational split-fp16 MFMA path")
     args = ap.parse_args()
 
-    import numpy as np
-    import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
+    B, K, Wm = args.batch_images, args.steps, args.warmup
+    letters = {"F": "flip", "C": "cut_out", "D": "smaller_resize", "R": "rotation", "G": "ga", "S": "sp"}
+    augs = [letters[ch] for ch in args.augs]
+    ncls = 21 if args.shape == "voc" else 91
+    mn, mx = (600, 1000) if args.shape == "voc" else (800, 1333)
+    headline = (args.model == "frcnn" and args.shape == "voc" and args.augs == "FCD" and args.precision == "fp32")
+    do_full = headline and world == 1 and not args.no_full_pool
+
+    # ---- the pool as files (host JPEG bytes): rank r owns pool positions p % world == r (rank-local inputs) ----
+    from cald_amd import synth
+    pool_total = world * K * B if args.scaling == "weak" else K * B
+    n_warm = Wm * B
+    total_needed = max(pool_total + world * n_warm, FULL_POOL if do_full else 0)
+    sizes = synth.pool_sizes(total_needed, args.shape, 0)
+    positions = list(range(rank, pool_total, world))                              # timed pool, this rank's shard
+    warm_positions = list(range(pool_total + rank, pool_total + world * n_warm, world))
+    blobs = make_jpeg_pool(positions, sizes)
+    warm_blobs = make_jpeg_pool(warm_positions, sizes)
+    full_blobs = None
+    if do_full:
+        have = dict(zip(positions, blobs))
+        missing = [p for p in range(FULL_POOL) if p not in have]
+        extra = dict(zip(missing, make_jpeg_pool(missing, sizes)))
+        full_blobs = [have[p] if p in have else extra[p] for p in range(FULL_POOL)]
+
+    import numpy as np
+    import torch
     assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback for the product path"
     # dry-run aid for 1-GPU boxes: CALD_BENCH_SHARE_GPU=1 puts every rank on cuda:0 with the gloo backend
     share = os.environ.get("CALD_BENCH_SHARE_GPU") == "1"
     if share:
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    dist = None
     if world > 1:
         import torch.distributed as dist
         if share:
@@ -90,13 +178,8 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from cald_amd import _ffi, detector, synth, sweep
-    B, K, Wm = args.batch_images, args.steps, args.warmup
-    letters = {"F": "flip", "C": "cut_out", "D": "smaller_resize", "R": "rotation", "G": "ga", "S": "sp"}
-    augs = [letters[ch] for ch in args.augs]
-    ncls = 21 if args.shape == "voc" else 91
-    mn, mx = (600, 1000) if args.shape == "voc" else (800, 1333)
-    headline = (args.model == "frcnn" and args.shape == "voc" and args.augs == "FCD" and args.precision == "fp32")
+    from cald_amd import _ffi, detector, sweep
+    from cald_amd.pool import DevicePool
     if args.model == "retinanet":
         sd = synth.pseudo_trained_retinanet(ncls, 50, seed=0)
         model = detector.retinanet_resnet50_fpn_cal(num_classes=ncls, min_size=mn, max_size=mx, precision=args.precision)
@@ -108,106 +191,136 @@ def main():
     model = model.to("cuda:%d" % local_rank)
     model.load_state_dict(sd)
     model.eval()
-
-    # distinct images per rank, resident in HBM before the timed region; rank r owns pool positions p % world == r
-    n_local = B * min(K + Wm, 2)
-    sizes = synth.pool_sizes(n_local * world, args.shape, 0)
-    positions = [rank + world * i for i in range(n_local)]
-    host_pool = [synth.synth_image(p, *sizes[p]) for p in positions]
-    dev_pool = [torch.from_numpy(im).cuda() for im in host_pool]
-    torch.cuda.synchronize()
-
-    def step(s):
-        lo = (s * B) % n_local
-        idx = [(lo + j) % n_local for j in range(B)]
-        return sweep.sweep_device_images(model, [dev_pool[i] for i in idx], [positions[i] for i in idx], augs,
-                                         bp=1.3, base_seed=0, batch_images=B)
+    labeled = synthetic_labeled_set(500, ncls, 0)
+    budget = max(1, min(FULL_BUDGET, int(round(FULL_BUDGET * pool_total / float(FULL_POOL)))))
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    if Wm == 0:
-        step(0)       # one-time initialisation (code objects, workspace arena) is model build, not a step
-    for s in range(Wm):
-        step(s)
-    L, ctx = _ffi.lib(), detector.get_ctx(local_rank)
-    _ffi.check(L.cald_profile_enable(ctx, 1))     # HIP events around every conv/linear launch on the launch stream
+    def sweep_batch(pool, pos, lo, hi):
+        return sweep.sweep_device_images(model, [pool[i] for i in range(lo, hi)], pos[lo:hi], augs, bp=1.3, base_seed=0, batch_images=B)
+
+    # ---- warm-up: decode path, code objects, workspace arena, W untimed steps ----
+    warm_pool = DevicePool.from_jpeg_bytes(warm_blobs if warm_blobs else blobs[:B])
+    wpos = warm_positions if warm_blobs else positions[:B]
+    for s in range(max(1, Wm)):
+        lo = (s * B) % len(warm_pool)
+        sweep_batch(warm_pool, wpos, lo, min(lo + B, len(warm_pool)))
+    del warm_pool
+
+    # ---- host JPEG bytes -> HBM-resident uint8 pool (decode on the GPU), timed on its own ----
     barrier()
     t0 = time.time()
-    last = None
-    for s in range(K):
-        last = step(Wm + s)
-    if world > 1:   # the one RCCL all-gather of (position, consistency, cls_corr) rows
-        idx = [(((Wm + K - 1) * B) % n_local + j) % n_local for j in range(B)]
-        sweep.allgather_scores([positions[i] for i in idx], last[0], last[1], world * n_local)
+    dev_pool = DevicePool.from_jpeg_bytes(blobs)
+    torch.cuda.synchronize()
+    t_decode = time.time() - t0
+
+    L, ctx = _ffi.lib(), detector.get_ctx(local_rank)
+    _ffi.check(L.cald_profile_enable(ctx, 1))     # HIP events around every conv/linear launch on the launch stream
+    n_local = len(positions)
+    steps_local = (n_local + B - 1) // B          # == K for weak scaling; K / N (rounded up) for strong scaling
+    barrier()
+    t0 = time.time()
+    cons_parts, cls_parts = [], []
+    for s in range(steps_local):
+        c, k = sweep_batch(dev_pool, positions, s * B, min((s + 1) * B, n_local))
+        cons_parts.append(c); cls_parts.append(k)
+    cons = np.concatenate(cons_parts) if cons_parts else np.zeros(0)
+    cls = np.concatenate(cls_parts) if cls_parts else np.zeros((0, ncls - 1))
+    if world > 1:   # the one RCCL all-gather of the (consistency, cls_corr) rows of the WHOLE timed pool
+        cons, cls = sweep.allgather_scores(positions, cons, cls, pool_total)
+    picked = sweep.select(list(cons), [cls[i] for i in range(cls.shape[0])], labeled, budget=budget, mr=1.2)   # every rank, host
     barrier()
     dt = time.time() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if share else "cuda")
+        t = torch.tensor([dt, t_decode], dtype=torch.float64, device="cpu" if share else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt, t_decode = float(t[0].item()), float(t[1].item())
     import ctypes as C
-    gm, gf, tot = C.c_double(), C.c_double(), C.c_double()
-    nl = C.c_int64()
+    gm, gf, tot, mean_r = C.c_double(), C.c_double(), C.c_double(), C.c_double()
+    nl, nviews = C.c_int64(), C.c_int64()
     _ffi.check(L.cald_profile_read(ctx, C.byref(gm), C.byref(gf), C.byref(nl), C.byref(tot)))
+    _ffi.check(L.cald_profile_roi_rows(ctx, C.byref(mean_r), C.byref(nviews)))
     if os.environ.get("CALD_PROFILE_DUMP"):
         _ffi.check(L.cald_profile_dump(ctx, os.environ["CALD_PROFILE_DUMP"].encode()))
     _ffi.check(L.cald_profile_enable(ctx, 0))
 
     if rank == 0:
-        # HBM bytes per GEMM launch from the rocprofv3 PMC passes of this same command (tools/profile_gpu.sh ->
-        # tools/summarize_profile.py -> profiles/*_pmc.json; FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, KB units)
-        traffic = None
-        try:
-            cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc.json"))
-            if cands:
-                traffic = json.load(open(os.path.join(ROOT, "profiles", cands[-1])))["conv_mfma"]["hbm_bytes_per_launch"]
-        except Exception:
-            traffic = None
-        images = world * K * B
+        traffic, traffic_src = latest_pmc()
         achieved = gf.value / (gm.value * 1e-3) / 1e12 if gm.value > 0 else 0.0
         peak = F32_MFMA_PEAK_TFLOPS if args.precision == "fp32" else F16_MFMA_PEAK_TFLOPS
         out = {
-            "metric": "unlabeled images scored/sec (CALD consistency sweep)", "value": images / dt, "unit": "images/s",
-            "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": dt / K * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "f16x3 (fp16 hi+lo split operands, fp32 accumulate)",
+            "metric": "unlabeled images scored/sec (CALD consistency sweep)", "value": pool_total / dt, "unit": "images/s",
+            "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": dt / max(1, steps_local) * 1e3, "higher_is_better": True,
+            "scaling": args.scaling, "vs_baseline": None,
+            "dtype": "f32" if args.precision == "fp32" else "f16x3 (fp16 hi+lo split operands, fp32 accumulate)",
             "data": "synthetic",
-            "config": {"workload": ("BASELINE.json configs[1]: Faster R-CNN ResNet-50 FPN, VOC2012-shaped synthetic pool, "
+            "config": {"workload": ("BASELINE.json configs[1]: Faster R-CNN ResNet-50 FPN, VOC2012-shaped synthetic pool (baseline JPEG files), "
                                     "3 augs (flip/cut_out/smaller_resize), 21 classes, min/max 600/1000, seeded pseudo-trained weights")
                        if headline else "informational: model=%s shape=%s augs=%s classes=%d min/max %d/%d precision=%s" % (args.model, args.shape, args.augs, ncls, mn, mx, args.precision),
-                       "images_per_step_per_gpu": B, "views_per_image": 1 + len(sweep.expand_augs(augs)), "parallelism": "pool sharded by position, dp%d" % world},
+                       "images_per_step_per_gpu": B, "views_per_image": 1 + len(sweep.expand_augs(augs)), "pool_images": pool_total,
+                       "timed_region": "HBM-resident decoded pool -> K sweep steps -> all-gather (N>1) -> argsort + cls_kldiv -> selected indices",
+                       "selection_budget": budget, "n_selected": int(len(picked)),
+                       "selected_sha1": hashlib.sha1(np.asarray(picked, np.int64).tobytes()).hexdigest(),
+                       "parallelism": "pool sharded by position (rank-local inputs), dp%d" % world},
+            "from_host_jpeg_bytes": {"value": pool_total / (dt + t_decode), "unit": "images/s", "decode_and_h2d_s": t_decode,
+                                     "note": "same pool, JPEG decode on the GPU + H2D included (max over ranks); never `value`"},
             "roofline": {"bound": "mfma",
                          "kernel": ("conv_p4_kernel + conv_mfma_f32_kernel (implicit-GEMM conv + linear, v_mfma_f32_32x32x2_f32)" if args.precision == "fp32"
                                     else "conv_h3_kernel (3 x v_mfma_f32_32x32x16_f16 per product; algorithmic flops counted once) + exact kernels for uncovered shapes"),
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic if args.precision == "fp32" else None,
+                         "traffic_source": traffic_src if args.precision == "fp32" else None,
                          "launches": int(nl.value), "avg_launch_ms": gm.value / max(1, nl.value),
-                         "gemm_ms_per_step": gm.value / K, "algorithmic_gflop_per_launch": gf.value / max(1, nl.value) / 1e9},
+                         "gemm_ms_per_step": gm.value / max(1, steps_local), "algorithmic_gflop_per_launch": gf.value / max(1, nl.value) / 1e9,
+                         "roi_rows_per_view_measured": mean_r.value,
+                         "note": "rank 0's launches, HIP events on the launch stream; RoI-head FLOPs counted on the measured proposal rows"},
         }
+        if do_full:
+            # BASELINE configs[1] at its full size, one clock around everything: host JPEG bytes -> decode on the GPU ->
+            # sweep -> argsort + cls_kldiv (budget 500, mr 1.2) -> indices
+            del dev_pool
+            torch.cuda.synchronize(); tf = time.time()
+            fp = DevicePool.from_jpeg_bytes(full_blobs)
+            unc, ccs = sweep.get_uncertainty(model, fp.loader(), augs, ncls, bp=1.3, base_seed=0, batch_images=B)
+            sel = sweep.select(unc, ccs, labeled, budget=FULL_BUDGET, mr=1.2)
+            torch.cuda.synchronize(); tf = time.time() - tf
+            u = np.asarray(unc)
+            out["full_pool"] = {"value": FULL_POOL / tf, "unit": "images/s", "pool_images": FULL_POOL, "seconds": tf, "budget": FULL_BUDGET,
+                                "n_selected": int(len(sel)), "selected_sha1": hashlib.sha1(np.asarray(sel, np.int64).tobytes()).hexdigest(),
+                                "zero_score_images": int((u == 0).sum()),
+                                "timed_region": "host JPEG bytes -> GPU decode -> get_uncertainty -> argsort + cls_kldiv -> 500 indices"}
+            dev_pool = fp
         if world == 1 and not args.no_cpu_baseline and headline:
-            out["cpu_baseline"] = cpu_baseline(sd, host_pool, augs)
+            out["cpu_baseline"] = cpu_baseline(sd, blobs, augs)
             out["cpu_baseline"]["host_cpus"] = os.cpu_count()
+        if world == 1 and headline and not args.no_f16x3:
             # informational second line, NOT the headline: the opt-in split-fp16 MFMA mode (BASELINE configs[4]'s
-            # "fp16 MFMA path") on the same workload.  Parity bar of that mode: 1e-4 / identical ranking, not bit-exact.
+            # "fp16 MFMA path") on the same workload.  Parity of that mode vs the exact mode on the full pool and vs an
+            # independent fp32 path: profiles/parity_vs_independent_fp32_r2.json (tools/parity_full_pool.py).
             fast = (detector.fasterrcnn_resnet50_fpn_feature(num_classes=ncls, min_size=mn, max_size=mx, precision="f16x3")
                     .to("cuda:%d" % local_rank))
             fast.load_state_dict(sd)
             fast.eval()
-            idx = list(range(B))
-            run = lambda: sweep.sweep_device_images(fast, [dev_pool[i] for i in idx], [positions[i] for i in idx], augs,
-                                                    bp=1.3, base_seed=0, batch_images=B)
-            fc, _ = run()
+            nb = min(2 * B, len(dev_pool))
+            imgs = [dev_pool[i] for i in range(nb)]
+            run = lambda mdl: sweep.sweep_device_images(mdl, imgs, list(range(nb)), augs, bp=1.3, base_seed=0, batch_images=B)
+            fc, _ = run(fast)
             torch.cuda.synchronize(); tf = time.time()
-            for _ in range(2):
-                run()
+            run(fast)
             torch.cuda.synchronize(); tf = time.time() - tf
-            ec, _ = sweep.sweep_device_images(model, [dev_pool[i] for i in idx], [positions[i] for i in idx], augs,
-                                              bp=1.3, base_seed=0, batch_images=B)
-            out["f16x3_mode"] = {"value": 2 * B / tf, "unit": "images/s", "dtype": "fp16 hi+lo split operands, 3 x v_mfma_f32_32x32x16_f16 per product, fp32 accumulate",
-                                 "headline": False, "max_abs_consistency_diff_vs_exact": float(np.abs(fc - ec).max()),
-                                 "same_ranking_as_exact": bool(np.array_equal(np.argsort(fc, kind="stable"), np.argsort(ec, kind="stable")))}
+            ec, _ = run(model)
+            d = np.abs(fc - ec)
+            out["f16x3_mode"] = {"value": nb / tf, "unit": "images/s", "dtype": "fp16 hi+lo split operands, 3 x v_mfma_f32_32x32x16_f16 per product, fp32 accumulate",
+                                 "headline": False, "images_compared": nb, "max_abs_consistency_diff_vs_exact": float(d.max()),
+                                 "images_beyond_1e-4_vs_exact": int((d > 1e-4).sum()),
+                                 "note": "not bit-identical by design: on the full 5 217 pool ~1 % of images move by > 1e-4 (profiles/)"}
+        try:
+            out["parity_vs_independent_fp32"] = json.load(open(os.path.join(ROOT, "profiles", "parity_vs_independent_fp32_r2.json")))["summary"]
+        except Exception:
+            pass
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

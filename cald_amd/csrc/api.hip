@@ -58,8 +58,18 @@ struct cald_ctx {
     double prof_flops = 0.0; int64_t prof_extra_launches = 0;
     std::vector<std::string> prof_desc; std::vector<double> prof_fl;
     hipEvent_t tot0 = nullptr, tot1 = nullptr; bool tot_open = false; double tot_ms = 0.0;
+    // RoI-head GEMMs run on a device-side row count (proposals after NMS): the profile counts their algorithmic FLOPs on the
+    // MEASURED rows, accumulated on the device while profiling (no host sync inside a forward)
+    unsigned long long* d_roi_rows = nullptr; double prof_roi_rows_cap = 0.0, prof_roi_flops_cap = 0.0; long long prof_roi_views = 0;
     std::map<PilKey, PilCoef> pil;
 };
+
+__global__ void accumulate_rows_kernel(const int* __restrict__ counts, int V, unsigned long long* acc) {
+    unsigned long long s = 0;
+    for (int v = threadIdx.x; v < V; v += 64) s += (unsigned long long)counts[v];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+    if (threadIdx.x == 0) atomicAdd(acc, s);
+}
 
 hipStream_t cald_internal_stream(cald_ctx* c) { return c->stream; }
 
@@ -114,6 +124,8 @@ extern "C" int cald_ctx_create(int device, void* stream, cald_ctx** out) {
     HIPCHK(hipMalloc((void**)&c->d_views, sizeof(ViewDesc) * CALD_MAX_VIEWS));
     HIPCHK(hipMalloc((void**)&c->d_zeros, 256));
     HIPCHK(hipMemset(c->d_zeros, 0, 256));
+    HIPCHK(hipMalloc((void**)&c->d_roi_rows, 8));
+    HIPCHK(hipMemset(c->d_roi_rows, 0, 8));
     for (int i = 0; i < cald_ctx::NSTAGE; i++) {
         HIPCHK(hipHostMalloc((void**)&c->h_stage[i], sizeof(BatchPlan) + sizeof(ViewDesc) * CALD_MAX_VIEWS));
         HIPCHK(hipEventCreateWithFlags(&c->stage_ev[i], hipEventDisableTiming));
@@ -137,7 +149,7 @@ extern "C" int cald_ctx_destroy(cald_ctx* c) {
     if (c->tot1) hipEventDestroy(c->tot1);
     if (c->arena) hipFree(c->arena);
     for (int i = 0; i < cald_ctx::NSTAGE; i++) { if (c->h_stage[i]) hipHostFree(c->h_stage[i]); if (c->stage_ev[i]) hipEventDestroy(c->stage_ev[i]); }
-    hipFree(c->d_plan); hipFree(c->d_views); hipFree(c->d_zeros);
+    hipFree(c->d_plan); hipFree(c->d_views); hipFree(c->d_zeros); hipFree(c->d_roi_rows);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
     return 0;
@@ -150,6 +162,8 @@ extern "C" int cald_profile_enable(cald_ctx* c, int on) {
     for (auto e : c->ev0) hipEventDestroy(e);
     for (auto e : c->ev1) hipEventDestroy(e);
     c->ev0.clear(); c->ev1.clear(); c->prof_flops = 0.0; c->prof_extra_launches = 0; c->tot_ms = 0.0; c->tot_open = false; c->prof_desc.clear(); c->prof_fl.clear();
+    c->prof_roi_rows_cap = 0.0; c->prof_roi_flops_cap = 0.0; c->prof_roi_views = 0;
+    HIPCHK(hipMemsetAsync(c->d_roi_rows, 0, 8, c->stream));
     if (on && !c->tot0) { HIPCHK(hipEventCreate(&c->tot0)); HIPCHK(hipEventCreate(&c->tot1)); }
     return 0;
 }
@@ -159,9 +173,24 @@ extern "C" int cald_profile_read(cald_ctx* c, double* gemm_ms, double* gemm_flop
     double ms = 0.0;
     for (size_t i = 0; i < c->ev0.size(); i++) { float t = 0.f; HIPCHK(hipEventElapsedTime(&t, c->ev0[i], c->ev1[i])); ms += t; }
     if (gemm_ms) *gemm_ms = ms;
-    if (gemm_flops) *gemm_flops = c->prof_flops;
+    // RoI-head layers were booked at the row capacity (CALD_ROI_CAP per view); rescale them to the measured rows
+    unsigned long long rows = 0;
+    HIPCHK(hipMemcpy(&rows, c->d_roi_rows, 8, hipMemcpyDeviceToHost));
+    double fl = c->prof_flops;
+    if (c->prof_roi_rows_cap > 0.0) fl -= c->prof_roi_flops_cap * (1.0 - (double)rows / c->prof_roi_rows_cap);
+    if (gemm_flops) *gemm_flops = fl;
     if (launches) *launches = (int64_t)c->ev0.size() + c->prof_extra_launches;   // a timed region can hold several kernel launches
     if (total_ms) *total_ms = c->tot_ms;
+    return 0;
+}
+
+extern "C" int cald_profile_roi_rows(cald_ctx* c, double* mean_rows_per_view, int64_t* views) {
+    if (!c) return fail(CALD_ERR_INVALID, "ctx is null");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    unsigned long long rows = 0;
+    HIPCHK(hipMemcpy(&rows, c->d_roi_rows, 8, hipMemcpyDeviceToHost));
+    if (views) *views = c->prof_roi_views;
+    if (mean_rows_per_view) *mean_rows_per_view = c->prof_roi_views ? (double)rows / (double)c->prof_roi_views : 0.0;
     return 0;
 }
 
@@ -889,9 +918,14 @@ static int forward_model(cald_model* m, int V, ViewDesc* views, const DetBuffers
     ro.C = 256; ro.V = V; ro.proposals = F.proposals; ro.prop_count = F.prop_count; ro.out = F.roi;
     launch_roi_align(ro, st);
     m->dbg["roi"] = {F.roi, 7, 12544, 1};
+    const double fl_before_roi = c->prof_flops;
     if ((rc = conv_on(m, m->fc6, F.roi, F.f6, 7, 7, V, true, nullptr, nullptr, 0, F.prop_count))) return rc;
     if ((rc = conv_on(m, m->fc7, F.f6, F.f7, 7, 7, V, true, nullptr, nullptr, 0, F.prop_count))) return rc;
     if ((rc = conv_on(m, m->pred, F.f7, F.pr, 7, 7, V, false, nullptr, nullptr, 0, F.prop_count))) return rc;
+    if (c->prof) {
+        hipLaunchKernelGGL(accumulate_rows_kernel, dim3(1), dim3(64), 0, st, F.prop_count, V, c->d_roi_rows);
+        c->prof_roi_rows_cap += (double)V * CALD_ROI_CAP; c->prof_roi_flops_cap += c->prof_flops - fl_before_roi; c->prof_roi_views += V;
+    }
     m->dbg["fc6"] = {F.f6, 7, 1024, 1}; m->dbg["fc7"] = {F.f7, 7, 1024, 1}; m->dbg["pred"] = {F.pr, 7, m->pred.Cout, 1};
     PostArgs pa;
     pa.pred = F.pr; pa.pred_ld = m->pred.Cout; pa.C = m->cfg.num_classes; pa.V = V;

@@ -113,8 +113,10 @@ class DevicePool:
             pool[i].copy_(torch.from_numpy(a), non_blocking=True)
         return pool
 
-    def loader(self, subset=None):
-        """Iterable with the reference loader's batch shape: (images: list of 1, targets: list of 1)."""
+    def loader(self, subset=None, rank=0, world_size=1):
+        """Iterable with the reference loader's batch shape: (images: list of 1, targets: list of 1).  With
+        world_size > 1 only this rank's strided shard subset[rank::world_size] is yielded (pass
+        ``loader_is_sharded=True`` to get_uncertainty)."""
         order = range(len(self)) if subset is None else subset
-        for i in order:
+        for i in list(order)[rank::world_size]:
             yield [self[int(i)]], [None]

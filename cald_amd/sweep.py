@@ -100,39 +100,77 @@ def sweep_device_images(task_model, images, positions, augs, bp=1.3, base_seed=0
     return cons, cls
 
 
+def shard_positions(pool_size, rank, world_size):
+    """Pool positions rank `rank` scores: the strided shard p % world_size == rank."""
+    return list(range(rank, pool_size, world_size))
+
+
+def shard_subset(subset, rank, world_size):
+    """The slice of cald_train.py's `subset` (the shuffled unlabeled indices, :427-431) that rank `rank` feeds its own
+    loader with: ``DataLoader(dataset_aug, batch_size=1, sampler=SubsetSequentialSampler(shard_subset(subset, r, W)))``
+    (:434, ll4al/data/sampler.py:3-16).  Every rank then decodes only its own 1/W of the pool; pass
+    ``loader_is_sharded=True`` to get_uncertainty() and the gathered results come back in `subset` order."""
+    return list(subset[rank::world_size])
+
+
+class ShardedSequentialSampler:
+    """ll4al/data/sampler.py:3-16 SubsetSequentialSampler restricted to one rank's strided shard."""
+
+    def __init__(self, indices, rank, world_size):
+        self.indices = shard_subset(indices, rank, world_size)
+
+    def __iter__(self):
+        return iter(self.indices)
+
+    def __len__(self):
+        return len(self.indices)
+
+
 def allgather_scores(local_pos, cons, cls, pool_size, group=None):
-    """One all-gather of (pool position, consistency, cls_corr) rows (RCCL on GPUs, gloo on CPU);
-    replaces detection/utils.py:75-115's pickled all_gather pattern.  Shards are padded to equal length."""
+    """One all-gather of the per-image score rows (consistency, cls_corr[C-1]) (RCCL on GPUs, gloo on CPU); replaces
+    detection/utils.py:75-115's pickled all_gather pattern.  Every rank holds the strided shard p % world == rank in
+    ascending position order, so row j of rank r IS position r + j * world: no index column travels, and shards are
+    padded to ceil(pool / world) rows.  Returns the full (consistency [pool], cls_corr [pool][C-1]) on every rank."""
     import torch.distributed as dist
-    world = dist.get_world_size(group)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
     Cm1 = cls.shape[1]
     rows = (pool_size + world - 1) // world
-    buf = torch.full((rows, 2 + Cm1), -1.0, dtype=torch.float64)
-    k = len(local_pos)
+    mine = shard_positions(pool_size, rank, world)
+    if list(local_pos) != mine:
+        raise ValueError("rank %d must hold exactly the strided shard p %% %d == %d of a pool of %d, in order" % (rank, world, rank, pool_size))
+    buf = torch.zeros((rows, 1 + Cm1), dtype=torch.float64)
+    k = len(mine)
     if k:
-        buf[:k, 0] = torch.from_numpy(np.asarray(local_pos, np.float64))
-        buf[:k, 1] = torch.from_numpy(cons)
-        buf[:k, 2:] = torch.from_numpy(cls)
+        buf[:k, 0] = torch.from_numpy(np.ascontiguousarray(cons, dtype=np.float64))
+        buf[:k, 1:] = torch.from_numpy(np.ascontiguousarray(cls, dtype=np.float64))
     backend = dist.get_backend(group)
     dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
     buf = buf.to(dev)
-    out = torch.empty((world * rows, 2 + Cm1), dtype=torch.float64, device=dev)
+    out = torch.empty((world * rows, 1 + Cm1), dtype=torch.float64, device=dev)
     dist.all_gather_into_tensor(out, buf, group=group)
-    out = out.cpu().numpy()
+    out = out.cpu().numpy().reshape(world, rows, 1 + Cm1)
     full_cons = np.zeros(pool_size, np.float64)
     full_cls = np.zeros((pool_size, Cm1), np.float64)
-    valid = out[:, 0] >= 0
-    idx = out[valid, 0].astype(np.int64)
-    full_cons[idx] = out[valid, 1]
-    full_cls[idx] = out[valid, 2:]
+    for r in range(world):
+        pos = shard_positions(pool_size, r, world)
+        full_cons[pos] = out[r, :len(pos), 0]
+        full_cls[pos] = out[r, :len(pos), 1:]
     return full_cons, full_cls
 
 
 def get_uncertainty(task_model, unlabeled_loader, augs, num_cls, bp=1.3, base_seed=0, rank=0, world_size=1,
-                    batch_images=64, group=None, chunk_images=4096):
+                    batch_images=64, group=None, chunk_images=4096, loader_is_sharded=False):
     """Drop-in for cald_train.py:91 (same positional signature).  Images are uploaded and swept ``chunk_images`` at a
     time, so a loader-fed sweep never holds more than that many decoded images in HBM (a DevicePool holds them all by
-    design); results do not depend on the chunking."""
+    design); results do not depend on the chunking.
+
+    Multi-GPU (one process per GPU): rank r scores pool positions p % world_size == r and one
+    all-gather returns the full vectors, in pool (= single-process loader) order, on every rank.
+      loader_is_sharded=False  every rank is handed the WHOLE loader and skips foreign items (they are still pulled,
+                               i.e. decoded, by the loader -- fine for a DevicePool, wasteful for a DataLoader);
+      loader_is_sharded=True   the loader yields ONLY this rank's items, item i being pool position rank + i*world_size
+                               (build it from shard_subset(subset, rank, world_size) / ShardedSequentialSampler /
+                               DevicePool.loader(subset, rank, world_size)): no rank touches another rank's images."""
     if not hasattr(task_model, "handle"):          # the reference's torch model: mirror it on the HIP side
         from .detector import from_torch_module
         task_model = from_torch_module(task_model)
@@ -140,7 +178,7 @@ def get_uncertainty(task_model, unlabeled_loader, augs, num_cls, bp=1.3, base_se
     # without a GPU the upload below is a no-op and sweep_device_images() raises (no CPU fallback)
     dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
     images, positions, all_pos, cons_parts, cls_parts = [], [], [], [], []
-    pool_size = 0
+    n_items = 0
 
     def flush():
         if images:
@@ -148,10 +186,14 @@ def get_uncertainty(task_model, unlabeled_loader, augs, num_cls, bp=1.3, base_se
             cons_parts.append(c); cls_parts.append(k); all_pos.extend(positions)
             images.clear(); positions.clear()
 
-    for pos, (imgs, _) in enumerate(unlabeled_loader):      # batch size 1, cald_train.py:101-104
-        pool_size += 1
-        if pos % world_size != rank:
-            continue
+    for i, (imgs, _) in enumerate(unlabeled_loader):      # batch size 1, cald_train.py:101-104
+        n_items += 1
+        if loader_is_sharded:
+            pos = rank + i * world_size
+        else:
+            pos = i
+            if pos % world_size != rank:
+                continue
         for image in imgs:
             images.append(_to_u8_cuda(image, dev)); positions.append(pos)
         if len(images) >= chunk_images:
@@ -160,6 +202,13 @@ def get_uncertainty(task_model, unlabeled_loader, augs, num_cls, bp=1.3, base_se
     cons = np.concatenate(cons_parts) if cons_parts else np.zeros(0, np.float64)
     cls = np.concatenate(cls_parts) if cls_parts else np.zeros((0, num_cls - 1), np.float64)
     if world_size > 1:
+        pool_size = n_items
+        if loader_is_sharded:      # the pool size is the sum of the shard lengths: one tiny all-reduce
+            import torch.distributed as dist
+            backend = dist.get_backend(group)
+            t = torch.tensor([n_items], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(t, group=group)
+            pool_size = int(t.item())
         cons, cls = allgather_scores(all_pos, cons, cls, pool_size, group)
     return [float(c) for c in cons], [cls[i] for i in range(cls.shape[0])]
 

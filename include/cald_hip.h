@@ -191,7 +191,11 @@ int cald_jpeg_decode_batch(cald_ctx* ctx, int n, const uint8_t* const* data, con
 
 /* ---- measurement: HIP-event timing of every conv/linear launch on the context stream ---- */
 int cald_profile_enable(cald_ctx* ctx, int on);
+/* gemm_flops = algorithmic FLOPs of the timed launches; the RoI-head layers (fc6 / fc7 / predictor) are counted on the
+ * MEASURED proposal rows (device-side count after RPN NMS), not on the row capacity */
 int cald_profile_read(cald_ctx* ctx, double* gemm_ms, double* gemm_flops, int64_t* gemm_launches, double* total_ms);
+/* mean proposals per view (R of SURVEY 8d) over the Faster R-CNN forwards profiled since cald_profile_enable */
+int cald_profile_roi_rows(cald_ctx* ctx, double* mean_rows_per_view, int64_t* views);
 /* per-launch CSV (shape, algorithmic GFLOP, ms, TFLOP/s) of the launches recorded since cald_profile_enable */
 int cald_profile_dump(cald_ctx* ctx, const char* path);
 

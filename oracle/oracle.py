@@ -46,6 +46,11 @@ def lib():
     return _LIB
 
 
+def set_threads(n):
+    """OpenMP threads of the conv / linear / RoIAlign loops (results do not depend on it: every output is one chain)."""
+    lib().orc_set_threads(C.c_int(max(1, int(n))))
+
+
 def _p(a, t=c_f):
     return a.ctypes.data_as(t) if a is not None else None
 

@@ -257,6 +257,79 @@ def test_get_uncertainty_sharded_equals_single_rank():
         np.testing.assert_array_equal(cls, np.stack(k1))
 
 
+class _CountingDataset:
+    """Stands in for dataset_aug (cald_train.py:288): records which indices were ever decoded in this process."""
+
+    def __init__(self, n):
+        rs = np.random.RandomState(0)
+        self.images = [(rs.rand(8, 9, 3) * 255).astype(np.uint8) for _ in range(n)]
+        self.touched = []
+
+    def __len__(self):
+        return len(self.images)
+
+    def __getitem__(self, i):
+        import torch
+        self.touched.append(int(i))
+        return torch.from_numpy(self.images[i]), None
+
+
+def _rank_local_worker(rank, world, port, subset, q):
+    import torch
+    import torch.distributed as dist
+    from torch.utils.data import DataLoader
+    from cald_amd import sweep
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    sweep.sweep_device_images = _fake_sweep
+    ds = _CountingDataset(16)
+    # cald_train.py:434 with the rank's own sampler: DataLoader(dataset_aug, batch_size=1, sampler=..., collate_fn=tuple-zip)
+    loader = DataLoader(ds, batch_size=1, sampler=sweep.ShardedSequentialSampler(subset, rank, world), num_workers=0,
+                        collate_fn=lambda b: tuple(zip(*b)))
+    cons, cls = sweep.get_uncertainty(_FakeModel(), loader, ["flip"], 21, rank=rank, world_size=world, loader_is_sharded=True)
+    q.put((rank, np.array(cons), np.stack(cls), sorted(ds.touched)))
+    dist.destroy_process_group()
+
+
+def test_rank_local_input_sharding_touches_only_own_images():
+    """SURVEY 8e / cald_train.py:434: with a per-rank sampler every rank pulls (decodes) ONLY its strided shard of
+    `subset`, and the gathered vectors still come back in `subset` order, equal to the single-process run."""
+    import torch
+    import torch.multiprocessing as mp
+    from torch.utils.data import DataLoader
+    from cald_amd import sweep
+    subset = [11, 3, 7, 0, 15, 2, 9, 5, 12, 6, 1]          # shuffled unlabeled indices (cald_train.py:427)
+    ds = _CountingDataset(16)
+    loader = DataLoader(ds, batch_size=1, sampler=sweep.ShardedSequentialSampler(subset, 0, 1), num_workers=0,
+                        collate_fn=lambda b: tuple(zip(*b)))
+    orig = sweep.sweep_device_images
+    try:
+        sweep.sweep_device_images = _fake_sweep
+        c1, k1 = sweep.get_uncertainty(_FakeModel(), loader, ["flip"], 21)
+    finally:
+        sweep.sweep_device_images = orig
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    world = 2
+    procs = [ctx.Process(target=_rank_local_worker, args=(r, world, port, subset, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, cons, cls, touched in res:
+        np.testing.assert_array_equal(cons, np.array(c1))
+        np.testing.assert_array_equal(cls, np.stack(k1))
+        assert touched == sorted(subset[rank::world]), (rank, touched)        # never another rank's images
+    with pytest.raises(ValueError):                                           # a shard that is not the strided one is refused
+        import torch.distributed as dist
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % _free_port(), rank=0, world_size=1)
+        try:
+            sweep.allgather_scores([1, 0], np.zeros(2), np.zeros((2, 20)), 2)
+        finally:
+            dist.destroy_process_group()
+
+
 def test_voc_results_wire_format_matches_reference(golden, tmp_path):
     """engine.write_voc_results_file == detection/voc_eval.py:188-222 on the same detections."""
     import torch

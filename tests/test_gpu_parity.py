@@ -456,6 +456,82 @@ def test_full_size_properties_and_oracle_spot_check(hip, oracle):
     np.testing.assert_array_equal(k1[3], wk[0])
 
 
+def _full_size_coco_case(hip, oracle, depth, augs, exact_positions, seed):
+    """BASELINE.json configs[3] / configs[4] at their FULL sizes: 91 classes, min/max 800/1333 (cald_train.py:345-347),
+    COCO-shaped images (640x480 / 480x640 / 640x427).  (i) the sweep of 12 images is deterministic and invariant to the
+    batch size and to a 2-way / 3-way strided shard; (ii) `exact_positions` are re-scored by the CPU oracle and must
+    agree bit for bit (consistency and cls_corr)."""
+    import os
+    torch = hip["torch"]
+    from cald_amd import synth, sweep
+    sd = synth.pseudo_trained_frcnn(91, depth, seed=seed)
+    make = hip["det"].fasterrcnn_resnet101_fpn_feature if depth == 101 else hip["det"].fasterrcnn_resnet50_fpn_feature
+    model = make(num_classes=91, min_size=800, max_size=1333).to("cuda")
+    model.load_state_dict(sd)
+    pool = synth.make_pool(12, "coco", 0)
+    assert {im.shape[:2] for im in pool} >= {(480, 640), (640, 480)}
+    dev = [torch.from_numpy(im).cuda() for im in pool]
+    pos = list(range(12))
+    c1, k1 = sweep.sweep_device_images(model, dev, pos, augs, base_seed=4, batch_images=64)
+    c2, k2 = sweep.sweep_device_images(model, dev, pos, augs, base_seed=4, batch_images=5)
+    np.testing.assert_array_equal(c1, c2); np.testing.assert_array_equal(k1, k2)                  # batch-size invariant
+    for world in (2, 3):                                                                          # shard invariant
+        cw = np.zeros(12); kw = np.zeros((12, 90))
+        for r in range(world):
+            idx = sweep.shard_positions(12, r, world)
+            cr, kr = sweep.sweep_device_images(model, [dev[i] for i in idx], idx, augs, base_seed=4)
+            cw[idx] = cr; kw[idx] = kr
+        np.testing.assert_array_equal(c1, cw); np.testing.assert_array_equal(k1, kw)
+    assert np.all(c1 >= 0) and np.all(c1 <= 1.0) and len(np.unique(np.round(c1, 6))) > 6 and (k1 > 0).any()
+    P = oracle.prepare_frcnn(sd, 91, depth)
+    oracle.set_threads(min(128, os.cpu_count() or 1))
+    try:
+        wc, wk = oracle.get_uncertainty(P, [pool[i] for i in exact_positions], augs, 91, bp=1.3, min_size=800, max_size=1333,
+                                        base_seed=4, positions=list(exact_positions))
+    finally:
+        oracle.set_threads(min(32, os.cpu_count() or 1))
+    for j, i in enumerate(exact_positions):
+        assert c1[i] == wc[j], (i, c1[i], wc[j])
+        np.testing.assert_array_equal(k1[i], wk[j])
+    del model
+    torch.cuda.empty_cache()
+
+
+def test_config3_full_size_frcnn_r50_coco(hip, oracle):
+    """BASELINE.json configs[3]: Faster R-CNN ResNet-50 FPN, COCO shapes, 91 classes, 800/1333, flip / cut_out / smaller_resize."""
+    _full_size_coco_case(hip, oracle, 50, ["flip", "cut_out", "smaller_resize"], (1, 6), seed=0)
+
+
+def test_config4_full_size_frcnn_r101_coco_five_augs(hip, oracle):
+    """BASELINE.json configs[4]: Faster R-CNN ResNet-101 FPN, COCO shapes, 5 augmentations (FCDR + G: flip, ga, cut_out,
+    smaller_resize, rotation -> 6 views per image), exact fp32."""
+    _full_size_coco_case(hip, oracle, 101, ["flip", "ga", "cut_out", "smaller_resize", "rotation"], (0, 3), seed=1)
+
+
+def test_float_inputs_reach_the_kernels_exactly(hip, oracle, small_model):
+    """model([x]) with arbitrary float32 images (the reference model accepts any float tensor, frcnn_la.py:237): a
+    to_tensor image, a to_tensor image plus Gaussian noise, and values outside [0, 1] -- each bit-identical to the
+    oracle fed the same floats (uint8 grid + float32 remainder, cald_view.noise_dev)."""
+    torch = hip["torch"]
+    from cald_amd import synth
+    model, P = small_model
+    img = synth.make_pool(3, "voc", 0, scale=0.5)[2]
+    base = torch.from_numpy(img).permute(2, 0, 1).float().div(255)
+    g = torch.Generator().manual_seed(5)
+    noisy = base + torch.randn(base.shape, generator=g) * (16 / 255.0)
+    wild = base * 1.7 - 0.3
+    for x in (base, noisy, wild):
+        got = model([x.cuda()])[0]
+        xn = x.numpy()
+        grid = np.clip(np.round(xn * np.float32(255.0)), 0, 255).astype(np.uint8)
+        rem = xn - grid.astype(np.float32) / np.float32(255.0)
+        assert np.array_equal(grid.astype(np.float32) / np.float32(255.0) + rem, xn)
+        want = oracle.frcnn_forward(P, np.ascontiguousarray(grid.transpose(1, 2, 0)), 300, 500, noise=np.ascontiguousarray(rem))
+        assert want["boxes"].shape[0] > 0
+        for k in ("boxes", "scores", "labels", "props", "prob_max", "scores_cls"):
+            assert got[k].cpu().numpy().tobytes() == want[k].tobytes(), "output %s differs" % k
+
+
 @pytest.mark.parametrize("shape", [(333, 500), (32, 40), (60, 400), (401, 97)])
 def test_odd_image_sizes_forward(hip, oracle, small_model, shape):
     """Ragged / extreme sizes: the 333-row floor case, tiny, very wide, very tall (max_size clamp)."""
@@ -541,3 +617,91 @@ def test_gpu_sweep_vs_independent_torch_cpu_path(hip, small_model):
     np.testing.assert_allclose(cls, np.stack(rcls), rtol=0, atol=1e-4)
     k = 4
     np.testing.assert_array_equal(np.argsort(cons)[:k], np.argsort(np.array(ref))[:k])
+
+
+def _two_rank_worker(rank, world, port, backend, q):
+    """One rank of the N>1 path on real hardware: its own process, its own library context, the strided shard of the
+    pool fed by a rank-local loader, one all-gather at the end."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from cald_amd import detector, synth, sweep
+    ndev = torch.cuda.device_count()
+    dev = rank % ndev                       # 1-GPU box: both ranks share cuda:0 (separate processes and contexts)
+    torch.cuda.set_device(dev)
+    kw = {"device_id": torch.device("cuda", dev)} if backend == "nccl" else {}
+    dist.init_process_group(backend, init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world, **kw)
+    try:
+        sd = synth.pseudo_trained_frcnn(21, 50, seed=0)
+        model = detector.fasterrcnn_resnet50_fpn_feature(num_classes=21, min_size=300, max_size=500).to("cuda:%d" % dev)
+        model.load_state_dict(sd)
+        pool = synth.make_pool(7, "voc", 0, scale=0.5)
+        local = [((torch.from_numpy(pool[p]),), (None,)) for p in sweep.shard_positions(len(pool), rank, world)]
+        cons, cls = sweep.get_uncertainty(model, local, ["flip", "cut_out", "smaller_resize"], 21, bp=1.3, base_seed=6,
+                                          rank=rank, world_size=world, loader_is_sharded=True)
+        q.put((rank, np.array(cons), np.stack(cls), None))
+    except Exception as e:                  # surface the failure in the parent instead of a queue timeout
+        q.put((rank, None, None, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_on_hardware_equal_one_rank(hip, small_model):
+    """The N>1 path executed on the GPU: 2 processes (one GPU each when >= 2 are visible, RCCL all-gather; otherwise both
+    on cuda:0 with the gloo backend, the same code path apart from the transport) -> every rank returns exactly the
+    1-rank vectors, in pool order."""
+    torch = hip["torch"]
+    import torch.multiprocessing as mp
+    from cald_amd import synth, sweep
+    import socket
+    model, _ = small_model
+    pool = synth.make_pool(7, "voc", 0, scale=0.5)
+    loader = [((torch.from_numpy(im),), (None,)) for im in pool]
+    c1, k1 = sweep.get_uncertainty(model, loader, ["flip", "cut_out", "smaller_resize"], 21, bp=1.3, base_seed=6)
+    backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, backend, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+    assert sorted(r[0] for r in res) == [0, 1]
+    for rank, cons, cls, err in res:
+        assert err is None, "rank %d failed: %s" % (rank, err)
+        np.testing.assert_array_equal(cons, np.array(c1))
+        np.testing.assert_array_equal(cls, np.stack(k1))
+
+
+def _nccl_single_rank_worker(port, q):
+    import torch
+    import torch.distributed as dist
+    from cald_amd import sweep
+    try:
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        rs = np.random.RandomState(3)
+        cons, cls = rs.rand(9), rs.rand(9, 20)
+        fc, fk = sweep.allgather_scores(list(range(9)), cons, cls, 9)
+        q.put((bool(np.array_equal(fc, cons) and np.array_equal(fk, cls)), None))
+        dist.destroy_process_group()
+    except Exception as e:
+        q.put((False, repr(e)))
+
+
+def test_rccl_branch_of_the_score_allgather_runs_on_the_gpu(hip):
+    """RCCL refuses two ranks on one device ("Duplicate GPU detected", tools/nccl_same_gpu_probe.py), so on a 1-GPU box the
+    nccl branch of allgather_scores (device buffers, all_gather_into_tensor through RCCL) is executed with world_size 1;
+    with >= 2 GPUs test_two_ranks_on_hardware_equal_one_rank runs it across devices."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_single_rank_worker, args=(port, q))
+    p.start()
+    ok, err = q.get(timeout=300)
+    p.join(timeout=60)
+    assert ok, err
