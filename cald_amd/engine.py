@@ -5,8 +5,8 @@ loader, runs the HIP detector -- batched, up to 64 images per launch sequence in
 batch-1 loop with a ``torch.cuda.synchronize()`` per image -- and returns ``(all_boxes, image_index)`` in the
 reference's structure.  ``write_voc_results_file`` emits the wire format of detection/voc_eval.py:188-222
 (``/tmp/{path}/det_test_{cls}.txt``: ``image_id score x1+1 y1+1 x2+1 y2+1``), which the reference's own
-``_do_python_eval`` then consumes.  AP computation itself stays with the reference (host code, needs the VOC
-annotation files).
+``_do_python_eval`` consumes; ``cald_amd.voc_eval`` is that consumer (AP over IoU .5:.95, same numbers, annotations
+parsed once), and ``voc_evaluate`` below is the whole of detection/engine.py:86-158 with the reference's signature.
 """
 import os
 import shutil
@@ -68,6 +68,26 @@ def write_voc_results_file(all_boxes, image_index, path, classes, root='/tmp'):
                         index, float(dets[k, -1]), float(dets[k, 0]) + 1, float(dets[k, 1]) + 1,
                         float(dets[k, 2]) + 1, float(dets[k, 3]) + 1))
     return out_dir
+
+
+def voc_evaluate(model, data_loader, year, feature=False, path='results', root='/tmp', batch_views=64):
+    """detection/engine.py:86-158: forward over the test loader (batched on the GPU), gather over ranks, results files,
+    AP table.  Returns what ``cald_amd.voc_eval.do_python_eval`` returns on the main process, None elsewhere."""
+    import torch.distributed as dist
+    from .voc_eval import do_python_eval
+    if feature:
+        raise NotImplementedError("feature=True (models returning (features, outputs)) belongs to the LL4AL baselines")
+    classes = data_loader.dataset._transforms.transforms[0].CLASSES
+    all_boxes, image_index = voc_detections(model, data_loader, len(classes), batch_views)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:     # utils.all_gather (:143-144)
+        parts = [None] * dist.get_world_size()
+        dist.all_gather_object(parts, (all_boxes, image_index))
+        if dist.get_rank() != 0:
+            return None
+        all_boxes = [sum((p[0][c] for p in parts), []) for c in range(len(classes))]
+        image_index = sum((p[1] for p in parts), [])
+    write_voc_results_file(all_boxes, image_index, path, classes, root=root)
+    return do_python_eval(data_loader, year, path, root=root)
 
 
 def coco_predictions(model, data_loader, batch_views=64):

@@ -404,3 +404,57 @@ def test_c_abi_rejects_bad_arguments_without_touching_the_gpu():
     rects = (C.c_int * 16)()
     assert L.cald_op_cutout_rects(1, 10, 10, 0, None, 9, rects, C.byref(n)) != 0      # cut_num > 4
     assert L.cald_ctx_destroy(None) == 0 and L.cald_model_destroy(None) == 0
+
+
+def _materialise_voc_tree(g, root):
+    """The synthetic VOCdevkit tree + results files of tests/golden/voc_eval.npz (annotation table and file text are data)."""
+    classes = [str(c) for c in g["classes"]]
+    names = [str(n) for n in g["names"]]
+    base = os.path.join(root, "VOCdevkit", "VOC2012")
+    os.makedirs(os.path.join(base, "ImageSets", "Main")); os.makedirs(os.path.join(base, "Annotations")); os.makedirs(os.path.join(root, "res"))
+    with open(os.path.join(base, "ImageSets", "Main", "test.txt"), "w") as f:
+        f.write("".join(n + "\n" for n in names))
+    for i, n in enumerate(names):
+        xml = "<annotation>"
+        for (ii, c, diff, x0, y0, x1, y1) in g["objects"]:
+            if ii == i:
+                xml += ("<object><name>%s</name><difficult>%d</difficult><bndbox><xmin>%d</xmin><ymin>%d</ymin><xmax>%d</xmax>"
+                        "<ymax>%d</ymax></bndbox></object>" % (classes[c], diff, x0, y0, x1, y1))
+        with open(os.path.join(base, "Annotations", n + ".xml"), "w") as f:
+            f.write(xml + "</annotation>")
+    for cls in classes[1:]:
+        with open(os.path.join(root, "res", "det_test_%s.txt" % cls), "w") as f:
+            f.write(str(g["det_%s" % cls]))
+    return classes, os.path.join(base, "ImageSets/Main/test.txt"), os.path.join(base, "Annotations/{:s}.xml")
+
+
+def test_voc_ap_matches_reference_golden(golden, tmp_path, capsys):
+    """SURVEY 8f rank 1, AP half: cald_amd.voc_eval (annotations parsed once, overlaps computed once per class) returns
+    exactly the rec / prec / ap arrays detection/voc_eval.py returned for every class x IoU threshold x metric, and
+    do_python_eval prints the reference's table line (oracle/make_golden_voc_eval.py)."""
+    from types import SimpleNamespace
+    from cald_amd import voc_eval as ve
+    g = golden("voc_eval")
+    root = str(tmp_path)
+    classes, imagesetfile, annopath = _materialise_voc_tree(g, root)
+    ann = ve.VocAnnotations(imagesetfile, annopath)
+    with np.errstate(all="ignore"):
+        for cls in classes[1:]:
+            fn = os.path.join(root, "res", "det_test_%s.txt" % cls)
+            for use07 in (False, True):
+                multi = ve.voc_eval_thresholds(cls, fn, ann, [float(t) for t in g["ious"]], use_07_metric=use07)
+                for t, (mrec, mprec, map_) in zip(g["ious"], multi):
+                    key = "%s_%d_%d" % (cls, int(round(float(t) * 100)), int(use07))
+                    rec, prec, ap = ve.voc_eval(cls, fn, imagesetfile, annopath, ovthresh=float(t), use_07_metric=use07)
+                    for got in ((rec, prec, ap), (mrec, mprec, map_)):
+                        np.testing.assert_array_equal(got[0], g["rec_" + key])
+                        np.testing.assert_array_equal(got[1], g["prec_" + key])
+                        np.testing.assert_array_equal(np.float64(got[2]), g["ap_" + key])
+        for key, ncls in (("python_eval_stdout", 5), ("python_eval_stdout_3cls", 4)):
+            loader = SimpleNamespace(dataset=SimpleNamespace(root=root, image_set="test",
+                                                             _transforms=SimpleNamespace(transforms=[SimpleNamespace(CLASSES=tuple(classes[:ncls]))])))
+            capsys.readouterr()
+            res = ve.do_python_eval(loader, "2012", "res", root=root)
+            assert capsys.readouterr().out == str(g[key])
+            assert res["line"] == str(g[key]).splitlines()[1]
+    assert 0.0 < res["AP50"] < 1.0

@@ -705,3 +705,59 @@ def test_rccl_branch_of_the_score_allgather_runs_on_the_gpu(hip):
     ok, err = q.get(timeout=300)
     p.join(timeout=60)
     assert ok, err
+
+
+def test_voc_evaluate_files_equal_oracle_files_and_ap(hip, oracle, small_model, tmp_path):
+    """SURVEY 8f rank 1 on the GPU: HIP detections -> results files == the files written from the ORACLE's detections of the
+    same images, byte for byte; then the AP table over synthetic annotations (cald_amd.voc_eval, pinned to the reference's
+    numbers by tests/golden/voc_eval.npz) through engine.voc_evaluate."""
+    import os
+    from types import SimpleNamespace
+    torch = hip["torch"]
+    from cald_amd import synth, engine
+    model, P = small_model
+    pool = synth.make_pool(6, "voc", 0, scale=0.5)
+    names = ["2010_%06d" % (7 * i + 3) for i in range(len(pool))]
+    classes = ('__background__',) + tuple(cald_helper.VOC_CLASSES) if hasattr(cald_helper, "VOC_CLASSES") else \
+        ('__background__',) + tuple("class%02d" % c for c in range(1, 21))
+    assert len(classes) == 21
+    # what the oracle detects, in the reference's all_boxes structure (engine.py:114-141)
+    want_boxes = [[] for _ in classes]
+    gt_objects = []
+    for i, im in enumerate(pool):
+        o = oracle.frcnn_forward(P, im, 300, 500)
+        per = [[] for _ in classes]
+        for k in range(o["boxes"].shape[0]):
+            per[int(o["labels"][k])].append(torch.cat([torch.from_numpy(o["boxes"][k]), torch.tensor([o["scores"][k]])]))
+        for c in range(len(classes)):
+            want_boxes[c].append([torch.stack(per[c])] if per[c] else [])
+        for k in range(min(3, o["boxes"].shape[0])):      # synthetic ground truth: the three best boxes, integer corners
+            b = np.round(o["boxes"][k]).astype(int) + 1
+            gt_objects.append((i, int(o["labels"][k]), int(k == 2), b[0], b[1], max(b[2], b[0] + 1), max(b[3], b[1] + 1)))
+    root = str(tmp_path)
+    base = os.path.join(root, "VOCdevkit", "VOC2012")
+    os.makedirs(os.path.join(base, "ImageSets", "Main")); os.makedirs(os.path.join(base, "Annotations"))
+    with open(os.path.join(base, "ImageSets", "Main", "test.txt"), "w") as f:
+        f.write("".join(n + "\n" for n in names))
+    for i, n in enumerate(names):
+        xml = "<annotation>" + "".join(
+            "<object><name>%s</name><difficult>%d</difficult><bndbox><xmin>%d</xmin><ymin>%d</ymin><xmax>%d</xmax><ymax>%d</ymax></bndbox></object>"
+            % (classes[c], d, x0, y0, x1, y1) for (ii, c, d, x0, y0, x1, y1) in gt_objects if ii == i) + "</annotation>"
+        with open(os.path.join(base, "Annotations", n + ".xml"), "w") as f:
+            f.write(xml)
+    ds = SimpleNamespace(root=root, image_set="test", _transforms=SimpleNamespace(transforms=[SimpleNamespace(CLASSES=classes)]))
+
+    class Loader(list):
+        dataset = ds
+    loader = Loader(((torch.from_numpy(im).permute(2, 0, 1).float().div(255),), ({"name": torch.tensor([ord(ch) for ch in n])},))
+                    for im, n in zip(pool, names))
+    res = engine.voc_evaluate(model, loader, "2012", path="hip", root=root, batch_views=4)
+    engine.write_voc_results_file(want_boxes, list(names), "orc", classes, root=root)
+    nonempty = 0
+    for cls in classes[1:]:
+        a = open(os.path.join(root, "hip", "det_test_%s.txt" % cls)).read()
+        b = open(os.path.join(root, "orc", "det_test_%s.txt" % cls)).read()
+        assert a == b, cls
+        nonempty += bool(a)
+    assert nonempty >= 3
+    assert res["AP50"] > 0.2 and res["mAP"] > 0.0 and len(res["ap_per_class"]) == 20
