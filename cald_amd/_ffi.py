@@ -77,6 +77,7 @@ SIGNATURES = {
                                  C.c_int, c_f, c_f, c_f, c_f, C.c_int, c_f]),
     "cald_op_conv2d_f16x3": (C.c_int, [C.c_void_p, c_f, C.c_int, C.c_int, C.c_int, c_f, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_int, c_f, c_f, c_f, c_f, C.c_int, c_f]),
+    "cald_op_conv_bench": (C.c_int, [C.c_void_p] + [C.c_int] * 12 + [c_d, c_d]),
     "cald_op_transform_size": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, c_i, c_i, c_i, c_i]),
     "cald_debug_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, c_f, C.c_int64, c_i64]),
     "cald_jpeg_info": (C.c_int, [C.c_void_p, C.c_size_t, c_i, c_i, c_i]),

@@ -371,6 +371,15 @@ struct cald_model {
 };
 
 static int round_up(int x, int m) { return (x + m - 1) / m * m; }
+// Position of input element (tap = kh*KW + kw, channel ci) in the k-ordered fma chain (DESIGN.md arithmetic contract).
+//   Cin % 16 == 0:  (channel chunk of 16, kh, kw, channel inside the chunk) -- all taps of a 16-channel chunk are consecutive
+//                   k-tiles, so the nine passes of a 3x3 filter re-touch the same 64-byte pixel segments while they are still
+//                   in L2 (with cin innermost over the whole channel vector every tap re-streamed the tensor from HBM);
+//   otherwise (or more than 32 taps: the tap-validity mask is 32 bits):  (kh, kw, cin), e.g. the 4-channel stem.
+// For 1x1 layers and linear layers both orders are the plain channel order.
+static inline int conv_k_index(int tap, int ci, int taps, int cinp) {
+    return (cinp % 16 == 0 && taps <= 32) ? ((ci >> 4) * taps + tap) * 16 + (ci & 15) : tap * cinp + ci;
+}
 static int cout_pad(int cout) { return cout >= 128 ? round_up(cout, 128) : (cout >= 64 ? round_up(cout, 64) : round_up(cout, 32)); }
 
 extern "C" int cald_model_create(cald_ctx* ctx, const cald_model_cfg* cfg, cald_model** out) {
@@ -430,15 +439,10 @@ static std::vector<uint16_t> pack_w16(const std::vector<float>& w, int Kpad, int
     if (S > 40) S = 40;
     if (S < -40) S = -40;
     *unscale = std::ldexp(1.0f, -(S + 4));
-    // k-tile order of conv_h3.hip: (kh, cin chunk of 16, kw) when Cin % 16 == 0; the stem (Cin == 4) keeps (kh, kw, cin)
-    const bool reorder = Cin % 16 == 0 && KH * KW > 1;
-    const int K = KH * KW * Cin, CC = Cin / 16;
+    // k-tiles in the order of the K-major matrix (conv_k_index): conv_h3.hip walks the same (chunk, kh, kw) cursor as the exact kernels
+    (void)KH; (void)KW; (void)Cin;
     for (int k = 0; k < Kpad; k++) {
-        int kt = k >> 4; const int kk = k & 15;
-        if (reorder && k < K) {
-            const int tap = k / Cin, ci = k - tap * Cin, kh = tap / KW, kw = tap - kh * KW;
-            kt = (kh * CC + (ci >> 4)) * KW + kw;
-        }
+        const int kt = k >> 4, kk = k & 15;
         for (int n = 0; n < CoutPad; n++) {
             const float x = std::ldexp(w[(size_t)k * CoutPad + n], S);
             const _Float16 hi = (_Float16)x;
@@ -464,7 +468,7 @@ template <typename T> static int upload(cald_model* m, const std::vector<T>& h, 
     return 0;
 }
 // torch conv weight [Cout][Cin][KH][KW] (optionally several tensors concatenated along Cout)
-// -> K-major [Kpad][CoutPad], k = (kh*KW + kw)*CinPad + ci
+// -> K-major [Kpad][CoutPad], k = conv_k_index(kh*KW + kw, ci)
 static int make_conv(cald_model* m, ConvLayer& L, const std::vector<std::string>& wkeys, const std::vector<std::string>& bkeys,
                      const std::string& bn_prefix, int stride, int pad, int cin_pad_to = 0) {
     std::vector<const HostTensor*> ws;
@@ -488,7 +492,7 @@ static int make_conv(cald_model* m, ConvLayer& L, const std::vector<std::string>
             for (int ci = 0; ci < cin; ci++)
                 for (int y = 0; y < kh; y++)
                     for (int x = 0; x < kw; x++)
-                        w[(size_t)((y * kw + x) * cinp + ci) * L.CoutPad + co0 + co] = t->data[(((size_t)co * cin + ci) * kh + y) * kw + x];
+                        w[(size_t)conv_k_index(y * kw + x, ci, kh * kw, cinp) * L.CoutPad + co0 + co] = t->data[(((size_t)co * cin + ci) * kh + y) * kw + x];
         co0 += c0;
     }
     int rc = upload(m, w, &L.w); if (rc) return rc;
@@ -684,7 +688,7 @@ static double fill_conv_args(cald_model* m, ConvArgs& a, const ConvLayer& L, con
     a.Cin = L.Cin; a.Cout = L.Cout; a.CoutPad = L.CoutPad; a.Kpad = L.Kpad;
     a.KH = L.KH; a.KW = L.KW; a.stride = L.stride; a.pad = L.pad; a.relu = relu ? 1 : 0;
     a.total_mtiles = level_tiles(m->plan, lout, V);
-    a.out_ld = L.Cout; a.in_relu = in_relu ? 1 : 0; a.zeros = m->ctx->d_zeros;
+    a.out_ld = L.Cout; a.in_relu = in_relu ? 1 : 0; a.zeros = m->ctx->d_zeros; a.exp_flags = 0;
     return 2.0 * (double)level_pix(m->plan, lout, V) * (double)L.Cout * (double)(L.KH * L.KW * L.CinTrue);
 }
 static int conv_on(cald_model* m, const ConvLayer& L, const float* in, float* out, int lin, int lout, int V, bool relu,
@@ -991,7 +995,7 @@ static int op_conv2d(cald_ctx* c, int precision, const float* in, int H, int W, 
         for (int ci = 0; ci < Cin; ci++)
             for (int y = 0; y < KH; y++)
                 for (int x = 0; x < KW; x++)
-                    w[(size_t)((y * KW + x) * Cin + ci) * CoutPad + co] = weight[(((size_t)co * Cin + ci) * KH + y) * KW + x];
+                    w[(size_t)conv_k_index(y * KW + x, ci, KH * KW, Cin) * CoutPad + co] = weight[(((size_t)co * Cin + ci) * KH + y) * KW + x];
     for (int i = 0; i < Cout; i++) { if (bias) b[i] = bias[i]; if (bn_scale) { sc[i] = bn_scale[i]; sh[i] = bn_shift[i]; } }
     BatchPlan P; memset(&P, 0, sizeof(P));
     P.seg[0][0].H = H; P.seg[0][0].W = W; P.seg[0][1].pix_off = (long long)H * W; P.seg[0][1].tile_start = (H * W + 127) / 128;
@@ -1043,6 +1047,70 @@ extern "C" int cald_op_conv2d_f16x3(cald_ctx* c, const float* in, int H, int W, 
                                     int stride, int pad, const float* bias, const float* bn_scale, const float* bn_shift,
                                     const float* residual, int relu, float* out) {
     return op_conv2d(c, CALD_PRECISION_F16X3, in, H, W, Cin, weight, Cout, KH, KW, stride, pad, bias, bn_scale, bn_shift, residual, relu, out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernel-tuning aid (tools/bench_conv.py): times ONE conv layer shape on a ragged batch of V equal views with
+// pseudo-random data (MFMA power, hence the sustained clock, depends on the operand values: never bench on zeros)
+// ---------------------------------------------------------------------------------------------
+__global__ void fill_random_kernel(float* p, long long n, unsigned seed) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        unsigned x = (unsigned)i * 2654435761u ^ seed; x ^= x >> 15; x *= 2246822519u; x ^= x >> 13; x *= 3266489917u; x ^= x >> 16;
+        p[i] = ((float)(x >> 8) * (1.0f / 8388608.0f) - 1.0f) * ((x & 7u) ? 1.0f : 0.0f);      // ~U(-1, 1), 1/8 zeros (post-ReLU-like)
+    }
+}
+extern "C" int cald_op_conv_bench(cald_ctx* c, int V, int H, int W, int Cin, int Cout, int KH, int stride, int pad, int residual,
+                                  int relu, int iters, int group, double* ms_out, double* tflops_out) {
+    if (!c || V < 1 || V > CALD_MAX_VIEWS || iters < 1 || !ms_out || group < 1 || group > CALD_MAX_GROUP) return fail(CALD_ERR_INVALID, "bad arguments");
+    if (Cin % 4) return fail(CALD_ERR_INVALID, "Cin must be a multiple of 4");
+    HIPCHK(hipSetDevice(c->device));
+    const int KW = KH, Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+    const int CoutPad = cout_pad(Cout), K = KH * KW * Cin, Kpad = round_up(K, 16);
+    std::vector<float> w((size_t)Kpad * CoutPad, 0.0f), b(CoutPad, 0.1f), sc(CoutPad, 1.0f), sh(CoutPad, 0.01f);
+    unsigned r = 12345u;
+    for (int k = 0; k < K; k++) for (int n = 0; n < Cout; n++) { r = r * 1664525u + 1013904223u; w[(size_t)k * CoutPad + n] = ((float)(r >> 8) / 8388608.0f - 1.0f) * 0.05f; }
+    BatchPlan P; memset(&P, 0, sizeof(P));
+    for (int v = 0; v <= V; v++) {
+        P.seg[0][v].pix_off = (long long)v * H * W; P.seg[0][v].tile_start = v * ((H * W + 127) / 128); P.seg[0][v].H = H; P.seg[0][v].W = W;
+        P.seg[1][v].pix_off = (long long)v * Ho * Wo; P.seg[1][v].tile_start = v * ((Ho * Wo + 127) / 128); P.seg[1][v].H = Ho; P.seg[1][v].W = Wo;
+    }
+    ScopedDev sd(c->stream);
+    float *d_in, *d_out, *d_w, *d_w4 = nullptr, *d_b, *d_sc, *d_sh, *d_res = nullptr; BatchPlan* d_p;
+    const size_t n_in = (size_t)V * H * W * Cin, n_out = (size_t)V * Ho * Wo * Cout;
+    int rc;
+    if ((rc = sd.alloc(&d_in, n_in * 4)) || (rc = sd.alloc(&d_out, n_out * 4 * group)) || (rc = sd.alloc(&d_w, w.size() * 4)) || (rc = sd.alloc(&d_b, b.size() * 4)) ||
+        (rc = sd.alloc(&d_sc, sc.size() * 4)) || (rc = sd.alloc(&d_sh, sh.size() * 4)) || (rc = sd.alloc(&d_p, sizeof(BatchPlan)))) return rc;
+    if (residual && (rc = sd.alloc(&d_res, n_out * 4))) return rc;
+    hipLaunchKernelGGL(fill_random_kernel, dim3(4096), dim3(256), 0, c->stream, d_in, (long long)n_in, 1u);
+    if (d_res) hipLaunchKernelGGL(fill_random_kernel, dim3(4096), dim3(256), 0, c->stream, d_res, (long long)n_out, 2u);
+    HIPCHK(hipMemcpy(d_w, w.data(), w.size() * 4, hipMemcpyHostToDevice));
+    if (CoutPad % 64 == 0 && ((Cin % 16 == 0 && KH * KW <= 32) || Cin == 4)) {
+        std::vector<float> w4 = pack_w4(w, Kpad, CoutPad);
+        if ((rc = sd.alloc(&d_w4, w4.size() * 4))) return rc;
+        HIPCHK(hipMemcpy(d_w4, w4.data(), w4.size() * 4, hipMemcpyHostToDevice));
+    }
+    HIPCHK(hipMemcpy(d_b, b.data(), b.size() * 4, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(d_sc, sc.data(), sc.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_sh, sh.data(), sh.size() * 4, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(d_p, &P, sizeof(P), hipMemcpyHostToDevice));
+    ConvArgs a[CALD_MAX_GROUP];
+    for (int gi = 0; gi < group; gi++) {
+        memset(&a[gi], 0, sizeof(ConvArgs));
+        a[gi].in = d_in; a[gi].out = d_out + (size_t)gi * n_out; a[gi].w = d_w; a[gi].w4 = d_w4; a[gi].bias = d_b; a[gi].scale = d_sc; a[gi].shift = d_sh; a[gi].residual = d_res;
+        a[gi].seg_in = d_p->seg[0]; a[gi].seg_out = d_p->seg[1]; a[gi].seg_up = d_p->seg[1]; a[gi].V = V; a[gi].Cin = Cin; a[gi].Cout = Cout; a[gi].CoutPad = CoutPad; a[gi].Kpad = Kpad;
+        a[gi].KH = KH; a[gi].KW = KW; a[gi].stride = stride; a[gi].pad = pad; a[gi].relu = relu; a[gi].total_mtiles = V * ((Ho * Wo + 127) / 128); a[gi].out_ld = Cout; a[gi].zeros = c->d_zeros;
+    }
+    auto launch = [&]() { if (group > 1) launch_conv_group(a, group, c->stream); else launch_conv(a[0], c->stream); };
+    launch(); launch();
+    HIPCHK(hipGetLastError());
+    hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipEventRecord(e0, c->stream));
+    for (int i = 0; i < iters; i++) launch();
+    HIPCHK(hipEventRecord(e1, c->stream));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0.f; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    *ms_out = (double)ms / iters;
+    if (tflops_out) *tflops_out = 2.0 * (double)V * Ho * Wo * Cout * (double)K * group / (*ms_out * 1e-3) / 1e12;
+    return 0;
 }
 
 // helper: device detection buffers

@@ -27,7 +27,7 @@ struct BatchPlan {
 struct ConvArgs {
     const float* in;
     float* out;
-    const float* w;        // [Kpad][CoutPad], K order (kh, kw, cin)
+    const float* w;        // [Kpad][CoutPad], rows in chain order (api.hip conv_k_index: (16-channel chunk, kh, kw, channel) or (kh, kw, cin))
     const float* w4;       // same weights packed [Kpad/16][2][CoutPad][2][4] for conv_p4.hip (k = 16 kt + 8 kq + 2 j + h), or null
     const void* w16;       // fp16 hi/lo split of the same weights * 2^S, [Kpad/16][2 (hi, lo)][CoutPad][16] (conv_h3.hip), or null
     float w16_unscale;     // 2^-(S + 4): undoes the weight scale 2^S and conv_h3's activation scale 2^4 (exact powers of two)
@@ -48,6 +48,7 @@ struct ConvArgs {
     int out_ld;            // output row stride in floats (== Cout normally)
     const float* zeros;    // >= 16 bytes of zeros, 16-byte aligned (source of out-of-image taps)
     int in_relu;           // apply ReLU to the input while gathering (LastLevelP6P7: p7(relu(p6)))
+    int exp_flags;         // kernel-tuning experiments only (0 in the product path): bit 0 = skip the output stores
 };
 
 // Several independent conv problems in ONE launch (the five FPN levels under the shared-weight RPN / RetinaNet heads, the

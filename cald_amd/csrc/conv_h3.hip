@@ -12,10 +12,10 @@
 // split -- weights by 2^S per layer at finalize (max |w| * 2^S <= 2^14), activations by 2^4 while staging -- and the
 // accumulator is multiplied by 2^-(S+4) first thing in the epilogue (exact).  Range: |activation| < 4094.
 //
-// k order.  This mode is not tied to the exact mode's (kh, kw, cin) summation order, so the k-tiles run (kh, cin-chunk, kw):
-// the three kw taps of a 16-channel chunk read the same 64-byte pixel segments shifted by one pixel, which turns two of
-// every three A-tile fetches into L1 hits -- the kernel is L2-bandwidth-bound otherwise (at 128 x 128 tiles the 3x3
-// 256->256 layer on P2 moves 74 GB per launch from L2, 10.6 TB/s).  Weights are packed in the same order (api.hip).
+// k order: the same (16-channel chunk, kh, kw) k-tile walk as the exact kernels (api.hip conv_k_index): all nine taps of a
+// chunk are consecutive k-tiles, the three kw taps of a row read the same 64-byte pixel segments shifted by one pixel (L1
+// hits) and the three rows stay in L2 -- the kernel is L2-bandwidth-bound otherwise (at 128 x 128 tiles the 3x3 256->256
+// layer on P2 moves 74 GB per launch from L2, 10.6 TB/s).
 //
 // Same implicit-GEMM structure as conv_p4.hip: 128 x 128 x 16 tiles, 4 waves (64 x 64 each), buffer loads with
 // hardware zero fill for out-of-image taps, XCD-aware tile map, fused fp32 epilogue.  Activations stay fp32 in HBM
@@ -130,7 +130,7 @@ __device__ __forceinline__ void conv_h3_body(const ConvArgs& a, const int blk) {
         if (TN == 2) rb1 = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, bvoff1, soffB, 0)); \
         u_kt++;                                                                                            \
         if (C4) { u_ci += BK; if (u_ci >= Cin) { u_ci = 0; u_kw++; if (u_kw == KW) { u_kw = 0; u_kh++; } } } \
-        else { u_kw++; if (u_kw == KW) { u_kw = 0; u_ci += BK; if (u_ci >= Cin) { u_ci = 0; u_kh++; } } }  \
+        else { u_kw++; if (u_kw == KW) { u_kw = 0; u_kh++; if (u_kh == KH) { u_kh = 0; u_ci += BK; } } }  \
     }
 #define H3_STORE(BUF)                                                                                      \
     {                                                                                                      \

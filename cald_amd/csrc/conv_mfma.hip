@@ -5,7 +5,7 @@
 // detection/frcnn_la.py:258, :261, :113-114).
 //
 //   GEMM view:  M = output pixels of all views of the ragged batch (each view padded to a multiple
-//               of the 128-row tile), N = Cout, K = KH*KW*Cin in (kh, kw, cin) order.
+//               of the 128-row tile), N = Cout, K = KH*KW*Cin in the contract's chain order (api.hip conv_k_index).
 //   MFMA:       v_mfma_f32_32x32x2_f32 -- exact fp32, one k-ordered fma chain per output, so the
 //               result is bit-identical to the CPU oracle's fmaf chain (DESIGN.md contract).
 //   Tile:       128 x BN x 16, 256 threads = 4 waves; each wave owns TM x TN 32x32 accumulators.
@@ -137,8 +137,7 @@ __global__ __launch_bounds__(256, (BK == 32 ? 2 : 3)) void conv_mfma_f32_kernel(
             }                                                                                              \
         }                                                                                                  \
         if (FAST) {                                                                                        \
-            u_ci += BK;                                                                                    \
-            if (u_ci >= Cin) { u_ci = 0; u_kw++; if (u_kw == KW) { u_kw = 0; u_kh++; } }                   \
+            u_kw++; if (u_kw == KW) { u_kw = 0; u_kh++; if (u_kh == KH) { u_kh = 0; u_ci += BK; } }        \
         } else {                                                                                           \
             ci += BK;                                                                                      \
             while (ci >= Cin) { ci -= Cin; kw++; if (kw == KW) { kw = 0; kh++; } }                         \
@@ -301,10 +300,7 @@ void launch_conv(const ConvArgs& a, hipStream_t stream) {
     static const int p4 = conv_env("CALD_CONV_P4", 1);   // conv_p4.hip: 3-buffer pipelined schedule, 128-bit LDS fragment reads; 0 = this file only
     if (a.w16 && launch_conv_h3(a, stream)) return;
     if (p4 && launch_conv_p4(a, stream)) return;
-    static const int bk32 = conv_env("CALD_CONV_BK32", 0);
-    if (a.CoutPad % 128 == 0) {
-        if (bk32 && a.Kpad % 32 == 0) launch_cfg<2, 2, 2, 2, 32>(a, 128, stream);
-        else launch_cfg<2, 2, 2, 2, 16>(a, 128, stream);
-    } else if (a.CoutPad % 64 == 0) launch_cfg<2, 2, 2, 1, 16>(a, 64, stream);
+    if (a.CoutPad % 128 == 0) launch_cfg<2, 2, 2, 2, 16>(a, 128, stream);
+    else if (a.CoutPad % 64 == 0) launch_cfg<2, 2, 2, 1, 16>(a, 64, stream);
     else launch_cfg<4, 1, 1, 1, 16>(a, 32, stream);
 }

@@ -29,7 +29,14 @@ __device__ __forceinline__ void conv_p4_body(const ConvArgs& a, const int blk) {
     const int wm = wave / WN, wn = wave % WN;
     const int NT = a.CoutPad / BN;
     int mt, nt;
-    {
+    if (a.KH * a.KW > 1) {
+        // filters with a spatial extent: XCD-contiguous map: block b runs on XCD b % 8; XCD x owns the contiguous M-tile range [x * CH, (x + 1) * CH), so
+        // tiles that share input rows (neighbours along a row, and the rows above / below ~W/128 tiles away) meet in ONE L2
+        const int MT = a.total_mtiles, CH = (MT + 7) >> 3;
+        const int xcd = blk & 7, idx = blk >> 3;
+        mt = xcd * CH + idx / NT; nt = idx % NT;
+        if (idx / NT >= CH || mt >= MT) return;
+    } else {
         const int b = blk, MT = a.total_mtiles, MT8 = MT & ~7;
         if (b < MT8 * NT) { const int xcd = b & 7, idx = b >> 3; mt = (idx / NT) * 8 + xcd; nt = idx % NT; }
         else { const int r = b - MT8 * NT; mt = MT8 + r / NT; nt = r % NT; }
@@ -112,8 +119,9 @@ __device__ __forceinline__ void conv_p4_body(const ConvArgs& a, const int blk) {
         ra1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, v1, soffA, 0));         \
         rb0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, bvoff0, soffB, 0));     \
         if (TN == 2) rb1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, bvoff1, soffB, 0)); \
-        u_kt++; u_ci += BK;                                                                                \
-        if (u_ci >= Cin) { u_ci = 0; u_kw++; if (u_kw == KW) { u_kw = 0; u_kh++; } }                       \
+        u_kt++;                                                                                            \
+        /* k-tile order (16-channel chunk, kh, kw): api.hip conv_k_index */                                \
+        u_kw++; if (u_kw == KW) { u_kw = 0; u_kh++; if (u_kh == KH) { u_kh = 0; u_ci += BK; } }            \
     }
 #define P4_STORE(BUF)                                                                                      \
     {                                                                                                      \
@@ -248,7 +256,7 @@ __device__ __forceinline__ void conv_p4_body(const ConvArgs& a, const int blk) {
                 val = val + sh;
                 if (EPI != 0) val = val + extra[r];
                 if (relu) val = val > 0.0f ? val : 0.0f;
-                if (m < Mv && nok) out_v[(long long)m * out_ld + n] = val;
+                if (m < Mv && nok && !((a.exp_flags & 1) && val != 12345.678f)) out_v[(long long)m * out_ld + n] = val;
             }
         }
     }
@@ -263,6 +271,9 @@ __global__ __launch_bounds__(256, 3) void conv_p4_group_kernel(const ConvGroup g
     conv_p4_body<EPI, C4, TN>(g.p[i], (int)blockIdx.x - g.blk0[i]);
 }
 
+// M-tile slots of the launch grid: the XCD-contiguous map of spatial filters rounds the tile count up to a multiple of 8
+static inline int p4_grid_mtiles(const ConvArgs& a) { return a.KH * a.KW > 1 ? 8 * ((a.total_mtiles + 7) / 8) : a.total_mtiles; }
+
 // grouped launch (EPI 0 only): returns true if every problem qualifies for the same variant
 bool launch_conv_p4_group(const ConvArgs* p, int n, hipStream_t stream) {
     if (n < 1 || n > CALD_MAX_GROUP) return false;
@@ -271,7 +282,7 @@ bool launch_conv_p4_group(const ConvArgs* p, int n, hipStream_t stream) {
     for (int i = 0; i < n; i++) {
         const ConvArgs& a = p[i];
         if (!a.w4 || a.w16 || a.CoutPad % 64 != 0 || (a.CoutPad % 128 == 0) != wide || a.Cin % 16 != 0 || a.KH * a.KW > 32 || a.residual || a.up) return false;
-        g.blk0[i] = blk; blk += a.total_mtiles * (a.CoutPad / (wide ? 128 : 64)); g.p[i] = a;
+        g.blk0[i] = blk; blk += p4_grid_mtiles(a) * (a.CoutPad / (wide ? 128 : 64)); g.p[i] = a; g.p[i].exp_flags = 0;
     }
     g.blk0[n] = blk;
     if (wide) hipLaunchKernelGGL((conv_p4_group_kernel<0, false, 2>), dim3((unsigned)blk), dim3(256), 0, stream, g);
@@ -280,8 +291,11 @@ bool launch_conv_p4_group(const ConvArgs* p, int n, hipStream_t stream) {
 }
 
 // returns true if this variant handled the launch
-bool launch_conv_p4(const ConvArgs& a, hipStream_t stream) {
-    if (!a.w4 || a.CoutPad % 64 != 0) return false;
+bool launch_conv_p4(const ConvArgs& a_in, hipStream_t stream) {
+    if (!a_in.w4 || a_in.CoutPad % 64 != 0) return false;
+    static const int exp_env = getenv("CALD_P4_EXP") ? atoi(getenv("CALD_P4_EXP")) : 0;          // tuning experiments (tools/bench_conv.py)
+    static const int pad_lds = getenv("CALD_P4_PADLDS") ? atoi(getenv("CALD_P4_PADLDS")) : 0;    // extra dynamic LDS: caps workgroups per CU
+    ConvArgs a = a_in; a.exp_flags = exp_env;
     bool wide = a.CoutPad % 128 == 0;
     if (wide) {
         // tail quantisation: a launch of B equal workgroups on 768 slots (256 CUs x 3) runs at B / (ceil(B / 768) * 768); the
@@ -291,22 +305,22 @@ bool launch_conv_p4(const ConvArgs& a, hipStream_t stream) {
         const double e2 = (double)b2 / (double)(((b2 + 767) / 768) * 768), e1 = 0.88 * (double)b1 / (double)(((b1 + 767) / 768) * 768);
         if (narrow_env && e1 > e2 && !a.dyn_rows) wide = false;
     }
-    dim3 grid((unsigned)(a.total_mtiles * (a.CoutPad / (wide ? 128 : 64)))), block(256);
+    dim3 grid((unsigned)(p4_grid_mtiles(a) * (a.CoutPad / (wide ? 128 : 64)))), block(256);
     if (a.Cin == 4) {
         if (a.residual || a.up || a.in_relu) return false;
-        if (wide) hipLaunchKernelGGL((conv_p4_kernel<0, true, 2>), grid, block, 0, stream, a);
-        else hipLaunchKernelGGL((conv_p4_kernel<0, true, 1>), grid, block, 0, stream, a);
+        if (wide) hipLaunchKernelGGL((conv_p4_kernel<0, true, 2>), grid, block, pad_lds, stream, a);
+        else hipLaunchKernelGGL((conv_p4_kernel<0, true, 1>), grid, block, pad_lds, stream, a);
         return true;
     }
     if (a.Cin % 16 != 0 || a.KH * a.KW > 32) return false;
     if (wide) {
-        if (a.residual) hipLaunchKernelGGL((conv_p4_kernel<1, false, 2>), grid, block, 0, stream, a);
-        else if (a.up) hipLaunchKernelGGL((conv_p4_kernel<2, false, 2>), grid, block, 0, stream, a);
-        else hipLaunchKernelGGL((conv_p4_kernel<0, false, 2>), grid, block, 0, stream, a);
+        if (a.residual) hipLaunchKernelGGL((conv_p4_kernel<1, false, 2>), grid, block, pad_lds, stream, a);
+        else if (a.up) hipLaunchKernelGGL((conv_p4_kernel<2, false, 2>), grid, block, pad_lds, stream, a);
+        else hipLaunchKernelGGL((conv_p4_kernel<0, false, 2>), grid, block, pad_lds, stream, a);
     } else {
-        if (a.residual) hipLaunchKernelGGL((conv_p4_kernel<1, false, 1>), grid, block, 0, stream, a);
-        else if (a.up) hipLaunchKernelGGL((conv_p4_kernel<2, false, 1>), grid, block, 0, stream, a);
-        else hipLaunchKernelGGL((conv_p4_kernel<0, false, 1>), grid, block, 0, stream, a);
+        if (a.residual) hipLaunchKernelGGL((conv_p4_kernel<1, false, 1>), grid, block, pad_lds, stream, a);
+        else if (a.up) hipLaunchKernelGGL((conv_p4_kernel<2, false, 1>), grid, block, pad_lds, stream, a);
+        else hipLaunchKernelGGL((conv_p4_kernel<0, false, 1>), grid, block, pad_lds, stream, a);
     }
     return true;
 }

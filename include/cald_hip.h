@@ -173,6 +173,11 @@ int cald_op_conv2d(cald_ctx* ctx, const float* in, int H, int W, int Cin, const 
 int cald_op_conv2d_f16x3(cald_ctx* ctx, const float* in, int H, int W, int Cin, const float* weight, int Cout, int KH, int KW,
                          int stride, int pad, const float* bias, const float* bn_scale, const float* bn_shift,
                          const float* residual, int relu, float* out);
+/* kernel-tuning aid (tools/bench_conv.py): average time of ONE conv layer shape (the model's own kernel selection) over a
+ * ragged batch of n_views equal views filled with pseudo-random data; `group` > 1 issues that many independent copies as one
+ * grouped launch (FPN / RPN style).  tflops_out counts algorithmic FLOPs (2 * M * Cout * KH*KW*Cin). */
+int cald_op_conv_bench(cald_ctx* ctx, int n_views, int H, int W, int Cin, int Cout, int KH, int stride, int pad, int residual,
+                       int relu, int iters, int group, double* ms_out, double* tflops_out);
 /* detector-transform size (GeneralizedRCNNTransform): resized and padded sizes */
 int cald_op_transform_size(int H, int W, int min_size, int max_size, int* Hr, int* Wr, int* Hp, int* Wp);
 /* intermediate tensors of the LAST cald_forward (parity debugging): name in

@@ -16,7 +16,7 @@
  *
  * Arithmetic contract (what makes GPU<->oracle comparison bit-exact):
  *   all float32, compiled with -ffp-contract=off; dot products are ONE k-ordered fmaf chain
- *   per output starting from +0 (k order = (kh, kw, cin) for convs, natural for linear);
+ *   per output starting from +0 (k order for convs: (16-channel chunk, kh, kw, channel) when Cin % 16 == 0, else (kh, kw, cin); natural for linear);
  *   exp/log are the fixed polynomials of orc_math.h; sorts are (key desc, index asc).
  * ===================================================================================== */
 #include <stdint.h>
@@ -410,8 +410,8 @@ ORC_API void orc_preprocess_view(const uint8_t* src, int H, int W, int flip, int
 }
 
 /* -------------------------------------------------------------------------------------
- * Convolution, NHWC, weights given K-major [KH][KW][Cin][Cout].  One fmaf chain per output
- * in (kh, kw, cin) order from +0; then (+bias) -> (*bn_scale, +bn_shift as two roundings,
+ * Convolution, NHWC, weights given K-major [KH][KW][Cin][Cout].  One fmaf chain per output from +0, in
+ * (16-channel chunk, kh, kw, channel) order when Cin % 16 == 0 (<= 32 taps), else (kh, kw, cin); then (+bias) -> (*bn_scale, +bn_shift as two roundings,
  * FrozenBatchNorm2d: x*scale+bias) -> (+residual) -> (+nearest-upsampled `up`) -> ReLU.
  * ------------------------------------------------------------------------------------- */
 #define CT_P 6
@@ -434,6 +434,11 @@ ORC_API void orc_conv2d_nhwc(const float* in, int H, int W, int Cin, const float
             int nv = Cout - co0 < CT_V ? Cout - co0 : CT_V;
             float acc[CT_P][CT_V];
             for (int p = 0; p < CT_P; p++) for (int v = 0; v < CT_V; v++) acc[p][v] = 0.0f;
+            /* chain order (DESIGN.md contract): Cin % 16 == 0 and <= 32 taps: (16-channel chunk, kh, kw, channel in chunk);
+             * otherwise (kh, kw, cin).  1x1 / linear layers: plain channel order either way. */
+            const int chunked = (Cin % 16 == 0) && (KH * KW <= 32);
+            const int cstep = chunked ? 16 : Cin;
+            for (int c0 = 0; c0 < Cin; c0 += cstep)
             for (int kh = 0; kh < KH; kh++)
                 for (int kw = 0; kw < KW; kw++) {
                     const float* rows[CT_P];
@@ -447,7 +452,7 @@ ORC_API void orc_conv2d_nhwc(const float* in, int H, int W, int Cin, const float
                     }
                     const float* wbase = wk + ((size_t)(kh * KW + kw) * Cin) * Cout + co0;
                     if (nv == CT_V) {
-                        for (int ci = 0; ci < Cin; ci++) {
+                        for (int ci = c0; ci < c0 + cstep; ci++) {
                             const float* wr = wbase + (size_t)ci * Cout;
 #pragma GCC unroll 8
                             for (int p = 0; p < CT_P; p++) {
@@ -457,7 +462,7 @@ ORC_API void orc_conv2d_nhwc(const float* in, int H, int W, int Cin, const float
                             }
                         }
                     } else {
-                        for (int ci = 0; ci < Cin; ci++) {
+                        for (int ci = c0; ci < c0 + cstep; ci++) {
                             const float* wr = wbase + (size_t)ci * Cout;
                             for (int p = 0; p < CT_P; p++) {
                                 float a = rows[p][ci];

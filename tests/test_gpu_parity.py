@@ -718,8 +718,7 @@ def test_voc_evaluate_files_equal_oracle_files_and_ap(hip, oracle, small_model, 
     model, P = small_model
     pool = synth.make_pool(6, "voc", 0, scale=0.5)
     names = ["2010_%06d" % (7 * i + 3) for i in range(len(pool))]
-    classes = ('__background__',) + tuple(cald_helper.VOC_CLASSES) if hasattr(cald_helper, "VOC_CLASSES") else \
-        ('__background__',) + tuple("class%02d" % c for c in range(1, 21))
+    classes = ('__background__',) + tuple("class%02d" % c for c in range(1, 21))
     assert len(classes) == 21
     # what the oracle detects, in the reference's all_boxes structure (engine.py:114-141)
     want_boxes = [[] for _ in classes]
@@ -760,4 +759,6 @@ def test_voc_evaluate_files_equal_oracle_files_and_ap(hip, oracle, small_model, 
         assert a == b, cls
         nonempty += bool(a)
     assert nonempty >= 3
-    assert res["AP50"] > 0.2 and res["mAP"] > 0.0 and len(res["ap_per_class"]) == 20
+    # classes without ground truth have npos == 0 -> AP is nan in the reference too (voc_eval.py:181); look at the annotated ones
+    annotated = [a for a in res["ap_per_class"] if a == a]
+    assert len(res["ap_per_class"]) == 20 and len(annotated) >= 2 and max(annotated) > 0.5, res["ap_per_class"]
