@@ -19,7 +19,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // C4: Cin == 4 (the stem conv on the NHWC4 input).  A thread's four consecutive k are one filter tap, so the tap and its
 // validity are per-thread quantities; the k order (tap, channel) is the contract's (kh, kw, cin) order unchanged.
 // TN = 2: 128 x 128 tiles; TN = 1: 128 x 64 tiles (64 x 32 per wave) for the 64-wide layers.
-template <int EPI, bool C4, int TN>
+// TAPS: 9 = 3 x 3 filter, 1 = 1 x 1 filter / linear layer: the k-loop is unrolled over the LDS buffer rotation (and the nine taps),
+// so LDS addresses are register + immediate and the per-tap load offsets are precomputed registers -- the loop body holds
+// no address / mask VALU at all (every VALU instruction beside v_mfma_f32_32x32x2_f32 costs matrix-pipe time: they share the
+// fp32 datapath).  0 = generic rolled loop (the 7 x 7 stem, other filter sizes).
+template <int EPI, bool C4, int TN, int TAPS>
 __device__ __forceinline__ void conv_p4_body(const ConvArgs& a, const int blk) {
     constexpr int BM = 128, BN = 64 * TN, BK = 16, TM = 2, WN = 2;
     constexpr int TILE_A = 2 * BM * 8, TILE_F = TILE_A + 2 * BN * 8;      // floats: 2048 + 2048 (TN = 2)
@@ -146,9 +150,37 @@ __device__ __forceinline__ void conv_p4_body(const ConvArgs& a, const int blk) {
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
 
     const int KT = a.Kpad / BK;
-    P4_LOAD();
-    P4_STORE(0);
-    if (KT > 1) P4_LOAD();
+    // unrolled variants: per-thread load offset of every tap (out-of-image taps -> an out-of-range offset: the buffer load
+    // returns zeros), and the loader's channel cursor
+    int voffA[2][TAPS > 0 ? TAPS : 1];
+    int ci_ld = 0;
+    if (TAPS > 0) {
+#pragma unroll
+        for (int p = 0; p < 2; p++)
+#pragma unroll
+            for (int t = 0; t < (TAPS > 0 ? TAPS : 1); t++) voffA[p][t] = ((rowmask[p] >> t) & 1u) ? rowvoff[p] : 0x7FFF0000;
+    }
+    if (TAPS == 0) {
+        P4_LOAD();
+        P4_STORE(0);
+        if (KT > 1) P4_LOAD();
+    } else {
+#define U_LOAD0(T)                                                                                         \
+    {                                                                                                      \
+        const int soffB = u_kt * 2 * CoutPad * 8 * 4;                                                      \
+        const int soffA = (TAPS == 9 ? ((((T) / 3) * Wi + ((T) % 3)) * Cin + ci_ld) : ci_ld) * 4;          \
+        ra0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, voffA[0][T], soffA, 0)); \
+        ra1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, voffA[1][T], soffA, 0)); \
+        rb0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, bvoff0, soffB, 0));     \
+        if (TN == 2) rb1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, bvoff1, soffB, 0)); \
+        u_kt++;                                                                                            \
+        if ((T) == TAPS - 1) ci_ld += BK;                                                                  \
+    }
+        U_LOAD0(0)
+        P4_STORE(0);
+        if (KT > 1) U_LOAD0(TAPS == 9 ? 1 : 0)
+#undef U_LOAD0
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
@@ -194,11 +226,94 @@ __device__ __forceinline__ void conv_p4_body(const ConvArgs& a, const int blk) {
         P4_MFMA(fa1, fb1, 3)                                                                               \
     }
 
-    int cur = 0;
-    for (int kt = 0; kt < KT; kt++) {
-        const int nxtb = cur == 2 ? 0 : cur + 1;
-        P4_TILE(cur, nxtb);
-        cur = nxtb;
+    if (TAPS == 0) {
+        int cur = 0;
+        for (int kt = 0; kt < KT; kt++) {
+            const int nxtb = cur == 2 ? 0 : cur + 1;
+            P4_TILE(cur, nxtb);
+            cur = nxtb;
+        }
+    } else {
+        // LDS addresses as pointers: buffer / kq offsets below are compile-time constants folded into the DS offset field
+        // A stores go out as ds_write2_b32 (8-bit dword offsets: no room for the buffer offset) -> one address register per (buffer, row, h)
+        unsigned awa[3][4];
+#pragma unroll
+        for (int b = 0; b < 3; b++) {
+            awa[b][0] = (unsigned)(uintptr_t)(smem + b * TILE_F + aw_off[0][0]); awa[b][1] = (unsigned)(uintptr_t)(smem + b * TILE_F + aw_off[0][1]);
+            awa[b][2] = (unsigned)(uintptr_t)(smem + b * TILE_F + aw_off[1][0]); awa[b][3] = (unsigned)(uintptr_t)(smem + b * TILE_F + aw_off[1][1]);
+        }
+        float* const bwp0 = smem + bw_off0; float* const bwp1 = smem + bw_off1;
+        const float* fpa[TM]; const float* fpb[TN];
+#pragma unroll
+        for (int t = 0; t < TM; t++) fpa[t] = smem + fo_a[t];
+#pragma unroll
+        for (int t = 0; t < TN; t++) fpb[t] = smem + fo_b[t];
+#define U_LOAD(T)                                                                                          \
+    {                                                                                                      \
+        const int soffB = u_kt * 2 * CoutPad * 8 * 4;                                                      \
+        const int soffA = (TAPS == 9 ? ((((T) / 3) * Wi + ((T) % 3)) * Cin + ci_ld) : ci_ld) * 4;          \
+        ra0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, voffA[0][T], soffA, 0)); \
+        ra1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, voffA[1][T], soffA, 0)); \
+        rb0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, bvoff0, soffB, 0));     \
+        if (TN == 2) rb1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, bvoff1, soffB, 0)); \
+        u_kt++;                                                                                            \
+        if ((T) == TAPS - 1) ci_ld += BK;                                                                  \
+    }
+/* two dwords from two independent registers to consecutive LDS words (hipcc would merge plain stores into a ds_write_b64  \
+   plus two v_mov; LDS completes in order, so the compiler's own lgkmcnt bookkeeping stays conservative-correct) */
+#define U_W2(ADDR, D0, D1)                                                                                 \
+    asm volatile("ds_write2_b32 %0, %1, %2 offset1:1" ::"v"(ADDR), "v"(D0), "v"(D1) : "memory");
+#define U_STORE(BUF)                                                                                       \
+    {                                                                                                      \
+        if (in_relu) {                                                                                     \
+            _Pragma("unroll") for (int q = 0; q < 4; q++) { ra0[q] = ra0[q] < 0.f ? 0.f : ra0[q]; ra1[q] = ra1[q] < 0.f ? 0.f : ra1[q]; } \
+        }                                                                                                  \
+        /* scalar stores: the pairs (k, k + 2) sit in non-adjacent registers -- ds_write2_b32 takes two independent data   \
+           registers, a ds_write_b64 would need two v_mov per pair (VALU beside the MFMAs) */                           \
+        U_W2(awa[BUF][0], ra0[0], ra0[2]) U_W2(awa[BUF][1], ra0[1], ra0[3])                                \
+        U_W2(awa[BUF][2], ra1[0], ra1[2]) U_W2(awa[BUF][3], ra1[1], ra1[3])                                \
+        *reinterpret_cast<f32x4*>(bwp0 + (BUF) * TILE_F) = rb0;                                            \
+        if (TN == 2) *reinterpret_cast<f32x4*>(bwp1 + (BUF) * TILE_F) = rb1;                               \
+    }
+#define U_TILE(CUR, NXT, TLD, KTX)                                                                         \
+    {                                                                                                      \
+        const bool has1 = (KTX) + 1 < KT, has2 = (KTX) + 2 < KT;                                           \
+        _Pragma("unroll") for (int t = 0; t < TM; t++) fa1[t] = *reinterpret_cast<const f32x4*>(fpa[t] + (CUR) * TILE_F + BM * 8); \
+        _Pragma("unroll") for (int t = 0; t < TN; t++) fb1[t] = *reinterpret_cast<const f32x4*>(fpb[t] + (CUR) * TILE_F + BN * 8); \
+        P4_MFMA(fa0, fb0, 0)                                                                               \
+        P4_MFMA(fa0, fb0, 1)                                                                               \
+        if (has1) U_STORE(NXT)                                                                             \
+        P4_MFMA(fa0, fb0, 2)                                                                               \
+        if (has2) U_LOAD(TLD)                                                                              \
+        P4_MFMA(fa0, fb0, 3)                                                                               \
+        P4_MFMA(fa1, fb1, 0)                                                                               \
+        P4_MFMA(fa1, fb1, 1)                                                                               \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                 \
+        __builtin_amdgcn_s_barrier();                                                                      \
+        if (has1) {                                                                                        \
+            _Pragma("unroll") for (int t = 0; t < TM; t++) fa0[t] = *reinterpret_cast<const f32x4*>(fpa[t] + (NXT) * TILE_F); \
+            _Pragma("unroll") for (int t = 0; t < TN; t++) fb0[t] = *reinterpret_cast<const f32x4*>(fpb[t] + (NXT) * TILE_F); \
+        }                                                                                                  \
+        P4_MFMA(fa1, fb1, 2)                                                                               \
+        P4_MFMA(fa1, fb1, 3)                                                                               \
+    }
+        if (TAPS == 9) {
+            for (int kt = 0; kt < KT; kt += 9) {      // one 16-channel chunk: nine taps, three turns of the buffer ring
+                U_TILE(0, 1, 2, kt)     U_TILE(1, 2, 3, kt + 1) U_TILE(2, 0, 4, kt + 2)
+                U_TILE(0, 1, 5, kt + 3) U_TILE(1, 2, 6, kt + 4) U_TILE(2, 0, 7, kt + 5)
+                U_TILE(0, 1, 8, kt + 6) U_TILE(1, 2, 0, kt + 7) U_TILE(2, 0, 1, kt + 8)
+            }
+        } else {
+            for (int kt = 0; kt < KT; kt += 3) {
+                U_TILE(0, 1, 0, kt)
+                if (kt + 1 < KT) U_TILE(1, 2, 0, kt + 1)
+                if (kt + 2 < KT) U_TILE(2, 0, 0, kt + 2)
+            }
+        }
+#undef U_LOAD
+#undef U_STORE
+#undef U_W2
+#undef U_TILE
     }
 #undef P4_LOAD
 #undef P4_STORE
@@ -262,13 +377,23 @@ __device__ __forceinline__ void conv_p4_body(const ConvArgs& a, const int blk) {
     }
 }
 
-template <int EPI, bool C4 = false, int TN = 2>
-__global__ __launch_bounds__(256, 3) void conv_p4_kernel(const ConvArgs a) { conv_p4_body<EPI, C4, TN>(a, blockIdx.x); }
-template <int EPI, bool C4, int TN>
+template <int EPI, bool C4, int TN, int TAPS>
+__global__ __launch_bounds__(256, 3) void conv_p4_kernel(const ConvArgs a) { conv_p4_body<EPI, C4, TN, TAPS>(a, blockIdx.x); }
+template <int EPI, bool C4, int TN, int TAPS>
 __global__ __launch_bounds__(256, 3) void conv_p4_group_kernel(const ConvGroup g) {
     int i = 0;
     while (i + 1 < g.n && g.blk0[i + 1] <= (int)blockIdx.x) i++;
-    conv_p4_body<EPI, C4, TN>(g.p[i], (int)blockIdx.x - g.blk0[i]);
+    conv_p4_body<EPI, C4, TN, TAPS>(g.p[i], (int)blockIdx.x - g.blk0[i]);
+}
+// filter shape -> k-loop variant
+static inline int p4_taps(const ConvArgs& a) {
+    static const int unroll_env = getenv("CALD_P4_UNROLL") ? atoi(getenv("CALD_P4_UNROLL")) : 1;      // 0: generic rolled loop everywhere
+    if (!unroll_env || a.Cin % 16 != 0) return 0;
+    if (a.KH == 3 && a.KW == 3) return 9;
+    // short 1 x 1 chains (K < 512) are prologue / epilogue bound: the extra address registers of the unrolled variant cost more
+    // set-up than its loop saves (measured: 256 -> 64 and 256 -> 1024 at K = 256 lose 10 %, K >= 512 gains 1.5 ... 8.5 %)
+    if (a.KH == 1 && a.KW == 1) return a.Kpad >= 512 ? 1 : 0;
+    return 0;
 }
 
 // M-tile slots of the launch grid: the XCD-contiguous map of spatial filters rounds the tile count up to a multiple of 8
@@ -285,8 +410,13 @@ bool launch_conv_p4_group(const ConvArgs* p, int n, hipStream_t stream) {
         g.blk0[i] = blk; blk += p4_grid_mtiles(a) * (a.CoutPad / (wide ? 128 : 64)); g.p[i] = a; g.p[i].exp_flags = 0;
     }
     g.blk0[n] = blk;
-    if (wide) hipLaunchKernelGGL((conv_p4_group_kernel<0, false, 2>), dim3((unsigned)blk), dim3(256), 0, stream, g);
-    else hipLaunchKernelGGL((conv_p4_group_kernel<0, false, 1>), dim3((unsigned)blk), dim3(256), 0, stream, g);
+    const int taps = p4_taps(p[0]);
+    for (int i = 1; i < n; i++) if (p4_taps(p[i]) != taps) return false;
+    const dim3 grid((unsigned)blk), block(256);
+#define P4_GROUP(TNV, TAPSV) hipLaunchKernelGGL((conv_p4_group_kernel<0, false, TNV, TAPSV>), grid, block, 0, stream, g)
+    if (wide) { if (taps == 9) P4_GROUP(2, 9); else if (taps == 1) P4_GROUP(2, 1); else P4_GROUP(2, 0); }
+    else { if (taps == 9) P4_GROUP(1, 9); else if (taps == 1) P4_GROUP(1, 1); else P4_GROUP(1, 0); }
+#undef P4_GROUP
     return true;
 }
 
@@ -308,19 +438,20 @@ bool launch_conv_p4(const ConvArgs& a_in, hipStream_t stream) {
     dim3 grid((unsigned)(p4_grid_mtiles(a) * (a.CoutPad / (wide ? 128 : 64)))), block(256);
     if (a.Cin == 4) {
         if (a.residual || a.up || a.in_relu) return false;
-        if (wide) hipLaunchKernelGGL((conv_p4_kernel<0, true, 2>), grid, block, pad_lds, stream, a);
-        else hipLaunchKernelGGL((conv_p4_kernel<0, true, 1>), grid, block, pad_lds, stream, a);
+        if (wide) hipLaunchKernelGGL((conv_p4_kernel<0, true, 2, 0>), grid, block, pad_lds, stream, a);
+        else hipLaunchKernelGGL((conv_p4_kernel<0, true, 1, 0>), grid, block, pad_lds, stream, a);
         return true;
     }
     if (a.Cin % 16 != 0 || a.KH * a.KW > 32) return false;
+    const int taps = p4_taps(a);
+#define P4_ONE(EPIV, TNV, TAPSV) hipLaunchKernelGGL((conv_p4_kernel<EPIV, false, TNV, TAPSV>), grid, block, pad_lds, stream, a)
+#define P4_TAPS(EPIV, TNV) { if (taps == 9) P4_ONE(EPIV, TNV, 9); else if (taps == 1) P4_ONE(EPIV, TNV, 1); else P4_ONE(EPIV, TNV, 0); }
     if (wide) {
-        if (a.residual) hipLaunchKernelGGL((conv_p4_kernel<1, false, 2>), grid, block, pad_lds, stream, a);
-        else if (a.up) hipLaunchKernelGGL((conv_p4_kernel<2, false, 2>), grid, block, pad_lds, stream, a);
-        else hipLaunchKernelGGL((conv_p4_kernel<0, false, 2>), grid, block, pad_lds, stream, a);
+        if (a.residual) P4_TAPS(1, 2) else if (a.up) P4_TAPS(2, 2) else P4_TAPS(0, 2)
     } else {
-        if (a.residual) hipLaunchKernelGGL((conv_p4_kernel<1, false, 1>), grid, block, pad_lds, stream, a);
-        else if (a.up) hipLaunchKernelGGL((conv_p4_kernel<2, false, 1>), grid, block, pad_lds, stream, a);
-        else hipLaunchKernelGGL((conv_p4_kernel<0, false, 1>), grid, block, pad_lds, stream, a);
+        if (a.residual) P4_TAPS(1, 1) else if (a.up) P4_TAPS(2, 1) else P4_TAPS(0, 1)
     }
+#undef P4_TAPS
+#undef P4_ONE
     return true;
 }
