@@ -320,7 +320,11 @@ __device__ __forceinline__ void conv_p4_body(const ConvArgs& a, const int blk) {
 #undef P4_MFMA
 #undef P4_TILE
 
-    // ---- fused epilogue: identical to conv_mfma.hip ----
+    // ---- fused epilogue (same arithmetic as conv_mfma.hip): (+bias) -> (*bn_scale, +bn_shift) -> (+residual | +upsampled) -> ReLU ----
+    // VALU instructions issued here take matrix-pipe time away from the two other workgroups of the CU, and for the short 1 x 1
+    // chains (K = 64 ... 256) the epilogue is a large part of a workgroup's life: addresses are therefore kept off the VALU --
+    // one byte offset per lane and accumulator tile, the 16 rows of a tile reached through the scalar offset of the buffer
+    // instruction -- and absent bias / BN terms are skipped by wave-uniform branches instead of neutral operands.
     const int out_ld = a.out_ld;
     float* __restrict__ out_v = a.out + so.pix_off * (long long)out_ld;
     const float* __restrict__ ex_v = nullptr;
@@ -333,21 +337,30 @@ __device__ __forceinline__ void conv_p4_body(const ConvArgs& a, const int blk) {
         upH = su.H; upW = su.W;
         uph_s = (float)upH / (float)Ho; upw_s = (float)upW / (float)Wo;
     }
-    const bool relu = a.relu != 0;
+    const bool relu = a.relu != 0, has_bias = a.bias != nullptr, has_bn = a.scale != nullptr;
+    const bool full_tile = m0 + BM <= Mv && !(a.exp_flags & 1);
+    const int row_b = out_ld * 4;
+    const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc((void*)out_v, 0, 0x7FFE0000, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)(EPI == 1 ? ex_v : out_v), 0, 0x7FFE0000, 0x00020000);
     const int Mlast = Mv - 1;
 #pragma unroll
     for (int j = 0; j < TN; j++) {
         const int n = n0 + wn * TN * 32 + j * 32 + l31;
         const bool nok = n < a.Cout;
         const int nc = nok ? n : 0;
-        const float bs = a.bias ? a.bias[nc] : 0.0f;
-        const float sc = a.scale ? a.scale[nc] : 1.0f;
-        const float sh = a.scale ? a.shift[nc] : 0.0f;
+        const float bs = has_bias ? a.bias[nc] : 0.0f;
+        const float sc = has_bn ? a.scale[nc] : 1.0f;
+        const float sh = has_bn ? a.shift[nc] : 0.0f;
 #pragma unroll
         for (int i = 0; i < TM; i++) {
             const int mbase = m0 + wm * TM * 32 + i * 32 + 4 * kh_lane;
             float extra[16];
-            if (EPI != 0) {
+            if (EPI == 1 && full_tile) {
+                const int vo = nok ? (mbase * out_ld + n) * 4 : 0x7FFF0000;
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    extra[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsX, vo, ((r & 3) + 8 * (r >> 2)) * row_b, 0));
+            } else if (EPI != 0) {
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     int m = mbase + (r & 3) + 8 * (r >> 2);
@@ -362,16 +375,36 @@ __device__ __forceinline__ void conv_p4_body(const ConvArgs& a, const int blk) {
                     }
                 }
             }
+            float val[16];
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int m = mbase + (r & 3) + 8 * (r >> 2);
-                float val = acc[i][j][r];
-                val = val + bs;
-                val = val * sc;
-                val = val + sh;
-                if (EPI != 0) val = val + extra[r];
-                if (relu) val = val > 0.0f ? val : 0.0f;
-                if (m < Mv && nok && !((a.exp_flags & 1) && val != 12345.678f)) out_v[(long long)m * out_ld + n] = val;
+            for (int r = 0; r < 16; r++) val[r] = acc[i][j][r];
+            if (has_bias) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) val[r] = val[r] + bs;
+            }
+            if (has_bn) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) { val[r] = val[r] * sc; val[r] = val[r] + sh; }
+            }
+            if (EPI != 0) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) val[r] = val[r] + extra[r];
+            }
+            if (relu) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) val[r] = val[r] > 0.0f ? val[r] : 0.0f;
+            }
+            if (full_tile) {
+                const int vo = nok ? (mbase * out_ld + n) * 4 : 0x7FFF0000;
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val[r]), rsO, vo, ((r & 3) + 8 * (r >> 2)) * row_b, 0);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int m = mbase + (r & 3) + 8 * (r >> 2);
+                    if (m < Mv && nok && !((a.exp_flags & 1) && val[r] != 12345.678f)) out_v[(long long)m * out_ld + n] = val[r];
+                }
             }
         }
     }
@@ -390,9 +423,7 @@ static inline int p4_taps(const ConvArgs& a) {
     static const int unroll_env = getenv("CALD_P4_UNROLL") ? atoi(getenv("CALD_P4_UNROLL")) : 1;      // 0: generic rolled loop everywhere
     if (!unroll_env || a.Cin % 16 != 0) return 0;
     if (a.KH == 3 && a.KW == 3) return 9;
-    // short 1 x 1 chains (K < 512) are prologue / epilogue bound: the extra address registers of the unrolled variant cost more
-    // set-up than its loop saves (measured: 256 -> 64 and 256 -> 1024 at K = 256 lose 10 %, K >= 512 gains 1.5 ... 8.5 %)
-    if (a.KH == 1 && a.KW == 1) return a.Kpad >= 512 ? 1 : 0;
+    if (a.KH == 1 && a.KW == 1) return 1;
     return 0;
 }
 
