@@ -390,7 +390,7 @@ extern "C" int cald_model_create(cald_ctx* ctx, const cald_model_cfg* cfg, cald_
     if (cfg->rpn_pre_nms_top_n > 1024 || cfg->rpn_post_nms_top_n > CALD_ROI_CAP || cfg->rpn_pre_nms_top_n < 1 || cfg->rpn_post_nms_top_n < 1)
         return fail(CALD_ERR_INVALID, "rpn top-n out of range (pre <= 1024, post <= %d)", CALD_ROI_CAP);
     if (cfg->detections_per_img < 1 || cfg->detections_per_img > 1024) return fail(CALD_ERR_INVALID, "detections_per_img out of range");
-    if (cfg->precision != CALD_PRECISION_FP32 && cfg->precision != CALD_PRECISION_F16X3) return fail(CALD_ERR_INVALID, "unknown precision %d", cfg->precision);
+    if (cfg->precision != CALD_PRECISION_FP32 && cfg->precision != CALD_PRECISION_F16X3 && cfg->precision != CALD_PRECISION_I8X3) return fail(CALD_ERR_INVALID, "unknown precision %d", cfg->precision);
     cald_model* m = new cald_model();
     m->ctx = ctx; m->cfg = *cfg;
     {   // softmax rows sum to 1, so fewer than 1/thr classes of one proposal can pass `score > thr` (frcnn_la.py:72):
@@ -452,6 +452,44 @@ static std::vector<uint16_t> pack_w16(const std::vector<float>& w, int Kpad, int
             o[(((size_t)kt * 2 + 1) * CoutPad + n) * 16 + kk] = lb;
         }
     }
+    return o;
+}
+
+// CALD_PRECISION_I8X3 (conv_i3.hip): per output channel n the weights are quantised to 24-bit fixed point,
+// q = clamp(rint(w * 2^(22 - e_w[n])), +-0x7F7F7F) with e_w[n] = ilogb(max_k |w[k][n]|) + 1, and written as three balanced
+// signed base-256 digits.  Packed [Kpad8/32][3 planes][CoutPad][32 B]; k-tiles in (32-channel chunk, kh, kw) order, byte j of
+// a tile = channel 32 * chunk + j of that tap.  unscale[n] = 2^(e_w[n] - 22).  `w` is the K-major matrix in conv_k_index order.
+static bool i8_covers(int Cin, int CoutPad, int taps) { return Cin % 32 == 0 && CoutPad % 64 == 0 && taps <= 32; }
+static void i8_digits(long long q, int* d) {
+    d[0] = (int)(signed char)(q & 255); const long long q1 = (q - d[0]) >> 8;
+    d[1] = (int)(signed char)(q1 & 255); d[2] = (int)((q1 - d[1]) >> 8);
+}
+static std::vector<signed char> pack_w8(const std::vector<float>& w, int CoutPad, int taps, int Cin, std::vector<float>& unscale) {
+    const int K8 = taps * Cin, KT = K8 / 32, CC = Cin / 32;
+    std::vector<signed char> o((size_t)KT * 3 * CoutPad * 32, 0);
+    unscale.assign(CoutPad, 1.0f);
+    std::vector<int> ew(CoutPad, 0);
+    for (int n = 0; n < CoutPad; n++) {
+        float mx = 0.0f;
+        for (int k = 0; k < K8; k++) { const float ax = std::fabs(w[(size_t)k * CoutPad + n]); if (ax > mx) mx = ax; }
+        int e = 0;
+        if (mx > 0.0f && std::isfinite(mx)) { std::frexp(mx, &e); }          // mx = f * 2^e, f in [0.5, 1): |w| < 2^e
+        if (e > 60) e = 60; if (e < -60) e = -60;
+        ew[n] = e; unscale[n] = std::ldexp(1.0f, e - 22);
+    }
+    for (int cc = 0; cc < CC; cc++)
+        for (int tap = 0; tap < taps; tap++) {
+            const int kt = cc * taps + tap;
+            for (int j = 0; j < 32; j++) {
+                const int k = conv_k_index(tap, cc * 32 + j, taps, Cin);
+                for (int n = 0; n < CoutPad; n++) {
+                    double t = std::nearbyint((double)std::ldexp(w[(size_t)k * CoutPad + n], 22 - ew[n]));
+                    if (t > 8355711.0) t = 8355711.0; if (t < -8355711.0) t = -8355711.0;
+                    int d[3]; i8_digits((long long)t, d);
+                    for (int pl = 0; pl < 3; pl++) o[(((size_t)kt * 3 + pl) * CoutPad + n) * 32 + j] = (signed char)d[pl];
+                }
+            }
+        }
     return o;
 }
 
@@ -984,7 +1022,7 @@ extern "C" int cald_debug_tensor(cald_model* m, const char* name, int view, floa
 // =============================================================================================
 static int op_conv2d(cald_ctx* c, int precision, const float* in, int H, int W, int Cin, const float* weight, int Cout, int KH, int KW,
                      int stride, int pad, const float* bias, const float* bn_scale, const float* bn_shift,
-                     const float* residual, int relu, float* out) {
+                     const float* residual, int relu, float* out, int in_exp = 0) {
     if (!c || !in || !weight || !out) return fail(CALD_ERR_INVALID, "null argument");
     if (Cin % 4) return fail(CALD_ERR_INVALID, "Cin must be a multiple of 4");
     HIPCHK(hipSetDevice(c->device));
@@ -1019,6 +1057,15 @@ static int op_conv2d(cald_ctx* c, int precision, const float* in, int H, int W, 
         HIPCHK(hipMalloc((void**)&d_w16, w16.size() * 2));
         HIPCHK(hipMemcpy(d_w16, w16.data(), w16.size() * 2, hipMemcpyHostToDevice));
     }
+    signed char *d_w8 = nullptr, *d_planes = nullptr; float* d_w8u = nullptr; long long plane_stride = 0;
+    if (precision == CALD_PRECISION_I8X3) {
+        if (!i8_covers(Cin, CoutPad, KH * KW)) return fail(CALD_ERR_UNSUPPORTED, "i8x3 covers Cin %% 32 == 0, Cout >= 64, <= 32 taps");
+        std::vector<float> un; std::vector<signed char> w8 = pack_w8(w, CoutPad, KH * KW, Cin, un);
+        plane_stride = (((long long)H * W * Cin) + 15) & ~15ll;
+        HIPCHK(hipMalloc((void**)&d_w8, w8.size())); HIPCHK(hipMalloc((void**)&d_w8u, un.size() * 4)); HIPCHK(hipMalloc((void**)&d_planes, (size_t)plane_stride * 3));
+        HIPCHK(hipMemcpy(d_w8, w8.data(), w8.size(), hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(d_w8u, un.data(), un.size() * 4, hipMemcpyHostToDevice));
+        launch_quantize_planes(d_in, (long long)H * W * Cin, in_exp, d_planes, plane_stride, c->stream);
+    }
     HIPCHK(hipMemcpy(d_b, b.data(), b.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_sc, sc.data(), sc.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_sh, sh.data(), sh.size() * 4, hipMemcpyHostToDevice));
@@ -1029,10 +1076,12 @@ static int op_conv2d(cald_ctx* c, int precision, const float* in, int H, int W, 
     a.residual = d_res; a.up = nullptr; a.seg_in = d_p->seg[0]; a.seg_out = d_p->seg[1]; a.seg_up = d_p->seg[1]; a.dyn_rows = nullptr;
     a.V = 1; a.Cin = Cin; a.Cout = Cout; a.CoutPad = CoutPad; a.Kpad = Kpad; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
     a.relu = relu; a.total_mtiles = (Ho * Wo + 127) / 128; a.out_ld = Cout; a.in_relu = 0; a.zeros = c->d_zeros;
+    a.i8_in = d_planes; a.i8_plane_stride = plane_stride; a.w8 = d_w8; a.w8_unscale = d_w8u; a.i8_in_unscale = std::ldexp(1.0f, in_exp - 22 + 16);
     launch_conv(a, c->stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemcpy(out, d_out, (size_t)Ho * Wo * Cout * 4, hipMemcpyDeviceToHost));
+    if (d_w8) { hipFree(d_w8); hipFree(d_w8u); hipFree(d_planes); }
     if (d_w4) hipFree(d_w4);
     if (d_w16) hipFree(d_w16);
     hipFree(d_in); hipFree(d_out); hipFree(d_w); hipFree(d_b); hipFree(d_sc); hipFree(d_sh); hipFree(d_p); if (d_res) hipFree(d_res);
@@ -1042,6 +1091,11 @@ extern "C" int cald_op_conv2d(cald_ctx* c, const float* in, int H, int W, int Ci
                               int stride, int pad, const float* bias, const float* bn_scale, const float* bn_shift,
                               const float* residual, int relu, float* out) {
     return op_conv2d(c, CALD_PRECISION_FP32, in, H, W, Cin, weight, Cout, KH, KW, stride, pad, bias, bn_scale, bn_shift, residual, relu, out);
+}
+extern "C" int cald_op_conv2d_i8x3(cald_ctx* c, const float* in, int H, int W, int Cin, const float* weight, int Cout, int KH, int KW,
+                                   int stride, int pad, int in_exp, const float* bias, const float* bn_scale, const float* bn_shift,
+                                   const float* residual, int relu, float* out) {
+    return op_conv2d(c, CALD_PRECISION_I8X3, in, H, W, Cin, weight, Cout, KH, KW, stride, pad, bias, bn_scale, bn_shift, residual, relu, out, in_exp);
 }
 extern "C" int cald_op_conv2d_f16x3(cald_ctx* c, const float* in, int H, int W, int Cin, const float* weight, int Cout, int KH, int KW,
                                     int stride, int pad, const float* bias, const float* bn_scale, const float* bn_shift,
@@ -1091,9 +1145,21 @@ extern "C" int cald_op_conv_bench(cald_ctx* c, int V, int H, int W, int Cin, int
     }
     HIPCHK(hipMemcpy(d_b, b.data(), b.size() * 4, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(d_sc, sc.data(), sc.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_sh, sh.data(), sh.size() * 4, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(d_p, &P, sizeof(P), hipMemcpyHostToDevice));
+    // relu bit 1 (value 2 / 3): run the layer in CALD_PRECISION_I8X3 (digit planes prepared outside the timed region)
+    const bool i8 = (relu & 2) != 0; relu &= 1;
+    signed char *d_w8 = nullptr, *d_planes = nullptr; float* d_w8u = nullptr; long long plane_stride = 0;
+    if (i8) {
+        if (!i8_covers(Cin, CoutPad, KH * KW)) return fail(CALD_ERR_UNSUPPORTED, "i8x3 does not cover this shape");
+        std::vector<float> un; std::vector<signed char> w8 = pack_w8(w, CoutPad, KH * KW, Cin, un);
+        plane_stride = ((long long)n_in + 15) & ~15ll;
+        if ((rc = sd.alloc(&d_w8, w8.size())) || (rc = sd.alloc(&d_w8u, un.size() * 4)) || (rc = sd.alloc(&d_planes, (size_t)plane_stride * 3))) return rc;
+        HIPCHK(hipMemcpy(d_w8, w8.data(), w8.size(), hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(d_w8u, un.data(), un.size() * 4, hipMemcpyHostToDevice));
+        launch_quantize_planes(d_in, (long long)n_in, 1, d_planes, plane_stride, c->stream);
+    }
     ConvArgs a[CALD_MAX_GROUP];
     for (int gi = 0; gi < group; gi++) {
         memset(&a[gi], 0, sizeof(ConvArgs));
+        a[gi].i8_in = d_planes; a[gi].i8_plane_stride = plane_stride; a[gi].w8 = d_w8; a[gi].w8_unscale = d_w8u; a[gi].i8_in_unscale = std::ldexp(1.0f, 1 - 22 + 16);
         a[gi].in = d_in; a[gi].out = d_out + (size_t)gi * n_out; a[gi].w = d_w; a[gi].w4 = d_w4; a[gi].bias = d_b; a[gi].scale = d_sc; a[gi].shift = d_sh; a[gi].residual = d_res;
         a[gi].seg_in = d_p->seg[0]; a[gi].seg_out = d_p->seg[1]; a[gi].seg_up = d_p->seg[1]; a[gi].V = V; a[gi].Cin = Cin; a[gi].Cout = Cout; a[gi].CoutPad = CoutPad; a[gi].Kpad = Kpad;
         a[gi].KH = KH; a[gi].KW = KW; a[gi].stride = stride; a[gi].pad = pad; a[gi].relu = relu; a[gi].total_mtiles = V * ((Ho * Wo + 127) / 128); a[gi].out_ld = Cout; a[gi].zeros = c->d_zeros;

@@ -137,3 +137,6 @@ void launch_retina_postprocess(const RetinaArgs& a, int max_anchors, hipStream_t
 // baseline sweeps
 void launch_lt_uncertainty(const DetBuffers& det, int V, float* out, hipStream_t st);
 void launch_max_iou(const ScoreArgs& a, float* out /*[P][50]*/, hipStream_t st);
+
+// conv_i3.hip (CALD_PRECISION_I8X3): fp32 tensor -> three balanced base-256 digit planes of clamp(rint(x * 2^(22 - exp)), +-0x7F7F7F)
+void launch_quantize_planes(const float* src, long long n, int exp, signed char* dst, long long plane_stride, hipStream_t st);

@@ -40,6 +40,13 @@ typedef struct cald_model cald_model;
  *          bar is met only by FP32; |activations| must stay below 4094. */
 #define CALD_PRECISION_FP32 0
 #define CALD_PRECISION_F16X3 1
+/*   I8X3   exact-integer int8 mode (conv_i3.hip): activations (one calibrated power-of-two exponent per layer input) and
+ *          weights (one exponent per output channel) quantised to 24-bit fixed point, three balanced base-256 digits each,
+ *          six digit products on v_mfma_i32_32x32x32_i8 with exact int32 accumulation, one rounding to float32, then the exact
+ *          mode's fp32 epilogue.  Reproducible bit for bit on a CPU (oracle/cald_oracle.c), fp32-grade (~2^-22 of the layer's
+ *          |x|max |w|max per product) but -- like any arithmetic other than the reference's -- not identical to FP32.
+ *          Needs cald_model_calibrate() (or cald_model_set_calibration()) once per model. */
+#define CALD_PRECISION_I8X3 2
 
 #define CALD_ARCH_FRCNN 0      /* detection/frcnn_la.py FRCNN_Feature */
 #define CALD_ARCH_RETINANET 1  /* detection/retinanet_cal.py RetinaNet */
@@ -168,6 +175,11 @@ int cald_op_augment(cald_ctx* ctx, int kind, double param, uint64_t seed, const 
 int cald_op_conv2d(cald_ctx* ctx, const float* in, int H, int W, int Cin, const float* weight, int Cout, int KH, int KW,
                    int stride, int pad, const float* bias, const float* bn_scale, const float* bn_shift,
                    const float* residual, int relu, float* out);
+/* the same convolution in CALD_PRECISION_I8X3 (conv_i3.hip) with input exponent in_exp (|in| < 2^in_exp, larger values
+ * saturate); shapes outside Cin % 32 == 0, Cout >= 64 return CALD_ERR_UNSUPPORTED */
+int cald_op_conv2d_i8x3(cald_ctx* ctx, const float* in, int H, int W, int Cin, const float* weight, int Cout, int KH, int KW,
+                        int stride, int pad, int in_exp, const float* bias, const float* bn_scale, const float* bn_shift,
+                        const float* residual, int relu, float* out);
 /* the same convolution in CALD_PRECISION_F16X3 (conv_h3.hip); falls back to the exact kernels for shapes it does not
  * cover (Cin % 16 != 0 or Cout not tiled by 128), exactly as inside a model */
 int cald_op_conv2d_f16x3(cald_ctx* ctx, const float* in, int H, int W, int Cin, const float* weight, int Cout, int KH, int KW,

@@ -498,6 +498,95 @@ ORC_API void orc_conv2d_nhwc(const float* in, int H, int W, int Cin, const float
     free(zero);
 }
 
+/* -------------------------------------------------------------------------------------
+ * CALD_PRECISION_I8X3 (cald_amd/csrc/conv_i3.hip): the same convolution with exact integer accumulation.
+ *   q_x = clamp(rint(x * 2^(22 - in_exp)), +-0x7F7F7F);  per output channel: e_w = frexp exponent of max |w|,
+ *   q_w = clamp(rint(w * 2^(22 - e_w)), +-0x7F7F7F);  q = d0 + 256 d1 + 65536 d2 with balanced digits in [-128, 127];
+ *   S2 = sum d2.d2, S1 = sum (d2.d1 + d1.d2), S0 = sum (d2.d0 + d0.d2 + d1.d1) (exact integers, any order);
+ *   val = (float)((double)(65536 S2 + 256 S1 + S0) * 2^(in_exp - 22 + 16) * 2^(e_w - 22)): ONE rounding; then the fp32 epilogue.
+ * ------------------------------------------------------------------------------------- */
+static void orc_i8_digits(long long q, int* d) {
+    d[0] = (int)(signed char)(q & 255); long long q1 = (q - d[0]) >> 8;
+    d[1] = (int)(signed char)(q1 & 255); d[2] = (int)((q1 - d[1]) >> 8);
+}
+ORC_API void orc_conv2d_i8x3(const float* in, int H, int W, int Cin, const float* wk, int Cout, int KH, int KW,
+                             int stride, int pad, int in_exp, const float* bias, const float* bn_scale, const float* bn_shift,
+                             const float* residual, const float* up, int upH, int upW, int relu,
+                             float* out, int Ho, int Wo) {
+    const long nin = (long)H * W * Cin; const int K = KH * KW * Cin;
+    signed char* xa = (signed char*)malloc((size_t)nin * 3);
+    signed char* wd = (signed char*)malloc((size_t)K * Cout * 3);
+    int* ew = (int*)malloc(sizeof(int) * Cout);
+    const float xs = ldexpf(1.0f, 22 - in_exp);
+#pragma omp parallel for schedule(static) num_threads(orc_threads)
+    for (long i = 0; i < nin; i++) {
+        float t = in[i] * xs;
+        t = t > 8355711.0f ? 8355711.0f : (t < -8355711.0f ? -8355711.0f : t);
+        int d[3]; orc_i8_digits((long long)rintf(t), d);
+        xa[i] = (signed char)d[0]; xa[nin + i] = (signed char)d[1]; xa[2 * nin + i] = (signed char)d[2];
+    }
+    for (int co = 0; co < Cout; co++) {
+        float mx = 0.0f;
+        for (int k = 0; k < K; k++) { float ax = fabsf(wk[(size_t)k * Cout + co]); if (ax > mx) mx = ax; }
+        int e = 0;
+        if (mx > 0.0f && isfinite(mx)) frexpf(mx, &e);
+        if (e > 60) e = 60; if (e < -60) e = -60;
+        ew[co] = e;
+        for (int k = 0; k < K; k++) {
+            double t = nearbyint((double)ldexpf(wk[(size_t)k * Cout + co], 22 - e));
+            if (t > 8355711.0) t = 8355711.0; if (t < -8355711.0) t = -8355711.0;
+            int d[3]; orc_i8_digits((long long)t, d);
+            for (int pl = 0; pl < 3; pl++) wd[((size_t)pl * K + k) * Cout + co] = (signed char)d[pl];
+        }
+    }
+    const signed char *w0 = wd, *w1 = wd + (size_t)K * Cout, *w2 = wd + 2 * (size_t)K * Cout;
+    const double xun = ldexp(1.0, in_exp - 22 + 16);
+    long npix = (long)Ho * Wo;
+    float uph_scale = up ? (float)upH / (float)Ho : 0.0f, upw_scale = up ? (float)upW / (float)Wo : 0.0f;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(orc_threads)
+    for (long pp = 0; pp < npix; pp++) {
+        int* S = (int*)calloc((size_t)3 * Cout, sizeof(int));
+        int *S0 = S, *S1 = S + Cout, *S2 = S + 2 * Cout;
+        int oy = (int)(pp / Wo), ox = (int)(pp % Wo);
+        for (int kh = 0; kh < KH; kh++)
+            for (int kw = 0; kw < KW; kw++) {
+                int iy = oy * stride - pad + kh, ix = ox * stride - pad + kw;
+                if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+                const size_t xo = ((size_t)iy * W + ix) * Cin;
+                for (int ci = 0; ci < Cin; ci++) {
+                    const int a0 = xa[xo + ci], a1 = xa[nin + xo + ci], a2 = xa[2 * nin + xo + ci];
+                    if (!(a0 | a1 | a2)) continue;
+                    const size_t wo = ((size_t)(kh * KW + kw) * Cin + ci) * Cout;
+                    const signed char *r0 = w0 + wo, *r1 = w1 + wo, *r2 = w2 + wo;
+#pragma omp simd
+                    for (int co = 0; co < Cout; co++) {
+                        S2[co] += a2 * r2[co];
+                        S1[co] += a2 * r1[co] + a1 * r2[co];
+                        S0[co] += a2 * r0[co] + a0 * r2[co] + a1 * r1[co];
+                    }
+                }
+            }
+        const float* upr = NULL;
+        if (up) {
+            int sy = (int)floorf((float)oy * uph_scale); if (sy > upH - 1) sy = upH - 1;
+            int sx = (int)floorf((float)ox * upw_scale); if (sx > upW - 1) sx = upW - 1;
+            upr = up + ((size_t)sy * upW + sx) * Cout;
+        }
+        for (int co = 0; co < Cout; co++) {
+            double T = fma((double)S2[co], 65536.0, fma((double)S1[co], 256.0, (double)S0[co]));
+            float r = (float)(T * (xun * ldexp(1.0, ew[co] - 22)));
+            if (bias) r = r + bias[co];
+            if (bn_scale) { r = r * bn_scale[co]; r = r + bn_shift[co]; }
+            if (residual) r = r + residual[(size_t)pp * Cout + co];
+            if (upr) r = r + upr[co];
+            if (relu) r = r > 0.0f ? r : 0.0f;
+            out[(size_t)pp * Cout + co] = r;
+        }
+        free(S);
+    }
+    free(xa); free(wd); free(ew);
+}
+
 /* Linear: out[m][n] = relu?(chain_k(in[m][k]*w[n][k]) + bias[n]);  wk given K-major [K][N]. */
 ORC_API void orc_linear(const float* in, int M, int K, const float* wk, int N, const float* bias, int relu, float* out) {
     orc_conv2d_nhwc(in, 1, M, K, wk, N, 1, 1, 1, 0, bias, NULL, NULL, NULL, NULL, 0, 0, relu, out, 1, M);

@@ -183,6 +183,49 @@ def test_conv_f16x3_within_split_precision_of_exact(hip, oracle, case):
     assert np.all(err <= bound), "max err %g, max err/bound %g" % (float(err.max()), float((err / bound).max()))
 
 
+I8_CASES = [c for c in CONV_CASES if c[2] % 32 == 0 and c[3] >= 64] + [
+    (30, 44, 64, 64, 3, 1, 1, False, True, False, True),       # layer1 conv2 (one 32-channel chunk pair)
+    (21, 33, 96, 192, 3, 2, 1, True, False, True, False),      # odd sizes, stride 2, bias + residual
+]
+
+
+@pytest.mark.parametrize("case", I8_CASES)
+def test_conv_i8x3_bit_exact(hip, oracle, case):
+    """CALD_PRECISION_I8X3 (conv_i3.hip): fixed-point operands, six int8 digit products, exact int32 accumulation, one rounding
+    -> tobytes()-equal to the C oracle; and fp32-grade: within 2^-20 * sum |a||w| of the exact fp32 chain."""
+    H, W, Cin, Cout, K, stride, pad, bias, bn, res, relu = case
+    ffi, L = hip["ffi"], hip["L"]
+    rs = np.random.RandomState(H * 1000 + Cout + 7)
+    x = rs.randn(H, W, Cin).astype(np.float32) * 3.0
+    x[rs.rand(H, W, Cin) < 0.3] = 0.0
+    x[0, 0, 0] = 1e4                                                            # saturates: |x| >= 2^in_exp clamps, deterministically
+    w = (rs.randn(Cout, Cin, K, K) * np.sqrt(2.0 / (Cin * K * K))).astype(np.float32)
+    w[1] *= 37.0; w[2] = 0.0                                                    # per-channel exponents differ; an all-zero channel
+    b = rs.randn(Cout).astype(np.float32) if bias else None
+    sc = (0.5 + rs.rand(Cout)).astype(np.float32) if bn else None
+    sh = rs.randn(Cout).astype(np.float32) if bn else None
+    Ho, Wo = (H + 2 * pad - K) // stride + 1, (W + 2 * pad - K) // stride + 1
+    r = rs.randn(Ho, Wo, Cout).astype(np.float32) if res else None
+    in_exp = 5                                                                  # |x| < 32 except the planted outlier
+    out = np.empty((Ho, Wo, Cout), np.float32)
+    ffi.check(L.cald_op_conv2d_i8x3(hip["ctx"], ffi.ptr(x), H, W, Cin, ffi.ptr(w), Cout, K, K, stride, pad, in_exp, ffi.ptr(b),
+                                    ffi.ptr(sc), ffi.ptr(sh), ffi.ptr(r), int(relu), ffi.ptr(out)))
+    wk = np.ascontiguousarray(w.transpose(2, 3, 1, 0).reshape(-1, Cout))
+    want = oracle.conv2d_i8x3(x, wk, K, K, stride, pad, in_exp, bias=b, bn=(sc, sh) if bn else None, residual=r, relu=relu)
+    assert out.tobytes() == want.tobytes(), "max abs diff %g" % float(np.abs(out - want).max())
+    sat = np.float32(0x7F7F7F) * np.float32(2.0 ** (in_exp - 22))                 # where the fixed-point grid saturates (63.75 here)
+    xc = np.clip(x, -sat, sat)
+    exact = oracle.conv2d(xc, wk, K, K, stride, pad, bias=b, bn=(sc, sh) if bn else None, residual=r, relu=relu)
+    mag = oracle.conv2d(np.abs(xc), np.abs(wk), K, K, stride, pad)
+    # fixed point relative to the block maxima: |err| <= sum over k of (|a| dw + |w| da) with da = 2^(in_exp - 23), dw = 2^(e_w - 23)
+    wmax = np.abs(wk).max(axis=0)
+    ew = np.where(wmax > 0, np.frexp(np.where(wmax > 0, wmax, 1.0))[1], 0)
+    kk = float(Cin * K * K)
+    bound = (np.abs(sc) if bn else 1.0) * (kk * (64.0 * 2.0 ** (ew - 23.0) + wmax * 2.0 ** (in_exp - 23.0)) + mag * 2.0 ** -21) + 1e-5
+    err = np.abs(out - exact)
+    assert np.all(err <= bound), "max err %g, max err/bound %g" % (float(err.max()), float((err / bound).max()))
+
+
 @pytest.fixture(scope="module")
 def small_model(hip, oracle):
     from cald_amd import synth
