@@ -9,6 +9,7 @@
 #include "kernels.h"
 #include "host_logic.h"
 
+#include <climits>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -345,6 +346,8 @@ struct HostTensor { std::vector<float> data; std::vector<int64_t> shape; };
 struct ConvLayer {
     float *w = nullptr, *w4 = nullptr, *bias = nullptr, *scale = nullptr, *shift = nullptr;
     uint16_t* w16 = nullptr; float w16_unscale = 1.0f;   // CALD_PRECISION_F16X3 only
+    signed char* w8 = nullptr; float* w8_unscale = nullptr;   // CALD_PRECISION_I8X3 only (layers conv_i3.hip covers)
+    int id = -1;           // index into cald_model::layer_names / calib_exp
     int Cin = 0, Cout = 0, CoutPad = 0, K = 0, Kpad = 0, KH = 1, KW = 1, stride = 1, pad = 0;
     int CinTrue = 0;   // un-padded input channels (algorithmic FLOP accounting)
 };
@@ -367,6 +370,10 @@ struct cald_model {
     std::vector<ViewDesc> last_views;
     // batch-level detection buffers used by cald_sweep
     DetBuffers sweep_det; int sweep_det_views = 0;
+    // CALD_PRECISION_I8X3: one input exponent per layer (|input| < 2^exp), INT_MIN = not calibrated
+    std::vector<std::string> layer_names; std::vector<int> calib_exp; std::vector<char> layer_i8;
+    bool calibrating = false; unsigned* d_amax = nullptr;
+    signed char* i8_scratch = nullptr; size_t i8_cap = 0, i8_off = 0;   // digit-plane scratch of the running forward
     int key_cap = 32768;   // FRCNN candidate (proposal, class) list capacity per view, sized from box_score_thresh at create
 };
 
@@ -459,7 +466,7 @@ static std::vector<uint16_t> pack_w16(const std::vector<float>& w, int Kpad, int
 // q = clamp(rint(w * 2^(22 - e_w[n])), +-0x7F7F7F) with e_w[n] = ilogb(max_k |w[k][n]|) + 1, and written as three balanced
 // signed base-256 digits.  Packed [Kpad8/32][3 planes][CoutPad][32 B]; k-tiles in (32-channel chunk, kh, kw) order, byte j of
 // a tile = channel 32 * chunk + j of that tap.  unscale[n] = 2^(e_w[n] - 22).  `w` is the K-major matrix in conv_k_index order.
-static bool i8_covers(int Cin, int CoutPad, int taps) { return Cin % 32 == 0 && CoutPad % 64 == 0 && taps <= 32; }
+static bool i8_covers(int Cin, int Cout, int taps) { return Cin % 32 == 0 && Cout >= 64 && taps <= 32; }
 static void i8_digits(long long q, int* d) {
     d[0] = (int)(signed char)(q & 255); const long long q1 = (q - d[0]) >> 8;
     d[1] = (int)(signed char)(q1 & 255); d[2] = (int)((q1 - d[1]) >> 8);
@@ -537,6 +544,14 @@ static int make_conv(cald_model* m, ConvLayer& L, const std::vector<std::string>
     if (L.CoutPad % 64 == 0 && ((L.Cin % 16 == 0 && kh * kw <= 32) || L.Cin == 4)) {   // conv_p4.hip layout
         std::vector<float> w4 = pack_w4(w, L.Kpad, L.CoutPad);
         if ((rc = upload(m, w4, &L.w4))) return rc;
+    }
+    L.id = (int)m->layer_names.size();
+    m->layer_names.push_back(wkeys[0] == "__fc6_perm" ? std::string("roi_heads.box_head.fc6.weight") : wkeys[0]);
+    m->calib_exp.push_back(INT_MIN); m->layer_i8.push_back(0);
+    if (m->cfg.precision == CALD_PRECISION_I8X3 && i8_covers(L.Cin, L.Cout, kh * kw)) {   // conv_i3.hip digits
+        m->layer_i8[L.id] = 1;
+        std::vector<float> un; std::vector<signed char> w8 = pack_w8(w, L.CoutPad, kh * kw, L.Cin, un);
+        if ((rc = upload(m, w8, &L.w8)) || (rc = upload(m, un, &L.w8_unscale))) return rc;
     }
     if (m->cfg.precision == CALD_PRECISION_F16X3 && L.CoutPad % 64 == 0 && ((L.Cin % 16 == 0 && kh * kw <= 32) || L.Cin == 4)) {   // conv_h3.hip layout
         std::vector<uint16_t> w16 = pack_w16(w, L.Kpad, L.CoutPad, &L.w16_unscale, kh, kw, L.Cin);
@@ -669,6 +684,7 @@ extern "C" int cald_model_finalize(cald_model* m) {
     return 0;
 }
 static void free_det(DetBuffers& d);
+static int alloc_det(DetBuffers& d, int V, int cap, int C);
 extern "C" int cald_model_destroy(cald_model* m) {
     if (!m) return 0;
     hipSetDevice(m->ctx->device);
@@ -713,6 +729,7 @@ struct FwdBufs {
     float *ret_t[2][2][5], *cls_h[5], *reg_h[5], *rcand_box, *kept_box; unsigned long long* rcand_key;   // ret_t[tower][ping-pong][level]
     float* rpn_tl[5];
     int *cand_count, *kept_anchor, *kept_count; int cand_cap; int max_anchors; unsigned char* cand_skip;
+    signed char* i8_planes; size_t i8_cap, i8_off;   // CALD_PRECISION_I8X3: digit planes of the conv input(s) being consumed
 };
 
 static double fill_conv_args(cald_model* m, ConvArgs& a, const ConvLayer& L, const float* in, float* out, int lin, int lout, int V, bool relu,
@@ -727,12 +744,29 @@ static double fill_conv_args(cald_model* m, ConvArgs& a, const ConvLayer& L, con
     a.KH = L.KH; a.KW = L.KW; a.stride = L.stride; a.pad = L.pad; a.relu = relu ? 1 : 0;
     a.total_mtiles = level_tiles(m->plan, lout, V);
     a.out_ld = L.Cout; a.in_relu = in_relu ? 1 : 0; a.zeros = m->ctx->d_zeros; a.exp_flags = 0;
+    a.i8_in = nullptr; a.i8_plane_stride = 0; a.w8 = nullptr; a.w8_unscale = nullptr; a.i8_in_unscale = 0.0f;
+    const long long n_in = level_pix(m->plan, lin, V) * (long long)L.Cin;
+    if (m->calibrating) {
+        if (m->d_amax && L.id >= 0) launch_absmax(in, n_in, m->d_amax + L.id, m->ctx->stream);
+    } else if (m->cfg.precision == CALD_PRECISION_I8X3 && L.w8 && !in_relu && m->i8_scratch) {
+        // this layer runs on the int8 pipe: write the three digit planes of its input, then hand them to conv_i3.hip
+        const int e = m->calib_exp[L.id];
+        const size_t stride = ((size_t)n_in + 15) & ~(size_t)15;
+        if (m->i8_off + 3 * stride <= m->i8_cap) {
+            signed char* pl = m->i8_scratch + m->i8_off;
+            m->i8_off += 3 * stride;
+            launch_quantize_planes(in, n_in, e, pl, (long long)stride, m->ctx->stream);
+            a.i8_in = pl; a.i8_plane_stride = (long long)stride; a.w8 = L.w8; a.w8_unscale = L.w8_unscale;
+            a.i8_in_unscale = std::ldexp(1.0f, e - 22 + 16);
+        }   // (no room: cannot happen with fwd_layout's sizing; the exact kernel would run)
+    }
     return 2.0 * (double)level_pix(m->plan, lout, V) * (double)L.Cout * (double)(L.KH * L.KW * L.CinTrue);
 }
 static int conv_on(cald_model* m, const ConvLayer& L, const float* in, float* out, int lin, int lout, int V, bool relu,
                    const float* residual = nullptr, const float* up = nullptr, int lup = 0, const int* dyn = nullptr,
                    bool in_relu = false) {
     ConvArgs a;
+    m->i8_off = 0;
     const double flops = fill_conv_args(m, a, L, in, out, lin, lout, V, relu, residual, up, lup, dyn, in_relu);
     return run_conv(m->ctx, a, flops);
 }
@@ -741,6 +775,7 @@ struct ConvSpec { const ConvLayer* L; const float* in; float* out; int level; bo
 static int conv_group_on(cald_model* m, const ConvSpec* sp, int n, int V) {
     ConvArgs a[CALD_MAX_GROUP];
     double flops = 0.0; int tiles = 0;
+    m->i8_off = 0;
     for (int i = 0; i < n; i++) { flops += fill_conv_args(m, a[i], *sp[i].L, sp[i].in, sp[i].out, sp[i].level, sp[i].level, V, sp[i].relu); tiles += a[i].total_mtiles; }
     cald_ctx* c = m->ctx;
     if (c->prof) {
@@ -762,6 +797,13 @@ static void fwd_layout(cald_model* m, Bump& B, FwdBufs& F, int V) {
     const BatchPlan& P = m->plan;
     const long long px[8] = {level_pix(P, 0, V), level_pix(P, 1, V), level_pix(P, 2, V), level_pix(P, 3, V),
                              level_pix(P, 4, V), level_pix(P, 5, V), level_pix(P, 6, V), level_pix(P, 7, V)};
+    F.i8_planes = nullptr; F.i8_cap = 0; F.i8_off = 0;
+    if (m->cfg.precision == CALD_PRECISION_I8X3) {     // largest set of tensors one (grouped) launch consumes: the FPN / tower levels, or the RoI rows
+        size_t need = (size_t)px[2] * 256 * 3 / 2;
+        if (m->cfg.arch == CALD_ARCH_FRCNN && (size_t)V * CALD_ROI_CAP * 12544 > need) need = (size_t)V * CALD_ROI_CAP * 12544;
+        F.i8_cap = 3 * (need + 4096);
+        F.i8_planes = B.get<signed char>(F.i8_cap);
+    }
     F.in0 = B.get<float>(px[0] * 4);
     F.c1 = B.get<float>(px[1] * 64);
     F.p1 = B.get<float>(px[2] * 64);
@@ -839,6 +881,11 @@ static int forward_model(cald_model* m, int V, ViewDesc* views, const DetBuffers
     FwdBufs F;
     { Bump dry(nullptr, true); fwd_layout(m, dry, F, V); int rc = arena_reserve(c, dry.off); if (rc) return rc; }
     { Bump real(c->arena, false); fwd_layout(m, real, F, V); }
+    m->i8_scratch = F.i8_planes; m->i8_cap = F.i8_cap; m->i8_off = 0;
+    if (m->cfg.precision == CALD_PRECISION_I8X3 && !m->calibrating)
+        for (size_t i = 0; i < m->calib_exp.size(); i++)
+            if (m->layer_i8[i] && m->calib_exp[i] == INT_MIN)
+                return fail(CALD_ERR_STATE, "CALD_PRECISION_I8X3: layer '%s' has no input exponent -- call cald_model_calibrate() (or cald_model_set_calibration()) first", m->layer_names[i].c_str());
     {
         const int si = c->stage_i; c->stage_i = (si + 1) % cald_ctx::NSTAGE;
         HIPCHK(hipEventSynchronize(c->stage_ev[si]));
@@ -1002,6 +1049,55 @@ extern "C" int cald_forward(cald_model* m, int n_views, const cald_view* views, 
     return forward_model(m, n_views, vd.data(), det);
 }
 
+// ---- CALD_PRECISION_I8X3 calibration: per layer the input exponent e (|input| < 2^e with one bit of headroom) ----
+extern "C" int cald_model_calibrate(cald_model* m, int n_views, const cald_view* views) {
+    if (!m || !views) return fail(CALD_ERR_INVALID, "null argument");
+    if (!m->finalized) return fail(CALD_ERR_STATE, "model not finalized");
+    if (n_views < 1 || n_views > CALD_MAX_VIEWS) return fail(CALD_ERR_INVALID, "n_views must be 1..%d", CALD_MAX_VIEWS);
+    cald_ctx* c = m->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    std::vector<ViewDesc> vd(n_views);
+    for (int i = 0; i < n_views; i++) { int rc = fill_view(vd[i], views[i]); if (rc) return rc; }
+    const size_t nl = m->layer_names.size();
+    ScopedDev sd(c->stream);
+    int rc = sd.alloc(&m->d_amax, nl * 4); if (rc) { m->d_amax = nullptr; return rc; }
+    DetBuffers det; rc = alloc_det(det, n_views, m->det_cap(), m->cfg.num_classes);
+    if (rc) { m->d_amax = nullptr; return rc; }
+    hipMemsetAsync(m->d_amax, 0, nl * 4, c->stream);
+    m->calibrating = true;                       // the exact fp32 kernels run; every conv records max |input|
+    rc = forward_model(m, n_views, vd.data(), det);
+    m->calibrating = false;
+    std::vector<unsigned> amax(nl, 0);
+    if (!rc && (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(amax.data(), m->d_amax, nl * 4, hipMemcpyDeviceToHost) != hipSuccess))
+        rc = fail(CALD_ERR_HIP, "calibration forward failed: %s", hipGetErrorString(hipGetLastError()));
+    free_det(det); m->d_amax = nullptr;
+    if (rc) return rc;
+    for (size_t i = 0; i < nl; i++) {
+        float f; memcpy(&f, &amax[i], 4);
+        int e = 0;
+        if (f > 0.0f && std::isfinite(f)) std::frexp(f, &e);                 // f < 2^e
+        e += 1;                                                               // one bit of headroom over the calibration set
+        if (e > 40) e = 40; if (e < -40) e = -40;
+        if (m->calib_exp[i] == INT_MIN || e > m->calib_exp[i]) m->calib_exp[i] = e;
+    }
+    return 0;
+}
+extern "C" int cald_model_get_calibration(cald_model* m, int index, char* name_out, int name_cap, int* exp_out, int* covered_out) {
+    if (!m) return fail(CALD_ERR_INVALID, "model is null");
+    if (index < 0 || index >= (int)m->layer_names.size()) return fail(CALD_ERR_INVALID, "layer index out of range");
+    if (name_out && name_cap > 0) { strncpy(name_out, m->layer_names[index].c_str(), name_cap - 1); name_out[name_cap - 1] = 0; }
+    if (exp_out) *exp_out = m->calib_exp[index];
+    if (covered_out) *covered_out = m->layer_i8[index];
+    return 0;
+}
+extern "C" int cald_model_set_calibration(cald_model* m, const char* name, int exp) {
+    if (!m || !name) return fail(CALD_ERR_INVALID, "null argument");
+    if (exp < -40 || exp > 40) return fail(CALD_ERR_INVALID, "exponent out of range");
+    for (size_t i = 0; i < m->layer_names.size(); i++)
+        if (m->layer_names[i] == name) { m->calib_exp[i] = exp; return 0; }
+    return fail(CALD_ERR_INVALID, "no layer named '%s'", name);
+}
+
 extern "C" int cald_debug_tensor(cald_model* m, const char* name, int view, float* host_out, int64_t capacity, int64_t* shape3) {
     if (!m || !name || !host_out || !shape3) return fail(CALD_ERR_INVALID, "null argument");
     auto it = m->dbg.find(name);
@@ -1059,7 +1155,7 @@ static int op_conv2d(cald_ctx* c, int precision, const float* in, int H, int W, 
     }
     signed char *d_w8 = nullptr, *d_planes = nullptr; float* d_w8u = nullptr; long long plane_stride = 0;
     if (precision == CALD_PRECISION_I8X3) {
-        if (!i8_covers(Cin, CoutPad, KH * KW)) return fail(CALD_ERR_UNSUPPORTED, "i8x3 covers Cin %% 32 == 0, Cout >= 64, <= 32 taps");
+        if (!i8_covers(Cin, Cout, KH * KW)) return fail(CALD_ERR_UNSUPPORTED, "i8x3 covers Cin %% 32 == 0, Cout >= 64, <= 32 taps");
         std::vector<float> un; std::vector<signed char> w8 = pack_w8(w, CoutPad, KH * KW, Cin, un);
         plane_stride = (((long long)H * W * Cin) + 15) & ~15ll;
         HIPCHK(hipMalloc((void**)&d_w8, w8.size())); HIPCHK(hipMalloc((void**)&d_w8u, un.size() * 4)); HIPCHK(hipMalloc((void**)&d_planes, (size_t)plane_stride * 3));
@@ -1149,7 +1245,7 @@ extern "C" int cald_op_conv_bench(cald_ctx* c, int V, int H, int W, int Cin, int
     const bool i8 = (relu & 2) != 0; relu &= 1;
     signed char *d_w8 = nullptr, *d_planes = nullptr; float* d_w8u = nullptr; long long plane_stride = 0;
     if (i8) {
-        if (!i8_covers(Cin, CoutPad, KH * KW)) return fail(CALD_ERR_UNSUPPORTED, "i8x3 does not cover this shape");
+        if (!i8_covers(Cin, Cout, KH * KW)) return fail(CALD_ERR_UNSUPPORTED, "i8x3 does not cover this shape");
         std::vector<float> un; std::vector<signed char> w8 = pack_w8(w, CoutPad, KH * KW, Cin, un);
         plane_stride = ((long long)n_in + 15) & ~15ll;
         if ((rc = sd.alloc(&d_w8, w8.size())) || (rc = sd.alloc(&d_w8u, un.size() * 4)) || (rc = sd.alloc(&d_planes, (size_t)plane_stride * 3))) return rc;

@@ -58,6 +58,23 @@ void launch_quantize_planes(const float* src, long long n, int exp, signed char*
                        ldexpf(1.0f, 22 - exp), reinterpret_cast<unsigned*>(dst), plane_stride / 4);
 }
 
+// max |x| of a tensor (calibration): bit pattern of a non-negative float orders like the float
+__global__ __launch_bounds__(256) void absmax_kernel(const float4* __restrict__ src, long long n4, unsigned* out) {
+    float m = 0.0f;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const float4 v = src[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o));
+    if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(out, __builtin_bit_cast(unsigned, m));
+}
+void launch_absmax(const float* src, long long n, unsigned* out, hipStream_t st) {
+    const long long n4 = n / 4;
+    if (n4 <= 0) return;
+    long long blocks = (n4 + 255) / 256; if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<const float4*>(src), n4, out);
+}
+
 // ---------------------------------------------------------------------------------------------
 // the GEMM
 // ---------------------------------------------------------------------------------------------

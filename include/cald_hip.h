@@ -84,6 +84,14 @@ int cald_model_load_tensor(cald_model* m, const char* key, const float* data, co
 int cald_model_finalize(cald_model* m);
 int cald_model_destroy(cald_model* m);
 
+/* CALD_PRECISION_I8X3 only: one exact-mode forward over n_views (<= 64) calibration views records max |input| of every conv /
+ * linear layer; the layer's input exponent becomes frexp-exponent + 1 (one bit of headroom; inputs beyond it saturate
+ * deterministically).  Repeated calls keep the maximum.  get: layers are enumerated by index until CALD_ERR_INVALID; exp_out is
+ * INT_MIN while uncalibrated, covered_out says whether the layer runs on the int8 pipe.  set: restores a stored calibration. */
+int cald_model_calibrate(cald_model* m, int n_views, const struct cald_view* views);
+int cald_model_get_calibration(cald_model* m, int index, char* name_out, int name_cap, int* exp_out, int* covered_out);
+int cald_model_set_calibration(cald_model* m, const char* layer_name, int exp);
+
 /* One detector input: task_model([tensor]) in cald_train.py:107 / :186.  The view is described by
  * its uint8 HWC source image in HBM plus the augmentation to apply on the fly. */
 typedef struct cald_view {

@@ -370,7 +370,7 @@ def prepare_frcnn(sd, num_classes, depth=50):
     for li, nb in enumerate(RESNET_LAYERS[depth]):
         for bi in range(nb):
             pre = "backbone.body.layer%d.%d" % (li + 1, bi)
-            blk = {"stride": 2 if (bi == 0 and li > 0) else 1}
+            blk = {"stride": 2 if (bi == 0 and li > 0) else 1, "name": pre}
             for ci in (1, 2, 3):
                 blk["conv%d" % ci] = (_kmajor_conv(sd[pre + ".conv%d.weight" % ci]), _frozen_bn(sd, pre + ".bn%d" % ci))
             if pre + ".downsample.0.weight" in sd:
@@ -395,6 +395,22 @@ def prepare_frcnn(sd, num_classes, depth=50):
     return P
 
 
+def _conv(P, name, x, wk, KH, KW, stride, pad, **kw):
+    """A conv layer in the model's precision: CALD_PRECISION_I8X3 when P["i8"] holds the layer's input exponent and conv_i3.hip
+    covers the shape (Cin % 32 == 0, Cout >= 64, <= 32 taps), else the exact fp32 chain."""
+    q = P.get("i8")
+    if q and name in q and x.shape[2] % 32 == 0 and wk.shape[1] >= 64 and KH * KW <= 32:
+        return conv2d_i8x3(x, wk, KH, KW, stride, pad, q[name], **kw)
+    return conv2d(x, wk, KH, KW, stride, pad, **kw)
+
+
+def _linear(P, name, x, wk, bias=None, relu=False):
+    q = P.get("i8")
+    if q and name in q and x.shape[1] % 32 == 0 and wk.shape[1] >= 64:
+        return conv2d_i8x3(x[None], wk, 1, 1, 1, 0, q[name], bias=bias, relu=relu)[0]
+    return linear(x, wk, bias, relu)
+
+
 def frcnn_backbone(P, x, keep=None):
     """ResNet body + FPN (rows A15, A16).  x: [Hp][Wp][4].  Returns [P2..P5, pool]."""
     wk, bn = P["conv1"]
@@ -405,19 +421,21 @@ def frcnn_backbone(P, x, keep=None):
     feats = []
     for bi, blk in enumerate(P["blocks"]):
         idn = y
+        pre = blk["name"]
         if "down" in blk:
-            idn = conv2d(y, blk["down"][0], 1, 1, blk["stride"], 0, bn=blk["down"][1])
-        o = conv2d(y, blk["conv1"][0], 1, 1, 1, 0, bn=blk["conv1"][1], relu=True)
-        o = conv2d(o, blk["conv2"][0], 3, 3, blk["stride"], 1, bn=blk["conv2"][1], relu=True)
-        y = conv2d(o, blk["conv3"][0], 1, 1, 1, 0, bn=blk["conv3"][1], residual=idn, relu=True)
+            idn = _conv(P, pre + ".downsample.0.weight", y, blk["down"][0], 1, 1, blk["stride"], 0, bn=blk["down"][1])
+        o = _conv(P, pre + ".conv1.weight", y, blk["conv1"][0], 1, 1, 1, 0, bn=blk["conv1"][1], relu=True)
+        o = _conv(P, pre + ".conv2.weight", o, blk["conv2"][0], 3, 3, blk["stride"], 1, bn=blk["conv2"][1], relu=True)
+        y = _conv(P, pre + ".conv3.weight", o, blk["conv3"][0], 1, 1, 1, 0, bn=blk["conv3"][1], residual=idn, relu=True)
         if blk["layer_end"]:
             feats.append(y)
     if keep is not None: keep["C"] = feats
     inner = [None] * 4
-    inner[3] = conv2d(feats[3], P["fpn_inner"][3][0], 1, 1, 1, 0, bias=P["fpn_inner"][3][1])
+    fi, fl = "backbone.fpn.inner_blocks.%d.weight", "backbone.fpn.layer_blocks.%d.weight"
+    inner[3] = _conv(P, fi % 3, feats[3], P["fpn_inner"][3][0], 1, 1, 1, 0, bias=P["fpn_inner"][3][1])
     for i in (2, 1, 0):
-        inner[i] = conv2d(feats[i], P["fpn_inner"][i][0], 1, 1, 1, 0, bias=P["fpn_inner"][i][1], up=inner[i + 1])
-    outs = [conv2d(inner[i], P["fpn_layer"][i][0], 3, 3, 1, 1, bias=P["fpn_layer"][i][1]) for i in range(4)]
+        inner[i] = _conv(P, fi % i, feats[i], P["fpn_inner"][i][0], 1, 1, 1, 0, bias=P["fpn_inner"][i][1], up=inner[i + 1])
+    outs = [_conv(P, fl % i, inner[i], P["fpn_layer"][i][0], 3, 3, 1, 1, bias=P["fpn_layer"][i][1]) for i in range(4)]
     outs.append(subsample2(outs[3]))
     return outs
 
@@ -432,7 +450,7 @@ def frcnn_forward(P, img, min_size, max_size, flip=False, rects=None, keep=None,
     if keep is not None: keep["fpn"] = feats
     heads = []
     for f in feats:
-        t = conv2d(f, P["rpn_conv"][0], 3, 3, 1, 1, bias=P["rpn_conv"][1], relu=True)
+        t = _conv(P, "rpn.head.conv.weight", f, P["rpn_conv"][0], 3, 3, 1, 1, bias=P["rpn_conv"][1], relu=True)
         heads.append(conv2d(t, P["rpn_head"][0], 1, 1, 1, 0, bias=P["rpn_head"][1]))
     if keep is not None: keep["rpn_head"] = heads
     props, pscores = rpn_proposals(heads, P["anchors"], Hp, Wp, Hr, Wr)
@@ -444,9 +462,9 @@ def frcnn_forward(P, img, min_size, max_size, flip=False, rects=None, keep=None,
                     prob_max=z(0, np.float32), scores_cls=z((0, Cn), np.float32))
     roi = roi_align(feats[:4], props)
     if keep is not None: keep["roi"] = roi
-    h = linear(roi.reshape(roi.shape[0], -1), P["fc6"][0], P["fc6"][1], relu=True)
-    h = linear(h, P["fc7"][0], P["fc7"][1], relu=True)
-    pred = linear(h, P["pred"][0], P["pred"][1])
+    h = _linear(P, "roi_heads.box_head.fc6.weight", roi.reshape(roi.shape[0], -1), P["fc6"][0], P["fc6"][1], relu=True)
+    h = _linear(P, "roi_heads.box_head.fc7.weight", h, P["fc7"][0], P["fc7"][1], relu=True)
+    pred = _linear(P, "roi_heads.box_predictor.cls_score.weight", h, P["pred"][0], P["pred"][1])
     if keep is not None: keep["fc7"] = h; keep["pred"] = pred
     return frcnn_postprocess(pred[:, :Cn], pred[:, Cn:], props, Hr, Wr, H, W, score_thr, nms_thr, det_max)
 
@@ -468,7 +486,7 @@ def prepare_retinanet(sd, num_classes, depth=50):
     for li, nb in enumerate(RESNET_LAYERS[depth]):
         for bi in range(nb):
             pre = "backbone.body.layer%d.%d" % (li + 1, bi)
-            blk = {"stride": 2 if (bi == 0 and li > 0) else 1}
+            blk = {"stride": 2 if (bi == 0 and li > 0) else 1, "name": pre}
             for ci in (1, 2, 3):
                 blk["conv%d" % ci] = (_kmajor_conv(sd[pre + ".conv%d.weight" % ci]), _frozen_bn(sd, pre + ".bn%d" % ci))
             if pre + ".downsample.0.weight" in sd:
@@ -494,22 +512,24 @@ def retina_backbone(P, x, keep=None):
     feats = []
     for blk in P["blocks"]:
         idn = y
+        pre = blk["name"]
         if "down" in blk:
-            idn = conv2d(y, blk["down"][0], 1, 1, blk["stride"], 0, bn=blk["down"][1])
-        o = conv2d(y, blk["conv1"][0], 1, 1, 1, 0, bn=blk["conv1"][1], relu=True)
-        o = conv2d(o, blk["conv2"][0], 3, 3, blk["stride"], 1, bn=blk["conv2"][1], relu=True)
-        y = conv2d(o, blk["conv3"][0], 1, 1, 1, 0, bn=blk["conv3"][1], residual=idn, relu=True)
+            idn = _conv(P, pre + ".downsample.0.weight", y, blk["down"][0], 1, 1, blk["stride"], 0, bn=blk["down"][1])
+        o = _conv(P, pre + ".conv1.weight", y, blk["conv1"][0], 1, 1, 1, 0, bn=blk["conv1"][1], relu=True)
+        o = _conv(P, pre + ".conv2.weight", o, blk["conv2"][0], 3, 3, blk["stride"], 1, bn=blk["conv2"][1], relu=True)
+        y = _conv(P, pre + ".conv3.weight", o, blk["conv3"][0], 1, 1, 1, 0, bn=blk["conv3"][1], residual=idn, relu=True)
         if blk["layer_end"]:
             feats.append(y)
     feats = feats[1:]   # returned_layers=[2, 3, 4]
     if keep is not None: keep["C"] = feats
     inner = [None] * 3
-    inner[2] = conv2d(feats[2], P["fpn_inner"][2][0], 1, 1, 1, 0, bias=P["fpn_inner"][2][1])
+    fi, fl = "backbone.fpn.inner_blocks.%d.weight", "backbone.fpn.layer_blocks.%d.weight"
+    inner[2] = _conv(P, fi % 2, feats[2], P["fpn_inner"][2][0], 1, 1, 1, 0, bias=P["fpn_inner"][2][1])
     for i in (1, 0):
-        inner[i] = conv2d(feats[i], P["fpn_inner"][i][0], 1, 1, 1, 0, bias=P["fpn_inner"][i][1], up=inner[i + 1])
-    outs = [conv2d(inner[i], P["fpn_layer"][i][0], 3, 3, 1, 1, bias=P["fpn_layer"][i][1]) for i in range(3)]
-    p6 = conv2d(outs[2], P["p6"][0], 3, 3, 2, 1, bias=P["p6"][1])
-    p7 = conv2d(np.maximum(p6, np.float32(0.0)), P["p7"][0], 3, 3, 2, 1, bias=P["p7"][1])
+        inner[i] = _conv(P, fi % i, feats[i], P["fpn_inner"][i][0], 1, 1, 1, 0, bias=P["fpn_inner"][i][1], up=inner[i + 1])
+    outs = [_conv(P, fl % i, inner[i], P["fpn_layer"][i][0], 3, 3, 1, 1, bias=P["fpn_layer"][i][1]) for i in range(3)]
+    p6 = _conv(P, "backbone.fpn.extra_blocks.p6.weight", outs[2], P["p6"][0], 3, 3, 2, 1, bias=P["p6"][1])
+    p7 = conv2d(np.maximum(p6, np.float32(0.0)), P["p7"][0], 3, 3, 2, 1, bias=P["p7"][1])     # relu-on-load layer: exact kernel in every mode
     return outs + [p6, p7]
 
 
@@ -538,13 +558,13 @@ def retina_forward(P, img, min_size, max_size, flip=False, rects=None, keep=None
     cls, reg = [], []
     for f in feats:
         t = f
-        for (wk, b) in P["classification_head"]:
-            t = conv2d(t, wk, 3, 3, 1, 1, bias=b, relu=True)
-        cls.append(conv2d(t, P["classification_head_out"][0], 3, 3, 1, 1, bias=P["classification_head_out"][1]))
+        for i, (wk, b) in enumerate(P["classification_head"]):
+            t = _conv(P, "head.classification_head.conv.%d.weight" % (2 * i), t, wk, 3, 3, 1, 1, bias=b, relu=True)
+        cls.append(_conv(P, "head.classification_head.cls_logits.weight", t, P["classification_head_out"][0], 3, 3, 1, 1, bias=P["classification_head_out"][1]))
         t = f
-        for (wk, b) in P["regression_head"]:
-            t = conv2d(t, wk, 3, 3, 1, 1, bias=b, relu=True)
-        reg.append(conv2d(t, P["regression_head_out"][0], 3, 3, 1, 1, bias=P["regression_head_out"][1]))
+        for i, (wk, b) in enumerate(P["regression_head"]):
+            t = _conv(P, "head.regression_head.conv.%d.weight" % (2 * i), t, wk, 3, 3, 1, 1, bias=b, relu=True)
+        reg.append(_conv(P, "head.regression_head.bbox_reg.weight", t, P["regression_head_out"][0], 3, 3, 1, 1, bias=P["regression_head_out"][1]))
     if keep is not None: keep["cls"] = cls; keep["reg"] = reg
     return retina_postprocess(cls, reg, P["anchors"], Hp, Wp, Hr, Wr, H, W, P["num_classes"], 9, score_thr, nms_thr, per_class)
 

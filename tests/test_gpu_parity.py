@@ -805,3 +805,74 @@ def test_voc_evaluate_files_equal_oracle_files_and_ap(hip, oracle, small_model, 
     # classes without ground truth have npos == 0 -> AP is nan in the reference too (voc_eval.py:181); look at the annotated ones
     annotated = [a for a in res["ap_per_class"] if a == a]
     assert len(res["ap_per_class"]) == 20 and len(annotated) >= 2 and max(annotated) > 0.5, res["ap_per_class"]
+
+
+def test_i8x3_mode_is_bit_identical_to_its_oracle(hip, oracle):
+    """CALD_PRECISION_I8X3 end to end (BASELINE configs[4]'s matrix-pipe path with a PINNED oracle): calibrate on three images,
+    then every stage of a forward and a whole 3-augmentation sweep equal the C oracle run with the same exponent table, bit
+    for bit -- and stay within the fp32-grade distance of the exact mode."""
+    torch = hip["torch"]
+    from cald_amd import synth, sweep
+    sd = synth.pseudo_trained_frcnn(21, 50, seed=0)
+    model = hip["det"].fasterrcnn_resnet50_fpn_feature(num_classes=21, min_size=300, max_size=500, precision="i8x3").to("cuda")
+    model.load_state_dict(sd)
+    pool = synth.make_pool(4, "voc", 0, scale=0.5)
+    with pytest.raises(RuntimeError):                                   # no exponents yet: refuses to run rather than guess
+        model.forward_views([(torch.from_numpy(pool[0]).cuda(), False, None)])
+    table = model.calibrate(pool[:3])
+    assert len(table) >= 60 and all(-8 <= e <= 20 for e in table.values()), table
+    assert "backbone.body.conv1.weight" not in table and "rpn.head.cls_logits.weight" not in table      # stem / narrow heads stay exact
+    P = oracle.prepare_frcnn(sd, 21, 50)
+    P["i8"] = table
+    keep = {}
+    want = oracle.frcnn_forward(P, pool[1], 300, 500, keep=keep)
+    got = model.forward_views([(torch.from_numpy(pool[1]).cuda(), False, None)])[0]
+    stages = [("C%d" % (i + 2), keep["C"][i]) for i in range(4)] + [("P%d" % (i + 2), keep["fpn"][i]) for i in range(5)]
+    stages += [("rpn%d" % i, keep["rpn_head"][i]) for i in range(5)]
+    for name, w in stages:
+        g = model.debug_tensor(name, 0)
+        assert g.tobytes() == w.tobytes(), "stage %s differs: max abs %g" % (name, float(np.abs(g - w).max()))
+    n = keep["proposals"].shape[0]
+    for name in ("roi", "fc7", "pred"):
+        g = model.debug_tensor(name, 0).reshape(1000, -1)[:n]
+        assert g.tobytes() == keep[name].reshape(n, -1).tobytes(), "stage %s differs" % name
+    assert want["boxes"].shape[0] > 0
+    for k in ("boxes", "scores", "labels", "props", "prob_max", "scores_cls"):
+        assert got[k].cpu().numpy().tobytes() == want[k].tobytes(), "output %s differs" % k
+    augs = ["flip", "cut_out", "smaller_resize"]
+    dev = [torch.from_numpy(im).cuda() for im in pool[:3]]
+    cons, cls = sweep.sweep_device_images(model, dev, [0, 1, 2], augs, bp=1.3, base_seed=3, batch_images=2)
+    wc, wcls = oracle.get_uncertainty(P, pool[:3], augs, 21, bp=1.3, min_size=300, max_size=500, base_seed=3)
+    np.testing.assert_array_equal(cons, np.array(wc))
+    np.testing.assert_array_equal(cls, np.stack(wcls))
+    # distance to the exact fp32 mode: fp32-grade (24-bit fixed point per layer), not bit-identical
+    exact = hip["det"].fasterrcnn_resnet50_fpn_feature(num_classes=21, min_size=300, max_size=500).to("cuda")
+    exact.load_state_dict(sd)
+    ce, _ = sweep.sweep_device_images(exact, dev, [0, 1, 2], augs, bp=1.3, base_seed=3)
+    assert float(np.abs(cons - ce).max()) < 1e-3, (cons, ce)
+    # a restored calibration table gives the same model
+    again = hip["det"].fasterrcnn_resnet50_fpn_feature(num_classes=21, min_size=300, max_size=500, precision="i8x3").to("cuda")
+    again.load_state_dict(sd)
+    again.set_calibration(table)
+    c2, _ = sweep.sweep_device_images(again, dev, [0, 1, 2], augs, bp=1.3, base_seed=3)
+    np.testing.assert_array_equal(cons, c2)
+
+
+def test_i8x3_mode_retinanet_forward_bit_exact(hip, oracle):
+    """The int8 mode on the other detector: FPN + P6 + both towers on the int8 pipe (P7, the 36-channel box head on the exact
+    kernels), per-class post-processing -- bit-identical to the oracle."""
+    torch = hip["torch"]
+    from cald_amd import synth
+    sd = synth.pseudo_trained_retinanet(21, 50, seed=0)
+    model = hip["det"].retinanet_resnet50_fpn_cal(num_classes=21, min_size=300, max_size=500, precision="i8x3").to("cuda")
+    model.load_state_dict(sd)
+    pool = synth.make_pool(3, "voc", 0, scale=0.5)
+    table = model.calibrate(pool)
+    assert "head.classification_head.cls_logits.weight" in table and "head.regression_head.bbox_reg.weight" not in table
+    P = oracle.prepare_retinanet(sd, 21, 50)
+    P["i8"] = table
+    want = oracle.retina_forward(P, pool[2], 300, 500, flip=True)
+    got = model.forward_views([(torch.from_numpy(pool[2]).cuda(), True, None)])[0]
+    assert want["boxes"].shape[0] > 0
+    for k in ("boxes", "scores", "labels", "prob_max", "scores_cls"):
+        assert got[k].cpu().numpy().tobytes() == want[k].tobytes(), "output %s differs" % k
