@@ -33,6 +33,7 @@ if ROOT not in sys.path:
 
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
 F16_MFMA_PEAK_TFLOPS = 2516.6  # v_mfma_f32_32x32x16_f16: 32 cycles / SIMD -> 16 x the f32-input rate (dense)
+I8_MFMA_PEAK_TOPS = 5033.2     # v_mfma_i32_32x32x32_i8: 2 x the f16 rate (dense); one algorithmic MAC costs six digit MACs
 FULL_POOL = 5217               # VOC2012 train 5 717 - 500 initially labeled (cald_train.py:299-300)
 FULL_BUDGET = 500
 
@@ -128,8 +129,8 @@ def main():
                     help="frcnn = the headline workload (BASELINE configs[1]); others are informational runs of configs[2]/[4]")
     ap.add_argument("--shape", default="voc", choices=["voc", "coco"])
     ap.add_argument("--augs", default="FCD", help="letters of cald_train.py --augs (F C D R G S)")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "f16x3"],
-                    help="fp32 = exact (headline, bit-identical to the oracle); f16x3 = informational split-fp16 MFMA path")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "f16x3", "i8x3"],
+                    help="fp32 = exact (headline, bit-identical to the oracle); f16x3 / i8x3 = informational matrix-pipe modes")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -191,6 +192,9 @@ def main():
     model = model.to("cuda:%d" % local_rank)
     model.load_state_dict(sd)
     model.eval()
+    if args.precision == "i8x3":      # static per-layer input exponents from the first images of the pool (not timed: once per model)
+        from PIL import Image
+        model.calibrate([np.asarray(Image.open(io.BytesIO(b)).convert("RGB")) for b in (warm_blobs or blobs)[:32]])
     labeled = synthetic_labeled_set(500, ncls, 0)
     budget = max(1, min(FULL_BUDGET, int(round(FULL_BUDGET * pool_total / float(FULL_POOL)))))
 
@@ -250,12 +254,13 @@ def main():
     if rank == 0:
         traffic, traffic_src = latest_pmc()
         achieved = gf.value / (gm.value * 1e-3) / 1e12 if gm.value > 0 else 0.0
-        peak = F32_MFMA_PEAK_TFLOPS if args.precision == "fp32" else F16_MFMA_PEAK_TFLOPS
+        peak = {"fp32": F32_MFMA_PEAK_TFLOPS, "f16x3": F16_MFMA_PEAK_TFLOPS, "i8x3": I8_MFMA_PEAK_TOPS}[args.precision]
         out = {
             "metric": "unlabeled images scored/sec (CALD consistency sweep)", "value": pool_total / dt, "unit": "images/s",
             "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": dt / max(1, steps_local) * 1e3, "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None,
-            "dtype": "f32" if args.precision == "fp32" else "f16x3 (fp16 hi+lo split operands, fp32 accumulate)",
+            "dtype": {"fp32": "f32", "f16x3": "f16x3 (fp16 hi+lo split operands, fp32 accumulate)",
+                      "i8x3": "i8x3 (24-bit fixed point as three int8 digits, exact int32 accumulation)"}[args.precision],
             "data": "synthetic",
             "config": {"workload": ("BASELINE.json configs[1]: Faster R-CNN ResNet-50 FPN, VOC2012-shaped synthetic pool (baseline JPEG files), "
                                     "3 augs (flip/cut_out/smaller_resize), 21 classes, min/max 600/1000, seeded pseudo-trained weights")
@@ -268,8 +273,10 @@ def main():
             "from_host_jpeg_bytes": {"value": pool_total / (dt + t_decode), "unit": "images/s", "decode_and_h2d_s": t_decode,
                                      "note": "same pool, JPEG decode on the GPU + H2D included (max over ranks); never `value`"},
             "roofline": {"bound": "mfma",
-                         "kernel": ("conv_p4_kernel + conv_mfma_f32_kernel (implicit-GEMM conv + linear, v_mfma_f32_32x32x2_f32)" if args.precision == "fp32"
-                                    else "conv_h3_kernel (3 x v_mfma_f32_32x32x16_f16 per product; algorithmic flops counted once) + exact kernels for uncovered shapes"),
+                         "kernel": {"fp32": "conv_p4_kernel + conv_mfma_f32_kernel (implicit-GEMM conv + linear, v_mfma_f32_32x32x2_f32)",
+                                    "f16x3": "conv_h3_kernel (3 x v_mfma_f32_32x32x16_f16 per product; algorithmic flops counted once) + exact kernels for uncovered shapes",
+                                    "i8x3": "conv_i3_kernel (6 x v_mfma_i32_32x32x32_i8 per product; algorithmic flops counted once; the digit-plane "
+                                            "quantiser passes are outside the GEMM timing) + exact kernels for uncovered shapes"}[args.precision],
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic if args.precision == "fp32" else None,
                          "traffic_source": traffic_src if args.precision == "fp32" else None,
@@ -317,6 +324,22 @@ def main():
                                  "headline": False, "images_compared": nb, "max_abs_consistency_diff_vs_exact": float(d.max()),
                                  "images_beyond_1e-4_vs_exact": int((d > 1e-4).sum()),
                                  "note": "not bit-identical by design: on the full 5 217 pool ~1 % of images move by > 1e-4 (profiles/)"}
+            del fast
+            # the exact-integer int8 mode: reproducible by its oracle (tests), fp32-grade vs the exact mode
+            i8m = (detector.fasterrcnn_resnet50_fpn_feature(num_classes=ncls, min_size=mn, max_size=mx, precision="i8x3")
+                   .to("cuda:%d" % local_rank))
+            i8m.load_state_dict(sd)
+            i8m.eval()
+            i8m.calibrate(imgs[:32])
+            ic, _ = run(i8m)
+            torch.cuda.synchronize(); tf = time.time()
+            run(i8m)
+            torch.cuda.synchronize(); tf = time.time() - tf
+            d = np.abs(ic - ec)
+            out["i8x3_mode"] = {"value": nb / tf, "unit": "images/s", "dtype": "24-bit fixed point as three int8 digits, 6 x v_mfma_i32_32x32x32_i8 per product, exact int32 accumulation",
+                                "headline": False, "images_compared": nb, "max_abs_consistency_diff_vs_exact": float(d.max()),
+                                "images_beyond_1e-4_vs_exact": int((d > 1e-4).sum()),
+                                "note": "bit-identical to its CPU oracle (tests/test_gpu_parity.py); vs the exact fp32 mode it behaves like any other fp32-grade arithmetic"}
         try:
             out["parity_vs_independent_fp32"] = json.load(open(os.path.join(ROOT, "profiles", "parity_vs_independent_fp32_r2.json")))["summary"]
         except Exception:

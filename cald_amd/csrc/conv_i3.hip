@@ -20,6 +20,7 @@
 // chunk re-touch the same bytes in L1 / L2; XCD-contiguous tile map for filters with a spatial extent.
 #include "common.h"
 #include "kernels.h"
+#include <cstdlib>
 
 typedef int i32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -78,14 +79,17 @@ void launch_absmax(const float* src, long long n, unsigned* out, hipStream_t st)
 // ---------------------------------------------------------------------------------------------
 // the GEMM
 // ---------------------------------------------------------------------------------------------
-template <int EPI>
+// WN = 2: 128 x 64 tiles, 256 threads (layers with 64 output channels, and the tail-quantised small launches);
+// WN = 4: 128 x 128 tiles, 512 threads = 8 waves of 64 x 32 -- 1.5 x the digit-MACs per byte moved from L2 into LDS, which is
+//         what bounds this kernel (the 128 x 64 tile sustains ~9 TB/s of L2 -> LDS traffic at 265 TF-eq).
+template <int EPI, int WN>
 __device__ __forceinline__ void conv_i3_body(const ConvArgs& a, const int blk) {
-    constexpr int BM = 128, BN = 64, BK = 32, TM = 2;
+    constexpr int BM = 128, BN = 32 * WN, BK = 32, TM = 2;
     constexpr int PLANE_A = BM * 32, PLANE_B = BN * 32, TILE_B = 3 * PLANE_A + 3 * PLANE_B;       // bytes: 12288 + 6144
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE_B];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int NT = a.CoutPad / BN;
     int mt, nt;
     if (a.KH * a.KW > 1) {
@@ -111,7 +115,8 @@ __device__ __forceinline__ void conv_i3_body(const ConvArgs& a, const int blk) {
     const int Cin = a.Cin, KW = a.KW, KH = a.KH, CoutPad = a.CoutPad;
 
     // ---- A gather: row = tid >> 1, 16-byte half = tid & 1, the three planes ----
-    const int arow = tid >> 1, ahalf = tid & 1;
+    const bool is_a = WN == 2 || tid < 256;          // WN = 4: waves 0-3 stage A, waves 4-7 stage B (three pieces each)
+    const int arow = (tid & 255) >> 1, ahalf = tid & 1;
     unsigned rowmask = 0;
     int rowvoff;
     {
@@ -133,14 +138,15 @@ __device__ __forceinline__ void conv_i3_body(const ConvArgs& a, const int blk) {
     // B: packed [kt][plane][CoutPad][32 B]; piece t: plane t >> 7, column (t & 127) >> 1, half t & 1; threads < 128 also plane 2
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(reinterpret_cast<const unsigned char*>(a.w8) + (long long)n0 * 32), 0, 0x7FFE0000, 0x00020000);
-    const int b_p = tid >> 7, b_nl = (tid & 127) >> 1, b_h = tid & 1;
-    const bool b_two = tid < 128;
+    // WN = 2: piece t: plane t >> 7, column (t & 127) >> 1; threads < 128 also plane 2.  WN = 4: thread 256 + t: column t >> 1, all planes
+    const int b_p = WN == 2 ? (tid >> 7) : 0, b_nl = WN == 2 ? ((tid & 127) >> 1) : ((tid & 255) >> 1), b_h = tid & 1;
+    const bool b_two = WN == 2 && tid < 128;
     const int bvoff0 = b_p * CoutPad * 32 + b_nl * 32 + b_h * 16, bvoff1 = 2 * CoutPad * 32 + b_nl * 32 + b_h * 16;
     const int aw_off = arow * 32 + ((ahalf ^ ((arow >> 3) & 1)) * 16);
     const int bw_off0 = 3 * PLANE_A + b_p * PLANE_B + b_nl * 32 + ((b_h ^ ((b_nl >> 3) & 1)) * 16);
     const int bw_off1 = 3 * PLANE_A + 2 * PLANE_B + b_nl * 32 + ((b_h ^ ((b_nl >> 3) & 1)) * 16);
     int u_kh = 0, u_kw = 0, u_ci = 0, u_kt = 0;
-    i32x4 ra0, ra1, ra2, rb0, rb1 = {0, 0, 0, 0};
+    i32x4 ra0, ra1, ra2, rb0, rb1 = {0, 0, 0, 0};     // WN = 4, B waves: ra0..ra2 carry the three B planes
 
 #define I3_LOAD()                                                                                          \
     {                                                                                                      \
@@ -148,22 +154,38 @@ __device__ __forceinline__ void conv_i3_body(const ConvArgs& a, const int blk) {
         const unsigned u_bit = 1u << (u_kh * KW + u_kw);                                                   \
         const int soffA = (u_kh * Wi + u_kw) * Cin + u_ci;                                                 \
         const int v0 = (rowmask & u_bit) ? rowvoff : 0x7FFF0000;                                           \
-        ra0 = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA0, v0, soffA, 0));        \
-        ra1 = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA1, v0, soffA, 0));        \
-        ra2 = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA2, v0, soffA, 0));        \
-        rb0 = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, bvoff0, soffB, 0));     \
-        if (b_two) rb1 = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, bvoff1, soffB, 0)); \
+        if (is_a) {                                                                                        \
+            ra0 = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA0, v0, soffA, 0));    \
+            ra1 = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA1, v0, soffA, 0));    \
+            ra2 = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA2, v0, soffA, 0));    \
+        }                                                                                                  \
+        if (WN == 2) {                                                                                     \
+            rb0 = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, bvoff0, soffB, 0)); \
+            if (b_two) rb1 = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, bvoff1, soffB, 0)); \
+        } else if (!is_a) {                                                                                \
+            ra0 = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, bvoff0, soffB, 0)); \
+            ra1 = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, bvoff0 + CoutPad * 32, soffB, 0)); \
+            ra2 = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, bvoff0 + 2 * CoutPad * 32, soffB, 0)); \
+        }                                                                                                  \
         u_kt++;                                                                                            \
         u_kw++; if (u_kw == KW) { u_kw = 0; u_kh++; if (u_kh == KH) { u_kh = 0; u_ci += BK; } }            \
     }
 #define I3_STORE(BUF)                                                                                      \
     {                                                                                                      \
         unsigned char* tb = smem + (BUF) * TILE_B;                                                         \
-        *reinterpret_cast<i32x4*>(tb + aw_off) = ra0;                                                      \
-        *reinterpret_cast<i32x4*>(tb + PLANE_A + aw_off) = ra1;                                            \
-        *reinterpret_cast<i32x4*>(tb + 2 * PLANE_A + aw_off) = ra2;                                        \
-        *reinterpret_cast<i32x4*>(tb + bw_off0) = rb0;                                                     \
-        if (b_two) *reinterpret_cast<i32x4*>(tb + bw_off1) = rb1;                                          \
+        if (is_a) {                                                                                        \
+            *reinterpret_cast<i32x4*>(tb + aw_off) = ra0;                                                  \
+            *reinterpret_cast<i32x4*>(tb + PLANE_A + aw_off) = ra1;                                        \
+            *reinterpret_cast<i32x4*>(tb + 2 * PLANE_A + aw_off) = ra2;                                    \
+        }                                                                                                  \
+        if (WN == 2) {                                                                                     \
+            *reinterpret_cast<i32x4*>(tb + bw_off0) = rb0;                                                 \
+            if (b_two) *reinterpret_cast<i32x4*>(tb + bw_off1) = rb1;                                      \
+        } else if (!is_a) {                                                                                \
+            *reinterpret_cast<i32x4*>(tb + bw_off0) = ra0;                                                 \
+            *reinterpret_cast<i32x4*>(tb + bw_off0 + PLANE_B) = ra1;                                       \
+            *reinterpret_cast<i32x4*>(tb + bw_off0 + 2 * PLANE_B) = ra2;                                   \
+        }                                                                                                  \
     }
 
     i32x16 acc0[TM], acc1[TM], acc2[TM];        // digit-product sums of weight 2^16, 2^24, 2^32
@@ -238,12 +260,22 @@ __device__ __forceinline__ void conv_i3_body(const ConvArgs& a, const int blk) {
     const float bs = has_bias ? a.bias[nc] : 0.0f;
     const float sc = has_bn ? a.scale[nc] : 1.0f;
     const float sh = has_bn ? a.shift[nc] : 0.0f;
-    const double unscale = (double)a.i8_in_unscale * (double)a.w8_unscale[nc];      // 2^(e_x - 22) * 2^(e_w[n] - 22) * 2^16... see api.hip
+    const double unscale = (double)a.i8_in_unscale * (double)a.w8_unscale[nc];      // 2^(e_x - 22 + 16) * 2^(e_w[n] - 22)
+    // full tiles: one byte offset per lane, the 16 rows of an accumulator tile through the scalar offset of the buffer instruction
+    const bool full_tile = m0 + BM <= Mv;
+    const int row_b = out_ld * 4;
+    const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc((void*)out_v, 0, 0x7FFE0000, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)(EPI == 1 ? ex_v : out_v), 0, 0x7FFE0000, 0x00020000);
 #pragma unroll
     for (int i = 0; i < TM; i++) {
         const int mbase = m0 + wm * 64 + i * 32 + 4 * kh_lane;
+        const int vo = nok ? (mbase * out_ld + n) * 4 : 0x7FFF0000;
         float extra[16];
-        if (EPI != 0) {
+        if (EPI == 1 && full_tile) {
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                extra[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsX, vo, ((r & 3) + 8 * (r >> 2)) * row_b, 0));
+        } else if (EPI != 0) {
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 int m = mbase + (r & 3) + 8 * (r >> 2);
@@ -258,51 +290,88 @@ __device__ __forceinline__ void conv_i3_body(const ConvArgs& a, const int blk) {
                 }
             }
         }
+        float val[16];
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            const int m = mbase + (r & 3) + 8 * (r >> 2);
             // T / 2^16 = 65536 S2 + 256 S1 + S0: |T / 2^16| < 2^47, exact in double; the factor 2^16 lives in `unscale`
             const double T = fma((double)acc2[i][r], 65536.0, fma((double)acc1[i][r], 256.0, (double)acc0[i][r]));
-            float val = (float)(T * unscale);
-            if (has_bias) val = val + bs;
-            if (has_bn) { val = val * sc; val = val + sh; }
-            if (EPI != 0) val = val + extra[r];
-            if (relu) val = val > 0.0f ? val : 0.0f;
-            if (m < Mv && nok) out_v[(long long)m * out_ld + n] = val;
+            val[r] = (float)(T * unscale);
+        }
+        if (has_bias) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) val[r] = val[r] + bs;
+        }
+        if (has_bn) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) { val[r] = val[r] * sc; val[r] = val[r] + sh; }
+        }
+        if (EPI != 0) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) val[r] = val[r] + extra[r];
+        }
+        if (relu) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) val[r] = val[r] > 0.0f ? val[r] : 0.0f;
+        }
+        if (full_tile) {
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val[r]), rsO, vo, ((r & 3) + 8 * (r >> 2)) * row_b, 0);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int m = mbase + (r & 3) + 8 * (r >> 2);
+                if (m < Mv && nok) out_v[(long long)m * out_ld + n] = val[r];
+            }
         }
     }
 }
 
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void conv_i3_kernel(const ConvArgs a) { conv_i3_body<EPI>(a, blockIdx.x); }
-__global__ __launch_bounds__(256, 2) void conv_i3_group_kernel(const ConvGroup g) {
+template <int EPI, int WN>
+__global__ __launch_bounds__(128 * WN, 2) void conv_i3_kernel(const ConvArgs a) { conv_i3_body<EPI, WN>(a, blockIdx.x); }
+template <int WN>
+__global__ __launch_bounds__(128 * WN, 2) void conv_i3_group_kernel(const ConvGroup g) {
     int i = 0;
     while (i + 1 < g.n && g.blk0[i + 1] <= (int)blockIdx.x) i++;
-    conv_i3_body<0>(g.p[i], (int)blockIdx.x - g.blk0[i]);
+    conv_i3_body<0, WN>(g.p[i], (int)blockIdx.x - g.blk0[i]);
 }
 
 static inline bool i3_covers(const ConvArgs& a) {
     return a.w8 && a.i8_in && a.CoutPad % 64 == 0 && a.Cin % 32 == 0 && a.KH * a.KW <= 32 && !a.in_relu;
 }
 static inline int i3_grid_mtiles(const ConvArgs& a) { return a.KH * a.KW > 1 ? 8 * ((a.total_mtiles + 7) / 8) : a.total_mtiles; }
+// 128 x 128 tiles when the channel count allows it and the launch still fills the chip (one 512-thread workgroup per CU)
+static inline bool i3_wide(const ConvArgs& a) {
+    static const int wide_env = getenv("CALD_I3_WIDE") ? atoi(getenv("CALD_I3_WIDE")) : 1;
+    // short chains (K < 512) are bound by HBM / per-workgroup overheads, where the smaller workgroup does better (measured)
+    return wide_env && a.CoutPad % 128 == 0 && a.Kpad >= 512 && (long long)a.total_mtiles * (a.CoutPad / 128) >= 512;
+}
 
 bool launch_conv_i3_group(const ConvArgs* p, int n, hipStream_t stream) {
     if (n < 1 || n > CALD_MAX_GROUP) return false;
+    bool wide = true;
+    for (int i = 0; i < n; i++) { if (!i3_covers(p[i]) || p[i].residual || p[i].up) return false; wide = wide && p[i].CoutPad % 128 == 0; }
+    static const int wide_env = getenv("CALD_I3_WIDE") ? atoi(getenv("CALD_I3_WIDE")) : 1;
+    wide = wide && wide_env;
     ConvGroup g; g.n = n; int blk = 0;
-    for (int i = 0; i < n; i++) {
-        const ConvArgs& a = p[i];
-        if (!i3_covers(a) || a.residual || a.up) return false;
-        g.blk0[i] = blk; blk += i3_grid_mtiles(a) * (a.CoutPad / 64); g.p[i] = a;
-    }
+    for (int i = 0; i < n; i++) { g.blk0[i] = blk; blk += i3_grid_mtiles(p[i]) * (p[i].CoutPad / (wide ? 128 : 64)); g.p[i] = p[i]; }
     g.blk0[n] = blk;
-    hipLaunchKernelGGL(conv_i3_group_kernel, dim3((unsigned)blk), dim3(256), 0, stream, g);
+    if (wide) hipLaunchKernelGGL((conv_i3_group_kernel<4>), dim3((unsigned)blk), dim3(512), 0, stream, g);
+    else hipLaunchKernelGGL((conv_i3_group_kernel<2>), dim3((unsigned)blk), dim3(256), 0, stream, g);
     return true;
 }
 bool launch_conv_i3(const ConvArgs& a, hipStream_t stream) {
     if (!i3_covers(a)) return false;
+    if (i3_wide(a)) {
+        const dim3 grid((unsigned)(i3_grid_mtiles(a) * (a.CoutPad / 128))), block(512);
+        if (a.residual) hipLaunchKernelGGL((conv_i3_kernel<1, 4>), grid, block, 0, stream, a);
+        else if (a.up) hipLaunchKernelGGL((conv_i3_kernel<2, 4>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((conv_i3_kernel<0, 4>), grid, block, 0, stream, a);
+        return true;
+    }
     const dim3 grid((unsigned)(i3_grid_mtiles(a) * (a.CoutPad / 64))), block(256);
-    if (a.residual) hipLaunchKernelGGL((conv_i3_kernel<1>), grid, block, 0, stream, a);
-    else if (a.up) hipLaunchKernelGGL((conv_i3_kernel<2>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((conv_i3_kernel<0>), grid, block, 0, stream, a);
+    if (a.residual) hipLaunchKernelGGL((conv_i3_kernel<1, 2>), grid, block, 0, stream, a);
+    else if (a.up) hipLaunchKernelGGL((conv_i3_kernel<2, 2>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((conv_i3_kernel<0, 2>), grid, block, 0, stream, a);
     return true;
 }
