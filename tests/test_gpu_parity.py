@@ -359,10 +359,12 @@ def test_sweep_every_augmentation_branch_matches_oracle(hip, oracle, small_model
     np.testing.assert_array_equal(cls, np.stack(wcls))
 
 
-def test_f16x3_mode_meets_the_parity_bar_against_the_exact_mode(hip):
-    """CALD_PRECISION_F16X3 (BASELINE configs[4]'s "fp16 MFMA path", conv_h3.hip) is not bit-identical by design; the bar
-    it has to meet is north_star's: consistency within 1e-4 and identical selection order.  The exact mode is
-    bit-identical to the oracle (tests above), so it stands in for the oracle here: 96 full-size VOC-shaped images."""
+def test_f16x3_mode_close_to_exact_on_96_images(hip):
+    """CALD_PRECISION_F16X3 (conv_h3.hip) is not bit-identical by design.  What this checks, on 96 full-size VOC-shaped images
+    against the exact mode (which is bit-identical to the oracle): consistency within 1e-4 and the same order ON THIS SAMPLE.
+    It does NOT establish north_star's identical-top-k bar: on the full 5 217-image pool ~1 % of the images move by more than
+    1e-4 and 496 of the 500 selected images match (profiles/f16x3_vs_exact_r1.json, profiles/parity_vs_independent_fp32_r2.json);
+    only the exact mode meets that bar, which is why it is the default and the headline."""
     torch = hip["torch"]
     from cald_amd import synth, sweep
     sd = synth.pseudo_trained_frcnn(21, 50, seed=0)
