@@ -1,6 +1,6 @@
 // conv_i3.hip -- CALD_PRECISION_I8X3: implicit-GEMM conv / linear on the int8 matrix pipe with EXACT integer accumulation.
 //
-// The arithmetic (restated bit for bit by oracle/cald_oracle.c orc_conv2d_i8x3):
+// The arithmetic (restated bit for bit by the CPU oracle, orc_conv2d_i8x3 under oracle/):
 //   * the layer's input tensor is quantised to 24-bit fixed point with ONE static power-of-two exponent e_x per layer
 //     (calibrated once per model, cald_model_calibrate): q_x = clamp(rint(x * 2^(22 - e_x)), +-0x7F7F7F);
 //     weights per output channel n: q_w = clamp(rint(w * 2^(22 - e_w[n])), +-0x7F7F7F), fixed at model finalize;

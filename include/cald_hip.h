@@ -43,7 +43,7 @@ typedef struct cald_model cald_model;
 /*   I8X3   exact-integer int8 mode (conv_i3.hip): activations (one calibrated power-of-two exponent per layer input) and
  *          weights (one exponent per output channel) quantised to 24-bit fixed point, three balanced base-256 digits each,
  *          six digit products on v_mfma_i32_32x32x32_i8 with exact int32 accumulation, one rounding to float32, then the exact
- *          mode's fp32 epilogue.  Reproducible bit for bit on a CPU (oracle/cald_oracle.c), fp32-grade (~2^-22 of the layer's
+ *          mode's fp32 epilogue.  Reproducible bit for bit on a CPU (the C oracle under oracle/), fp32-grade (~2^-22 of the layer's
  *          |x|max |w|max per product) but -- like any arithmetic other than the reference's -- not identical to FP32.
  *          Needs cald_model_calibrate() (or cald_model_set_calibration()) once per model. */
 #define CALD_PRECISION_I8X3 2
