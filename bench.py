@@ -194,7 +194,7 @@ def main():
     model.eval()
     if args.precision == "i8x3":      # static per-layer input exponents from the first images of the pool (not timed: once per model)
         from PIL import Image
-        model.calibrate([np.asarray(Image.open(io.BytesIO(b)).convert("RGB")) for b in (warm_blobs or blobs)[:32]])
+        model.calibrate([np.asarray(Image.open(io.BytesIO(b)).convert("RGB")) for b in (warm_blobs or blobs)[:32]], augs=augs)
     labeled = synthetic_labeled_set(500, ncls, 0)
     budget = max(1, min(FULL_BUDGET, int(round(FULL_BUDGET * pool_total / float(FULL_POOL)))))
 
@@ -325,12 +325,12 @@ def main():
                                  "images_beyond_1e-4_vs_exact": int((d > 1e-4).sum()),
                                  "note": "not bit-identical by design: on the full 5 217 pool ~1 % of images move by > 1e-4 (profiles/)"}
             del fast
-            # the exact-integer int8 mode: reproducible by its oracle (tests), fp32-grade vs the exact mode
+            # the exact-integer int8 mode: reproducible by its oracle (tests); fixed point per layer, coarser than fp32
             i8m = (detector.fasterrcnn_resnet50_fpn_feature(num_classes=ncls, min_size=mn, max_size=mx, precision="i8x3")
                    .to("cuda:%d" % local_rank))
             i8m.load_state_dict(sd)
             i8m.eval()
-            i8m.calibrate(imgs[:32])
+            i8m.calibrate(imgs[:32], augs=augs)
             ic, _ = run(i8m)
             torch.cuda.synchronize(); tf = time.time()
             run(i8m)
@@ -339,7 +339,7 @@ def main():
             out["i8x3_mode"] = {"value": nb / tf, "unit": "images/s", "dtype": "24-bit fixed point as three int8 digits, 6 x v_mfma_i32_32x32x32_i8 per product, exact int32 accumulation",
                                 "headline": False, "images_compared": nb, "max_abs_consistency_diff_vs_exact": float(d.max()),
                                 "images_beyond_1e-4_vs_exact": int((d > 1e-4).sum()),
-                                "note": "bit-identical to its CPU oracle (tests/test_gpu_parity.py); vs the exact fp32 mode it behaves like any other fp32-grade arithmetic"}
+                                "note": "bit-identical to its CPU oracle (tests/test_gpu_parity.py); fixed point per layer: coarser than fp32 / f16x3 (profiles/parity_vs_independent_fp32_r2.json)"}
         try:
             out["parity_vs_independent_fp32"] = json.load(open(os.path.join(ROOT, "profiles", "parity_vs_independent_fp32_r2.json")))["summary"]
         except Exception:

@@ -64,6 +64,8 @@ SIGNATURES = {
     "cald_model_finalize": (C.c_int, [C.c_void_p]),
     "cald_model_destroy": (C.c_int, [C.c_void_p]),
     "cald_model_calibrate": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(View)]),
+    "cald_model_calibrate_begin": (C.c_int, [C.c_void_p]),
+    "cald_model_calibrate_end": (C.c_int, [C.c_void_p]),
     "cald_model_get_calibration": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int, c_i, c_i]),
     "cald_model_set_calibration": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "cald_forward": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(View), C.POINTER(Dets)]),

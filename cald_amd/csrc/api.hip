@@ -1050,37 +1050,49 @@ extern "C" int cald_forward(cald_model* m, int n_views, const cald_view* views, 
 }
 
 // ---- CALD_PRECISION_I8X3 calibration: per layer the input exponent e (|input| < 2^e with one bit of headroom) ----
-extern "C" int cald_model_calibrate(cald_model* m, int n_views, const cald_view* views) {
-    if (!m || !views) return fail(CALD_ERR_INVALID, "null argument");
+// begin / end bracket ANY number of forwards or sweeps (they run the exact fp32 kernels meanwhile); end folds the recorded maxima
+extern "C" int cald_model_calibrate_begin(cald_model* m) {
+    if (!m) return fail(CALD_ERR_INVALID, "model is null");
     if (!m->finalized) return fail(CALD_ERR_STATE, "model not finalized");
-    if (n_views < 1 || n_views > CALD_MAX_VIEWS) return fail(CALD_ERR_INVALID, "n_views must be 1..%d", CALD_MAX_VIEWS);
-    cald_ctx* c = m->ctx;
-    HIPCHK(hipSetDevice(c->device));
-    std::vector<ViewDesc> vd(n_views);
-    for (int i = 0; i < n_views; i++) { int rc = fill_view(vd[i], views[i]); if (rc) return rc; }
+    if (m->calibrating) return fail(CALD_ERR_STATE, "calibration already running");
+    HIPCHK(hipSetDevice(m->ctx->device));
     const size_t nl = m->layer_names.size();
-    ScopedDev sd(c->stream);
-    int rc = sd.alloc(&m->d_amax, nl * 4); if (rc) { m->d_amax = nullptr; return rc; }
-    DetBuffers det; rc = alloc_det(det, n_views, m->det_cap(), m->cfg.num_classes);
-    if (rc) { m->d_amax = nullptr; return rc; }
-    hipMemsetAsync(m->d_amax, 0, nl * 4, c->stream);
-    m->calibrating = true;                       // the exact fp32 kernels run; every conv records max |input|
-    rc = forward_model(m, n_views, vd.data(), det);
+    HIPCHK(hipMalloc((void**)&m->d_amax, nl * 4));
+    HIPCHK(hipMemsetAsync(m->d_amax, 0, nl * 4, m->ctx->stream));
+    m->calibrating = true;
+    return 0;
+}
+extern "C" int cald_model_calibrate_end(cald_model* m) {
+    if (!m) return fail(CALD_ERR_INVALID, "model is null");
+    if (!m->calibrating) return fail(CALD_ERR_STATE, "no calibration running");
     m->calibrating = false;
+    const size_t nl = m->layer_names.size();
     std::vector<unsigned> amax(nl, 0);
-    if (!rc && (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(amax.data(), m->d_amax, nl * 4, hipMemcpyDeviceToHost) != hipSuccess))
-        rc = fail(CALD_ERR_HIP, "calibration forward failed: %s", hipGetErrorString(hipGetLastError()));
-    free_det(det); m->d_amax = nullptr;
-    if (rc) return rc;
+    hipError_t e = hipStreamSynchronize(m->ctx->stream);
+    if (e == hipSuccess) e = hipMemcpy(amax.data(), m->d_amax, nl * 4, hipMemcpyDeviceToHost);
+    hipFree(m->d_amax); m->d_amax = nullptr;
+    if (e != hipSuccess) return fail(CALD_ERR_HIP, "calibration read-back failed: %s", hipGetErrorString(e));
     for (size_t i = 0; i < nl; i++) {
+        if (amax[i] == 0) continue;                                           // layer not reached by the calibration forwards
         float f; memcpy(&f, &amax[i], 4);
-        int e = 0;
-        if (f > 0.0f && std::isfinite(f)) std::frexp(f, &e);                 // f < 2^e
-        e += 1;                                                               // one bit of headroom over the calibration set
-        if (e > 40) e = 40; if (e < -40) e = -40;
-        if (m->calib_exp[i] == INT_MIN || e > m->calib_exp[i]) m->calib_exp[i] = e;
+        int ex = 0;
+        if (f > 0.0f && std::isfinite(f)) std::frexp(f, &ex);                // f < 2^ex
+        ex += 1;                                                              // one bit of headroom over the calibration set
+        if (ex > 40) ex = 40; if (ex < -40) ex = -40;
+        if (m->calib_exp[i] == INT_MIN || ex > m->calib_exp[i]) m->calib_exp[i] = ex;
     }
     return 0;
+}
+extern "C" int cald_model_calibrate(cald_model* m, int n_views, const cald_view* views) {
+    if (!m || !views) return fail(CALD_ERR_INVALID, "null argument");
+    if (n_views < 1 || n_views > CALD_MAX_VIEWS) return fail(CALD_ERR_INVALID, "n_views must be 1..%d", CALD_MAX_VIEWS);
+    std::vector<ViewDesc> vd(n_views);
+    for (int i = 0; i < n_views; i++) { int rc = fill_view(vd[i], views[i]); if (rc) return rc; }
+    int rc = cald_model_calibrate_begin(m); if (rc) return rc;
+    DetBuffers det; rc = alloc_det(det, n_views, m->det_cap(), m->cfg.num_classes);
+    if (!rc) { rc = forward_model(m, n_views, vd.data(), det); hipStreamSynchronize(m->ctx->stream); free_det(det); }
+    const int rc2 = cald_model_calibrate_end(m);
+    return rc ? rc : rc2;
 }
 extern "C" int cald_model_get_calibration(cald_model* m, int index, char* name_out, int name_cap, int* exp_out, int* covered_out) {
     if (!m) return fail(CALD_ERR_INVALID, "model is null");

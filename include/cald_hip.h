@@ -43,8 +43,9 @@ typedef struct cald_model cald_model;
 /*   I8X3   exact-integer int8 mode (conv_i3.hip): activations (one calibrated power-of-two exponent per layer input) and
  *          weights (one exponent per output channel) quantised to 24-bit fixed point, three balanced base-256 digits each,
  *          six digit products on v_mfma_i32_32x32x32_i8 with exact int32 accumulation, one rounding to float32, then the exact
- *          mode's fp32 epilogue.  Reproducible bit for bit on a CPU (the C oracle under oracle/), fp32-grade (~2^-22 of the layer's
- *          |x|max |w|max per product) but -- like any arithmetic other than the reference's -- not identical to FP32.
+ *          mode's fp32 epilogue.  Reproducible bit for bit on a CPU (the C oracle under oracle/).  Accuracy: fixed point per LAYER --
+ *          ~2^-22 of the layer's |x|max |w|max per product, i.e. ~14 significant bits on typical activations: coarser than FP32 /
+ *          F16X3 (median |d consistency| 2.6e-5 vs 1e-6 on the configs[1] pool; more on deep nets).
  *          Needs cald_model_calibrate() (or cald_model_set_calibration()) once per model. */
 #define CALD_PRECISION_I8X3 2
 
@@ -89,6 +90,10 @@ int cald_model_destroy(cald_model* m);
  * deterministically).  Repeated calls keep the maximum.  get: layers are enumerated by index until CALD_ERR_INVALID; exp_out is
  * INT_MIN while uncalibrated, covered_out says whether the layer runs on the int8 pipe.  set: restores a stored calibration. */
 int cald_model_calibrate(cald_model* m, int n_views, const struct cald_view* views);
+/* the same around ANY forwards / sweeps issued in between (e.g. one cald_sweep with the augmentations that will be used: noisy
+ * or rotated views reach larger activations than clean images); those calls run the exact fp32 kernels */
+int cald_model_calibrate_begin(cald_model* m);
+int cald_model_calibrate_end(cald_model* m);
 int cald_model_get_calibration(cald_model* m, int index, char* name_out, int name_cap, int* exp_out, int* covered_out);
 int cald_model_set_calibration(cald_model* m, const char* layer_name, int exp);
 

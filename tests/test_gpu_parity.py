@@ -192,7 +192,8 @@ I8_CASES = [c for c in CONV_CASES if c[2] % 32 == 0 and c[3] >= 64] + [
 @pytest.mark.parametrize("case", I8_CASES)
 def test_conv_i8x3_bit_exact(hip, oracle, case):
     """CALD_PRECISION_I8X3 (conv_i3.hip): fixed-point operands, six int8 digit products, exact int32 accumulation, one rounding
-    -> tobytes()-equal to the C oracle; and fp32-grade: within 2^-20 * sum |a||w| of the exact fp32 chain."""
+    -> tobytes()-equal to the C oracle; and within the fixed-point error bound (2^-23 of the layer / channel maxima per operand)
+    of the exact fp32 chain."""
     H, W, Cin, Cout, K, stride, pad, bias, bn, res, relu = case
     ffi, L = hip["ffi"], hip["L"]
     rs = np.random.RandomState(H * 1000 + Cout + 7)
@@ -812,7 +813,7 @@ def test_voc_evaluate_files_equal_oracle_files_and_ap(hip, oracle, small_model, 
 def test_i8x3_mode_is_bit_identical_to_its_oracle(hip, oracle):
     """CALD_PRECISION_I8X3 end to end (BASELINE configs[4]'s matrix-pipe path with a PINNED oracle): calibrate on three images,
     then every stage of a forward and a whole 3-augmentation sweep equal the C oracle run with the same exponent table, bit
-    for bit -- and stay within the fp32-grade distance of the exact mode."""
+    for bit -- and stay close to the exact mode (fixed point per layer: ~1e-5-grade, not fp32-grade)."""
     torch = hip["torch"]
     from cald_amd import synth, sweep
     sd = synth.pseudo_trained_frcnn(21, 50, seed=0)
@@ -878,3 +879,48 @@ def test_i8x3_mode_retinanet_forward_bit_exact(hip, oracle):
     assert want["boxes"].shape[0] > 0
     for k in ("boxes", "scores", "labels", "prob_max", "scores_cls"):
         assert got[k].cpu().numpy().tobytes() == want[k].tobytes(), "output %s differs" % k
+
+
+def test_config4_full_size_i8x3_matrix_pipe_mode(hip, oracle):
+    """BASELINE.json configs[4] as written -- Faster R-CNN ResNet-101 FPN, COCO shapes (800/1333, 91 classes), 5 augmentations,
+    matrix-pipe arithmetic -- at FULL size in the mode an oracle can pin: one image (6 views) re-scored by the CPU oracle in
+    CALD_PRECISION_I8X3 with the same calibration table, bit for bit; batch / shard invariance over 8 images; and the distance
+    to the exact fp32 mode on those images."""
+    import os
+    torch = hip["torch"]
+    from cald_amd import synth, sweep
+    sd = synth.pseudo_trained_frcnn(91, 101, seed=1)
+    model = hip["det"].fasterrcnn_resnet101_fpn_feature(num_classes=91, min_size=800, max_size=1333, precision="i8x3").to("cuda")
+    model.load_state_dict(sd)
+    pool = synth.make_pool(8, "coco", 0)
+    augs = ["flip", "ga", "cut_out", "smaller_resize", "rotation"]
+    table = model.calibrate(pool[:4], augs=augs)          # the noisy / rotated views are part of the calibration set
+    dev = [torch.from_numpy(im).cuda() for im in pool]
+    pos = list(range(8))
+    c1, k1 = sweep.sweep_device_images(model, dev, pos, augs, base_seed=4, batch_images=64)
+    c2, k2 = sweep.sweep_device_images(model, dev, pos, augs, base_seed=4, batch_images=3)
+    np.testing.assert_array_equal(c1, c2); np.testing.assert_array_equal(k1, k2)
+    cw = np.zeros(8); kw = np.zeros((8, 90))
+    for r in range(2):
+        idx = sweep.shard_positions(8, r, 2)
+        cr, kr = sweep.sweep_device_images(model, [dev[i] for i in idx], idx, augs, base_seed=4)
+        cw[idx] = cr; kw[idx] = kr
+    np.testing.assert_array_equal(c1, cw); np.testing.assert_array_equal(k1, kw)
+    P = oracle.prepare_frcnn(sd, 91, 101)
+    P["i8"] = table
+    oracle.set_threads(min(128, os.cpu_count() or 1))
+    try:
+        wc, wk = oracle.get_uncertainty(P, [pool[5]], augs, 91, bp=1.3, min_size=800, max_size=1333, base_seed=4, positions=[5])
+    finally:
+        oracle.set_threads(min(32, os.cpu_count() or 1))
+    assert c1[5] == wc[0], (c1[5], wc[0])
+    np.testing.assert_array_equal(k1[5], wk[0])
+    exact = hip["det"].fasterrcnn_resnet101_fpn_feature(num_classes=91, min_size=800, max_size=1333).to("cuda")
+    exact.load_state_dict(sd)
+    ce, _ = sweep.sweep_device_images(exact, dev, pos, augs, base_seed=4)
+    d = np.abs(c1 - ce)
+    print("i8x3 vs exact fp32, configs[4] shapes, 8 images: max |d consistency| %.3g, median %.3g" % (d.max(), np.median(d)))
+    # 24-bit fixed point per LAYER (not per element): typical activations sit ~2^-8 below the layer maximum, i.e. keep ~14
+    # significant bits -- coarser than fp32 / f16x3, the price of exact integer accumulation.  Over ~100 layers and 6 views with
+    # 91 classes, borderline detections flip often: |d consistency| is 1e-3 ... 3e-2 here (measured), bounded loosely below.
+    assert float(np.median(d)) < 5e-2 and float(d.max()) < 0.5, d
