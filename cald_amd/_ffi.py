@@ -63,11 +63,6 @@ SIGNATURES = {
     "cald_model_load_tensor": (C.c_int, [C.c_void_p, C.c_char_p, c_f, c_i64, C.c_int]),
     "cald_model_finalize": (C.c_int, [C.c_void_p]),
     "cald_model_destroy": (C.c_int, [C.c_void_p]),
-    "cald_model_calibrate": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(View)]),
-    "cald_model_calibrate_begin": (C.c_int, [C.c_void_p]),
-    "cald_model_calibrate_end": (C.c_int, [C.c_void_p]),
-    "cald_model_get_calibration": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int, c_i, c_i]),
-    "cald_model_set_calibration": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "cald_forward": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(View), C.POINTER(Dets)]),
     "cald_sweep": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), c_i, c_i, c_i64, C.POINTER(SweepCfg), c_d, c_d]),
     "cald_sweep_ltc": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), c_i, c_i, C.c_int, c_d]),
@@ -81,7 +76,7 @@ SIGNATURES = {
     "cald_op_conv2d": (C.c_int, [C.c_void_p, c_f, C.c_int, C.c_int, C.c_int, c_f, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_int, c_f, c_f, c_f, c_f, C.c_int, c_f]),
     "cald_op_conv2d_i8x3": (C.c_int, [C.c_void_p, c_f, C.c_int, C.c_int, C.c_int, c_f, C.c_int, C.c_int, C.c_int, C.c_int,
-                                      C.c_int, C.c_int, c_f, c_f, c_f, c_f, C.c_int, c_f]),
+                                      C.c_int, c_f, c_f, c_f, c_f, C.c_int, c_f]),
     "cald_op_conv2d_f16x3": (C.c_int, [C.c_void_p, c_f, C.c_int, C.c_int, C.c_int, c_f, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_int, c_f, c_f, c_f, c_f, C.c_int, c_f]),
     "cald_op_conv_bench": (C.c_int, [C.c_void_p] + [C.c_int] * 12 + [c_d, c_d]),

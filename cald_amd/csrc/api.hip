@@ -347,7 +347,6 @@ struct ConvLayer {
     float *w = nullptr, *w4 = nullptr, *bias = nullptr, *scale = nullptr, *shift = nullptr;
     uint16_t* w16 = nullptr; float w16_unscale = 1.0f;   // CALD_PRECISION_F16X3 only
     signed char* w8 = nullptr; float* w8_unscale = nullptr;   // CALD_PRECISION_I8X3 only (layers conv_i3.hip covers)
-    int id = -1;           // index into cald_model::layer_names / calib_exp
     int Cin = 0, Cout = 0, CoutPad = 0, K = 0, Kpad = 0, KH = 1, KW = 1, stride = 1, pad = 0;
     int CinTrue = 0;   // un-padded input channels (algorithmic FLOP accounting)
 };
@@ -370,9 +369,6 @@ struct cald_model {
     std::vector<ViewDesc> last_views;
     // batch-level detection buffers used by cald_sweep
     DetBuffers sweep_det; int sweep_det_views = 0;
-    // CALD_PRECISION_I8X3: one input exponent per layer (|input| < 2^exp), INT_MIN = not calibrated
-    std::vector<std::string> layer_names; std::vector<int> calib_exp; std::vector<char> layer_i8;
-    bool calibrating = false; unsigned* d_amax = nullptr;
     signed char* i8_scratch = nullptr; size_t i8_cap = 0, i8_off = 0;   // digit-plane scratch of the running forward
     int key_cap = 32768;   // FRCNN candidate (proposal, class) list capacity per view, sized from box_score_thresh at create
 };
@@ -462,11 +458,11 @@ static std::vector<uint16_t> pack_w16(const std::vector<float>& w, int Kpad, int
     return o;
 }
 
-// CALD_PRECISION_I8X3 (conv_i3.hip): per output channel n the weights are quantised to 24-bit fixed point,
-// q = clamp(rint(w * 2^(22 - e_w[n])), +-0x7F7F7F) with e_w[n] = ilogb(max_k |w[k][n]|) + 1, and written as three balanced
-// signed base-256 digits.  Packed [Kpad8/32][3 planes][CoutPad][32 B]; k-tiles in (32-channel chunk, kh, kw) order, byte j of
-// a tile = channel 32 * chunk + j of that tap.  unscale[n] = 2^(e_w[n] - 22).  `w` is the K-major matrix in conv_k_index order.
-static bool i8_covers(int Cin, int Cout, int taps) { return Cin % 32 == 0 && Cout >= 64 && taps <= 32; }
+// CALD_PRECISION_I8X3 (conv_i3.hip): per output channel n the weights are quantised to fixed point,
+// q = rint(w * 2^(22 - e_w[n])) with max_k |w[k][n]| = f * 2^e_w[n], f in [0.5, 1) (|q| <= 2^22), and written as three balanced signed
+// base-256 digits.  Packed [K/32][3 planes][CoutPad][32 B]; k-tiles in (kh, kw, 32-channel chunk) order, byte j of a tile = channel
+// 32 * chunk + j of that tap.  unscale[n] = 2^(e_w[n] - 22 + 16).  `w` is the K-major matrix in conv_k_index order.
+static bool i8_covers(int Cin, int Cout, int taps) { return Cin % 32 == 0 && Cin >= 64 && Cout >= 64 && taps <= 32; }
 static void i8_digits(long long q, int* d) {
     d[0] = (int)(signed char)(q & 255); const long long q1 = (q - d[0]) >> 8;
     d[1] = (int)(signed char)(q1 & 255); d[2] = (int)((q1 - d[1]) >> 8);
@@ -482,16 +478,15 @@ static std::vector<signed char> pack_w8(const std::vector<float>& w, int CoutPad
         int e = 0;
         if (mx > 0.0f && std::isfinite(mx)) { std::frexp(mx, &e); }          // mx = f * 2^e, f in [0.5, 1): |w| < 2^e
         if (e > 60) e = 60; if (e < -60) e = -60;
-        ew[n] = e; unscale[n] = std::ldexp(1.0f, e - 22);
+        ew[n] = e; unscale[n] = std::ldexp(1.0f, e - 22 + 16);
     }
-    for (int cc = 0; cc < CC; cc++)
-        for (int tap = 0; tap < taps; tap++) {
-            const int kt = cc * taps + tap;
+    for (int tap = 0; tap < taps; tap++)
+        for (int cc = 0; cc < CC; cc++) {
+            const int kt = tap * CC + cc;
             for (int j = 0; j < 32; j++) {
                 const int k = conv_k_index(tap, cc * 32 + j, taps, Cin);
                 for (int n = 0; n < CoutPad; n++) {
-                    double t = std::nearbyint((double)std::ldexp(w[(size_t)k * CoutPad + n], 22 - ew[n]));
-                    if (t > 8355711.0) t = 8355711.0; if (t < -8355711.0) t = -8355711.0;
+                    const double t = std::nearbyint((double)std::ldexp(w[(size_t)k * CoutPad + n], 22 - ew[n]));
                     int d[3]; i8_digits((long long)t, d);
                     for (int pl = 0; pl < 3; pl++) o[(((size_t)kt * 3 + pl) * CoutPad + n) * 32 + j] = (signed char)d[pl];
                 }
@@ -545,11 +540,7 @@ static int make_conv(cald_model* m, ConvLayer& L, const std::vector<std::string>
         std::vector<float> w4 = pack_w4(w, L.Kpad, L.CoutPad);
         if ((rc = upload(m, w4, &L.w4))) return rc;
     }
-    L.id = (int)m->layer_names.size();
-    m->layer_names.push_back(wkeys[0] == "__fc6_perm" ? std::string("roi_heads.box_head.fc6.weight") : wkeys[0]);
-    m->calib_exp.push_back(INT_MIN); m->layer_i8.push_back(0);
     if (m->cfg.precision == CALD_PRECISION_I8X3 && i8_covers(L.Cin, L.Cout, kh * kw)) {   // conv_i3.hip digits
-        m->layer_i8[L.id] = 1;
         std::vector<float> un; std::vector<signed char> w8 = pack_w8(w, L.CoutPad, kh * kw, L.Cin, un);
         if ((rc = upload(m, w8, &L.w8)) || (rc = upload(m, un, &L.w8_unscale))) return rc;
     }
@@ -744,20 +735,17 @@ static double fill_conv_args(cald_model* m, ConvArgs& a, const ConvLayer& L, con
     a.KH = L.KH; a.KW = L.KW; a.stride = L.stride; a.pad = L.pad; a.relu = relu ? 1 : 0;
     a.total_mtiles = level_tiles(m->plan, lout, V);
     a.out_ld = L.Cout; a.in_relu = in_relu ? 1 : 0; a.zeros = m->ctx->d_zeros; a.exp_flags = 0;
-    a.i8_in = nullptr; a.i8_plane_stride = 0; a.w8 = nullptr; a.w8_unscale = nullptr; a.i8_in_unscale = 0.0f;
-    const long long n_in = level_pix(m->plan, lin, V) * (long long)L.Cin;
-    if (m->calibrating) {
-        if (m->d_amax && L.id >= 0) launch_absmax(in, n_in, m->d_amax + L.id, m->ctx->stream);
-    } else if (m->cfg.precision == CALD_PRECISION_I8X3 && L.w8 && !in_relu && m->i8_scratch) {
-        // this layer runs on the int8 pipe: write the three digit planes of its input, then hand them to conv_i3.hip
-        const int e = m->calib_exp[L.id];
-        const size_t stride = ((size_t)n_in + 15) & ~(size_t)15;
-        if (m->i8_off + 3 * stride <= m->i8_cap) {
+    a.i8_in = nullptr; a.i8_plane_stride = 0; a.w8 = nullptr; a.w8_unscale = nullptr; a.i8_rowscale = nullptr;
+    if (m->cfg.precision == CALD_PRECISION_I8X3 && L.w8 && !in_relu && m->i8_scratch) {
+        // this layer runs on the int8 pipe: write the three digit planes + per-pixel scales of its input, then hand them to conv_i3.hip
+        const long long P = level_pix(m->plan, lin, V);
+        const size_t stride = ((size_t)P * L.Cin + 15) & ~(size_t)15, rs_bytes = ((size_t)P * 4 + 255) & ~(size_t)255;
+        if (m->i8_off + 3 * stride + rs_bytes <= m->i8_cap) {
             signed char* pl = m->i8_scratch + m->i8_off;
-            m->i8_off += 3 * stride;
-            launch_quantize_planes(in, n_in, e, pl, (long long)stride, m->ctx->stream);
-            a.i8_in = pl; a.i8_plane_stride = (long long)stride; a.w8 = L.w8; a.w8_unscale = L.w8_unscale;
-            a.i8_in_unscale = std::ldexp(1.0f, e - 22 + 16);
+            float* rs = reinterpret_cast<float*>(pl + 3 * stride);
+            m->i8_off += 3 * stride + rs_bytes;
+            launch_quantize_pixels(in, P, L.Cin, pl, (long long)stride, rs, m->ctx->stream);
+            a.i8_in = pl; a.i8_plane_stride = (long long)stride; a.w8 = L.w8; a.w8_unscale = L.w8_unscale; a.i8_rowscale = rs;
         }   // (no room: cannot happen with fwd_layout's sizing; the exact kernel would run)
     }
     return 2.0 * (double)level_pix(m->plan, lout, V) * (double)L.Cout * (double)(L.KH * L.KW * L.CinTrue);
@@ -801,7 +789,7 @@ static void fwd_layout(cald_model* m, Bump& B, FwdBufs& F, int V) {
     if (m->cfg.precision == CALD_PRECISION_I8X3) {     // largest set of tensors one (grouped) launch consumes: the FPN / tower levels, or the RoI rows
         size_t need = (size_t)px[2] * 256 * 3 / 2;
         if (m->cfg.arch == CALD_ARCH_FRCNN && (size_t)V * CALD_ROI_CAP * 12544 > need) need = (size_t)V * CALD_ROI_CAP * 12544;
-        F.i8_cap = 3 * (need + 4096);
+        F.i8_cap = 3 * (need + 4096) + (size_t)px[2] * 4 * 2 + (size_t)V * CALD_ROI_CAP * 4 + (1 << 16);
         F.i8_planes = B.get<signed char>(F.i8_cap);
     }
     F.in0 = B.get<float>(px[0] * 4);
@@ -882,10 +870,6 @@ static int forward_model(cald_model* m, int V, ViewDesc* views, const DetBuffers
     { Bump dry(nullptr, true); fwd_layout(m, dry, F, V); int rc = arena_reserve(c, dry.off); if (rc) return rc; }
     { Bump real(c->arena, false); fwd_layout(m, real, F, V); }
     m->i8_scratch = F.i8_planes; m->i8_cap = F.i8_cap; m->i8_off = 0;
-    if (m->cfg.precision == CALD_PRECISION_I8X3 && !m->calibrating)
-        for (size_t i = 0; i < m->calib_exp.size(); i++)
-            if (m->layer_i8[i] && m->calib_exp[i] == INT_MIN)
-                return fail(CALD_ERR_STATE, "CALD_PRECISION_I8X3: layer '%s' has no input exponent -- call cald_model_calibrate() (or cald_model_set_calibration()) first", m->layer_names[i].c_str());
     {
         const int si = c->stage_i; c->stage_i = (si + 1) % cald_ctx::NSTAGE;
         HIPCHK(hipEventSynchronize(c->stage_ev[si]));
@@ -1049,67 +1033,6 @@ extern "C" int cald_forward(cald_model* m, int n_views, const cald_view* views, 
     return forward_model(m, n_views, vd.data(), det);
 }
 
-// ---- CALD_PRECISION_I8X3 calibration: per layer the input exponent e (|input| < 2^e with one bit of headroom) ----
-// begin / end bracket ANY number of forwards or sweeps (they run the exact fp32 kernels meanwhile); end folds the recorded maxima
-extern "C" int cald_model_calibrate_begin(cald_model* m) {
-    if (!m) return fail(CALD_ERR_INVALID, "model is null");
-    if (!m->finalized) return fail(CALD_ERR_STATE, "model not finalized");
-    if (m->calibrating) return fail(CALD_ERR_STATE, "calibration already running");
-    HIPCHK(hipSetDevice(m->ctx->device));
-    const size_t nl = m->layer_names.size();
-    HIPCHK(hipMalloc((void**)&m->d_amax, nl * 4));
-    HIPCHK(hipMemsetAsync(m->d_amax, 0, nl * 4, m->ctx->stream));
-    m->calibrating = true;
-    return 0;
-}
-extern "C" int cald_model_calibrate_end(cald_model* m) {
-    if (!m) return fail(CALD_ERR_INVALID, "model is null");
-    if (!m->calibrating) return fail(CALD_ERR_STATE, "no calibration running");
-    m->calibrating = false;
-    const size_t nl = m->layer_names.size();
-    std::vector<unsigned> amax(nl, 0);
-    hipError_t e = hipStreamSynchronize(m->ctx->stream);
-    if (e == hipSuccess) e = hipMemcpy(amax.data(), m->d_amax, nl * 4, hipMemcpyDeviceToHost);
-    hipFree(m->d_amax); m->d_amax = nullptr;
-    if (e != hipSuccess) return fail(CALD_ERR_HIP, "calibration read-back failed: %s", hipGetErrorString(e));
-    for (size_t i = 0; i < nl; i++) {
-        if (amax[i] == 0) continue;                                           // layer not reached by the calibration forwards
-        float f; memcpy(&f, &amax[i], 4);
-        int ex = 0;
-        if (f > 0.0f && std::isfinite(f)) std::frexp(f, &ex);                // f < 2^ex
-        ex += 1;                                                              // one bit of headroom over the calibration set
-        if (ex > 40) ex = 40; if (ex < -40) ex = -40;
-        if (m->calib_exp[i] == INT_MIN || ex > m->calib_exp[i]) m->calib_exp[i] = ex;
-    }
-    return 0;
-}
-extern "C" int cald_model_calibrate(cald_model* m, int n_views, const cald_view* views) {
-    if (!m || !views) return fail(CALD_ERR_INVALID, "null argument");
-    if (n_views < 1 || n_views > CALD_MAX_VIEWS) return fail(CALD_ERR_INVALID, "n_views must be 1..%d", CALD_MAX_VIEWS);
-    std::vector<ViewDesc> vd(n_views);
-    for (int i = 0; i < n_views; i++) { int rc = fill_view(vd[i], views[i]); if (rc) return rc; }
-    int rc = cald_model_calibrate_begin(m); if (rc) return rc;
-    DetBuffers det; rc = alloc_det(det, n_views, m->det_cap(), m->cfg.num_classes);
-    if (!rc) { rc = forward_model(m, n_views, vd.data(), det); hipStreamSynchronize(m->ctx->stream); free_det(det); }
-    const int rc2 = cald_model_calibrate_end(m);
-    return rc ? rc : rc2;
-}
-extern "C" int cald_model_get_calibration(cald_model* m, int index, char* name_out, int name_cap, int* exp_out, int* covered_out) {
-    if (!m) return fail(CALD_ERR_INVALID, "model is null");
-    if (index < 0 || index >= (int)m->layer_names.size()) return fail(CALD_ERR_INVALID, "layer index out of range");
-    if (name_out && name_cap > 0) { strncpy(name_out, m->layer_names[index].c_str(), name_cap - 1); name_out[name_cap - 1] = 0; }
-    if (exp_out) *exp_out = m->calib_exp[index];
-    if (covered_out) *covered_out = m->layer_i8[index];
-    return 0;
-}
-extern "C" int cald_model_set_calibration(cald_model* m, const char* name, int exp) {
-    if (!m || !name) return fail(CALD_ERR_INVALID, "null argument");
-    if (exp < -40 || exp > 40) return fail(CALD_ERR_INVALID, "exponent out of range");
-    for (size_t i = 0; i < m->layer_names.size(); i++)
-        if (m->layer_names[i] == name) { m->calib_exp[i] = exp; return 0; }
-    return fail(CALD_ERR_INVALID, "no layer named '%s'", name);
-}
-
 extern "C" int cald_debug_tensor(cald_model* m, const char* name, int view, float* host_out, int64_t capacity, int64_t* shape3) {
     if (!m || !name || !host_out || !shape3) return fail(CALD_ERR_INVALID, "null argument");
     auto it = m->dbg.find(name);
@@ -1130,7 +1053,7 @@ extern "C" int cald_debug_tensor(cald_model* m, const char* name, int view, floa
 // =============================================================================================
 static int op_conv2d(cald_ctx* c, int precision, const float* in, int H, int W, int Cin, const float* weight, int Cout, int KH, int KW,
                      int stride, int pad, const float* bias, const float* bn_scale, const float* bn_shift,
-                     const float* residual, int relu, float* out, int in_exp = 0) {
+                     const float* residual, int relu, float* out) {
     if (!c || !in || !weight || !out) return fail(CALD_ERR_INVALID, "null argument");
     if (Cin % 4) return fail(CALD_ERR_INVALID, "Cin must be a multiple of 4");
     HIPCHK(hipSetDevice(c->device));
@@ -1165,14 +1088,15 @@ static int op_conv2d(cald_ctx* c, int precision, const float* in, int H, int W, 
         HIPCHK(hipMalloc((void**)&d_w16, w16.size() * 2));
         HIPCHK(hipMemcpy(d_w16, w16.data(), w16.size() * 2, hipMemcpyHostToDevice));
     }
-    signed char *d_w8 = nullptr, *d_planes = nullptr; float* d_w8u = nullptr; long long plane_stride = 0;
+    signed char *d_w8 = nullptr, *d_planes = nullptr; float *d_w8u = nullptr, *d_rs = nullptr; long long plane_stride = 0;
     if (precision == CALD_PRECISION_I8X3) {
-        if (!i8_covers(Cin, Cout, KH * KW)) return fail(CALD_ERR_UNSUPPORTED, "i8x3 covers Cin %% 32 == 0, Cout >= 64, <= 32 taps");
+        if (!i8_covers(Cin, Cout, KH * KW)) return fail(CALD_ERR_UNSUPPORTED, "i8x3 covers Cin %% 32 == 0 (>= 64), Cout >= 64, <= 32 taps");
         std::vector<float> un; std::vector<signed char> w8 = pack_w8(w, CoutPad, KH * KW, Cin, un);
         plane_stride = (((long long)H * W * Cin) + 15) & ~15ll;
         HIPCHK(hipMalloc((void**)&d_w8, w8.size())); HIPCHK(hipMalloc((void**)&d_w8u, un.size() * 4)); HIPCHK(hipMalloc((void**)&d_planes, (size_t)plane_stride * 3));
+        HIPCHK(hipMalloc((void**)&d_rs, (size_t)H * W * 4));
         HIPCHK(hipMemcpy(d_w8, w8.data(), w8.size(), hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(d_w8u, un.data(), un.size() * 4, hipMemcpyHostToDevice));
-        launch_quantize_planes(d_in, (long long)H * W * Cin, in_exp, d_planes, plane_stride, c->stream);
+        launch_quantize_pixels(d_in, (long long)H * W, Cin, d_planes, plane_stride, d_rs, c->stream);
     }
     HIPCHK(hipMemcpy(d_b, b.data(), b.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_sc, sc.data(), sc.size() * 4, hipMemcpyHostToDevice));
@@ -1184,12 +1108,12 @@ static int op_conv2d(cald_ctx* c, int precision, const float* in, int H, int W, 
     a.residual = d_res; a.up = nullptr; a.seg_in = d_p->seg[0]; a.seg_out = d_p->seg[1]; a.seg_up = d_p->seg[1]; a.dyn_rows = nullptr;
     a.V = 1; a.Cin = Cin; a.Cout = Cout; a.CoutPad = CoutPad; a.Kpad = Kpad; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
     a.relu = relu; a.total_mtiles = (Ho * Wo + 127) / 128; a.out_ld = Cout; a.in_relu = 0; a.zeros = c->d_zeros;
-    a.i8_in = d_planes; a.i8_plane_stride = plane_stride; a.w8 = d_w8; a.w8_unscale = d_w8u; a.i8_in_unscale = std::ldexp(1.0f, in_exp - 22 + 16);
+    a.i8_in = d_planes; a.i8_plane_stride = plane_stride; a.w8 = d_w8; a.w8_unscale = d_w8u; a.i8_rowscale = d_rs;
     launch_conv(a, c->stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemcpy(out, d_out, (size_t)Ho * Wo * Cout * 4, hipMemcpyDeviceToHost));
-    if (d_w8) { hipFree(d_w8); hipFree(d_w8u); hipFree(d_planes); }
+    if (d_w8) { hipFree(d_w8); hipFree(d_w8u); hipFree(d_planes); hipFree(d_rs); }
     if (d_w4) hipFree(d_w4);
     if (d_w16) hipFree(d_w16);
     hipFree(d_in); hipFree(d_out); hipFree(d_w); hipFree(d_b); hipFree(d_sc); hipFree(d_sh); hipFree(d_p); if (d_res) hipFree(d_res);
@@ -1201,9 +1125,9 @@ extern "C" int cald_op_conv2d(cald_ctx* c, const float* in, int H, int W, int Ci
     return op_conv2d(c, CALD_PRECISION_FP32, in, H, W, Cin, weight, Cout, KH, KW, stride, pad, bias, bn_scale, bn_shift, residual, relu, out);
 }
 extern "C" int cald_op_conv2d_i8x3(cald_ctx* c, const float* in, int H, int W, int Cin, const float* weight, int Cout, int KH, int KW,
-                                   int stride, int pad, int in_exp, const float* bias, const float* bn_scale, const float* bn_shift,
+                                   int stride, int pad, const float* bias, const float* bn_scale, const float* bn_shift,
                                    const float* residual, int relu, float* out) {
-    return op_conv2d(c, CALD_PRECISION_I8X3, in, H, W, Cin, weight, Cout, KH, KW, stride, pad, bias, bn_scale, bn_shift, residual, relu, out, in_exp);
+    return op_conv2d(c, CALD_PRECISION_I8X3, in, H, W, Cin, weight, Cout, KH, KW, stride, pad, bias, bn_scale, bn_shift, residual, relu, out);
 }
 extern "C" int cald_op_conv2d_f16x3(cald_ctx* c, const float* in, int H, int W, int Cin, const float* weight, int Cout, int KH, int KW,
                                     int stride, int pad, const float* bias, const float* bn_scale, const float* bn_shift,
@@ -1255,19 +1179,20 @@ extern "C" int cald_op_conv_bench(cald_ctx* c, int V, int H, int W, int Cin, int
     HIPCHK(hipMemcpy(d_sh, sh.data(), sh.size() * 4, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(d_p, &P, sizeof(P), hipMemcpyHostToDevice));
     // relu bit 1 (value 2 / 3): run the layer in CALD_PRECISION_I8X3 (digit planes prepared outside the timed region)
     const bool i8 = (relu & 2) != 0; relu &= 1;
-    signed char *d_w8 = nullptr, *d_planes = nullptr; float* d_w8u = nullptr; long long plane_stride = 0;
+    signed char *d_w8 = nullptr, *d_planes = nullptr; float *d_w8u = nullptr, *d_rs = nullptr; long long plane_stride = 0;
     if (i8) {
         if (!i8_covers(Cin, Cout, KH * KW)) return fail(CALD_ERR_UNSUPPORTED, "i8x3 does not cover this shape");
         std::vector<float> un; std::vector<signed char> w8 = pack_w8(w, CoutPad, KH * KW, Cin, un);
         plane_stride = ((long long)n_in + 15) & ~15ll;
-        if ((rc = sd.alloc(&d_w8, w8.size())) || (rc = sd.alloc(&d_w8u, un.size() * 4)) || (rc = sd.alloc(&d_planes, (size_t)plane_stride * 3))) return rc;
+        if ((rc = sd.alloc(&d_w8, w8.size())) || (rc = sd.alloc(&d_w8u, un.size() * 4)) || (rc = sd.alloc(&d_planes, (size_t)plane_stride * 3)) ||
+            (rc = sd.alloc(&d_rs, (size_t)V * H * W * 4))) return rc;
         HIPCHK(hipMemcpy(d_w8, w8.data(), w8.size(), hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(d_w8u, un.data(), un.size() * 4, hipMemcpyHostToDevice));
-        launch_quantize_planes(d_in, (long long)n_in, 1, d_planes, plane_stride, c->stream);
+        launch_quantize_pixels(d_in, (long long)V * H * W, Cin, d_planes, plane_stride, d_rs, c->stream);
     }
     ConvArgs a[CALD_MAX_GROUP];
     for (int gi = 0; gi < group; gi++) {
         memset(&a[gi], 0, sizeof(ConvArgs));
-        a[gi].i8_in = d_planes; a[gi].i8_plane_stride = plane_stride; a[gi].w8 = d_w8; a[gi].w8_unscale = d_w8u; a[gi].i8_in_unscale = std::ldexp(1.0f, 1 - 22 + 16);
+        a[gi].i8_in = d_planes; a[gi].i8_plane_stride = plane_stride; a[gi].w8 = d_w8; a[gi].w8_unscale = d_w8u; a[gi].i8_rowscale = d_rs;
         a[gi].in = d_in; a[gi].out = d_out + (size_t)gi * n_out; a[gi].w = d_w; a[gi].w4 = d_w4; a[gi].bias = d_b; a[gi].scale = d_sc; a[gi].shift = d_sh; a[gi].residual = d_res;
         a[gi].seg_in = d_p->seg[0]; a[gi].seg_out = d_p->seg[1]; a[gi].seg_up = d_p->seg[1]; a[gi].V = V; a[gi].Cin = Cin; a[gi].Cout = Cout; a[gi].CoutPad = CoutPad; a[gi].Kpad = Kpad;
         a[gi].KH = KH; a[gi].KW = KW; a[gi].stride = stride; a[gi].pad = pad; a[gi].relu = relu; a[gi].total_mtiles = V * ((Ho * Wo + 127) / 128); a[gi].out_ld = Cout; a[gi].zeros = c->d_zeros;

@@ -52,9 +52,9 @@ struct ConvArgs {
     // CALD_PRECISION_I8X3 (conv_i3.hip); all null / 0 otherwise
     const signed char* i8_in;   // three int8 digit planes of the (whole ragged-batch) input tensor [pixel][Cin]; plane p at + p * i8_plane_stride
     long long i8_plane_stride;
-    const void* w8;             // weight digits packed [Kpad/32][3][CoutPad][32 B], k-tiles in (32-channel chunk, kh, kw) order
-    const float* w8_unscale;    // [CoutPad] 2^(e_w[n] - 22)
-    float i8_in_unscale;        // 2^(e_x - 22 + 16)
+    const float* i8_rowscale;   // per input pixel 2^(e_p - 22) (e_p = exponent of the pixel's largest |channel|)
+    const void* w8;             // weight digits packed [Kpad/32][3][CoutPad][32 B], k-tiles in (kh, kw, 32-channel chunk) order
+    const float* w8_unscale;    // [CoutPad] 2^(e_w[n] - 22 + 16)
 };
 
 // Several independent conv problems in ONE launch (the five FPN levels under the shared-weight RPN / RetinaNet heads, the

@@ -1,92 +1,106 @@
-// conv_i3.hip -- CALD_PRECISION_I8X3: implicit-GEMM conv / linear on the int8 matrix pipe with EXACT integer accumulation.
+// conv_i3.hip -- CALD_PRECISION_I8X3: implicit-GEMM conv / linear on the int8 matrix pipe with EXACT integer accumulation and
+// block-floating-point operands (one exponent per pixel / per output channel).
 //
 // The arithmetic (restated bit for bit by the CPU oracle, orc_conv2d_i8x3 under oracle/):
-//   * the layer's input tensor is quantised to 24-bit fixed point with ONE static power-of-two exponent e_x per layer
-//     (calibrated once per model, cald_model_calibrate): q_x = clamp(rint(x * 2^(22 - e_x)), +-0x7F7F7F);
-//     weights per output channel n: q_w = clamp(rint(w * 2^(22 - e_w[n])), +-0x7F7F7F), fixed at model finalize;
-//   * both are written as three balanced signed base-256 digits (d0 + 256 d1 + 65536 d2, each in [-128, 127]); the six digit
-//     products of weight >= 2^16 -- d2.d2 | d2.d1 + d1.d2 | d2.d0 + d0.d2 + d1.d1 -- are accumulated in int32 by
-//     v_mfma_i32_32x32x32_i8 (integer sums are exact and order-free, so no summation order is part of the contract); the
-//     three dropped products are < 2^-23 of |x|max |w|max per term;
-//   * T = 2^32 S2 + 2^24 S1 + 2^16 S0 is formed exactly in double, scaled by the exact power of two 2^(e_x + e_w[n] - 44) and
-//     rounded ONCE to float32; then the exact mode's fp32 epilogue: (+bias) -> (*bn_scale, +bn_shift) -> (+residual |
-//     +upsampled) -> ReLU.
-// That makes the mode reproducible on a CPU (tests compare tobytes()-equal), which the split-fp16 mode (conv_h3.hip) is not.
+//   * activations: every PIXEL p of the layer's input (its Cin channels) gets the exponent e_p of its largest magnitude
+//     (max |x| = f * 2^e_p, f in [0.5, 1); all-zero pixel: 0) and is quantised to 23-bit fixed point,
+//     q = rint(x * 2^(22 - e_p));  weights: per output channel n, q = rint(w * 2^(22 - e_w[n])), fixed at model finalize;
+//   * both are written as three balanced signed base-256 digits (d0 + 256 d1 + 65536 d2, each in [-128, 127]);
+//   * per filter TAP the six digit products of weight >= 2^16 -- d2.d2 | d2.d1 + d1.d2 | d2.d0 + d0.d2 + d1.d1 -- are summed
+//     over the tap's Cin channels in int32 by v_mfma_i32_32x32x32_i8: integer sums are exact and order-free, so no summation
+//     order is part of the contract (the three dropped products are < 2^-23 of the pixel's / channel's maxima per term);
+//   * the tap's sums are folded into one float32 accumulator per output, taps in (kh, kw) order:
+//         T = fmaf((float)S2, 65536, fmaf((float)S1, 256, (float)S0));   acc = fmaf(T, 2^(e_p - 22), acc)      (p = the tap's pixel)
+//     and the result is acc * 2^(e_w[n] - 22 + 16) (exact power of two), followed by the exact mode's fp32 epilogue
+//     (+bias) -> (*bn_scale, +bn_shift) -> (+residual | +upsampled) -> ReLU.
+// Every step is either exact integer arithmetic or a float32 operation in a fixed order, so a CPU reproduces it bit for bit
+// (tests compare tobytes()-equal) -- which the split-fp16 mode (conv_h3.hip) cannot offer -- and the per-pixel exponent keeps
+// ~19-20 significant bits on typical activations (a per-LAYER exponent, tried first, kept ~14: 14 % of the images moved by
+// more than 1e-4).  No calibration, no saturation: the exponents come from the data.
 //
-// Data path: the quantised digits of the input come as three int8 planes [pixel][Cin] written by quantize_planes_kernel
-// (one streaming pass over the fp32 tensor), so the GEMM loop is copy + MFMA only: 16-byte buffer loads (hardware zero
-// fill for out-of-image taps) -> ds_write_b128 -> ds_read_b128 -> MFMA.  128 x 64 x 32 tiles, 4 waves (64 x 32 each, 96
-// accumulator registers), two LDS buffers, one barrier per k-tile; k-tiles walk (32-channel chunk, kh, kw) so the taps of a
-// chunk re-touch the same bytes in L1 / L2; XCD-contiguous tile map for filters with a spatial extent.
+// Data path: quantize_pixels_kernel writes the three int8 digit planes [pixel][Cin] and the per-pixel scale 2^(e_p - 22) in one
+// streaming pass over the fp32 tensor; the GEMM loop is copy + MFMA: 16-byte buffer loads (hardware zero fill for
+// out-of-image taps) -> ds_write_b128 -> ds_read_b128 -> MFMA.  k-tiles walk (kh, kw, 32-channel chunk); after the last chunk
+// of a tap the int32 sums are folded with the tap's per-row scales (staged in LDS) and the next tap starts from zero.
+// Tiles: 128 x 128 x 32 with 512 threads (8 waves of 64 x 32) for K >= 512, 128 x 64 / 256 threads otherwise; two LDS buffers,
+// one barrier per k-tile; XCD-contiguous tile map for filters with a spatial extent.
 #include "common.h"
 #include "kernels.h"
 #include <cstdlib>
 
 typedef int i32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
-
-#define I3_QMAX 0x7F7F7F     /* 127 * (1 + 256 + 65536): the largest magnitude three balanced digits can hold */
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ---------------------------------------------------------------------------------------------
-// fp32 tensor -> three digit planes.  n4 = elements / 4; plane p at dst + p * plane_stride.
+// fp32 tensor [P][C] -> three digit planes [P][C] (plane p at dst + p * plane_stride) + per-pixel scale 2^(e_p - 22).
+// G lanes per pixel (G = 16 / 32 / 64 by C), 256 / G pixels per workgroup pass.
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned i3_pack_digit(int a, int b, int c, int d) {
+    return (unsigned)(a & 255) | ((unsigned)(b & 255) << 8) | ((unsigned)(c & 255) << 16) | ((unsigned)(d & 255) << 24);
+}
 __device__ __forceinline__ void i3_digits(float x, float scale, int& d0, int& d1, int& d2) {
-    float t = x * scale;                               // exact: scale is a power of two (no overflow: |x| 2^(22-e) stays finite)
-    t = t > (float)I3_QMAX ? (float)I3_QMAX : (t < -(float)I3_QMAX ? -(float)I3_QMAX : t);
-    const int q = (int)rintf(t);                       // round to nearest even
+    const int q = (int)rintf(x * scale);               // x * scale is exact (power of two); |q| <= 2^22; round to nearest even
     d0 = (int)(signed char)(q & 255);
     const int q1 = (q - d0) >> 8;
     d1 = (int)(signed char)(q1 & 255);
     d2 = (q1 - d1) >> 8;
 }
-__global__ __launch_bounds__(256) void quantize_planes_kernel(const float4* __restrict__ src, long long n4, float scale,
-                                                              unsigned* __restrict__ dst, long long plane_stride4) {
-    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
-        const float4 v = src[i];
-        int a0, a1, a2, b0, b1, b2, c0, c1, c2, e0, e1, e2;
-        i3_digits(v.x, scale, a0, a1, a2); i3_digits(v.y, scale, b0, b1, b2);
-        i3_digits(v.z, scale, c0, c1, c2); i3_digits(v.w, scale, e0, e1, e2);
-        dst[i] = (unsigned)(a0 & 255) | ((unsigned)(b0 & 255) << 8) | ((unsigned)(c0 & 255) << 16) | ((unsigned)(e0 & 255) << 24);
-        dst[i + plane_stride4] = (unsigned)(a1 & 255) | ((unsigned)(b1 & 255) << 8) | ((unsigned)(c1 & 255) << 16) | ((unsigned)(e1 & 255) << 24);
-        dst[i + 2 * plane_stride4] = (unsigned)(a2 & 255) | ((unsigned)(b2 & 255) << 8) | ((unsigned)(c2 & 255) << 16) | ((unsigned)(e2 & 255) << 24);
+template <int G>
+__global__ __launch_bounds__(256) void quantize_pixels_kernel(const float4* __restrict__ src, long long P, int C4, unsigned* __restrict__ dst,
+                                                              long long plane_stride4, float* __restrict__ rowscale) {
+    const int sub = threadIdx.x % G, grp = threadIdx.x / G;
+    constexpr int PPB = 256 / G;
+    for (long long p = (long long)blockIdx.x * PPB + grp; p < P; p += (long long)gridDim.x * PPB) {
+        const float4* row = src + p * C4;
+        float m = 0.0f;
+        for (int i = sub; i < C4; i += G) {
+            const float4 v = row[i];
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        }
+#pragma unroll
+        for (int o = G / 2; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        // m = f * 2^e, f in [0.5, 1)  ->  e = biased exponent - 126 (zero: 0; tiny / huge maxima: clamped, digits saturate to 0 / garbage-free)
+        const unsigned bits = __builtin_bit_cast(unsigned, m);
+        int e = (int)((bits >> 23) & 255u) - 126;
+        if (m == 0.0f) e = 0;
+        e = e < -100 ? -100 : (e > 100 ? 100 : e);
+        const float qs = __builtin_bit_cast(float, (unsigned)(22 - e + 127) << 23);      // 2^(22 - e)
+        for (int i = sub; i < C4; i += G) {
+            const float4 v = row[i];
+            int a0, a1, a2, b0, b1, b2, c0, c1, c2, d0, d1, d2;
+            i3_digits(v.x, qs, a0, a1, a2); i3_digits(v.y, qs, b0, b1, b2);
+            i3_digits(v.z, qs, c0, c1, c2); i3_digits(v.w, qs, d0, d1, d2);
+            const long long o = p * C4 + i;
+            dst[o] = i3_pack_digit(a0, b0, c0, d0);
+            dst[o + plane_stride4] = i3_pack_digit(a1, b1, c1, d1);
+            dst[o + 2 * plane_stride4] = i3_pack_digit(a2, b2, c2, d2);
+        }
+        if (sub == 0) rowscale[p] = __builtin_bit_cast(float, (unsigned)(e - 22 + 127) << 23);   // 2^(e - 22)
     }
 }
-void launch_quantize_planes(const float* src, long long n, int exp, signed char* dst, long long plane_stride, hipStream_t st) {
-    const long long n4 = n / 4;
-    if (n4 <= 0) return;
-    long long blocks = (n4 + 255) / 256; if (blocks > 65536) blocks = 65536;
-    hipLaunchKernelGGL(quantize_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<const float4*>(src), n4,
-                       ldexpf(1.0f, 22 - exp), reinterpret_cast<unsigned*>(dst), plane_stride / 4);
-}
-
-// max |x| of a tensor (calibration): bit pattern of a non-negative float orders like the float
-__global__ __launch_bounds__(256) void absmax_kernel(const float4* __restrict__ src, long long n4, unsigned* out) {
-    float m = 0.0f;
-    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
-        const float4 v = src[i];
-        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
-    }
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o));
-    if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(out, __builtin_bit_cast(unsigned, m));
-}
-void launch_absmax(const float* src, long long n, unsigned* out, hipStream_t st) {
-    const long long n4 = n / 4;
-    if (n4 <= 0) return;
-    long long blocks = (n4 + 255) / 256; if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<const float4*>(src), n4, out);
+void launch_quantize_pixels(const float* src, long long P, int C, signed char* dst, long long plane_stride, float* rowscale, hipStream_t st) {
+    if (P <= 0 || C < 4) return;
+    const int C4 = C / 4;
+    const int G = C4 >= 64 ? 64 : (C4 >= 32 ? 32 : 16);
+    long long blocks = (P + (256 / G) - 1) / (256 / G); if (blocks > 65536) blocks = 65536;
+    const float4* s4 = reinterpret_cast<const float4*>(src); unsigned* d4 = reinterpret_cast<unsigned*>(dst);
+    if (G == 64) hipLaunchKernelGGL((quantize_pixels_kernel<64>), dim3((unsigned)blocks), dim3(256), 0, st, s4, P, C4, d4, plane_stride / 4, rowscale);
+    else if (G == 32) hipLaunchKernelGGL((quantize_pixels_kernel<32>), dim3((unsigned)blocks), dim3(256), 0, st, s4, P, C4, d4, plane_stride / 4, rowscale);
+    else hipLaunchKernelGGL((quantize_pixels_kernel<16>), dim3((unsigned)blocks), dim3(256), 0, st, s4, P, C4, d4, plane_stride / 4, rowscale);
 }
 
 // ---------------------------------------------------------------------------------------------
 // the GEMM
 // ---------------------------------------------------------------------------------------------
-// WN = 2: 128 x 64 tiles, 256 threads (layers with 64 output channels, and the tail-quantised small launches);
-// WN = 4: 128 x 128 tiles, 512 threads = 8 waves of 64 x 32 -- 1.5 x the digit-MACs per byte moved from L2 into LDS, which is
-//         what bounds this kernel (the 128 x 64 tile sustains ~9 TB/s of L2 -> LDS traffic at 265 TF-eq).
+// WN = 2: 128 x 64 tiles, 256 threads (layers with 64 output channels, short chains);
+// WN = 4: 128 x 128 tiles, 512 threads = 8 waves of 64 x 32 -- 1.5 x the digit-MACs per byte moved from L2 into LDS.
 template <int EPI, int WN>
 __device__ __forceinline__ void conv_i3_body(const ConvArgs& a, const int blk) {
     constexpr int BM = 128, BN = 32 * WN, BK = 32, TM = 2;
-    constexpr int PLANE_A = BM * 32, PLANE_B = BN * 32, TILE_B = 3 * PLANE_A + 3 * PLANE_B;       // bytes: 12288 + 6144
+    constexpr int PLANE_A = BM * 32, PLANE_B = BN * 32, TILE_B = 3 * PLANE_A + 3 * PLANE_B;       // bytes
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE_B];
+    __shared__ __attribute__((aligned(16))) float s_scale[2][BM];        // per-row scale 2^(e_p - 22) of the tap being accumulated
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -113,12 +127,13 @@ __device__ __forceinline__ void conv_i3_body(const ConvArgs& a, const int blk) {
     const int m0 = (mt - so.tile_start) * BM;
     if (m0 >= Mv) return;
     const int Cin = a.Cin, KW = a.KW, KH = a.KH, CoutPad = a.CoutPad;
+    const int CC = Cin / BK;                            // 32-channel chunks per tap
 
-    // ---- A gather: row = tid >> 1, 16-byte half = tid & 1, the three planes ----
+    // ---- A gather: row = tid >> 1, 16-byte half = tid & 1, the three planes; half 0 also fetches the row's scale per tap ----
     const bool is_a = WN == 2 || tid < 256;          // WN = 4: waves 0-3 stage A, waves 4-7 stage B (three pieces each)
     const int arow = (tid & 255) >> 1, ahalf = tid & 1;
     unsigned rowmask = 0;
-    int rowvoff;
+    int rowvoff, rowpix;
     {
         const int m = m0 + arow;
         const int oy = m / Wo, ox = m - oy * Wo;
@@ -129,13 +144,16 @@ __device__ __forceinline__ void conv_i3_body(const ConvArgs& a, const int blk) {
                 const int iy = iy0 + th, ix = ix0 + tw;
                 if (iy >= 0 && iy < Hi && ix >= 0 && ix < Wi) rowmask |= 1u << t;
             }
-        rowvoff = ((oy * a.stride) * Wi + ox * a.stride) * Cin + 16 * ahalf;
+        rowpix = (oy * a.stride) * Wi + ox * a.stride;
+        rowvoff = rowpix * Cin + 16 * ahalf;
     }
     const signed char* pl0 = a.i8_in + si.pix_off * (long long)Cin - (long long)a.pad * (Wi + 1) * Cin;
     const __amdgpu_buffer_rsrc_t rsA0 = __builtin_amdgcn_make_buffer_rsrc((void*)pl0, 0, 0x7FFE0000, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsA1 = __builtin_amdgcn_make_buffer_rsrc((void*)(pl0 + a.i8_plane_stride), 0, 0x7FFE0000, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsA2 = __builtin_amdgcn_make_buffer_rsrc((void*)(pl0 + 2 * a.i8_plane_stride), 0, 0x7FFE0000, 0x00020000);
-    // B: packed [kt][plane][CoutPad][32 B]; piece t: plane t >> 7, column (t & 127) >> 1, half t & 1; threads < 128 also plane 2
+    const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.i8_rowscale + si.pix_off - (long long)a.pad * (Wi + 1)), 0, 0x7FFE0000, 0x00020000);
+    // B: packed [kt][plane][CoutPad][32 B], kt = tap * CC + chunk
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(reinterpret_cast<const unsigned char*>(a.w8) + (long long)n0 * 32), 0, 0x7FFE0000, 0x00020000);
     // WN = 2: piece t: plane t >> 7, column (t & 127) >> 1; threads < 128 also plane 2.  WN = 4: thread 256 + t: column t >> 1, all planes
@@ -145,19 +163,25 @@ __device__ __forceinline__ void conv_i3_body(const ConvArgs& a, const int blk) {
     const int aw_off = arow * 32 + ((ahalf ^ ((arow >> 3) & 1)) * 16);
     const int bw_off0 = 3 * PLANE_A + b_p * PLANE_B + b_nl * 32 + ((b_h ^ ((b_nl >> 3) & 1)) * 16);
     const int bw_off1 = 3 * PLANE_A + 2 * PLANE_B + b_nl * 32 + ((b_h ^ ((b_nl >> 3) & 1)) * 16);
-    int u_kh = 0, u_kw = 0, u_ci = 0, u_kt = 0;
+    int u_tap = 0, u_kh = 0, u_kw = 0, u_cc = 0, u_kt = 0;     // loader cursor: tile u_kt = (tap u_tap, chunk u_cc)
     i32x4 ra0, ra1, ra2, rb0, rb1 = {0, 0, 0, 0};     // WN = 4, B waves: ra0..ra2 carry the three B planes
+    float rs_new = 0.0f; bool rs_have = false; int rs_tap = 0;
 
 #define I3_LOAD()                                                                                          \
     {                                                                                                      \
         const int soffB = u_kt * 3 * CoutPad * 32;                                                         \
-        const unsigned u_bit = 1u << (u_kh * KW + u_kw);                                                   \
-        const int soffA = (u_kh * Wi + u_kw) * Cin + u_ci;                                                 \
-        const int v0 = (rowmask & u_bit) ? rowvoff : 0x7FFF0000;                                           \
+        const bool ok = (rowmask >> u_tap) & 1u;                                                           \
+        const int soffA = (u_kh * Wi + u_kw) * Cin + u_cc * BK;                                            \
+        const int v0 = ok ? rowvoff : 0x7FFF0000;                                                          \
         if (is_a) {                                                                                        \
             ra0 = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA0, v0, soffA, 0));    \
             ra1 = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA1, v0, soffA, 0));    \
             ra2 = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA2, v0, soffA, 0));    \
+            rs_have = u_cc == 0;                                                                           \
+            if (rs_have) {      /* first chunk of a tap: the row's scale at that tap's pixel (out of image: 0) */ \
+                rs_tap = u_tap;                                                                            \
+                rs_new = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsS, ok ? rowpix * 4 : 0x7FFF0000, (u_kh * Wi + u_kw) * 4, 0)); \
+            }                                                                                              \
         }                                                                                                  \
         if (WN == 2) {                                                                                     \
             rb0 = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, bvoff0, soffB, 0)); \
@@ -168,7 +192,7 @@ __device__ __forceinline__ void conv_i3_body(const ConvArgs& a, const int blk) {
             ra2 = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, bvoff0 + 2 * CoutPad * 32, soffB, 0)); \
         }                                                                                                  \
         u_kt++;                                                                                            \
-        u_kw++; if (u_kw == KW) { u_kw = 0; u_kh++; if (u_kh == KH) { u_kh = 0; u_ci += BK; } }            \
+        u_cc++; if (u_cc == CC) { u_cc = 0; u_tap++; u_kw++; if (u_kw == KW) { u_kw = 0; u_kh++; } }       \
     }
 #define I3_STORE(BUF)                                                                                      \
     {                                                                                                      \
@@ -177,6 +201,7 @@ __device__ __forceinline__ void conv_i3_body(const ConvArgs& a, const int blk) {
             *reinterpret_cast<i32x4*>(tb + aw_off) = ra0;                                                  \
             *reinterpret_cast<i32x4*>(tb + PLANE_A + aw_off) = ra1;                                        \
             *reinterpret_cast<i32x4*>(tb + 2 * PLANE_A + aw_off) = ra2;                                    \
+            if (rs_have && ahalf == 0) s_scale[rs_tap & 1][arow] = rs_new;                                 \
         }                                                                                                  \
         if (WN == 2) {                                                                                     \
             *reinterpret_cast<i32x4*>(tb + bw_off0) = rb0;                                                 \
@@ -188,11 +213,13 @@ __device__ __forceinline__ void conv_i3_body(const ConvArgs& a, const int blk) {
         }                                                                                                  \
     }
 
-    i32x16 acc0[TM], acc1[TM], acc2[TM];        // digit-product sums of weight 2^16, 2^24, 2^32
+    i32x16 acc0[TM], acc1[TM], acc2[TM];        // digit-product sums of the current tap, weights 2^16, 2^24, 2^32
+    float accf[TM][16];                         // the output's float32 accumulator over the taps
 #pragma unroll
     for (int i = 0; i < TM; i++)
 #pragma unroll
-        for (int r = 0; r < 16; r++) { acc0[i][r] = 0; acc1[i][r] = 0; acc2[i][r] = 0; }
+        for (int r = 0; r < 16; r++) accf[i][r] = 0.0f;
+    const i32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
     const int KT = a.Kpad / BK;
     I3_LOAD();
@@ -209,7 +236,9 @@ __device__ __forceinline__ void conv_i3_body(const ConvArgs& a, const int blk) {
 
 #define I3_MFMA(ACC, FA, FB)                                                                               \
     _Pragma("unroll") for (int i = 0; i < TM; i++) ACC[i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(FA[i], FB, ACC[i], 0, 0, 0);
-    int cur = 0;
+#define I3_MFMA0(ACC, FA, FB)      /* first product of a tap into this accumulator set: starts from zero */  \
+    _Pragma("unroll") for (int i = 0; i < TM; i++) ACC[i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(FA[i], FB, zero16, 0, 0, 0);
+    int cur = 0, c_cc = 0, c_tap = 0;           // the tile being computed: (tap c_tap, chunk c_cc)
     for (int kt = 0; kt < KT; kt++) {
         const unsigned char* tc = smem + cur * TILE_B;
         const bool has1 = kt + 1 < KT, has2 = kt + 2 < KT;
@@ -223,23 +252,51 @@ __device__ __forceinline__ void conv_i3_body(const ConvArgs& a, const int blk) {
         b2 = *reinterpret_cast<const i32x4*>(tc + 2 * PLANE_B + fo_b);
         b1 = *reinterpret_cast<const i32x4*>(tc + PLANE_B + fo_b);
         b0 = *reinterpret_cast<const i32x4*>(tc + fo_b);
-        I3_MFMA(acc2, a2, b2)
-        I3_MFMA(acc1, a2, b1)
-        if (has1) I3_STORE(cur ^ 1)
-        I3_MFMA(acc1, a1, b2)
-        I3_MFMA(acc0, a2, b0)
+        if (c_cc == 0) {
+            I3_MFMA0(acc2, a2, b2)
+            I3_MFMA0(acc1, a2, b1)
+            if (has1) I3_STORE(cur ^ 1)
+            I3_MFMA(acc1, a1, b2)
+            I3_MFMA0(acc0, a2, b0)
+        } else {
+            I3_MFMA(acc2, a2, b2)
+            I3_MFMA(acc1, a2, b1)
+            if (has1) I3_STORE(cur ^ 1)
+            I3_MFMA(acc1, a1, b2)
+            I3_MFMA(acc0, a2, b0)
+        }
         if (has2) I3_LOAD()
         I3_MFMA(acc0, a0, b2)
         I3_MFMA(acc0, a1, b1)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         cur ^= 1;
+        if (++c_cc == CC) {
+            // the tap is complete: fold its exact integer sums into the float accumulators with the per-row scales
+            const float* sp = s_scale[c_tap & 1];
+#pragma unroll
+            for (int i = 0; i < TM; i++) {
+                const int rb = wm * 64 + i * 32 + 4 * kh_lane;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const f32x4 s4 = *reinterpret_cast<const f32x4*>(sp + rb + 8 * q);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int r = 4 * q + j;
+                        const float T = fmaf((float)acc2[i][r], 65536.0f, fmaf((float)acc1[i][r], 256.0f, (float)acc0[i][r]));
+                        accf[i][r] = fmaf(T, s4[j], accf[i][r]);
+                    }
+                }
+            }
+            c_cc = 0; c_tap++;
+        }
     }
 #undef I3_LOAD
 #undef I3_STORE
 #undef I3_MFMA
+#undef I3_MFMA0
 
-    // ---- epilogue: exact combine in double, one rounding to float32, then the exact mode's fp32 epilogue ----
+    // ---- epilogue: * 2^(e_w[n] - 22 + 16) (exact), then the exact mode's fp32 epilogue ----
     const int out_ld = a.out_ld;
     float* __restrict__ out_v = a.out + so.pix_off * (long long)out_ld;
     const float* __restrict__ ex_v = nullptr;
@@ -260,7 +317,7 @@ __device__ __forceinline__ void conv_i3_body(const ConvArgs& a, const int blk) {
     const float bs = has_bias ? a.bias[nc] : 0.0f;
     const float sc = has_bn ? a.scale[nc] : 1.0f;
     const float sh = has_bn ? a.shift[nc] : 0.0f;
-    const double unscale = (double)a.i8_in_unscale * (double)a.w8_unscale[nc];      // 2^(e_x - 22 + 16) * 2^(e_w[n] - 22)
+    const float unscale = a.w8_unscale[nc];                                          // 2^(e_w[n] - 22 + 16)
     // full tiles: one byte offset per lane, the 16 rows of an accumulator tile through the scalar offset of the buffer instruction
     const bool full_tile = m0 + BM <= Mv;
     const int row_b = out_ld * 4;
@@ -292,11 +349,7 @@ __device__ __forceinline__ void conv_i3_body(const ConvArgs& a, const int blk) {
         }
         float val[16];
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            // T / 2^16 = 65536 S2 + 256 S1 + S0: |T / 2^16| < 2^47, exact in double; the factor 2^16 lives in `unscale`
-            const double T = fma((double)acc2[i][r], 65536.0, fma((double)acc1[i][r], 256.0, (double)acc0[i][r]));
-            val[r] = (float)(T * unscale);
-        }
+        for (int r = 0; r < 16; r++) val[r] = accf[i][r] * unscale;
         if (has_bias) {
 #pragma unroll
             for (int r = 0; r < 16; r++) val[r] = val[r] + bs;
@@ -337,7 +390,7 @@ __global__ __launch_bounds__(128 * WN, 2) void conv_i3_group_kernel(const ConvGr
 }
 
 static inline bool i3_covers(const ConvArgs& a) {
-    return a.w8 && a.i8_in && a.CoutPad % 64 == 0 && a.Cin % 32 == 0 && a.KH * a.KW <= 32 && !a.in_relu;
+    return a.w8 && a.i8_in && a.i8_rowscale && a.CoutPad % 64 == 0 && a.Cin % 32 == 0 && a.KH * a.KW <= 32 && !a.in_relu;
 }
 static inline int i3_grid_mtiles(const ConvArgs& a) { return a.KH * a.KW > 1 ? 8 * ((a.total_mtiles + 7) / 8) : a.total_mtiles; }
 // 128 x 128 tiles when the channel count allows it and the launch still fills the chip (one 512-thread workgroup per CU)

@@ -48,9 +48,8 @@ class HipDetector:
                  box_detections_per_img=100, rpn_pre_nms_top_n_test=1000, rpn_post_nms_top_n_test=1000,
                  rpn_nms_thresh=0.7, arch=0, precision="fp32", **unused):
         """precision: "fp32" (exact, bit-identical to the oracle; default), "f16x3" (split-fp16 MFMA path, 2x faster, fp32-grade
-        but not reproducible on a CPU) or "i8x3" (exact-integer int8 MFMA path: fixed-point operands per layer, bit-identical to
-        ITS oracle but coarser than fp32; needs ``calibrate(images, augs)`` once) -- include/cald_hip.h, DESIGN.md section 4b / 4c.
-        Neither fast mode is bit-identical to fp32: f16x3 moves ~1 % of the images by more than 1e-4, i8x3 ~14 %."""
+        but not reproducible on a CPU) or "i8x3" (exact-integer int8 MFMA path: block floating point per pixel, bit-identical to
+        ITS oracle) -- include/cald_hip.h, DESIGN.md section 4b / 4c.  Neither matrix-pipe mode is bit-identical to fp32."""
         self.arch = arch
         self.cfg = _ffi.ModelCfg(self.arch, depth, num_classes, int(min_size), int(max_size), box_score_thresh,
                                  box_nms_thresh, box_detections_per_img, rpn_pre_nms_top_n_test, rpn_post_nms_top_n_test,
@@ -60,7 +59,6 @@ class HipDetector:
         self._state = None
         self._handle = None
         self._device = None
-        self._calibration = {}          # layer name -> input exponent (precision "i8x3")
 
     # ---- nn.Module-like surface used by cald_train.py ----
     def eval(self):
@@ -118,66 +116,8 @@ class HipDetector:
                 shape = (C.c_int64 * a.ndim)(*a.shape)
                 _ffi.check(L.cald_model_load_tensor(h, k.encode(), _ffi.ptr(a), shape, a.ndim))
             _ffi.check(L.cald_model_finalize(h))
-            for name, e in self._calibration.items():
-                _ffi.check(L.cald_model_set_calibration(h, name.encode(), int(e)))
             self._handle = h
         return self._handle
-
-    # ---- precision "i8x3": static per-layer input exponents ----
-    def _views_of(self, images):
-        views = []
-        for img in images:
-            if isinstance(img, np.ndarray):
-                img = torch.from_numpy(img)
-            if img.dtype != torch.uint8:
-                img = (img * 255.0).round().clamp(0, 255).to(torch.uint8)
-            if img.shape[-1] != 3:
-                img = img.permute(1, 2, 0)
-            views.append(img.contiguous().cuda())
-        return views
-
-    def calibrate(self, images, augs=None, base_seed=0):
-        """Fixes every layer's input exponent: max |input| over an exact-fp32 pass of `images` (uint8 HWC or float CHW), plus one
-        bit of headroom.  With `augs` (the aug names the sweep will use) the pass is a whole consistency sweep, so the noisy /
-        rotated / resized views -- which reach larger activations than clean images -- are part of the calibration set.
-        Returns the {layer: exponent} table; repeated calls keep the maximum."""
-        L, h = _ffi.lib(), self.handle()
-        views = self._views_of(images)
-        _ffi.check(L.cald_model_calibrate_begin(h))
-        try:
-            if augs:
-                from . import sweep
-                sweep.sweep_device_images(self, views, list(range(len(views))), augs, base_seed=base_seed)
-            else:
-                for lo in range(0, len(views), 64):
-                    self.forward_views([(v, False, None) for v in views[lo:lo + 64]])
-        finally:
-            _ffi.check(L.cald_model_calibrate_end(h))
-        self._calibration = {k: e for k, (e, cov) in self.calibration(all_layers=True).items() if e is not None}
-        return self.calibration()
-
-    def calibration(self, all_layers=False):
-        """{layer name: input exponent} of the layers that run on the int8 pipe (all layers with all_layers=True, as
-        {name: (exponent or None, covered)})."""
-        L, h = _ffi.lib(), self.handle()
-        out, i = {}, 0
-        name = C.create_string_buffer(256)
-        e, cov = C.c_int(), C.c_int()
-        while L.cald_model_get_calibration(h, i, name, 256, C.byref(e), C.byref(cov)) == 0:
-            val = None if e.value == -2 ** 31 else e.value
-            if all_layers:
-                out[name.value.decode()] = (val, bool(cov.value))
-            elif cov.value and val is not None:
-                out[name.value.decode()] = val
-            i += 1
-        return out
-
-    def set_calibration(self, table):
-        self._calibration = dict(table)
-        if self._handle is not None:
-            for name, e in self._calibration.items():
-                _ffi.check(_ffi.lib().cald_model_set_calibration(self._handle, name.encode(), int(e)))
-        return self
 
     # ---- inference ----
     def forward_views(self, views):

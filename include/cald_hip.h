@@ -40,13 +40,11 @@ typedef struct cald_model cald_model;
  *          bar is met only by FP32; |activations| must stay below 4094. */
 #define CALD_PRECISION_FP32 0
 #define CALD_PRECISION_F16X3 1
-/*   I8X3   exact-integer int8 mode (conv_i3.hip): activations (one calibrated power-of-two exponent per layer input) and
- *          weights (one exponent per output channel) quantised to 24-bit fixed point, three balanced base-256 digits each,
- *          six digit products on v_mfma_i32_32x32x32_i8 with exact int32 accumulation, one rounding to float32, then the exact
- *          mode's fp32 epilogue.  Reproducible bit for bit on a CPU (the C oracle under oracle/).  Accuracy: fixed point per LAYER --
- *          ~2^-22 of the layer's |x|max |w|max per product, i.e. ~14 significant bits on typical activations: coarser than FP32 /
- *          F16X3 (median |d consistency| 2.6e-5 vs 1e-6 on the configs[1] pool; more on deep nets).
- *          Needs cald_model_calibrate() (or cald_model_set_calibration()) once per model. */
+/*   I8X3   exact-integer int8 mode (conv_i3.hip): block floating point -- one exponent per input PIXEL (from its largest
+ *          |channel|, computed on the fly: no calibration, no saturation) and per output channel of the weights; operands as three
+ *          balanced base-256 digits, six digit products per filter tap on v_mfma_i32_32x32x32_i8 with exact int32 accumulation,
+ *          taps folded into one float32 accumulator in (kh, kw) order, then the exact mode's fp32 epilogue.  Reproducible bit
+ *          for bit on a CPU (the C oracle under oracle/); ~19-20 significant bits on typical activations. */
 #define CALD_PRECISION_I8X3 2
 
 #define CALD_ARCH_FRCNN 0      /* detection/frcnn_la.py FRCNN_Feature */
@@ -84,18 +82,6 @@ int cald_model_load_tensor(cald_model* m, const char* key, const float* data, co
 /* folds FrozenBatchNorm into per-channel scale/shift, repacks weights K-major for the MFMA kernels */
 int cald_model_finalize(cald_model* m);
 int cald_model_destroy(cald_model* m);
-
-/* CALD_PRECISION_I8X3 only: one exact-mode forward over n_views (<= 64) calibration views records max |input| of every conv /
- * linear layer; the layer's input exponent becomes frexp-exponent + 1 (one bit of headroom; inputs beyond it saturate
- * deterministically).  Repeated calls keep the maximum.  get: layers are enumerated by index until CALD_ERR_INVALID; exp_out is
- * INT_MIN while uncalibrated, covered_out says whether the layer runs on the int8 pipe.  set: restores a stored calibration. */
-int cald_model_calibrate(cald_model* m, int n_views, const struct cald_view* views);
-/* the same around ANY forwards / sweeps issued in between (e.g. one cald_sweep with the augmentations that will be used: noisy
- * or rotated views reach larger activations than clean images); those calls run the exact fp32 kernels */
-int cald_model_calibrate_begin(cald_model* m);
-int cald_model_calibrate_end(cald_model* m);
-int cald_model_get_calibration(cald_model* m, int index, char* name_out, int name_cap, int* exp_out, int* covered_out);
-int cald_model_set_calibration(cald_model* m, const char* layer_name, int exp);
 
 /* One detector input: task_model([tensor]) in cald_train.py:107 / :186.  The view is described by
  * its uint8 HWC source image in HBM plus the augmentation to apply on the fly. */
@@ -188,10 +174,10 @@ int cald_op_augment(cald_ctx* ctx, int kind, double param, uint64_t seed, const 
 int cald_op_conv2d(cald_ctx* ctx, const float* in, int H, int W, int Cin, const float* weight, int Cout, int KH, int KW,
                    int stride, int pad, const float* bias, const float* bn_scale, const float* bn_shift,
                    const float* residual, int relu, float* out);
-/* the same convolution in CALD_PRECISION_I8X3 (conv_i3.hip) with input exponent in_exp (|in| < 2^in_exp, larger values
- * saturate); shapes outside Cin % 32 == 0, Cout >= 64 return CALD_ERR_UNSUPPORTED */
+/* the same convolution in CALD_PRECISION_I8X3 (conv_i3.hip); shapes outside Cin % 32 == 0 (>= 64), Cout >= 64, <= 32 taps
+ * return CALD_ERR_UNSUPPORTED */
 int cald_op_conv2d_i8x3(cald_ctx* ctx, const float* in, int H, int W, int Cin, const float* weight, int Cout, int KH, int KW,
-                        int stride, int pad, int in_exp, const float* bias, const float* bn_scale, const float* bn_shift,
+                        int stride, int pad, const float* bias, const float* bn_scale, const float* bn_shift,
                         const float* residual, int relu, float* out);
 /* the same convolution in CALD_PRECISION_F16X3 (conv_h3.hip); falls back to the exact kernels for shapes it does not
  * cover (Cin % 16 != 0 or Cout not tiled by 128), exactly as inside a model */

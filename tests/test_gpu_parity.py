@@ -191,15 +191,16 @@ I8_CASES = [c for c in CONV_CASES if c[2] % 32 == 0 and c[3] >= 64] + [
 
 @pytest.mark.parametrize("case", I8_CASES)
 def test_conv_i8x3_bit_exact(hip, oracle, case):
-    """CALD_PRECISION_I8X3 (conv_i3.hip): fixed-point operands, six int8 digit products, exact int32 accumulation, one rounding
-    -> tobytes()-equal to the C oracle; and within the fixed-point error bound (2^-23 of the layer / channel maxima per operand)
-    of the exact fp32 chain."""
+    """CALD_PRECISION_I8X3 (conv_i3.hip): block floating point (one exponent per pixel / per output channel), six int8 digit
+    products per tap with exact int32 accumulation, taps folded in float32 in a fixed order -> tobytes()-equal to the C oracle;
+    and close to the exact fp32 chain: per term 2^-22 of (pixel max x channel max)."""
     H, W, Cin, Cout, K, stride, pad, bias, bn, res, relu = case
     ffi, L = hip["ffi"], hip["L"]
     rs = np.random.RandomState(H * 1000 + Cout + 7)
     x = rs.randn(H, W, Cin).astype(np.float32) * 3.0
     x[rs.rand(H, W, Cin) < 0.3] = 0.0
-    x[0, 0, 0] = 1e4                                                            # saturates: |x| >= 2^in_exp clamps, deterministically
+    xf = x.reshape(-1, Cin)                                                     # (view) an outlier pixel, an all-zero pixel, a tiny pixel
+    xf[0, 0] = 1e4; xf[min(7, len(xf) - 1), :] = 0.0; xf[min(13, len(xf) - 1), :] *= 1e-6
     w = (rs.randn(Cout, Cin, K, K) * np.sqrt(2.0 / (Cin * K * K))).astype(np.float32)
     w[1] *= 37.0; w[2] = 0.0                                                    # per-channel exponents differ; an all-zero channel
     b = rs.randn(Cout).astype(np.float32) if bias else None
@@ -207,22 +208,20 @@ def test_conv_i8x3_bit_exact(hip, oracle, case):
     sh = rs.randn(Cout).astype(np.float32) if bn else None
     Ho, Wo = (H + 2 * pad - K) // stride + 1, (W + 2 * pad - K) // stride + 1
     r = rs.randn(Ho, Wo, Cout).astype(np.float32) if res else None
-    in_exp = 5                                                                  # |x| < 32 except the planted outlier
     out = np.empty((Ho, Wo, Cout), np.float32)
-    ffi.check(L.cald_op_conv2d_i8x3(hip["ctx"], ffi.ptr(x), H, W, Cin, ffi.ptr(w), Cout, K, K, stride, pad, in_exp, ffi.ptr(b),
+    ffi.check(L.cald_op_conv2d_i8x3(hip["ctx"], ffi.ptr(x), H, W, Cin, ffi.ptr(w), Cout, K, K, stride, pad, ffi.ptr(b),
                                     ffi.ptr(sc), ffi.ptr(sh), ffi.ptr(r), int(relu), ffi.ptr(out)))
     wk = np.ascontiguousarray(w.transpose(2, 3, 1, 0).reshape(-1, Cout))
-    want = oracle.conv2d_i8x3(x, wk, K, K, stride, pad, in_exp, bias=b, bn=(sc, sh) if bn else None, residual=r, relu=relu)
+    want = oracle.conv2d_i8x3(x, wk, K, K, stride, pad, bias=b, bn=(sc, sh) if bn else None, residual=r, relu=relu)
     assert out.tobytes() == want.tobytes(), "max abs diff %g" % float(np.abs(out - want).max())
-    sat = np.float32(0x7F7F7F) * np.float32(2.0 ** (in_exp - 22))                 # where the fixed-point grid saturates (63.75 here)
-    xc = np.clip(x, -sat, sat)
-    exact = oracle.conv2d(xc, wk, K, K, stride, pad, bias=b, bn=(sc, sh) if bn else None, residual=r, relu=relu)
-    mag = oracle.conv2d(np.abs(xc), np.abs(wk), K, K, stride, pad)
-    # fixed point relative to the block maxima: |err| <= sum over k of (|a| dw + |w| da) with da = 2^(in_exp - 23), dw = 2^(e_w - 23)
+    exact = oracle.conv2d(x, wk, K, K, stride, pad, bias=b, bn=(sc, sh) if bn else None, residual=r, relu=relu)
+    # error per output <= sum over taps of Cin * (pixel max * 2^-23 * |w|max_n + |x| * w-step) + fp32 rounding of the fold
+    pmax = np.abs(x).max(axis=2, keepdims=True)                                  # [H][W][1]
     wmax = np.abs(wk).max(axis=0)
-    ew = np.where(wmax > 0, np.frexp(np.where(wmax > 0, wmax, 1.0))[1], 0)
-    kk = float(Cin * K * K)
-    bound = (np.abs(sc) if bn else 1.0) * (kk * (64.0 * 2.0 ** (ew - 23.0) + wmax * 2.0 ** (in_exp - 23.0)) + mag * 2.0 ** -21) + 1e-5
+    ones = np.ones((K * K * 1, 1), np.float32)
+    reach = oracle.conv2d(np.ascontiguousarray(np.repeat(pmax, 4, axis=2)), np.ascontiguousarray(np.repeat(ones, 4, axis=0) / 4.0), K, K, stride, pad)[:, :, 0:1]
+    mag = oracle.conv2d(np.abs(x), np.abs(wk), K, K, stride, pad)
+    bound = (np.abs(sc) if bn else 1.0) * (reach * Cin * wmax[None, None, :] * 2.0 ** -21 + mag * 2.0 ** -20) + 1e-5
     err = np.abs(out - exact)
     assert np.all(err <= bound), "max err %g, max err/bound %g" % (float(err.max()), float((err / bound).max()))
 
@@ -811,22 +810,16 @@ def test_voc_evaluate_files_equal_oracle_files_and_ap(hip, oracle, small_model, 
 
 
 def test_i8x3_mode_is_bit_identical_to_its_oracle(hip, oracle):
-    """CALD_PRECISION_I8X3 end to end (BASELINE configs[4]'s matrix-pipe path with a PINNED oracle): calibrate on three images,
-    then every stage of a forward and a whole 3-augmentation sweep equal the C oracle run with the same exponent table, bit
-    for bit -- and stay close to the exact mode (fixed point per layer: ~1e-5-grade, not fp32-grade)."""
+    """CALD_PRECISION_I8X3 end to end (BASELINE configs[4]'s matrix-pipe path with a PINNED oracle): every stage of a forward and
+    a whole 3-augmentation sweep equal the C oracle in the same mode, bit for bit -- and stay close to the exact fp32 mode."""
     torch = hip["torch"]
     from cald_amd import synth, sweep
     sd = synth.pseudo_trained_frcnn(21, 50, seed=0)
     model = hip["det"].fasterrcnn_resnet50_fpn_feature(num_classes=21, min_size=300, max_size=500, precision="i8x3").to("cuda")
     model.load_state_dict(sd)
     pool = synth.make_pool(4, "voc", 0, scale=0.5)
-    with pytest.raises(RuntimeError):                                   # no exponents yet: refuses to run rather than guess
-        model.forward_views([(torch.from_numpy(pool[0]).cuda(), False, None)])
-    table = model.calibrate(pool[:3])
-    assert len(table) >= 60 and all(-8 <= e <= 20 for e in table.values()), table
-    assert "backbone.body.conv1.weight" not in table and "rpn.head.cls_logits.weight" not in table      # stem / narrow heads stay exact
     P = oracle.prepare_frcnn(sd, 21, 50)
-    P["i8"] = table
+    P["i8"] = True                                                      # stem / < 64-channel heads stay on the exact chain on both sides
     keep = {}
     want = oracle.frcnn_forward(P, pool[1], 300, 500, keep=keep)
     got = model.forward_views([(torch.from_numpy(pool[1]).cuda(), False, None)])[0]
@@ -853,12 +846,6 @@ def test_i8x3_mode_is_bit_identical_to_its_oracle(hip, oracle):
     exact.load_state_dict(sd)
     ce, _ = sweep.sweep_device_images(exact, dev, [0, 1, 2], augs, bp=1.3, base_seed=3)
     assert float(np.abs(cons - ce).max()) < 1e-3, (cons, ce)
-    # a restored calibration table gives the same model
-    again = hip["det"].fasterrcnn_resnet50_fpn_feature(num_classes=21, min_size=300, max_size=500, precision="i8x3").to("cuda")
-    again.load_state_dict(sd)
-    again.set_calibration(table)
-    c2, _ = sweep.sweep_device_images(again, dev, [0, 1, 2], augs, bp=1.3, base_seed=3)
-    np.testing.assert_array_equal(cons, c2)
 
 
 def test_i8x3_mode_retinanet_forward_bit_exact(hip, oracle):
@@ -870,10 +857,8 @@ def test_i8x3_mode_retinanet_forward_bit_exact(hip, oracle):
     model = hip["det"].retinanet_resnet50_fpn_cal(num_classes=21, min_size=300, max_size=500, precision="i8x3").to("cuda")
     model.load_state_dict(sd)
     pool = synth.make_pool(3, "voc", 0, scale=0.5)
-    table = model.calibrate(pool)
-    assert "head.classification_head.cls_logits.weight" in table and "head.regression_head.bbox_reg.weight" not in table
     P = oracle.prepare_retinanet(sd, 21, 50)
-    P["i8"] = table
+    P["i8"] = True
     want = oracle.retina_forward(P, pool[2], 300, 500, flip=True)
     got = model.forward_views([(torch.from_numpy(pool[2]).cuda(), True, None)])[0]
     assert want["boxes"].shape[0] > 0
@@ -884,8 +869,7 @@ def test_i8x3_mode_retinanet_forward_bit_exact(hip, oracle):
 def test_config4_full_size_i8x3_matrix_pipe_mode(hip, oracle):
     """BASELINE.json configs[4] as written -- Faster R-CNN ResNet-101 FPN, COCO shapes (800/1333, 91 classes), 5 augmentations,
     matrix-pipe arithmetic -- at FULL size in the mode an oracle can pin: one image (6 views) re-scored by the CPU oracle in
-    CALD_PRECISION_I8X3 with the same calibration table, bit for bit; batch / shard invariance over 8 images; and the distance
-    to the exact fp32 mode on those images."""
+    CALD_PRECISION_I8X3, bit for bit; batch / shard invariance over 8 images; and the distance to the exact fp32 mode."""
     import os
     torch = hip["torch"]
     from cald_amd import synth, sweep
@@ -894,7 +878,6 @@ def test_config4_full_size_i8x3_matrix_pipe_mode(hip, oracle):
     model.load_state_dict(sd)
     pool = synth.make_pool(8, "coco", 0)
     augs = ["flip", "ga", "cut_out", "smaller_resize", "rotation"]
-    table = model.calibrate(pool[:4], augs=augs)          # the noisy / rotated views are part of the calibration set
     dev = [torch.from_numpy(im).cuda() for im in pool]
     pos = list(range(8))
     c1, k1 = sweep.sweep_device_images(model, dev, pos, augs, base_seed=4, batch_images=64)
@@ -907,7 +890,7 @@ def test_config4_full_size_i8x3_matrix_pipe_mode(hip, oracle):
         cw[idx] = cr; kw[idx] = kr
     np.testing.assert_array_equal(c1, cw); np.testing.assert_array_equal(k1, kw)
     P = oracle.prepare_frcnn(sd, 91, 101)
-    P["i8"] = table
+    P["i8"] = True
     oracle.set_threads(min(128, os.cpu_count() or 1))
     try:
         wc, wk = oracle.get_uncertainty(P, [pool[5]], augs, 91, bp=1.3, min_size=800, max_size=1333, base_seed=4, positions=[5])
@@ -920,7 +903,5 @@ def test_config4_full_size_i8x3_matrix_pipe_mode(hip, oracle):
     ce, _ = sweep.sweep_device_images(exact, dev, pos, augs, base_seed=4)
     d = np.abs(c1 - ce)
     print("i8x3 vs exact fp32, configs[4] shapes, 8 images: max |d consistency| %.3g, median %.3g" % (d.max(), np.median(d)))
-    # 24-bit fixed point per LAYER (not per element): typical activations sit ~2^-8 below the layer maximum, i.e. keep ~14
-    # significant bits -- coarser than fp32 / f16x3, the price of exact integer accumulation.  Over ~100 layers and 6 views with
-    # 91 classes, borderline detections flip often: |d consistency| is 1e-3 ... 3e-2 here (measured), bounded loosely below.
-    assert float(np.median(d)) < 5e-2 and float(d.max()) < 0.5, d
+    # not bit-identical to fp32 (nothing but the exact mode is): a borderline detection that flips moves an image by ~1e-2
+    assert float(np.median(d)) < 1e-2 and float(d.max()) < 0.5, d

@@ -59,8 +59,6 @@ def main():
     for prec in ("fp32", "f16x3", "i8x3"):
         m = detector.fasterrcnn_resnet50_fpn_feature(num_classes=21, min_size=600, max_size=1000, precision=prec).to("cuda")
         m.load_state_dict(sd); m.eval()
-        if prec == "i8x3":
-            m.calibrate(pool[:64], augs=AUGS)
         sweep.sweep_device_images(m, pool[:64], list(range(64)), AUGS)
         torch.cuda.synchronize(); t = time.time()
         res[prec] = sweep.sweep_device_images(m, pool, list(range(n)), AUGS, bp=1.3, base_seed=0)
