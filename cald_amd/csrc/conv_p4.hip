@@ -22,7 +22,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // TAPS: 9 = 3 x 3 filter, 1 = 1 x 1 filter / linear layer: the k-loop is unrolled over the LDS buffer rotation (and the nine taps),
 // so LDS addresses are register + immediate and the per-tap load offsets are precomputed registers -- the loop body holds
 // no address / mask VALU at all (every VALU instruction beside v_mfma_f32_32x32x2_f32 costs matrix-pipe time: they share the
-// fp32 datapath).  0 = generic rolled loop (the 7 x 7 stem, other filter sizes).
+// fp32 datapath).  13 = the 7 x 7 stem on the 4-channel input (13 k-tiles, fully unrolled).  0 = generic rolled loop.
 template <int EPI, bool C4, int TN, int TAPS>
 __device__ __forceinline__ void conv_p4_body(const ConvArgs& a, const int blk) {
     constexpr int BM = 128, BN = 64 * TN, BK = 16, TM = 2, WN = 2;
@@ -154,7 +154,18 @@ __device__ __forceinline__ void conv_p4_body(const ConvArgs& a, const int blk) {
     // returns zeros), and the loader's channel cursor
     int voffA[2][TAPS > 0 ? TAPS : 1];
     int ci_ld = 0;
-    if (TAPS > 0) {
+    if (TAPS == 13) {
+        // the 7 x 7 stem on the 4-channel input: 13 k-tiles of four taps; thread g owns tap 4 kt + g of k-tile kt -- its offset (or the
+        // out-of-range offset for taps outside the image / beyond tap 48) is computed once here instead of in every k-tile
+#pragma unroll
+        for (int p = 0; p < 2; p++)
+#pragma unroll
+            for (int t = 0; t < 13; t++) {
+                const int tap = 4 * t + g, th = tap / 7, tw = tap - th * 7;
+                const bool ok = th < 7 && (unsigned)(riy0[p] + th) < (unsigned)Hi && (unsigned)(rix0[p] + tw) < (unsigned)Wi;
+                voffA[p][t] = ok ? rowvoff[p] + (th * Wi + tw) * 16 : 0x7FFF0000;
+            }
+    } else if (TAPS > 0) {
 #pragma unroll
         for (int p = 0; p < 2; p++)
 #pragma unroll
@@ -178,7 +189,7 @@ __device__ __forceinline__ void conv_p4_body(const ConvArgs& a, const int blk) {
     }
         U_LOAD0(0)
         P4_STORE(0);
-        if (KT > 1) U_LOAD0(TAPS == 9 ? 1 : 0)
+        if (KT > 1) U_LOAD0((TAPS == 9 || TAPS == 13) ? 1 : 0)
 #undef U_LOAD0
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -297,7 +308,11 @@ __device__ __forceinline__ void conv_p4_body(const ConvArgs& a, const int blk) {
         P4_MFMA(fa1, fb1, 2)                                                                               \
         P4_MFMA(fa1, fb1, 3)                                                                               \
     }
-        if (TAPS == 9) {
+        if (TAPS == 13) {                              // the stem: all 13 k-tiles, k-tile index = load-offset index
+            U_TILE(0, 1, 2, 0)  U_TILE(1, 2, 3, 1)  U_TILE(2, 0, 4, 2)  U_TILE(0, 1, 5, 3)  U_TILE(1, 2, 6, 4)
+            U_TILE(2, 0, 7, 5)  U_TILE(0, 1, 8, 6)  U_TILE(1, 2, 9, 7)  U_TILE(2, 0, 10, 8) U_TILE(0, 1, 11, 9)
+            U_TILE(1, 2, 12, 10) U_TILE(2, 0, 12, 11) U_TILE(0, 1, 12, 12)
+        } else if (TAPS == 9) {
             for (int kt = 0; kt < KT; kt += 9) {      // one 16-channel chunk: nine taps, three turns of the buffer ring
                 U_TILE(0, 1, 2, kt)     U_TILE(1, 2, 3, kt + 1) U_TILE(2, 0, 4, kt + 2)
                 U_TILE(0, 1, 5, kt + 3) U_TILE(1, 2, 6, kt + 4) U_TILE(2, 0, 7, kt + 5)
@@ -469,6 +484,12 @@ bool launch_conv_p4(const ConvArgs& a_in, hipStream_t stream) {
     dim3 grid((unsigned)(p4_grid_mtiles(a) * (a.CoutPad / (wide ? 128 : 64)))), block(256);
     if (a.Cin == 4) {
         if (a.residual || a.up || a.in_relu) return false;
+        static const int stem_env = getenv("CALD_P4_UNROLL") ? atoi(getenv("CALD_P4_UNROLL")) : 1;
+        if (stem_env && a.KH == 7 && a.KW == 7 && a.Kpad == 208) {      // unrolled stem: per-k-tile tap offsets precomputed
+            if (wide) hipLaunchKernelGGL((conv_p4_kernel<0, true, 2, 13>), grid, block, pad_lds, stream, a);
+            else hipLaunchKernelGGL((conv_p4_kernel<0, true, 1, 13>), grid, block, pad_lds, stream, a);
+            return true;
+        }
         if (wide) hipLaunchKernelGGL((conv_p4_kernel<0, true, 2, 0>), grid, block, pad_lds, stream, a);
         else hipLaunchKernelGGL((conv_p4_kernel<0, true, 1, 0>), grid, block, pad_lds, stream, a);
         return true;
