@@ -356,8 +356,22 @@ __device__ __forceinline__ void conv_p4_body(const ConvArgs& a, const int blk) {
     const bool full_tile = m0 + BM <= Mv && !(a.exp_flags & 1);
     const int row_b = out_ld * 4;
     const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc((void*)out_v, 0, 0x7FFE0000, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)(EPI == 1 ? ex_v : out_v), 0, 0x7FFE0000, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)(EPI != 0 ? ex_v : out_v), 0, 0x7FFE0000, 0x00020000);
+    // FPN top-down (EPI 2): the nearest-neighbour source pixel of each of the tile's 128 rows is computed ONCE (one thread per
+    // row; the LDS tile buffers are free after the k-loop's last barrier) instead of by every lane for each of its 32 rows
     const int Mlast = Mv - 1;
+    int* const s_src = reinterpret_cast<int*>(smem);
+    if (EPI == 2) {
+        if (tid < BM) {
+            int m = m0 + tid;
+            m = m < Mlast ? m : Mlast;
+            const int oy = m / Wo, ox = m - oy * Wo;
+            int sy = (int)floorf((float)oy * uph_s); sy = sy > upH - 1 ? upH - 1 : sy;
+            int sx = (int)floorf((float)ox * upw_s); sx = sx > upW - 1 ? upW - 1 : sx;
+            s_src[tid] = (sy * upW + sx) * out_ld * 4;
+        }
+        __syncthreads();
+    }
 #pragma unroll
     for (int j = 0; j < TN; j++) {
         const int n = n0 + wn * TN * 32 + j * 32 + l31;
@@ -375,19 +389,21 @@ __device__ __forceinline__ void conv_p4_body(const ConvArgs& a, const int blk) {
 #pragma unroll
                 for (int r = 0; r < 16; r++)
                     extra[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsX, vo, ((r & 3) + 8 * (r >> 2)) * row_b, 0));
-            } else if (EPI != 0) {
+            } else if (EPI == 2) {
+                const int rl = wm * TM * 32 + i * 32 + 4 * kh_lane;          // tile-local row of accumulator register 0
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const i32x4 so4 = *reinterpret_cast<const i32x4*>(s_src + rl + 8 * q);
+#pragma unroll
+                    for (int jj = 0; jj < 4; jj++)
+                        extra[4 * q + jj] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsX, so4[jj] + nc * 4, 0, 0));
+                }
+            } else if (EPI == 1) {
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     int m = mbase + (r & 3) + 8 * (r >> 2);
                     m = m < Mlast ? m : Mlast;
-                    if (EPI == 1) {
-                        extra[r] = ex_v[(long long)m * out_ld + nc];
-                    } else {
-                        const int oy = m / Wo, ox = m - oy * Wo;
-                        int sy = (int)floorf((float)oy * uph_s); sy = sy > upH - 1 ? upH - 1 : sy;
-                        int sx = (int)floorf((float)ox * upw_s); sx = sx > upW - 1 ? upW - 1 : sx;
-                        extra[r] = ex_v[(long long)(sy * upW + sx) * out_ld + nc];
-                    }
+                    extra[r] = ex_v[(long long)m * out_ld + nc];
                 }
             }
             float val[16];
