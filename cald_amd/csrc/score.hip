@@ -2,7 +2,8 @@
 // SURVEY.md section 3.2) and the per-view class-max vector (cald_train.py:114-117, :194-197).
 //
 // The reference runs ~25 tiny torch kernels + 6 host syncs per (reference box, augmentation);
-// here one workgroup scores one (image, augmentation) pair: a wavefront per reference box does the
+// here one workgroup scores one (image, augmentation) pair: the augmented view's boxes are staged in LDS
+// once (every one of the <= 50 reference boxes walks the whole list), a wavefront per reference box does the
 // IoU row + first-index argmax across lanes, then the Jensen-Shannon divergence with one class per
 // lane and 64-lane butterfly reductions (the same addition order the oracle's wave_sum uses).
 #include "common.h"
@@ -42,8 +43,10 @@ __device__ inline bool better(float v1, int j1, float v2, int j2) {
     return v1 > v2 || (v1 == v2 && j1 < j2);
 }
 
+#define SCORE_LDS_BOXES 2048      /* 32 KB: Faster R-CNN lists (<= 100) fit whole; RetinaNet's (<= classes x 300) go through in chunks */
 __global__ __launch_bounds__(256) void consistency_kernel(ScoreArgs a) {
     __shared__ float wmin[4];
+    __shared__ float4 s_box[SCORE_LDS_BOXES];
     const int p = blockIdx.x;
     const int rv = a.ref_view[p], av = a.aug_view[p], img = a.pair_img[p];
     const int N = a.ref_n[img];
@@ -57,8 +60,13 @@ __global__ __launch_bounds__(256) void consistency_kernel(ScoreArgs a) {
     const float* prmv = a.aug_param + (long long)p * 12;
     const float prm = prmv[0];
     float cur = 1.0f;
-    for (int i = wave; i < N; i += 4) {
-        const int ri = a.ref_sel[img * 50 + i];
+    // N <= 50 reference boxes over 4 waves: every wave runs the same number of rounds so that the staging barriers line up
+    const int rounds = (N + 3) / 4;
+    const int nchunk = (M + SCORE_LDS_BOXES - 1) / SCORE_LDS_BOXES;
+    for (int rd = 0; rd < rounds; rd++) {
+        const int i = rd * 4 + wave;
+        const bool live = i < N;
+        const int ri = live ? a.ref_sel[img * 50 + i] : 0;
         float4 ab = rboxes[ri];
         if (kind == 1) { float x0 = prm - ab.z, x2 = prm - ab.x; ab.x = x0; ab.z = x2; }   // cald_helper.py:29
         else if (kind == 2) { ab.x = ab.x * prm; ab.y = ab.y * prm; ab.z = ab.z * prm; ab.w = ab.w * prm; }  // :53
@@ -77,15 +85,24 @@ __global__ __launch_bounds__(256) void consistency_kernel(ScoreArgs a) {
             ab.z = det_clamp(xmax / prmv[6], 0.0f, prmv[8]); ab.w = det_clamp(ymax / prmv[7], 0.0f, prmv[9]);
         }
         float best = -INFINITY; int bj = 0x7fffffff;
-        for (int j = lane; j < M; j += 64) {
-            float v = cald_iou(ab, aboxes[j]);
-            if (better(v, j, best, bj)) { best = v; bj = j; }
+        for (int ch = 0; ch < nchunk; ch++) {
+            const int j0 = ch * SCORE_LDS_BOXES, nj = (M - j0 < SCORE_LDS_BOXES) ? M - j0 : SCORE_LDS_BOXES;
+            if (rd == 0 || nchunk > 1) {      // one chunk (the usual case): staged once, reused by every round
+                __syncthreads();
+                for (int j = threadIdx.x; j < nj; j += 256) s_box[j] = aboxes[j0 + j];
+                __syncthreads();
+            }
+            for (int j = lane; j < nj; j += 64) {
+                float v = cald_iou(ab, s_box[j]);
+                if (better(v, j0 + j, best, bj)) { best = v; bj = j0 + j; }
+            }
         }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
             float ov = __shfl_xor(best, off, 64); int oj = __shfl_xor(bj, off, 64);
             if (better(ov, oj, best, bj)) { best = ov; bj = oj; }
         }
+        if (!live) continue;
         // Jensen-Shannon divergence through scipy.stats.entropy semantics (float32, renormalised)
         const float* pv = a.det.scores_cls + ((long long)rv * cap + ri) * C;
         const float* qv = a.det.scores_cls + ((long long)av * cap + bj) * C;
