@@ -186,7 +186,8 @@ int cald_op_conv2d_f16x3(cald_ctx* ctx, const float* in, int H, int W, int Cin, 
                          const float* residual, int relu, float* out);
 /* kernel-tuning aid (tools/bench_conv.py): average time of ONE conv layer shape (the model's own kernel selection) over a
  * ragged batch of n_views equal views filled with pseudo-random data; `group` > 1 issues that many independent copies as one
- * grouped launch (FPN / RPN style).  tflops_out counts algorithmic FLOPs (2 * M * Cout * KH*KW*Cin). */
+ * grouped launch (FPN / RPN style).  tflops_out counts algorithmic FLOPs (2 * M * Cout * KH*KW*Cin).  relu: bit 0 = ReLU in the
+ * epilogue, bit 1 = time the CALD_PRECISION_I8X3 kernel instead of the exact one (digit planes prepared outside the timed region). */
 int cald_op_conv_bench(cald_ctx* ctx, int n_views, int H, int W, int Cin, int Cout, int KH, int stride, int pad, int residual,
                        int relu, int iters, int group, double* ms_out, double* tflops_out);
 /* detector-transform size (GeneralizedRCNNTransform): resized and padded sizes */

@@ -458,3 +458,49 @@ def test_voc_ap_matches_reference_golden(golden, tmp_path, capsys):
             assert capsys.readouterr().out == str(g[key])
             assert res["line"] == str(g[key]).splitlines()[1]
     assert 0.0 < res["AP50"] < 1.0
+
+
+def test_voc_dataset_conversion_matches_reference_golden(golden, tmp_path):
+    """SURVEY 8f rank 2 (data format feeding cls_kldiv and voc_evaluate): cald_amd.voc_utils parses VOC annotation XML into the
+    torchvision dict layout and converts it exactly as detection/voc_utils.py:16-44 did (oracle/make_golden_voc_utils.py):
+    same values AND dtypes, for the object-list layout and the older bare-dict single-object layout; then the same through
+    VOCDetection over a VOCdevkit tree on disk (ids, targets without image decode, images through PIL)."""
+    import xml.etree.ElementTree as ET
+    import torch
+    from PIL import Image
+    from cald_amd import voc_utils as vu
+    g = golden("voc_utils")
+    assert tuple(str(c) for c in g["classes"]) == vu.ConvertVOCtoCOCO.CLASSES
+    n = int(g["n"])
+    base = tmp_path / "VOCdevkit" / "VOC2012"
+    for d in ("ImageSets/Main", "Annotations", "JPEGImages"):
+        (base / d).mkdir(parents=True)
+    stems = []
+    rs = np.random.RandomState(0)
+    for i in range(n):
+        xml = str(g["xml_%d" % i])
+        anno = vu.parse_voc_xml(ET.fromstring(xml))["annotation"]
+        assert isinstance(anno["object"], list)
+        if bool(g["bare_%d" % i]):
+            anno["object"] = anno["object"][0]
+        _, t = vu.ConvertVOCtoCOCO()("img", dict(image_id=i, annotations=anno))
+        for k, dt in (("boxes", torch.float32), ("labels", torch.int64), ("ishard", torch.int64), ("name", torch.int8)):
+            assert t[k].dtype == dt
+            np.testing.assert_array_equal(t[k].numpy(), g["%s_%d" % (k, i)])
+        stem = "".join(chr(int(c)) for c in g["name_%d" % i])
+        stems.append(stem)
+        (base / "Annotations" / (stem + ".xml")).write_text(xml)
+        Image.fromarray(rs.randint(0, 256, (20 + i, 30, 3), dtype=np.uint8)).save(str(base / "JPEGImages" / (stem + ".jpg")), quality=90)
+    (base / "ImageSets" / "Main" / "trainval.txt").write_text("".join(s + "\n" for s in stems))
+    ds = vu.get_voc2012(str(tmp_path), "trainval", vu.ToTensor())
+    assert len(ds) == n and ds.root == str(tmp_path) and ds.image_set == "trainval"
+    assert ds._transforms.transforms[0].CLASSES == vu.VOC_CLASSES
+    for i in (0, 7, n - 1):
+        img, t = ds[i]
+        assert img.dtype == torch.float32 and tuple(img.shape) == (3, 20 + i, 30) and float(img.max()) <= 1.0
+        t2 = ds.target(i)
+        for k in ("boxes", "labels", "ishard", "name"):
+            np.testing.assert_array_equal(t[k].numpy(), g["%s_%d" % (k, i)])
+            assert torch.equal(t[k], t2[k])
+    labeled = ds.label_loader([1, 2, 3])
+    assert [int(x) for _, (t,) in labeled for x in t["labels"]] == [int(x) for i in (1, 2, 3) for x in g["labels_%d" % i]]

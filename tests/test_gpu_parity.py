@@ -905,3 +905,65 @@ def test_config4_full_size_i8x3_matrix_pipe_mode(hip, oracle):
     print("i8x3 vs exact fp32, configs[4] shapes, 8 images: max |d consistency| %.3g, median %.3g" % (d.max(), np.median(d)))
     # not bit-identical to fp32 (nothing but the exact mode is): a borderline detection that flips moves an image by ~1e-2
     assert float(np.median(d)) < 1e-2 and float(d.max()) < 0.5, d
+
+
+def test_selection_cycle_from_a_vocdevkit_directory(hip, oracle, small_model, tmp_path):
+    """a VOCdevkit tree on disk -> cald_amd.voc_utils dataset -> JPEGs decoded once on the GPU into the
+    resident pool -> sweep -> class-balanced selection with the labeled set's annotation histogram -> voc_evaluate over the
+    resident test loader.  The oracle walks the same files on the CPU (its own JPEG decoder, its own forward); scores,
+    selection and results files must be identical."""
+    import os
+    from PIL import Image
+    torch = hip["torch"]
+    from cald_amd import synth, sweep, engine, voc_utils as vu
+    model, P = small_model
+    imgs = synth.make_pool(10, "voc", 3, scale=0.5)
+    base = tmp_path / "VOCdevkit" / "VOC2007"
+    for d in ("ImageSets/Main", "Annotations", "JPEGImages"):
+        (base / d).mkdir(parents=True)
+    stems = ["%06d" % (13 * i + 5) for i in range(len(imgs))]
+    rs = np.random.RandomState(2)
+    for i, (im, stem) in enumerate(zip(imgs, stems)):
+        Image.fromarray(im).save(str(base / "JPEGImages" / (stem + ".jpg")), quality=92, subsampling=(0, 1, 2)[i % 3])
+        H, W = im.shape[:2]
+        objs = ""
+        for _ in range(1 + i % 3):
+            x0, y0 = int(rs.randint(1, W // 2)), int(rs.randint(1, H // 2))
+            objs += ("<object><name>%s</name><difficult>0</difficult><bndbox><xmin>%d</xmin><ymin>%d</ymin><xmax>%d</xmax><ymax>%d</ymax>"
+                     "</bndbox></object>" % (vu.VOC_CLASSES[1 + (i * 3) % 20], x0, y0, x0 + W // 3, y0 + H // 3))
+        (base / "Annotations" / (stem + ".xml")).write_text("<annotation><filename>%s.jpg</filename>%s</annotation>" % (stem, objs))
+    (base / "ImageSets" / "Main" / "trainval.txt").write_text("".join(s + "\n" for s in stems))
+    ds = vu.get_voc2007(str(tmp_path), "trainval", None)
+    labeled_idx, unlabeled_idx = [0, 1, 2], list(range(3, len(ds)))
+    augs = ["flip", "cut_out", "smaller_resize"]
+
+    pool = ds.device_pool(unlabeled_idx)
+    decoded = [oracle.jpeg_decode(open(ds.images[i], "rb").read()) for i in unlabeled_idx]
+    for k, want in enumerate(decoded):
+        np.testing.assert_array_equal(pool[k].cpu().numpy(), want)
+        np.testing.assert_array_equal(want, np.asarray(Image.open(ds.images[unlabeled_idx[k]]).convert("RGB")))
+    unc, cls = sweep.get_uncertainty(model, pool.loader(), augs, 21, bp=1.3, base_seed=5)
+    wc, wcls = oracle.get_uncertainty(P, decoded, augs, 21, bp=1.3, min_size=300, max_size=500, base_seed=5)
+    assert unc == wc
+    np.testing.assert_array_equal(np.stack(cls), np.stack(wcls))
+    labeled = ds.label_loader(labeled_idx)
+    got = sweep.select(unc, cls, labeled, budget=3, mr=1.7)
+    want = sweep.select(wc, wcls, labeled, budget=3, mr=1.7)
+    np.testing.assert_array_equal(got, want)
+    assert len(set(int(unlabeled_idx[p]) for p in got)) == 3
+
+    # the evaluation consumer over the same tree: resident test loader with the converted targets
+    res = engine.voc_evaluate(model, ds.resident_loader(), "2007", path="hip", root=str(tmp_path), batch_views=4)
+    want_boxes = [[] for _ in vu.VOC_CLASSES]
+    for i in range(len(ds)):
+        o = oracle.frcnn_forward(P, oracle.jpeg_decode(open(ds.images[i], "rb").read()), 300, 500)
+        per = [[] for _ in vu.VOC_CLASSES]
+        for k in range(o["boxes"].shape[0]):
+            per[int(o["labels"][k])].append(torch.cat([torch.from_numpy(o["boxes"][k]), torch.tensor([o["scores"][k]])]))
+        for c in range(len(vu.VOC_CLASSES)):
+            want_boxes[c].append([torch.stack(per[c])] if per[c] else [])
+    engine.write_voc_results_file(want_boxes, stems, "orc", vu.VOC_CLASSES, root=str(tmp_path))
+    for c in vu.VOC_CLASSES[1:]:
+        assert open(os.path.join(str(tmp_path), "hip", "det_test_%s.txt" % c)).read() == \
+            open(os.path.join(str(tmp_path), "orc", "det_test_%s.txt" % c)).read(), c
+    assert len(res["ap_per_class"]) == 20
