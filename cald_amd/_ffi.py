@@ -88,6 +88,20 @@ SIGNATURES = {
     "cald_profile_read": (C.c_int, [C.c_void_p, c_d, c_d, c_i64, c_d]),
     "cald_profile_roi_rows": (C.c_int, [C.c_void_p, c_d, c_i64]),
     "cald_profile_dump": (C.c_int, [C.c_void_p, C.c_char_p]),
+    # training step (device pointers as c_void_p)
+    "cald_train_packed_floats": (C.c_int, [C.c_int] * 6 + [c_i64]),
+    "cald_train_pack_conv": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 6 + [C.c_void_p]),
+    "cald_train_conv": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p] + [C.c_int] * 8
+                        + [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]),
+    "cald_train_conv_wgrad": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
+    "cald_train_linear_wgrad": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                          C.c_void_p, C.c_void_p, C.c_int]),
+    "cald_train_relu_bwd": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cald_train_add": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cald_train_dilate": (C.c_int, [C.c_void_p] + [C.c_int] * 7 + [C.c_void_p, C.c_void_p]),
+    "cald_train_upsample_bwd": (C.c_int, [C.c_void_p] + [C.c_int] * 6 + [C.c_void_p, C.c_void_p]),
+    "cald_train_sgd": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_int]),
 }
 
 

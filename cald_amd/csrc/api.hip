@@ -32,6 +32,7 @@ int cald_internal_fail(int code, const char* fmt, ...) {
     return code;
 }
 hipStream_t cald_internal_stream(cald_ctx* c);
+void cald_internal_train_release(cald_ctx* c);   // train.hip: per-context geometry cache
 
 extern "C" const char* cald_last_error(void) { return g_err; }
 extern "C" int cald_version(void) { return 100; }
@@ -63,6 +64,7 @@ struct cald_ctx {
     // MEASURED rows, accumulated on the device while profiling (no host sync inside a forward)
     unsigned long long* d_roi_rows = nullptr; double prof_roi_rows_cap = 0.0, prof_roi_flops_cap = 0.0; long long prof_roi_views = 0;
     std::map<PilKey, PilCoef> pil;
+    char* train_scratch = nullptr; size_t train_scratch_cap = 0;   // train.hip: split-K partial tiles of the weight gradients
 };
 
 __global__ void accumulate_rows_kernel(const int* __restrict__ counts, int V, unsigned long long* acc) {
@@ -73,6 +75,21 @@ __global__ void accumulate_rows_kernel(const int* __restrict__ counts, int V, un
 }
 
 hipStream_t cald_internal_stream(cald_ctx* c) { return c->stream; }
+int cald_internal_device(cald_ctx* c) { return c->device; }
+const float* cald_internal_zeros(cald_ctx* c) { return c->d_zeros; }
+// grow-only scratch shared by the calls of one context; every user is ordered on the context stream
+int cald_internal_scratch(cald_ctx* c, size_t bytes, void** out) {
+    if (bytes > c->train_scratch_cap) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (c->train_scratch) HIPCHK(hipFree(c->train_scratch));
+        c->train_scratch = nullptr; c->train_scratch_cap = 0;
+        const size_t want = bytes + (bytes >> 2);
+        HIPCHK(hipMalloc((void**)&c->train_scratch, want));
+        c->train_scratch_cap = want;
+    }
+    *out = c->train_scratch;
+    return 0;
+}
 
 static int arena_reserve(cald_ctx* c, size_t bytes) {
     if (bytes <= c->arena_cap) return 0;
@@ -149,6 +166,8 @@ extern "C" int cald_ctx_destroy(cald_ctx* c) {
     if (c->tot0) hipEventDestroy(c->tot0);
     if (c->tot1) hipEventDestroy(c->tot1);
     if (c->arena) hipFree(c->arena);
+    if (c->train_scratch) hipFree(c->train_scratch);
+    cald_internal_train_release(c);
     for (int i = 0; i < cald_ctx::NSTAGE; i++) { if (c->h_stage[i]) hipHostFree(c->h_stage[i]); if (c->stage_ev[i]) hipEventDestroy(c->stage_ev[i]); }
     hipFree(c->d_plan); hipFree(c->d_views); hipFree(c->d_zeros); hipFree(c->d_roi_rows);
     if (c->own_stream) hipStreamDestroy(c->stream);
@@ -372,18 +391,6 @@ struct cald_model {
     signed char* i8_scratch = nullptr; size_t i8_cap = 0, i8_off = 0;   // digit-plane scratch of the running forward
     int key_cap = 32768;   // FRCNN candidate (proposal, class) list capacity per view, sized from box_score_thresh at create
 };
-
-static int round_up(int x, int m) { return (x + m - 1) / m * m; }
-// Position of input element (tap = kh*KW + kw, channel ci) in the k-ordered fma chain (DESIGN.md arithmetic contract).
-//   Cin % 16 == 0:  (channel chunk of 16, kh, kw, channel inside the chunk) -- all taps of a 16-channel chunk are consecutive
-//                   k-tiles, so the nine passes of a 3x3 filter re-touch the same 64-byte pixel segments while they are still
-//                   in L2 (with cin innermost over the whole channel vector every tap re-streamed the tensor from HBM);
-//   otherwise (or more than 32 taps: the tap-validity mask is 32 bits):  (kh, kw, cin), e.g. the 4-channel stem.
-// For 1x1 layers and linear layers both orders are the plain channel order.
-static inline int conv_k_index(int tap, int ci, int taps, int cinp) {
-    return (cinp % 16 == 0 && taps <= 32) ? ((ci >> 4) * taps + tap) * 16 + (ci & 15) : tap * cinp + ci;
-}
-static int cout_pad(int cout) { return cout >= 128 ? round_up(cout, 128) : (cout >= 64 ? round_up(cout, 64) : round_up(cout, 32)); }
 
 extern "C" int cald_model_create(cald_ctx* ctx, const cald_model_cfg* cfg, cald_model** out) {
     if (!ctx || !cfg || !out) return fail(CALD_ERR_INVALID, "null argument");

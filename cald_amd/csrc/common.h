@@ -67,6 +67,18 @@ struct ConvGroup {
     ConvArgs p[CALD_MAX_GROUP];
 };
 
+// Position of input element (tap = kh*KW + kw, channel ci) in the k-ordered fma chain (DESIGN.md arithmetic contract).
+//   Cin % 16 == 0:  (channel chunk of 16, kh, kw, channel inside the chunk) -- all taps of a 16-channel chunk are consecutive
+//                   k-tiles, so the nine passes of a 3x3 filter re-touch the same 64-byte pixel segments while they are still
+//                   in L2 (with cin innermost over the whole channel vector every tap re-streamed the tensor from HBM);
+//   otherwise (or more than 32 taps: the tap-validity mask is 32 bits):  (kh, kw, cin), e.g. the 4-channel stem.
+// For 1x1 layers and linear layers both orders are the plain channel order.
+__host__ __device__ inline int conv_k_index(int tap, int ci, int taps, int cinp) {
+    return (cinp % 16 == 0 && taps <= 32) ? ((ci >> 4) * taps + tap) * 16 + (ci & 15) : tap * cinp + ci;
+}
+__host__ __device__ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+__host__ __device__ inline int cout_pad(int cout) { return cout >= 128 ? round_up(cout, 128) : (cout >= 64 ? round_up(cout, 64) : round_up(cout, 32)); }
+
 // ---------------------------------------------------------------------------------------------
 // Deterministic float32 elementary functions (DESIGN.md "arithmetic contract"): fixed fmaf
 // polynomials, built with -ffp-contract=off so that every fused multiply-add is explicit.

@@ -1,0 +1,459 @@
+// train.hip -- the training step of the detector (cald_train.py:40-74 train_one_epoch ->
+// task_model(images, targets) / losses.backward() / optimizer.step(); the arithmetic the reference delegates to
+// torchvision 0.8.2 + cuDNN/cuBLAS autograd).
+//
+// Operator-level C ABI on device pointers (the host side that strings them into the Faster R-CNN training graph is
+// cald_amd/train.py).  Activations are dense NHWC batches [N][H][W][C] (torchvision pads a training batch to one common
+// size, GeneralizedRCNNTransform.batch_images).
+//
+//   forward conv / linear      the inference kernels (conv_p4.hip / conv_mfma.hip) on weights packed ON THE DEVICE from the
+//                              torch-layout parameter tensor every step (pack_weight_kernel)
+//   data gradient              the same kernels on the spatially flipped, channel-transposed filter (mode 1 of the packer);
+//                              stride-2 layers first scatter dY onto the stride-1 grid (dilate_kernel)
+//   weight gradient            wgrad_kernel: GEMM  dW[co][(tap, ci)] = sum over output pixels  dY[q][co] * X[q @ tap][ci]
+//                              on v_mfma_f32_32x32x2_f32; both operands are read in their natural NHWC order (the channel
+//                              index is the MFMA row / column, the pixel index is k: no transposes), staged through LDS,
+//                              pixels split over workgroups, partial tiles summed in a fixed order (deterministic)
+//   RoIAlign forward/backward  roi_align_train_kernel / roi_align_bwd_kernel (bilinear weights scattered with atomics)
+//   losses                     softmax cross-entropy, smooth-L1, binary cross-entropy with logits: value + gradient in one pass
+//   optimizer                  sgd_kernel: torch.optim.SGD (weight decay, momentum, no dampening / nesterov) over the flat
+//                              parameter buffer
+#include "common.h"
+#include "kernels.h"
+#include "sortnms.h"
+#include "../../include/cald_hip.h"
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
+
+int cald_internal_fail(int code, const char* fmt, ...);
+hipStream_t cald_internal_stream(cald_ctx* c);
+int cald_internal_device(cald_ctx* c);
+const float* cald_internal_zeros(cald_ctx* c);
+int cald_internal_scratch(cald_ctx* c, size_t bytes, void** out);   // grow-only per-context device scratch (stream-ordered reuse)
+
+#define TFAIL(code, ...) return cald_internal_fail(code, __VA_ARGS__)
+#define THIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return cald_internal_fail(CALD_ERR_HIP, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------------------------------------------------
+// dense-batch geometry: N equal views of H x W, cached on the device per (context, N, H, W)
+// ---------------------------------------------------------------------------------------------------------------------
+static std::mutex g_seg_mu;
+static std::map<std::tuple<cald_ctx*, int, int, int>, LevelSeg*> g_seg;
+static int dense_seg(cald_ctx* c, int N, int H, int W, const LevelSeg** out) {
+    std::lock_guard<std::mutex> lk(g_seg_mu);
+    auto key = std::make_tuple(c, N, H, W);
+    auto it = g_seg.find(key);
+    if (it == g_seg.end()) {
+        std::vector<LevelSeg> h(N + 1);
+        const int tiles = (H * W + 127) / 128;
+        for (int v = 0; v <= N; v++) { h[v].pix_off = (long long)v * H * W; h[v].H = H; h[v].W = W; h[v].tile_start = v * tiles; h[v].pad_ = 0; }
+        LevelSeg* d = nullptr;
+        THIP(hipMalloc((void**)&d, sizeof(LevelSeg) * (N + 1)));
+        THIP(hipMemcpy(d, h.data(), sizeof(LevelSeg) * (N + 1), hipMemcpyHostToDevice));
+        it = g_seg.emplace(key, d).first;
+    }
+    *out = it->second;
+    return 0;
+}
+
+void cald_internal_train_release(cald_ctx* c) {
+    std::lock_guard<std::mutex> lk(g_seg_mu);
+    for (auto it = g_seg.begin(); it != g_seg.end();) {
+        if (std::get<0>(it->first) == c) { hipFree(it->second); it = g_seg.erase(it); } else ++it;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// weight packing on the device
+// ---------------------------------------------------------------------------------------------------------------------
+// mode 0: forward      K rows = (tap, ci) of a Cin_k-channel input (Cin_k >= Cin, the input buffer's channel stride), N = Cout
+// mode 1: data grad    K rows = (flipped tap, co) of a Cin_k-channel dY (Cin_k >= Cout),                      N = Cin
+// mode 2: forward of a linear layer whose torch weight is [Cout][Cin][taps] (fc6: [1024][256][7*7]) applied to rows laid out
+//         [tap][Cin] (the RoIAlign output [R][49][256]): K rows = tap * Cin + ci
+struct PackArgs { const float* w; float* wk; float* w4; int Cout, Cin, taps, CinK, Kpad, NPad, mode; };
+__global__ void pack_weight_kernel(PackArgs a) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)a.Kpad * a.NPad) return;
+    const int k = (int)(i / a.NPad), n = (int)(i - (long long)k * a.NPad);
+    int tap, ci;
+    if (a.mode == 2) { tap = k / a.Cin; ci = k - tap * a.Cin; }
+    else if (a.CinK % 16 == 0 && a.taps <= 32) { const int chunk = k / (16 * a.taps), rem = k - chunk * 16 * a.taps; tap = rem >> 4; ci = chunk * 16 + (rem & 15); }
+    else { tap = k / a.CinK; ci = k - tap * a.CinK; }
+    float v = 0.0f;
+    if (a.mode == 1) {
+        if (tap < a.taps && ci < a.Cout && n < a.Cin) v = a.w[((long long)ci * a.Cin + n) * a.taps + (a.taps - 1 - tap)];
+    } else {
+        if (tap < a.taps && ci < a.Cin && n < a.Cout) v = a.w[((long long)n * a.Cin + ci) * a.taps + tap];
+    }
+    a.wk[i] = v;
+    const int kt = k >> 4, kk = k & 15, kq = kk >> 3, j = (kk & 7) >> 1, h = kk & 1;
+    a.w4[(((long long)(kt * 2 + kq) * a.NPad + n) * 2 + h) * 4 + j] = v;
+}
+__global__ void pack_vec_kernel(const float* src, int n, float* dst, int npad) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < npad) dst[i] = (src && i < n) ? src[i] : 0.0f;
+}
+
+struct PackGeom { int K, Kpad, NPad, n_true, cin_conv; long long floats; };
+static PackGeom pack_geom(int Cout, int Cin, int KH, int KW, int CinK, int mode) {
+    PackGeom g;
+    const int taps = KH * KW;
+    if (mode == 2) { g.K = taps * Cin; g.n_true = Cout; g.cin_conv = taps * Cin; }
+    else { g.K = taps * CinK; g.n_true = mode == 1 ? Cin : Cout; g.cin_conv = CinK; }
+    g.Kpad = round_up(g.K, 16);
+    g.NPad = cout_pad(g.n_true);
+    g.floats = 2ll * g.Kpad * g.NPad + 3ll * g.NPad;
+    return g;
+}
+extern "C" int cald_train_packed_floats(int Cout, int Cin, int KH, int KW, int CinK, int mode, int64_t* floats_out) {
+    if (!floats_out || Cout < 1 || Cin < 1 || KH < 1 || KW < 1 || mode < 0 || mode > 2) TFAIL(CALD_ERR_INVALID, "bad arguments");
+    *floats_out = pack_geom(Cout, Cin, KH, KW, CinK, mode).floats;
+    return 0;
+}
+extern "C" int cald_train_pack_conv(cald_ctx* c, const float* w, const float* bias, const float* scale, const float* shift,
+                                    int Cout, int Cin, int KH, int KW, int CinK, int mode, float* packed) {
+    if (!c || !w || !packed) TFAIL(CALD_ERR_INVALID, "null argument");
+    if (mode < 0 || mode > 2) TFAIL(CALD_ERR_INVALID, "mode must be 0 (forward), 1 (data gradient) or 2 (tap-major linear)");
+    if (mode != 2 && (CinK % 4 || CinK < (mode == 1 ? Cout : Cin))) TFAIL(CALD_ERR_INVALID, "CinK must be a multiple of 4 and cover the contracted channels");
+    THIP(hipSetDevice(cald_internal_device(c)));
+    const PackGeom g = pack_geom(Cout, Cin, KH, KW, CinK, mode);
+    PackArgs a{w, packed, packed + (long long)g.Kpad * g.NPad, Cout, Cin, KH * KW, CinK, g.Kpad, g.NPad, mode};
+    hipStream_t st = cald_internal_stream(c);
+    const long long n = (long long)g.Kpad * g.NPad;
+    hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+    float* vec = packed + 2 * n;
+    const int nt = g.n_true, blocks = (g.NPad + 255) / 256;
+    hipLaunchKernelGGL(pack_vec_kernel, dim3(blocks), dim3(256), 0, st, mode == 1 ? nullptr : bias, nt, vec, g.NPad);
+    hipLaunchKernelGGL(pack_vec_kernel, dim3(blocks), dim3(256), 0, st, mode == 1 ? nullptr : scale, nt, vec + g.NPad, g.NPad);
+    hipLaunchKernelGGL(pack_vec_kernel, dim3(blocks), dim3(256), 0, st, mode == 1 ? nullptr : shift, nt, vec + 2 * g.NPad, g.NPad);
+    THIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// forward conv / linear / data gradient: the inference kernels on a dense batch
+// ---------------------------------------------------------------------------------------------------------------------
+// in  [N][H][W][CinK];  out [N][Ho][Wo][out_ld] (channels >= Cout of a row are not written);  residual: same geometry as out
+// with row stride Cout... (out_ld == Cout required when residual / up is given);  up: [N][Hup][Wup][Cout] nearest-upsampled and added.
+// flags: bit 0 bias, bit 1 scale/shift (FrozenBatchNorm), bit 2 ReLU.  mode as in cald_train_pack_conv (the packed buffer's).
+extern "C" int cald_train_conv(cald_ctx* c, int N, int H, int W, const float* in, int CinK, const float* packed, int Cout, int Cin,
+                               int KH, int KW, int stride, int pad, int mode, int flags, const float* residual, const float* up,
+                               int Hup, int Wup, float* out, int out_ld) {
+    if (!c || !in || !packed || !out) TFAIL(CALD_ERR_INVALID, "null argument");
+    if (N < 1 || H < 1 || W < 1 || stride < 1) TFAIL(CALD_ERR_INVALID, "bad geometry");
+    THIP(hipSetDevice(cald_internal_device(c)));
+    const PackGeom g = pack_geom(Cout, Cin, KH, KW, CinK, mode);
+    const int kh = mode == 2 ? 1 : KH, kw = mode == 2 ? 1 : KW;
+    const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
+    if (Ho < 1 || Wo < 1) TFAIL(CALD_ERR_INVALID, "empty output");
+    if ((residual || up) && out_ld != g.n_true) TFAIL(CALD_ERR_INVALID, "residual / upsample-add need out_ld == Cout");
+    if (out_ld < g.n_true) TFAIL(CALD_ERR_INVALID, "out_ld < Cout");
+    const LevelSeg *si, *so, *su = nullptr;
+    if (int rc = dense_seg(c, N, H, W, &si)) return rc;
+    if (int rc = dense_seg(c, N, Ho, Wo, &so)) return rc;
+    if (up) { if (int rc = dense_seg(c, N, Hup, Wup, &su)) return rc; }
+    const long long n = (long long)g.Kpad * g.NPad;
+    ConvArgs a; memset(&a, 0, sizeof(a));
+    a.in = in; a.out = out; a.w = packed; a.w4 = packed + n;
+    const float* vec = packed + 2 * n;
+    a.bias = (flags & 1) ? vec : nullptr; a.scale = (flags & 2) ? vec + g.NPad : nullptr; a.shift = (flags & 2) ? vec + 2 * g.NPad : nullptr;
+    a.residual = residual; a.up = up; a.seg_in = si; a.seg_out = so; a.seg_up = up ? su : so;
+    a.V = N; a.Cin = g.cin_conv; a.Cout = g.n_true; a.CoutPad = g.NPad; a.Kpad = g.Kpad; a.KH = kh; a.KW = kw; a.stride = stride; a.pad = pad;
+    a.relu = (flags & 4) ? 1 : 0; a.total_mtiles = N * ((Ho * Wo + 127) / 128); a.out_ld = out_ld; a.zeros = cald_internal_zeros(c);
+    launch_conv(a, cald_internal_stream(c));
+    THIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// weight gradient
+// ---------------------------------------------------------------------------------------------------------------------
+struct WgradArgs {
+    const float* x; const float* g; float* partial;
+    int N, H, W, Cin, ldx;
+    int Ho, Wo, Cout, ldg;
+    int KH, KW, stride, pad;
+    int J, JT, MT;
+    long long Q, chunk;
+};
+// grid (MT * JT, S), 256 threads = 4 waves (2 x 2), tile 128 (co) x 128 (j = tap * Cin + ci) x 16 output pixels per stage
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
+    __shared__ __attribute__((aligned(16))) float sA[2][16][128];
+    __shared__ __attribute__((aligned(16))) float sB[2][16][128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int mt = blockIdx.x / a.JT, jt = blockIdx.x - mt * a.JT;
+    const int m0 = mt * 128, j0 = jt * 128;
+    const long long q0 = (long long)blockIdx.y * a.chunk;
+    long long q1 = q0 + a.chunk; if (q1 > a.Q) q1 = a.Q;
+    const int col4 = (tid & 31) * 4, row = tid >> 5;          // this thread stages rows row, row + 8 of both tiles
+    // B column (fixed for the whole kernel): j -> (tap, ci)
+    const int j = j0 + col4;
+    const bool jvalid = j < a.J;
+    const int tap = jvalid ? j / a.Cin : 0, ci = j - tap * a.Cin;
+    const int ky = tap / a.KW, kx = tap - ky * a.KW;
+    const bool mvalid = m0 + col4 < a.ldg;
+    // pixel cursors of the two staged rows
+    int pn[2], py[2], px[2];
+    long long pq[2];
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        pq[r] = q0 + row + 8 * r;
+        const long long hw = (long long)a.Ho * a.Wo;
+        pn[r] = (int)(pq[r] / hw);
+        const int rem = (int)(pq[r] - (long long)pn[r] * hw);
+        py[r] = rem / a.Wo; px[r] = rem - py[r] * a.Wo;
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int jn = 0; jn < 2; jn++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][jn][r] = 0.0f;
+    float4 ra[2], rb[2];
+    auto load = [&]() {
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            ra[r] = make_float4(0.f, 0.f, 0.f, 0.f); rb[r] = ra[r];
+            if (pq[r] < q1) {
+                if (mvalid) ra[r] = *reinterpret_cast<const float4*>(a.g + pq[r] * a.ldg + m0 + col4);
+                const int iy = py[r] * a.stride + ky - a.pad, ix = px[r] * a.stride + kx - a.pad;
+                if (jvalid && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
+                    rb[r] = *reinterpret_cast<const float4*>(a.x + (((long long)pn[r] * a.H + iy) * a.W + ix) * a.ldx + ci);
+            }
+            // advance the cursor by one stage (16 pixels)
+            pq[r] += 16; px[r] += 16;
+            while (px[r] >= a.Wo) { px[r] -= a.Wo; if (++py[r] >= a.Ho) { py[r] = 0; pn[r]++; } }
+        }
+    };
+    auto store = [&](int buf) {
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            *reinterpret_cast<float4*>(&sA[buf][row + 8 * r][col4]) = ra[r];
+            *reinterpret_cast<float4*>(&sB[buf][row + 8 * r][col4]) = rb[r];
+        }
+    };
+    const int stages = (int)((q1 - q0 + 15) / 16);
+    if (stages > 0) { load(); store(0); }
+    __syncthreads();
+    const int kl = lane >> 5, cl = lane & 31;
+    for (int s = 0; s < stages; s++) {
+        const int buf = s & 1;
+        if (s + 1 < stages) load();
+#pragma unroll
+        for (int ks = 0; ks < 8; ks++) {
+            const float a0 = sA[buf][2 * ks + kl][wm * 64 + cl], a1 = sA[buf][2 * ks + kl][wm * 64 + 32 + cl];
+            const float b0 = sB[buf][2 * ks + kl][wn * 64 + cl], b1 = sB[buf][2 * ks + kl][wn * 64 + 32 + cl];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (s + 1 < stages) store(buf ^ 1);
+        __syncthreads();
+    }
+    // partial tile -> partial[S][MT*128][JT*128]
+    const long long ldp = (long long)a.JT * 128;
+    float* P = a.partial + (long long)blockIdx.y * ((long long)a.MT * 128) * ldp;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int jn = 0; jn < 2; jn++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int rr = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
+                const int cc = j0 + wn * 64 + jn * 32 + cl;
+                P[(long long)rr * ldp + cc] = acc[i][jn][r];
+            }
+}
+// grad[co][ci][tap] (torch layout) (+)= sum over splits, in split order
+__global__ void wgrad_reduce_kernel(const float* partial, int S, long long split_stride, long long ldp, int Cout, int Cin, int taps,
+                                    float* grad, int accumulate) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long J = (long long)taps * Cin;
+    if (i >= (long long)Cout * J) return;
+    const int co = (int)(i / J); const int j = (int)(i - (long long)co * J);
+    const int tap = j / Cin, ci = j - tap * Cin;
+    float s = 0.0f;
+    for (int k = 0; k < S; k++) s += partial[(long long)k * split_stride + (long long)co * ldp + j];
+    float* dst = grad + ((long long)co * Cin + ci) * taps + tap;
+    *dst = accumulate ? *dst + s : s;
+}
+// db[c] = sum over rows of g[q][c]: stage 1 partial sums over row blocks, stage 2 fixed-order sum
+__global__ void colsum_partial_kernel(const float* g, long long Q, int C, int ld, long long rows_per_block, float* partial) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const long long q0 = (long long)blockIdx.y * rows_per_block;
+    long long q1 = q0 + rows_per_block; if (q1 > Q) q1 = Q;
+    float s = 0.0f;
+    for (long long q = q0; q < q1; q++) s += g[q * ld + c];
+    partial[(long long)blockIdx.y * C + c] = s;
+}
+__global__ void colsum_final_kernel(const float* partial, int S, int C, float* out, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.0f;
+    for (int k = 0; k < S; k++) s += partial[(long long)k * C + c];
+    out[c] = accumulate ? out[c] + s : s;
+}
+
+// x [N][H][W][ldx] (Cin channels used, Cin % 4 == 0), g [N][Ho][Wo][ldg] (Cout channels used; ldg % 4 == 0 and the pad channels
+// readable).  dw: torch layout [Cout][Cin][KH][KW]; for a tap-major linear layer pass KH*KW = taps, H = W = 1 and x rows
+// [R][taps * Cin] as N = R... (see cald_train_linear_wgrad).  db: [Cout] or null.
+static int wgrad_impl(cald_ctx* c, long long Q, int N, int H, int W, const float* x, int Cin, int ldx, int Ho, int Wo, const float* g,
+                      int Cout, int ldg, int KH, int KW, int stride, int pad, int red_taps, int red_cin, float* dw, float* db, int accumulate) {
+    if (Cin % 4 || ldx % 4 || ldg % 4) TFAIL(CALD_ERR_INVALID, "Cin and the row strides must be multiples of 4");
+    THIP(hipSetDevice(cald_internal_device(c)));
+    hipStream_t st = cald_internal_stream(c);
+    WgradArgs a; memset(&a, 0, sizeof(a));
+    a.x = x; a.g = g; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.ldx = ldx; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout; a.ldg = ldg;
+    a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.J = KH * KW * Cin; a.JT = (a.J + 127) / 128; a.MT = (Cout + 127) / 128; a.Q = Q;
+    const long long tiles = (long long)a.MT * a.JT;
+    const long long tile_floats = tiles * 128 * 128;
+    long long S = (2048 + tiles - 1) / tiles;
+    const long long maxS_rows = (Q + 255) / 256; if (S > maxS_rows) S = maxS_rows;
+    const long long cap = (512ll << 20) / 4 / tile_floats; if (S > cap) S = cap;
+    if (S < 1) S = 1;
+    a.chunk = ((Q + S - 1) / S + 15) / 16 * 16;
+    S = (Q + a.chunk - 1) / a.chunk;
+    const long long csplit = (Q + 1023) / 1024 > 256 ? 256 : (Q + 1023) / 1024;
+    void* scratch = nullptr;
+    if (int rc = cald_internal_scratch(c, (size_t)(S * tile_floats + csplit * Cout + 64) * 4, &scratch)) return rc;
+    a.partial = (float*)scratch;
+    hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)tiles, (unsigned)S), dim3(256), 0, st, a);
+    const long long nred = (long long)Cout * a.J;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nred + 255) / 256)), dim3(256), 0, st, a.partial, (int)S, tile_floats,
+                       (long long)a.JT * 128, Cout, red_cin, red_taps, dw, accumulate);
+    if (db) {
+        float* cp = a.partial + S * tile_floats;
+        const long long rpb = (Q + csplit - 1) / csplit;
+        hipLaunchKernelGGL(colsum_partial_kernel, dim3((Cout + 63) / 64, (unsigned)csplit), dim3(64), 0, st, g, Q, Cout, ldg, rpb, cp);
+        hipLaunchKernelGGL(colsum_final_kernel, dim3((Cout + 63) / 64), dim3(64), 0, st, cp, (int)csplit, Cout, db, accumulate);
+    }
+    THIP(hipGetLastError());
+    return 0;
+}
+extern "C" int cald_train_conv_wgrad(cald_ctx* c, int N, int H, int W, const float* x, int Cin, int ldx, const float* g, int Cout, int ldg,
+                                     int KH, int KW, int stride, int pad, float* dw, float* db, int accumulate) {
+    if (!c || !x || !g || !dw) TFAIL(CALD_ERR_INVALID, "null argument");
+    const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+    if (N < 1 || Ho < 1 || Wo < 1) TFAIL(CALD_ERR_INVALID, "bad geometry");
+    return wgrad_impl(c, (long long)N * Ho * Wo, N, H, W, x, Cin, ldx, Ho, Wo, g, Cout, ldg, KH, KW, stride, pad, KH * KW, Cin, dw, db, accumulate);
+}
+// linear layer on rows: x [R][K], g [R][ldg] -> dw [Cout][K] torch layout; taps > 1: rows are [tap][K / taps] and the torch
+// weight is [Cout][K / taps][taps] (fc6 on the RoIAlign output)
+extern "C" int cald_train_linear_wgrad(cald_ctx* c, int R, const float* x, int K, const float* g, int Cout, int ldg, int taps,
+                                       float* dw, float* db, int accumulate) {
+    if (!c || !x || !g || !dw) TFAIL(CALD_ERR_INVALID, "null argument");
+    if (R < 1 || taps < 1 || K % taps) TFAIL(CALD_ERR_INVALID, "bad geometry");
+    return wgrad_impl(c, R, 1, 1, R, x, K, K, 1, R, g, Cout, ldg, 1, 1, 1, 0, taps, K / taps, dw, db, accumulate);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// elementwise pieces of the backward pass
+// ---------------------------------------------------------------------------------------------------------------------
+// g[q][c] = (act[q][c] > 0 ? g[q][c] : 0) * (scale ? scale[c] : 1): ReLU backward (act = the layer's post-ReLU output) and
+// the FrozenBatchNorm scale in one pass.  act == null: scale only.
+__global__ void relu_bwd_kernel(float* g, const float* act, const float* scale, long long n4, int C4) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    float4 v = reinterpret_cast<float4*>(g)[i];
+    if (act) { const float4 y = reinterpret_cast<const float4*>(act)[i]; if (!(y.x > 0.f)) v.x = 0.f; if (!(y.y > 0.f)) v.y = 0.f; if (!(y.z > 0.f)) v.z = 0.f; if (!(y.w > 0.f)) v.w = 0.f; }
+    if (scale) { const float4 s = reinterpret_cast<const float4*>(scale)[i % C4]; v.x *= s.x; v.y *= s.y; v.z *= s.z; v.w *= s.w; }
+    reinterpret_cast<float4*>(g)[i] = v;
+}
+extern "C" int cald_train_relu_bwd(cald_ctx* c, long long rows, int C, float* g, const float* act, const float* scale) {
+    if (!c || !g || C % 4) TFAIL(CALD_ERR_INVALID, "bad arguments (C must be a multiple of 4)");
+    THIP(hipSetDevice(cald_internal_device(c)));
+    const long long n4 = rows * C / 4;
+    if (n4 > 0) hipLaunchKernelGGL(relu_bwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, cald_internal_stream(c), g, act, scale, n4, C / 4);
+    THIP(hipGetLastError());
+    return 0;
+}
+// dst = a + b (b may be null: copy), float4 granularity
+__global__ void add_kernel(float* dst, const float* a, const float* b, long long n4) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    float4 v = reinterpret_cast<const float4*>(a)[i];
+    if (b) { const float4 w = reinterpret_cast<const float4*>(b)[i]; v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w; }
+    reinterpret_cast<float4*>(dst)[i] = v;
+}
+extern "C" int cald_train_add(cald_ctx* c, long long n, float* dst, const float* a, const float* b) {
+    if (!c || !dst || !a || n % 4) TFAIL(CALD_ERR_INVALID, "bad arguments (n must be a multiple of 4)");
+    THIP(hipSetDevice(cald_internal_device(c)));
+    if (n > 0) hipLaunchKernelGGL(add_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, cald_internal_stream(c), dst, a, b, n / 4);
+    THIP(hipGetLastError());
+    return 0;
+}
+// stride-s data gradient, step 1: scatter g [N][Ho][Wo][C] onto the stride-1 grid [N][Hd][Wd][C] (zeros elsewhere), Hd = (Ho-1)*s+1 + extra
+__global__ void dilate_kernel(const float* g, float* out, int N, int Ho, int Wo, int Hd, int Wd, int C4, int s) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long n4 = (long long)N * Hd * Wd * C4;
+    if (i >= n4) return;
+    const int c = (int)(i % C4); long long p = i / C4;
+    const int x = (int)(p % Wd); p /= Wd; const int y = (int)(p % Hd); const int n = (int)(p / Hd);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (y % s == 0 && x % s == 0 && y / s < Ho && x / s < Wo) v = reinterpret_cast<const float4*>(g)[(((long long)n * Ho + y / s) * Wo + x / s) * C4 + c];
+    reinterpret_cast<float4*>(out)[i] = v;
+}
+extern "C" int cald_train_dilate(cald_ctx* c, int N, int Ho, int Wo, int C, int s, int Hd, int Wd, const float* g, float* out) {
+    if (!c || !g || !out || C % 4 || s < 1) TFAIL(CALD_ERR_INVALID, "bad arguments");
+    THIP(hipSetDevice(cald_internal_device(c)));
+    const long long n4 = (long long)N * Hd * Wd * (C / 4);
+    hipLaunchKernelGGL(dilate_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, cald_internal_stream(c), g, out, N, Ho, Wo, Hd, Wd, C / 4, s);
+    THIP(hipGetLastError());
+    return 0;
+}
+// FPN top-down backward: coarse[n][yc][xc][c] += sum of fine[n][yf][xf][c] over the fine pixels whose nearest source is (yc, xc)
+// (F.interpolate(size=fine, mode='nearest'): source = floor(dst * coarse / fine))
+__global__ void upsample_bwd_kernel(const float* fine, float* coarse, int N, int Hf, int Wf, int Hc, int Wc, int C4) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long n4 = (long long)N * Hc * Wc * C4;
+    if (i >= n4) return;
+    const int c = (int)(i % C4); long long p = i / C4;
+    const int xc = (int)(p % Wc); p /= Wc; const int yc = (int)(p % Hc); const int n = (int)(p / Hc);
+    // fine rows y with floor(y * Hc / Hf) == yc  <=>  y in [ceil(yc * Hf / Hc), ceil((yc + 1) * Hf / Hc))
+    const int y0 = (yc * Hf + Hc - 1) / Hc, y1 = ((yc + 1) * Hf + Hc - 1) / Hc;
+    const int x0 = (xc * Wf + Wc - 1) / Wc, x1 = ((xc + 1) * Wf + Wc - 1) / Wc;
+    float4 s = reinterpret_cast<float4*>(coarse)[i];
+    for (int y = y0; y < y1 && y < Hf; y++)
+        for (int x = x0; x < x1 && x < Wf; x++) {
+            const float4 v = reinterpret_cast<const float4*>(fine)[(((long long)n * Hf + y) * Wf + x) * C4 + c];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    reinterpret_cast<float4*>(coarse)[i] = s;
+}
+extern "C" int cald_train_upsample_bwd(cald_ctx* c, int N, int Hf, int Wf, int Hc, int Wc, int C, const float* fine, float* coarse) {
+    if (!c || !fine || !coarse || C % 4) TFAIL(CALD_ERR_INVALID, "bad arguments");
+    THIP(hipSetDevice(cald_internal_device(c)));
+    const long long n4 = (long long)N * Hc * Wc * (C / 4);
+    hipLaunchKernelGGL(upsample_bwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, cald_internal_stream(c), fine, coarse, N, Hf, Wf, Hc, Wc, C / 4);
+    THIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// optimizer: torch.optim.SGD(lr, momentum, weight_decay), dampening 0, no nesterov (cald_train.py:397)
+//   d = grad + wd * p;  buf = first ? d : momentum * buf + d;  p -= lr * buf
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void sgd_kernel(float* p, const float* grad, float* buf, long long n, float lr, float momentum, float wd, int first) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float d = grad[i];
+    if (wd != 0.0f) d = d + wd * p[i];
+    if (momentum != 0.0f) { const float b = first ? d : momentum * buf[i] + d; buf[i] = b; d = b; }
+    p[i] = p[i] - lr * d;
+}
+extern "C" int cald_train_sgd(cald_ctx* c, long long n, float* param, const float* grad, float* momentum_buf, float lr, float momentum,
+                              float weight_decay, int first_step) {
+    if (!c || !param || !grad || (momentum != 0.0f && !momentum_buf)) TFAIL(CALD_ERR_INVALID, "null argument");
+    THIP(hipSetDevice(cald_internal_device(c)));
+    if (n > 0) hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cald_internal_stream(c), param, grad, momentum_buf, n, lr, momentum, weight_decay, first_step);
+    THIP(hipGetLastError());
+    return 0;
+}

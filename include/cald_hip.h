@@ -216,6 +216,43 @@ int cald_profile_roi_rows(cald_ctx* ctx, double* mean_rows_per_view, int64_t* vi
 /* per-launch CSV (shape, algorithmic GFLOP, ms, TFLOP/s) of the launches recorded since cald_profile_enable */
 int cald_profile_dump(cald_ctx* ctx, const char* path);
 
+/* ---- training step: the device operators behind task_model(images, targets) / losses.backward() /
+ * optimizer.step() of cald_train.py:40-74 (detection/engine.py:19-61), which the reference delegates to torchvision 0.8.2 +
+ * cuDNN autograd.  cald_amd/train.py strings them into the Faster R-CNN training graph.  All pointers are DEVICE pointers,
+ * activations are dense NHWC batches [N][H][W][C], every call is asynchronous on the context stream. ---- */
+/* size in floats of the packed form of a torch-layout weight [Cout][Cin][KH][KW] (see cald_train_pack_conv) */
+int cald_train_packed_floats(int Cout, int Cin, int KH, int KW, int CinK, int mode, int64_t* floats_out);
+/* packs weight (+ optional bias / FrozenBatchNorm scale, shift: [Cout]) for the MFMA conv kernels, on the device.
+ *   mode 0  forward over an input whose channel stride is CinK >= Cin (multiple of 4; extra channels must be zero or finite)
+ *   mode 1  data gradient: the flipped, transposed filter applied to dY with channel stride CinK >= Cout
+ *   mode 2  linear layer on rows laid out [tap][Cin] whose torch weight is [Cout][Cin * taps] (box_head.fc6 on RoIAlign rows) */
+int cald_train_pack_conv(cald_ctx* ctx, const float* weight, const float* bias, const float* bn_scale, const float* bn_shift,
+                         int Cout, int Cin, int KH, int KW, int CinK, int mode, float* packed);
+/* out[N][Ho][Wo][out_ld] = epilogue(conv(in[N][H][W][CinK], packed)); flags: 1 bias, 2 scale/shift, 4 ReLU; residual (same
+ * shape as out) and up ([N][Hup][Wup][Cout], nearest-upsampled) are added before the ReLU.  With mode 1 the call computes the
+ * data gradient of a stride-1 conv (pad = K - 1 - forward pad); Cout / Cin are always those of the FORWARD weight. */
+int cald_train_conv(cald_ctx* ctx, int N, int H, int W, const float* in, int CinK, const float* packed, int Cout, int Cin,
+                    int KH, int KW, int stride, int pad, int mode, int flags, const float* residual, const float* up,
+                    int Hup, int Wup, float* out, int out_ld);
+/* dw[Cout][Cin][KH][KW] (=, or += when accumulate) sum over output pixels of g[q][co] * x[q @ tap][ci]; db[Cout] likewise (or
+ * null).  x [N][H][W][ldx], g [N][Ho][Wo][ldg]; Cin, ldx, ldg multiples of 4.  Deterministic (fixed-order split reduction). */
+int cald_train_conv_wgrad(cald_ctx* ctx, int N, int H, int W, const float* x, int Cin, int ldx, const float* g, int Cout, int ldg,
+                          int KH, int KW, int stride, int pad, float* dw, float* db, int accumulate);
+/* linear layer: x [R][K], g [R][ldg] -> dw [Cout][K]; taps > 1: x rows are [tap][K / taps], dw is [Cout][K / taps][taps] */
+int cald_train_linear_wgrad(cald_ctx* ctx, int R, const float* x, int K, const float* g, int Cout, int ldg, int taps,
+                            float* dw, float* db, int accumulate);
+/* g = (act > 0 ? g : 0) * scale[c]  (ReLU backward on the layer's output + FrozenBatchNorm scale); act / scale may be null */
+int cald_train_relu_bwd(cald_ctx* ctx, long long rows, int C, float* g, const float* act, const float* scale);
+/* dst = a + b (b null: copy); n floats, multiple of 4 */
+int cald_train_add(cald_ctx* ctx, long long n, float* dst, const float* a, const float* b);
+/* scatter g [N][Ho][Wo][C] onto the stride-1 grid out [N][Hd][Wd][C] (zeros elsewhere): first step of a strided data gradient */
+int cald_train_dilate(cald_ctx* ctx, int N, int Ho, int Wo, int C, int s, int Hd, int Wd, const float* g, float* out);
+/* FPN top-down backward: coarse += sum of the fine pixels that nearest-upsampling reads from each coarse pixel */
+int cald_train_upsample_bwd(cald_ctx* ctx, int N, int Hf, int Wf, int Hc, int Wc, int C, const float* fine, float* coarse);
+/* torch.optim.SGD step over a flat buffer: d = grad + wd * p; buf = first_step ? d : momentum * buf + d; p -= lr * buf */
+int cald_train_sgd(cald_ctx* ctx, long long n, float* param, const float* grad, float* momentum_buf, float lr, float momentum,
+                   float weight_decay, int first_step);
+
 #ifdef __cplusplus
 }
 #endif
