@@ -989,7 +989,7 @@ static int forward_model(cald_model* m, int V, ViewDesc* views, const DetBuffers
     ra.head_ld = 15; ra.A = 3; ra.V = V; ra.pre_n = m->cfg.rpn_pre_nms_top_n; ra.post_n = m->cfg.rpn_post_nms_top_n;
     ra.nms_thr = m->cfg.rpn_nms_thresh; ra.min_size = 1e-3f;
     ra.cand_key = F.cand_key; ra.cand_box = F.cand_box; ra.sorted_box = F.sorted_box; ra.sorted_raw = F.sorted_raw;
-    ra.sorted_count = F.sorted_count; ra.proposals = F.proposals; ra.prop_count = F.prop_count;
+    ra.sorted_count = F.sorted_count; ra.proposals = F.proposals; ra.prop_stride = CALD_ROI_CAP; ra.prop_count = F.prop_count;
     launch_rpn(ra, st);
     m->dbg["proposals"] = {F.proposals, 7, 4, 1};
     // ---- box head (rows A18, A19, A20) ----

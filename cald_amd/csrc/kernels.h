@@ -60,7 +60,8 @@ struct RpnArgs {
     float* sorted_box;             // [V][5*pre_n][4]  (score order, level offset applied)
     float* sorted_raw;             // [V][5*pre_n][4]  (score order, no offset)
     int* sorted_count;             // [V]
-    float* proposals;              // [V][post_n][4]
+    float* proposals;              // [V][prop_stride][4]
+    int prop_stride;               // rows per view in `proposals` (>= post_n)
     int* prop_count;               // [V]
 };
 void launch_rpn(const RpnArgs& a, hipStream_t st);
@@ -75,6 +76,30 @@ struct RoiArgs {
     float* out;              // [V][ROI_CAP][49][C]
 };
 void launch_roi_align(const RoiArgs& a, hipStream_t st);
+
+// MultiScaleRoIAlign pieces shared by the inference kernel (roi.hip) and the training kernels (train.hip)
+__device__ inline int roi_level(const float4 b) {
+    const float area = (b.z - b.x) * (b.w - b.y);
+    const float s = sqrtf(area);
+    float k = floorf((4.0f + det_log2f(s / 224.0f)) + 1e-6f);
+    if (!(k >= 2.0f)) k = 2.0f;
+    if (k > 5.0f) k = 5.0f;
+    return (int)k - 2;
+}
+
+struct RoiSample { int lo, hi; float l, h; int valid; };
+__device__ inline RoiSample roi_sample(float start, float bin, int p, int i, int size) {
+    RoiSample s;
+    const float t = start + (float)p * bin + ((float)i + 0.5f) * bin / 2.0f;
+    s.valid = !(t < -1.0f || t > (float)size);
+    float tt = t <= 0.0f ? 0.0f : t;
+    int lo = (int)tt, hi;
+    if (lo >= size - 1) { hi = lo = size - 1; tt = (float)lo; } else hi = lo + 1;
+    s.lo = lo; s.hi = hi;
+    s.l = tt - (float)lo; s.h = 1.0f - s.l;
+    if (!s.valid) { s.lo = s.hi = 0; }
+    return s;
+}
 
 struct PostArgs {
     const float* pred;        // [V][ROI_CAP][pred_ld]: logits C, then deltas 4C

@@ -9,32 +9,10 @@
 #include "kernels.h"
 #include "sortnms.h"
 
-__device__ inline int roi_level(const float4 b) {
-    const float area = (b.z - b.x) * (b.w - b.y);
-    const float s = sqrtf(area);
-    float k = floorf((4.0f + det_log2f(s / 224.0f)) + 1e-6f);
-    if (!(k >= 2.0f)) k = 2.0f;
-    if (k > 5.0f) k = 5.0f;
-    return (int)k - 2;
-}
-
 // grid = (ROI_CAP, V), block = 256.  The 14 sample rows and 14 sample columns of the RoI (7 bins x 2 samples,
 // separable) are set up once per workgroup in LDS; then a thread owns (bin, 4 consecutive channels): 16 float4
 // gathers in flight per bin and one float4 store, 1 KB contiguous per wavefront.  Arithmetic order per channel is
 // the oracle's: acc += ((w1*v1 + w2*v2) + w3*v3) + w4*v4 over samples (iy, ix), then / 4.
-struct RoiSample { int lo, hi; float l, h; int valid; };
-__device__ inline RoiSample roi_sample(float start, float bin, int p, int i, int size) {
-    RoiSample s;
-    const float t = start + (float)p * bin + ((float)i + 0.5f) * bin / 2.0f;
-    s.valid = !(t < -1.0f || t > (float)size);
-    float tt = t <= 0.0f ? 0.0f : t;
-    int lo = (int)tt, hi;
-    if (lo >= size - 1) { hi = lo = size - 1; tt = (float)lo; } else hi = lo + 1;
-    s.lo = lo; s.hi = hi;
-    s.l = tt - (float)lo; s.h = 1.0f - s.l;
-    if (!s.valid) { s.lo = s.hi = 0; }
-    return s;
-}
 __global__ __launch_bounds__(256) void roi_align_kernel(RoiArgs a) {
     __shared__ RoiSample sy[14], sx[14];
     const int r = blockIdx.x, v = blockIdx.y, tid = threadIdx.x;

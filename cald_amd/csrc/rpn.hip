@@ -9,11 +9,12 @@
 
 // ---------------------------------------------------------------------------------------------
 // Kernel 1: per (level, view): exact top-k of the objectness logits by 8-pass radix select on
-// 64-bit keys, bitonic sort of the <=1024 survivors in LDS, anchor decode + clip + min-size test.
-// grid = (5, V), block = 1024.
+// 64-bit keys, bitonic sort of the <=CAP survivors in LDS, anchor decode + clip + min-size test.
+// grid = (5, V), block = 1024.  CAP = 1024 (inference: pre_nms_top_n 1000) or 2048 (training: 2000).
 // ---------------------------------------------------------------------------------------------
+template <int CAP>
 __global__ __launch_bounds__(1024) void rpn_topk_kernel(RpnArgs a) {
-    __shared__ unsigned long long sel[1024];
+    __shared__ unsigned long long sel[CAP];
     __shared__ int hist[256];
     __shared__ unsigned long long s_prefix, s_mask;
     __shared__ int s_remaining, s_cnt;
@@ -27,7 +28,7 @@ __global__ __launch_bounds__(1024) void rpn_topk_kernel(RpnArgs a) {
         const float lg = head[(long long)pix * a.head_ld + an];
         return ((unsigned long long)det_orderable(lg) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
     };
-    sel[tid] = 0ull;
+    for (int i = tid; i < CAP; i += 1024) sel[i] = 0ull;
     if (tid == 0) { s_prefix = 0ull; s_mask = 0ull; s_remaining = k; s_cnt = 0; }
     __syncthreads();
     if (n > k) {
@@ -60,13 +61,12 @@ __global__ __launch_bounds__(1024) void rpn_topk_kernel(RpnArgs a) {
     const unsigned long long thresh = (n > k) ? s_prefix : 0ull;   // k-th largest key (keys are unique)
     for (int i = tid; i < n; i += 1024) {
         const unsigned long long key = key_of(i);
-        if (key >= thresh) { const int slot = atomicAdd(&s_cnt, 1); if (slot < 1024) sel[slot] = key; }
+        if (key >= thresh) { const int slot = atomicAdd(&s_cnt, 1); if (slot < CAP) sel[slot] = key; }
     }
     __syncthreads();
-    block_bitonic_sort_desc(sel, 1024);
+    block_bitonic_sort_desc(sel, CAP);
     // decode the t-th best anchor
-    const int t = tid;
-    if (t < a.pre_n) {
+    for (int t = tid; t < a.pre_n; t += 1024) {
         unsigned long long outkey = 0ull;
         float4 box = make_float4(0.f, 0.f, 0.f, 0.f);
         if (t < k) {
@@ -97,15 +97,18 @@ __global__ __launch_bounds__(1024) void rpn_topk_kernel(RpnArgs a) {
 // ---------------------------------------------------------------------------------------------
 // Kernel 2: per view: sort the <=5*pre_n candidates by (score desc, position asc), apply the
 // batched_nms coordinate offset level*(max_coord+1) in fp32, run greedy NMS, emit <=post_n boxes.
-// grid = V, block = 1024, dynamic LDS.
+// grid = V, block = 1024, dynamic LDS.  alias != 0 (training sizes, 5 x 2000 candidates): the kept-box scratch of the NMS
+// reuses the key array, which is dead once the sorted boxes are written out.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void rpn_nms_kernel(RpnArgs a, int NP) {
+__global__ __launch_bounds__(1024) void rpn_nms_kernel(RpnArgs a, int NP, int alias) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+    const size_t key_bytes = (size_t)NP * 8, kept_bytes = (size_t)a.post_n * 24;
+    const size_t kept_off = alias ? 0 : key_bytes, tail_off = alias ? (key_bytes > kept_bytes ? key_bytes : kept_bytes) : key_bytes + kept_bytes;
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(dyn);                 // NP
-    float4* kept_box = reinterpret_cast<float4*>(dyn + (size_t)NP * 8);                    // post_n
-    float* kept_area = reinterpret_cast<float*>(dyn + (size_t)NP * 8 + (size_t)a.post_n * 16);
+    float4* kept_box = reinterpret_cast<float4*>(dyn + kept_off);                          // post_n
+    float* kept_area = reinterpret_cast<float*>(dyn + kept_off + (size_t)a.post_n * 16);
     int* keep_idx = reinterpret_cast<int*>(kept_area + a.post_n);                          // post_n
-    int* dead_or = keep_idx + a.post_n;                                                    // 256
+    int* dead_or = reinterpret_cast<int*>(dyn + tail_off);                                 // 256
     float* red = reinterpret_cast<float*>(dead_or + 256);                                  // 1024
     __shared__ int s_nc, s_nk;
     const int v = blockIdx.x, tid = threadIdx.x;
@@ -142,17 +145,20 @@ __global__ __launch_bounds__(1024) void rpn_nms_kernel(RpnArgs a, int NP) {
     __syncthreads();   // global writes by this block are read back below by other threads
     block_nms_sorted(sb, nc, a.nms_thr, a.post_n, kept_box, kept_area, dead_or, keep_idx, &s_nk);
     const int nk = s_nk;
-    float4* pr = reinterpret_cast<float4*>(a.proposals) + (long long)v * CALD_ROI_CAP;
+    float4* pr = reinterpret_cast<float4*>(a.proposals) + (long long)v * a.prop_stride;
     for (int i = tid; i < nk; i += 1024) pr[i] = sr[keep_idx[i]];
     if (tid == 0) { a.prop_count[v] = nk; a.sorted_count[v] = nc; }
 }
 
 void launch_rpn(const RpnArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(rpn_topk_kernel, dim3(5, a.V), dim3(1024), 0, st, a);
+    if (a.pre_n <= 1024) hipLaunchKernelGGL(rpn_topk_kernel<1024>, dim3(5, a.V), dim3(1024), 0, st, a);
+    else hipLaunchKernelGGL(rpn_topk_kernel<2048>, dim3(5, a.V), dim3(1024), 0, st, a);     // pre_n <= 2048 (checked by the callers)
     int NP = 1024;
     while (NP < 5 * a.pre_n) NP <<= 1;
-    size_t lds = (size_t)NP * 8 + (size_t)a.post_n * (16 + 4 + 4) + 256 * 4 + 1024 * 4;
+    const size_t key_bytes = (size_t)NP * 8, kept_bytes = (size_t)a.post_n * (16 + 4 + 4), tail = 256 * 4 + 1024 * 4;
+    const int alias = key_bytes + kept_bytes + tail > 150 * 1024;
+    const size_t lds = (alias ? (key_bytes > kept_bytes ? key_bytes : kept_bytes) : key_bytes + kept_bytes) + tail;
     static PerDeviceOnce once;
     allow_big_lds(once, rpn_nms_kernel);
-    hipLaunchKernelGGL(rpn_nms_kernel, dim3(a.V), dim3(1024), lds, st, a, NP);
+    hipLaunchKernelGGL(rpn_nms_kernel, dim3(a.V), dim3(1024), lds, st, a, NP, alias);
 }

@@ -75,6 +75,7 @@ void cald_internal_train_release(cald_ctx* c) {
 // mode 1: data grad    K rows = (flipped tap, co) of a Cin_k-channel dY (Cin_k >= Cout),                      N = Cin
 // mode 2: forward of a linear layer whose torch weight is [Cout][Cin][taps] (fc6: [1024][256][7*7]) applied to rows laid out
 //         [tap][Cin] (the RoIAlign output [R][49][256]): K rows = tap * Cin + ci
+// mode 3: data gradient of a mode-2 layer: K rows = co of a CinK-channel dY, N = tap * Cin + ci
 struct PackArgs { const float* w; float* wk; float* w4; int Cout, Cin, taps, CinK, Kpad, NPad, mode; };
 __global__ void pack_weight_kernel(PackArgs a) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -82,11 +83,15 @@ __global__ void pack_weight_kernel(PackArgs a) {
     const int k = (int)(i / a.NPad), n = (int)(i - (long long)k * a.NPad);
     int tap, ci;
     if (a.mode == 2) { tap = k / a.Cin; ci = k - tap * a.Cin; }
+    else if (a.mode == 3) { tap = 0; ci = k; }
     else if (a.CinK % 16 == 0 && a.taps <= 32) { const int chunk = k / (16 * a.taps), rem = k - chunk * 16 * a.taps; tap = rem >> 4; ci = chunk * 16 + (rem & 15); }
     else { tap = k / a.CinK; ci = k - tap * a.CinK; }
     float v = 0.0f;
     if (a.mode == 1) {
         if (tap < a.taps && ci < a.Cout && n < a.Cin) v = a.w[((long long)ci * a.Cin + n) * a.taps + (a.taps - 1 - tap)];
+    } else if (a.mode == 3) {
+        const int t = n / a.Cin, cc = n - t * a.Cin;
+        if (ci < a.Cout && t < a.taps) v = a.w[((long long)ci * a.Cin + cc) * a.taps + t];
     } else {
         if (tap < a.taps && ci < a.Cin && n < a.Cout) v = a.w[((long long)n * a.Cin + ci) * a.taps + tap];
     }
@@ -104,6 +109,7 @@ static PackGeom pack_geom(int Cout, int Cin, int KH, int KW, int CinK, int mode)
     PackGeom g;
     const int taps = KH * KW;
     if (mode == 2) { g.K = taps * Cin; g.n_true = Cout; g.cin_conv = taps * Cin; }
+    else if (mode == 3) { g.K = CinK; g.n_true = taps * Cin; g.cin_conv = CinK; }
     else { g.K = taps * CinK; g.n_true = mode == 1 ? Cin : Cout; g.cin_conv = CinK; }
     g.Kpad = round_up(g.K, 16);
     g.NPad = cout_pad(g.n_true);
@@ -111,15 +117,15 @@ static PackGeom pack_geom(int Cout, int Cin, int KH, int KW, int CinK, int mode)
     return g;
 }
 extern "C" int cald_train_packed_floats(int Cout, int Cin, int KH, int KW, int CinK, int mode, int64_t* floats_out) {
-    if (!floats_out || Cout < 1 || Cin < 1 || KH < 1 || KW < 1 || mode < 0 || mode > 2) TFAIL(CALD_ERR_INVALID, "bad arguments");
+    if (!floats_out || Cout < 1 || Cin < 1 || KH < 1 || KW < 1 || mode < 0 || mode > 3) TFAIL(CALD_ERR_INVALID, "bad arguments");
     *floats_out = pack_geom(Cout, Cin, KH, KW, CinK, mode).floats;
     return 0;
 }
 extern "C" int cald_train_pack_conv(cald_ctx* c, const float* w, const float* bias, const float* scale, const float* shift,
                                     int Cout, int Cin, int KH, int KW, int CinK, int mode, float* packed) {
     if (!c || !w || !packed) TFAIL(CALD_ERR_INVALID, "null argument");
-    if (mode < 0 || mode > 2) TFAIL(CALD_ERR_INVALID, "mode must be 0 (forward), 1 (data gradient) or 2 (tap-major linear)");
-    if (mode != 2 && (CinK % 4 || CinK < (mode == 1 ? Cout : Cin))) TFAIL(CALD_ERR_INVALID, "CinK must be a multiple of 4 and cover the contracted channels");
+    if (mode < 0 || mode > 3) TFAIL(CALD_ERR_INVALID, "mode must be 0 (forward), 1 (data gradient), 2 (tap-major linear) or 3 (its data gradient)");
+    if (mode != 2 && (CinK % 4 || CinK < (mode == 0 ? Cin : Cout))) TFAIL(CALD_ERR_INVALID, "CinK must be a multiple of 4 and cover the contracted channels");
     THIP(hipSetDevice(cald_internal_device(c)));
     const PackGeom g = pack_geom(Cout, Cin, KH, KW, CinK, mode);
     PackArgs a{w, packed, packed + (long long)g.Kpad * g.NPad, Cout, Cin, KH * KW, CinK, g.Kpad, g.NPad, mode};
@@ -128,9 +134,10 @@ extern "C" int cald_train_pack_conv(cald_ctx* c, const float* w, const float* bi
     hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
     float* vec = packed + 2 * n;
     const int nt = g.n_true, blocks = (g.NPad + 255) / 256;
-    hipLaunchKernelGGL(pack_vec_kernel, dim3(blocks), dim3(256), 0, st, mode == 1 ? nullptr : bias, nt, vec, g.NPad);
-    hipLaunchKernelGGL(pack_vec_kernel, dim3(blocks), dim3(256), 0, st, mode == 1 ? nullptr : scale, nt, vec + g.NPad, g.NPad);
-    hipLaunchKernelGGL(pack_vec_kernel, dim3(blocks), dim3(256), 0, st, mode == 1 ? nullptr : shift, nt, vec + 2 * g.NPad, g.NPad);
+    const bool grad_mode = mode == 1 || mode == 3;
+    hipLaunchKernelGGL(pack_vec_kernel, dim3(blocks), dim3(256), 0, st, grad_mode ? nullptr : bias, nt, vec, g.NPad);
+    hipLaunchKernelGGL(pack_vec_kernel, dim3(blocks), dim3(256), 0, st, grad_mode ? nullptr : scale, nt, vec + g.NPad, g.NPad);
+    hipLaunchKernelGGL(pack_vec_kernel, dim3(blocks), dim3(256), 0, st, grad_mode ? nullptr : shift, nt, vec + 2 * g.NPad, g.NPad);
     THIP(hipGetLastError());
     return 0;
 }
@@ -148,7 +155,7 @@ extern "C" int cald_train_conv(cald_ctx* c, int N, int H, int W, const float* in
     if (N < 1 || H < 1 || W < 1 || stride < 1) TFAIL(CALD_ERR_INVALID, "bad geometry");
     THIP(hipSetDevice(cald_internal_device(c)));
     const PackGeom g = pack_geom(Cout, Cin, KH, KW, CinK, mode);
-    const int kh = mode == 2 ? 1 : KH, kw = mode == 2 ? 1 : KW;
+    const int kh = mode >= 2 ? 1 : KH, kw = mode >= 2 ? 1 : KW;
     const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
     if (Ho < 1 || Wo < 1) TFAIL(CALD_ERR_INVALID, "empty output");
     if ((residual || up) && out_ld != g.n_true) TFAIL(CALD_ERR_INVALID, "residual / upsample-add need out_ld == Cout");
@@ -454,6 +461,409 @@ extern "C" int cald_train_sgd(cald_ctx* c, long long n, float* param, const floa
     if (!c || !param || !grad || (momentum != 0.0f && !momentum_buf)) TFAIL(CALD_ERR_INVALID, "null argument");
     THIP(hipSetDevice(cald_internal_device(c)));
     if (n > 0) hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cald_internal_stream(c), param, grad, momentum_buf, n, lr, momentum, weight_decay, first_step);
+    THIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// region proposals in training mode (torchvision RegionProposalNetwork.filter_proposals with pre/post_nms_top_n_train = 2000,
+// detection/frcnn_la.py:154-158): the inference kernels of rpn.hip at the larger capacity
+// ---------------------------------------------------------------------------------------------------------------------
+// heads[l]: [N][Hl][Wl][head_ld], channel a = objectness logit of anchor a, channel A + 4a + j = delta j.  image_sizes: host [N][2]
+// (resized, unpadded h, w).  proposals_out: device [N][post_n][4], counts_out: device int [N].
+extern "C" int cald_train_rpn_proposals(cald_ctx* c, int N, int Hp, int Wp, const int* image_sizes, const float* const* heads,
+                                        const int* level_hw, int head_ld, int pre_n, int post_n, float nms_thr, float min_size,
+                                        float* proposals_out, int* counts_out) {
+    if (!c || !image_sizes || !heads || !level_hw || !proposals_out || !counts_out) TFAIL(CALD_ERR_INVALID, "null argument");
+    if (N < 1 || N > CALD_MAX_VIEWS || pre_n < 1 || pre_n > 2048 || post_n < 1 || post_n > 2048) TFAIL(CALD_ERR_INVALID, "N <= %d, pre/post top-n <= 2048", CALD_MAX_VIEWS);
+    THIP(hipSetDevice(cald_internal_device(c)));
+    hipStream_t st = cald_internal_stream(c);
+    RpnArgs ra; memset(&ra, 0, sizeof(ra));
+    const LevelSeg* s0;
+    if (int rc = dense_seg(c, N, Hp, Wp, &s0)) return rc;
+    ra.seg0 = s0;
+    for (int l = 0; l < 5; l++) {
+        const LevelSeg* sl;
+        if (int rc = dense_seg(c, N, level_hw[2 * l], level_hw[2 * l + 1], &sl)) return rc;
+        ra.seg[l] = sl; ra.head[l] = heads[l];
+    }
+    const size_t ntot = (size_t)N * 5 * pre_n;
+    const size_t b_views = (sizeof(ViewDesc) * N + 255) & ~(size_t)255, b_anch = 256, b_key = (ntot * 8 + 255) & ~(size_t)255, b_box = (ntot * 16 + 255) & ~(size_t)255;
+    void* scratch = nullptr;
+    if (int rc = cald_internal_scratch(c, b_views + b_anch + b_key + 3 * b_box + 256, &scratch)) return rc;
+    char* p = (char*)scratch;
+    ViewDesc* d_views = (ViewDesc*)p; p += b_views;
+    float* d_base = (float*)p; p += b_anch;
+    ra.cand_key = (unsigned long long*)p; p += b_key;
+    ra.cand_box = (float*)p; p += b_box; ra.sorted_box = (float*)p; p += b_box; ra.sorted_raw = (float*)p; p += b_box;
+    ra.sorted_count = (int*)p;
+    std::vector<ViewDesc> hv(N);
+    memset(hv.data(), 0, sizeof(ViewDesc) * N);
+    for (int v = 0; v < N; v++) { hv[v].Hr = image_sizes[2 * v]; hv[v].Wr = image_sizes[2 * v + 1]; }
+    float base[5 * 3 * 4];
+    {   // AnchorGenerator base anchors: sizes (32, 64, 128, 256, 512), ratios (0.5, 1, 2)  (frcnn_la.py:185-187)
+        const float sizes[5] = {32.f, 64.f, 128.f, 256.f, 512.f}, ratios[3] = {0.5f, 1.0f, 2.0f};
+        for (int l = 0; l < 5; l++)
+            for (int r = 0; r < 3; r++) {
+                const float hr = sqrtf(ratios[r]), wr = 1.0f / hr, ws = wr * sizes[l], hs = hr * sizes[l];
+                float* b = &base[(l * 3 + r) * 4];
+                b[0] = rintf(-ws / 2.0f); b[1] = rintf(-hs / 2.0f); b[2] = rintf(ws / 2.0f); b[3] = rintf(hs / 2.0f);
+            }
+    }
+    THIP(hipMemcpyAsync(d_views, hv.data(), sizeof(ViewDesc) * N, hipMemcpyHostToDevice, st));
+    THIP(hipMemcpyAsync(d_base, base, sizeof(base), hipMemcpyHostToDevice, st));
+    THIP(hipStreamSynchronize(st));   // the host arrays above are stack / vector storage
+    ra.views = d_views; ra.base_anchors = d_base; ra.head_ld = head_ld; ra.A = 3; ra.V = N; ra.pre_n = pre_n; ra.post_n = post_n;
+    ra.nms_thr = nms_thr; ra.min_size = min_size; ra.proposals = proposals_out; ra.prop_stride = post_n; ra.prop_count = counts_out;
+    launch_rpn(ra, st);
+    THIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Matcher (torchvision 0.8.2 _utils.Matcher): IoU of every candidate box with every ground-truth box, best ground truth per
+// candidate, thresholds, optional low-quality matches.  out[i] = ground-truth index, -1 below `lo`, -2 between `lo` and `hi`.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ inline float box_iou_tv(const float4 a, const float4 b) {   // torchvision.ops.box_iou
+    const float aa = (a.z - a.x) * (a.w - a.y), ab = (b.z - b.x) * (b.w - b.y);
+    float w = fminf(a.z, b.z) - fmaxf(a.x, b.x), h = fminf(a.w, b.w) - fmaxf(a.y, b.y);
+    w = w < 0.0f ? 0.0f : w; h = h < 0.0f ? 0.0f : h;
+    const float inter = w * h;
+    return inter / ((aa + ab) - inter);
+}
+__global__ void match_gtmax_kernel(const float4* boxes, int nB, const float4* gt, int nG, unsigned* gtmax_bits) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nB) return;
+    const float4 b = boxes[i];
+    for (int g = 0; g < nG; g++) {
+        const float v = box_iou_tv(gt[g], b);
+        if (v > 0.0f) atomicMax(&gtmax_bits[g], __float_as_uint(v));   // IoU >= 0: the bit pattern orders like the value
+    }
+}
+__global__ void match_assign_kernel(const float4* boxes, int nB, const float4* gt, int nG, const unsigned* gtmax_bits, float hi, float lo,
+                                    int allow_low, int* out, float* best_iou) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nB) return;
+    const float4 b = boxes[i];
+    float best = -1.0f; int arg = 0; bool low = false;
+    for (int g = 0; g < nG; g++) {
+        const float v = box_iou_tv(gt[g], b);
+        if (v > best) { best = v; arg = g; }                         // first maximum, as torch.max(dim=0)
+        if (allow_low && v == __uint_as_float(gtmax_bits[g])) low = true;
+    }
+    int m = arg;
+    if (best < lo) m = -1; else if (best < hi) m = -2;
+    if (low) m = arg;
+    out[i] = m;
+    if (best_iou) best_iou[i] = best;
+}
+extern "C" int cald_train_match(cald_ctx* c, int n_boxes, const float* boxes, int n_gt, const float* gt, float hi, float lo,
+                                int allow_low_quality, int* matched_out, float* best_iou_out) {
+    if (!c || !boxes || !gt || !matched_out) TFAIL(CALD_ERR_INVALID, "null argument");
+    if (n_boxes < 1 || n_gt < 1) TFAIL(CALD_ERR_INVALID, "needs at least one box and one ground-truth box");
+    THIP(hipSetDevice(cald_internal_device(c)));
+    hipStream_t st = cald_internal_stream(c);
+    void* scratch = nullptr;
+    if (int rc = cald_internal_scratch(c, (size_t)n_gt * 4 + 256, &scratch)) return rc;
+    unsigned* gm = (unsigned*)scratch;
+    THIP(hipMemsetAsync(gm, 0, (size_t)n_gt * 4, st));
+    const int blocks = (n_boxes + 255) / 256;
+    if (allow_low_quality)
+        hipLaunchKernelGGL(match_gtmax_kernel, dim3(blocks), dim3(256), 0, st, (const float4*)boxes, n_boxes, (const float4*)gt, n_gt, gm);
+    hipLaunchKernelGGL(match_assign_kernel, dim3(blocks), dim3(256), 0, st, (const float4*)boxes, n_boxes, (const float4*)gt, n_gt, gm, hi, lo,
+                       allow_low_quality, matched_out, best_iou_out);
+    THIP(hipGetLastError());
+    return 0;
+}
+
+// all anchors of one image, in torchvision's order (level, y, x, anchor): [sum_l Hl*Wl*A][4]
+__global__ void anchors_kernel(float4* out, int Hl, int Wl, int sy, int sx, const float* base, int A, long long off) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)Hl * Wl * A) return;
+    const int an = (int)(i % A); const long long pix = i / A;
+    const int x = (int)(pix % Wl), y = (int)(pix / Wl);
+    out[off + i] = make_float4((float)(x * sx) + base[an * 4], (float)(y * sy) + base[an * 4 + 1], (float)(x * sx) + base[an * 4 + 2], (float)(y * sy) + base[an * 4 + 3]);
+}
+extern "C" int cald_train_anchors(cald_ctx* c, int Hp, int Wp, const int* level_hw, float* anchors_out) {
+    if (!c || !level_hw || !anchors_out) TFAIL(CALD_ERR_INVALID, "null argument");
+    THIP(hipSetDevice(cald_internal_device(c)));
+    hipStream_t st = cald_internal_stream(c);
+    float base[5 * 3 * 4];
+    const float sizes[5] = {32.f, 64.f, 128.f, 256.f, 512.f}, ratios[3] = {0.5f, 1.0f, 2.0f};
+    for (int l = 0; l < 5; l++)
+        for (int r = 0; r < 3; r++) {
+            const float hr = sqrtf(ratios[r]), wr = 1.0f / hr, ws = wr * sizes[l], hs = hr * sizes[l];
+            float* b = &base[(l * 3 + r) * 4];
+            b[0] = rintf(-ws / 2.0f); b[1] = rintf(-hs / 2.0f); b[2] = rintf(ws / 2.0f); b[3] = rintf(hs / 2.0f);
+        }
+    void* scratch = nullptr;
+    if (int rc = cald_internal_scratch(c, 256, &scratch)) return rc;
+    THIP(hipMemcpyAsync(scratch, base, sizeof(base), hipMemcpyHostToDevice, st));
+    THIP(hipStreamSynchronize(st));
+    long long off = 0;
+    for (int l = 0; l < 5; l++) {
+        const int Hl = level_hw[2 * l], Wl = level_hw[2 * l + 1];
+        const long long n = (long long)Hl * Wl * 3;
+        hipLaunchKernelGGL(anchors_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (float4*)anchors_out, Hl, Wl, Hp / Hl, Wp / Wl,
+                           (const float*)scratch + l * 12, 3, off);
+        off += n;
+    }
+    THIP(hipGetLastError());
+    THIP(hipStreamSynchronize(st));   // the scratch holding the base anchors may be reused by the next call
+    return 0;
+}
+
+// BoxCoder.encode_single (torchvision 0.8.2 _utils.py): regression targets of `proposals` towards `reference` boxes
+__global__ void box_encode_kernel(const float4* reference, const float4* proposals, int n, float wx, float wy, float ww, float wh, float4* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 r = reference[i], p = proposals[i];
+    const float ex_w = p.z - p.x, ex_h = p.w - p.y, ex_cx = p.x + 0.5f * ex_w, ex_cy = p.y + 0.5f * ex_h;
+    const float gt_w = r.z - r.x, gt_h = r.w - r.y, gt_cx = r.x + 0.5f * gt_w, gt_cy = r.y + 0.5f * gt_h;
+    out[i] = make_float4(wx * (gt_cx - ex_cx) / ex_w, wy * (gt_cy - ex_cy) / ex_h, ww * det_logf(gt_w / ex_w), wh * det_logf(gt_h / ex_h));
+}
+extern "C" int cald_train_box_encode(cald_ctx* c, int n, const float* reference, const float* proposals, float wx, float wy, float ww, float wh,
+                                     float* out) {
+    if (!c || (n > 0 && (!reference || !proposals || !out))) TFAIL(CALD_ERR_INVALID, "null argument");
+    THIP(hipSetDevice(cald_internal_device(c)));
+    if (n > 0) hipLaunchKernelGGL(box_encode_kernel, dim3((n + 255) / 256), dim3(256), 0, cald_internal_stream(c), (const float4*)reference,
+                                  (const float4*)proposals, n, wx, wy, ww, wh, (float4*)out);
+    THIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// MultiScaleRoIAlign (7x7, sampling_ratio 2, aligned=False) on a dense batch, forward and backward
+// ---------------------------------------------------------------------------------------------------------------------
+struct RoiTrainArgs {
+    const float* feat[4]; float* gfeat[4]; int H[4], W[4];
+    int C, R;
+    const float* rois;     // [R][5]: image index, x1, y1, x2, y2 (resized-image coordinates)
+    float* out;            // forward: [R][49][C]
+    const float* gout;     // backward: [R][49][C]
+};
+template <bool BWD>
+__global__ __launch_bounds__(256) void roi_align_train_kernel(RoiTrainArgs a) {
+    __shared__ RoiSample sy[14], sx[14];
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const float* rp = a.rois + (long long)r * 5;
+    const int n = (int)rp[0];
+    const float4 box = make_float4(rp[1], rp[2], rp[3], rp[4]);
+    const int l = roi_level(box);
+    const int Hf = a.H[l], Wf = a.W[l], C = a.C, Cq = C >> 2;
+    if (tid < 28) {
+        const float scale = 1.0f / (float)(4 << l);
+        const float x1 = box.x * scale, y1 = box.y * scale, x2 = box.z * scale, y2 = box.w * scale;
+        float rw = x2 - x1; if (!(rw >= 1.0f)) rw = 1.0f;
+        float rh = y2 - y1; if (!(rh >= 1.0f)) rh = 1.0f;
+        const float bw = rw / 7.0f, bh = rh / 7.0f;
+        if (tid < 14) sy[tid] = roi_sample(y1, bh, tid >> 1, tid & 1, Hf);
+        else sx[tid - 14] = roi_sample(x1, bw, (tid - 14) >> 1, (tid - 14) & 1, Wf);
+    }
+    __syncthreads();
+    const long long img_off = (long long)n * Hf * Wf * Cq;
+    const float4* f = reinterpret_cast<const float4*>(a.feat[l]) + img_off;
+    float* gf = BWD ? a.gfeat[l] + img_off * 4 : nullptr;
+    for (int idx = tid; idx < 49 * Cq; idx += 256) {
+        const int bin = idx / Cq, q = idx - bin * Cq;
+        const int ph = bin / 7, pw = bin - ph * 7;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), go = acc;
+        if (BWD) { go = reinterpret_cast<const float4*>(a.gout)[(long long)r * 49 * Cq + idx]; go.x *= 0.25f; go.y *= 0.25f; go.z *= 0.25f; go.w *= 0.25f; }
+#pragma unroll
+        for (int iy = 0; iy < 2; iy++) {
+            const RoiSample Y = sy[ph * 2 + iy];
+#pragma unroll
+            for (int ix = 0; ix < 2; ix++) {
+                const RoiSample X = sx[pw * 2 + ix];
+                if (!(Y.valid && X.valid)) continue;
+                const float w1 = Y.h * X.h, w2 = Y.h * X.l, w3 = Y.l * X.h, w4 = Y.l * X.l;
+                const long long o1 = (long long)(Y.lo * Wf + X.lo) * Cq + q, o2 = (long long)(Y.lo * Wf + X.hi) * Cq + q;
+                const long long o3 = (long long)(Y.hi * Wf + X.lo) * Cq + q, o4 = (long long)(Y.hi * Wf + X.hi) * Cq + q;
+                if (!BWD) {
+                    const float4 v1 = f[o1], v2 = f[o2], v3 = f[o3], v4 = f[o4];
+                    acc.x = acc.x + (((w1 * v1.x + w2 * v2.x) + w3 * v3.x) + w4 * v4.x);
+                    acc.y = acc.y + (((w1 * v1.y + w2 * v2.y) + w3 * v3.y) + w4 * v4.y);
+                    acc.z = acc.z + (((w1 * v1.z + w2 * v2.z) + w3 * v3.z) + w4 * v4.z);
+                    acc.w = acc.w + (((w1 * v1.w + w2 * v2.w) + w3 * v3.w) + w4 * v4.w);
+                } else {
+                    const long long oo[4] = {o1, o2, o3, o4}; const float ww[4] = {w1, w2, w3, w4};
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        float* d = gf + oo[k] * 4;
+                        unsafeAtomicAdd(d, ww[k] * go.x); unsafeAtomicAdd(d + 1, ww[k] * go.y);
+                        unsafeAtomicAdd(d + 2, ww[k] * go.z); unsafeAtomicAdd(d + 3, ww[k] * go.w);
+                    }
+                }
+            }
+        }
+        if (!BWD) reinterpret_cast<float4*>(a.out)[(long long)r * 49 * Cq + idx] = make_float4(acc.x / 4.0f, acc.y / 4.0f, acc.z / 4.0f, acc.w / 4.0f);
+    }
+}
+static int roi_args(RoiTrainArgs& a, const float* const* feats, float* const* gfeats, const int* level_hw, int C, int R, const float* rois) {
+    if (C % 4 || R < 1 || !rois || !level_hw) return cald_internal_fail(CALD_ERR_INVALID, "bad RoIAlign arguments");
+    memset(&a, 0, sizeof(a));
+    for (int l = 0; l < 4; l++) { a.feat[l] = feats ? feats[l] : nullptr; a.gfeat[l] = gfeats ? gfeats[l] : nullptr; a.H[l] = level_hw[2 * l]; a.W[l] = level_hw[2 * l + 1]; }
+    a.C = C; a.R = R; a.rois = rois;
+    return 0;
+}
+extern "C" int cald_train_roi_align(cald_ctx* c, const float* const* feats, const int* level_hw, int C, int R, const float* rois, float* out) {
+    if (!c || !feats || !out) TFAIL(CALD_ERR_INVALID, "null argument");
+    THIP(hipSetDevice(cald_internal_device(c)));
+    RoiTrainArgs a; if (int rc = roi_args(a, feats, nullptr, level_hw, C, R, rois)) return rc;
+    a.out = out;
+    hipLaunchKernelGGL(roi_align_train_kernel<false>, dim3(R), dim3(256), 0, cald_internal_stream(c), a);
+    THIP(hipGetLastError());
+    return 0;
+}
+/* gfeats[l] += scatter of gout through the bilinear weights (float atomics: the summation order is not fixed) */
+extern "C" int cald_train_roi_align_bwd(cald_ctx* c, float* const* gfeats, const int* level_hw, int C, int R, const float* rois, const float* gout) {
+    if (!c || !gfeats || !gout) TFAIL(CALD_ERR_INVALID, "null argument");
+    THIP(hipSetDevice(cald_internal_device(c)));
+    RoiTrainArgs a; if (int rc = roi_args(a, (const float* const*)gfeats, gfeats, level_hw, C, R, rois)) return rc;
+    a.gout = gout;
+    hipLaunchKernelGGL(roi_align_train_kernel<true>, dim3(R), dim3(256), 0, cald_internal_stream(c), a);
+    THIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// losses: value and gradient in one pass.  Each kernel is ONE workgroup (the row counts are a few thousand), so the sums are
+// taken in a fixed order.  `gscale` multiplies the gradient (the upstream gradient of the scalar loss, normally 1).
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ inline float block_sum_256(float v, float* red) {
+    const int tid = threadIdx.x;
+    red[tid] = v; __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; __syncthreads(); }
+    const float r = red[0]; __syncthreads();
+    return r;
+}
+// F.cross_entropy(logits[R][C], labels) (mean over rows); grad[r][c] = (softmax - onehot) / R; rows have stride ld
+__global__ __launch_bounds__(256) void softmax_ce_kernel(const float* logits, const long long* labels, int R, int C, int ld, float gscale,
+                                                         float* loss, float* grad) {
+    __shared__ float red[256];
+    float local = 0.0f;
+    for (int r = threadIdx.x; r < R; r += 256) {
+        const float* z = logits + (long long)r * ld;
+        float m = z[0];
+        for (int k = 1; k < C; k++) m = fmaxf(m, z[k]);
+        float s = 0.0f;
+        for (int k = 0; k < C; k++) s += det_expf(z[k] - m);
+        const int y = (int)labels[r];
+        local += (det_logf(s) + m) - z[y];
+        if (grad) {
+            float* g = grad + (long long)r * ld;
+            const float inv = gscale / (float)R;
+            for (int k = 0; k < C; k++) g[k] = (det_expf(z[k] - m) / s - (k == y ? 1.0f : 0.0f)) * inv;
+        }
+    }
+    const float tot = block_sum_256(local, red);
+    if (threadIdx.x == 0) *loss = tot / (float)R;
+}
+extern "C" int cald_train_softmax_ce(cald_ctx* c, int R, int C, int ld, const float* logits, const int64_t* labels, float gscale, float* loss_out,
+                                     float* grad_out) {
+    if (!c || !logits || !labels || !loss_out || R < 1 || C < 1) TFAIL(CALD_ERR_INVALID, "bad arguments");
+    THIP(hipSetDevice(cald_internal_device(c)));
+    hipLaunchKernelGGL(softmax_ce_kernel, dim3(1), dim3(256), 0, cald_internal_stream(c), logits, (const long long*)labels, R, C, ld, gscale, loss_out, grad_out);
+    THIP(hipGetLastError());
+    return 0;
+}
+// det_utils.smooth_l1_loss(pred, target, beta, size_average=False) / denom over n gathered 4-vectors: pred 4-vector i starts at
+// float offset idx[i] of `pred` (and of `grad`, which the caller has zeroed)
+__global__ __launch_bounds__(256) void smooth_l1_kernel(const float* pred, const long long* idx, const float* target, int n, float beta, float denom,
+                                                        float gscale, float* loss, float* grad) {
+    __shared__ float red[256];
+    float local = 0.0f;
+    for (int e = threadIdx.x; e < 4 * n; e += 256) {
+        const long long o = idx[e >> 2] + (e & 3);
+        const float d = pred[o] - target[e], ad = fabsf(d);
+        local += ad < beta ? 0.5f * d * d / beta : ad - 0.5f * beta;
+        if (grad) grad[o] = (ad < beta ? d / beta : (d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f))) * (gscale / denom);
+    }
+    const float tot = block_sum_256(local, red);
+    if (threadIdx.x == 0) *loss = tot / denom;
+}
+extern "C" int cald_train_smooth_l1(cald_ctx* c, int n, const float* pred, const int64_t* idx, const float* target, float beta, float denom,
+                                    float gscale, float* loss_out, float* grad) {
+    if (!c || !loss_out || (n > 0 && (!pred || !idx || !target))) TFAIL(CALD_ERR_INVALID, "bad arguments");
+    THIP(hipSetDevice(cald_internal_device(c)));
+    hipLaunchKernelGGL(smooth_l1_kernel, dim3(1), dim3(256), 0, cald_internal_stream(c), pred, (const long long*)idx, target, n, beta, denom, gscale, loss_out, grad);
+    THIP(hipGetLastError());
+    return 0;
+}
+// F.binary_cross_entropy_with_logits(x[idx], y) (mean over n gathered logits)
+__global__ __launch_bounds__(256) void bce_logits_kernel(const float* x, const long long* idx, const float* y, int n, float gscale, float* loss, float* grad) {
+    __shared__ float red[256];
+    float local = 0.0f;
+    for (int e = threadIdx.x; e < n; e += 256) {
+        const long long o = idx[e];
+        const float z = x[o], t = y[e];
+        // max(z, 0) - z * t + log(1 + exp(-|z|))
+        local += ((z > 0.0f ? z : 0.0f) - z * t) + det_logf(1.0f + det_expf(-fabsf(z)));
+        if (grad) grad[o] = (det_sigmoidf(z) - t) * (gscale / (float)n);
+    }
+    const float tot = block_sum_256(local, red);
+    if (threadIdx.x == 0) *loss = tot / (float)n;
+}
+extern "C" int cald_train_bce_logits(cald_ctx* c, int n, const float* logits, const int64_t* idx, const float* labels, float gscale, float* loss_out,
+                                     float* grad) {
+    if (!c || !loss_out || n < 1 || !logits || !idx || !labels) TFAIL(CALD_ERR_INVALID, "bad arguments");
+    THIP(hipSetDevice(cald_internal_device(c)));
+    hipLaunchKernelGGL(bce_logits_kernel, dim3(1), dim3(256), 0, cald_internal_stream(c), logits, (const long long*)idx, labels, n, gscale, loss_out, grad);
+    THIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// input side of the training forward: GeneralizedRCNNTransform (normalize, bilinear resize, zero-pad to the batch size), the
+// stem's max-pool, LastLevelMaxPool -- the inference kernels of elementwise.hip on a dense batch
+// ---------------------------------------------------------------------------------------------------------------------
+// images[i]: device uint8 [H_i][W_i][3]; hw = host {H_0, W_0, Hr_0, Wr_0, ...} (source size, resized size); remainders[i]: optional
+// device float [3][H_i][W_i] added to image / 255 (inputs that are not on the uint8 grid), or null.  out [N][Hp][Wp][4] (channel 3 = 0).
+extern "C" int cald_train_preprocess(cald_ctx* c, int N, const uint8_t* const* images, const float* const* remainders, const int* hw, int Hp, int Wp,
+                                     float* out) {
+    if (!c || !images || !hw || !out) TFAIL(CALD_ERR_INVALID, "null argument");
+    if (N < 1 || N > CALD_MAX_VIEWS) TFAIL(CALD_ERR_INVALID, "N must be 1..%d", CALD_MAX_VIEWS);
+    THIP(hipSetDevice(cald_internal_device(c)));
+    hipStream_t st = cald_internal_stream(c);
+    std::vector<ViewDesc> hv(N);
+    memset(hv.data(), 0, sizeof(ViewDesc) * N);
+    for (int v = 0; v < N; v++) {
+        hv[v].src = images[v]; hv[v].H = hw[4 * v]; hv[v].W = hw[4 * v + 1]; hv[v].Hr = hw[4 * v + 2]; hv[v].Wr = hw[4 * v + 3];
+        hv[v].Ho = hv[v].H; hv[v].Wo = hv[v].W; hv[v].noise = remainders ? remainders[v] : nullptr;
+        if (hv[v].Hr > Hp || hv[v].Wr > Wp) TFAIL(CALD_ERR_INVALID, "resized image %d exceeds the padded batch size", v);
+    }
+    void* scratch = nullptr;
+    if (int rc = cald_internal_scratch(c, sizeof(ViewDesc) * N, &scratch)) return rc;
+    THIP(hipMemcpyAsync(scratch, hv.data(), sizeof(ViewDesc) * N, hipMemcpyHostToDevice, st));
+    THIP(hipStreamSynchronize(st));
+    const LevelSeg* s0;
+    if (int rc = dense_seg(c, N, Hp, Wp, &s0)) return rc;
+    launch_preprocess((const ViewDesc*)scratch, s0, out, N, Hp * Wp, st);
+    THIP(hipGetLastError());
+    THIP(hipStreamSynchronize(st));   // the descriptors live in the shared scratch
+    return 0;
+}
+/* max_pool2d(3, 2, 1): in [N][H][W][C] -> out [N][(H-1)/2+1][(W-1)/2+1][C] */
+extern "C" int cald_train_maxpool(cald_ctx* c, int N, int H, int W, int C, const float* in, float* out) {
+    if (!c || !in || !out || C % 4) TFAIL(CALD_ERR_INVALID, "bad arguments");
+    THIP(hipSetDevice(cald_internal_device(c)));
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const LevelSeg *si, *so;
+    if (int rc = dense_seg(c, N, H, W, &si)) return rc;
+    if (int rc = dense_seg(c, N, Ho, Wo, &so)) return rc;
+    launch_maxpool(in, out, si, so, C, N, Ho * Wo, cald_internal_stream(c));
+    THIP(hipGetLastError());
+    return 0;
+}
+/* max_pool2d(1, 2, 0) (LastLevelMaxPool): every second pixel */
+extern "C" int cald_train_subsample2(cald_ctx* c, int N, int H, int W, int C, const float* in, float* out) {
+    if (!c || !in || !out || C % 4) TFAIL(CALD_ERR_INVALID, "bad arguments");
+    THIP(hipSetDevice(cald_internal_device(c)));
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const LevelSeg *si, *so;
+    if (int rc = dense_seg(c, N, H, W, &si)) return rc;
+    if (int rc = dense_seg(c, N, Ho, Wo, &so)) return rc;
+    launch_subsample2(in, out, si, so, C, N, Ho * Wo, cald_internal_stream(c));
     THIP(hipGetLastError());
     return 0;
 }

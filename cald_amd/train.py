@@ -1,0 +1,524 @@
+"""Training step of the Faster R-CNN detector on the MI355X.
+
+What the reference does per iteration (cald_train.py:40-74 ``train_one_epoch``; detection/engine.py:19-61):
+
+    loss_dict = task_model(images, targets); losses = sum(loss_dict.values())
+    task_optimizer.zero_grad(); losses.backward(); task_optimizer.step()
+
+with ``task_model`` = detection/frcnn_la.py ``FRCNN_Feature`` in train mode -- i.e. torchvision 0.8.2's GeneralizedRCNN training
+forward (transform -> ResNet-FPN -> RPN losses -> sampled RoI-head losses) under torch autograd on cuDNN/cuBLAS.  Here the same
+graph is strung from the ``cald_train_*`` device operators (cald_amd/csrc/train.hip): the forward runs on the inference MFMA
+kernels with weights packed on the device every step, the backward is hand-written (data gradients on the same kernels with the
+flipped filter, weight gradients on the split-K MFMA kernel, RoIAlign / FPN / ReLU / FrozenBatchNorm backward kernels), and
+``SGD`` is one fused kernel per tensor.  torch supplies device memory, the stream, the Parameter / Optimizer / autograd-Function
+*interfaces* (so ``losses.backward()`` and the reference's lr schedulers work unchanged) and the CPU random permutations of the
+samplers; it performs none of the arithmetic.
+
+torchvision semantics restated here (0.8.2, "TV-mem" in SURVEY Appendix A; in-repo copies cited where they exist):
+  * trainable parameters: body layers 2-4 (``resnet_fpn_backbone(trainable_layers=3)``), FPN, RPN head, box head, predictor;
+    every BatchNorm is FrozenBatchNorm2d; conv1 / layer1 are frozen                                    (frcnn_la.py:283)
+  * RPN: anchors (32..512) x (0.5, 1, 2); Matcher(0.7, 0.3, allow_low_quality); BalancedPositiveNegativeSampler(256, 0.5);
+    BCE-with-logits objectness loss; smooth-L1 (beta 1/9) box loss / #sampled; proposals from pre/post_nms_top_n_train = 2000
+                                                                                                        (frcnn_la.py:154-203)
+  * RoI heads: proposals + ground truth; Matcher(0.5, 0.5); sampler(512, 0.25); BoxCoder (10, 10, 5, 5); cross-entropy +
+    smooth-L1 (beta 1/9) / #sampled                                                                     (frcnn_la.py:160-222)
+The samplers draw ``torch.randperm`` from the CPU generator (the reference draws on its CUDA device: a different stream of
+random numbers, the same distribution).
+"""
+import numpy as np
+import torch
+
+from . import train_ops as ops
+
+
+def _bn_fold(sd, prefix, eps=1e-5):
+    """FrozenBatchNorm2d as y = x * scale + shift (torchvision.ops.misc.FrozenBatchNorm2d, eps 1e-5 in 0.8.x)."""
+    w, b = sd[prefix + ".weight"].double(), sd[prefix + ".bias"].double()
+    rm, rv = sd[prefix + ".running_mean"].double(), sd[prefix + ".running_var"].double()
+    scale = w * (rv + eps).rsqrt()
+    return scale.float(), (b - rm * scale).float()
+
+
+class _Conv(object):
+    """One conv / linear layer of the graph: forward on the packed weight, backward = weight gradient + data gradient."""
+
+    def __init__(self, net, wnames, bnames=None, bn=None, stride=1, pad=0, cin_k=None, out_ld=None, mode=0, taps=None):
+        self.net, self.stride, self.pad, self.mode, self.taps = net, stride, pad, mode, taps
+        self.w = net.merged(wnames)                     # torch-layout view (several adjacent parameters merged along dim 0)
+        self.b = net.merged(bnames) if bnames else None
+        self.gw = net.merged_grad(wnames)
+        self.gb = net.merged_grad(bnames) if bnames else None
+        self.trainable = self.gw is not None
+        self.scale, self.shift = (None, None) if bn is None else net.bn[bn]
+        if mode == 2:
+            self.Cout, self.Cin, self.K = self.w.shape[0], self.w.shape[1] // taps, 1
+        elif self.w.dim() == 2:
+            self.Cout, self.Cin, self.K = self.w.shape[0], self.w.shape[1], 1
+        else:
+            self.Cout, self.Cin, self.K = self.w.shape[0], self.w.shape[1], self.w.shape[2]
+        self.cin_k = cin_k if cin_k is not None else self.Cin
+        self.out_ld = out_ld if out_ld is not None else self.Cout
+        self._pk = self._pkd = None
+        self._pk_version = self._pkd_version = -1
+        self.x = None
+
+    def _packed(self):
+        if self._pk is None or (self.trainable and self._pk_version != self.net.version):
+            buf = self._pk.buf if self._pk is not None else None
+            self._pk = ops.PackedConv(self.w, self.b, self.scale, self.shift, CinK=self.cin_k, mode=self.mode, taps=self.taps, out=buf)
+            self._pk_version = self.net.version
+            self._pkd_version = -1
+        return self._pk
+
+    def _packed_grad(self):
+        if self._pkd is None or self._pkd_version != self.net.version:
+            buf = self._pkd.buf if self._pkd is not None else None
+            self._pkd = ops.PackedConv(self.w, CinK=self.out_ld, mode=3 if self.mode == 2 else 1, taps=self.taps, out=buf)
+            self._pkd_version = self.net.version
+        return self._pkd
+
+    def fwd(self, x, relu=False, residual=None, up=None, out=None):
+        if self.trainable:
+            self.x = x
+        return ops.conv(x, self._packed(), stride=self.stride, pad=self.pad, relu=relu, residual=residual, up=up, out=out, out_ld=self.out_ld)
+
+    def bwd(self, g, need_dx=True, residual=None, accumulate=False, x=None):
+        """g: gradient wrt this layer's conv output (after the caller applied ReLU mask / BN scale), row stride out_ld."""
+        x = self.x if x is None else x
+        if self.mode == 2 or self.w.dim() == 2:
+            ops.linear_wgrad(x.view(g.shape[2], -1), g.view(g.shape[2], -1), self.Cout, self.gw, self.gb, taps=self.taps or 1, accumulate=accumulate)
+        else:
+            ops.conv_wgrad(x, g, self.Cin, self.Cout, self.K, self.K, self.stride, self.pad, self.gw, self.gb, accumulate=accumulate)
+        if not need_dx:
+            return None
+        pkd = self._packed_grad()
+        if self.mode == 2 or self.w.dim() == 2:
+            return ops.conv(g, pkd, residual=residual)
+        return ops.conv_dgrad(g, pkd, x.shape[1], x.shape[2], self.stride, self.pad, residual=residual)
+
+
+class _Bottleneck(object):
+    def __init__(self, net, prefix, stride, has_down, need_dx):
+        self.c1 = _Conv(net, [prefix + ".conv1.weight"], bn=prefix + ".bn1")
+        self.c2 = _Conv(net, [prefix + ".conv2.weight"], bn=prefix + ".bn2", stride=stride, pad=1)
+        self.c3 = _Conv(net, [prefix + ".conv3.weight"], bn=prefix + ".bn3")
+        self.down = _Conv(net, [prefix + ".downsample.0.weight"], bn=prefix + ".downsample.1", stride=stride) if has_down else None
+        self.trainable, self.need_dx = self.c1.trainable, need_dx
+
+    def fwd(self, x):
+        self.a1 = self.c1.fwd(x, relu=True)
+        self.a2 = self.c2.fwd(self.a1, relu=True)
+        idt = self.down.fwd(x) if self.down is not None else x
+        self.out = self.c3.fwd(self.a2, relu=True, residual=idt)
+        return self.out
+
+    def bwd(self, gout):
+        """gout: gradient wrt the block output (after its ReLU); consumed.  Returns the gradient wrt the block input (or None)."""
+        g = ops.relu_bwd_(gout, self.out)                                   # through the final ReLU: shared by both branches
+        g3 = ops.relu_bwd_(ops.add(g), None, self.c3.scale)                 # bn3 scale
+        ga2 = self.c3.bwd(g3)
+        ops.relu_bwd_(ga2, self.a2, self.c2.scale)
+        ga1 = self.c2.bwd(ga2)
+        ops.relu_bwd_(ga1, self.a1, self.c1.scale)
+        if self.down is not None:
+            gd = ops.relu_bwd_(g, None, self.down.scale)                    # g is no longer needed unscaled
+            if not self.need_dx:
+                self.c1.bwd(ga1, need_dx=False); self.down.bwd(gd, need_dx=False)
+                return None
+            gx = self.down.bwd(gd)
+            return self.c1.bwd(ga1, residual=gx)
+        return self.c1.bwd(ga1, residual=g)
+
+
+class FasterRCNNTrainer(object):
+    """The trainable mirror of detection/frcnn_la.py FRCNN_Feature (ResNet-50/101 FPN Faster R-CNN) on one MI355X."""
+
+    def __init__(self, state_dict, num_classes, depth=50, min_size=600, max_size=1000, device="cuda", trainable_layers=3,
+                 rpn_pre_nms_top_n=2000, rpn_post_nms_top_n=2000, rpn_nms_thresh=0.7, rpn_fg_iou=0.7, rpn_bg_iou=0.3,
+                 rpn_batch=256, rpn_pos_fraction=0.5, box_fg_iou=0.5, box_bg_iou=0.5, box_batch=512, box_pos_fraction=0.25,
+                 bbox_reg_weights=(10.0, 10.0, 5.0, 5.0), generator=None):
+        self.dev = torch.device(device)
+        self.C, self.min_size, self.max_size = num_classes, int(min_size), int(max_size)
+        self.cfg = dict(pre_n=rpn_pre_nms_top_n, post_n=rpn_post_nms_top_n, nms=rpn_nms_thresh, rpn_fg=rpn_fg_iou, rpn_bg=rpn_bg_iou,
+                        rpn_batch=rpn_batch, rpn_pos=rpn_pos_fraction, box_fg=box_fg_iou, box_bg=box_bg_iou, box_batch=box_batch,
+                        box_pos=box_pos_fraction, w=tuple(bbox_reg_weights))
+        self.generator = generator
+        self.version = 0                                   # bumped whenever the parameters change: packed weights are rebuilt lazily
+        sd = {k: (v.detach().float().cpu() if hasattr(v, "detach") else torch.from_numpy(np.asarray(v, np.float32)))
+              for k, v in state_dict.items() if not k.endswith("num_batches_tracked")}
+        frozen_layers = ["layer4", "layer3", "layer2", "layer1", "conv1"][trainable_layers:]
+        def is_frozen(k):
+            if ".bn" in k or "downsample.1" in k or k.startswith("backbone.body.bn1"):
+                return True
+            return k.startswith("backbone.body.") and any(k.startswith("backbone.body." + f) for f in frozen_layers + ["bn1"])
+        # parameter storage: trainable tensors live in ONE flat buffer in state-dict order, so that tensors torchvision keeps
+        # apart but the kernels treat as one matrix (RPN cls_logits + bbox_pred, predictor cls_score + bbox_pred) are adjacent
+        self.names = [k for k in sd if not is_frozen(k)]
+        for a, b in (("rpn.head.cls_logits.weight", "rpn.head.bbox_pred.weight"), ("rpn.head.cls_logits.bias", "rpn.head.bbox_pred.bias"),
+                     ("roi_heads.box_predictor.cls_score.weight", "roi_heads.box_predictor.bbox_pred.weight"),
+                     ("roi_heads.box_predictor.cls_score.bias", "roi_heads.box_predictor.bbox_pred.bias")):
+            self.names.remove(b)
+            self.names.insert(self.names.index(a) + 1, b)
+        sizes = [sd[k].numel() for k in self.names]
+        pad = [(-s) % 4 for s in sizes]                    # keep every tensor 16-byte aligned...
+        self._merge_groups = [["rpn.head.cls_logits.weight", "rpn.head.bbox_pred.weight"], ["rpn.head.cls_logits.bias", "rpn.head.bbox_pred.bias"],
+                              ["roi_heads.box_predictor.cls_score.weight", "roi_heads.box_predictor.bbox_pred.weight"],
+                              ["roi_heads.box_predictor.cls_score.bias", "roi_heads.box_predictor.bbox_pred.bias"]]
+        for grp in self._merge_groups:                     # ...except inside a merged group, which must be contiguous
+            i = self.names.index(grp[0])
+            assert self.names[i + 1] == grp[1], "state-dict order must keep %s adjacent" % grp
+            pad[i] = 0
+        offs, o = [], 0
+        for s, p in zip(sizes, pad):
+            offs.append(o); o += s + p
+        self.flat = torch.zeros(o, dtype=torch.float32, device=self.dev)
+        self.gflat = torch.zeros(o, dtype=torch.float32, device=self.dev)
+        self._off = dict(zip(self.names, offs))
+        self.params, self.grads, self.frozen = {}, {}, {}
+        for k, off in zip(self.names, offs):
+            v = self.flat[off:off + sd[k].numel()].view(sd[k].shape)
+            v.copy_(sd[k])
+            self.params[k] = torch.nn.Parameter(v, requires_grad=True)
+            self.grads[k] = self.gflat[off:off + sd[k].numel()].view(sd[k].shape)
+        for k in sd:
+            if k not in self.params:
+                self.frozen[k] = sd[k].to(self.dev)
+        self.bn = {}
+        for k in sd:
+            if k.endswith(".running_var"):
+                p = k[:-len(".running_var")]
+                sc, sh = _bn_fold(sd, p)
+                self.bn[p] = (sc.to(self.dev), sh.to(self.dev))
+        # ---- graph ----
+        w1 = self.frozen["backbone.body.conv1.weight"]
+        self.frozen["__conv1_4ch"] = torch.cat([w1, torch.zeros_like(w1[:, :1])], dim=1).contiguous()      # the stem reads RGB0
+        self.stem = _Conv(self, ["__conv1_4ch"], bn="backbone.body.bn1", stride=2, pad=3)
+        nblocks = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}[depth]
+        self.layers = []
+        for li, nb in enumerate(nblocks):
+            name = "layer%d" % (li + 1)
+            trainable = name not in frozen_layers
+            prev_trainable = li > 0 and ("layer%d" % li) not in frozen_layers
+            blocks = [_Bottleneck(self, "backbone.body.%s.%d" % (name, b), stride=(2 if (b == 0 and li > 0) else 1), has_down=(b == 0),
+                                  need_dx=(b > 0 or prev_trainable)) for b in range(nb)]
+            self.layers.append((trainable, blocks))
+        self.lat = [_Conv(self, ["backbone.fpn.inner_blocks.%d.weight" % i], ["backbone.fpn.inner_blocks.%d.bias" % i]) for i in range(4)]
+        self.fout = [_Conv(self, ["backbone.fpn.layer_blocks.%d.weight" % i], ["backbone.fpn.layer_blocks.%d.bias" % i], pad=1) for i in range(4)]
+        self.rpn_conv = _Conv(self, ["rpn.head.conv.weight"], ["rpn.head.conv.bias"], pad=1)
+        self.rpn_head = _Conv(self, self._merge_groups[0], self._merge_groups[1], out_ld=16)
+        self.fc6 = _Conv(self, ["roi_heads.box_head.fc6.weight"], ["roi_heads.box_head.fc6.bias"], mode=2, taps=49)
+        self.fc7 = _Conv(self, ["roi_heads.box_head.fc7.weight"], ["roi_heads.box_head.fc7.bias"])
+        self.pred_ld = ops.round_up(5 * num_classes, 4)
+        self.pred = _Conv(self, self._merge_groups[2], self._merge_groups[3], out_ld=self.pred_ld)
+        assert self.pred.Cout == 5 * num_classes, "box predictor does not match num_classes"
+        self._anchors = {}
+        self.last = None
+
+    # ---- parameter plumbing ----
+    def _lookup(self, name):
+        return self.params[name] if name in self.params else self.frozen[name]
+
+    def merged(self, names):
+        if names is None:
+            return None
+        if len(names) == 1:
+            return self._lookup(names[0]).detach()
+        first, n = self._lookup(names[0]).detach(), sum(self._lookup(k).numel() for k in names)
+        rows = sum(self._lookup(k).shape[0] for k in names)
+        return self.flat[self._off[names[0]]:self._off[names[0]] + n].view((rows,) + tuple(first.shape[1:]))
+
+    def merged_grad(self, names):
+        if names is None or names[0] not in self.params:
+            return None
+        first, n = self.params[names[0]], sum(self.params[k].numel() for k in names)
+        rows = sum(self.params[k].shape[0] for k in names)
+        return self.gflat[self._off[names[0]]:self._off[names[0]] + n].view((rows,) + tuple(first.shape[1:]))
+
+    def parameters(self):
+        return [self.params[k] for k in self.names]
+
+    def named_parameters(self):
+        return [(k, self.params[k]) for k in self.names]
+
+    def state_dict(self):
+        out = {k: v.detach().clone() for k, v in self.params.items()}
+        out.update({k: v.clone() for k, v in self.frozen.items() if not k.startswith("__")})
+        return out
+
+    def parameters_changed(self):
+        self.version += 1
+
+    # ---- forward ----
+    def _prepare_images(self, images):
+        u8, rem = [], []
+        for img in images:
+            if img.dtype == torch.uint8:
+                u8.append((img if img.shape[-1] == 3 else img.permute(1, 2, 0)).contiguous().to(self.dev)); rem.append(None)
+                continue
+            x = img.detach().to(torch.float32).to(self.dev).contiguous()
+            g = (x * 255.0).round().clamp(0, 255).to(torch.uint8)
+            from .detector import _u8_over_255
+            r = x - _u8_over_255(x.device)[g.long()]
+            u8.append(g.permute(1, 2, 0).contiguous()); rem.append(r.contiguous() if bool((r != 0).any()) else None)
+        return u8, rem
+
+    def anchors(self, Hp, Wp, level_hw):
+        key = (Hp, Wp)
+        if key not in self._anchors:
+            self._anchors[key] = ops.anchors(Hp, Wp, level_hw, self.dev)
+        return self._anchors[key]
+
+    def _randperm(self, n):
+        return torch.randperm(n, generator=self.generator)
+
+    def _sample(self, pos, neg, batch, frac):
+        """BalancedPositiveNegativeSampler for one image: index tensors (CPU) of the sampled positives / negatives."""
+        num_pos = min(int(batch * frac), pos.numel())
+        num_neg = min(batch - num_pos, neg.numel())
+        p = pos[self._randperm(pos.numel())[:num_pos]]
+        n = neg[self._randperm(neg.numel())[:num_neg]]
+        return p, n
+
+    def forward(self, images, targets, proposals_override=None):
+        """Training forward.  Returns the four losses as 1-element device tensors (no autograd) and keeps what backward needs."""
+        cfg, N, Ccls = self.cfg, len(images), self.C
+        self.version += 1                                  # whoever updated the parameters (any optimizer): repack the trainable layers
+        u8, rem = self._prepare_images(images)
+        sizes = [ops.transform_size(im.shape[0], im.shape[1], self.min_size, self.max_size) for im in u8]
+        Hp, Wp = max(s[2] for s in sizes), max(s[3] for s in sizes)
+        img_sizes = [(s[0], s[1]) for s in sizes]
+        gts, gt_labels = [], []
+        for im, s, t in zip(u8, sizes, targets):                    # resize_boxes: per-axis ratio in float32
+            b = t["boxes"].detach().float().cpu().reshape(-1, 4)
+            rh = torch.tensor(s[0], dtype=torch.float32) / torch.tensor(im.shape[0], dtype=torch.float32)
+            rw = torch.tensor(s[1], dtype=torch.float32) / torch.tensor(im.shape[1], dtype=torch.float32)
+            gts.append(torch.stack([b[:, 0] * rw, b[:, 1] * rh, b[:, 2] * rw, b[:, 3] * rh], dim=1).to(self.dev).contiguous())
+            gt_labels.append(t["labels"].detach().long().cpu().reshape(-1))
+        x = ops.preprocess(u8, img_sizes, Hp, Wp, rem)
+        x = ops.maxpool(self.stem.fwd(x, relu=True))
+        feats = []
+        for trainable, blocks in self.layers:
+            for blk in blocks:
+                x = blk.fwd(x)
+            feats.append(x)
+        # FPN (top-down), LastLevelMaxPool
+        inner = [None] * 4
+        inner[3] = self.lat[3].fwd(feats[3])
+        for i in (2, 1, 0):
+            inner[i] = self.lat[i].fwd(feats[i], up=inner[i + 1])
+        P = [self.fout[i].fwd(inner[i]) for i in range(4)]
+        P.append(ops.subsample2(P[3]))
+        level_hw = [(p.shape[1], p.shape[2]) for p in P]
+        # RPN head on the five levels: outputs in ONE buffer so that the loss kernels address (level, pixel, channel) by offset
+        head_sizes = [N * h * w * 16 for h, w in level_hw]
+        head_flat = torch.zeros(sum(head_sizes), dtype=torch.float32, device=self.dev)
+        heads, tl, o = [], [], 0
+        for i, (h, w) in enumerate(level_hw):
+            t = ops.conv(P[i], self.rpn_conv._packed(), pad=1, relu=True)
+            tl.append(t)
+            heads.append(ops.conv(t, self.rpn_head._packed(), out=head_flat[o:o + head_sizes[i]].view(N, h, w, 16), out_ld=16))
+            o += head_sizes[i]
+        anchors = self.anchors(Hp, Wp, level_hw)
+        A_img = anchors.shape[0]
+        if proposals_override is None:
+            props, counts = ops.rpn_proposals(heads, Hp, Wp, img_sizes, cfg["pre_n"], cfg["post_n"], cfg["nms"], 1e-3)
+            counts = counts.cpu().tolist()
+            proposals = [props[i, :counts[i]] for i in range(N)]
+        else:
+            proposals = [p.to(self.dev).float().contiguous() for p in proposals_override]
+        # ---- RPN targets and sampling (anchor order: level, y, x, anchor) ----
+        lvl_start = np.cumsum([0] + [h * w * 3 for h, w in level_hw])
+        head_off = np.cumsum([0] + head_sizes)
+        def head_offsets(img, idx):                                  # float offset of anchor idx's objectness logit in head_flat
+            idx = idx.numpy()
+            l = np.searchsorted(lvl_start, idx, side="right") - 1
+            rel = idx - lvl_start[l]
+            pix, a = rel // 3, rel % 3
+            hw = np.array([h * w for h, w in level_hw])[l]
+            return head_off[l] + (img * hw + pix) * 16 + a, a
+        obj_idx, obj_lab, box_idx, box_anchor, box_gt = [], [], [], [], []
+        for i in range(N):
+            if gts[i].shape[0] == 0:
+                matched = torch.full((A_img,), -1, dtype=torch.int32)
+            else:
+                matched = ops.match(anchors, gts[i], cfg["rpn_fg"], cfg["rpn_bg"], True).cpu()
+            pos, neg = torch.nonzero(matched >= 0).squeeze(1), torch.nonzero(matched == -1).squeeze(1)
+            sp, sn = self._sample(pos, neg, cfg["rpn_batch"], cfg["rpn_pos"])
+            sp, sn = sp.sort().values, sn.sort().values
+            op_, ap_ = head_offsets(i, sp); on_, _ = head_offsets(i, sn)
+            obj_idx += [op_, on_]; obj_lab += [np.ones(len(op_), np.float32), np.zeros(len(on_), np.float32)]
+            box_idx.append(op_ - ap_ + 3 + 4 * ap_)                  # channel 3 + 4a of the same pixel
+            box_anchor.append(anchors[sp.to(self.dev)]); box_gt.append(gts[i][matched[sp].long().to(self.dev)] if len(sp) else gts[i][:0])
+        obj_idx = torch.from_numpy(np.concatenate(obj_idx).astype(np.int64)).to(self.dev)
+        obj_lab = torch.from_numpy(np.concatenate(obj_lab)).to(self.dev)
+        box_idx = torch.from_numpy(np.concatenate(box_idx).astype(np.int64)).to(self.dev)
+        rpn_tgt = ops.box_encode(torch.cat(box_gt), torch.cat(box_anchor), (1.0, 1.0, 1.0, 1.0))
+        # ---- RoI sampling ----
+        rois, roi_labels, roi_gt = [], [], []
+        for i in range(N):
+            pr = torch.cat([proposals[i], gts[i]]) if gts[i].shape[0] else proposals[i]
+            if gts[i].shape[0] == 0:
+                matched = torch.full((pr.shape[0],), -1, dtype=torch.int32); labels = torch.zeros(pr.shape[0], dtype=torch.int64)
+            else:
+                matched = ops.match(pr.contiguous(), gts[i], cfg["box_fg"], cfg["box_bg"], False).cpu()
+                labels = gt_labels[i][matched.clamp(min=0).long()]
+                labels[matched == -1] = 0
+                labels[matched == -2] = -1
+            pos, neg = torch.nonzero(labels >= 1).squeeze(1), torch.nonzero(labels == 0).squeeze(1)
+            sp, sn = self._sample(pos, neg, cfg["box_batch"], cfg["box_pos"])
+            keep = torch.cat([sp, sn]).sort().values
+            kd = keep.to(self.dev)
+            boxes = pr[kd]
+            rois.append(torch.cat([torch.full((len(keep), 1), float(i), device=self.dev), boxes], dim=1))
+            roi_labels.append(labels[keep])
+            roi_gt.append(gts[i][matched[keep].clamp(min=0).long().to(self.dev)] if gts[i].shape[0] else torch.zeros_like(boxes))
+        rois = torch.cat(rois).contiguous(); roi_labels = torch.cat(roi_labels)
+        R = rois.shape[0]
+        box_tgt_all = ops.box_encode(torch.cat(roi_gt).contiguous(), rois[:, 1:].contiguous(), cfg["w"])
+        pos_rows = torch.nonzero(roi_labels > 0).squeeze(1)
+        pred_idx = (pos_rows * self.pred_ld + Ccls + 4 * roi_labels[pos_rows]).to(self.dev)
+        box_tgt = box_tgt_all[pos_rows.to(self.dev)].contiguous()
+        # ---- box head ----
+        roi_rows = ops.roi_align(P[:4], rois)
+        f6 = self.fc6.fwd(roi_rows.view(1, 1, R, -1), relu=True)
+        f7 = self.fc7.fwd(f6, relu=True)
+        pred = self.pred.fwd(f7)
+        labels_dev = roi_labels.to(self.dev)
+        self.last = dict(N=N, R=R, feats=feats, inner=inner, P=P, tl=tl, heads=heads, head_flat=head_flat, head_sizes=head_sizes, level_hw=level_hw,
+                         obj_idx=obj_idx, obj_lab=obj_lab, box_idx=box_idx, rpn_tgt=rpn_tgt, rois=rois, roi_rows=roi_rows, f6=f6, f7=f7, pred=pred,
+                         labels=labels_dev, pred_idx=pred_idx, box_tgt=box_tgt, proposals=proposals, roi_labels=roi_labels)
+        n_obj = obj_idx.numel()
+        losses = {
+            "loss_classifier": ops.softmax_ce(pred.view(R, -1), labels_dev, Ccls),
+            "loss_box_reg": ops.smooth_l1(pred, pred_idx, box_tgt, 1.0 / 9, R),
+            "loss_objectness": ops.bce_logits(head_flat, obj_idx, obj_lab),
+            "loss_rpn_box_reg": ops.smooth_l1(head_flat, box_idx, rpn_tgt, 1.0 / 9, n_obj),
+        }
+        return losses
+
+    def relu_decisions(self):
+        """{name: bool NCHW / [R, C] CPU tensor}: which side every ReLU of the last forward's differentiated part took (for
+        gradient checks against a higher-precision restatement, which must take the same branches)."""
+        L, out = self.last, {}
+        nchw = lambda t: (t > 0).permute(0, 3, 1, 2).cpu()
+        for li, (trainable, blocks) in enumerate(self.layers):
+            for b, blk in enumerate(blocks):
+                if trainable:
+                    out.update({"layer%d.%d.a1" % (li + 1, b): nchw(blk.a1), "layer%d.%d.a2" % (li + 1, b): nchw(blk.a2), "layer%d.%d.out" % (li + 1, b): nchw(blk.out)})
+        for i, t in enumerate(L["tl"]):
+            out["rpn.%d" % i] = nchw(t)
+        out["fc6"] = (L["f6"] > 0).view(L["R"], -1).cpu(); out["fc7"] = (L["f7"] > 0).view(L["R"], -1).cpu()
+        return out
+
+    # ---- backward ----
+    def backward(self, gscale=(1.0, 1.0, 1.0, 1.0)):
+        """Gradients of sum_i gscale[i] * loss_i (order: classifier, box_reg, objectness, rpn_box_reg) into the flat gradient buffer."""
+        L = self.last
+        N, R, P, level_hw = L["N"], L["R"], L["P"], L["level_hw"]
+        # box head
+        gpred = torch.zeros_like(L["pred"])
+        ops.softmax_ce(L["pred"].view(R, -1), L["labels"], self.C, grad=gpred, gscale=gscale[0])
+        ops.smooth_l1(L["pred"], L["pred_idx"], L["box_tgt"], 1.0 / 9, R, grad=gpred, gscale=gscale[1])
+        g7 = self.pred.bwd(gpred)
+        ops.relu_bwd_(g7, L["f7"])
+        g6 = self.fc7.bwd(g7)
+        ops.relu_bwd_(g6, L["f6"])
+        groi = self.fc6.bwd(g6)
+        gP = [torch.zeros_like(p) for p in P[:4]]
+        ops.roi_align_bwd_(gP, L["rois"], groi.view(R, 49, -1))
+        # RPN head (shared weights: gradients accumulate over the five levels)
+        ghead_flat = torch.zeros_like(L["head_flat"])
+        ops.bce_logits(L["head_flat"], L["obj_idx"], L["obj_lab"], grad=ghead_flat, gscale=gscale[2])
+        ops.smooth_l1(L["head_flat"], L["box_idx"], L["rpn_tgt"], 1.0 / 9, L["obj_idx"].numel(), grad=ghead_flat, gscale=gscale[3])
+        o, gpool = 0, None
+        for i, (h, w) in enumerate(level_hw):
+            gh = ghead_flat[o:o + L["head_sizes"][i]].view(N, h, w, 16); o += L["head_sizes"][i]
+            gt = self.rpn_head.bwd(gh, accumulate=i > 0, x=L["tl"][i])
+            ops.relu_bwd_(gt, L["tl"][i])
+            if i < 4:
+                gP[i] = self.rpn_conv.bwd(gt, residual=gP[i], accumulate=i > 0, x=P[i])
+            else:
+                gpool = self.rpn_conv.bwd(gt, accumulate=True, x=P[4])
+        gP[3] = ops.add(gP[3], ops.dilate(gpool, 2, P[3].shape[1], P[3].shape[2]))          # LastLevelMaxPool (kernel 1, stride 2)
+        # FPN
+        ginner = [None] * 4
+        for i in range(4):
+            ginner[i] = self.fout[i].bwd(gP[i])
+            if i > 0:
+                ops.upsample_bwd_(ginner[i - 1], ginner[i])
+        gC = [None] * 4
+        for i in range(4):
+            need = self.layers[i][0]                                                       # the body layer producing feats[i] is trainable
+            gC[i] = self.lat[i].bwd(ginner[i], need_dx=need)
+        # body
+        g = None
+        for li in (3, 2, 1, 0):
+            trainable, blocks = self.layers[li]
+            if not trainable:
+                break
+            g = gC[li] if g is None else ops.add(gC[li], g)
+            for blk in reversed(blocks):
+                g = blk.bwd(g)
+        return self.grads
+
+
+class _LossFn(torch.autograd.Function):
+    """Bridges the hand-written backward into torch autograd so that the reference's ``losses.backward()`` works unchanged."""
+
+    @staticmethod
+    def forward(ctx, anchor, net, images, targets):
+        ctx.net = net
+        d = net.forward(images, targets)
+        return tuple(d[k].reshape(()) for k in ("loss_classifier", "loss_box_reg", "loss_objectness", "loss_rpn_box_reg"))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        net = ctx.net
+        gscale = [0.0 if g is None else float(g) for g in gs]
+        net.backward(gscale)
+        for k in net.names:
+            p = net.params[k]
+            if p.grad is None:
+                p.grad = net.grads[k]
+            elif p.grad.data_ptr() != net.grads[k].data_ptr():
+                p.grad.add_(net.grads[k])
+        return None, None, None, None
+
+
+class TrainableFasterRCNN(object):
+    """``task_model`` in train mode: ``model(images, targets) -> {loss name: scalar tensor}`` whose sum can be ``.backward()``-ed."""
+
+    def __init__(self, net):
+        self.net = net
+        self._anchor = torch.zeros(1, device=net.dev, requires_grad=True)
+        self.training = True
+
+    def parameters(self):
+        return self.net.parameters()
+
+    def __call__(self, images, targets):
+        out = _LossFn.apply(self._anchor, self.net, images, targets)
+        return dict(zip(("loss_classifier", "loss_box_reg", "loss_objectness", "loss_rpn_box_reg"), out))
+
+
+class SGD(torch.optim.Optimizer):
+    """torch.optim.SGD(params, lr, momentum, weight_decay) (cald_train.py:397) with the update done by one HIP kernel per tensor.
+    ``param_groups[i]['lr']`` is read every step, so torch's lr schedulers (warmup LambdaLR, MultiStepLR) drive it unchanged."""
+
+    def __init__(self, params, lr, momentum=0.0, weight_decay=0.0, net=None):
+        super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
+        self.net = net
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        for grp in self.param_groups:
+            for p in grp["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                first = "momentum_buffer" not in st
+                if first and grp["momentum"] != 0:
+                    st["momentum_buffer"] = torch.zeros_like(p)
+                ops.sgd_(p.data, p.grad, st.get("momentum_buffer"), grp["lr"], grp["momentum"], grp["weight_decay"], first)
+        if self.net is not None:
+            self.net.parameters_changed()

@@ -36,9 +36,9 @@ class PackedConv(object):
 
     def __init__(self, weight, bias=None, scale=None, shift=None, CinK=None, mode=0, taps=None, out=None):
         _chk(weight, "weight")
-        if mode == 2:                                    # linear on [tap][Cin] rows, torch weight [Cout, Cin * taps]
+        if mode in (2, 3):                               # linear on [tap][Cin] rows, torch weight [Cout, Cin * taps] (3: its data gradient)
             self.Cout, self.Cin, self.KH, self.KW = weight.shape[0], weight.shape[1] // taps, taps, 1
-            CinK = self.Cin
+            CinK = self.Cin if mode == 2 else (CinK if CinK is not None else round_up(self.Cout, 4))
         elif weight.dim() == 2:                          # plain linear layer = 1x1 conv
             self.Cout, self.Cin, self.KH, self.KW = weight.shape[0], weight.shape[1], 1, 1
         else:
@@ -57,9 +57,12 @@ def conv(x, pk, stride=1, pad=0, relu=False, residual=None, up=None, out=None, o
     """Forward conv / linear (pk.mode 0 or 2) or stride-1 data gradient (pk.mode 1) of a dense NHWC batch."""
     _chk(x, "x")
     N, H, W, Cx = x.shape
-    n_out = pk.Cin if pk.mode == 1 else pk.Cout
+    n_out = pk.Cin if pk.mode == 1 else (pk.Cin * pk.KH if pk.mode == 3 else pk.Cout)
     if pk.mode == 2:
         assert Cx == pk.Cin * pk.KH
+        kh = kw = 1
+    elif pk.mode == 3:
+        assert Cx == pk.CinK
         kh = kw = 1
     else:
         assert Cx == pk.CinK, (Cx, pk.CinK)
@@ -70,7 +73,7 @@ def conv(x, pk, stride=1, pad=0, relu=False, residual=None, up=None, out=None, o
         out = (torch.zeros if ld != n_out else torch.empty)((N, Ho, Wo, ld), dtype=torch.float32, device=x.device)
     Hup, Wup = (up.shape[1], up.shape[2]) if up is not None else (0, 0)
     flags = pk.flags | (FLAG_RELU if relu else 0)
-    _ffi.check(_ffi.lib().cald_train_conv(get_ctx(x.device.index), N, H, W, _p(x), Cx if pk.mode != 2 else pk.Cin, _p(pk.buf), pk.Cout,
+    _ffi.check(_ffi.lib().cald_train_conv(get_ctx(x.device.index), N, H, W, _p(x), pk.CinK, _p(pk.buf), pk.Cout,
                                           pk.Cin, pk.KH, pk.KW, stride, pad, pk.mode, flags, _p(residual), _p(up), Hup, Wup, _p(out), ld))
     return out
 
@@ -129,3 +132,114 @@ def upsample_bwd_(fine, coarse):
 def sgd_(param, grad, buf, lr, momentum, weight_decay, first_step):
     _ffi.check(_ffi.lib().cald_train_sgd(get_ctx(param.device.index), param.numel(), _p(param), _p(grad), _p(buf), lr, momentum, weight_decay,
                                          int(first_step)))
+
+
+def _ptr_array(ts):
+    return (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+
+
+def _int_array(vals):
+    return (C.c_int * len(vals))(*[int(v) for v in vals])
+
+
+def rpn_proposals(heads, Hp, Wp, image_sizes, pre_n=2000, post_n=2000, nms_thr=0.7, min_size=1e-3):
+    """heads: five [N, Hl, Wl, 16] tensors (3 logits + 12 deltas + 1 pad).  Returns (proposals [N, post_n, 4], counts [N] int32)."""
+    N = heads[0].shape[0]
+    dev = heads[0].device
+    props = torch.zeros((N, post_n, 4), dtype=torch.float32, device=dev)
+    counts = torch.zeros(N, dtype=torch.int32, device=dev)
+    hw = [v for h in heads for v in (h.shape[1], h.shape[2])]
+    _ffi.check(_ffi.lib().cald_train_rpn_proposals(get_ctx(dev.index), N, Hp, Wp, _int_array([v for s in image_sizes for v in s]), _ptr_array(heads),
+                                                   _int_array(hw), heads[0].shape[3], pre_n, post_n, nms_thr, min_size, _p(props), _p(counts)))
+    return props, counts
+
+
+def anchors(Hp, Wp, level_hw, device):
+    n = sum(h * w * 3 for h, w in level_hw)
+    out = torch.empty((n, 4), dtype=torch.float32, device=device)
+    _ffi.check(_ffi.lib().cald_train_anchors(get_ctx(device.index), Hp, Wp, _int_array([v for s in level_hw for v in s]), _p(out)))
+    return out
+
+
+def match(boxes, gt, hi, lo, allow_low_quality):
+    out = torch.empty(boxes.shape[0], dtype=torch.int32, device=boxes.device)
+    _ffi.check(_ffi.lib().cald_train_match(get_ctx(boxes.device.index), boxes.shape[0], _p(boxes), gt.shape[0], _p(gt), hi, lo, int(allow_low_quality),
+                                           _p(out), None))
+    return out
+
+
+def box_encode(reference, proposals, weights):
+    out = torch.empty_like(proposals)
+    _ffi.check(_ffi.lib().cald_train_box_encode(get_ctx(proposals.device.index), proposals.shape[0], _p(reference), _p(proposals), *[float(w) for w in weights],
+                                                _p(out)))
+    return out
+
+
+def roi_align(feats, rois):
+    """feats: four [N, Hl, Wl, C]; rois [R, 5] (image index, box).  Returns [R, 49, C]."""
+    R, Cc = rois.shape[0], feats[0].shape[3]
+    out = torch.empty((R, 49, Cc), dtype=torch.float32, device=rois.device)
+    hw = [v for f in feats for v in (f.shape[1], f.shape[2])]
+    _ffi.check(_ffi.lib().cald_train_roi_align(get_ctx(rois.device.index), _ptr_array(feats), _int_array(hw), Cc, R, _p(rois), _p(out)))
+    return out
+
+
+def roi_align_bwd_(gfeats, rois, gout):
+    hw = [v for f in gfeats for v in (f.shape[1], f.shape[2])]
+    _ffi.check(_ffi.lib().cald_train_roi_align_bwd(get_ctx(rois.device.index), _ptr_array(gfeats), _int_array(hw), gfeats[0].shape[3], rois.shape[0], _p(rois),
+                                                   _p(gout)))
+    return gfeats
+
+
+def softmax_ce(logits, labels, Ccls, grad=None, gscale=1.0):
+    """logits [R, ld] (first Ccls columns are the class logits), labels int64 [R].  Returns the loss as a 1-element tensor."""
+    loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+    _ffi.check(_ffi.lib().cald_train_softmax_ce(get_ctx(logits.device.index), logits.shape[0], Ccls, logits.shape[1], _p(logits), _p(labels), gscale,
+                                                _p(loss), _p(grad)))
+    return loss
+
+
+def smooth_l1(pred, idx, target, beta, denom, grad=None, gscale=1.0):
+    loss = torch.empty(1, dtype=torch.float32, device=pred.device)
+    _ffi.check(_ffi.lib().cald_train_smooth_l1(get_ctx(pred.device.index), idx.numel(), _p(pred), _p(idx), _p(target), beta, float(denom), gscale, _p(loss),
+                                               _p(grad)))
+    return loss
+
+
+def bce_logits(logits, idx, labels, grad=None, gscale=1.0):
+    loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+    _ffi.check(_ffi.lib().cald_train_bce_logits(get_ctx(logits.device.index), idx.numel(), _p(logits), _p(idx), _p(labels), gscale, _p(loss), _p(grad)))
+    return loss
+
+
+def preprocess(images_u8, sizes, Hp, Wp, remainders=None):
+    """images_u8: list of uint8 [H, W, 3] cuda tensors; sizes: list of (Hr, Wr).  Returns [N, Hp, Wp, 4] float32."""
+    N = len(images_u8)
+    dev = images_u8[0].device
+    out = torch.empty((N, Hp, Wp, 4), dtype=torch.float32, device=dev)
+    hw = [v for im, (hr, wr) in zip(images_u8, sizes) for v in (im.shape[0], im.shape[1], hr, wr)]
+    rem = None
+    if remainders is not None and any(r is not None for r in remainders):
+        rem = (C.c_void_p * N)(*[(r.data_ptr() if r is not None else None) for r in remainders])
+    _ffi.check(_ffi.lib().cald_train_preprocess(get_ctx(dev.index), N, _ptr_array(images_u8), rem, _int_array(hw), Hp, Wp, _p(out)))
+    return out
+
+
+def maxpool(x):
+    N, H, W, Cc = x.shape
+    out = torch.empty((N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, Cc), dtype=torch.float32, device=x.device)
+    _ffi.check(_ffi.lib().cald_train_maxpool(get_ctx(x.device.index), N, H, W, Cc, _p(x), _p(out)))
+    return out
+
+
+def subsample2(x):
+    N, H, W, Cc = x.shape
+    out = torch.empty((N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, Cc), dtype=torch.float32, device=x.device)
+    _ffi.check(_ffi.lib().cald_train_subsample2(get_ctx(x.device.index), N, H, W, Cc, _p(x), _p(out)))
+    return out
+
+
+def transform_size(H, W, min_size, max_size):
+    hr, wr, hp, wp = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    _ffi.check(_ffi.lib().cald_op_transform_size(H, W, min_size, max_size, C.byref(hr), C.byref(wr), C.byref(hp), C.byref(wp)))
+    return hr.value, wr.value, hp.value, wp.value

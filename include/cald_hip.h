@@ -225,7 +225,8 @@ int cald_train_packed_floats(int Cout, int Cin, int KH, int KW, int CinK, int mo
 /* packs weight (+ optional bias / FrozenBatchNorm scale, shift: [Cout]) for the MFMA conv kernels, on the device.
  *   mode 0  forward over an input whose channel stride is CinK >= Cin (multiple of 4; extra channels must be zero or finite)
  *   mode 1  data gradient: the flipped, transposed filter applied to dY with channel stride CinK >= Cout
- *   mode 2  linear layer on rows laid out [tap][Cin] whose torch weight is [Cout][Cin * taps] (box_head.fc6 on RoIAlign rows) */
+ *   mode 2  linear layer on rows laid out [tap][Cin] whose torch weight is [Cout][Cin * taps] (box_head.fc6 on RoIAlign rows)
+ *   mode 3  data gradient of a mode-2 layer (dY rows with channel stride CinK >= Cout -> rows laid out [tap][Cin]) */
 int cald_train_pack_conv(cald_ctx* ctx, const float* weight, const float* bias, const float* bn_scale, const float* bn_shift,
                          int Cout, int Cin, int KH, int KW, int CinK, int mode, float* packed);
 /* out[N][Ho][Wo][out_ld] = epilogue(conv(in[N][H][W][CinK], packed)); flags: 1 bias, 2 scale/shift, 4 ReLU; residual (same
@@ -249,6 +250,44 @@ int cald_train_add(cald_ctx* ctx, long long n, float* dst, const float* a, const
 int cald_train_dilate(cald_ctx* ctx, int N, int Ho, int Wo, int C, int s, int Hd, int Wd, const float* g, float* out);
 /* FPN top-down backward: coarse += sum of the fine pixels that nearest-upsampling reads from each coarse pixel */
 int cald_train_upsample_bwd(cald_ctx* ctx, int N, int Hf, int Wf, int Hc, int Wc, int C, const float* fine, float* coarse);
+/* RegionProposalNetwork.filter_proposals at training sizes (pre / post_nms_top_n <= 2048): heads[l] = [N][Hl][Wl][head_ld] with
+ * channel a = objectness of anchor a (A = 3), channel 3 + 4a + j = delta j; level_hw = {H0, W0, ..., H4, W4}; image_sizes = host
+ * [N][2] resized (h, w).  proposals_out [N][post_n][4] and counts_out [N] are device buffers. */
+int cald_train_rpn_proposals(cald_ctx* ctx, int N, int Hp, int Wp, const int* image_sizes, const float* const* heads,
+                             const int* level_hw, int head_ld, int pre_n, int post_n, float nms_thr, float min_size,
+                             float* proposals_out, int* counts_out);
+/* AnchorGenerator: all anchors of one padded image, order (level, y, x, anchor): anchors_out [sum Hl*Wl*3][4] */
+int cald_train_anchors(cald_ctx* ctx, int Hp, int Wp, const int* level_hw, float* anchors_out);
+/* det_utils.Matcher: matched_out[i] = index of the best ground-truth box (torchvision.ops.box_iou), -1 if its IoU < lo, -2 if
+ * lo <= IoU < hi; allow_low_quality restores every box that is some ground truth's best.  best_iou_out may be null. */
+int cald_train_match(cald_ctx* ctx, int n_boxes, const float* boxes, int n_gt, const float* gt, float hi, float lo,
+                     int allow_low_quality, int* matched_out, float* best_iou_out);
+/* det_utils.BoxCoder.encode_single */
+int cald_train_box_encode(cald_ctx* ctx, int n, const float* reference, const float* proposals, float wx, float wy, float ww,
+                          float wh, float* out);
+/* MultiScaleRoIAlign(7, sampling_ratio 2) over four dense levels feats[l] = [N][Hl][Wl][C]; rois [R][5] = (image, x1, y1, x2,
+ * y2); out [R][49][C].  _bwd scatters gout into gfeats[l] (+=, float atomics). */
+int cald_train_roi_align(cald_ctx* ctx, const float* const* feats, const int* level_hw, int C, int R, const float* rois, float* out);
+int cald_train_roi_align_bwd(cald_ctx* ctx, float* const* gfeats, const int* level_hw, int C, int R, const float* rois,
+                             const float* gout);
+/* F.cross_entropy over R rows of stride ld (mean); grad_out (same layout, may be null) = gscale * d loss / d logits */
+int cald_train_softmax_ce(cald_ctx* ctx, int R, int C, int ld, const float* logits, const int64_t* labels, float gscale,
+                          float* loss_out, float* grad_out);
+/* det_utils.smooth_l1_loss(size_average=False) / denom over n 4-vectors starting at float offsets idx[i] of pred; grad (zeroed by
+ * the caller, same offsets) may be null */
+int cald_train_smooth_l1(cald_ctx* ctx, int n, const float* pred, const int64_t* idx, const float* target, float beta, float denom,
+                         float gscale, float* loss_out, float* grad);
+/* F.binary_cross_entropy_with_logits over n logits at float offsets idx[i] (mean) */
+int cald_train_bce_logits(cald_ctx* ctx, int n, const float* logits, const int64_t* idx, const float* labels, float gscale,
+                          float* loss_out, float* grad);
+/* GeneralizedRCNNTransform of a training batch: images[i] = device uint8 [H_i][W_i][3]; hw = host {H_i, W_i, Hr_i, Wr_i} per image
+ * (source and resized sizes); remainders[i] (or null) = device float [3][H_i][W_i] added to image / 255.  out [N][Hp][Wp][4]:
+ * normalized, bilinearly resized, zero-padded; channel 3 is zero. */
+int cald_train_preprocess(cald_ctx* ctx, int N, const uint8_t* const* images, const float* const* remainders, const int* hw,
+                          int Hp, int Wp, float* out);
+/* max_pool2d(3, 2, 1) and max_pool2d(1, 2, 0) on [N][H][W][C] */
+int cald_train_maxpool(cald_ctx* ctx, int N, int H, int W, int C, const float* in, float* out);
+int cald_train_subsample2(cald_ctx* ctx, int N, int H, int W, int C, const float* in, float* out);
 /* torch.optim.SGD step over a flat buffer: d = grad + wd * p; buf = first_step ? d : momentum * buf + d; p -= lr * buf */
 int cald_train_sgd(cald_ctx* ctx, long long n, float* param, const float* grad, float* momentum_buf, float lr, float momentum,
                    float weight_decay, int first_step);

@@ -164,3 +164,213 @@ def test_sgd_step_equals_torch_optim(T):
         ref.grad = gr.clone(); opt.step()
         ops.sgd_(p, gr.cuda(), buf, 0.0025, 0.9, 1e-4, step == 0)
     np.testing.assert_allclose(p.cpu().numpy(), ref.detach().numpy(), rtol=0, atol=5e-7)     # one float32 ulp: torch folds -lr * buf into an fma
+
+
+def test_training_proposals_equal_the_inference_oracle(T, oracle):
+    """RegionProposalNetwork.filter_proposals at TRAINING sizes (2 000 per level before NMS, 2 000 after): the HIP kernels at
+    the larger capacity == the C oracle's rpn_proposals on the same head tensors, bit for bit (index work)."""
+    torch, ops = T
+    g = torch.Generator().manual_seed(11)
+    N, Hp, Wp = 2, 256, 320
+    level_hw = [(64, 80), (32, 40), (16, 20), (8, 10), (4, 5)]
+    heads = []
+    for h, w in level_hw:
+        t = torch.zeros(N, h, w, 16)
+        t[..., :3] = torch.randn(N, h, w, 3, generator=g) * 2
+        t[..., 3:15] = torch.randn(N, h, w, 12, generator=g) * 0.3
+        heads.append(t)
+    sizes = [(250, 300), (256, 317)]
+    props, counts = ops.rpn_proposals([h.cuda() for h in heads], Hp, Wp, sizes, 2000, 2000, 0.7, 1e-3)
+    base = np.concatenate([oracle.base_anchors([32.0 * 2 ** l], [0.5, 1.0, 2.0]) for l in range(5)])
+    for i in range(N):
+        want, _ = oracle.rpn_proposals([h[i].numpy() for h in heads], base, Hp, Wp, sizes[i][0], sizes[i][1], 3, 2000, 2000, 0.7, 1e-3)
+        n = int(counts[i])
+        assert n == want.shape[0] and n > 1000
+        np.testing.assert_array_equal(props[i, :n].cpu().numpy(), want)
+
+
+def test_anchors_matcher_and_box_coder(T, oracle):
+    torch, ops = T
+    from oracle import torch_train as tt
+    g = torch.Generator().manual_seed(2)
+    level_hw = [(48, 64), (24, 32), (12, 16), (6, 8), (3, 4)]
+    anchors = ops.anchors(192, 256, level_hw, torch.device("cuda"))
+    want = []
+    for l, (h, w) in enumerate(level_hw):
+        base = torch.from_numpy(oracle.base_anchors([32.0 * 2 ** l], [0.5, 1.0, 2.0])).reshape(-1, 4)
+        ys, xs = torch.meshgrid(torch.arange(h) * (192 // h), torch.arange(w) * (256 // w), indexing="ij")
+        want.append((torch.stack([xs, ys, xs, ys], dim=-1).reshape(-1, 1, 4).float() + base[None]).reshape(-1, 4))
+    want = torch.cat(want)
+    assert torch.equal(anchors.cpu(), want)
+    xy = torch.rand(7, 2, generator=g) * torch.tensor([200.0, 140.0]); wh = torch.rand(7, 2, generator=g) * 90 + 8
+    gt = torch.cat([xy, xy + wh], dim=1)
+    for hi, lo, low in ((0.7, 0.3, True), (0.5, 0.5, False)):
+        got = ops.match(anchors, gt.cuda(), hi, lo, low).cpu().long()
+        assert torch.equal(got, tt.matcher(tt.box_iou(gt, want), hi, lo, low))
+    pos = torch.nonzero(got >= 0).squeeze(1)
+    assert len(pos) > 3
+    enc = ops.box_encode(gt[got[pos]].cuda().contiguous(), anchors[pos.cuda()].contiguous(), (10.0, 10.0, 5.0, 5.0))
+    _close(enc, tt.encode(gt[got[pos]].double(), want[pos].double(), (10.0, 10.0, 5.0, 5.0)), 1e-6, "BoxCoder.encode")
+
+
+def test_roi_align_forward_backward_vs_autograd(T, oracle):
+    torch, ops = T
+    from oracle import torch_train as tt
+    g = torch.Generator().manual_seed(4)
+    N, Cc = 2, 16
+    dims = [(40, 56), (20, 28), (10, 14), (5, 7)]
+    feats = [torch.randn(N, Cc, h, w, generator=g) for h, w in dims]
+    boxes = []
+    for s in (12, 30, 70, 150, 400, 700):             # square roots of the areas that land on every pyramid level
+        for _ in range(3):
+            x, y = float(torch.rand(1, generator=g)) * 120 - 10, float(torch.rand(1, generator=g)) * 90 - 10
+            boxes.append([x, y, x + s * 1.3, y + s / 1.3])
+    boxes = torch.tensor(boxes); img = torch.arange(len(boxes)) % N
+    fd = [f.double().requires_grad_() for f in feats]
+    want = tt.roi_align(fd, img, boxes)                # [R, C, 7, 7]
+    gy = torch.randn(want.shape, generator=g)
+    want.backward(gy.double())
+    fc = [f.permute(0, 2, 3, 1).contiguous().cuda() for f in feats]
+    rois = torch.cat([img[:, None].float(), boxes], dim=1).cuda().contiguous()
+    got = ops.roi_align(fc, rois)                      # [R, 49, C]
+    _close(got.view(-1, 7, 7, Cc).permute(0, 3, 1, 2), want, 1e-5, "RoIAlign forward")
+    gf = [torch.zeros_like(f) for f in fc]
+    ops.roi_align_bwd_(gf, rois, gy.permute(0, 2, 3, 1).reshape(-1, 49, Cc).contiguous().cuda())
+    for l in range(4):
+        _close(gf[l].permute(0, 3, 1, 2), fd[l].grad, 1e-5, "RoIAlign backward level %d" % l)
+
+
+def test_losses_value_and_gradient(T, oracle):
+    torch, ops = T
+    import torch.nn.functional as F
+    from oracle import torch_train as tt
+    g = torch.Generator().manual_seed(6)
+    R, Cc, ld = 300, 21, 108
+    z = torch.zeros(R, ld); z[:, :105] = torch.randn(R, 105, generator=g) * 2
+    lab = torch.randint(0, Cc, (R,), generator=g)
+    zd = z.double().requires_grad_()
+    ce = F.cross_entropy(zd[:, :Cc], lab)
+    pos = torch.nonzero(lab > 0).squeeze(1); tgt = torch.randn(len(pos), 4, generator=g)
+    sl = tt.smooth_l1_sum(zd[:, Cc:105].reshape(R, -1, 4)[pos, lab[pos]], tgt.double(), 1.0 / 9) / R
+    (0.7 * ce + 1.3 * sl).backward()
+    zc = z.cuda(); grad = torch.zeros_like(zc)
+    l1 = ops.softmax_ce(zc, lab.cuda(), Cc, grad=grad, gscale=0.7)
+    idx = (pos * ld + Cc + 4 * lab[pos]).cuda()
+    l2 = ops.smooth_l1(zc, idx, tgt.cuda(), 1.0 / 9, R, grad=grad, gscale=1.3)
+    _close(l1, ce.reshape(1), 1e-6, "cross entropy"); _close(l2, sl.reshape(1), 1e-6, "smooth L1")
+    _close(grad, zd.grad, 1e-5, "d(0.7 ce + 1.3 smooth_l1)/d logits")
+    x = torch.randn(5000, generator=g) * 3; sel = torch.randperm(5000, generator=g)[:256]; y = (torch.rand(256, generator=g) < 0.5).float()
+    xd = x.double().requires_grad_()
+    bce = F.binary_cross_entropy_with_logits(xd[sel], y.double()); bce.backward()
+    gx = torch.zeros(5000, device="cuda")
+    l3 = ops.bce_logits(x.cuda(), sel.cuda(), y.cuda(), grad=gx)
+    _close(l3, bce.reshape(1), 1e-6, "BCE with logits"); _close(gx, xd.grad, 1e-5, "BCE gradient")
+
+
+def _train_case(torch, n_images=2, seed=0):
+    from cald_amd import synth
+    sd = synth.pseudo_trained_frcnn(21, 50, seed=3)
+    imgs = synth.make_pool(n_images, "voc", seed, scale=0.4)                     # ~150 x 200 uint8 HWC
+    images = [torch.from_numpy(im).permute(2, 0, 1).float().div(255) for im in imgs]
+    rs = np.random.RandomState(seed + 1)
+    targets = []
+    for im in imgs:
+        H, W = im.shape[:2]
+        k = 2 + rs.randint(0, 3)
+        x0 = rs.rand(k) * W * 0.6; y0 = rs.rand(k) * H * 0.6
+        bw = W * (0.15 + 0.3 * rs.rand(k)); bh = H * (0.15 + 0.3 * rs.rand(k))
+        boxes = np.stack([x0, y0, np.minimum(x0 + bw, W - 1), np.minimum(y0 + bh, H - 1)], axis=1).astype(np.float32)
+        targets.append({"boxes": torch.from_numpy(boxes), "labels": torch.from_numpy(rs.randint(1, 21, k).astype(np.int64))})
+    return sd, images, targets
+
+
+def test_training_step_losses_and_gradients_vs_autograd(T, oracle):
+    """One whole training step (forward in train mode, the four losses, the gradient of their sum wrt EVERY trainable tensor:
+    layers 2-4, FPN, RPN head, box head, predictor; 64 sampled RoIs per image to keep the CPU checker quick) against torch-CPU autograd in float64 on the same images, targets,
+    proposals, sampler permutations and ReLU decisions.  Losses to 1e-4 relative; each gradient tensor to 1e-4 of its largest
+    magnitude (float32 forward + backward vs float64)."""
+    torch, ops = T
+    from cald_amd import train
+    from oracle import torch_train as tt
+    sd, images, targets = _train_case(torch)
+    net = train.FasterRCNNTrainer(sd, 21, min_size=160, max_size=256, box_batch=64, generator=torch.Generator().manual_seed(7))
+    losses = net.forward(images, targets)
+    props = [p.cpu() for p in net.last["proposals"]]
+    assert all(p.shape[0] > 100 for p in props)
+    grads = {k: v.clone() for k, v in net.backward().items()}
+    ref = tt.TorchTrainFRCNN(sd, 21, min_size=160, max_size=256)
+    ref.masks = net.relu_decisions()           # both sides take the same branch at every differentiated ReLU (see TorchTrainFRCNN.relu)
+    want, rec = ref.losses(images, targets, props, torch.Generator().manual_seed(7), cfg=dict(box_batch=64))
+    assert torch.equal(rec["roi_labels"], net.last["roi_labels"]), "same sampled RoIs"
+    for k in want:
+        got = float(losses[k]); w = float(want[k].detach())
+        assert abs(got - w) <= 1e-4 * max(1.0, abs(w)), (k, got, w)
+    sum(want.values()).backward()
+    tr = ref.trainable()
+    assert sorted(tr) == sorted(grads), "same set of trainable tensors as resnet_fpn_backbone(trainable_layers=3)"
+    worst = ("", 0.0)
+    for k, g in grads.items():
+        w = tr[k].grad
+        assert w is not None, k
+        scale = float(w.abs().max())
+        assert scale > 0, k
+        err = float((g.double().cpu() - w).abs().max()) / scale
+        if err > worst[1]:
+            worst = (k, err)
+    assert worst[1] <= 1e-4, "largest gradient error %.3g at %s" % (worst[1], worst[0])
+
+
+def test_drop_in_training_loop_updates_like_torch_sgd(T, oracle):
+    """The reference's loop body verbatim (cald_train.py:54-71): loss_dict = model(images, targets); losses = sum(...);
+    optimizer.zero_grad(); losses.backward(); optimizer.step(); lr_scheduler.step() -- with the HIP model, the HIP SGD and
+    torch's own LambdaLR warmup.  After two iterations the parameters equal float64 autograd + torch.optim.SGD to 1e-5 of each
+    tensor's largest magnitude."""
+    torch, ops = T
+    from cald_amd import train
+    from oracle import torch_train as tt
+    sd, images, targets = _train_case(torch, seed=5)
+    net = train.FasterRCNNTrainer(sd, 21, min_size=160, max_size=256, box_batch=64, generator=torch.Generator().manual_seed(1))
+    model = train.TrainableFasterRCNN(net)
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = train.SGD(params, lr=0.002, momentum=0.9, weight_decay=1e-4, net=net)
+    warm = lambda x: 1.0 if x >= 3 else 0.001 * (1 - x / 3.0) + x / 3.0        # utils.warmup_lr_scheduler
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, warm)
+    ref = tt.TorchTrainFRCNN(sd, 21, min_size=160, max_size=256)
+    rparams = ref.trainable()
+    ropt = torch.optim.SGD(list(rparams.values()), lr=0.002, momentum=0.9, weight_decay=1e-4)
+    rsched = torch.optim.lr_scheduler.LambdaLR(ropt, warm)
+    rgen = torch.Generator().manual_seed(1)
+    seen = []
+    for it in range(2):
+        loss_dict = model(images, targets)
+        losses = sum(loss for loss in loss_dict.values())
+        seen.append(float(losses.detach()))
+        opt.zero_grad(); losses.backward(); opt.step(); sched.step()
+        ref.masks = net.relu_decisions()
+        want, _ = ref.losses(images, targets, [p.cpu() for p in net.last["proposals"]], rgen, cfg=dict(box_batch=64))
+        rl = sum(want.values())
+        assert abs(float(rl) - seen[-1]) <= 2e-4 * max(1.0, abs(float(rl))), (it, float(rl), seen[-1])
+        ropt.zero_grad(); rl.backward(); ropt.step(); rsched.step()
+    for k, p in net.named_parameters():
+        w = rparams[k].detach()
+        err = float((p.detach().double().cpu() - w).abs().max()) / float(w.abs().max())
+        assert err <= 1e-5, (k, err)
+
+
+def test_fitting_one_batch_lowers_the_loss(T):
+    """Ten plain SGD steps on one batch (same sampler permutations every step): the summed loss falls."""
+    torch, ops = T
+    from cald_amd import train
+    sd, images, targets = _train_case(torch, seed=9)
+    net = train.FasterRCNNTrainer(sd, 21, min_size=160, max_size=256, generator=torch.Generator())
+    model = train.TrainableFasterRCNN(net)
+    opt = train.SGD([p for p in model.parameters() if p.requires_grad], lr=5e-5, momentum=0.0, weight_decay=0.0, net=net)
+    seen = []
+    for it in range(10):
+        net.generator.manual_seed(3)
+        loss_dict = model(images, targets)
+        losses = sum(loss for loss in loss_dict.values())
+        assert bool(torch.isfinite(losses))
+        seen.append(float(losses.detach()))
+        opt.zero_grad(); losses.backward(); opt.step()
+    assert np.mean(seen[-3:]) < seen[0] - 0.05 and max(seen) <= seen[0] + 0.05, seen
