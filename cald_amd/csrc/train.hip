@@ -99,9 +99,44 @@ __global__ void pack_weight_kernel(PackArgs a) {
     const int kt = k >> 4, kk = k & 15, kq = kk >> 3, j = (kk & 7) >> 1, h = kk & 1;
     a.w4[(((long long)(kt * 2 + kq) * a.NPad + n) * 2 + h) * 4 + j] = v;
 }
-__global__ void pack_vec_kernel(const float* src, int n, float* dst, int npad) {
+// Forward packs (modes 0, 2) in two coalesced passes: (1) every torch row n (Cin * taps contiguous floats) is read in order and
+// written to T[n][k] (k = position in the chain order: neighbours stay inside one 16-channel chunk); (2) a tiled LDS transpose
+// T[n][k] -> wk[k][n] + the conv_p4 layout.  (pack_weight_kernel reads with a stride of one whole row between lanes.)
+__global__ void pack_rows_kernel(PackArgs a, float* T) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long row = (long long)a.Cin * a.taps;
+    if (i >= (long long)a.Cout * row) return;
+    const int n = (int)(i / row); const int r = (int)(i - (long long)n * row);
+    const int ci = r / a.taps, tap = r - ci * a.taps;
+    int k;
+    if (a.mode == 2) k = tap * a.Cin + ci;
+    else k = (a.CinK % 16 == 0 && a.taps <= 32) ? ((ci >> 4) * a.taps + tap) * 16 + (ci & 15) : tap * a.CinK + ci;
+    T[(long long)n * a.Kpad + k] = a.w[i];
+}
+__global__ __launch_bounds__(256) void pack_transpose_kernel(PackArgs a, const float* T) {
+    __shared__ float tile[32][33];
+    const int k0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int n = n0 + r, k = k0 + tx;
+        tile[r][tx] = (n < a.Cout && k < a.Kpad) ? T[(long long)n * a.Kpad + k] : 0.0f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int k = k0 + r, n = n0 + tx;
+        if (k >= a.Kpad || n >= a.NPad) continue;
+        const float v = tile[tx][r];
+        a.wk[(long long)k * a.NPad + n] = v;
+        const int kt = k >> 4, kk = k & 15, kq = kk >> 3, j = (kk & 7) >> 1, h = kk & 1;
+        a.w4[(((long long)(kt * 2 + kq) * a.NPad + n) * 2 + h) * 4 + j] = v;
+    }
+}
+__global__ void pack_vec_kernel(const float* bias, const float* scale, const float* shift, int n, float* dst, int npad) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < npad) dst[i] = (src && i < n) ? src[i] : 0.0f;
+    if (i >= npad) return;
+    dst[i] = (bias && i < n) ? bias[i] : 0.0f;
+    dst[npad + i] = (scale && i < n) ? scale[i] : 0.0f;
+    dst[2 * npad + i] = (shift && i < n) ? shift[i] : 0.0f;
 }
 
 struct PackGeom { int K, Kpad, NPad, n_true, cin_conv; long long floats; };
@@ -131,13 +166,23 @@ extern "C" int cald_train_pack_conv(cald_ctx* c, const float* w, const float* bi
     PackArgs a{w, packed, packed + (long long)g.Kpad * g.NPad, Cout, Cin, KH * KW, CinK, g.Kpad, g.NPad, mode};
     hipStream_t st = cald_internal_stream(c);
     const long long n = (long long)g.Kpad * g.NPad;
-    hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+    if (mode == 0 || mode == 2) {
+        void* scratch = nullptr;
+        const long long tn = (long long)Cout * g.Kpad;
+        if (int rc = cald_internal_scratch(c, (size_t)tn * 4, &scratch)) return rc;
+        float* T = (float*)scratch;
+        if (g.Kpad != Cin * KH * KW)     // k positions no source element maps to (channel / K padding)
+            THIP(hipMemsetAsync(T, 0, (size_t)tn * 4, st));
+        const long long src = (long long)Cout * Cin * KH * KW;
+        hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)((src + 255) / 256)), dim3(256), 0, st, a, T);
+        hipLaunchKernelGGL(pack_transpose_kernel, dim3((g.Kpad + 31) / 32, (g.NPad + 31) / 32), dim3(256), 0, st, a, (const float*)T);
+    } else {
+        hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+    }
     float* vec = packed + 2 * n;
     const int nt = g.n_true, blocks = (g.NPad + 255) / 256;
-    const bool grad_mode = mode == 1 || mode == 3;
-    hipLaunchKernelGGL(pack_vec_kernel, dim3(blocks), dim3(256), 0, st, grad_mode ? nullptr : bias, nt, vec, g.NPad);
-    hipLaunchKernelGGL(pack_vec_kernel, dim3(blocks), dim3(256), 0, st, grad_mode ? nullptr : scale, nt, vec + g.NPad, g.NPad);
-    hipLaunchKernelGGL(pack_vec_kernel, dim3(blocks), dim3(256), 0, st, grad_mode ? nullptr : shift, nt, vec + 2 * g.NPad, g.NPad);
+    if (mode == 0 || mode == 2)     // the data-gradient packs carry no epilogue vectors (cald_train_conv never reads them: flags 0)
+        hipLaunchKernelGGL(pack_vec_kernel, dim3(blocks), dim3(256), 0, st, bias, scale, shift, nt, vec, g.NPad);
     THIP(hipGetLastError());
     return 0;
 }
@@ -291,15 +336,30 @@ __global__ void wgrad_reduce_kernel(const float* partial, int S, long long split
     float* dst = grad + ((long long)co * Cin + ci) * taps + tap;
     *dst = accumulate ? *dst + s : s;
 }
-// db[c] = sum over rows of g[q][c]: stage 1 partial sums over row blocks, stage 2 fixed-order sum
-__global__ void colsum_partial_kernel(const float* g, long long Q, int C, int ld, long long rows_per_block, float* partial) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// db[c] = sum over rows of g[q][c]: stage 1 partial sums over row blocks (128 channels x 8 row lanes per workgroup, float4
+// loads), stage 2 fixed-order sum over the row blocks
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* g, long long Q, int C, int ld, long long rows_per_block, float* partial) {
+    __shared__ float4 red[8][32];
+    const int cq = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 128 + cq * 4;
     const long long q0 = (long long)blockIdx.y * rows_per_block;
     long long q1 = q0 + rows_per_block; if (q1 > Q) q1 = Q;
-    float s = 0.0f;
-    for (long long q = q0; q < q1; q++) s += g[q * ld + c];
-    partial[(long long)blockIdx.y * C + c] = s;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < ld)
+        for (long long q = q0 + rl; q < q1; q += 8) {
+            const float4 v = *reinterpret_cast<const float4*>(g + q * ld + c);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    red[rl][cq] = s;
+    __syncthreads();
+    if (rl == 0) {
+        for (int r = 1; r < 8; r++) { const float4 v = red[r][cq]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+        float* o = partial + (long long)blockIdx.y * C;
+        if (c < C) o[c] = s.x;
+        if (c + 1 < C) o[c + 1] = s.y;
+        if (c + 2 < C) o[c + 2] = s.z;
+        if (c + 3 < C) o[c + 3] = s.w;
+    }
 }
 __global__ void colsum_final_kernel(const float* partial, int S, int C, float* out, int accumulate) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -328,7 +388,7 @@ static int wgrad_impl(cald_ctx* c, long long Q, int N, int H, int W, const float
     if (S < 1) S = 1;
     a.chunk = ((Q + S - 1) / S + 15) / 16 * 16;
     S = (Q + a.chunk - 1) / a.chunk;
-    const long long csplit = (Q + 1023) / 1024 > 256 ? 256 : (Q + 1023) / 1024;
+    const long long csplit = (Q + 255) / 256 > 1024 ? 1024 : (Q + 255) / 256;
     void* scratch = nullptr;
     if (int rc = cald_internal_scratch(c, (size_t)(S * tile_floats + csplit * Cout + 64) * 4, &scratch)) return rc;
     a.partial = (float*)scratch;
@@ -339,7 +399,7 @@ static int wgrad_impl(cald_ctx* c, long long Q, int N, int H, int W, const float
     if (db) {
         float* cp = a.partial + S * tile_floats;
         const long long rpb = (Q + csplit - 1) / csplit;
-        hipLaunchKernelGGL(colsum_partial_kernel, dim3((Cout + 63) / 64, (unsigned)csplit), dim3(64), 0, st, g, Q, Cout, ldg, rpb, cp);
+        hipLaunchKernelGGL(colsum_partial_kernel, dim3((Cout + 127) / 128, (unsigned)csplit), dim3(256), 0, st, g, Q, Cout, ldg, rpb, cp);
         hipLaunchKernelGGL(colsum_final_kernel, dim3((Cout + 63) / 64), dim3(64), 0, st, cp, (int)csplit, Cout, db, accumulate);
     }
     THIP(hipGetLastError());

@@ -59,16 +59,50 @@ class HipDetector:
         self._state = None
         self._handle = None
         self._device = None
+        self._depth = depth
+        self._trainer = None          # cald_amd.train.FasterRCNNTrainer while the weights are being trained
+        self._train_fn = None
 
     # ---- nn.Module-like surface used by cald_train.py ----
     def eval(self):
+        if self.training and self._trainer is not None:
+            self._sync_from_trainer()
         self.training = False
         return self
 
     def train(self, mode=True):
-        if mode:
-            raise NotImplementedError("cald_amd detectors are inference-only (training stays with stock PyTorch, SURVEY 8b)")
-        return self.eval()
+        """task_model.train() (cald_train.py:41): the Faster R-CNN training step runs on the HIP operators of cald_amd/train.py
+        (SURVEY 8f rank 4); ``model(images, targets)`` then returns the loss dict.  RetinaNet training is not built."""
+        if not mode:
+            return self.eval()
+        if self.arch != 0:
+            raise NotImplementedError("training is implemented for the Faster R-CNN detector only")
+        self._ensure_trainer()
+        self.training = True
+        return self
+
+    def _ensure_trainer(self):
+        if self._trainer is None:
+            if self._state is None:
+                raise RuntimeError("no weights: call load_state_dict() first (cald_train.py:356)")
+            from . import train as _train
+            dev = "cuda:%d" % (self._device if self._device is not None else torch.cuda.current_device())
+            self._trainer = _train.FasterRCNNTrainer(self._state, self.num_classes, depth=self._depth, min_size=self.cfg.min_size,
+                                                     max_size=self.cfg.max_size, device=dev, rpn_nms_thresh=self.cfg.rpn_nms_thresh)
+            self._train_fn = _train.TrainableFasterRCNN(self._trainer)
+        return self._trainer
+
+    def _sync_from_trainer(self):
+        """The trained parameters become the inference engine's weights (the native model is rebuilt on the next forward)."""
+        self._state = {k: v.detach().cpu().numpy() for k, v in self._trainer.state_dict().items()}
+        self._destroy()
+
+    def parameters(self):
+        """task_model.parameters() (cald_train.py:396): the trainable tensors (``requires_grad`` True), torch Parameters."""
+        return self._ensure_trainer().parameters()
+
+    def named_parameters(self):
+        return self._ensure_trainer().named_parameters()
 
     def to(self, device):
         dev = torch.device(device)
@@ -81,12 +115,15 @@ class HipDetector:
         return self.to("cuda" if device is None else "cuda:%d" % device)
 
     def state_dict(self):
+        if self._trainer is not None and self.training:
+            return {k: v.detach().cpu().numpy() for k, v in self._trainer.state_dict().items()}
         return dict(self._state or {})
 
     def load_state_dict(self, sd, strict=True):
         self._state = {k: (v.detach().cpu().float().numpy() if hasattr(v, "detach") else np.asarray(v, np.float32))
                        for k, v in sd.items() if not k.endswith("num_batches_tracked")}
         self._destroy()
+        self._trainer = self._train_fn = None
         return self
 
     # ---- native handle ----
@@ -163,7 +200,9 @@ class HipDetector:
         the subtraction is exact and fl(g/255 + (x - g/255)) == x), so to_tensor outputs (remainder all zero, no extra
         traffic) and arbitrary floats -- e.g. a caller-made GaussianNoise image -- both reach the kernels bit for bit."""
         if self.training:
-            raise NotImplementedError("inference only")
+            if targets is None:
+                raise ValueError("In training mode, targets should be passed")      # GeneralizedRCNN.forward (frcnn_la.py:247-248)
+            return self._train_fn(images, targets)
         views = []
         for img in images:
             if img.dtype == torch.uint8:

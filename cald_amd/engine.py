@@ -14,6 +14,51 @@ import shutil
 import torch
 
 
+def warmup_lr_scheduler(optimizer, warmup_iters, warmup_factor):
+    """detection/utils.py:239-247."""
+    def f(x):
+        if x >= warmup_iters:
+            return 1
+        alpha = float(x) / warmup_iters
+        return warmup_factor * (1 - alpha) + alpha
+    return torch.optim.lr_scheduler.LambdaLR(optimizer, f)
+
+
+def train_one_epoch(task_model, task_optimizer, data_loader, device, cycle, epoch, print_freq):
+    """cald_train.py:40-74 with the HIP detector in train mode: warmup in epoch 0, per batch ``loss_dict = model(images, targets)``,
+    non-finite loss stops the run (sys.exit(1), :62-65), zero_grad / backward / step / scheduler step.  Returns the list of
+    per-iteration summed losses (the reference returns its MetricLogger).  Single process (no reduce_dict)."""
+    import math
+    import sys
+    task_model.train()
+    sched = None
+    if epoch == 0:
+        warmup_iters = min(1000, len(data_loader) - 1)
+        if warmup_iters > 0:
+            sched = warmup_lr_scheduler(task_optimizer, warmup_iters, 1. / 1000)
+    history = []
+    for i, (images, targets) in enumerate(data_loader):
+        images = list(images)
+        targets = [dict(t) for t in targets]
+        loss_dict = task_model(images, targets)
+        losses = sum(loss for loss in loss_dict.values())
+        value = float(losses.detach())
+        if not math.isfinite(value):
+            print("Loss is {}, stopping training".format(value))
+            print({k: float(v.detach()) for k, v in loss_dict.items()})
+            sys.exit(1)
+        task_optimizer.zero_grad()
+        losses.backward()
+        task_optimizer.step()
+        if sched is not None:
+            sched.step()
+        history.append(value)
+        if print_freq and i % print_freq == 0:
+            print("Cycle:[{}] Epoch: [{}]  [{}/{}]  task_loss: {:.4f}  task_lr: {:.6f}".format(
+                cycle, epoch, i, len(data_loader), value, task_optimizer.param_groups[0]["lr"]))
+    return history
+
+
 def voc_detections(model, data_loader, num_classes=21, batch_views=64):
     model.eval()
     all_boxes = [[] for _ in range(num_classes)]

@@ -213,6 +213,7 @@ class FasterRCNNTrainer(object):
         assert self.pred.Cout == 5 * num_classes, "box predictor does not match num_classes"
         self._anchors = {}
         self.last = None
+        self.timing = None          # set to a list to collect (section, wall-clock) marks of forward(); each mark synchronizes
 
     # ---- parameter plumbing ----
     def _lookup(self, name):
@@ -282,6 +283,11 @@ class FasterRCNNTrainer(object):
     def forward(self, images, targets, proposals_override=None):
         """Training forward.  Returns the four losses as 1-element device tensors (no autograd) and keeps what backward needs."""
         cfg, N, Ccls = self.cfg, len(images), self.C
+        marks = self.timing
+        def mark(name):
+            if marks is not None:
+                torch.cuda.synchronize(self.dev); marks.append((name, __import__("time").time()))
+        mark("start")
         self.version += 1                                  # whoever updated the parameters (any optimizer): repack the trainable layers
         u8, rem = self._prepare_images(images)
         sizes = [ops.transform_size(im.shape[0], im.shape[1], self.min_size, self.max_size) for im in u8]
@@ -294,6 +300,7 @@ class FasterRCNNTrainer(object):
             rw = torch.tensor(s[1], dtype=torch.float32) / torch.tensor(im.shape[1], dtype=torch.float32)
             gts.append(torch.stack([b[:, 0] * rw, b[:, 1] * rh, b[:, 2] * rw, b[:, 3] * rh], dim=1).to(self.dev).contiguous())
             gt_labels.append(t["labels"].detach().long().cpu().reshape(-1))
+        mark("inputs")
         x = ops.preprocess(u8, img_sizes, Hp, Wp, rem)
         x = ops.maxpool(self.stem.fwd(x, relu=True))
         feats = []
@@ -301,6 +308,7 @@ class FasterRCNNTrainer(object):
             for blk in blocks:
                 x = blk.fwd(x)
             feats.append(x)
+        mark("body")
         # FPN (top-down), LastLevelMaxPool
         inner = [None] * 4
         inner[3] = self.lat[3].fwd(feats[3])
@@ -318,6 +326,7 @@ class FasterRCNNTrainer(object):
             tl.append(t)
             heads.append(ops.conv(t, self.rpn_head._packed(), out=head_flat[o:o + head_sizes[i]].view(N, h, w, 16), out_ld=16))
             o += head_sizes[i]
+        mark("fpn+rpn head")
         anchors = self.anchors(Hp, Wp, level_hw)
         A_img = anchors.shape[0]
         if proposals_override is None:
@@ -326,74 +335,95 @@ class FasterRCNNTrainer(object):
             proposals = [props[i, :counts[i]] for i in range(N)]
         else:
             proposals = [p.to(self.dev).float().contiguous() for p in proposals_override]
-        # ---- RPN targets and sampling (anchor order: level, y, x, anchor) ----
+        mark("proposals")
+        # ---- RPN targets and sampling (anchor order: level, y, x, anchor).  One device->host copy of all match results, host-side
+        # sampling (torch CPU generator), one host->device copy of every index the loss kernels need. ----
         lvl_start = np.cumsum([0] + [h * w * 3 for h, w in level_hw])
         head_off = np.cumsum([0] + head_sizes)
+        lvl_pix = np.array([h * w for h, w in level_hw])
         def head_offsets(img, idx):                                  # float offset of anchor idx's objectness logit in head_flat
-            idx = idx.numpy()
             l = np.searchsorted(lvl_start, idx, side="right") - 1
             rel = idx - lvl_start[l]
             pix, a = rel // 3, rel % 3
-            hw = np.array([h * w for h, w in level_hw])[l]
-            return head_off[l] + (img * hw + pix) * 16 + a, a
-        obj_idx, obj_lab, box_idx, box_anchor, box_gt = [], [], [], [], []
+            return head_off[l] + (img * lvl_pix[l] + pix) * 16 + a, a
+        n_gt = [int(g.shape[0]) for g in gts]
+        gt_off = np.cumsum([0] + n_gt)
+        gts_all = torch.cat(gts) if sum(n_gt) else torch.zeros((1, 4), device=self.dev)
+        matched_dev = torch.full((N, A_img), -1, dtype=torch.int32, device=self.dev)
         for i in range(N):
-            if gts[i].shape[0] == 0:
-                matched = torch.full((A_img,), -1, dtype=torch.int32)
-            else:
-                matched = ops.match(anchors, gts[i], cfg["rpn_fg"], cfg["rpn_bg"], True).cpu()
-            pos, neg = torch.nonzero(matched >= 0).squeeze(1), torch.nonzero(matched == -1).squeeze(1)
+            if n_gt[i]:
+                ops.match(anchors, gts[i], cfg["rpn_fg"], cfg["rpn_bg"], True, out=matched_dev[i])
+        matched_all = matched_dev.cpu().numpy()
+        obj_idx, obj_lab, box_idx, anc_idx, gt_idx = [], [], [], [], []
+        for i in range(N):
+            m = matched_all[i]
+            pos, neg = torch.from_numpy(np.flatnonzero(m >= 0)), torch.from_numpy(np.flatnonzero(m == -1))
             sp, sn = self._sample(pos, neg, cfg["rpn_batch"], cfg["rpn_pos"])
-            sp, sn = sp.sort().values, sn.sort().values
+            sp, sn = np.sort(sp.numpy()), np.sort(sn.numpy())
             op_, ap_ = head_offsets(i, sp); on_, _ = head_offsets(i, sn)
             obj_idx += [op_, on_]; obj_lab += [np.ones(len(op_), np.float32), np.zeros(len(on_), np.float32)]
             box_idx.append(op_ - ap_ + 3 + 4 * ap_)                  # channel 3 + 4a of the same pixel
-            box_anchor.append(anchors[sp.to(self.dev)]); box_gt.append(gts[i][matched[sp].long().to(self.dev)] if len(sp) else gts[i][:0])
-        obj_idx = torch.from_numpy(np.concatenate(obj_idx).astype(np.int64)).to(self.dev)
+            anc_idx.append(sp); gt_idx.append(gt_off[i] + m[sp])
+        obj_idx, box_idx, anc_idx, gt_idx = [np.concatenate(v).astype(np.int64) for v in (obj_idx, box_idx, anc_idx, gt_idx)]
+        packed = torch.from_numpy(np.concatenate([obj_idx, box_idx, anc_idx, gt_idx])).to(self.dev)
+        n_obj, n_pos = len(obj_idx), len(box_idx)
+        obj_idx, box_idx = packed[:n_obj], packed[n_obj:n_obj + n_pos]
+        anc_sel, gt_sel = packed[n_obj + n_pos:n_obj + 2 * n_pos], packed[n_obj + 2 * n_pos:]
         obj_lab = torch.from_numpy(np.concatenate(obj_lab)).to(self.dev)
-        box_idx = torch.from_numpy(np.concatenate(box_idx).astype(np.int64)).to(self.dev)
-        rpn_tgt = ops.box_encode(torch.cat(box_gt), torch.cat(box_anchor), (1.0, 1.0, 1.0, 1.0))
+        rpn_tgt = ops.box_encode(gts_all[gt_sel], anchors[anc_sel], (1.0, 1.0, 1.0, 1.0))
+        mark("rpn targets")
         # ---- RoI sampling ----
-        rois, roi_labels, roi_gt = [], [], []
+        n_pr = [int(proposals[i].shape[0]) + n_gt[i] for i in range(N)]
+        pr_off = np.cumsum([0] + n_pr)
+        pr_all = torch.cat([t for i in range(N) for t in ((proposals[i], gts[i]) if n_gt[i] else (proposals[i],))]).contiguous()
+        matched_dev = torch.full((int(pr_off[-1]),), -1, dtype=torch.int32, device=self.dev)
         for i in range(N):
-            pr = torch.cat([proposals[i], gts[i]]) if gts[i].shape[0] else proposals[i]
-            if gts[i].shape[0] == 0:
-                matched = torch.full((pr.shape[0],), -1, dtype=torch.int32); labels = torch.zeros(pr.shape[0], dtype=torch.int64)
+            if n_gt[i]:
+                ops.match(pr_all[pr_off[i]:pr_off[i + 1]], gts[i], cfg["box_fg"], cfg["box_bg"], False, out=matched_dev[pr_off[i]:pr_off[i + 1]])
+        matched_all = matched_dev.cpu().numpy()
+        keep_all, lab_all, gtsel_all, img_col = [], [], [], []
+        for i in range(N):
+            m = matched_all[pr_off[i]:pr_off[i + 1]]
+            if n_gt[i]:
+                labels = gt_labels[i].numpy()[np.maximum(m, 0)].copy()
+                labels[m == -1] = 0
+                labels[m == -2] = -1
             else:
-                matched = ops.match(pr.contiguous(), gts[i], cfg["box_fg"], cfg["box_bg"], False).cpu()
-                labels = gt_labels[i][matched.clamp(min=0).long()]
-                labels[matched == -1] = 0
-                labels[matched == -2] = -1
-            pos, neg = torch.nonzero(labels >= 1).squeeze(1), torch.nonzero(labels == 0).squeeze(1)
+                labels = np.zeros(len(m), np.int64)
+            pos, neg = torch.from_numpy(np.flatnonzero(labels >= 1)), torch.from_numpy(np.flatnonzero(labels == 0))
             sp, sn = self._sample(pos, neg, cfg["box_batch"], cfg["box_pos"])
-            keep = torch.cat([sp, sn]).sort().values
-            kd = keep.to(self.dev)
-            boxes = pr[kd]
-            rois.append(torch.cat([torch.full((len(keep), 1), float(i), device=self.dev), boxes], dim=1))
-            roi_labels.append(labels[keep])
-            roi_gt.append(gts[i][matched[keep].clamp(min=0).long().to(self.dev)] if gts[i].shape[0] else torch.zeros_like(boxes))
-        rois = torch.cat(rois).contiguous(); roi_labels = torch.cat(roi_labels)
-        R = rois.shape[0]
-        box_tgt_all = ops.box_encode(torch.cat(roi_gt).contiguous(), rois[:, 1:].contiguous(), cfg["w"])
-        pos_rows = torch.nonzero(roi_labels > 0).squeeze(1)
-        pred_idx = (pos_rows * self.pred_ld + Ccls + 4 * roi_labels[pos_rows]).to(self.dev)
-        box_tgt = box_tgt_all[pos_rows.to(self.dev)].contiguous()
+            keep = np.sort(np.concatenate([sp.numpy(), sn.numpy()]))
+            keep_all.append(pr_off[i] + keep); lab_all.append(labels[keep]); gtsel_all.append(gt_off[i] + np.maximum(m[keep], 0))
+            img_col.append(np.full(len(keep), float(i), np.float32))
+        roi_labels_np = np.concatenate(lab_all).astype(np.int64)
+        R = len(roi_labels_np)
+        pos_rows = np.flatnonzero(roi_labels_np > 0)
+        pred_idx_np = pos_rows * self.pred_ld + Ccls + 4 * roi_labels_np[pos_rows]
+        packed = torch.from_numpy(np.concatenate([np.concatenate(keep_all), np.concatenate(gtsel_all), roi_labels_np, pred_idx_np, pos_rows]).astype(np.int64)).to(self.dev)
+        keep_sel, gt_sel2, labels_dev = packed[:R], packed[R:2 * R], packed[2 * R:3 * R]
+        pred_idx, pos_sel = packed[3 * R:3 * R + len(pos_rows)], packed[3 * R + len(pos_rows):]
+        boxes = pr_all[keep_sel]
+        rois = torch.cat([torch.from_numpy(np.concatenate(img_col)).to(self.dev)[:, None], boxes], dim=1).contiguous()
+        roi_gt = gts_all[gt_sel2] if sum(n_gt) else torch.zeros_like(boxes)
+        box_tgt = ops.box_encode(roi_gt.contiguous(), boxes.contiguous(), cfg["w"])[pos_sel].contiguous()
+        roi_labels = torch.from_numpy(roi_labels_np)
+        mark("roi sampling")
         # ---- box head ----
         roi_rows = ops.roi_align(P[:4], rois)
         f6 = self.fc6.fwd(roi_rows.view(1, 1, R, -1), relu=True)
         f7 = self.fc7.fwd(f6, relu=True)
         pred = self.pred.fwd(f7)
-        labels_dev = roi_labels.to(self.dev)
         self.last = dict(N=N, R=R, feats=feats, inner=inner, P=P, tl=tl, heads=heads, head_flat=head_flat, head_sizes=head_sizes, level_hw=level_hw,
                          obj_idx=obj_idx, obj_lab=obj_lab, box_idx=box_idx, rpn_tgt=rpn_tgt, rois=rois, roi_rows=roi_rows, f6=f6, f7=f7, pred=pred,
                          labels=labels_dev, pred_idx=pred_idx, box_tgt=box_tgt, proposals=proposals, roi_labels=roi_labels)
-        n_obj = obj_idx.numel()
+        mark("box head")
         losses = {
             "loss_classifier": ops.softmax_ce(pred.view(R, -1), labels_dev, Ccls),
             "loss_box_reg": ops.smooth_l1(pred, pred_idx, box_tgt, 1.0 / 9, R),
             "loss_objectness": ops.bce_logits(head_flat, obj_idx, obj_lab),
             "loss_rpn_box_reg": ops.smooth_l1(head_flat, box_idx, rpn_tgt, 1.0 / 9, n_obj),
         }
+        mark("losses")
         return losses
 
     def relu_decisions(self):

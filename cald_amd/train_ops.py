@@ -161,8 +161,10 @@ def anchors(Hp, Wp, level_hw, device):
     return out
 
 
-def match(boxes, gt, hi, lo, allow_low_quality):
-    out = torch.empty(boxes.shape[0], dtype=torch.int32, device=boxes.device)
+def match(boxes, gt, hi, lo, allow_low_quality, out=None):
+    if out is None:
+        out = torch.empty(boxes.shape[0], dtype=torch.int32, device=boxes.device)
+    assert boxes.is_contiguous() and out.is_contiguous()
     _ffi.check(_ffi.lib().cald_train_match(get_ctx(boxes.device.index), boxes.shape[0], _p(boxes), gt.shape[0], _p(gt), hi, lo, int(allow_low_quality),
                                            _p(out), None))
     return out

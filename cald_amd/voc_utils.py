@@ -75,6 +75,32 @@ class ToTensor(object):
         return torch.from_numpy(np.array(image)).permute(2, 0, 1).float().div(255), target
 
 
+class RandomHorizontalFlip(object):
+    """detection/transforms.py RandomHorizontalFlip (detection/transforms.py:27-37; the training transform of get_transform): with probability
+    ``prob`` (Python ``random``) the CHW tensor is mirrored and the boxes become (width - xmax, ymin, width - xmin, ymax)."""
+
+    def __init__(self, prob):
+        self.prob = prob
+
+    def __call__(self, image, target):
+        import random
+        if random.random() < self.prob:
+            width = image.shape[-1]
+            image = image.flip(-1)
+            bbox = target["boxes"]
+            bbox[:, [0, 2]] = width - bbox[:, [2, 0]]
+            target["boxes"] = bbox
+        return image, target
+
+
+def get_transform(train):
+    """detection/train.py:54-59 (used at cald_train.py:288-294): ToTensor (+ RandomHorizontalFlip(0.5) for training)."""
+    t = [ToTensor()]
+    if train:
+        t.append(RandomHorizontalFlip(0.5))
+    return Compose(t)
+
+
 class VOCDetection(object):
     """detection/voc_utils.py:47-58 over a VOCdevkit tree: ``root/VOCdevkit/VOC<year>/{ImageSets/Main,Annotations,JPEGImages}``."""
 

@@ -374,3 +374,36 @@ def test_fitting_one_batch_lowers_the_loss(T):
         seen.append(float(losses.detach()))
         opt.zero_grad(); losses.backward(); opt.step()
     assert np.mean(seen[-3:]) < seen[0] - 0.05 and max(seen) <= seen[0] + 0.05, seen
+
+
+def test_active_learning_cycle_train_then_sweep_with_the_same_model_object(T, oracle):
+    """cald_train.py's cycle on ONE model object: task_model.train() -> train_one_epoch (engine mirror, HIP SGD, warmup) ->
+    task_model.eval() -> get_uncertainty.  After training, the inference engine must run on the UPDATED weights: its sweep
+    equals the C oracle prepared from model.state_dict(), bit for bit, and differs from the sweep before training."""
+    torch, ops = T
+    from cald_amd import detector, engine, synth, sweep, train
+    sd, images, targets = _train_case(torch, n_images=4, seed=2)
+    model = detector.fasterrcnn_resnet50_fpn_feature(num_classes=21, min_size=160, max_size=256).to("cuda")
+    model.load_state_dict(sd)
+    pool = synth.make_pool(3, "voc", 7, scale=0.4)
+    loader = [((torch.from_numpy(im),), (None,)) for im in pool]
+    augs = ["flip", "smaller_resize"]
+    before, _ = sweep.get_uncertainty(model, loader, augs, 21)
+    model.train()
+    params = [p for p in model.parameters() if p.requires_grad]
+    assert len(params) == 72
+    opt = train.SGD(params, lr=2e-4, momentum=0.9, weight_decay=1e-4)
+    batches = [(tuple(images[:2]), tuple(targets[:2])), (tuple(images[2:]), tuple(targets[2:]))]
+    history = engine.train_one_epoch(model, opt, batches, "cuda", cycle=0, epoch=0, print_freq=0)
+    assert len(history) == 2 and all(np.isfinite(history))
+    with pytest.raises(ValueError):
+        model(list(images[:1]))                       # training mode needs targets (frcnn_la.py:247-248)
+    model.eval()
+    after, _ = sweep.get_uncertainty(model, loader, augs, 21)
+    new_sd = model.state_dict()
+    assert not np.array_equal(new_sd["roi_heads.box_head.fc7.weight"], np.asarray(sd["roi_heads.box_head.fc7.weight"]))
+    np.testing.assert_array_equal(new_sd["backbone.body.layer1.0.conv1.weight"], np.asarray(sd["backbone.body.layer1.0.conv1.weight"]))
+    P = oracle.prepare_frcnn(new_sd, 21, 50)
+    want, _ = oracle.get_uncertainty(P, pool, augs, 21, min_size=160, max_size=256)
+    assert after == want
+    assert after != before

@@ -1,0 +1,80 @@
+"""Throughput of the training step on one MI355X: images / s of forward + backward + SGD at the reference's
+training configuration (cald_train.py: batch size 4 per GPU, VOC images at min_size 600 / max_size 1000, 2 000 proposals,
+512 sampled RoIs per image).  Synthetic VOC-sized images and boxes, pseudo-trained weights.
+
+    python tools/bench_train.py [--batch 4] [--steps 10] [--warmup 3] [--profile out.csv]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from cald_amd import synth, train
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=4); ap.add_argument("--steps", type=int, default=10); ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--depth", type=int, default=50)
+    a = ap.parse_args()
+    sd = synth.pseudo_trained_frcnn(21, a.depth, seed=0)
+    net = train.FasterRCNNTrainer(sd, 21, depth=a.depth, min_size=600, max_size=1000, generator=torch.Generator().manual_seed(0))
+    model = train.TrainableFasterRCNN(net)
+    opt = train.SGD([p for p in model.parameters() if p.requires_grad], lr=1e-5, momentum=0.9, weight_decay=1e-4, net=net)
+    imgs = synth.make_pool(a.batch * 2, "voc", 0)
+    rs = np.random.RandomState(0)
+    batches = []
+    for b in range(2):
+        ims, tgs = [], []
+        for im in imgs[b * a.batch:(b + 1) * a.batch]:
+            H, W = im.shape[:2]
+            k = 3
+            x0 = rs.rand(k) * W * 0.6; y0 = rs.rand(k) * H * 0.6
+            boxes = np.stack([x0, y0, x0 + W * 0.3, y0 + H * 0.3], axis=1).astype(np.float32)
+            ims.append(torch.from_numpy(im).cuda()); tgs.append({"boxes": torch.from_numpy(boxes), "labels": torch.from_numpy(rs.randint(1, 21, k).astype(np.int64))})
+        batches.append((ims, tgs))
+
+    def step(i, parts=None):
+        ims, tgs = batches[i % 2]
+        t0 = time.time()
+        loss_dict = model(ims, tgs); losses = sum(loss_dict.values())
+        if parts is not None:
+            torch.cuda.synchronize(); t1 = time.time()
+        opt.zero_grad(); losses.backward()
+        if parts is not None:
+            torch.cuda.synchronize(); t2 = time.time()
+        opt.step()
+        if parts is not None:
+            torch.cuda.synchronize(); parts.append((t1 - t0, t2 - t1, time.time() - t2))
+        return losses
+    for i in range(a.warmup):
+        step(i)
+    torch.cuda.synchronize(); t = time.time()
+    per = []
+    for i in range(a.steps):
+        ts = time.time()
+        last = step(i)
+        per.append(round((time.time() - ts) * 1e3, 1))
+    torch.cuda.synchronize(); dt = (time.time() - t) / a.steps
+    print("host time per step (ms, not synchronized):", per, file=sys.stderr)
+    parts = []
+    for i in range(4):
+        step(i, parts)
+    p = np.mean(parts, axis=0)
+    net.timing = []
+    step(0)
+    sections = {b[0]: round((b[1] - a_[1]) * 1e3, 2) for a_, b in zip(net.timing[:-1], net.timing[1:])}
+    net.timing = None
+    print("forward sections (ms, synchronized):", sections, file=sys.stderr)
+    print(json.dumps({"metric": "training step throughput (forward + backward + SGD)", "value": a.batch / dt, "unit": "images/s", "ms_per_step": dt * 1e3,
+                      "batch": a.batch, "depth": a.depth, "forward_ms": p[0] * 1e3, "backward_ms": p[1] * 1e3, "sgd_ms": p[2] * 1e3,
+                      "loss": float(last.detach()), "config": "VOC-sized synthetic images, min_size 600 / max_size 1000, 2000 proposals, 512 RoIs / image"}))
+
+
+if __name__ == "__main__":
+    main()

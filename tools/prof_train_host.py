@@ -1,0 +1,11 @@
+import cProfile, pstats, sys, os, io
+sys.argv = ["bench_train.py", "--steps", "6", "--warmup", "3"]
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import runpy
+pr = cProfile.Profile()
+pr.enable()
+runpy.run_path(os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "tools", "bench_train.py"), run_name="__main__")
+pr.disable()
+s = io.StringIO()
+pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(28)
+print(s.getvalue()[:6000])
