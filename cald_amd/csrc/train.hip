@@ -702,33 +702,34 @@ struct RoiTrainArgs {
     float* out;            // forward: [R][49][C]
     const float* gout;     // backward: [R][49][C]
 };
-template <bool BWD>
-__global__ __launch_bounds__(256) void roi_align_train_kernel(RoiTrainArgs a) {
-    __shared__ RoiSample sy[14], sx[14];
-    const int r = blockIdx.x, tid = threadIdx.x;
+__device__ inline void roi_setup(const RoiTrainArgs& a, int r, RoiSample* sy, RoiSample* sx, int* n_out, int* l_out) {
     const float* rp = a.rois + (long long)r * 5;
-    const int n = (int)rp[0];
     const float4 box = make_float4(rp[1], rp[2], rp[3], rp[4]);
-    const int l = roi_level(box);
-    const int Hf = a.H[l], Wf = a.W[l], C = a.C, Cq = C >> 2;
+    const int l = roi_level(box), tid = threadIdx.x;
     if (tid < 28) {
         const float scale = 1.0f / (float)(4 << l);
         const float x1 = box.x * scale, y1 = box.y * scale, x2 = box.z * scale, y2 = box.w * scale;
         float rw = x2 - x1; if (!(rw >= 1.0f)) rw = 1.0f;
         float rh = y2 - y1; if (!(rh >= 1.0f)) rh = 1.0f;
         const float bw = rw / 7.0f, bh = rh / 7.0f;
-        if (tid < 14) sy[tid] = roi_sample(y1, bh, tid >> 1, tid & 1, Hf);
-        else sx[tid - 14] = roi_sample(x1, bw, (tid - 14) >> 1, (tid - 14) & 1, Wf);
+        if (tid < 14) sy[tid] = roi_sample(y1, bh, tid >> 1, tid & 1, a.H[l]);
+        else sx[tid - 14] = roi_sample(x1, bw, (tid - 14) >> 1, (tid - 14) & 1, a.W[l]);
     }
+    *n_out = (int)rp[0]; *l_out = l;
     __syncthreads();
-    const long long img_off = (long long)n * Hf * Wf * Cq;
-    const float4* f = reinterpret_cast<const float4*>(a.feat[l]) + img_off;
-    float* gf = BWD ? a.gfeat[l] + img_off * 4 : nullptr;
+}
+// forward: a thread owns (bin, 4 consecutive channels): 16 float4 gathers in flight per bin, one float4 store
+__global__ __launch_bounds__(256) void roi_align_train_kernel(RoiTrainArgs a) {
+    __shared__ RoiSample sy[14], sx[14];
+    const int r = blockIdx.x, tid = threadIdx.x;
+    int n, l;
+    roi_setup(a, r, sy, sx, &n, &l);
+    const int Hf = a.H[l], Wf = a.W[l], Cq = a.C >> 2;
+    const float4* f = reinterpret_cast<const float4*>(a.feat[l]) + (long long)n * Hf * Wf * Cq;
     for (int idx = tid; idx < 49 * Cq; idx += 256) {
         const int bin = idx / Cq, q = idx - bin * Cq;
         const int ph = bin / 7, pw = bin - ph * 7;
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), go = acc;
-        if (BWD) { go = reinterpret_cast<const float4*>(a.gout)[(long long)r * 49 * Cq + idx]; go.x *= 0.25f; go.y *= 0.25f; go.z *= 0.25f; go.w *= 0.25f; }
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int iy = 0; iy < 2; iy++) {
             const RoiSample Y = sy[ph * 2 + iy];
@@ -737,26 +738,43 @@ __global__ __launch_bounds__(256) void roi_align_train_kernel(RoiTrainArgs a) {
                 const RoiSample X = sx[pw * 2 + ix];
                 if (!(Y.valid && X.valid)) continue;
                 const float w1 = Y.h * X.h, w2 = Y.h * X.l, w3 = Y.l * X.h, w4 = Y.l * X.l;
-                const long long o1 = (long long)(Y.lo * Wf + X.lo) * Cq + q, o2 = (long long)(Y.lo * Wf + X.hi) * Cq + q;
-                const long long o3 = (long long)(Y.hi * Wf + X.lo) * Cq + q, o4 = (long long)(Y.hi * Wf + X.hi) * Cq + q;
-                if (!BWD) {
-                    const float4 v1 = f[o1], v2 = f[o2], v3 = f[o3], v4 = f[o4];
-                    acc.x = acc.x + (((w1 * v1.x + w2 * v2.x) + w3 * v3.x) + w4 * v4.x);
-                    acc.y = acc.y + (((w1 * v1.y + w2 * v2.y) + w3 * v3.y) + w4 * v4.y);
-                    acc.z = acc.z + (((w1 * v1.z + w2 * v2.z) + w3 * v3.z) + w4 * v4.z);
-                    acc.w = acc.w + (((w1 * v1.w + w2 * v2.w) + w3 * v3.w) + w4 * v4.w);
-                } else {
-                    const long long oo[4] = {o1, o2, o3, o4}; const float ww[4] = {w1, w2, w3, w4};
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        float* d = gf + oo[k] * 4;
-                        unsafeAtomicAdd(d, ww[k] * go.x); unsafeAtomicAdd(d + 1, ww[k] * go.y);
-                        unsafeAtomicAdd(d + 2, ww[k] * go.z); unsafeAtomicAdd(d + 3, ww[k] * go.w);
-                    }
-                }
+                const float4 v1 = f[(long long)(Y.lo * Wf + X.lo) * Cq + q], v2 = f[(long long)(Y.lo * Wf + X.hi) * Cq + q];
+                const float4 v3 = f[(long long)(Y.hi * Wf + X.lo) * Cq + q], v4 = f[(long long)(Y.hi * Wf + X.hi) * Cq + q];
+                acc.x = acc.x + (((w1 * v1.x + w2 * v2.x) + w3 * v3.x) + w4 * v4.x);
+                acc.y = acc.y + (((w1 * v1.y + w2 * v2.y) + w3 * v3.y) + w4 * v4.y);
+                acc.z = acc.z + (((w1 * v1.z + w2 * v2.z) + w3 * v3.z) + w4 * v4.z);
+                acc.w = acc.w + (((w1 * v1.w + w2 * v2.w) + w3 * v3.w) + w4 * v4.w);
             }
         }
-        if (!BWD) reinterpret_cast<float4*>(a.out)[(long long)r * 49 * Cq + idx] = make_float4(acc.x / 4.0f, acc.y / 4.0f, acc.z / 4.0f, acc.w / 4.0f);
+        reinterpret_cast<float4*>(a.out)[(long long)r * 49 * Cq + idx] = make_float4(acc.x / 4.0f, acc.y / 4.0f, acc.z / 4.0f, acc.w / 4.0f);
+    }
+}
+// backward: a thread owns (bin, ONE channel), consecutive lanes = consecutive channels, so that every atomic instruction of a
+// wavefront lands on 256 contiguous bytes (two cache lines) of one feature pixel
+__global__ __launch_bounds__(256) void roi_align_bwd_kernel(RoiTrainArgs a) {
+    __shared__ RoiSample sy[14], sx[14];
+    const int r = blockIdx.x, tid = threadIdx.x;
+    int n, l;
+    roi_setup(a, r, sy, sx, &n, &l);
+    const int Hf = a.H[l], Wf = a.W[l], C = a.C;
+    float* gf = a.gfeat[l] + (long long)n * Hf * Wf * C;
+    for (int idx = tid; idx < 49 * C; idx += 256) {
+        const int bin = idx / C, c = idx - bin * C;
+        const int ph = bin / 7, pw = bin - ph * 7;
+        const float go = a.gout[(long long)r * 49 * C + idx] * 0.25f;
+#pragma unroll
+        for (int iy = 0; iy < 2; iy++) {
+            const RoiSample Y = sy[ph * 2 + iy];
+#pragma unroll
+            for (int ix = 0; ix < 2; ix++) {
+                const RoiSample X = sx[pw * 2 + ix];
+                if (!(Y.valid && X.valid)) continue;
+                unsafeAtomicAdd(gf + (long long)(Y.lo * Wf + X.lo) * C + c, Y.h * X.h * go);
+                unsafeAtomicAdd(gf + (long long)(Y.lo * Wf + X.hi) * C + c, Y.h * X.l * go);
+                unsafeAtomicAdd(gf + (long long)(Y.hi * Wf + X.lo) * C + c, Y.l * X.h * go);
+                unsafeAtomicAdd(gf + (long long)(Y.hi * Wf + X.hi) * C + c, Y.l * X.l * go);
+            }
+        }
     }
 }
 static int roi_args(RoiTrainArgs& a, const float* const* feats, float* const* gfeats, const int* level_hw, int C, int R, const float* rois) {
@@ -771,7 +789,7 @@ extern "C" int cald_train_roi_align(cald_ctx* c, const float* const* feats, cons
     THIP(hipSetDevice(cald_internal_device(c)));
     RoiTrainArgs a; if (int rc = roi_args(a, feats, nullptr, level_hw, C, R, rois)) return rc;
     a.out = out;
-    hipLaunchKernelGGL(roi_align_train_kernel<false>, dim3(R), dim3(256), 0, cald_internal_stream(c), a);
+    hipLaunchKernelGGL(roi_align_train_kernel, dim3(R), dim3(256), 0, cald_internal_stream(c), a);
     THIP(hipGetLastError());
     return 0;
 }
@@ -781,7 +799,7 @@ extern "C" int cald_train_roi_align_bwd(cald_ctx* c, float* const* gfeats, const
     THIP(hipSetDevice(cald_internal_device(c)));
     RoiTrainArgs a; if (int rc = roi_args(a, (const float* const*)gfeats, gfeats, level_hw, C, R, rois)) return rc;
     a.gout = gout;
-    hipLaunchKernelGGL(roi_align_train_kernel<true>, dim3(R), dim3(256), 0, cald_internal_stream(c), a);
+    hipLaunchKernelGGL(roi_align_bwd_kernel, dim3(R), dim3(256), 0, cald_internal_stream(c), a);
     THIP(hipGetLastError());
     return 0;
 }

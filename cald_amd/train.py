@@ -22,8 +22,8 @@ torchvision semantics restated here (0.8.2, "TV-mem" in SURVEY Appendix A; in-re
                                                                                                         (frcnn_la.py:154-203)
   * RoI heads: proposals + ground truth; Matcher(0.5, 0.5); sampler(512, 0.25); BoxCoder (10, 10, 5, 5); cross-entropy +
     smooth-L1 (beta 1/9) / #sampled                                                                     (frcnn_la.py:160-222)
-The samplers draw ``torch.randperm`` from the CPU generator (the reference draws on its CUDA device: a different stream of
-random numbers, the same distribution).
+The samplers draw from torch's CPU generator (the reference draws ``torch.randperm`` on its CUDA device: a different stream of
+random numbers, the same distribution over subsets).
 """
 import numpy as np
 import torch
@@ -269,16 +269,27 @@ class FasterRCNNTrainer(object):
             self._anchors[key] = ops.anchors(Hp, Wp, level_hw, self.dev)
         return self._anchors[key]
 
-    def _randperm(self, n):
-        return torch.randperm(n, generator=self.generator)
+    def _choose(self, n, k):
+        """k distinct indices of range(n), every k-subset equally likely -- what ``torch.randperm(n)[:k]`` of
+        BalancedPositiveNegativeSampler selects, without permuting all n candidates (n is ~10^5 RPN negatives per image):
+        sequential uniform draws from the CPU generator, repeats skipped."""
+        if k >= n:
+            return torch.arange(n)
+        if 4 * k > n:
+            return torch.randperm(n, generator=self.generator)[:k]
+        got = np.empty(0, np.int64)
+        while len(got) < k:
+            draw = torch.randint(n, (2 * (k - len(got)) + 16,), generator=self.generator).numpy()
+            allv = np.concatenate([got, draw])
+            _, first = np.unique(allv, return_index=True)
+            got = allv[np.sort(first)][:k]
+        return torch.from_numpy(got)
 
     def _sample(self, pos, neg, batch, frac):
         """BalancedPositiveNegativeSampler for one image: index tensors (CPU) of the sampled positives / negatives."""
         num_pos = min(int(batch * frac), pos.numel())
         num_neg = min(batch - num_pos, neg.numel())
-        p = pos[self._randperm(pos.numel())[:num_pos]]
-        n = neg[self._randperm(neg.numel())[:num_neg]]
-        return p, n
+        return pos[self._choose(pos.numel(), num_pos)], neg[self._choose(neg.numel(), num_neg)]
 
     def forward(self, images, targets, proposals_override=None):
         """Training forward.  Returns the four losses as 1-element device tensors (no autograd) and keeps what backward needs."""
@@ -355,11 +366,13 @@ class FasterRCNNTrainer(object):
                 ops.match(anchors, gts[i], cfg["rpn_fg"], cfg["rpn_bg"], True, out=matched_dev[i])
         matched_all = matched_dev.cpu().numpy()
         obj_idx, obj_lab, box_idx, anc_idx, gt_idx = [], [], [], [], []
+        rpn_samples, box_samples = [], []
         for i in range(N):
             m = matched_all[i]
             pos, neg = torch.from_numpy(np.flatnonzero(m >= 0)), torch.from_numpy(np.flatnonzero(m == -1))
             sp, sn = self._sample(pos, neg, cfg["rpn_batch"], cfg["rpn_pos"])
             sp, sn = np.sort(sp.numpy()), np.sort(sn.numpy())
+            rpn_samples.append((sp, sn))
             op_, ap_ = head_offsets(i, sp); on_, _ = head_offsets(i, sn)
             obj_idx += [op_, on_]; obj_lab += [np.ones(len(op_), np.float32), np.zeros(len(on_), np.float32)]
             box_idx.append(op_ - ap_ + 3 + 4 * ap_)                  # channel 3 + 4a of the same pixel
@@ -392,6 +405,7 @@ class FasterRCNNTrainer(object):
                 labels = np.zeros(len(m), np.int64)
             pos, neg = torch.from_numpy(np.flatnonzero(labels >= 1)), torch.from_numpy(np.flatnonzero(labels == 0))
             sp, sn = self._sample(pos, neg, cfg["box_batch"], cfg["box_pos"])
+            box_samples.append((np.sort(sp.numpy()), np.sort(sn.numpy())))
             keep = np.sort(np.concatenate([sp.numpy(), sn.numpy()]))
             keep_all.append(pr_off[i] + keep); lab_all.append(labels[keep]); gtsel_all.append(gt_off[i] + np.maximum(m[keep], 0))
             img_col.append(np.full(len(keep), float(i), np.float32))
@@ -415,7 +429,8 @@ class FasterRCNNTrainer(object):
         pred = self.pred.fwd(f7)
         self.last = dict(N=N, R=R, feats=feats, inner=inner, P=P, tl=tl, heads=heads, head_flat=head_flat, head_sizes=head_sizes, level_hw=level_hw,
                          obj_idx=obj_idx, obj_lab=obj_lab, box_idx=box_idx, rpn_tgt=rpn_tgt, rois=rois, roi_rows=roi_rows, f6=f6, f7=f7, pred=pred,
-                         labels=labels_dev, pred_idx=pred_idx, box_tgt=box_tgt, proposals=proposals, roi_labels=roi_labels)
+                         labels=labels_dev, pred_idx=pred_idx, box_tgt=box_tgt, proposals=proposals, roi_labels=roi_labels,
+                         samples=dict(rpn=rpn_samples, box=box_samples))
         mark("box head")
         losses = {
             "loss_classifier": ops.softmax_ce(pred.view(R, -1), labels_dev, Ccls),

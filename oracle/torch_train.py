@@ -10,8 +10,7 @@ What is restated, with the reference call sites (the arithmetic itself lives in 
                                                          detection/frcnn_la.py:185-203 (in-repo copy detection/frcnn_ll.py:323-374)
   * RoIHeads.select_training_samples / fastrcnn_loss     detection/frcnn_la.py:104-128, :160-222
 Proposals are an INPUT here (the region-proposal arithmetic is index work pinned by the inference oracle, cald_oracle.c); the
-random permutations of the samplers come from the torch generator handed in, in the order rpn(image 0: pos, neg), rpn(image 1),
-..., box(image 0: pos, neg), ...
+samplers' random choices are either drawn here (torch.randperm from the generator handed in) or handed in and validated.
 """
 import math
 
@@ -162,9 +161,21 @@ class TorchTrainFRCNN(object):
         P.append(F.max_pool2d(P[3], 1, 2, 0))
         return P
 
-    def losses(self, images, targets, proposals, gen, cfg=None):
+    def losses(self, images, targets, proposals, gen, cfg=None, samples=None):
         """images: list of float CHW in [0, 1]; targets: dicts with boxes (original image coordinates) / labels; proposals: list
-        of [n_i, 4] tensors in resized-image coordinates (what the RPN produced).  Returns (loss dict, records)."""
+        of [n_i, 4] tensors in resized-image coordinates (what the RPN produced).  samples: optional {"rpn": [(pos, neg) index
+        arrays per image], "box": [...]} -- the samplers' random choices as made by the implementation under test; each is checked
+        to be a legal draw of BalancedPositiveNegativeSampler (right sizes, drawn from this restatement's own positive / negative
+        sets).  Without it the draws are torch.randperm(n, generator=gen)[:k].  Returns (loss dict, records)."""
+        def draw(kind, i, pos, neg, batch, frac):
+            if samples is None:
+                return sample(pos, neg, batch, frac, gen)
+            sp, sn = [torch.as_tensor(np.asarray(v), dtype=torch.int64) for v in samples[kind][i]]
+            num_pos = min(int(batch * frac), pos.numel())
+            assert len(sp) == num_pos and len(sn) == min(batch - num_pos, neg.numel()), "sampler sizes"
+            assert len(set(sp.tolist())) == len(sp) and len(set(sn.tolist())) == len(sn), "sampled twice"
+            assert set(sp.tolist()) <= set(pos.tolist()) and set(sn.tolist()) <= set(neg.tolist()), "sampled outside the candidate sets"
+            return sp, sn
         cfg = dict(dict(rpn_fg=0.7, rpn_bg=0.3, rpn_batch=256, rpn_pos=0.5, box_fg=0.5, box_bg=0.5, box_batch=512, box_pos=0.25, w=(10.0, 10.0, 5.0, 5.0)),
                    **(cfg or {}))
         p, N = self.p, len(images)
@@ -210,7 +221,7 @@ class TorchTrainFRCNN(object):
             else:
                 m = matcher(box_iou(gts[i], anchors), cfg["rpn_fg"], cfg["rpn_bg"], True)
             pos, neg = torch.nonzero(m >= 0).squeeze(1), torch.nonzero(m == -1).squeeze(1)
-            sp, sn = sample(pos, neg, cfg["rpn_batch"], cfg["rpn_pos"], gen)
+            sp, sn = draw("rpn", i, pos, neg, cfg["rpn_batch"], cfg["rpn_pos"])
             sp, sn = sp.sort().values, sn.sort().values
             pos_all.append(i * A + sp); neg_all.append(i * A + sn)
             tgt_all.append(encode(gts[i][m[sp]].double(), anchors[sp].double(), (1.0, 1.0, 1.0, 1.0)) if len(sp) else torch.zeros(0, 4, dtype=torch.float64))
@@ -232,7 +243,7 @@ class TorchTrainFRCNN(object):
                 labels[m == -1] = 0
                 labels[m == -2] = -1
             pos, neg = torch.nonzero(labels >= 1).squeeze(1), torch.nonzero(labels == 0).squeeze(1)
-            sp, sn = sample(pos, neg, cfg["box_batch"], cfg["box_pos"], gen)
+            sp, sn = draw("box", i, pos, neg, cfg["box_batch"], cfg["box_pos"])
             keep = torch.cat([sp, sn]).sort().values
             r_img.append(torch.full((len(keep),), i, dtype=torch.int64)); r_box.append(pr[keep]); r_lab.append(labels[keep])
             mg = gts[i][m[keep].clamp(min=0)] if gts[i].shape[0] else torch.zeros(len(keep), 4)

@@ -287,7 +287,7 @@ def _train_case(torch, n_images=2, seed=0):
 def test_training_step_losses_and_gradients_vs_autograd(T, oracle):
     """One whole training step (forward in train mode, the four losses, the gradient of their sum wrt EVERY trainable tensor:
     layers 2-4, FPN, RPN head, box head, predictor; 64 sampled RoIs per image to keep the CPU checker quick) against torch-CPU autograd in float64 on the same images, targets,
-    proposals, sampler permutations and ReLU decisions.  Losses to 1e-4 relative; each gradient tensor to 1e-4 of its largest
+    proposals, sampler draws (validated by the oracle as legal draws) and ReLU decisions.  Losses to 1e-4 relative; each gradient tensor to 1e-4 of its largest
     magnitude (float32 forward + backward vs float64)."""
     torch, ops = T
     from cald_amd import train
@@ -300,7 +300,7 @@ def test_training_step_losses_and_gradients_vs_autograd(T, oracle):
     grads = {k: v.clone() for k, v in net.backward().items()}
     ref = tt.TorchTrainFRCNN(sd, 21, min_size=160, max_size=256)
     ref.masks = net.relu_decisions()           # both sides take the same branch at every differentiated ReLU (see TorchTrainFRCNN.relu)
-    want, rec = ref.losses(images, targets, props, torch.Generator().manual_seed(7), cfg=dict(box_batch=64))
+    want, rec = ref.losses(images, targets, props, None, cfg=dict(box_batch=64), samples=net.last["samples"])
     assert torch.equal(rec["roi_labels"], net.last["roi_labels"]), "same sampled RoIs"
     for k in want:
         got = float(losses[k]); w = float(want[k].detach())
@@ -339,7 +339,6 @@ def test_drop_in_training_loop_updates_like_torch_sgd(T, oracle):
     rparams = ref.trainable()
     ropt = torch.optim.SGD(list(rparams.values()), lr=0.002, momentum=0.9, weight_decay=1e-4)
     rsched = torch.optim.lr_scheduler.LambdaLR(ropt, warm)
-    rgen = torch.Generator().manual_seed(1)
     seen = []
     for it in range(2):
         loss_dict = model(images, targets)
@@ -347,7 +346,7 @@ def test_drop_in_training_loop_updates_like_torch_sgd(T, oracle):
         seen.append(float(losses.detach()))
         opt.zero_grad(); losses.backward(); opt.step(); sched.step()
         ref.masks = net.relu_decisions()
-        want, _ = ref.losses(images, targets, [p.cpu() for p in net.last["proposals"]], rgen, cfg=dict(box_batch=64))
+        want, _ = ref.losses(images, targets, [p.cpu() for p in net.last["proposals"]], None, cfg=dict(box_batch=64), samples=net.last["samples"])
         rl = sum(want.values())
         assert abs(float(rl) - seen[-1]) <= 2e-4 * max(1.0, abs(float(rl))), (it, float(rl), seen[-1])
         ropt.zero_grad(); rl.backward(); ropt.step(); rsched.step()

@@ -66,6 +66,10 @@ def main():
     for i in range(4):
         step(i, parts)
     p = np.mean(parts, axis=0)
+    ims, tgs = batches[0]
+    net.forward(ims, tgs); torch.cuda.synchronize()
+    t0 = time.time(); net.backward(); t_enq = time.time() - t0; torch.cuda.synchronize(); t_all = time.time() - t0
+    print("backward: host enqueue %.1f ms, until the GPU is done %.1f ms" % (t_enq * 1e3, t_all * 1e3), file=sys.stderr)
     net.timing = []
     step(0)
     sections = {b[0]: round((b[1] - a_[1]) * 1e3, 2) for a_, b in zip(net.timing[:-1], net.timing[1:])}

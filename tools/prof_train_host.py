@@ -7,5 +7,5 @@ pr.enable()
 runpy.run_path(os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "tools", "bench_train.py"), run_name="__main__")
 pr.disable()
 s = io.StringIO()
-pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(28)
-print(s.getvalue()[:6000])
+pstats.Stats(pr, stream=s).sort_stats("cumtime").print_stats("train|_ffi|ctypes|detector", 45)
+print(s.getvalue()[:9000])

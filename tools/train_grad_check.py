@@ -13,7 +13,7 @@ props = [p.cpu() for p in net.last["proposals"]]
 grads = {k: v.clone() for k, v in net.backward().items()}
 ref = tt.TorchTrainFRCNN(sd, 21, min_size=160, max_size=256)
 ref.masks = net.relu_decisions()
-want, rec = ref.losses(images, targets, props, torch.Generator().manual_seed(7), cfg=dict(box_batch=64))
+want, rec = ref.losses(images, targets, props, None, cfg=dict(box_batch=64), samples=net.last["samples"])
 sum(want.values()).backward()
 tr = ref.trainable()
 for k in net.names:
