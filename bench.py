@@ -125,6 +125,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-full-pool", action="store_true", help="skip the 5 217-image end-to-end run (N = 1 headline only)")
     ap.add_argument("--no-f16x3", action="store_true")
+    ap.add_argument("--no-train", action="store_true", help="skip the training-step leg (SURVEY 8f rank 4, informational)")
     ap.add_argument("--model", default="frcnn", choices=["frcnn", "frcnn101", "retinanet"],
                     help="frcnn = the headline workload (BASELINE configs[1]); others are informational runs of configs[2]/[4]")
     ap.add_argument("--shape", default="voc", choices=["voc", "coco"])
@@ -336,6 +337,13 @@ def main():
                                 "headline": False, "images_compared": nb, "max_abs_consistency_diff_vs_exact": float(d.max()),
                                 "images_beyond_1e-4_vs_exact": int((d > 1e-4).sum()),
                                 "note": "bit-identical to its CPU oracle (tests/test_gpu_parity.py); distance to fp32: profiles/parity_vs_independent_fp32_r2.json"}
+        if world == 1 and headline and not args.no_train:
+            # informational, NOT the headline: one training step of the same detector, cald_train.py's defaults
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_train
+            del model
+            torch.cuda.empty_cache()
+            out["training_step"] = dict(bench_train.measure(batch=4, steps=10, warmup=3), headline=False)
         try:
             out["parity_vs_independent_fp32"] = json.load(open(os.path.join(ROOT, "profiles", "parity_vs_independent_fp32_r2.json")))["summary"]
         except Exception:

@@ -17,11 +17,9 @@ import torch
 from cald_amd import synth, train
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--batch", type=int, default=4); ap.add_argument("--steps", type=int, default=10); ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--depth", type=int, default=50)
-    a = ap.parse_args()
+def measure(batch=4, steps=10, warmup=3, depth=50, verbose=False):
+    from types import SimpleNamespace
+    a = SimpleNamespace(batch=batch, steps=steps, warmup=warmup, depth=depth)
     sd = synth.pseudo_trained_frcnn(21, a.depth, seed=0)
     net = train.FasterRCNNTrainer(sd, 21, depth=a.depth, min_size=600, max_size=1000, generator=torch.Generator().manual_seed(0))
     model = train.TrainableFasterRCNN(net)
@@ -61,7 +59,8 @@ def main():
         last = step(i)
         per.append(round((time.time() - ts) * 1e3, 1))
     torch.cuda.synchronize(); dt = (time.time() - t) / a.steps
-    print("host time per step (ms, not synchronized):", per, file=sys.stderr)
+    if verbose:
+        print("host time per step (ms, not synchronized):", per, file=sys.stderr)
     parts = []
     for i in range(4):
         step(i, parts)
@@ -69,15 +68,26 @@ def main():
     ims, tgs = batches[0]
     net.forward(ims, tgs); torch.cuda.synchronize()
     t0 = time.time(); net.backward(); t_enq = time.time() - t0; torch.cuda.synchronize(); t_all = time.time() - t0
-    print("backward: host enqueue %.1f ms, until the GPU is done %.1f ms" % (t_enq * 1e3, t_all * 1e3), file=sys.stderr)
+    if verbose:
+        print("backward: host enqueue %.1f ms, until the GPU is done %.1f ms" % (t_enq * 1e3, t_all * 1e3), file=sys.stderr)
     net.timing = []
     step(0)
     sections = {b[0]: round((b[1] - a_[1]) * 1e3, 2) for a_, b in zip(net.timing[:-1], net.timing[1:])}
     net.timing = None
-    print("forward sections (ms, synchronized):", sections, file=sys.stderr)
-    print(json.dumps({"metric": "training step throughput (forward + backward + SGD)", "value": a.batch / dt, "unit": "images/s", "ms_per_step": dt * 1e3,
-                      "batch": a.batch, "depth": a.depth, "forward_ms": p[0] * 1e3, "backward_ms": p[1] * 1e3, "sgd_ms": p[2] * 1e3,
-                      "loss": float(last.detach()), "config": "VOC-sized synthetic images, min_size 600 / max_size 1000, 2000 proposals, 512 RoIs / image"}))
+    if verbose:
+        print("forward sections (ms, synchronized):", sections, file=sys.stderr)
+    return {"metric": "training step throughput (forward + backward + SGD)", "value": a.batch / dt, "unit": "images/s", "ms_per_step": dt * 1e3,
+            "batch": a.batch, "depth": a.depth, "forward_ms": p[0] * 1e3, "backward_ms": p[1] * 1e3, "sgd_ms": p[2] * 1e3,
+            "backward_gpu_ms": t_all * 1e3, "loss": float(last.detach()), "dtype": "f32",
+            "config": "cald_train.py defaults: batch 4, VOC-sized synthetic images, min_size 600 / max_size 1000, 2000 proposals, 512 RoIs / image, SGD momentum 0.9"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=4); ap.add_argument("--steps", type=int, default=10); ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--depth", type=int, default=50)
+    a = ap.parse_args()
+    print(json.dumps(measure(a.batch, a.steps, a.warmup, a.depth, verbose=True)))
 
 
 if __name__ == "__main__":
