@@ -39,6 +39,23 @@ def _bn_fold(sd, prefix, eps=1e-5):
     return scale.float(), (b - rm * scale).float()
 
 
+def choose_k(n, k, generator=None):
+    """k distinct indices of range(n), every k-subset equally likely -- what ``torch.randperm(n)[:k]`` of torchvision's
+    BalancedPositiveNegativeSampler selects, without permuting all n candidates (n is ~10^5 RPN negatives per image):
+    sequential uniform draws from the CPU generator, repeats skipped."""
+    if k >= n:
+        return torch.arange(n)
+    if 4 * k > n:
+        return torch.randperm(n, generator=generator)[:k]
+    got = np.empty(0, np.int64)
+    while len(got) < k:
+        draw = torch.randint(n, (2 * (k - len(got)) + 16,), generator=generator).numpy()
+        allv = np.concatenate([got, draw])
+        _, first = np.unique(allv, return_index=True)
+        got = allv[np.sort(first)][:k]
+    return torch.from_numpy(got)
+
+
 class _Conv(object):
     """One conv / linear layer of the graph: forward on the packed weight, backward = weight gradient + data gradient."""
 
@@ -269,27 +286,11 @@ class FasterRCNNTrainer(object):
             self._anchors[key] = ops.anchors(Hp, Wp, level_hw, self.dev)
         return self._anchors[key]
 
-    def _choose(self, n, k):
-        """k distinct indices of range(n), every k-subset equally likely -- what ``torch.randperm(n)[:k]`` of
-        BalancedPositiveNegativeSampler selects, without permuting all n candidates (n is ~10^5 RPN negatives per image):
-        sequential uniform draws from the CPU generator, repeats skipped."""
-        if k >= n:
-            return torch.arange(n)
-        if 4 * k > n:
-            return torch.randperm(n, generator=self.generator)[:k]
-        got = np.empty(0, np.int64)
-        while len(got) < k:
-            draw = torch.randint(n, (2 * (k - len(got)) + 16,), generator=self.generator).numpy()
-            allv = np.concatenate([got, draw])
-            _, first = np.unique(allv, return_index=True)
-            got = allv[np.sort(first)][:k]
-        return torch.from_numpy(got)
-
     def _sample(self, pos, neg, batch, frac):
         """BalancedPositiveNegativeSampler for one image: index tensors (CPU) of the sampled positives / negatives."""
         num_pos = min(int(batch * frac), pos.numel())
         num_neg = min(batch - num_pos, neg.numel())
-        return pos[self._choose(pos.numel(), num_pos)], neg[self._choose(neg.numel(), num_neg)]
+        return pos[choose_k(pos.numel(), num_pos, self.generator)], neg[choose_k(neg.numel(), num_neg, self.generator)]
 
     def forward(self, images, targets, proposals_override=None):
         """Training forward.  Returns the four losses as 1-element device tensors (no autograd) and keeps what backward needs."""
@@ -359,7 +360,7 @@ class FasterRCNNTrainer(object):
             return head_off[l] + (img * lvl_pix[l] + pix) * 16 + a, a
         n_gt = [int(g.shape[0]) for g in gts]
         gt_off = np.cumsum([0] + n_gt)
-        gts_all = torch.cat(gts) if sum(n_gt) else torch.zeros((1, 4), device=self.dev)
+        gts_all = torch.cat(gts + [torch.zeros((1, 4), device=self.dev)])      # last row: the "matched box" of images without ground truth
         matched_dev = torch.full((N, A_img), -1, dtype=torch.int32, device=self.dev)
         for i in range(N):
             if n_gt[i]:
@@ -407,7 +408,8 @@ class FasterRCNNTrainer(object):
             sp, sn = self._sample(pos, neg, cfg["box_batch"], cfg["box_pos"])
             box_samples.append((np.sort(sp.numpy()), np.sort(sn.numpy())))
             keep = np.sort(np.concatenate([sp.numpy(), sn.numpy()]))
-            keep_all.append(pr_off[i] + keep); lab_all.append(labels[keep]); gtsel_all.append(gt_off[i] + np.maximum(m[keep], 0))
+            keep_all.append(pr_off[i] + keep); lab_all.append(labels[keep])
+            gtsel_all.append(gt_off[i] + np.maximum(m[keep], 0) if n_gt[i] else np.full(len(keep), gt_off[-1], np.int64))
             img_col.append(np.full(len(keep), float(i), np.float32))
         roi_labels_np = np.concatenate(lab_all).astype(np.int64)
         R = len(roi_labels_np)
@@ -418,7 +420,7 @@ class FasterRCNNTrainer(object):
         pred_idx, pos_sel = packed[3 * R:3 * R + len(pos_rows)], packed[3 * R + len(pos_rows):]
         boxes = pr_all[keep_sel]
         rois = torch.cat([torch.from_numpy(np.concatenate(img_col)).to(self.dev)[:, None], boxes], dim=1).contiguous()
-        roi_gt = gts_all[gt_sel2] if sum(n_gt) else torch.zeros_like(boxes)
+        roi_gt = gts_all[gt_sel2]
         box_tgt = ops.box_encode(roi_gt.contiguous(), boxes.contiguous(), cfg["w"])[pos_sel].contiguous()
         roi_labels = torch.from_numpy(roi_labels_np)
         mark("roi sampling")

@@ -504,3 +504,22 @@ def test_voc_dataset_conversion_matches_reference_golden(golden, tmp_path):
             assert torch.equal(t[k], t2[k])
     labeled = ds.label_loader([1, 2, 3])
     assert [int(x) for _, (t,) in labeled for x in t["labels"]] == [int(x) for i in (1, 2, 3) for x in g["labels_%d" % i]]
+
+
+def test_sampler_draws_are_uniform_subsets():
+    """cald_amd.train.choose_k (the O(k) stand-in for BalancedPositiveNegativeSampler's randperm(n)[:k]):
+    k distinct indices in range, reproducible from the generator, every element equally likely."""
+    import torch
+    from cald_amd.train import choose_k
+    g = torch.Generator().manual_seed(3)
+    for n, k in ((100000, 128), (1000, 128), (300, 256), (40, 64), (5, 0), (0, 8)):
+        idx = choose_k(n, k, g).numpy()
+        assert len(idx) == min(n, k) and len(set(idx.tolist())) == len(idx)
+        assert len(idx) == 0 or (idx.min() >= 0 and idx.max() < n)
+    a = choose_k(100000, 128, torch.Generator().manual_seed(9)); b = choose_k(100000, 128, torch.Generator().manual_seed(9))
+    assert torch.equal(a, b)
+    counts = np.zeros(50)
+    g = torch.Generator().manual_seed(0)
+    for _ in range(4000):
+        counts[choose_k(50, 5, g).numpy()] += 1
+    assert abs(counts / 4000 - 0.1).max() < 0.02          # each element is drawn with probability k / n = 0.1

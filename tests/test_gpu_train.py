@@ -406,3 +406,26 @@ def test_active_learning_cycle_train_then_sweep_with_the_same_model_object(T, or
     want, _ = oracle.get_uncertainty(P, pool, augs, 21, min_size=160, max_size=256)
     assert after == want
     assert after != before
+
+
+def test_training_batch_with_an_image_without_boxes_and_resnet101(T):
+    """Edge cases of the training forward: an image with NO ground-truth boxes (torchvision: every anchor / proposal is background,
+    zero regression targets), a batch of one, and the ResNet-101 body: finite losses, gradients for all trainable tensors."""
+    torch, ops = T
+    from cald_amd import synth, train
+    sd, images, targets = _train_case(torch, n_images=2, seed=4)
+    targets[1] = {"boxes": torch.zeros((0, 4)), "labels": torch.zeros((0,), dtype=torch.int64)}
+    net = train.FasterRCNNTrainer(sd, 21, min_size=160, max_size=256, generator=torch.Generator().manual_seed(2))
+    losses = net.forward(images, targets)
+    assert all(bool(torch.isfinite(v).all()) for v in losses.values())
+    assert int((net.last["roi_labels"][net.last["rois"][:, 0].cpu() == 1] != 0).sum()) == 0      # image 1: background only
+    grads = net.backward()
+    assert all(bool(torch.isfinite(g).all()) for g in grads.values())
+    one = net.forward(images[:1], targets[:1])
+    assert all(bool(torch.isfinite(v).all()) for v in one.values())
+    sd101 = synth.pseudo_trained_frcnn(21, 101, seed=1)
+    net101 = train.FasterRCNNTrainer(sd101, 21, depth=101, min_size=160, max_size=256, generator=torch.Generator().manual_seed(2))
+    l101 = net101.forward(images[:1], targets[:1])
+    g101 = net101.backward()
+    assert len(g101) == 72 + 17 * 3 and all(bool(torch.isfinite(g).all()) for g in g101.values()) and all(bool(torch.isfinite(v).all()) for v in l101.values())
+    assert float(g101["backbone.body.layer3.22.conv2.weight"].abs().max()) > 0
