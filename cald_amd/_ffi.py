@@ -103,14 +103,16 @@ SIGNATURES = {
     "cald_train_upsample_bwd": (C.c_int, [C.c_void_p] + [C.c_int] * 6 + [C.c_void_p, C.c_void_p]),
     "cald_train_rpn_proposals": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_i, C.POINTER(C.c_void_p), c_i, C.c_int, C.c_int, C.c_int,
                                            C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
-    "cald_train_anchors": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_i, C.c_void_p]),
+    "cald_train_anchors": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_i, C.c_void_p]),
     "cald_train_match": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
     "cald_train_box_encode": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "cald_train_roi_align": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), c_i, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "cald_train_roi_align_bwd": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), c_i, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "cald_train_softmax_ce": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
-    "cald_train_smooth_l1": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_void_p,
-                                       C.c_void_p]),
+    "cald_train_smooth_l1": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_float,
+                                       C.c_void_p, C.c_void_p]),
+    "cald_train_focal_loss": (C.c_int, [C.c_void_p, C.c_int, c_i, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     "cald_train_bce_logits": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
     "cald_train_preprocess": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), c_i, C.c_int, C.c_int, C.c_void_p]),
     "cald_train_maxpool": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

@@ -644,28 +644,41 @@ __global__ void anchors_kernel(float4* out, int Hl, int Wl, int sy, int sx, cons
     const int x = (int)(pix % Wl), y = (int)(pix / Wl);
     out[off + i] = make_float4((float)(x * sx) + base[an * 4], (float)(y * sy) + base[an * 4 + 1], (float)(x * sx) + base[an * 4 + 2], (float)(y * sy) + base[an * 4 + 3]);
 }
-extern "C" int cald_train_anchors(cald_ctx* c, int Hp, int Wp, const int* level_hw, float* anchors_out) {
-    if (!c || !level_hw || !anchors_out) TFAIL(CALD_ERR_INVALID, "null argument");
+// kind 0: Faster R-CNN AnchorGenerator, sizes (32, 64, 128, 256, 512) x ratios (0.5, 1, 2), A = 3 (frcnn_la.py:185-187)
+// kind 1: RetinaNet, sizes (x, int(x 2^(1/3)), int(x 2^(2/3))) for x in the same five, A = 9, index = ratio * 3 + size (retinanet_cal.py:346-351)
+static int base_anchors_host(int kind, float* base) {
+    const float ratios[3] = {0.5f, 1.0f, 2.0f};
+    for (int l = 0; l < 5; l++) {
+        const int x = 32 << l;
+        const float sizes[3] = {(float)x, (float)(int)((double)x * pow(2.0, 1.0 / 3)), (float)(int)((double)x * pow(2.0, 2.0 / 3))};
+        const int ns = kind == 1 ? 3 : 1;
+        for (int r = 0; r < 3; r++) {
+            const float hr = sqrtf(ratios[r]), wr = 1.0f / hr;
+            for (int si = 0; si < ns; si++) {
+                const float ws = wr * sizes[si], hs = hr * sizes[si];
+                float* b = &base[((l * 3 + r) * ns + si) * 4];
+                b[0] = rintf(-ws / 2.0f); b[1] = rintf(-hs / 2.0f); b[2] = rintf(ws / 2.0f); b[3] = rintf(hs / 2.0f);
+            }
+        }
+    }
+    return kind == 1 ? 9 : 3;
+}
+extern "C" int cald_train_anchors(cald_ctx* c, int kind, int Hp, int Wp, const int* level_hw, float* anchors_out) {
+    if (!c || !level_hw || !anchors_out || kind < 0 || kind > 1) TFAIL(CALD_ERR_INVALID, "bad arguments");
     THIP(hipSetDevice(cald_internal_device(c)));
     hipStream_t st = cald_internal_stream(c);
-    float base[5 * 3 * 4];
-    const float sizes[5] = {32.f, 64.f, 128.f, 256.f, 512.f}, ratios[3] = {0.5f, 1.0f, 2.0f};
-    for (int l = 0; l < 5; l++)
-        for (int r = 0; r < 3; r++) {
-            const float hr = sqrtf(ratios[r]), wr = 1.0f / hr, ws = wr * sizes[l], hs = hr * sizes[l];
-            float* b = &base[(l * 3 + r) * 4];
-            b[0] = rintf(-ws / 2.0f); b[1] = rintf(-hs / 2.0f); b[2] = rintf(ws / 2.0f); b[3] = rintf(hs / 2.0f);
-        }
+    float base[5 * 9 * 4];
+    const int A = base_anchors_host(kind, base);
     void* scratch = nullptr;
-    if (int rc = cald_internal_scratch(c, 256, &scratch)) return rc;
+    if (int rc = cald_internal_scratch(c, sizeof(base), &scratch)) return rc;
     THIP(hipMemcpyAsync(scratch, base, sizeof(base), hipMemcpyHostToDevice, st));
     THIP(hipStreamSynchronize(st));
     long long off = 0;
     for (int l = 0; l < 5; l++) {
         const int Hl = level_hw[2 * l], Wl = level_hw[2 * l + 1];
-        const long long n = (long long)Hl * Wl * 3;
+        const long long n = (long long)Hl * Wl * A;
         hipLaunchKernelGGL(anchors_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (float4*)anchors_out, Hl, Wl, Hp / Hl, Wp / Wl,
-                           (const float*)scratch + l * 12, 3, off);
+                           (const float*)scratch + l * A * 4, A, off);
         off += n;
     }
     THIP(hipGetLastError());
@@ -846,25 +859,27 @@ extern "C" int cald_train_softmax_ce(cald_ctx* c, int R, int C, int ld, const fl
     return 0;
 }
 // det_utils.smooth_l1_loss(pred, target, beta, size_average=False) / denom over n gathered 4-vectors: pred 4-vector i starts at
-// float offset idx[i] of `pred` (and of `grad`, which the caller has zeroed)
+// float offset idx[i] of `pred` (and of `grad`, which the caller has zeroed).  beta = 0 is the plain L1 loss (retinanet_cal.py:217);
+// weights (optional, one per 4-vector) multiply each vector's term (per-image 1 / num_foreground of RetinaNet).
 __global__ __launch_bounds__(256) void smooth_l1_kernel(const float* pred, const long long* idx, const float* target, int n, float beta, float denom,
-                                                        float gscale, float* loss, float* grad) {
+                                                        const float* weights, float gscale, float* loss, float* grad) {
     __shared__ float red[256];
     float local = 0.0f;
     for (int e = threadIdx.x; e < 4 * n; e += 256) {
         const long long o = idx[e >> 2] + (e & 3);
         const float d = pred[o] - target[e], ad = fabsf(d);
-        local += ad < beta ? 0.5f * d * d / beta : ad - 0.5f * beta;
-        if (grad) grad[o] = (ad < beta ? d / beta : (d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f))) * (gscale / denom);
+        const float w = weights ? weights[e >> 2] : 1.0f;
+        local += w * (ad < beta ? 0.5f * d * d / beta : ad - 0.5f * beta);
+        if (grad) grad[o] = (ad < beta ? d / beta : (d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f))) * (w * gscale / denom);
     }
     const float tot = block_sum_256(local, red);
     if (threadIdx.x == 0) *loss = tot / denom;
 }
 extern "C" int cald_train_smooth_l1(cald_ctx* c, int n, const float* pred, const int64_t* idx, const float* target, float beta, float denom,
-                                    float gscale, float* loss_out, float* grad) {
+                                    const float* weights, float gscale, float* loss_out, float* grad) {
     if (!c || !loss_out || (n > 0 && (!pred || !idx || !target))) TFAIL(CALD_ERR_INVALID, "bad arguments");
     THIP(hipSetDevice(cald_internal_device(c)));
-    hipLaunchKernelGGL(smooth_l1_kernel, dim3(1), dim3(256), 0, cald_internal_stream(c), pred, (const long long*)idx, target, n, beta, denom, gscale, loss_out, grad);
+    hipLaunchKernelGGL(smooth_l1_kernel, dim3(1), dim3(256), 0, cald_internal_stream(c), pred, (const long long*)idx, target, n, beta, denom, weights, gscale, loss_out, grad);
     THIP(hipGetLastError());
     return 0;
 }
@@ -942,6 +957,82 @@ extern "C" int cald_train_subsample2(cald_ctx* c, int N, int H, int W, int C, co
     if (int rc = dense_seg(c, N, H, W, &si)) return rc;
     if (int rc = dense_seg(c, N, Ho, Wo, &so)) return rc;
     launch_subsample2(in, out, si, so, C, N, Ho * Wo, cald_internal_stream(c));
+    THIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// RetinaNet classification loss (retinanet_cal.py:100-133): torchvision.ops.sigmoid_focal_loss(alpha 0.25, gamma 2, 'sum') over the
+// anchors whose match is not BETWEEN_THRESHOLDS, / max(1, #foreground) per image, mean over images.
+//   logits: five level blocks in one buffer, level l = [N][pix_l][ld] with channel a * K + k; anchor order (level, y, x, a).
+//   target(n, anchor, k) = matched >= 0 and gt_labels[gt_off[n] + matched] == k;  img_weight[n] = 1 / (max(1, #fg_n) * N).
+// One thread per (image, anchor); block partial sums are added in a fixed order by the second kernel.
+// ---------------------------------------------------------------------------------------------------------------------
+struct FocalArgs {
+    const float* logits; float* grad; const int* matched; const long long* gt_labels; const int* gt_off; const float* img_weight;
+    long long lvl_anchor0[6], lvl_off[5]; int lvl_pix[5];
+    int N, A, K, ld; long long A_tot; float alpha, gscale;
+};
+__global__ __launch_bounds__(256) void focal_loss_kernel(FocalArgs a, float* partial) {
+    __shared__ float red[256];
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    float local = 0.0f;
+    if (i < a.N * a.A_tot) {
+        const int n = (int)(i / a.A_tot); const long long an = i - (long long)n * a.A_tot;
+        const int m = a.matched[i];
+        if (m != -2) {
+            int l = 0;
+            while (l < 4 && an >= a.lvl_anchor0[l + 1]) l++;
+            const long long rel = an - a.lvl_anchor0[l];
+            const long long pix = rel / a.A; const int aa = (int)(rel - pix * a.A);
+            const long long base = a.lvl_off[l] + ((long long)n * a.lvl_pix[l] + pix) * a.ld + (long long)aa * a.K;
+            const int cls = m >= 0 ? (int)a.gt_labels[a.gt_off[n] + m] : -1;
+            const float w = a.img_weight[n];
+            for (int k = 0; k < a.K; k++) {
+                const float x = a.logits[base + k];
+                const float lse = det_logf(1.0f + det_expf(-fabsf(x)));          // log(1 + exp(-|x|))
+                const float logp = -((x < 0.0f ? -x : 0.0f) + lse);               // log sigmoid(x)
+                const float log1mp = -((x > 0.0f ? x : 0.0f) + lse);              // log (1 - sigmoid(x))
+                const float p = det_sigmoidf(x), q = 1.0f - p;
+                float loss, g;
+                if (k == cls) { loss = -a.alpha * q * q * logp; g = a.alpha * q * q * (2.0f * p * logp - q); }
+                else { loss = -(1.0f - a.alpha) * p * p * log1mp; g = (1.0f - a.alpha) * p * p * (p - 2.0f * q * log1mp); }
+                local += w * loss;
+                if (a.grad) a.grad[base + k] = g * w * a.gscale;
+            }
+        }
+    }
+    const float tot = block_sum_256(local, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* partial, int n, float* out) {
+    __shared__ float red[256];
+    float local = 0.0f;
+    for (int i = threadIdx.x; i < n; i += 256) local += partial[i];
+    const float tot = block_sum_256(local, red);
+    if (threadIdx.x == 0) *out = tot;
+}
+extern "C" int cald_train_focal_loss(cald_ctx* c, int N, const int* level_pix, int A, int K, int ld, const float* logits, const int* matched,
+                                     const int64_t* gt_labels, const int* gt_off, const float* img_weight, float alpha, float gscale,
+                                     float* loss_out, float* grad) {
+    if (!c || !level_pix || !logits || !matched || !gt_labels || !gt_off || !img_weight || !loss_out) TFAIL(CALD_ERR_INVALID, "null argument");
+    if (N < 1 || A < 1 || K < 1 || ld < A * K) TFAIL(CALD_ERR_INVALID, "bad geometry");
+    THIP(hipSetDevice(cald_internal_device(c)));
+    hipStream_t st = cald_internal_stream(c);
+    FocalArgs a; memset(&a, 0, sizeof(a));
+    a.logits = logits; a.grad = grad; a.matched = matched; a.gt_labels = (const long long*)gt_labels; a.gt_off = gt_off; a.img_weight = img_weight;
+    long long an = 0, off = 0;
+    for (int l = 0; l < 5; l++) {
+        a.lvl_anchor0[l] = an; a.lvl_off[l] = off; a.lvl_pix[l] = level_pix[l];
+        an += (long long)level_pix[l] * A; off += (long long)N * level_pix[l] * ld;
+    }
+    a.lvl_anchor0[5] = an; a.A_tot = an; a.N = N; a.A = A; a.K = K; a.ld = ld; a.alpha = alpha; a.gscale = gscale;
+    const long long total = (long long)N * an;
+    const int blocks = (int)((total + 255) / 256);
+    void* scratch = nullptr;
+    if (int rc = cald_internal_scratch(c, (size_t)blocks * 4 + 64, &scratch)) return rc;
+    hipLaunchKernelGGL(focal_loss_kernel, dim3(blocks), dim3(256), 0, st, a, (float*)scratch);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, (const float*)scratch, blocks, loss_out);
     THIP(hipGetLastError());
     return 0;
 }

@@ -72,11 +72,10 @@ class HipDetector:
 
     def train(self, mode=True):
         """task_model.train() (cald_train.py:41): the Faster R-CNN training step runs on the HIP operators of cald_amd/train.py
-        (SURVEY 8f rank 4); ``model(images, targets)`` then returns the loss dict.  RetinaNet training is not built."""
+        (SURVEY 8f rank 4); ``model(images, targets)`` then returns the loss dict (Faster R-CNN: four losses, frcnn_la.py; RetinaNet:
+        'classification' / 'bbox_regression', retinanet_cal.py:50-55)."""
         if not mode:
             return self.eval()
-        if self.arch != 0:
-            raise NotImplementedError("training is implemented for the Faster R-CNN detector only")
         self._ensure_trainer()
         self.training = True
         return self
@@ -87,9 +86,13 @@ class HipDetector:
                 raise RuntimeError("no weights: call load_state_dict() first (cald_train.py:356)")
             from . import train as _train
             dev = "cuda:%d" % (self._device if self._device is not None else torch.cuda.current_device())
-            self._trainer = _train.FasterRCNNTrainer(self._state, self.num_classes, depth=self._depth, min_size=self.cfg.min_size,
-                                                     max_size=self.cfg.max_size, device=dev, rpn_nms_thresh=self.cfg.rpn_nms_thresh)
-            self._train_fn = _train.TrainableFasterRCNN(self._trainer)
+            if self.arch == 0:
+                self._trainer = _train.FasterRCNNTrainer(self._state, self.num_classes, depth=self._depth, min_size=self.cfg.min_size,
+                                                         max_size=self.cfg.max_size, device=dev, rpn_nms_thresh=self.cfg.rpn_nms_thresh)
+            else:
+                self._trainer = _train.RetinaNetTrainer(self._state, self.num_classes, depth=self._depth, min_size=self.cfg.min_size,
+                                                        max_size=self.cfg.max_size, device=dev)
+            self._train_fn = _train.TrainableDetector(self._trainer)
         return self._trainer
 
     def _sync_from_trainer(self):

@@ -147,18 +147,14 @@ class _Bottleneck(object):
         return self.c1.bwd(ga1, residual=g)
 
 
-class FasterRCNNTrainer(object):
-    """The trainable mirror of detection/frcnn_la.py FRCNN_Feature (ResNet-50/101 FPN Faster R-CNN) on one MI355X."""
+class _TrainerBase(object):
+    """What the two detectors share: parameter storage, the ResNet body (forward + backward), input preparation."""
+    LOSS_NAMES = ()
+    MERGE_GROUPS = ()
 
-    def __init__(self, state_dict, num_classes, depth=50, min_size=600, max_size=1000, device="cuda", trainable_layers=3,
-                 rpn_pre_nms_top_n=2000, rpn_post_nms_top_n=2000, rpn_nms_thresh=0.7, rpn_fg_iou=0.7, rpn_bg_iou=0.3,
-                 rpn_batch=256, rpn_pos_fraction=0.5, box_fg_iou=0.5, box_bg_iou=0.5, box_batch=512, box_pos_fraction=0.25,
-                 bbox_reg_weights=(10.0, 10.0, 5.0, 5.0), generator=None):
+    def _init_common(self, state_dict, num_classes, depth, min_size, max_size, device, trainable_layers, generator):
         self.dev = torch.device(device)
         self.C, self.min_size, self.max_size = num_classes, int(min_size), int(max_size)
-        self.cfg = dict(pre_n=rpn_pre_nms_top_n, post_n=rpn_post_nms_top_n, nms=rpn_nms_thresh, rpn_fg=rpn_fg_iou, rpn_bg=rpn_bg_iou,
-                        rpn_batch=rpn_batch, rpn_pos=rpn_pos_fraction, box_fg=box_fg_iou, box_bg=box_bg_iou, box_batch=box_batch,
-                        box_pos=box_pos_fraction, w=tuple(bbox_reg_weights))
         self.generator = generator
         self.version = 0                                   # bumped whenever the parameters change: packed weights are rebuilt lazily
         sd = {k: (v.detach().float().cpu() if hasattr(v, "detach") else torch.from_numpy(np.asarray(v, np.float32)))
@@ -171,16 +167,12 @@ class FasterRCNNTrainer(object):
         # parameter storage: trainable tensors live in ONE flat buffer in state-dict order, so that tensors torchvision keeps
         # apart but the kernels treat as one matrix (RPN cls_logits + bbox_pred, predictor cls_score + bbox_pred) are adjacent
         self.names = [k for k in sd if not is_frozen(k)]
-        for a, b in (("rpn.head.cls_logits.weight", "rpn.head.bbox_pred.weight"), ("rpn.head.cls_logits.bias", "rpn.head.bbox_pred.bias"),
-                     ("roi_heads.box_predictor.cls_score.weight", "roi_heads.box_predictor.bbox_pred.weight"),
-                     ("roi_heads.box_predictor.cls_score.bias", "roi_heads.box_predictor.bbox_pred.bias")):
+        self._merge_groups = [list(g) for g in self.MERGE_GROUPS]
+        for a, b in self._merge_groups:
             self.names.remove(b)
             self.names.insert(self.names.index(a) + 1, b)
         sizes = [sd[k].numel() for k in self.names]
         pad = [(-s) % 4 for s in sizes]                    # keep every tensor 16-byte aligned...
-        self._merge_groups = [["rpn.head.cls_logits.weight", "rpn.head.bbox_pred.weight"], ["rpn.head.cls_logits.bias", "rpn.head.bbox_pred.bias"],
-                              ["roi_heads.box_predictor.cls_score.weight", "roi_heads.box_predictor.bbox_pred.weight"],
-                              ["roi_heads.box_predictor.cls_score.bias", "roi_heads.box_predictor.bbox_pred.bias"]]
         for grp in self._merge_groups:                     # ...except inside a merged group, which must be contiguous
             i = self.names.index(grp[0])
             assert self.names[i + 1] == grp[1], "state-dict order must keep %s adjacent" % grp
@@ -219,18 +211,10 @@ class FasterRCNNTrainer(object):
             blocks = [_Bottleneck(self, "backbone.body.%s.%d" % (name, b), stride=(2 if (b == 0 and li > 0) else 1), has_down=(b == 0),
                                   need_dx=(b > 0 or prev_trainable)) for b in range(nb)]
             self.layers.append((trainable, blocks))
-        self.lat = [_Conv(self, ["backbone.fpn.inner_blocks.%d.weight" % i], ["backbone.fpn.inner_blocks.%d.bias" % i]) for i in range(4)]
-        self.fout = [_Conv(self, ["backbone.fpn.layer_blocks.%d.weight" % i], ["backbone.fpn.layer_blocks.%d.bias" % i], pad=1) for i in range(4)]
-        self.rpn_conv = _Conv(self, ["rpn.head.conv.weight"], ["rpn.head.conv.bias"], pad=1)
-        self.rpn_head = _Conv(self, self._merge_groups[0], self._merge_groups[1], out_ld=16)
-        self.fc6 = _Conv(self, ["roi_heads.box_head.fc6.weight"], ["roi_heads.box_head.fc6.bias"], mode=2, taps=49)
-        self.fc7 = _Conv(self, ["roi_heads.box_head.fc7.weight"], ["roi_heads.box_head.fc7.bias"])
-        self.pred_ld = ops.round_up(5 * num_classes, 4)
-        self.pred = _Conv(self, self._merge_groups[2], self._merge_groups[3], out_ld=self.pred_ld)
-        assert self.pred.Cout == 5 * num_classes, "box predictor does not match num_classes"
         self._anchors = {}
         self.last = None
         self.timing = None          # set to a list to collect (section, wall-clock) marks of forward(); each mark synchronizes
+
 
     # ---- parameter plumbing ----
     def _lookup(self, name):
@@ -283,7 +267,7 @@ class FasterRCNNTrainer(object):
     def anchors(self, Hp, Wp, level_hw):
         key = (Hp, Wp)
         if key not in self._anchors:
-            self._anchors[key] = ops.anchors(Hp, Wp, level_hw, self.dev)
+            self._anchors[key] = ops.anchors(Hp, Wp, level_hw, self.dev, kind=self.ANCHOR_KIND)
         return self._anchors[key]
 
     def _sample(self, pos, neg, batch, frac):
@@ -292,14 +276,13 @@ class FasterRCNNTrainer(object):
         num_neg = min(batch - num_pos, neg.numel())
         return pos[choose_k(pos.numel(), num_pos, self.generator)], neg[choose_k(neg.numel(), num_neg, self.generator)]
 
-    def forward(self, images, targets, proposals_override=None):
-        """Training forward.  Returns the four losses as 1-element device tensors (no autograd) and keeps what backward needs."""
-        cfg, N, Ccls = self.cfg, len(images), self.C
-        marks = self.timing
-        def mark(name):
-            if marks is not None:
-                torch.cuda.synchronize(self.dev); marks.append((name, __import__("time").time()))
-        mark("start")
+    def _mark(self, name):
+        if self.timing is not None:
+            torch.cuda.synchronize(self.dev); self.timing.append((name, __import__("time").time()))
+
+    def _inputs_and_body(self, images, targets):
+        """GeneralizedRCNNTransform (normalize, resize image and boxes, pad the batch) and the ResNet body.  Returns
+        (feats C2..C5, padded size, resized image sizes, ground-truth boxes on the device, ground-truth labels on the host)."""
         self.version += 1                                  # whoever updated the parameters (any optimizer): repack the trainable layers
         u8, rem = self._prepare_images(images)
         sizes = [ops.transform_size(im.shape[0], im.shape[1], self.min_size, self.max_size) for im in u8]
@@ -312,7 +295,7 @@ class FasterRCNNTrainer(object):
             rw = torch.tensor(s[1], dtype=torch.float32) / torch.tensor(im.shape[1], dtype=torch.float32)
             gts.append(torch.stack([b[:, 0] * rw, b[:, 1] * rh, b[:, 2] * rw, b[:, 3] * rh], dim=1).to(self.dev).contiguous())
             gt_labels.append(t["labels"].detach().long().cpu().reshape(-1))
-        mark("inputs")
+        self._mark("inputs")
         x = ops.preprocess(u8, img_sizes, Hp, Wp, rem)
         x = ops.maxpool(self.stem.fwd(x, relu=True))
         feats = []
@@ -320,7 +303,63 @@ class FasterRCNNTrainer(object):
             for blk in blocks:
                 x = blk.fwd(x)
             feats.append(x)
-        mark("body")
+        self._mark("body")
+        return feats, Hp, Wp, img_sizes, gts, gt_labels
+
+    def _body_backward(self, gC):
+        """gC[li]: gradient wrt the output of body layer li + 1 coming from the FPN laterals (None where there is none)."""
+        g = None
+        for li in (3, 2, 1, 0):
+            trainable, blocks = self.layers[li]
+            if not trainable:
+                break
+            if gC[li] is not None:
+                g = gC[li] if g is None else ops.add(gC[li], g)
+            for blk in reversed(blocks):
+                g = blk.bwd(g)
+
+    def body_relu_decisions(self):
+        out = {}
+        nchw = lambda t: (t > 0).permute(0, 3, 1, 2).cpu()
+        for li, (trainable, blocks) in enumerate(self.layers):
+            for b, blk in enumerate(blocks):
+                if trainable:
+                    out.update({"layer%d.%d.a1" % (li + 1, b): nchw(blk.a1), "layer%d.%d.a2" % (li + 1, b): nchw(blk.a2), "layer%d.%d.out" % (li + 1, b): nchw(blk.out)})
+        return out
+
+
+class FasterRCNNTrainer(_TrainerBase):
+    """The trainable mirror of detection/frcnn_la.py FRCNN_Feature (ResNet-50/101 FPN Faster R-CNN) on one MI355X."""
+    LOSS_NAMES = ("loss_classifier", "loss_box_reg", "loss_objectness", "loss_rpn_box_reg")
+    MERGE_GROUPS = (("rpn.head.cls_logits.weight", "rpn.head.bbox_pred.weight"), ("rpn.head.cls_logits.bias", "rpn.head.bbox_pred.bias"),
+                    ("roi_heads.box_predictor.cls_score.weight", "roi_heads.box_predictor.bbox_pred.weight"),
+                    ("roi_heads.box_predictor.cls_score.bias", "roi_heads.box_predictor.bbox_pred.bias"))
+    ANCHOR_KIND = 0
+
+    def __init__(self, state_dict, num_classes, depth=50, min_size=600, max_size=1000, device="cuda", trainable_layers=3,
+                 rpn_pre_nms_top_n=2000, rpn_post_nms_top_n=2000, rpn_nms_thresh=0.7, rpn_fg_iou=0.7, rpn_bg_iou=0.3,
+                 rpn_batch=256, rpn_pos_fraction=0.5, box_fg_iou=0.5, box_bg_iou=0.5, box_batch=512, box_pos_fraction=0.25,
+                 bbox_reg_weights=(10.0, 10.0, 5.0, 5.0), generator=None):
+        self._init_common(state_dict, num_classes, depth, min_size, max_size, device, trainable_layers, generator)
+        self.cfg = dict(pre_n=rpn_pre_nms_top_n, post_n=rpn_post_nms_top_n, nms=rpn_nms_thresh, rpn_fg=rpn_fg_iou, rpn_bg=rpn_bg_iou,
+                        rpn_batch=rpn_batch, rpn_pos=rpn_pos_fraction, box_fg=box_fg_iou, box_bg=box_bg_iou, box_batch=box_batch,
+                        box_pos=box_pos_fraction, w=tuple(bbox_reg_weights))
+        self.lat = [_Conv(self, ["backbone.fpn.inner_blocks.%d.weight" % i], ["backbone.fpn.inner_blocks.%d.bias" % i]) for i in range(4)]
+        self.fout = [_Conv(self, ["backbone.fpn.layer_blocks.%d.weight" % i], ["backbone.fpn.layer_blocks.%d.bias" % i], pad=1) for i in range(4)]
+        self.rpn_conv = _Conv(self, ["rpn.head.conv.weight"], ["rpn.head.conv.bias"], pad=1)
+        self.rpn_head = _Conv(self, self._merge_groups[0], self._merge_groups[1], out_ld=16)
+        self.fc6 = _Conv(self, ["roi_heads.box_head.fc6.weight"], ["roi_heads.box_head.fc6.bias"], mode=2, taps=49)
+        self.fc7 = _Conv(self, ["roi_heads.box_head.fc7.weight"], ["roi_heads.box_head.fc7.bias"])
+        self.pred_ld = ops.round_up(5 * num_classes, 4)
+        self.pred = _Conv(self, self._merge_groups[2], self._merge_groups[3], out_ld=self.pred_ld)
+        assert self.pred.Cout == 5 * num_classes, "box predictor does not match num_classes"
+
+    def forward(self, images, targets, proposals_override=None):
+        """Training forward.  Returns the four losses as 1-element device tensors (no autograd) and keeps what backward needs."""
+        cfg, N, Ccls = self.cfg, len(images), self.C
+        mark = self._mark
+        mark("start")
+        feats, Hp, Wp, img_sizes, gts, gt_labels = self._inputs_and_body(images, targets)
         # FPN (top-down), LastLevelMaxPool
         inner = [None] * 4
         inner[3] = self.lat[3].fwd(feats[3])
@@ -446,12 +485,8 @@ class FasterRCNNTrainer(object):
     def relu_decisions(self):
         """{name: bool NCHW / [R, C] CPU tensor}: which side every ReLU of the last forward's differentiated part took (for
         gradient checks against a higher-precision restatement, which must take the same branches)."""
-        L, out = self.last, {}
+        L, out = self.last, self.body_relu_decisions()
         nchw = lambda t: (t > 0).permute(0, 3, 1, 2).cpu()
-        for li, (trainable, blocks) in enumerate(self.layers):
-            for b, blk in enumerate(blocks):
-                if trainable:
-                    out.update({"layer%d.%d.a1" % (li + 1, b): nchw(blk.a1), "layer%d.%d.a2" % (li + 1, b): nchw(blk.a2), "layer%d.%d.out" % (li + 1, b): nchw(blk.out)})
         for i, t in enumerate(L["tl"]):
             out["rpn.%d" % i] = nchw(t)
         out["fc6"] = (L["f6"] > 0).view(L["R"], -1).cpu(); out["fc7"] = (L["f7"] > 0).view(L["R"], -1).cpu()
@@ -497,15 +532,152 @@ class FasterRCNNTrainer(object):
         for i in range(4):
             need = self.layers[i][0]                                                       # the body layer producing feats[i] is trainable
             gC[i] = self.lat[i].bwd(ginner[i], need_dx=need)
-        # body
-        g = None
-        for li in (3, 2, 1, 0):
-            trainable, blocks = self.layers[li]
-            if not trainable:
-                break
-            g = gC[li] if g is None else ops.add(gC[li], g)
-            for blk in reversed(blocks):
-                g = blk.bwd(g)
+        self._body_backward(gC)
+        return self.grads
+
+
+class RetinaNetTrainer(_TrainerBase):
+    """The trainable mirror of detection/retinanet_cal.py RetinaNet (ResNet-50 FPN, P3-P7, 9 anchors per location): training forward
+    :545-564, matcher :389-400 (IoU 0.5 / 0.4, low-quality matches), classification loss :100-133 (sigmoid focal loss, sum over the
+    anchors outside the ignore band / max(1, #foreground), mean over images), regression loss :185-221 (L1 on the foreground
+    anchors / max(1, #foreground), mean over images).  As in the reference, every image must carry at least one box."""
+    LOSS_NAMES = ("classification", "bbox_regression")
+    ANCHOR_KIND = 1
+
+    def __init__(self, state_dict, num_classes, depth=50, min_size=600, max_size=1000, device="cuda", trainable_layers=3,
+                 fg_iou_thresh=0.5, bg_iou_thresh=0.4, generator=None):
+        self._init_common(state_dict, num_classes, depth, min_size, max_size, device, trainable_layers, generator)
+        self.cfg = dict(fg=fg_iou_thresh, bg=bg_iou_thresh)
+        cin = [None, 0, 1, 2]                                    # body layer index -> FPN block index (returned_layers = [2, 3, 4])
+        self.lat = [_Conv(self, ["backbone.fpn.inner_blocks.%d.weight" % i], ["backbone.fpn.inner_blocks.%d.bias" % i]) for i in range(3)]
+        self.fout = [_Conv(self, ["backbone.fpn.layer_blocks.%d.weight" % i], ["backbone.fpn.layer_blocks.%d.bias" % i], pad=1) for i in range(3)]
+        self.p6 = _Conv(self, ["backbone.fpn.extra_blocks.p6.weight"], ["backbone.fpn.extra_blocks.p6.bias"], stride=2, pad=1)
+        self.p7 = _Conv(self, ["backbone.fpn.extra_blocks.p7.weight"], ["backbone.fpn.extra_blocks.p7.bias"], stride=2, pad=1)
+        tower = lambda head: [_Conv(self, ["head.%s.conv.%d.weight" % (head, 2 * j)], ["head.%s.conv.%d.bias" % (head, 2 * j)], pad=1) for j in range(4)]
+        self.cls_tower, self.reg_tower = tower("classification_head"), tower("regression_head")
+        self.K = num_classes
+        self.cls_ld = ops.round_up(9 * num_classes, 4)
+        self.cls_out = _Conv(self, ["head.classification_head.cls_logits.weight"], ["head.classification_head.cls_logits.bias"], pad=1, out_ld=self.cls_ld)
+        self.reg_out = _Conv(self, ["head.regression_head.bbox_reg.weight"], ["head.regression_head.bbox_reg.bias"], pad=1)
+        assert self.cls_out.Cout == 9 * num_classes and self.reg_out.Cout == 36, "RetinaNet heads must have 9 * num_classes / 36 outputs"
+
+    def forward(self, images, targets):
+        N, K, mark = len(images), self.K, self._mark
+        mark("start")
+        feats, Hp, Wp, img_sizes, gts, gt_labels = self._inputs_and_body(images, targets)
+        if any(g.shape[0] == 0 for g in gts):
+            raise ValueError("RetinaNet training needs at least one ground-truth box per image (retinanet_cal.py:110-124)")
+        inner = [None] * 3
+        inner[2] = self.lat[2].fwd(feats[3])
+        for i in (1, 0):
+            inner[i] = self.lat[i].fwd(feats[i + 1], up=inner[i + 1])
+        P = [self.fout[i].fwd(inner[i]) for i in range(3)]
+        P.append(self.p6.fwd(P[2]))
+        p6_relu = ops.relu_bwd_(ops.add(P[3]), P[3])                       # relu(p6): x * (x > 0) on a copy
+        P.append(self.p7.fwd(p6_relu))
+        level_hw = [(p.shape[1], p.shape[2]) for p in P]
+        level_pix = [h * w for h, w in level_hw]
+        # head outputs of the five levels in ONE buffer each (level block l = [N][pix_l][ld])
+        cls_sizes, reg_sizes = [N * n * self.cls_ld for n in level_pix], [N * n * 36 for n in level_pix]
+        cls_flat = torch.zeros(sum(cls_sizes), dtype=torch.float32, device=self.dev)
+        reg_flat = torch.empty(sum(reg_sizes), dtype=torch.float32, device=self.dev)
+        acts = {"cls": [], "reg": []}
+        oc = orr = 0
+        for l, (h, w) in enumerate(level_hw):
+            for name, tower, out_conv in (("cls", self.cls_tower, self.cls_out), ("reg", self.reg_tower, self.reg_out)):
+                xs = [P[l]]
+                for cv in tower:
+                    xs.append(ops.conv(xs[-1], cv._packed(), pad=1, relu=True))
+                acts[name].append(xs)
+                if name == "cls":
+                    ops.conv(xs[-1], out_conv._packed(), pad=1, out=cls_flat[oc:oc + cls_sizes[l]].view(N, h, w, self.cls_ld), out_ld=self.cls_ld)
+                else:
+                    ops.conv(xs[-1], out_conv._packed(), pad=1, out=reg_flat[orr:orr + reg_sizes[l]].view(N, h, w, 36), out_ld=36)
+            oc += cls_sizes[l]; orr += reg_sizes[l]
+        mark("fpn+heads")
+        anchors = self.anchors(Hp, Wp, level_hw)
+        A_tot = anchors.shape[0]
+        matched_dev = torch.empty((N, A_tot), dtype=torch.int32, device=self.dev)
+        for i in range(N):
+            ops.match(anchors, gts[i], self.cfg["fg"], self.cfg["bg"], True, out=matched_dev[i])
+        matched_all = matched_dev.cpu().numpy()
+        n_gt = [int(g.shape[0]) for g in gts]
+        gt_off = np.cumsum([0] + n_gt)
+        gts_all = torch.cat(gts)
+        lvl_start = np.cumsum([0] + [n * 9 for n in level_pix])
+        reg_off = np.cumsum([0] + reg_sizes)
+        lvl_pix = np.array(level_pix)
+        box_idx, anc_idx, gt_idx, wts, nfg = [], [], [], [], []
+        for i in range(N):
+            m = matched_all[i]
+            fg = np.flatnonzero(m >= 0)
+            l = np.searchsorted(lvl_start, fg, side="right") - 1
+            rel = fg - lvl_start[l]
+            pix, a = rel // 9, rel % 9
+            box_idx.append(reg_off[l] + (i * lvl_pix[l] + pix) * 36 + 4 * a)
+            anc_idx.append(fg); gt_idx.append(gt_off[i] + m[fg])
+            nfg.append(len(fg)); wts.append(np.full(len(fg), 1.0 / (max(1, len(fg)) * N), np.float32))
+        box_idx, anc_idx, gt_idx = [np.concatenate(v).astype(np.int64) for v in (box_idx, anc_idx, gt_idx)]
+        packed = torch.from_numpy(np.concatenate([box_idx, anc_idx, gt_idx])).to(self.dev)
+        nb = len(box_idx)
+        box_idx, anc_sel, gt_sel = packed[:nb], packed[nb:2 * nb], packed[2 * nb:]
+        fl = torch.from_numpy(np.concatenate([np.concatenate(wts), np.array([1.0 / (max(1, n) * N) for n in nfg], np.float32)])).to(self.dev)
+        box_w, img_w = fl[:nb], fl[nb:]
+        reg_tgt = ops.box_encode(gts_all[gt_sel], anchors[anc_sel], (1.0, 1.0, 1.0, 1.0))
+        gt_labels_dev = torch.cat(gt_labels).to(self.dev)
+        gt_off_dev = torch.from_numpy(gt_off.astype(np.int32)).to(self.dev)
+        mark("targets")
+        self.last = dict(N=N, P=P, p6_relu=p6_relu, feats=feats, inner=inner, acts=acts, level_hw=level_hw, level_pix=level_pix, cls_flat=cls_flat, reg_flat=reg_flat,
+                         cls_sizes=cls_sizes, reg_sizes=reg_sizes, matched=matched_dev, gt_labels=gt_labels_dev, gt_off=gt_off_dev, img_w=img_w, box_idx=box_idx,
+                         box_w=box_w, reg_tgt=reg_tgt, matched_host=matched_all)
+        losses = {"classification": ops.focal_loss(cls_flat, level_pix, N, 9, K, self.cls_ld, matched_dev, gt_labels_dev, gt_off_dev, img_w),
+                  "bbox_regression": ops.smooth_l1(reg_flat, box_idx, reg_tgt, 0.0, 1.0, weights=box_w)}
+        mark("losses")
+        return losses
+
+    def relu_decisions(self):
+        L, out = self.last, self.body_relu_decisions()
+        nchw = lambda t: (t > 0).permute(0, 3, 1, 2).cpu()
+        for name in ("cls", "reg"):
+            for l, xs in enumerate(L["acts"][name]):
+                for j in range(4):
+                    out["%s.%d.%d" % (name, l, j)] = nchw(xs[j + 1])
+        out["p6"] = nchw(L["P"][3])
+        return out
+
+    def backward(self, gscale=(1.0, 1.0)):
+        L = self.last
+        N, P, level_hw = L["N"], L["P"], L["level_hw"]
+        gcls = torch.zeros_like(L["cls_flat"]); greg = torch.zeros_like(L["reg_flat"])
+        ops.focal_loss(L["cls_flat"], L["level_pix"], N, 9, self.K, self.cls_ld, L["matched"], L["gt_labels"], L["gt_off"], L["img_w"], grad=gcls, gscale=gscale[0])
+        ops.smooth_l1(L["reg_flat"], L["box_idx"], L["reg_tgt"], 0.0, 1.0, weights=L["box_w"], grad=greg, gscale=gscale[1])
+        gP = [None] * 5
+        oc = orr = 0
+        for l, (h, w) in enumerate(level_hw):
+            for name, tower, out_conv in (("cls", self.cls_tower, self.cls_out), ("reg", self.reg_tower, self.reg_out)):
+                xs = L["acts"][name][l]
+                if name == "cls":
+                    g = out_conv.bwd(gcls[oc:oc + L["cls_sizes"][l]].view(N, h, w, self.cls_ld), accumulate=l > 0, x=xs[4])
+                else:
+                    g = out_conv.bwd(greg[orr:orr + L["reg_sizes"][l]].view(N, h, w, 36), accumulate=l > 0, x=xs[4])
+                for j in (3, 2, 1, 0):
+                    ops.relu_bwd_(g, xs[j + 1])
+                    g = tower[j].bwd(g, accumulate=l > 0, x=xs[j], residual=(gP[l] if j == 0 else None))
+                gP[l] = g
+            oc += L["cls_sizes"][l]; orr += L["reg_sizes"][l]
+        g6 = self.p7.bwd(gP[4], x=L["p6_relu"])
+        ops.relu_bwd_(g6, P[3])
+        g6 = ops.add(g6, gP[3])
+        gP[2] = ops.add(gP[2], self.p6.bwd(g6, x=P[2]))
+        ginner = [None] * 3
+        for i in range(3):
+            ginner[i] = self.fout[i].bwd(gP[i])
+            if i > 0:
+                ops.upsample_bwd_(ginner[i - 1], ginner[i])
+        gC = [None] * 4
+        for i in range(3):
+            gC[i + 1] = self.lat[i].bwd(ginner[i], need_dx=self.layers[i + 1][0])
+        self._body_backward(gC)
         return self.grads
 
 
@@ -516,7 +688,7 @@ class _LossFn(torch.autograd.Function):
     def forward(ctx, anchor, net, images, targets):
         ctx.net = net
         d = net.forward(images, targets)
-        return tuple(d[k].reshape(()) for k in ("loss_classifier", "loss_box_reg", "loss_objectness", "loss_rpn_box_reg"))
+        return tuple(d[k].reshape(()) for k in net.LOSS_NAMES)
 
     @staticmethod
     def backward(ctx, *gs):
@@ -532,7 +704,7 @@ class _LossFn(torch.autograd.Function):
         return None, None, None, None
 
 
-class TrainableFasterRCNN(object):
+class TrainableDetector(object):
     """``task_model`` in train mode: ``model(images, targets) -> {loss name: scalar tensor}`` whose sum can be ``.backward()``-ed."""
 
     def __init__(self, net):
@@ -545,7 +717,7 @@ class TrainableFasterRCNN(object):
 
     def __call__(self, images, targets):
         out = _LossFn.apply(self._anchor, self.net, images, targets)
-        return dict(zip(("loss_classifier", "loss_box_reg", "loss_objectness", "loss_rpn_box_reg"), out))
+        return dict(zip(self.net.LOSS_NAMES, out))
 
 
 class SGD(torch.optim.Optimizer):
@@ -569,3 +741,6 @@ class SGD(torch.optim.Optimizer):
                 ops.sgd_(p.data, p.grad, st.get("momentum_buffer"), grp["lr"], grp["momentum"], grp["weight_decay"], first)
         if self.net is not None:
             self.net.parameters_changed()
+
+
+TrainableFasterRCNN = TrainableDetector

@@ -154,10 +154,11 @@ def rpn_proposals(heads, Hp, Wp, image_sizes, pre_n=2000, post_n=2000, nms_thr=0
     return props, counts
 
 
-def anchors(Hp, Wp, level_hw, device):
-    n = sum(h * w * 3 for h, w in level_hw)
+def anchors(Hp, Wp, level_hw, device, kind=0):
+    """kind 0: Faster R-CNN (3 per location), 1: RetinaNet (9 per location)."""
+    n = sum(h * w * (9 if kind else 3) for h, w in level_hw)
     out = torch.empty((n, 4), dtype=torch.float32, device=device)
-    _ffi.check(_ffi.lib().cald_train_anchors(get_ctx(device.index), Hp, Wp, _int_array([v for s in level_hw for v in s]), _p(out)))
+    _ffi.check(_ffi.lib().cald_train_anchors(get_ctx(device.index), kind, Hp, Wp, _int_array([v for s in level_hw for v in s]), _p(out)))
     return out
 
 
@@ -201,10 +202,17 @@ def softmax_ce(logits, labels, Ccls, grad=None, gscale=1.0):
     return loss
 
 
-def smooth_l1(pred, idx, target, beta, denom, grad=None, gscale=1.0):
+def smooth_l1(pred, idx, target, beta, denom, grad=None, gscale=1.0, weights=None):
     loss = torch.empty(1, dtype=torch.float32, device=pred.device)
-    _ffi.check(_ffi.lib().cald_train_smooth_l1(get_ctx(pred.device.index), idx.numel(), _p(pred), _p(idx), _p(target), beta, float(denom), gscale, _p(loss),
-                                               _p(grad)))
+    _ffi.check(_ffi.lib().cald_train_smooth_l1(get_ctx(pred.device.index), idx.numel(), _p(pred), _p(idx), _p(target), beta, float(denom), _p(weights),
+                                               gscale, _p(loss), _p(grad)))
+    return loss
+
+
+def focal_loss(logits_flat, level_pix, N, A, K, ld, matched, gt_labels, gt_off, img_weight, grad=None, gscale=1.0, alpha=0.25):
+    loss = torch.empty(1, dtype=torch.float32, device=logits_flat.device)
+    _ffi.check(_ffi.lib().cald_train_focal_loss(get_ctx(logits_flat.device.index), N, _int_array(level_pix), A, K, ld, _p(logits_flat), _p(matched),
+                                                _p(gt_labels), _p(gt_off), _p(img_weight), alpha, gscale, _p(loss), _p(grad)))
     return loss
 
 

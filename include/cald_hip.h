@@ -256,8 +256,9 @@ int cald_train_upsample_bwd(cald_ctx* ctx, int N, int Hf, int Wf, int Hc, int Wc
 int cald_train_rpn_proposals(cald_ctx* ctx, int N, int Hp, int Wp, const int* image_sizes, const float* const* heads,
                              const int* level_hw, int head_ld, int pre_n, int post_n, float nms_thr, float min_size,
                              float* proposals_out, int* counts_out);
-/* AnchorGenerator: all anchors of one padded image, order (level, y, x, anchor): anchors_out [sum Hl*Wl*3][4] */
-int cald_train_anchors(cald_ctx* ctx, int Hp, int Wp, const int* level_hw, float* anchors_out);
+/* AnchorGenerator: all anchors of one padded image over five levels, order (level, y, x, anchor): anchors_out [sum Hl*Wl*A][4].
+ * kind 0 = Faster R-CNN (A = 3, frcnn_la.py:185-187), kind 1 = RetinaNet (A = 9, retinanet_cal.py:346-351) */
+int cald_train_anchors(cald_ctx* ctx, int kind, int Hp, int Wp, const int* level_hw, float* anchors_out);
 /* det_utils.Matcher: matched_out[i] = index of the best ground-truth box (torchvision.ops.box_iou), -1 if its IoU < lo, -2 if
  * lo <= IoU < hi; allow_low_quality restores every box that is some ground truth's best.  best_iou_out may be null. */
 int cald_train_match(cald_ctx* ctx, int n_boxes, const float* boxes, int n_gt, const float* gt, float hi, float lo,
@@ -273,10 +274,17 @@ int cald_train_roi_align_bwd(cald_ctx* ctx, float* const* gfeats, const int* lev
 /* F.cross_entropy over R rows of stride ld (mean); grad_out (same layout, may be null) = gscale * d loss / d logits */
 int cald_train_softmax_ce(cald_ctx* ctx, int R, int C, int ld, const float* logits, const int64_t* labels, float gscale,
                           float* loss_out, float* grad_out);
-/* det_utils.smooth_l1_loss(size_average=False) / denom over n 4-vectors starting at float offsets idx[i] of pred; grad (zeroed by
- * the caller, same offsets) may be null */
+/* det_utils.smooth_l1_loss(size_average=False) / denom over n 4-vectors starting at float offsets idx[i] of pred; beta = 0 is the L1
+ * loss; weights (one per 4-vector, or null) scale each term; grad (zeroed by the caller, same offsets) may be null */
 int cald_train_smooth_l1(cald_ctx* ctx, int n, const float* pred, const int64_t* idx, const float* target, float beta, float denom,
-                         float gscale, float* loss_out, float* grad);
+                         const float* weights, float gscale, float* loss_out, float* grad);
+/* RetinaNet classification loss (retinanet_cal.py:100-133): sigmoid focal loss (gamma 2) summed over the anchors not between the
+ * matcher thresholds, weighted per image by img_weight[n] = 1 / (max(1, #foreground) * N).  logits / grad: five level blocks
+ * [N][level_pix[l]][ld] back to back, channel a * K + k; matched [N][sum level_pix * A] (cald_train_match values);
+ * gt_labels[gt_off[n] + m] = class index (0-based logit column) of image n's ground-truth box m. */
+int cald_train_focal_loss(cald_ctx* ctx, int N, const int* level_pix, int A, int K, int ld, const float* logits, const int* matched,
+                          const int64_t* gt_labels, const int* gt_off, const float* img_weight, float alpha, float gscale,
+                          float* loss_out, float* grad);
 /* F.binary_cross_entropy_with_logits over n logits at float offsets idx[i] (mean) */
 int cald_train_bce_logits(cald_ctx* ctx, int n, const float* logits, const int64_t* idx, const float* labels, float gscale,
                           float* loss_out, float* grad);

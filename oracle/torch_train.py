@@ -134,7 +134,7 @@ class TorchTrainFRCNN(object):
         shift = p[prefix + ".bias"] - p[prefix + ".running_mean"] * scale
         return x * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
 
-    def backbone(self, x):
+    def body(self, x):
         p = self.p
         x = F.relu(self._bn(F.conv2d(x, p["backbone.body.conv1.weight"], stride=2, padding=3), "backbone.body.bn1"))
         x = F.max_pool2d(x, 3, 2, 1)
@@ -152,6 +152,11 @@ class TorchTrainFRCNN(object):
                     idt = self._bn(F.conv2d(x, p[pre + ".downsample.0.weight"], stride=s), pre + ".downsample.1")
                 x = self.relu(o + idt, key + ".out")
             feats.append(x)
+        return feats
+
+    def backbone(self, x):
+        p = self.p
+        feats = self.body(x)
         inner = [None] * 4
         inner[3] = F.conv2d(feats[3], p["backbone.fpn.inner_blocks.3.weight"], p["backbone.fpn.inner_blocks.3.bias"])
         for i in (2, 1, 0):
@@ -160,6 +165,23 @@ class TorchTrainFRCNN(object):
         P = [F.conv2d(inner[i], p["backbone.fpn.layer_blocks.%d.weight" % i], p["backbone.fpn.layer_blocks.%d.bias" % i], padding=1) for i in range(4)]
         P.append(F.max_pool2d(P[3], 1, 2, 0))
         return P
+
+    def batch(self, images, targets):
+        """GeneralizedRCNNTransform: normalized, resized, zero-padded batch (float64) and the resized ground-truth boxes (float32)."""
+        N = len(images)
+        sizes = [orc.transform_size(int(im.shape[1]), int(im.shape[2]), self.min_size, self.max_size) for im in images]
+        Hp, Wp = max(s[2] for s in sizes), max(s[3] for s in sizes)
+        batch = torch.zeros(N, 3, Hp, Wp, dtype=torch.float64)
+        gts = []
+        for i, (im, s, t) in enumerate(zip(images, sizes, targets)):
+            x = (im.double() - MEAN) / STD
+            x = F.interpolate(x[None], size=(s[0], s[1]), mode="bilinear", align_corners=False)[0]
+            batch[i, :, :s[0], :s[1]] = x
+            b = t["boxes"].float().reshape(-1, 4)
+            rh = torch.tensor(s[0], dtype=torch.float32) / torch.tensor(im.shape[1], dtype=torch.float32)
+            rw = torch.tensor(s[1], dtype=torch.float32) / torch.tensor(im.shape[2], dtype=torch.float32)
+            gts.append(torch.stack([b[:, 0] * rw, b[:, 1] * rh, b[:, 2] * rw, b[:, 3] * rh], dim=1))
+        return batch, gts, Hp, Wp
 
     def losses(self, images, targets, proposals, gen, cfg=None, samples=None):
         """images: list of float CHW in [0, 1]; targets: dicts with boxes (original image coordinates) / labels; proposals: list
@@ -179,18 +201,7 @@ class TorchTrainFRCNN(object):
         cfg = dict(dict(rpn_fg=0.7, rpn_bg=0.3, rpn_batch=256, rpn_pos=0.5, box_fg=0.5, box_bg=0.5, box_batch=512, box_pos=0.25, w=(10.0, 10.0, 5.0, 5.0)),
                    **(cfg or {}))
         p, N = self.p, len(images)
-        sizes = [orc.transform_size(int(im.shape[1]), int(im.shape[2]), self.min_size, self.max_size) for im in images]
-        Hp, Wp = max(s[2] for s in sizes), max(s[3] for s in sizes)
-        batch = torch.zeros(N, 3, Hp, Wp, dtype=torch.float64)
-        gts = []
-        for i, (im, s, t) in enumerate(zip(images, sizes, targets)):
-            x = (im.double() - MEAN) / STD
-            x = F.interpolate(x[None], size=(s[0], s[1]), mode="bilinear", align_corners=False)[0]
-            batch[i, :, :s[0], :s[1]] = x
-            b = t["boxes"].float().reshape(-1, 4)
-            rh = torch.tensor(s[0], dtype=torch.float32) / torch.tensor(im.shape[1], dtype=torch.float32)
-            rw = torch.tensor(s[1], dtype=torch.float32) / torch.tensor(im.shape[2], dtype=torch.float32)
-            gts.append(torch.stack([b[:, 0] * rw, b[:, 1] * rh, b[:, 2] * rw, b[:, 3] * rh], dim=1))
+        batch, gts, Hp, Wp = self.batch(images, targets)
         P = self.backbone(batch)
         # RPN head, flattened in torchvision's order (image, level, y, x, anchor)
         obj, deltas = [], []
@@ -259,3 +270,65 @@ class TorchTrainFRCNN(object):
         loss_box = smooth_l1_sum(breg.reshape(len(r_lab), -1, 4)[posr, r_lab[posr]], r_tgt[posr], 1.0 / 9) / r_lab.numel()
         rec.update(roi_img=r_img, roi_box=r_box, roi_labels=r_lab, P=P, logits=logits)
         return {"loss_classifier": loss_cls, "loss_box_reg": loss_box, "loss_objectness": loss_obj, "loss_rpn_box_reg": loss_rpn_box}, rec
+
+
+def sigmoid_focal_loss_sum(x, t, alpha=0.25, gamma=2.0):
+    """torchvision.ops.sigmoid_focal_loss(reduction='sum')."""
+    p = torch.sigmoid(x)
+    ce = F.binary_cross_entropy_with_logits(x, t, reduction="none")
+    p_t = p * t + (1 - p) * (1 - t)
+    loss = ce * (1 - p_t) ** gamma
+    return ((alpha * t + (1 - alpha) * (1 - t)) * loss).sum()
+
+
+class TorchTrainRetinaNet(TorchTrainFRCNN):
+    """detection/retinanet_cal.py RetinaNet in training mode (forward :545-564, compute_loss :389-400, head losses :100-133 and
+    :185-221), float64 torch autograd.  The loss code is the reference's own (in-repo); backbone / anchors / matcher are torchvision's."""
+
+    def losses(self, images, targets, cfg=None):
+        p, N, K = self.p, len(images), self.C
+        batch, gts, Hp, Wp = self.batch(images, targets)
+        feats = self.body(batch)
+        inner = [None] * 3
+        inner[2] = F.conv2d(feats[3], p["backbone.fpn.inner_blocks.2.weight"], p["backbone.fpn.inner_blocks.2.bias"])
+        for i in (1, 0):
+            lat = F.conv2d(feats[i + 1], p["backbone.fpn.inner_blocks.%d.weight" % i], p["backbone.fpn.inner_blocks.%d.bias" % i])
+            inner[i] = lat + F.interpolate(inner[i + 1], size=lat.shape[-2:], mode="nearest")
+        P = [F.conv2d(inner[i], p["backbone.fpn.layer_blocks.%d.weight" % i], p["backbone.fpn.layer_blocks.%d.bias" % i], padding=1) for i in range(3)]
+        p6 = F.conv2d(P[2], p["backbone.fpn.extra_blocks.p6.weight"], p["backbone.fpn.extra_blocks.p6.bias"], stride=2, padding=1)
+        p7 = F.conv2d(self.relu(p6, "p6"), p["backbone.fpn.extra_blocks.p7.weight"], p["backbone.fpn.extra_blocks.p7.bias"], stride=2, padding=1)
+        P += [p6, p7]
+        cls, reg = [], []
+        for l, f in enumerate(P):
+            for name, head, outs, last in (("cls", "classification_head", cls, "cls_logits"), ("reg", "regression_head", reg, "bbox_reg")):
+                t = f
+                for j in range(4):
+                    t = self.relu(F.conv2d(t, p["head.%s.conv.%d.weight" % (head, 2 * j)], p["head.%s.conv.%d.bias" % (head, 2 * j)], padding=1), "%s.%d.%d" % (name, l, j))
+                o = F.conv2d(t, p["head.%s.%s.weight" % (head, last)], p["head.%s.%s.bias" % (head, last)], padding=1)
+                Nn, _, H, W = o.shape
+                c = K if name == "cls" else 4
+                outs.append(o.view(Nn, -1, c, H, W).permute(0, 3, 4, 1, 2).reshape(Nn, -1, c))
+        cls, reg = torch.cat(cls, dim=1), torch.cat(reg, dim=1)
+        anchors = []
+        for l, f in enumerate(P):
+            Hl, Wl = f.shape[-2:]
+            x = 32 * 2 ** l
+            base = torch.from_numpy(orc.base_anchors([float(x), float(int(x * 2 ** (1.0 / 3))), float(int(x * 2 ** (2.0 / 3)))], [0.5, 1.0, 2.0])).float().reshape(-1, 4)
+            ys, xs = torch.meshgrid(torch.arange(Hl) * (Hp // Hl), torch.arange(Wl) * (Wp // Wl), indexing="ij")
+            anchors.append((torch.stack([xs, ys, xs, ys], dim=-1).reshape(-1, 1, 4).float() + base[None]).reshape(-1, 4))
+        anchors = torch.cat(anchors)
+        cfg = dict(dict(fg=0.5, bg=0.4), **(cfg or {}))
+        lc, lr, matched = [], [], []
+        for i in range(N):
+            m = matcher(box_iou(gts[i], anchors), cfg["fg"], cfg["bg"], True)
+            matched.append(m)
+            fg = m >= 0
+            nfg = max(1, int(fg.sum()))
+            tgt = torch.zeros_like(cls[i])
+            tgt[fg, targets[i]["labels"].long()[m[fg]]] = 1.0
+            valid = m != -2
+            lc.append(sigmoid_focal_loss_sum(cls[i][valid], tgt[valid]) / nfg)
+            t_reg = encode(gts[i][m.clamp(min=0)][fg].double(), anchors[fg].double(), (1.0, 1.0, 1.0, 1.0))
+            lr.append((reg[i][fg] - t_reg).abs().sum() / nfg)
+        rec = dict(anchors=anchors, matched=torch.stack(matched))
+        return {"classification": sum(lc) / N, "bbox_regression": sum(lr) / max(1, N)}, rec

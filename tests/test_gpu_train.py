@@ -429,3 +429,92 @@ def test_training_batch_with_an_image_without_boxes_and_resnet101(T):
     g101 = net101.backward()
     assert len(g101) == 72 + 17 * 3 and all(bool(torch.isfinite(g).all()) for g in g101.values()) and all(bool(torch.isfinite(v).all()) for v in l101.values())
     assert float(g101["backbone.body.layer3.22.conv2.weight"].abs().max()) > 0
+
+
+def test_focal_and_l1_losses_value_and_gradient(T, oracle):
+    """RetinaNet's classification loss (sigmoid focal loss summed over the anchors outside the ignore band, / max(1, #fg) per image,
+    mean over images) and its L1 box loss, value + gradient, against the float64 formulas of torchvision.ops.sigmoid_focal_loss."""
+    torch, ops = T
+    from oracle import torch_train as tt
+    g = torch.Generator().manual_seed(8)
+    N, A, K, ld = 2, 9, 7, 64
+    level_pix = [20, 12, 6, 2, 1]
+    A_tot = sum(level_pix) * A
+    blocks = [torch.randn(N, n, ld, generator=g) * 2 for n in level_pix]
+    flat = torch.cat([b.reshape(-1) for b in blocks])
+    matched = torch.randint(-2, 3, (N, A_tot), generator=g, dtype=torch.int32)
+    gt_labels = torch.tensor([1, 4, 6, 2, 3, 5], dtype=torch.int64); gt_off = torch.tensor([0, 3, 6], dtype=torch.int32)
+    nfg = [(matched[i] >= 0).sum().item() for i in range(N)]
+    img_w = torch.tensor([1.0 / (max(1, n) * N) for n in nfg])
+    fd = flat.double().requires_grad_()
+    want = 0.0
+    for i in range(N):
+        logits = []
+        o = 0
+        for n in level_pix:
+            blk = fd[o:o + N * n * ld].view(N, n, ld)[i, :, :A * K].reshape(n * A, K); o += N * n * ld
+            logits.append(blk)
+        logits = torch.cat(logits)
+        tgt = torch.zeros_like(logits)
+        fg = matched[i] >= 0
+        tgt[fg, gt_labels[gt_off[i] + matched[i][fg].long()]] = 1.0
+        valid = matched[i] != -2
+        want = want + tt.sigmoid_focal_loss_sum(logits[valid], tgt[valid]) / max(1, nfg[i]) / N
+    (1.7 * want).backward()
+    grad = torch.zeros_like(flat, device="cuda")
+    got = ops.focal_loss(flat.cuda(), level_pix, N, A, K, ld, matched.cuda(), gt_labels.cuda(), gt_off.cuda(), img_w.cuda(), grad=grad, gscale=1.7)
+    _close(got, want.reshape(1), 2e-6, "focal loss"); _close(grad, fd.grad, 1e-5, "focal loss gradient")
+    pred = torch.randn(500, generator=g); idx = torch.arange(0, 480, 8)[:50]; tgt4 = torch.randn(50, 4, generator=g); w = torch.rand(50, generator=g)
+    pd = pred.double().requires_grad_()
+    sel = torch.stack([pd[idx + j] for j in range(4)], dim=1)
+    l1 = ((sel - tgt4.double()).abs().sum(dim=1) * w.double()).sum(); l1.backward()
+    gp = torch.zeros(500, device="cuda")
+    got = ops.smooth_l1(pred.cuda(), idx.cuda(), tgt4.cuda(), 0.0, 1.0, grad=gp, weights=w.cuda())
+    _close(got, l1.reshape(1), 2e-6, "weighted L1"); _close(gp, pd.grad, 1e-6, "weighted L1 gradient")
+
+
+def test_retinanet_training_step_vs_autograd_and_drop_in(T, oracle):
+    """RetinaNet (detection/retinanet_cal.py) training step: both losses and the gradient of every trainable tensor (body layers
+    2-4, FPN, P6/P7, both towers, both output convs) against float64 autograd with the reference's own loss code restated
+    (oracle/torch_train.py TorchTrainRetinaNet), same ReLU decisions; then the drop-in loop on the HipDetector object."""
+    torch, ops = T
+    from cald_amd import synth, train, detector
+    from oracle import torch_train as tt
+    _, images, targets = _train_case(torch, seed=6)
+    sd = synth.pseudo_trained_retinanet(21, 50, seed=2)
+    net = train.RetinaNetTrainer(sd, 21, min_size=160, max_size=256)
+    losses = net.forward(images, targets)
+    grads = {k: v.clone() for k, v in net.backward().items()}
+    ref = tt.TorchTrainRetinaNet(sd, 21, min_size=160, max_size=256)
+    ref.masks = net.relu_decisions()
+    want, rec = ref.losses(images, targets)
+    assert torch.equal(rec["matched"].int(), torch.from_numpy(net.last["matched_host"])), "same anchor matching"
+    for k in want:
+        got, w = float(losses[k]), float(want[k].detach())
+        assert abs(got - w) <= 1e-4 * max(1.0, abs(w)), (k, got, w)
+    sum(want.values()).backward()
+    tr = ref.trainable()
+    assert sorted(tr) == sorted(grads) and len(grads) == 78
+    worst = ("", 0.0)
+    for k, g in grads.items():
+        w = tr[k].grad
+        err = float((g.double().cpu() - w).abs().max()) / float(w.abs().max())
+        if err > worst[1]:
+            worst = (k, err)
+    assert worst[1] <= 1e-4, "largest gradient error %.3g at %s" % (worst[1], worst[0])
+    # drop-in: the HipDetector in train mode, HIP SGD, then back to inference on the updated weights
+    model = detector.retinanet_resnet50_fpn_cal(num_classes=21, min_size=160, max_size=256).to("cuda")
+    model.load_state_dict(sd)
+    model.train()
+    opt = train.SGD([p for p in model.parameters() if p.requires_grad], lr=2e-5, momentum=0.0, weight_decay=1e-4)
+    seen = []
+    for it in range(6):
+        loss_dict = model(images, targets)
+        assert sorted(loss_dict) == ["bbox_regression", "classification"]
+        losses_sum = sum(loss for loss in loss_dict.values())
+        seen.append(float(losses_sum.detach()))
+        opt.zero_grad(); losses_sum.backward(); opt.step()
+    assert all(np.isfinite(seen)) and seen[-1] < seen[0], seen
+    model.eval()
+    out = model([images[0]])
+    assert set(out[0]) >= {"boxes", "scores", "labels"}
