@@ -17,12 +17,17 @@ import torch
 from cald_amd import synth, train
 
 
-def measure(batch=4, steps=10, warmup=3, depth=50, verbose=False):
+def measure(batch=4, steps=10, warmup=3, depth=50, verbose=False, model="frcnn"):
     from types import SimpleNamespace
     a = SimpleNamespace(batch=batch, steps=steps, warmup=warmup, depth=depth)
-    sd = synth.pseudo_trained_frcnn(21, a.depth, seed=0)
-    net = train.FasterRCNNTrainer(sd, 21, depth=a.depth, min_size=600, max_size=1000, generator=torch.Generator().manual_seed(0))
-    model = train.TrainableFasterRCNN(net)
+    if model == "retinanet":
+        sd = synth.pseudo_trained_retinanet(21, a.depth, seed=0)
+        net = train.RetinaNetTrainer(sd, 21, depth=a.depth, min_size=600, max_size=1000)
+    else:
+        sd = synth.pseudo_trained_frcnn(21, a.depth, seed=0)
+        net = train.FasterRCNNTrainer(sd, 21, depth=a.depth, min_size=600, max_size=1000, generator=torch.Generator().manual_seed(0))
+    arch = model
+    model = train.TrainableDetector(net)
     opt = train.SGD([p for p in model.parameters() if p.requires_grad], lr=1e-5, momentum=0.9, weight_decay=1e-4, net=net)
     imgs = synth.make_pool(a.batch * 2, "voc", 0)
     rs = np.random.RandomState(0)
@@ -77,17 +82,18 @@ def measure(batch=4, steps=10, warmup=3, depth=50, verbose=False):
     if verbose:
         print("forward sections (ms, synchronized):", sections, file=sys.stderr)
     return {"metric": "training step throughput (forward + backward + SGD)", "value": a.batch / dt, "unit": "images/s", "ms_per_step": dt * 1e3,
-            "batch": a.batch, "depth": a.depth, "forward_ms": p[0] * 1e3, "backward_ms": p[1] * 1e3, "sgd_ms": p[2] * 1e3,
+            "batch": a.batch, "model": arch, "depth": a.depth, "forward_ms": p[0] * 1e3, "backward_ms": p[1] * 1e3, "sgd_ms": p[2] * 1e3,
             "backward_gpu_ms": t_all * 1e3, "loss": float(last.detach()), "dtype": "f32",
-            "config": "cald_train.py defaults: batch 4, VOC-sized synthetic images, min_size 600 / max_size 1000, 2000 proposals, 512 RoIs / image, SGD momentum 0.9"}
+            "config": "cald_train.py defaults: batch 4, VOC-sized synthetic images, min_size 600 / max_size 1000, SGD momentum 0.9"
+                      + (", 2000 proposals, 512 RoIs / image" if arch == "frcnn" else ", 9 anchors / location on P3-P7")}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=4); ap.add_argument("--steps", type=int, default=10); ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--depth", type=int, default=50)
+    ap.add_argument("--depth", type=int, default=50); ap.add_argument("--model", default="frcnn", choices=["frcnn", "retinanet"])
     a = ap.parse_args()
-    print(json.dumps(measure(a.batch, a.steps, a.warmup, a.depth, verbose=True)))
+    print(json.dumps(measure(a.batch, a.steps, a.warmup, a.depth, verbose=True, model=a.model)))
 
 
 if __name__ == "__main__":
