@@ -32,6 +32,20 @@ def get_ctx(device_index=None):
     return _CTX[device_index]
 
 
+_SIDE_CTX = {}
+
+
+def get_side_ctx(device_index, stream):
+    """A second library context of the same device bound to `stream` (a torch.cuda.Stream): lets independent kernels (the weight
+    gradients of the training backward) run beside the main stream's.  The caller orders the two streams with events."""
+    key = (device_index, stream.cuda_stream)
+    if key not in _SIDE_CTX:
+        h = C.c_void_p()
+        _ffi.check(_ffi.lib().cald_ctx_create(device_index, C.c_void_p(stream.cuda_stream), C.byref(h)))
+        _SIDE_CTX[key] = h
+    return _SIDE_CTX[key]
+
+
 _U8_TABLE = {}
 
 

@@ -94,18 +94,39 @@ class _Conv(object):
             self._pkd_version = self.net.version
         return self._pkd
 
+    def _count(self, x, passes):
+        """algorithmic FLOPs of `passes` GEMM passes (forward, data gradient, weight gradient) over input x"""
+        net = self.net
+        if net.flops is not None:
+            if self.mode == 2 or self.w.dim() == 2:
+                rows, k = x.shape[2], self.w.shape[1]
+            else:
+                ho, wo = (x.shape[1] + 2 * self.pad - self.K) // self.stride + 1, (x.shape[2] + 2 * self.pad - self.K) // self.stride + 1
+                rows, k = x.shape[0] * ho * wo, (3 if self.Cin == 4 else self.Cin) * self.K * self.K
+            net.flops += 2.0 * rows * self.Cout * k * passes
+
     def fwd(self, x, relu=False, residual=None, up=None, out=None):
         if self.trainable:
             self.x = x
+        self._count(x, 1)
         return ops.conv(x, self._packed(), stride=self.stride, pad=self.pad, relu=relu, residual=residual, up=up, out=out, out_ld=self.out_ld)
 
     def bwd(self, g, need_dx=True, residual=None, accumulate=False, x=None):
         """g: gradient wrt this layer's conv output (after the caller applied ReLU mask / BN scale), row stride out_ld."""
         x = self.x if x is None else x
-        if self.mode == 2 or self.w.dim() == 2:
-            ops.linear_wgrad(x.view(g.shape[2], -1), g.view(g.shape[2], -1), self.Cout, self.gw, self.gb, taps=self.taps or 1, accumulate=accumulate)
-        else:
-            ops.conv_wgrad(x, g, self.Cin, self.Cout, self.K, self.K, self.stride, self.pad, self.gw, self.gb, accumulate=accumulate)
+        self._count(x, 2 if need_dx else 1)
+        side = self.net.side
+        if side is not None:            # the weight gradient depends on (x, g) only: issue it beside the data gradient
+            side[0].wait_stream(torch.cuda.current_stream(self.net.dev))
+            x.record_stream(side[0]); g.record_stream(side[0])
+            ops._WGRAD_CTX[0] = side[1]
+        try:
+            if self.mode == 2 or self.w.dim() == 2:
+                ops.linear_wgrad(x.view(g.shape[2], -1), g.view(g.shape[2], -1), self.Cout, self.gw, self.gb, taps=self.taps or 1, accumulate=accumulate)
+            else:
+                ops.conv_wgrad(x, g, self.Cin, self.Cout, self.K, self.K, self.stride, self.pad, self.gw, self.gb, accumulate=accumulate)
+        finally:
+            ops._WGRAD_CTX[0] = None
         if not need_dx:
             return None
         pkd = self._packed_grad()
@@ -214,6 +235,18 @@ class _TrainerBase(object):
         self._anchors = {}
         self.last = None
         self.timing = None          # set to a list to collect (section, wall-clock) marks of forward(); each mark synchronizes
+        self.flops = None           # set to 0.0 to accumulate the algorithmic GEMM FLOPs of forward() + backward()
+        # weight gradients run on a second stream: at batch 4 most layers fill a fraction of the 256 CUs, and dW / dX of one layer
+        # are independent.  CALD_TRAIN_SIDE_STREAM=0 keeps everything on one stream.
+        self.side = None
+        if __import__("os").environ.get("CALD_TRAIN_SIDE_STREAM", "1") != "0":
+            from .detector import get_side_ctx
+            st = torch.cuda.Stream(device=self.dev)
+            self.side = (st, get_side_ctx(self.dev.index if self.dev.index is not None else torch.cuda.current_device(), st))
+
+    def _join_side(self):
+        if self.side is not None:
+            torch.cuda.current_stream(self.dev).wait_stream(self.side[0])
 
 
     # ---- parameter plumbing ----
@@ -376,6 +409,7 @@ class FasterRCNNTrainer(_TrainerBase):
             t = ops.conv(P[i], self.rpn_conv._packed(), pad=1, relu=True)
             tl.append(t)
             heads.append(ops.conv(t, self.rpn_head._packed(), out=head_flat[o:o + head_sizes[i]].view(N, h, w, 16), out_ld=16))
+            self.rpn_conv._count(P[i], 1); self.rpn_head._count(t, 1)
             o += head_sizes[i]
         mark("fpn+rpn head")
         anchors = self.anchors(Hp, Wp, level_hw)
@@ -533,6 +567,7 @@ class FasterRCNNTrainer(_TrainerBase):
             need = self.layers[i][0]                                                       # the body layer producing feats[i] is trainable
             gC[i] = self.lat[i].bwd(ginner[i], need_dx=need)
         self._body_backward(gC)
+        self._join_side()
         return self.grads
 
 
@@ -587,7 +622,9 @@ class RetinaNetTrainer(_TrainerBase):
             for name, tower, out_conv in (("cls", self.cls_tower, self.cls_out), ("reg", self.reg_tower, self.reg_out)):
                 xs = [P[l]]
                 for cv in tower:
+                    cv._count(xs[-1], 1)
                     xs.append(ops.conv(xs[-1], cv._packed(), pad=1, relu=True))
+                out_conv._count(xs[-1], 1)
                 acts[name].append(xs)
                 if name == "cls":
                     ops.conv(xs[-1], out_conv._packed(), pad=1, out=cls_flat[oc:oc + cls_sizes[l]].view(N, h, w, self.cls_ld), out_ld=self.cls_ld)
@@ -678,6 +715,7 @@ class RetinaNetTrainer(_TrainerBase):
         for i in range(3):
             gC[i + 1] = self.lat[i].bwd(ginner[i], need_dx=self.layers[i + 1][0])
         self._body_backward(gC)
+        self._join_side()
         return self.grads
 
 

@@ -17,6 +17,13 @@ def _p(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
+_WGRAD_CTX = [None]     # set by train.py while the weight gradients are issued on the side stream
+
+
+def _wctx(t):
+    return _WGRAD_CTX[0] if _WGRAD_CTX[0] is not None else get_ctx(t.device.index)
+
+
 def _chk(t, name):
     assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), name
 
@@ -98,7 +105,7 @@ def conv_dgrad(g, pk_d, H, W, stride, pad, residual=None):
 def conv_wgrad(x, g, Cin, Cout, KH, KW, stride, pad, dw, db=None, accumulate=False):
     _chk(x, "x"); _chk(g, "g")
     N, H, W, ldx = x.shape
-    _ffi.check(_ffi.lib().cald_train_conv_wgrad(get_ctx(x.device.index), N, H, W, _p(x), Cin, ldx, _p(g), Cout, g.shape[-1], KH, KW, stride,
+    _ffi.check(_ffi.lib().cald_train_conv_wgrad(_wctx(x), N, H, W, _p(x), Cin, ldx, _p(g), Cout, g.shape[-1], KH, KW, stride,
                                                 pad, _p(dw), _p(db), int(accumulate)))
     return dw
 
@@ -106,7 +113,7 @@ def conv_wgrad(x, g, Cin, Cout, KH, KW, stride, pad, dw, db=None, accumulate=Fal
 def linear_wgrad(x, g, Cout, dw, db=None, taps=1, accumulate=False):
     _chk(x, "x"); _chk(g, "g")
     R, K = x.shape[0], x[0].numel()
-    _ffi.check(_ffi.lib().cald_train_linear_wgrad(get_ctx(x.device.index), R, _p(x), K, _p(g), Cout, g.shape[-1], taps, _p(dw), _p(db),
+    _ffi.check(_ffi.lib().cald_train_linear_wgrad(_wctx(x), R, _p(x), K, _p(g), Cout, g.shape[-1], taps, _p(dw), _p(db),
                                                   int(accumulate)))
     return dw
 

@@ -75,6 +75,9 @@ def measure(batch=4, steps=10, warmup=3, depth=50, verbose=False, model="frcnn")
     t0 = time.time(); net.backward(); t_enq = time.time() - t0; torch.cuda.synchronize(); t_all = time.time() - t0
     if verbose:
         print("backward: host enqueue %.1f ms, until the GPU is done %.1f ms" % (t_enq * 1e3, t_all * 1e3), file=sys.stderr)
+    net.flops = 0.0
+    step(0)
+    flops, net.flops = net.flops, None
     net.timing = []
     step(0)
     sections = {b[0]: round((b[1] - a_[1]) * 1e3, 2) for a_, b in zip(net.timing[:-1], net.timing[1:])}
@@ -83,7 +86,9 @@ def measure(batch=4, steps=10, warmup=3, depth=50, verbose=False, model="frcnn")
         print("forward sections (ms, synchronized):", sections, file=sys.stderr)
     return {"metric": "training step throughput (forward + backward + SGD)", "value": a.batch / dt, "unit": "images/s", "ms_per_step": dt * 1e3,
             "batch": a.batch, "model": arch, "depth": a.depth, "forward_ms": p[0] * 1e3, "backward_ms": p[1] * 1e3, "sgd_ms": p[2] * 1e3,
-            "backward_gpu_ms": t_all * 1e3, "loss": float(last.detach()), "dtype": "f32",
+            "backward_gpu_ms": t_all * 1e3,
+            "gemm": {"algorithmic_gflop_per_step": flops / 1e9, "achieved_tflops_over_whole_step": flops / dt / 1e12, "peak_tflops": 157.3,
+                     "frac_of_fp32_mfma_peak": flops / dt / 1e12 / 157.3, "note": "forward + data-gradient + weight-gradient GEMM FLOPs (true channels, no padding, strided data gradients at their algorithmic cost) / wall-clock of the whole step incl. host work"}, "loss": float(last.detach()), "dtype": "f32",
             "config": "cald_train.py defaults: batch 4, VOC-sized synthetic images, min_size 600 / max_size 1000, SGD momentum 0.9"
                       + (", 2000 proposals, 512 RoIs / image" if arch == "frcnn" else ", 9 anchors / location on P3-P7")}
 
