@@ -313,9 +313,8 @@ class _TrainerBase(object):
         if self.timing is not None:
             torch.cuda.synchronize(self.dev); self.timing.append((name, __import__("time").time()))
 
-    def _inputs_and_body(self, images, targets):
-        """GeneralizedRCNNTransform (normalize, resize image and boxes, pad the batch) and the ResNet body.  Returns
-        (feats C2..C5, padded size, resized image sizes, ground-truth boxes on the device, ground-truth labels on the host)."""
+    def _inputs(self, images, targets):
+        """Host side of GeneralizedRCNNTransform: sizes, resized ground-truth boxes (device) and labels (host)."""
         self.version += 1                                  # whoever updated the parameters (any optimizer): repack the trainable layers
         u8, rem = self._prepare_images(images)
         sizes = [ops.transform_size(im.shape[0], im.shape[1], self.min_size, self.max_size) for im in u8]
@@ -329,6 +328,10 @@ class _TrainerBase(object):
             gts.append(torch.stack([b[:, 0] * rw, b[:, 1] * rh, b[:, 2] * rw, b[:, 3] * rh], dim=1).to(self.dev).contiguous())
             gt_labels.append(t["labels"].detach().long().cpu().reshape(-1))
         self._mark("inputs")
+        return u8, rem, Hp, Wp, img_sizes, gts, gt_labels
+
+    def _body(self, u8, rem, Hp, Wp, img_sizes):
+        """normalize + resize + pad on the device, stem, the four body stages.  Returns feats C2..C5."""
         x = ops.preprocess(u8, img_sizes, Hp, Wp, rem)
         x = ops.maxpool(self.stem.fwd(x, relu=True))
         feats = []
@@ -337,7 +340,11 @@ class _TrainerBase(object):
                 x = blk.fwd(x)
             feats.append(x)
         self._mark("body")
-        return feats, Hp, Wp, img_sizes, gts, gt_labels
+        return feats
+
+    def _inputs_and_body(self, images, targets):
+        u8, rem, Hp, Wp, img_sizes, gts, gt_labels = self._inputs(images, targets)
+        return self._body(u8, rem, Hp, Wp, img_sizes), Hp, Wp, img_sizes, gts, gt_labels
 
     def _body_backward(self, gC):
         """gC[li]: gradient wrt the output of body layer li + 1 coming from the FPN laterals (None where there is none)."""
@@ -392,35 +399,14 @@ class FasterRCNNTrainer(_TrainerBase):
         cfg, N, Ccls = self.cfg, len(images), self.C
         mark = self._mark
         mark("start")
-        feats, Hp, Wp, img_sizes, gts, gt_labels = self._inputs_and_body(images, targets)
-        # FPN (top-down), LastLevelMaxPool
-        inner = [None] * 4
-        inner[3] = self.lat[3].fwd(feats[3])
-        for i in (2, 1, 0):
-            inner[i] = self.lat[i].fwd(feats[i], up=inner[i + 1])
-        P = [self.fout[i].fwd(inner[i]) for i in range(4)]
-        P.append(ops.subsample2(P[3]))
-        level_hw = [(p.shape[1], p.shape[2]) for p in P]
-        # RPN head on the five levels: outputs in ONE buffer so that the loss kernels address (level, pixel, channel) by offset
+        u8, rem, Hp, Wp, img_sizes, gts, gt_labels = self._inputs(images, targets)
+        # The RPN targets depend on the anchors and the ground truth only: match + sample them BEFORE the network is enqueued, so the
+        # device->host copy of the match results does not wait for (and the host-side sampling does not stall) the body's kernels.
+        level_hw = [(Hp // 4, Wp // 4), (Hp // 8, Wp // 8), (Hp // 16, Wp // 16), (Hp // 32, Wp // 32)]
+        level_hw.append(((level_hw[3][0] - 1) // 2 + 1, (level_hw[3][1] - 1) // 2 + 1))
         head_sizes = [N * h * w * 16 for h, w in level_hw]
-        head_flat = torch.zeros(sum(head_sizes), dtype=torch.float32, device=self.dev)
-        heads, tl, o = [], [], 0
-        for i, (h, w) in enumerate(level_hw):
-            t = ops.conv(P[i], self.rpn_conv._packed(), pad=1, relu=True)
-            tl.append(t)
-            heads.append(ops.conv(t, self.rpn_head._packed(), out=head_flat[o:o + head_sizes[i]].view(N, h, w, 16), out_ld=16))
-            self.rpn_conv._count(P[i], 1); self.rpn_head._count(t, 1)
-            o += head_sizes[i]
-        mark("fpn+rpn head")
         anchors = self.anchors(Hp, Wp, level_hw)
         A_img = anchors.shape[0]
-        if proposals_override is None:
-            props, counts = ops.rpn_proposals(heads, Hp, Wp, img_sizes, cfg["pre_n"], cfg["post_n"], cfg["nms"], 1e-3)
-            counts = counts.cpu().tolist()
-            proposals = [props[i, :counts[i]] for i in range(N)]
-        else:
-            proposals = [p.to(self.dev).float().contiguous() for p in proposals_override]
-        mark("proposals")
         # ---- RPN targets and sampling (anchor order: level, y, x, anchor).  One device->host copy of all match results, host-side
         # sampling (torch CPU generator), one host->device copy of every index the loss kernels need. ----
         lvl_start = np.cumsum([0] + [h * w * 3 for h, w in level_hw])
@@ -459,6 +445,32 @@ class FasterRCNNTrainer(_TrainerBase):
         obj_lab = torch.from_numpy(np.concatenate(obj_lab)).to(self.dev)
         rpn_tgt = ops.box_encode(gts_all[gt_sel], anchors[anc_sel], (1.0, 1.0, 1.0, 1.0))
         mark("rpn targets")
+        feats = self._body(u8, rem, Hp, Wp, img_sizes)
+        # FPN (top-down), LastLevelMaxPool
+        inner = [None] * 4
+        inner[3] = self.lat[3].fwd(feats[3])
+        for i in (2, 1, 0):
+            inner[i] = self.lat[i].fwd(feats[i], up=inner[i + 1])
+        P = [self.fout[i].fwd(inner[i]) for i in range(4)]
+        P.append(ops.subsample2(P[3]))
+        assert level_hw == [(p.shape[1], p.shape[2]) for p in P]
+        # RPN head on the five levels: outputs in ONE buffer so that the loss kernels address (level, pixel, channel) by offset
+        head_flat = torch.zeros(sum(head_sizes), dtype=torch.float32, device=self.dev)
+        heads, tl, o = [], [], 0
+        for i, (h, w) in enumerate(level_hw):
+            t = ops.conv(P[i], self.rpn_conv._packed(), pad=1, relu=True)
+            tl.append(t)
+            heads.append(ops.conv(t, self.rpn_head._packed(), out=head_flat[o:o + head_sizes[i]].view(N, h, w, 16), out_ld=16))
+            self.rpn_conv._count(P[i], 1); self.rpn_head._count(t, 1)
+            o += head_sizes[i]
+        mark("fpn+rpn head")
+        if proposals_override is None:
+            props, counts = ops.rpn_proposals(heads, Hp, Wp, img_sizes, cfg["pre_n"], cfg["post_n"], cfg["nms"], 1e-3)
+            counts = counts.cpu().tolist()
+            proposals = [props[i, :counts[i]] for i in range(N)]
+        else:
+            proposals = [p.to(self.dev).float().contiguous() for p in proposals_override]
+        mark("proposals")
         # ---- RoI sampling ----
         n_pr = [int(proposals[i].shape[0]) + n_gt[i] for i in range(N)]
         pr_off = np.cumsum([0] + n_pr)

@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 
-AUGS = ["flip", "cut_out", "smaller_resize"]
+AUGS = os.environ.get("CALD_PARITY_AUGS", "flip,cut_out,smaller_resize").split(",")     # configs[0]: CALD_PARITY_AUGS=flip
 FULL_POOL, FULL_BUDGET = 5217, 500
 
 
@@ -49,6 +49,7 @@ def main():
     out_path = sys.argv[2] if len(sys.argv) > 2 else None
     z = np.load(ref_path)
     done = z["done"]
+    assert [str(a) for a in z["augs"]] == AUGS, "reference file was made with augs %s (set CALD_PARITY_AUGS)" % list(z["augs"])
     n = int(np.argmin(done)) if not done.all() else len(done)       # the completed prefix
     assert n >= 64, "torch-CPU reference holds only %d images" % n
     cpu = (z["consistency"][:n].astype(np.float64), z["cls_corr"][:n].astype(np.float64))

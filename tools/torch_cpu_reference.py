@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 
-AUGS = ["flip", "cut_out", "smaller_resize"]
+AUGS = os.environ.get("CALD_PARITY_AUGS", "flip,cut_out,smaller_resize").split(",")     # configs[0]: CALD_PARITY_AUGS=flip
 
 
 def main():
