@@ -51,6 +51,21 @@ def main():
         blob["bare_%d" % i] = np.array(bare)
         for k in ("boxes", "labels", "ishard", "name"):
             blob["%s_%d" % (k, i)] = t[k].numpy()
+    # detection/transforms.py RandomHorizontalFlip (:27-37) and ToTensor, as cald_train.py's get_transform(train=True) chains them:
+    # ten draws of Python's `random` seeded with 11 on a small image + boxes
+    import random
+    import torch
+    T = importlib.import_module("detection.transforms")
+    flip = T.RandomHorizontalFlip(0.5)
+    random.seed(11)
+    img = torch.arange(3 * 4 * 7, dtype=torch.float32).reshape(3, 4, 7) / 100.0
+    boxes0 = torch.tensor([[0.0, 1.0, 3.0, 2.0], [2.0, 0.0, 6.0, 3.0]])
+    outs_i, outs_b = [], []
+    for _ in range(10):
+        im2, t2 = flip(img.clone(), {"boxes": boxes0.clone()})
+        outs_i.append(im2.numpy()); outs_b.append(t2["boxes"].numpy())
+    blob["flip_image_in"], blob["flip_boxes_in"] = img.numpy(), boxes0.numpy()
+    blob["flip_images_out"], blob["flip_boxes_out"] = np.stack(outs_i), np.stack(outs_b)
     blob["n"] = np.array(n_img)
     np.savez_compressed(os.path.join(OUT, "voc_utils.npz"), **blob)
     print("wrote", os.path.join(OUT, "voc_utils.npz"))

@@ -523,3 +523,23 @@ def test_sampler_draws_are_uniform_subsets():
     for _ in range(4000):
         counts[choose_k(50, 5, g).numpy()] += 1
     assert abs(counts / 4000 - 0.1).max() < 0.02          # each element is drawn with probability k / n = 0.1
+
+
+def test_training_transform_flip_matches_reference_golden(golden):
+    """cald_amd.voc_utils.RandomHorizontalFlip (the training transform of get_transform(train=True)) == the imported
+    detection/transforms.py class on ten draws of Python's `random` (seed 11): same flips, same mirrored boxes."""
+    import random
+    import torch
+    from cald_amd import voc_utils as vu
+    g = golden("voc_utils")
+    flip = vu.RandomHorizontalFlip(0.5)
+    random.seed(11)
+    flipped = 0
+    for k in range(10):
+        im, t = flip(torch.from_numpy(g["flip_image_in"].copy()), {"boxes": torch.from_numpy(g["flip_boxes_in"].copy())})
+        np.testing.assert_array_equal(im.numpy(), g["flip_images_out"][k])
+        np.testing.assert_array_equal(t["boxes"].numpy(), g["flip_boxes_out"][k])
+        flipped += not np.array_equal(g["flip_images_out"][k], g["flip_image_in"])
+    assert 0 < flipped < 10
+    tr = vu.get_transform(train=True)
+    assert isinstance(tr.transforms[0], vu.ToTensor) and isinstance(tr.transforms[1], vu.RandomHorizontalFlip) and len(vu.get_transform(False).transforms) == 1
