@@ -132,9 +132,12 @@ class HipDetector:
         return self.to("cuda" if device is None else "cuda:%d" % device)
 
     def state_dict(self):
+        """{name: CPU float32 tensor} in torchvision's key layout, like ``nn.Module.state_dict()``: ``torch.save({'model':
+        task_model.state_dict()})`` (cald_train.py:421) and ``stock_torch_model.load_state_dict(hip_model.state_dict())`` both work."""
+        from collections import OrderedDict
         if self._trainer is not None and self.training:
-            return {k: v.detach().cpu().numpy() for k, v in self._trainer.state_dict().items()}
-        return dict(self._state or {})
+            return OrderedDict((k, v.detach().cpu()) for k, v in self._trainer.state_dict().items())
+        return OrderedDict((k, torch.from_numpy(np.array(v, dtype=np.float32))) for k, v in (self._state or {}).items())
 
     def load_state_dict(self, sd, strict=True):
         self._state = {k: (v.detach().cpu().float().numpy() if hasattr(v, "detach") else np.asarray(v, np.float32))

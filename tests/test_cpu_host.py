@@ -543,3 +543,23 @@ def test_training_transform_flip_matches_reference_golden(golden):
     assert 0 < flipped < 10
     tr = vu.get_transform(train=True)
     assert isinstance(tr.transforms[0], vu.ToTensor) and isinstance(tr.transforms[1], vu.RandomHorizontalFlip) and len(vu.get_transform(False).transforms) == 1
+
+
+def test_training_operator_host_side_contracts():
+    """The cald_train_* entry points that need no GPU: packed-weight geometry (what cald_amd/train.py allocates for) and argument
+    validation -- a null context / bad mode is an error code with a message, never a crash, and nothing silently falls back."""
+    from cald_amd import _ffi
+    L = _ffi.lib()
+    n = C.c_int64()
+    # forward pack of a 3x3 256 -> 256 conv: K = 2304 rows (multiple of 16), N padded to 256: [wk | w4 | bias, scale, shift]
+    assert L.cald_train_packed_floats(256, 256, 3, 3, 256, 0, C.byref(n)) == 0 and n.value == 2 * 2304 * 256 + 3 * 256
+    # merged RPN head (15 outputs): N pads to 32; its data gradient contracts over 16 channels of dY and produces 256 columns
+    assert L.cald_train_packed_floats(15, 256, 1, 1, 256, 0, C.byref(n)) == 0 and n.value == 2 * 256 * 32 + 3 * 32
+    assert L.cald_train_packed_floats(15, 256, 1, 1, 16, 1, C.byref(n)) == 0 and n.value == 2 * 16 * 256 + 3 * 256
+    # fc6 on RoIAlign rows: K = 49 * 256
+    assert L.cald_train_packed_floats(1024, 256, 49, 1, 256, 2, C.byref(n)) == 0 and n.value == 2 * 12544 * 1024 + 3 * 1024
+    assert L.cald_train_packed_floats(1024, 256, 49, 1, 256, 7, C.byref(n)) != 0 and b"bad arguments" in L.cald_last_error()
+    assert L.cald_train_pack_conv(None, None, None, None, None, 8, 8, 1, 1, 8, 0, None) != 0
+    assert L.cald_train_conv(None, 1, 8, 8, None, 8, None, 8, 8, 1, 1, 1, 0, 0, 0, None, None, 0, 0, None, 8) != 0
+    assert L.cald_train_sgd(None, 10, None, None, None, 0.1, 0.9, 0.0, 1) != 0
+    assert L.cald_train_focal_loss(None, 1, None, 9, 21, 192, None, None, None, None, None, 0.25, 1.0, None, None) != 0

@@ -633,7 +633,7 @@ def test_drop_in_selection_stage(hip, oracle, small_model):
         transform = SimpleNamespace(min_size=(300,), max_size=500)
 
         def state_dict(self):
-            return {k: torch.from_numpy(v) for k, v in model.state_dict().items()}
+            return dict(model.state_dict())
     pool = synth.make_pool(8, "voc", 0, scale=0.5)
     loader = [((torch.from_numpy(im),), (None,)) for im in pool]
     augs = ["flip", "cut_out", "smaller_resize"]

@@ -400,8 +400,9 @@ def test_active_learning_cycle_train_then_sweep_with_the_same_model_object(T, or
     model.eval()
     after, _ = sweep.get_uncertainty(model, loader, augs, 21)
     new_sd = model.state_dict()
-    assert not np.array_equal(new_sd["roi_heads.box_head.fc7.weight"], np.asarray(sd["roi_heads.box_head.fc7.weight"]))
-    np.testing.assert_array_equal(new_sd["backbone.body.layer1.0.conv1.weight"], np.asarray(sd["backbone.body.layer1.0.conv1.weight"]))
+    assert all(isinstance(v, torch.Tensor) and v.dtype == torch.float32 and not v.is_cuda for v in new_sd.values())     # as nn.Module.state_dict()
+    assert not np.array_equal(new_sd["roi_heads.box_head.fc7.weight"].numpy(), np.asarray(sd["roi_heads.box_head.fc7.weight"]))
+    np.testing.assert_array_equal(new_sd["backbone.body.layer1.0.conv1.weight"].numpy(), np.asarray(sd["backbone.body.layer1.0.conv1.weight"]))
     P = oracle.prepare_frcnn(new_sd, 21, 50)
     want, _ = oracle.get_uncertainty(P, pool, augs, 21, min_size=160, max_size=256)
     assert after == want
