@@ -356,6 +356,29 @@ def test_drop_in_training_loop_updates_like_torch_sgd(T, oracle):
         assert err <= 1e-5, (k, err)
 
 
+def test_stock_torch_optimizer_drives_the_hip_model(T):
+    """cald_train.py:397 verbatim -- torch.optim.SGD over task_model.parameters(): the parameters are ordinary torch Parameters whose
+    .grad the hand-written backward fills, so torch's own optimizer (and anything else that reads .grad) works; the result equals
+    the HIP SGD kernel's to float32 rounding."""
+    torch, ops = T
+    from cald_amd import train
+    sd, images, targets = _train_case(torch, seed=12)
+    outs = []
+    for use_torch in (True, False):
+        net = train.FasterRCNNTrainer(sd, 21, min_size=160, max_size=256, box_batch=64, generator=torch.Generator().manual_seed(4))
+        model = train.TrainableDetector(net)
+        params = [p for p in model.parameters() if p.requires_grad]
+        opt = (torch.optim.SGD(params, lr=1e-4, momentum=0.9, weight_decay=1e-4) if use_torch
+               else train.SGD(params, lr=1e-4, momentum=0.9, weight_decay=1e-4))
+        for it in range(2):
+            losses = sum(loss for loss in model(images, targets).values())
+            opt.zero_grad(); losses.backward(); opt.step()
+        outs.append({k: p.detach().clone() for k, p in net.named_parameters()})
+    for k in outs[0]:
+        scale = float(outs[1][k].abs().max())
+        assert float((outs[0][k] - outs[1][k]).abs().max()) <= 2e-5 * scale, k
+
+
 def test_fitting_one_batch_lowers_the_loss(T):
     """Ten plain SGD steps on one batch (same sampler permutations every step): the summed loss falls."""
     torch, ops = T
