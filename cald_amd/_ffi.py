@@ -107,7 +107,7 @@ SIGNATURES = {
     "cald_train_match": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
     "cald_train_box_encode": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "cald_train_roi_align": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), c_i, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
-    "cald_train_roi_align_bwd": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), c_i, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "cald_train_roi_align_bwd": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), c_i, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "cald_train_softmax_ce": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
     "cald_train_smooth_l1": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_float,
                                        C.c_void_p, C.c_void_p]),

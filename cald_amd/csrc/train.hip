@@ -22,6 +22,7 @@
 #include "kernels.h"
 #include "sortnms.h"
 #include "../../include/cald_hip.h"
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -806,13 +807,88 @@ extern "C" int cald_train_roi_align(cald_ctx* c, const float* const* feats, cons
     THIP(hipGetLastError());
     return 0;
 }
-/* gfeats[l] += scatter of gout through the bilinear weights (float atomics: the summation order is not fixed) */
-extern "C" int cald_train_roi_align_bwd(cald_ctx* c, float* const* gfeats, const int* level_hw, int C, int R, const float* rois, const float* gout) {
-    if (!c || !gfeats || !gout) TFAIL(CALD_ERR_INVALID, "null argument");
+// Deterministic scatter: contributions are accumulated as 64-bit FIXED-POINT integers (integer addition is associative, so the
+// arrival order of the atomics does not matter), scaled by 2^k with k chosen from max|gout| so that the largest single term is
+// 2^40 (resolution 2^-40 of it; 2^21 such terms still fit), then converted and added to the float gradient.
+__global__ void absmax_kernel(const float* x, long long n, unsigned* out_bits) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    float m = 0.0f;
+    for (long long j = i; j < n; j += (long long)gridDim.x * blockDim.x) { const float v = fabsf(x[j]); if (v > m) m = v; }   // NaN never wins
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o));
+    if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(out_bits, __float_as_uint(m));
+}
+__device__ inline double fixed_scale(unsigned max_bits) {
+    const int e = (int)((max_bits >> 23) & 255) - 127;          // max = 1.f x 2^e  (0 if the tensor is all zero)
+    return max_bits ? ldexp(1.0, 40 - (e + 1)) : 1.0;
+}
+__global__ __launch_bounds__(256) void roi_align_bwd_fixed_kernel(RoiTrainArgs a, long long* const* acc, const unsigned* max_bits) {
+    __shared__ RoiSample sy[14], sx[14];
+    const int r = blockIdx.x, tid = threadIdx.x;
+    int n, l;
+    roi_setup(a, r, sy, sx, &n, &l);
+    const int Hf = a.H[l], Wf = a.W[l], C = a.C;
+    unsigned long long* gf = reinterpret_cast<unsigned long long*>(acc[l]) + (long long)n * Hf * Wf * C;
+    const double scale = fixed_scale(*max_bits);
+    for (int idx = tid; idx < 49 * C; idx += 256) {
+        const int bin = idx / C, c = idx - bin * C;
+        const int ph = bin / 7, pw = bin - ph * 7;
+        const float go = a.gout[(long long)r * 49 * C + idx] * 0.25f;
+        if (!(go == go) || fabsf(go) == INFINITY) continue;          // non-finite gradients are reported by the loss check, not spread
+#pragma unroll
+        for (int iy = 0; iy < 2; iy++) {
+            const RoiSample Y = sy[ph * 2 + iy];
+#pragma unroll
+            for (int ix = 0; ix < 2; ix++) {
+                const RoiSample X = sx[pw * 2 + ix];
+                if (!(Y.valid && X.valid)) continue;
+                const float w[4] = {Y.h * X.h, Y.h * X.l, Y.l * X.h, Y.l * X.l};
+                const long long o[4] = {(long long)(Y.lo * Wf + X.lo) * C + c, (long long)(Y.lo * Wf + X.hi) * C + c,
+                                        (long long)(Y.hi * Wf + X.lo) * C + c, (long long)(Y.hi * Wf + X.hi) * C + c};
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    atomicAdd(gf + o[k], (unsigned long long)(long long)rint((double)(w[k] * go) * scale));      // two's complement wrap = signed add
+            }
+        }
+    }
+}
+__global__ void fixed_to_float_kernel(const long long* acc, float* g, long long n, const unsigned* max_bits) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const long long v = acc[i];
+    if (v) g[i] = g[i] + (float)((double)v / fixed_scale(*max_bits));
+}
+/* gfeats[l] += scatter of gout through the bilinear weights.  Deterministic (fixed-point accumulation, see above); CALD_ROI_BWD_FLOAT=1
+ * selects plain float atomics (summation in arrival order). */
+extern "C" int cald_train_roi_align_bwd(cald_ctx* c, int N, float* const* gfeats, const int* level_hw, int C, int R, const float* rois, const float* gout) {
+    if (!c || !gfeats || !gout || N < 1) TFAIL(CALD_ERR_INVALID, "bad arguments");
     THIP(hipSetDevice(cald_internal_device(c)));
+    hipStream_t st = cald_internal_stream(c);
     RoiTrainArgs a; if (int rc = roi_args(a, (const float* const*)gfeats, gfeats, level_hw, C, R, rois)) return rc;
     a.gout = gout;
-    hipLaunchKernelGGL(roi_align_bwd_kernel, dim3(R), dim3(256), 0, cald_internal_stream(c), a);
+    static const bool float_atomics = getenv("CALD_ROI_BWD_FLOAT") && atoi(getenv("CALD_ROI_BWD_FLOAT")) != 0;
+    if (float_atomics) {
+        hipLaunchKernelGGL(roi_align_bwd_kernel, dim3(R), dim3(256), 0, st, a);
+        THIP(hipGetLastError());
+        return 0;
+    }
+    long long n[4], total = 0;
+    for (int l = 0; l < 4; l++) { n[l] = (long long)N * a.H[l] * a.W[l] * C; total += n[l]; }
+    void* scratch = nullptr;
+    if (int rc = cald_internal_scratch(c, (size_t)total * 8 + 4 * sizeof(long long*) + 256, &scratch)) return rc;
+    long long* acc = (long long*)scratch;
+    long long** d_ptrs = (long long**)(acc + total);
+    unsigned* d_max = (unsigned*)(d_ptrs + 4);
+    long long* h_ptrs[4]; long long off = 0;
+    for (int l = 0; l < 4; l++) { h_ptrs[l] = acc + off; off += n[l]; }
+    THIP(hipMemsetAsync(acc, 0, (size_t)total * 8, st));
+    THIP(hipMemsetAsync(d_max, 0, 4, st));
+    THIP(hipMemcpyAsync(d_ptrs, h_ptrs, sizeof(h_ptrs), hipMemcpyHostToDevice, st));
+    THIP(hipStreamSynchronize(st));      // h_ptrs is stack storage
+    const long long ng = (long long)R * 49 * C;
+    hipLaunchKernelGGL(absmax_kernel, dim3(1024), dim3(256), 0, st, gout, ng, d_max);
+    hipLaunchKernelGGL(roi_align_bwd_fixed_kernel, dim3(R), dim3(256), 0, st, a, (long long* const*)d_ptrs, (const unsigned*)d_max);
+    for (int l = 0; l < 4; l++)
+        hipLaunchKernelGGL(fixed_to_float_kernel, dim3((unsigned)((n[l] + 255) / 256)), dim3(256), 0, st, (const long long*)h_ptrs[l], gfeats[l], n[l], (const unsigned*)d_max);
     THIP(hipGetLastError());
     return 0;
 }

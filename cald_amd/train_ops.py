@@ -196,8 +196,8 @@ def roi_align(feats, rois):
 
 def roi_align_bwd_(gfeats, rois, gout):
     hw = [v for f in gfeats for v in (f.shape[1], f.shape[2])]
-    _ffi.check(_ffi.lib().cald_train_roi_align_bwd(get_ctx(rois.device.index), _ptr_array(gfeats), _int_array(hw), gfeats[0].shape[3], rois.shape[0], _p(rois),
-                                                   _p(gout)))
+    _ffi.check(_ffi.lib().cald_train_roi_align_bwd(get_ctx(rois.device.index), gfeats[0].shape[0], _ptr_array(gfeats), _int_array(hw), gfeats[0].shape[3],
+                                                   rois.shape[0], _p(rois), _p(gout)))
     return gfeats
 
 

@@ -267,9 +267,10 @@ int cald_train_match(cald_ctx* ctx, int n_boxes, const float* boxes, int n_gt, c
 int cald_train_box_encode(cald_ctx* ctx, int n, const float* reference, const float* proposals, float wx, float wy, float ww,
                           float wh, float* out);
 /* MultiScaleRoIAlign(7, sampling_ratio 2) over four dense levels feats[l] = [N][Hl][Wl][C]; rois [R][5] = (image, x1, y1, x2,
- * y2); out [R][49][C].  _bwd scatters gout into gfeats[l] (+=, float atomics). */
+ * y2); out [R][49][C].  _bwd scatters gout into gfeats[l] = [N][Hl][Wl][C] (+=): deterministic -- the contributions are summed as
+ * 64-bit fixed-point integers (scale from max|gout|), so the arrival order of the atomics does not matter. */
 int cald_train_roi_align(cald_ctx* ctx, const float* const* feats, const int* level_hw, int C, int R, const float* rois, float* out);
-int cald_train_roi_align_bwd(cald_ctx* ctx, float* const* gfeats, const int* level_hw, int C, int R, const float* rois,
+int cald_train_roi_align_bwd(cald_ctx* ctx, int N, float* const* gfeats, const int* level_hw, int C, int R, const float* rois,
                              const float* gout);
 /* F.cross_entropy over R rows of stride ld (mean); grad_out (same layout, may be null) = gscale * d loss / d logits */
 int cald_train_softmax_ce(cald_ctx* ctx, int R, int C, int ld, const float* logits, const int64_t* labels, float gscale,

@@ -356,6 +356,24 @@ def test_drop_in_training_loop_updates_like_torch_sgd(T, oracle):
         assert err <= 1e-5, (k, err)
 
 
+def test_training_step_is_bit_reproducible(T):
+    """Same weights, images, targets and sampler seed twice: identical losses AND identical gradients of every tensor, bit for bit --
+    with the weight gradients on the side stream and RoIAlign backward scattering through atomics (fixed-point accumulation)."""
+    torch, ops = T
+    from cald_amd import train
+    sd, images, targets = _train_case(torch, n_images=3, seed=21)
+    runs = []
+    for _ in range(2):
+        net = train.FasterRCNNTrainer(sd, 21, min_size=160, max_size=256, generator=torch.Generator().manual_seed(5))
+        losses = net.forward(images, targets)
+        grads = net.backward()
+        torch.cuda.synchronize()
+        runs.append(({k: float(v) for k, v in losses.items()}, {k: v.clone() for k, v in grads.items()}))
+    assert runs[0][0] == runs[1][0]
+    for k in runs[0][1]:
+        assert torch.equal(runs[0][1][k], runs[1][1][k]), k
+
+
 def test_stock_torch_optimizer_drives_the_hip_model(T):
     """cald_train.py:397 verbatim -- torch.optim.SGD over task_model.parameters(): the parameters are ordinary torch Parameters whose
     .grad the hand-written backward fills, so torch's own optimizer (and anything else that reads .grad) works; the result equals
