@@ -78,6 +78,7 @@ class _Conv(object):
         self._pk = self._pkd = None
         self._pk_version = self._pkd_version = -1
         self.x = None
+        net.convs.append(self)
 
     def _packed(self):
         if self._pk is None or (self.trainable and self._pk_version != self.net.version):
@@ -177,6 +178,7 @@ class _TrainerBase(object):
         self.dev = torch.device(device)
         self.C, self.min_size, self.max_size = num_classes, int(min_size), int(max_size)
         self.generator = generator
+        self.convs = []
         self.version = 0                                   # bumped whenever the parameters change: packed weights are rebuilt lazily
         sd = {k: (v.detach().float().cpu() if hasattr(v, "detach") else torch.from_numpy(np.asarray(v, np.float32)))
               for k, v in state_dict.items() if not k.endswith("num_batches_tracked")}
@@ -313,9 +315,28 @@ class _TrainerBase(object):
         if self.timing is not None:
             torch.cuda.synchronize(self.dev); self.timing.append((name, __import__("time").time()))
 
+    def _repack(self):
+        """Forward and data-gradient forms of every trainable weight, packed on the side stream while the main stream runs the
+        frozen stem / layer 1 (the packs depend on the parameters only)."""
+        if self.side is None:
+            return
+        st, ctx = self.side
+        main = torch.cuda.current_stream(self.dev)
+        st.wait_stream(main)                                # the optimizer's update of the flat parameter buffer
+        ops._WGRAD_CTX[0] = ctx
+        try:
+            for cv in self.convs:
+                if cv.trainable:
+                    cv._packed(); cv._packed_grad()
+        finally:
+            ops._WGRAD_CTX[0] = None
+        self._packs_ready = torch.cuda.Event()
+        self._packs_ready.record(st)
+
     def _inputs(self, images, targets):
         """Host side of GeneralizedRCNNTransform: sizes, resized ground-truth boxes (device) and labels (host)."""
         self.version += 1                                  # whoever updated the parameters (any optimizer): repack the trainable layers
+        self._repack()
         u8, rem = self._prepare_images(images)
         sizes = [ops.transform_size(im.shape[0], im.shape[1], self.min_size, self.max_size) for im in u8]
         Hp, Wp = max(s[2] for s in sizes), max(s[3] for s in sizes)
@@ -335,10 +356,16 @@ class _TrainerBase(object):
         x = ops.preprocess(u8, img_sizes, Hp, Wp, rem)
         x = ops.maxpool(self.stem.fwd(x, relu=True))
         feats = []
+        waited = self.side is None
         for trainable, blocks in self.layers:
+            if trainable and not waited:                    # first layer that reads a freshly packed weight
+                torch.cuda.current_stream(self.dev).wait_event(self._packs_ready)
+                waited = True
             for blk in blocks:
                 x = blk.fwd(x)
             feats.append(x)
+        if not waited:
+            torch.cuda.current_stream(self.dev).wait_event(self._packs_ready)
         self._mark("body")
         return feats
 

@@ -17,7 +17,7 @@ def _p(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
-_WGRAD_CTX = [None]     # set by train.py while the weight gradients are issued on the side stream
+_WGRAD_CTX = [None]     # set by train.py while weight gradients / weight packing are issued on the side stream
 
 
 def _wctx(t):
@@ -56,7 +56,7 @@ class PackedConv(object):
         self.buf = out if out is not None else torch.empty(n, dtype=torch.float32, device=weight.device)
         assert self.buf.numel() >= n
         self.flags = (FLAG_BIAS if bias is not None else 0) | (FLAG_BN if scale is not None else 0)
-        _ffi.check(_ffi.lib().cald_train_pack_conv(get_ctx(weight.device.index), _p(weight), _p(bias), _p(scale), _p(shift), self.Cout,
+        _ffi.check(_ffi.lib().cald_train_pack_conv(_wctx(weight), _p(weight), _p(bias), _p(scale), _p(shift), self.Cout,
                                                    self.Cin, self.KH, self.KW, self.CinK, mode, _p(self.buf)))
 
 
