@@ -86,7 +86,13 @@ __global__ __launch_bounds__(1024) void rpn_topk_kernel(RpnArgs a) {
             box.x = det_clamp(o[0], 0.0f, Wr); box.z = det_clamp(o[2], 0.0f, Wr);
             box.y = det_clamp(o[1], 0.0f, Hr); box.w = det_clamp(o[3], 0.0f, Hr);
             const bool ok = (box.z - box.x) >= a.min_size && (box.w - box.y) >= a.min_size;
-            if (ok) outkey = (key & 0xFFFFFFFF00000000ull) | (unsigned long long)(0xFFFFFFFFu - (unsigned)(l * a.pre_n + t));
+            if (ok) {
+                outkey = (key & 0xFFFFFFFF00000000ull) | (unsigned long long)(0xFFFFFFFFu - (unsigned)(l * a.pre_n + t));
+                // largest coordinate over the view's valid candidates (batched_nms offsets): coordinates are clamped to >= 0, so the
+                // bit pattern orders like the value
+                const float m = fmaxf(fmaxf(box.x, box.y), fmaxf(box.z, box.w));
+                if (m > 0.0f) atomicMax(reinterpret_cast<unsigned*>(a.sorted_count) + v, __float_as_uint(m));
+            }
         }
         const long long o = (long long)v * 5 * a.pre_n + l * a.pre_n + t;
         a.cand_key[o] = outkey;
@@ -95,70 +101,75 @@ __global__ __launch_bounds__(1024) void rpn_topk_kernel(RpnArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Kernel 2: per view: sort the <=5*pre_n candidates by (score desc, position asc), apply the
-// batched_nms coordinate offset level*(max_coord+1) in fp32, run greedy NMS, emit <=post_n boxes.
-// grid = V, block = 1024, dynamic LDS.  alias != 0 (training sizes, 5 x 2000 candidates): the kept-box scratch of the NMS
-// reuses the key array, which is dead once the sorted boxes are written out.
+// Kernel 2: per (level, view): greedy NMS of the level's <= pre_n candidates, which kernel 1 left in score order.  torchvision's
+// batched_nms separates the levels by the coordinate offset level * (max_coord + 1), so NMS never acts across levels: the five
+// levels of a view run as five workgroups instead of one (the offset is still applied, in fp32, because it changes the rounding of
+// the IoU).  Writes a keep flag per candidate.  grid = (5, V), block = 512, dynamic LDS.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void rpn_nms_kernel(RpnArgs a, int NP, int alias) {
+__global__ __launch_bounds__(512) void rpn_level_nms_kernel(RpnArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
-    const size_t key_bytes = (size_t)NP * 8, kept_bytes = (size_t)a.post_n * 24;
-    const size_t kept_off = alias ? 0 : key_bytes, tail_off = alias ? (key_bytes > kept_bytes ? key_bytes : kept_bytes) : key_bytes + kept_bytes;
-    unsigned long long* keys = reinterpret_cast<unsigned long long*>(dyn);                 // NP
-    float4* kept_box = reinterpret_cast<float4*>(dyn + kept_off);                          // post_n
-    float* kept_area = reinterpret_cast<float*>(dyn + kept_off + (size_t)a.post_n * 16);
+    float4* kept_box = reinterpret_cast<float4*>(dyn);                                     // post_n
+    float* kept_area = reinterpret_cast<float*>(dyn + (size_t)a.post_n * 16);
     int* keep_idx = reinterpret_cast<int*>(kept_area + a.post_n);                          // post_n
-    int* dead_or = reinterpret_cast<int*>(dyn + tail_off);                                 // 256
-    float* red = reinterpret_cast<float*>(dead_or + 256);                                  // 1024
-    __shared__ int s_nc, s_nk;
+    __shared__ int s_nk;
+    const int l = blockIdx.x, v = blockIdx.y, tid = threadIdx.x;
+    const long long base = (long long)v * 5 * a.pre_n + (long long)l * a.pre_n;
+    const unsigned long long* ck = a.cand_key + base;
+    const float4* cb = reinterpret_cast<const float4*>(a.cand_box) + base;
+    float4* sb = reinterpret_cast<float4*>(a.sorted_box) + base;
+    unsigned char* skip = reinterpret_cast<unsigned char*>(a.sorted_raw) + (long long)v * 10 * a.pre_n + (long long)l * a.pre_n;          // [V][2][5*pre_n] bytes: skip, keep
+    unsigned char* keep = skip + 5 * a.pre_n;
+    const float maxc = __uint_as_float(reinterpret_cast<const unsigned*>(a.sorted_count)[v]);
+    const float off = (float)l * (maxc + 1.0f);
+    for (int i = tid; i < a.pre_n; i += 512) {
+        const float4 b = cb[i];
+        sb[i] = make_float4(b.x + off, b.y + off, b.z + off, b.w + off);
+        skip[i] = ck[i] == 0ull;
+        keep[i] = 0;
+    }
+    __syncthreads();   // global writes by this block are read back below by other threads
+    block_nms_sorted(sb, a.pre_n, a.nms_thr, a.post_n, kept_box, kept_area, nullptr, keep_idx, &s_nk, skip);
+    const int nk = s_nk;
+    for (int i = tid; i < nk; i += 512) keep[keep_idx[i]] = 1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Kernel 3: per view: the kept candidates of the five levels in (score desc, position asc) order, first post_n of them.
+// grid = V, block = 1024, dynamic LDS (NP keys).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void rpn_merge_kernel(RpnArgs a, int NP) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(dyn);
+    __shared__ int s_nk;
     const int v = blockIdx.x, tid = threadIdx.x;
     const int ntot = 5 * a.pre_n;
     const unsigned long long* ck = a.cand_key + (long long)v * ntot;
     const float4* cb = reinterpret_cast<const float4*>(a.cand_box) + (long long)v * ntot;
-    if (tid == 0) s_nc = 0;
-    float mx = -INFINITY;
-    for (int i = tid; i < NP; i += 1024) {
-        unsigned long long key = i < ntot ? ck[i] : 0ull;
-        keys[i] = key;
-        if (key) { const float4 b = cb[i]; mx = fmaxf(mx, fmaxf(fmaxf(b.x, b.y), fmaxf(b.z, b.w))); }
-    }
-    red[tid] = mx;
-    __syncthreads();
-    for (int s = 512; s > 0; s >>= 1) { if (tid < s) red[tid] = fmaxf(red[tid], red[tid + s]); __syncthreads(); }
-    const float maxc = red[0];
-    block_bitonic_sort_desc(keys, NP);
+    const unsigned char* keep = reinterpret_cast<const unsigned char*>(a.sorted_raw) + (long long)v * 10 * a.pre_n + 5 * a.pre_n;
+    if (tid == 0) s_nk = 0;
     int local = 0;
-    for (int i = tid; i < NP; i += 1024) local += keys[i] != 0ull;
-    if (local) atomicAdd(&s_nc, local);
-    __syncthreads();
-    const int nc = s_nc;
-    float4* sb = reinterpret_cast<float4*>(a.sorted_box) + (long long)v * ntot;
-    float4* sr = reinterpret_cast<float4*>(a.sorted_raw) + (long long)v * ntot;
-    for (int i = tid; i < nc; i += 1024) {
-        const int pos = (int)(0xFFFFFFFFu - (unsigned)(keys[i] & 0xFFFFFFFFull));
-        const int lvl = pos / a.pre_n;
-        const float off = (float)lvl * (maxc + 1.0f);
-        const float4 b = cb[pos];
-        sr[i] = b;
-        sb[i] = make_float4(b.x + off, b.y + off, b.z + off, b.w + off);
+    for (int i = tid; i < NP; i += 1024) {
+        const unsigned long long key = (i < ntot && keep[i]) ? ck[i] : 0ull;
+        keys[i] = key;
+        local += key != 0ull;
     }
-    __syncthreads();   // global writes by this block are read back below by other threads
-    block_nms_sorted(sb, nc, a.nms_thr, a.post_n, kept_box, kept_area, dead_or, keep_idx, &s_nk);
-    const int nk = s_nk;
+    __syncthreads();
+    if (local) atomicAdd(&s_nk, local);
+    block_bitonic_sort_desc(keys, NP);
+    int nk = s_nk; if (nk > a.post_n) nk = a.post_n;
     float4* pr = reinterpret_cast<float4*>(a.proposals) + (long long)v * a.prop_stride;
-    for (int i = tid; i < nk; i += 1024) pr[i] = sr[keep_idx[i]];
-    if (tid == 0) { a.prop_count[v] = nk; a.sorted_count[v] = nc; }
+    for (int i = tid; i < nk; i += 1024) pr[i] = cb[(int)(0xFFFFFFFFu - (unsigned)(keys[i] & 0xFFFFFFFFull))];
+    if (tid == 0) a.prop_count[v] = nk;
 }
 
 void launch_rpn(const RpnArgs& a, hipStream_t st) {
+    hipMemsetAsync(a.sorted_count, 0, sizeof(int) * a.V, st);      // per-view max coordinate (float bits), filled by kernel 1
     if (a.pre_n <= 1024) hipLaunchKernelGGL(rpn_topk_kernel<1024>, dim3(5, a.V), dim3(1024), 0, st, a);
     else hipLaunchKernelGGL(rpn_topk_kernel<2048>, dim3(5, a.V), dim3(1024), 0, st, a);     // pre_n <= 2048 (checked by the callers)
+    hipLaunchKernelGGL(rpn_level_nms_kernel, dim3(5, a.V), dim3(512), (size_t)a.post_n * 24, st, a);
     int NP = 1024;
     while (NP < 5 * a.pre_n) NP <<= 1;
-    const size_t key_bytes = (size_t)NP * 8, kept_bytes = (size_t)a.post_n * (16 + 4 + 4), tail = 256 * 4 + 1024 * 4;
-    const int alias = key_bytes + kept_bytes + tail > 150 * 1024;
-    const size_t lds = (alias ? (key_bytes > kept_bytes ? key_bytes : kept_bytes) : key_bytes + kept_bytes) + tail;
     static PerDeviceOnce once;
-    allow_big_lds(once, rpn_nms_kernel);
-    hipLaunchKernelGGL(rpn_nms_kernel, dim3(a.V), dim3(1024), lds, st, a, NP, alias);
+    allow_big_lds(once, rpn_merge_kernel);
+    hipLaunchKernelGGL(rpn_merge_kernel, dim3(a.V), dim3(1024), (size_t)NP * 8, st, a, NP);
 }
