@@ -116,7 +116,7 @@ class _Conv(object):
         """g: gradient wrt this layer's conv output (after the caller applied ReLU mask / BN scale), row stride out_ld."""
         x = self.x if x is None else x
         self._count(x, 2 if need_dx else 1)
-        side = self.net.side
+        side, prev = self.net.side, ops._WGRAD_CTX[0]
         if side is not None:            # the weight gradient depends on (x, g) only: issue it beside the data gradient
             side[0].wait_stream(torch.cuda.current_stream(self.net.dev))
             x.record_stream(side[0]); g.record_stream(side[0])
@@ -127,7 +127,7 @@ class _Conv(object):
             else:
                 ops.conv_wgrad(x, g, self.Cin, self.Cout, self.K, self.K, self.stride, self.pad, self.gw, self.gb, accumulate=accumulate)
         finally:
-            ops._WGRAD_CTX[0] = None
+            ops._WGRAD_CTX[0] = prev
         if not need_dx:
             return None
         pkd = self._packed_grad()
@@ -240,11 +240,16 @@ class _TrainerBase(object):
         self.flops = None           # set to 0.0 to accumulate the algorithmic GEMM FLOPs of forward() + backward()
         # weight gradients run on a second stream: at batch 4 most layers fill a fraction of the 256 CUs, and dW / dX of one layer
         # are independent.  CALD_TRAIN_SIDE_STREAM=0 keeps everything on one stream.
-        self.side = None
+        self.side = self.aux = None
         if __import__("os").environ.get("CALD_TRAIN_SIDE_STREAM", "1") != "0":
             from .detector import get_side_ctx
             st = torch.cuda.Stream(device=self.dev)
-            self.side = (st, get_side_ctx(self.dev.index if self.dev.index is not None else torch.cuda.current_device(), st))
+            di = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
+            self.side = (st, get_side_ctx(di, st))
+            # a third stream for what depends on the batch only (input upload, anchor matching, RPN sampling): its device->host copy
+            # then waits for the match kernels, not for the previous step's backward still queued on the main stream
+            st2 = torch.cuda.Stream(device=self.dev)
+            self.aux = (st2, get_side_ctx(di, st2))
 
     def _join_side(self):
         if self.side is not None:
@@ -321,23 +326,26 @@ class _TrainerBase(object):
         if self.side is None:
             return
         st, ctx = self.side
-        main = torch.cuda.current_stream(self.dev)
-        st.wait_stream(main)                                # the optimizer's update of the flat parameter buffer
-        ops._WGRAD_CTX[0] = ctx
+        st.wait_stream(self._main)                          # the optimizer's update of the flat parameter buffer
+        prev, ops._WGRAD_CTX[0] = ops._WGRAD_CTX[0], ctx
         try:
             for cv in self.convs:
                 if cv.trainable:
                     cv._packed(); cv._packed_grad()
         finally:
-            ops._WGRAD_CTX[0] = None
+            ops._WGRAD_CTX[0] = prev
         self._packs_ready = torch.cuda.Event()
         self._packs_ready.record(st)
 
-    def _inputs(self, images, targets):
-        """Host side of GeneralizedRCNNTransform: sizes, resized ground-truth boxes (device) and labels (host)."""
+    def _begin_step(self):
+        from .detector import get_ctx
+        get_ctx(self.dev.index if self.dev.index is not None else torch.cuda.current_device())     # binds the main context to THIS stream on first use
+        self._main = torch.cuda.current_stream(self.dev)
         self.version += 1                                  # whoever updated the parameters (any optimizer): repack the trainable layers
         self._repack()
-        u8, rem = self._prepare_images(images)
+
+    def _inputs(self, u8, rem, targets):
+        """Host side of GeneralizedRCNNTransform: sizes, resized ground-truth boxes (device) and labels (host)."""
         sizes = [ops.transform_size(im.shape[0], im.shape[1], self.min_size, self.max_size) for im in u8]
         Hp, Wp = max(s[2] for s in sizes), max(s[3] for s in sizes)
         img_sizes = [(s[0], s[1]) for s in sizes]
@@ -359,18 +367,20 @@ class _TrainerBase(object):
         waited = self.side is None
         for trainable, blocks in self.layers:
             if trainable and not waited:                    # first layer that reads a freshly packed weight
-                torch.cuda.current_stream(self.dev).wait_event(self._packs_ready)
+                self._main.wait_event(self._packs_ready)
                 waited = True
             for blk in blocks:
                 x = blk.fwd(x)
             feats.append(x)
         if not waited:
-            torch.cuda.current_stream(self.dev).wait_event(self._packs_ready)
+            self._main.wait_event(self._packs_ready)
         self._mark("body")
         return feats
 
     def _inputs_and_body(self, images, targets):
-        u8, rem, Hp, Wp, img_sizes, gts, gt_labels = self._inputs(images, targets)
+        self._begin_step()
+        u8, rem = self._prepare_images(images)
+        u8, rem, Hp, Wp, img_sizes, gts, gt_labels = self._inputs(u8, rem, targets)
         return self._body(u8, rem, Hp, Wp, img_sizes), Hp, Wp, img_sizes, gts, gt_labels
 
     def _body_backward(self, gC):
@@ -426,52 +436,66 @@ class FasterRCNNTrainer(_TrainerBase):
         cfg, N, Ccls = self.cfg, len(images), self.C
         mark = self._mark
         mark("start")
-        u8, rem, Hp, Wp, img_sizes, gts, gt_labels = self._inputs(images, targets)
-        # The RPN targets depend on the anchors and the ground truth only: match + sample them BEFORE the network is enqueued, so the
-        # device->host copy of the match results does not wait for (and the host-side sampling does not stall) the body's kernels.
-        level_hw = [(Hp // 4, Wp // 4), (Hp // 8, Wp // 8), (Hp // 16, Wp // 16), (Hp // 32, Wp // 32)]
-        level_hw.append(((level_hw[3][0] - 1) // 2 + 1, (level_hw[3][1] - 1) // 2 + 1))
-        head_sizes = [N * h * w * 16 for h, w in level_hw]
-        anchors = self.anchors(Hp, Wp, level_hw)
-        A_img = anchors.shape[0]
-        # ---- RPN targets and sampling (anchor order: level, y, x, anchor).  One device->host copy of all match results, host-side
-        # sampling (torch CPU generator), one host->device copy of every index the loss kernels need. ----
-        lvl_start = np.cumsum([0] + [h * w * 3 for h, w in level_hw])
-        head_off = np.cumsum([0] + head_sizes)
-        lvl_pix = np.array([h * w for h, w in level_hw])
-        def head_offsets(img, idx):                                  # float offset of anchor idx's objectness logit in head_flat
-            l = np.searchsorted(lvl_start, idx, side="right") - 1
-            rel = idx - lvl_start[l]
-            pix, a = rel // 3, rel % 3
-            return head_off[l] + (img * lvl_pix[l] + pix) * 16 + a, a
-        n_gt = [int(g.shape[0]) for g in gts]
-        gt_off = np.cumsum([0] + n_gt)
-        gts_all = torch.cat(gts + [torch.zeros((1, 4), device=self.dev)])      # last row: the "matched box" of images without ground truth
-        matched_dev = torch.full((N, A_img), -1, dtype=torch.int32, device=self.dev)
-        for i in range(N):
-            if n_gt[i]:
-                ops.match(anchors, gts[i], cfg["rpn_fg"], cfg["rpn_bg"], True, out=matched_dev[i])
-        matched_all = matched_dev.cpu().numpy()
-        obj_idx, obj_lab, box_idx, anc_idx, gt_idx = [], [], [], [], []
-        rpn_samples, box_samples = [], []
-        for i in range(N):
-            m = matched_all[i]
-            pos, neg = torch.from_numpy(np.flatnonzero(m >= 0)), torch.from_numpy(np.flatnonzero(m == -1))
-            sp, sn = self._sample(pos, neg, cfg["rpn_batch"], cfg["rpn_pos"])
-            sp, sn = np.sort(sp.numpy()), np.sort(sn.numpy())
-            rpn_samples.append((sp, sn))
-            op_, ap_ = head_offsets(i, sp); on_, _ = head_offsets(i, sn)
-            obj_idx += [op_, on_]; obj_lab += [np.ones(len(op_), np.float32), np.zeros(len(on_), np.float32)]
-            box_idx.append(op_ - ap_ + 3 + 4 * ap_)                  # channel 3 + 4a of the same pixel
-            anc_idx.append(sp); gt_idx.append(gt_off[i] + m[sp])
-        obj_idx, box_idx, anc_idx, gt_idx = [np.concatenate(v).astype(np.int64) for v in (obj_idx, box_idx, anc_idx, gt_idx)]
-        packed = torch.from_numpy(np.concatenate([obj_idx, box_idx, anc_idx, gt_idx])).to(self.dev)
-        n_obj, n_pos = len(obj_idx), len(box_idx)
-        obj_idx, box_idx = packed[:n_obj], packed[n_obj:n_obj + n_pos]
-        anc_sel, gt_sel = packed[n_obj + n_pos:n_obj + 2 * n_pos], packed[n_obj + 2 * n_pos:]
-        obj_lab = torch.from_numpy(np.concatenate(obj_lab)).to(self.dev)
-        rpn_tgt = ops.box_encode(gts_all[gt_sel], anchors[anc_sel], (1.0, 1.0, 1.0, 1.0))
-        mark("rpn targets")
+        self._begin_step()
+        u8, rem = self._prepare_images(images)              # on the main stream: the images may have just been produced there
+        aux, prev = self.aux, ops._WGRAD_CTX[0]
+        import contextlib
+        with (torch.cuda.stream(aux[0]) if aux is not None else contextlib.nullcontext()):
+            if aux is not None:
+                ops._WGRAD_CTX[0] = aux[1]
+            try:
+                u8, rem, Hp, Wp, img_sizes, gts, gt_labels = self._inputs(u8, rem, targets)
+                # The RPN targets depend on the anchors and the ground truth only: match + sample them BEFORE the network is enqueued, so the
+                # device->host copy of the match results does not wait for (and the host-side sampling does not stall) the body's kernels.
+                level_hw = [(Hp // 4, Wp // 4), (Hp // 8, Wp // 8), (Hp // 16, Wp // 16), (Hp // 32, Wp // 32)]
+                level_hw.append(((level_hw[3][0] - 1) // 2 + 1, (level_hw[3][1] - 1) // 2 + 1))
+                head_sizes = [N * h * w * 16 for h, w in level_hw]
+                anchors = self.anchors(Hp, Wp, level_hw)
+                A_img = anchors.shape[0]
+                # ---- RPN targets and sampling (anchor order: level, y, x, anchor).  One device->host copy of all match results, host-side
+                # sampling (torch CPU generator), one host->device copy of every index the loss kernels need. ----
+                lvl_start = np.cumsum([0] + [h * w * 3 for h, w in level_hw])
+                head_off = np.cumsum([0] + head_sizes)
+                lvl_pix = np.array([h * w for h, w in level_hw])
+                def head_offsets(img, idx):                                  # float offset of anchor idx's objectness logit in head_flat
+                    l = np.searchsorted(lvl_start, idx, side="right") - 1
+                    rel = idx - lvl_start[l]
+                    pix, a = rel // 3, rel % 3
+                    return head_off[l] + (img * lvl_pix[l] + pix) * 16 + a, a
+                n_gt = [int(g.shape[0]) for g in gts]
+                gt_off = np.cumsum([0] + n_gt)
+                gts_all = torch.cat(gts + [torch.zeros((1, 4), device=self.dev)])      # last row: the "matched box" of images without ground truth
+                matched_dev = torch.full((N, A_img), -1, dtype=torch.int32, device=self.dev)
+                for i in range(N):
+                    if n_gt[i]:
+                        ops.match(anchors, gts[i], cfg["rpn_fg"], cfg["rpn_bg"], True, out=matched_dev[i])
+                matched_all = matched_dev.cpu().numpy()
+                obj_idx, obj_lab, box_idx, anc_idx, gt_idx = [], [], [], [], []
+                rpn_samples, box_samples = [], []
+                for i in range(N):
+                    m = matched_all[i]
+                    pos, neg = torch.from_numpy(np.flatnonzero(m >= 0)), torch.from_numpy(np.flatnonzero(m == -1))
+                    sp, sn = self._sample(pos, neg, cfg["rpn_batch"], cfg["rpn_pos"])
+                    sp, sn = np.sort(sp.numpy()), np.sort(sn.numpy())
+                    rpn_samples.append((sp, sn))
+                    op_, ap_ = head_offsets(i, sp); on_, _ = head_offsets(i, sn)
+                    obj_idx += [op_, on_]; obj_lab += [np.ones(len(op_), np.float32), np.zeros(len(on_), np.float32)]
+                    box_idx.append(op_ - ap_ + 3 + 4 * ap_)                  # channel 3 + 4a of the same pixel
+                    anc_idx.append(sp); gt_idx.append(gt_off[i] + m[sp])
+                obj_idx, box_idx, anc_idx, gt_idx = [np.concatenate(v).astype(np.int64) for v in (obj_idx, box_idx, anc_idx, gt_idx)]
+                packed = torch.from_numpy(np.concatenate([obj_idx, box_idx, anc_idx, gt_idx])).to(self.dev)
+                n_obj, n_pos = len(obj_idx), len(box_idx)
+                obj_idx, box_idx = packed[:n_obj], packed[n_obj:n_obj + n_pos]
+                anc_sel, gt_sel = packed[n_obj + n_pos:n_obj + 2 * n_pos], packed[n_obj + 2 * n_pos:]
+                obj_lab = torch.from_numpy(np.concatenate(obj_lab)).to(self.dev)
+                rpn_tgt = ops.box_encode(gts_all[gt_sel], anchors[anc_sel], (1.0, 1.0, 1.0, 1.0))
+                mark("rpn targets")
+            finally:
+                ops._WGRAD_CTX[0] = prev
+        if aux is not None:                                 # what the main stream consumes from the batch-only stream
+            self._main.wait_stream(aux[0])
+            for t in list(gts) + [gts_all, packed, obj_lab, rpn_tgt]:
+                t.record_stream(self._main)
         feats = self._body(u8, rem, Hp, Wp, img_sizes)
         # FPN (top-down), LastLevelMaxPool
         inner = [None] * 4

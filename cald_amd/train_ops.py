@@ -17,7 +17,7 @@ def _p(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
-_WGRAD_CTX = [None]     # set by train.py while weight gradients / weight packing are issued on the side stream
+_WGRAD_CTX = [None]     # set by train.py while weight gradients / weight packing / target matching are issued on another stream
 
 
 def _wctx(t):
@@ -173,14 +173,14 @@ def match(boxes, gt, hi, lo, allow_low_quality, out=None):
     if out is None:
         out = torch.empty(boxes.shape[0], dtype=torch.int32, device=boxes.device)
     assert boxes.is_contiguous() and out.is_contiguous()
-    _ffi.check(_ffi.lib().cald_train_match(get_ctx(boxes.device.index), boxes.shape[0], _p(boxes), gt.shape[0], _p(gt), hi, lo, int(allow_low_quality),
+    _ffi.check(_ffi.lib().cald_train_match(_wctx(boxes), boxes.shape[0], _p(boxes), gt.shape[0], _p(gt), hi, lo, int(allow_low_quality),
                                            _p(out), None))
     return out
 
 
 def box_encode(reference, proposals, weights):
     out = torch.empty_like(proposals)
-    _ffi.check(_ffi.lib().cald_train_box_encode(get_ctx(proposals.device.index), proposals.shape[0], _p(reference), _p(proposals), *[float(w) for w in weights],
+    _ffi.check(_ffi.lib().cald_train_box_encode(_wctx(proposals), proposals.shape[0], _p(reference), _p(proposals), *[float(w) for w in weights],
                                                 _p(out)))
     return out
 
