@@ -307,6 +307,8 @@ class _TrainerBase(object):
     def anchors(self, Hp, Wp, level_hw):
         key = (Hp, Wp)
         if key not in self._anchors:
+            if len(self._anchors) >= 16:                    # a few MB per padded batch size: keep the cache bounded over a long epoch
+                self._anchors.pop(next(iter(self._anchors)))
             self._anchors[key] = ops.anchors(Hp, Wp, level_hw, self.dev, kind=self.ANCHOR_KIND)
         return self._anchors[key]
 
