@@ -234,32 +234,33 @@ struct WgradArgs {
     int J, JT, MT;
     long long Q, chunk;
 };
-// grid (MT * JT, S), 256 threads = 4 waves (2 x 2), tile 128 (co) x 128 (j = tap * Cin + ci) x 16 output pixels per stage.
+// grid (MT * JT, S), 256 threads = 4 waves (2 x 2), tile 128 (co) x 128 (j = tap * Cin + ci) x BK output pixels per stage.
 // FAST (both tensors < 2 GB): raw buffer loads whose byte offsets advance by additions only; a row outside its image / past the end of
 // the split gets the out-of-range offset and loads zeros -- no branches, no 64-bit multiplies in the loop (the fp32 MFMA shares its
 // issue slots with the VALU: the first version spent a third of the loop on address arithmetic).
 typedef float f32x4v __attribute__((ext_vector_type(4)));
-template <bool FAST>
+template <bool FAST, int BK>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
-    __shared__ __attribute__((aligned(16))) float sA[2][16][128];
-    __shared__ __attribute__((aligned(16))) float sB[2][16][128];
+    constexpr int R = BK / 8;                                    // rows of both tiles staged per thread
+    __shared__ __attribute__((aligned(16))) float sA[2][BK][128];
+    __shared__ __attribute__((aligned(16))) float sB[2][BK][128];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
     const int mt = blockIdx.x / a.JT, jt = blockIdx.x - mt * a.JT;
     const int m0 = mt * 128, j0 = jt * 128;
     const long long q0 = (long long)blockIdx.y * a.chunk;
     long long q1 = q0 + a.chunk; if (q1 > a.Q) q1 = a.Q;
-    const int col4 = (tid & 31) * 4, row = tid >> 5;          // this thread stages rows row, row + 8 of both tiles
+    const int col4 = (tid & 31) * 4, row = tid >> 5;          // this thread stages rows row, row + 8, ... of both tiles
     // B column (fixed for the whole kernel): j -> (tap, ci)
     const int j = j0 + col4;
     const bool jvalid = j < a.J;
     const int tap = jvalid ? j / a.Cin : 0, ci = j - tap * a.Cin;
     const int ky = tap / a.KW, kx = tap - ky * a.KW;
     const bool mvalid = m0 + col4 < a.ldg;
-    // pixel cursors of the two staged rows
-    int pn[2], py[2], px[2];
-    long long pq[2];
+    // pixel cursors of the staged rows
+    int pn[R], py[R], px[R];
+    long long pq[R];
 #pragma unroll
-    for (int r = 0; r < 2; r++) {
+    for (int r = 0; r < R; r++) {
         pq[r] = q0 + row + 8 * r;
         const long long hw = (long long)a.Ho * a.Wo;
         pn[r] = (int)(pq[r] / hw);
@@ -273,18 +274,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
         for (int jn = 0; jn < 2; jn++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][jn][r] = 0.0f;
-    // Two stages of global loads in flight: while stage s is multiplied out of LDS, stage s + 1 sits in one register set (loaded a
-    // whole iteration ago, stored to the other LDS buffer after the MFMAs) and stage s + 2 is being fetched into the other set.
-    float4 ra[2][2], rb[2][2];
+    float4 ra[R], rb[R];
     // FAST-path cursor: byte offsets from the tensor bases, remaining rows of the split, input coordinates of this thread's tap
     const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc((void*)a.g, 0, 0x7FFE0000, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, 0x7FFE0000, 0x00020000);
-    int voffG[2], voffX[2], left[2], fiy[2], fix[2], fpx[2], fpy[2];
-    const int stepG = 16 * a.ldg * 4, stepX = 16 * a.stride * a.ldx * 4, stepI = 16 * a.stride;
+    int voffG[R], voffX[R], left[R], fiy[R], fix[R], fpx[R], fpy[R];
+    const int stepG = BK * a.ldg * 4, stepX = BK * a.stride * a.ldx * 4, stepI = BK * a.stride;
     const int rowX = (a.stride * a.W - a.Wo * a.stride) * a.ldx * 4, imgX = (a.H - a.Ho * a.stride) * a.W * a.ldx * 4;
     if (FAST) {
 #pragma unroll
-        for (int r = 0; r < 2; r++) {
+        for (int r = 0; r < R; r++) {
             voffG[r] = (int)((pq[r] * a.ldg + m0 + col4) * 4);
             left[r] = (int)(q1 - pq[r]);
             fpy[r] = py[r]; fpx[r] = px[r];
@@ -292,18 +291,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
             voffX[r] = (int)(((((long long)pn[r] * a.H + fiy[r]) * a.W + fix[r]) * a.ldx + ci) * 4);
         }
     }
-    auto load = [&](float4* qa, float4* qb) {
+    auto load = [&]() {
         if (FAST) {
 #pragma unroll
-            for (int r = 0; r < 2; r++) {
+            for (int r = 0; r < R; r++) {
                 const bool live = left[r] > 0;
                 const int vg = (live && mvalid) ? voffG[r] : 0x7FFF0000;
                 const bool inimg = fiy[r] >= 0 && fiy[r] < a.H && fix[r] >= 0 && fix[r] < a.W;
                 const int vx = (live && jvalid && inimg) ? voffX[r] : 0x7FFF0000;
-                qa[r] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsG, vg, 0, 0));
-                qb[r] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsX, vx, 0, 0));
-                voffG[r] += stepG; left[r] -= 16;
-                voffX[r] += stepX; fix[r] += stepI; fpx[r] += 16;
+                ra[r] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsG, vg, 0, 0));
+                rb[r] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsX, vx, 0, 0));
+                voffG[r] += stepG; left[r] -= BK;
+                voffX[r] += stepX; fix[r] += stepI; fpx[r] += BK;
                 while (fpx[r] >= a.Wo) {
                     fpx[r] -= a.Wo; fix[r] -= a.Wo * a.stride; voffX[r] += rowX; fiy[r] += a.stride;
                     if (++fpy[r] >= a.Ho) { fpy[r] = 0; fiy[r] -= a.Ho * a.stride; voffX[r] += imgX; }
@@ -312,30 +311,35 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
             return;
         }
 #pragma unroll
-        for (int r = 0; r < 2; r++) {
-            qa[r] = make_float4(0.f, 0.f, 0.f, 0.f); qb[r] = qa[r];
+        for (int r = 0; r < R; r++) {
+            ra[r] = make_float4(0.f, 0.f, 0.f, 0.f); rb[r] = ra[r];
             if (pq[r] < q1) {
-                if (mvalid) qa[r] = *reinterpret_cast<const float4*>(a.g + pq[r] * a.ldg + m0 + col4);
+                if (mvalid) ra[r] = *reinterpret_cast<const float4*>(a.g + pq[r] * a.ldg + m0 + col4);
                 const int iy = py[r] * a.stride + ky - a.pad, ix = px[r] * a.stride + kx - a.pad;
                 if (jvalid && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
-                    qb[r] = *reinterpret_cast<const float4*>(a.x + (((long long)pn[r] * a.H + iy) * a.W + ix) * a.ldx + ci);
+                    rb[r] = *reinterpret_cast<const float4*>(a.x + (((long long)pn[r] * a.H + iy) * a.W + ix) * a.ldx + ci);
             }
-            // advance the cursor by one stage (16 pixels); stages past the end of the split load nothing and contribute zeros
-            pq[r] += 16; px[r] += 16;
+            // advance the cursor by one stage (BK pixels); stages past the end of the split load nothing and contribute zeros
+            pq[r] += BK; px[r] += BK;
             while (px[r] >= a.Wo) { px[r] -= a.Wo; if (++py[r] >= a.Ho) { py[r] = 0; pn[r]++; } }
         }
     };
-    auto store = [&](int buf, const float4* qa, const float4* qb) {
+    auto store = [&](int buf) {
 #pragma unroll
-        for (int r = 0; r < 2; r++) {
-            *reinterpret_cast<float4*>(&sA[buf][row + 8 * r][col4]) = qa[r];
-            *reinterpret_cast<float4*>(&sB[buf][row + 8 * r][col4]) = qb[r];
+        for (int r = 0; r < R; r++) {
+            *reinterpret_cast<float4*>(&sA[buf][row + 8 * r][col4]) = ra[r];
+            *reinterpret_cast<float4*>(&sB[buf][row + 8 * r][col4]) = rb[r];
         }
     };
     const int kl = lane >> 5, cl = lane & 31;
-    auto multiply = [&](int buf) {
+    const int stages = (int)((q1 - q0 + BK - 1) / BK);
+    load(); store(0);
+    __syncthreads();
+    for (int s = 0; s < stages; s++) {
+        const int buf = s & 1;
+        load();                                               // stage s + 1 (zeros past the end)
 #pragma unroll
-        for (int ks = 0; ks < 8; ks++) {
+        for (int ks = 0; ks < BK / 2; ks++) {
             const float a0 = sA[buf][2 * ks + kl][wm * 64 + cl], a1 = sA[buf][2 * ks + kl][wm * 64 + 32 + cl];
             const float b0 = sB[buf][2 * ks + kl][wn * 64 + cl], b1 = sB[buf][2 * ks + kl][wn * 64 + 32 + cl];
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
@@ -343,20 +347,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
         }
-    };
-    const int stages = (int)((q1 - q0 + 15) / 16);
-    load(ra[0], rb[0]); store(0, ra[0], rb[0]);          // stage 0 -> LDS buffer 0
-    load(ra[0], rb[0]);                                   // stage 1 -> register set 0
-    load(ra[1], rb[1]);                                   // stage 2 -> register set 1
-    __syncthreads();
-    for (int s = 0; s < stages; s += 2) {
-        multiply(0);                                      // stage s
-        store(1, ra[0], rb[0]);                           // stage s + 1 -> LDS buffer 1
-        load(ra[0], rb[0]);                               // stage s + 3
-        __syncthreads();
-        multiply(1);                                      // stage s + 1 (zeros when past the end)
-        store(0, ra[1], rb[1]);                           // stage s + 2 -> LDS buffer 0
-        load(ra[1], rb[1]);                               // stage s + 4
+        store(buf ^ 1);
         __syncthreads();
     }
     // partial tile -> partial[S][MT*128][JT*128]
@@ -436,15 +427,18 @@ static int wgrad_impl(cald_ctx* c, long long Q, int N, int H, int W, const float
     const long long maxS_rows = (Q + 255) / 256; if (S > maxS_rows) S = maxS_rows;
     const long long cap = (512ll << 20) / 4 / tile_floats; if (S > cap) S = cap;
     if (S < 1) S = 1;
-    a.chunk = ((Q + S - 1) / S + 15) / 16 * 16;
+    a.chunk = ((Q + S - 1) / S + 31) / 32 * 32;
     S = (Q + a.chunk - 1) / a.chunk;
     const long long csplit = (Q + 255) / 256 > 1024 ? 1024 : (Q + 255) / 256;
     void* scratch = nullptr;
     if (int rc = cald_internal_scratch(c, (size_t)(S * tile_floats + csplit * Cout + 64) * 4, &scratch)) return rc;
     a.partial = (float*)scratch;
     const long long bytesG = Q * ldg * 4, bytesX = (long long)N * H * W * ldx * 4;
-    if (bytesG < 0x7FFE0000ll && bytesX < 0x7FFE0000ll) hipLaunchKernelGGL(wgrad_kernel<true>, dim3((unsigned)tiles, (unsigned)S), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(wgrad_kernel<false>, dim3((unsigned)tiles, (unsigned)S), dim3(256), 0, st, a);
+    static const int bk_env = getenv("CALD_WGRAD_BK") ? atoi(getenv("CALD_WGRAD_BK")) : 16;     // 32-pixel stages measured slower (109 vs 115 TFLOP/s on the largest layer)
+    const bool fast = bytesG < 0x7FFE0000ll && bytesX < 0x7FFE0000ll;
+    if (fast && bk_env == 32) hipLaunchKernelGGL((wgrad_kernel<true, 32>), dim3((unsigned)tiles, (unsigned)S), dim3(256), 0, st, a);
+    else if (fast) hipLaunchKernelGGL((wgrad_kernel<true, 16>), dim3((unsigned)tiles, (unsigned)S), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((wgrad_kernel<false, 16>), dim3((unsigned)tiles, (unsigned)S), dim3(256), 0, st, a);
     const long long nred = (long long)Cout * a.J;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nred + 255) / 256)), dim3(256), 0, st, a.partial, (int)S, tile_floats,
                        (long long)a.JT * 128, Cout, red_cin, red_taps, dw, accumulate);
