@@ -182,6 +182,8 @@ class _TrainerBase(object):
         self.version = 0                                   # bumped whenever the parameters change: packed weights are rebuilt lazily
         sd = {k: (v.detach().float().cpu() if hasattr(v, "detach") else torch.from_numpy(np.asarray(v, np.float32)))
               for k, v in state_dict.items() if not k.endswith("num_batches_tracked")}
+        if not 0 <= trainable_layers <= 4:
+            raise NotImplementedError("trainable_layers must be 0..4 (the reference uses torchvision's default 3; 5 would also train conv1)")
         frozen_layers = ["layer4", "layer3", "layer2", "layer1", "conv1"][trainable_layers:]
         def is_frozen(k):
             if ".bn" in k or "downsample.1" in k or k.startswith("backbone.body.bn1"):

@@ -356,6 +356,30 @@ def test_drop_in_training_loop_updates_like_torch_sgd(T, oracle):
         assert err <= 1e-5, (k, err)
 
 
+@pytest.mark.parametrize("trainable_layers", [0, 4])
+def test_other_trainable_layer_settings_vs_autograd(T, oracle, trainable_layers):
+    """resnet_fpn_backbone(trainable_layers=0 / 4): body frozen entirely / layer 1 trained too -- the set of trainable tensors and
+    every gradient still equal float64 autograd (the data gradient stops exactly where the frozen part begins)."""
+    torch, ops = T
+    from cald_amd import train
+    from oracle import torch_train as tt
+    sd, images, targets = _train_case(torch, n_images=1, seed=30 + trainable_layers)
+    net = train.FasterRCNNTrainer(sd, 21, min_size=160, max_size=256, box_batch=32, trainable_layers=trainable_layers, generator=torch.Generator().manual_seed(3))
+    losses = net.forward(images, targets)
+    grads = {k: v.clone() for k, v in net.backward().items()}
+    ref = tt.TorchTrainFRCNN(sd, 21, min_size=160, max_size=256, trainable_layers=trainable_layers)
+    ref.masks = net.relu_decisions()
+    want, _ = ref.losses(images, targets, [p.cpu() for p in net.last["proposals"]], None, cfg=dict(box_batch=32), samples=net.last["samples"])
+    sum(want.values()).backward()
+    tr = ref.trainable()
+    assert sorted(tr) == sorted(grads) and len(grads) == {0: 30, 4: 82}[trainable_layers]
+    for k, g in grads.items():
+        w = tr[k].grad
+        assert float((g.double().cpu() - w).abs().max()) <= 1e-4 * float(w.abs().max()), k
+    with pytest.raises(NotImplementedError):
+        train.FasterRCNNTrainer(sd, 21, trainable_layers=5)
+
+
 def test_training_step_is_bit_reproducible(T):
     """Same weights, images, targets and sampler seed twice: identical losses AND identical gradients of every tensor, bit for bit --
     with the weight gradients on the side stream and RoIAlign backward scattering through atomics (fixed-point accumulation)."""
