@@ -338,10 +338,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
     for (int s = 0; s < stages; s++) {
         const int buf = s & 1;
         load();                                               // stage s + 1 (zeros past the end)
+        // fragments of k-step ks + 1 are read from LDS before the MFMAs of k-step ks issue (the compiler does not hoist them itself)
+        float fa0 = sA[buf][kl][wm * 64 + cl], fa1 = sA[buf][kl][wm * 64 + 32 + cl];
+        float fb0 = sB[buf][kl][wn * 64 + cl], fb1 = sB[buf][kl][wn * 64 + 32 + cl];
 #pragma unroll
         for (int ks = 0; ks < BK / 2; ks++) {
-            const float a0 = sA[buf][2 * ks + kl][wm * 64 + cl], a1 = sA[buf][2 * ks + kl][wm * 64 + 32 + cl];
-            const float b0 = sB[buf][2 * ks + kl][wn * 64 + cl], b1 = sB[buf][2 * ks + kl][wn * 64 + 32 + cl];
+            const float a0 = fa0, a1 = fa1, b0 = fb0, b1 = fb1;
+            if (ks + 1 < BK / 2) {
+                fa0 = sA[buf][2 * ks + 2 + kl][wm * 64 + cl]; fa1 = sA[buf][2 * ks + 2 + kl][wm * 64 + 32 + cl];
+                fb0 = sB[buf][2 * ks + 2 + kl][wn * 64 + cl]; fb1 = sB[buf][2 * ks + 2 + kl][wn * 64 + 32 + cl];
+            }
+            __builtin_amdgcn_sched_barrier(0);      // keep the reads above the MFMAs: the scheduler otherwise sinks them to their use
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
@@ -423,7 +430,8 @@ static int wgrad_impl(cald_ctx* c, long long Q, int N, int H, int W, const float
     a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.J = KH * KW * Cin; a.JT = (a.J + 127) / 128; a.MT = (Cout + 127) / 128; a.Q = Q;
     const long long tiles = (long long)a.MT * a.JT;
     const long long tile_floats = tiles * 128 * 128;
-    long long S = (2048 + tiles - 1) / tiles;
+    static const long long target = getenv("CALD_WGRAD_TARGET") ? atoll(getenv("CALD_WGRAD_TARGET")) : 2048;     // workgroups aimed at per launch
+    long long S = (target + tiles - 1) / tiles;
     const long long maxS_rows = (Q + 255) / 256; if (S > maxS_rows) S = maxS_rows;
     const long long cap = (512ll << 20) / 4 / tile_floats; if (S > cap) S = cap;
     if (S < 1) S = 1;
