@@ -115,6 +115,7 @@ class _Conv(object):
     def bwd(self, g, need_dx=True, residual=None, accumulate=False, x=None):
         """g: gradient wrt this layer's conv output (after the caller applied ReLU mask / BN scale), row stride out_ld."""
         x = self.x if x is None else x
+        accumulate = accumulate or self.net.accumulate_grads
         self._count(x, 2 if need_dx else 1)
         side, prev = self.net.side, ops._WGRAD_CTX[0]
         if side is not None:            # the weight gradient depends on (x, g) only: issue it beside the data gradient
@@ -240,6 +241,7 @@ class _TrainerBase(object):
         self.last = None
         self.timing = None          # set to a list to collect (section, wall-clock) marks of forward(); each mark synchronizes
         self.flops = None           # set to 0.0 to accumulate the algorithmic GEMM FLOPs of forward() + backward()
+        self.accumulate_grads = False   # True: backward() adds to the flat gradient buffer (autograd's semantics when .grad is already set)
         # weight gradients run on a second stream: at batch 4 most layers fill a fraction of the 256 CUs, and dW / dX of one layer
         # are independent.  CALD_TRAIN_SIDE_STREAM=0 keeps everything on one stream.
         self.side = self.aux = None
@@ -799,13 +801,22 @@ class _LossFn(torch.autograd.Function):
     def backward(ctx, *gs):
         net = ctx.net
         gscale = [0.0 if g is None else float(g) for g in gs]
-        net.backward(gscale)
+        # autograd semantics: a parameter whose .grad is set (no zero_grad since the last backward, or zero_grad(set_to_none=False))
+        # accumulates.  The .grad tensors ARE views of the flat gradient buffer, so accumulation happens inside the kernels.
+        mine = [p.grad is not None and p.grad.data_ptr() == net.grads[k].data_ptr() for k, p in net.params.items()]
+        foreign = [k for k, p in net.params.items() if p.grad is not None and p.grad.data_ptr() != net.grads[k].data_ptr()]
+        if foreign:
+            raise RuntimeError("parameter .grad was replaced by another tensor (%s ...): use zero_grad() between steps" % foreign[0])
+        if any(mine) and not all(mine):
+            raise RuntimeError("some parameters carry a gradient and some do not: call zero_grad() on all of them")
+        net.accumulate_grads = all(mine)
+        try:
+            net.backward(gscale)
+        finally:
+            net.accumulate_grads = False
         for k in net.names:
-            p = net.params[k]
-            if p.grad is None:
-                p.grad = net.grads[k]
-            elif p.grad.data_ptr() != net.grads[k].data_ptr():
-                p.grad.add_(net.grads[k])
+            if net.params[k].grad is None:
+                net.params[k].grad = net.grads[k]
         return None, None, None, None
 
 

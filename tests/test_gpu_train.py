@@ -380,6 +380,29 @@ def test_other_trainable_layer_settings_vs_autograd(T, oracle, trainable_layers)
         train.FasterRCNNTrainer(sd, 21, trainable_layers=5)
 
 
+def test_gradient_accumulation_follows_autograd_semantics(T):
+    """backward() twice without zero_grad() adds (here: exactly doubles, same batch and samples); zero_grad() starts over."""
+    torch, ops = T
+    from cald_amd import train
+    sd, images, targets = _train_case(torch, n_images=2, seed=17)
+    net = train.FasterRCNNTrainer(sd, 21, min_size=160, max_size=256, box_batch=64, generator=torch.Generator())
+    model = train.TrainableDetector(net)
+    params = dict(net.named_parameters())
+    def step():
+        net.generator.manual_seed(9)
+        sum(model(images, targets).values()).backward()
+    step()
+    once = {k: p.grad.clone() for k, p in params.items()}
+    step()
+    for k, p in params.items():          # (tensors shared by five pyramid levels add level by level: equal to float32 rounding, not bitwise)
+        assert float((p.grad - 2 * once[k]).abs().max()) <= 1e-5 * float(once[k].abs().max()), k
+    for p in params.values():
+        p.grad = None
+    step()
+    for k, p in params.items():
+        assert torch.equal(p.grad, once[k]), k
+
+
 def test_training_step_is_bit_reproducible(T):
     """Same weights, images, targets and sampler seed twice: identical losses AND identical gradients of every tensor, bit for bit --
     with the weight gradients on the side stream and RoIAlign backward scattering through atomics (fixed-point accumulation)."""
