@@ -668,9 +668,63 @@ class RetinaNetTrainer(_TrainerBase):
     def forward(self, images, targets):
         N, K, mark = len(images), self.K, self._mark
         mark("start")
-        feats, Hp, Wp, img_sizes, gts, gt_labels = self._inputs_and_body(images, targets)
-        if any(g.shape[0] == 0 for g in gts):
-            raise ValueError("RetinaNet training needs at least one ground-truth box per image (retinanet_cal.py:110-124)")
+        self._begin_step()
+        u8, rem = self._prepare_images(images)              # on the main stream: the images may have just been produced there
+        # Everything that depends on the batch only (ground-truth upload, anchor matching, regression targets) goes first, on its own
+        # stream: the device->host copy of the match results then does not wait for the network's kernels.
+        aux, prev = self.aux, ops._WGRAD_CTX[0]
+        import contextlib
+        with (torch.cuda.stream(aux[0]) if aux is not None else contextlib.nullcontext()):
+            if aux is not None:
+                ops._WGRAD_CTX[0] = aux[1]
+            try:
+                u8, rem, Hp, Wp, img_sizes, gts, gt_labels = self._inputs(u8, rem, targets)
+                if any(g.shape[0] == 0 for g in gts):
+                    raise ValueError("RetinaNet training needs at least one ground-truth box per image (retinanet_cal.py:110-124)")
+                level_hw = [(Hp // 8, Wp // 8), (Hp // 16, Wp // 16), (Hp // 32, Wp // 32)]
+                for _ in range(2):                              # P6, P7: 3x3 stride-2 convs with padding 1
+                    level_hw.append(((level_hw[-1][0] - 1) // 2 + 1, (level_hw[-1][1] - 1) // 2 + 1))
+                level_pix = [h * w for h, w in level_hw]
+                cls_sizes, reg_sizes = [N * n * self.cls_ld for n in level_pix], [N * n * 36 for n in level_pix]
+                anchors = self.anchors(Hp, Wp, level_hw)
+                A_tot = anchors.shape[0]
+                matched_dev = torch.empty((N, A_tot), dtype=torch.int32, device=self.dev)
+                for i in range(N):
+                    ops.match(anchors, gts[i], self.cfg["fg"], self.cfg["bg"], True, out=matched_dev[i])
+                matched_all = matched_dev.cpu().numpy()
+                n_gt = [int(g.shape[0]) for g in gts]
+                gt_off = np.cumsum([0] + n_gt)
+                gts_all = torch.cat(gts)
+                lvl_start = np.cumsum([0] + [n * 9 for n in level_pix])
+                reg_off = np.cumsum([0] + reg_sizes)
+                lvl_pix = np.array(level_pix)
+                box_idx, anc_idx, gt_idx, wts, nfg = [], [], [], [], []
+                for i in range(N):
+                    m = matched_all[i]
+                    fg = np.flatnonzero(m >= 0)
+                    l = np.searchsorted(lvl_start, fg, side="right") - 1
+                    rel = fg - lvl_start[l]
+                    pix, a = rel // 9, rel % 9
+                    box_idx.append(reg_off[l] + (i * lvl_pix[l] + pix) * 36 + 4 * a)
+                    anc_idx.append(fg); gt_idx.append(gt_off[i] + m[fg])
+                    nfg.append(len(fg)); wts.append(np.full(len(fg), 1.0 / (max(1, len(fg)) * N), np.float32))
+                box_idx, anc_idx, gt_idx = [np.concatenate(v).astype(np.int64) for v in (box_idx, anc_idx, gt_idx)]
+                packed = torch.from_numpy(np.concatenate([box_idx, anc_idx, gt_idx])).to(self.dev)
+                nb = len(box_idx)
+                box_idx, anc_sel, gt_sel = packed[:nb], packed[nb:2 * nb], packed[2 * nb:]
+                fl = torch.from_numpy(np.concatenate([np.concatenate(wts), np.array([1.0 / (max(1, n) * N) for n in nfg], np.float32)])).to(self.dev)
+                box_w, img_w = fl[:nb], fl[nb:]
+                reg_tgt = ops.box_encode(gts_all[gt_sel], anchors[anc_sel], (1.0, 1.0, 1.0, 1.0))
+                gt_labels_dev = torch.cat(gt_labels).to(self.dev)
+                gt_off_dev = torch.from_numpy(gt_off.astype(np.int32)).to(self.dev)
+            finally:
+                ops._WGRAD_CTX[0] = prev
+        if aux is not None:
+            self._main.wait_stream(aux[0])
+            for t in list(gts) + [gts_all, packed, fl, reg_tgt, matched_dev, gt_labels_dev, gt_off_dev]:
+                t.record_stream(self._main)
+        mark("targets")
+        feats = self._body(u8, rem, Hp, Wp, img_sizes)
         inner = [None] * 3
         inner[2] = self.lat[2].fwd(feats[3])
         for i in (1, 0):
@@ -679,10 +733,8 @@ class RetinaNetTrainer(_TrainerBase):
         P.append(self.p6.fwd(P[2]))
         p6_relu = ops.relu_bwd_(ops.add(P[3]), P[3])                       # relu(p6): x * (x > 0) on a copy
         P.append(self.p7.fwd(p6_relu))
-        level_hw = [(p.shape[1], p.shape[2]) for p in P]
-        level_pix = [h * w for h, w in level_hw]
+        assert level_hw == [(p.shape[1], p.shape[2]) for p in P]
         # head outputs of the five levels in ONE buffer each (level block l = [N][pix_l][ld])
-        cls_sizes, reg_sizes = [N * n * self.cls_ld for n in level_pix], [N * n * 36 for n in level_pix]
         cls_flat = torch.zeros(sum(cls_sizes), dtype=torch.float32, device=self.dev)
         reg_flat = torch.empty(sum(reg_sizes), dtype=torch.float32, device=self.dev)
         acts = {"cls": [], "reg": []}
@@ -701,38 +753,6 @@ class RetinaNetTrainer(_TrainerBase):
                     ops.conv(xs[-1], out_conv._packed(), pad=1, out=reg_flat[orr:orr + reg_sizes[l]].view(N, h, w, 36), out_ld=36)
             oc += cls_sizes[l]; orr += reg_sizes[l]
         mark("fpn+heads")
-        anchors = self.anchors(Hp, Wp, level_hw)
-        A_tot = anchors.shape[0]
-        matched_dev = torch.empty((N, A_tot), dtype=torch.int32, device=self.dev)
-        for i in range(N):
-            ops.match(anchors, gts[i], self.cfg["fg"], self.cfg["bg"], True, out=matched_dev[i])
-        matched_all = matched_dev.cpu().numpy()
-        n_gt = [int(g.shape[0]) for g in gts]
-        gt_off = np.cumsum([0] + n_gt)
-        gts_all = torch.cat(gts)
-        lvl_start = np.cumsum([0] + [n * 9 for n in level_pix])
-        reg_off = np.cumsum([0] + reg_sizes)
-        lvl_pix = np.array(level_pix)
-        box_idx, anc_idx, gt_idx, wts, nfg = [], [], [], [], []
-        for i in range(N):
-            m = matched_all[i]
-            fg = np.flatnonzero(m >= 0)
-            l = np.searchsorted(lvl_start, fg, side="right") - 1
-            rel = fg - lvl_start[l]
-            pix, a = rel // 9, rel % 9
-            box_idx.append(reg_off[l] + (i * lvl_pix[l] + pix) * 36 + 4 * a)
-            anc_idx.append(fg); gt_idx.append(gt_off[i] + m[fg])
-            nfg.append(len(fg)); wts.append(np.full(len(fg), 1.0 / (max(1, len(fg)) * N), np.float32))
-        box_idx, anc_idx, gt_idx = [np.concatenate(v).astype(np.int64) for v in (box_idx, anc_idx, gt_idx)]
-        packed = torch.from_numpy(np.concatenate([box_idx, anc_idx, gt_idx])).to(self.dev)
-        nb = len(box_idx)
-        box_idx, anc_sel, gt_sel = packed[:nb], packed[nb:2 * nb], packed[2 * nb:]
-        fl = torch.from_numpy(np.concatenate([np.concatenate(wts), np.array([1.0 / (max(1, n) * N) for n in nfg], np.float32)])).to(self.dev)
-        box_w, img_w = fl[:nb], fl[nb:]
-        reg_tgt = ops.box_encode(gts_all[gt_sel], anchors[anc_sel], (1.0, 1.0, 1.0, 1.0))
-        gt_labels_dev = torch.cat(gt_labels).to(self.dev)
-        gt_off_dev = torch.from_numpy(gt_off.astype(np.int32)).to(self.dev)
-        mark("targets")
         self.last = dict(N=N, P=P, p6_relu=p6_relu, feats=feats, inner=inner, acts=acts, level_hw=level_hw, level_pix=level_pix, cls_flat=cls_flat, reg_flat=reg_flat,
                          cls_sizes=cls_sizes, reg_sizes=reg_sizes, matched=matched_dev, gt_labels=gt_labels_dev, gt_off=gt_off_dev, img_w=img_w, box_idx=box_idx,
                          box_w=box_w, reg_tgt=reg_tgt, matched_host=matched_all)
