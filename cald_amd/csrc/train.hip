@@ -223,6 +223,39 @@ extern "C" int cald_train_conv(cald_ctx* c, int N, int H, int W, const float* in
     return 0;
 }
 
+// The same layer shape applied to several tensors in ONE launch (the pyramid levels under shared-weight heads; problems may carry
+// different weights of equal shape, e.g. RetinaNet's two towers): workgroups of the small levels fill the tail of the large ones.
+// Falls back to one launch per problem when the shape does not qualify for the grouped kernel (conv_p4.hip launch_conv_p4_group).
+extern "C" int cald_train_conv_group(cald_ctx* c, int n, int N, const int* hw, const float* const* ins, int CinK, const float* const* packed,
+                                     int Cout, int Cin, int KH, int KW, int stride, int pad, int mode, int flags, float* const* outs, int out_ld) {
+    if (!c || !hw || !ins || !packed || !outs) TFAIL(CALD_ERR_INVALID, "null argument");
+    if (n < 1 || n > CALD_MAX_GROUP) TFAIL(CALD_ERR_INVALID, "1..%d problems per group", CALD_MAX_GROUP);
+    THIP(hipSetDevice(cald_internal_device(c)));
+    const PackGeom g = pack_geom(Cout, Cin, KH, KW, CinK, mode);
+    const int kh = mode >= 2 ? 1 : KH, kw = mode >= 2 ? 1 : KW;
+    if (out_ld < g.n_true) TFAIL(CALD_ERR_INVALID, "out_ld < Cout");
+    ConvArgs probs[CALD_MAX_GROUP];
+    const long long nw = (long long)g.Kpad * g.NPad;
+    for (int i = 0; i < n; i++) {
+        const int H = hw[2 * i], W = hw[2 * i + 1];
+        const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
+        if (H < 1 || W < 1 || Ho < 1 || Wo < 1 || !ins[i] || !outs[i] || !packed[i]) TFAIL(CALD_ERR_INVALID, "bad problem %d", i);
+        const LevelSeg *si, *so;
+        if (int rc = dense_seg(c, N, H, W, &si)) return rc;
+        if (int rc = dense_seg(c, N, Ho, Wo, &so)) return rc;
+        ConvArgs& a = probs[i]; memset(&a, 0, sizeof(a));
+        a.in = ins[i]; a.out = outs[i]; a.w = packed[i]; a.w4 = packed[i] + nw;
+        const float* vec = packed[i] + 2 * nw;
+        a.bias = (flags & 1) ? vec : nullptr; a.scale = (flags & 2) ? vec + g.NPad : nullptr; a.shift = (flags & 2) ? vec + 2 * g.NPad : nullptr;
+        a.seg_in = si; a.seg_out = so; a.seg_up = so;
+        a.V = N; a.Cin = g.cin_conv; a.Cout = g.n_true; a.CoutPad = g.NPad; a.Kpad = g.Kpad; a.KH = kh; a.KW = kw; a.stride = stride; a.pad = pad;
+        a.relu = (flags & 4) ? 1 : 0; a.total_mtiles = N * ((Ho * Wo + 127) / 128); a.out_ld = out_ld; a.zeros = cald_internal_zeros(c);
+    }
+    launch_conv_group(probs, n, cald_internal_stream(c));
+    THIP(hipGetLastError());
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // weight gradient
 // ---------------------------------------------------------------------------------------------------------------------

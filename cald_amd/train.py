@@ -513,12 +513,11 @@ class FasterRCNNTrainer(_TrainerBase):
         assert level_hw == [(p.shape[1], p.shape[2]) for p in P]
         # RPN head on the five levels: outputs in ONE buffer so that the loss kernels address (level, pixel, channel) by offset
         head_flat = torch.zeros(sum(head_sizes), dtype=torch.float32, device=self.dev)
-        heads, tl, o = [], [], 0
+        heads, o = [], 0
+        tl = ops.conv_group(P, self.rpn_conv._packed(), pad=1, relu=True)            # shared 3x3 conv on the five levels: one launch
         for i, (h, w) in enumerate(level_hw):
-            t = ops.conv(P[i], self.rpn_conv._packed(), pad=1, relu=True)
-            tl.append(t)
-            heads.append(ops.conv(t, self.rpn_head._packed(), out=head_flat[o:o + head_sizes[i]].view(N, h, w, 16), out_ld=16))
-            self.rpn_conv._count(P[i], 1); self.rpn_head._count(t, 1)
+            heads.append(ops.conv(tl[i], self.rpn_head._packed(), out=head_flat[o:o + head_sizes[i]].view(N, h, w, 16), out_ld=16))
+            self.rpn_conv._count(P[i], 1); self.rpn_head._count(tl[i], 1)
             o += head_sizes[i]
         mark("fpn+rpn head")
         if proposals_override is None:
@@ -615,11 +614,14 @@ class FasterRCNNTrainer(_TrainerBase):
         ghead_flat = torch.zeros_like(L["head_flat"])
         ops.bce_logits(L["head_flat"], L["obj_idx"], L["obj_lab"], grad=ghead_flat, gscale=gscale[2])
         ops.smooth_l1(L["head_flat"], L["box_idx"], L["rpn_tgt"], 1.0 / 9, L["obj_idx"].numel(), grad=ghead_flat, gscale=gscale[3])
-        o, gpool = 0, None
+        o, gpool, ghs = 0, None, []
         for i, (h, w) in enumerate(level_hw):
-            gh = ghead_flat[o:o + L["head_sizes"][i]].view(N, h, w, 16); o += L["head_sizes"][i]
-            gt = self.rpn_head.bwd(gh, accumulate=i > 0, x=L["tl"][i])
-            ops.relu_bwd_(gt, L["tl"][i])
+            ghs.append(ghead_flat[o:o + L["head_sizes"][i]].view(N, h, w, 16)); o += L["head_sizes"][i]
+            self.rpn_head.bwd(ghs[i], need_dx=False, accumulate=i > 0, x=L["tl"][i])
+            self.rpn_head._count(L["tl"][i], 1)
+        gts_ = ops.conv_group(ghs, self.rpn_head._packed_grad())                         # 1x1 head: data gradient of the five levels in one launch
+        for i in range(5):
+            gt = ops.relu_bwd_(gts_[i], L["tl"][i])
             if i < 4:
                 gP[i] = self.rpn_conv.bwd(gt, residual=gP[i], accumulate=i > 0, x=P[i])
             else:
@@ -737,21 +739,22 @@ class RetinaNetTrainer(_TrainerBase):
         # head outputs of the five levels in ONE buffer each (level block l = [N][pix_l][ld])
         cls_flat = torch.zeros(sum(cls_sizes), dtype=torch.float32, device=self.dev)
         reg_flat = torch.empty(sum(reg_sizes), dtype=torch.float32, device=self.dev)
-        acts = {"cls": [], "reg": []}
+        # both towers on the five levels: ten problems of one shape per launch (the small levels fill the tail of the large ones)
+        acts = {"cls": [[P[l]] for l in range(5)], "reg": [[P[l]] for l in range(5)]}
+        for j in range(4):
+            xs = [acts["cls"][l][-1] for l in range(5)] + [acts["reg"][l][-1] for l in range(5)]
+            ys = ops.conv_group(xs, [self.cls_tower[j]._packed()] * 5 + [self.reg_tower[j]._packed()] * 5, pad=1, relu=True)
+            for l in range(5):
+                self.cls_tower[j]._count(xs[l], 1); self.reg_tower[j]._count(xs[5 + l], 1)
+                acts["cls"][l].append(ys[l]); acts["reg"][l].append(ys[5 + l])
         oc = orr = 0
+        cls_views, reg_views = [], []
         for l, (h, w) in enumerate(level_hw):
-            for name, tower, out_conv in (("cls", self.cls_tower, self.cls_out), ("reg", self.reg_tower, self.reg_out)):
-                xs = [P[l]]
-                for cv in tower:
-                    cv._count(xs[-1], 1)
-                    xs.append(ops.conv(xs[-1], cv._packed(), pad=1, relu=True))
-                out_conv._count(xs[-1], 1)
-                acts[name].append(xs)
-                if name == "cls":
-                    ops.conv(xs[-1], out_conv._packed(), pad=1, out=cls_flat[oc:oc + cls_sizes[l]].view(N, h, w, self.cls_ld), out_ld=self.cls_ld)
-                else:
-                    ops.conv(xs[-1], out_conv._packed(), pad=1, out=reg_flat[orr:orr + reg_sizes[l]].view(N, h, w, 36), out_ld=36)
+            cls_views.append(cls_flat[oc:oc + cls_sizes[l]].view(N, h, w, self.cls_ld)); reg_views.append(reg_flat[orr:orr + reg_sizes[l]].view(N, h, w, 36))
             oc += cls_sizes[l]; orr += reg_sizes[l]
+            self.cls_out._count(acts["cls"][l][4], 1); self.reg_out._count(acts["reg"][l][4], 1)
+        ops.conv_group([acts["cls"][l][4] for l in range(5)], self.cls_out._packed(), pad=1, outs=cls_views, out_ld=self.cls_ld)
+        ops.conv_group([acts["reg"][l][4] for l in range(5)], self.reg_out._packed(), pad=1, outs=reg_views, out_ld=36)
         mark("fpn+heads")
         self.last = dict(N=N, P=P, p6_relu=p6_relu, feats=feats, inner=inner, acts=acts, level_hw=level_hw, level_pix=level_pix, cls_flat=cls_flat, reg_flat=reg_flat,
                          cls_sizes=cls_sizes, reg_sizes=reg_sizes, matched=matched_dev, gt_labels=gt_labels_dev, gt_off=gt_off_dev, img_w=img_w, box_idx=box_idx,
@@ -777,20 +780,29 @@ class RetinaNetTrainer(_TrainerBase):
         gcls = torch.zeros_like(L["cls_flat"]); greg = torch.zeros_like(L["reg_flat"])
         ops.focal_loss(L["cls_flat"], L["level_pix"], N, 9, self.K, self.cls_ld, L["matched"], L["gt_labels"], L["gt_off"], L["img_w"], grad=gcls, gscale=gscale[0])
         ops.smooth_l1(L["reg_flat"], L["box_idx"], L["reg_tgt"], 0.0, 1.0, weights=L["box_w"], grad=greg, gscale=gscale[1])
-        gP = [None] * 5
+        # heads: weight gradients level by level (shared weights accumulate; they run on the side stream), data gradients of one layer of
+        # BOTH towers on all five levels in one grouped launch
         oc = orr = 0
+        g_cls, g_reg = [], []
         for l, (h, w) in enumerate(level_hw):
-            for name, tower, out_conv in (("cls", self.cls_tower, self.cls_out), ("reg", self.reg_tower, self.reg_out)):
-                xs = L["acts"][name][l]
-                if name == "cls":
-                    g = out_conv.bwd(gcls[oc:oc + L["cls_sizes"][l]].view(N, h, w, self.cls_ld), accumulate=l > 0, x=xs[4])
-                else:
-                    g = out_conv.bwd(greg[orr:orr + L["reg_sizes"][l]].view(N, h, w, 36), accumulate=l > 0, x=xs[4])
-                for j in (3, 2, 1, 0):
-                    ops.relu_bwd_(g, xs[j + 1])
-                    g = tower[j].bwd(g, accumulate=l > 0, x=xs[j], residual=(gP[l] if j == 0 else None))
-                gP[l] = g
+            g_cls.append(gcls[oc:oc + L["cls_sizes"][l]].view(N, h, w, self.cls_ld)); g_reg.append(greg[orr:orr + L["reg_sizes"][l]].view(N, h, w, 36))
             oc += L["cls_sizes"][l]; orr += L["reg_sizes"][l]
+        acts = L["acts"]
+        for l in range(5):
+            self.cls_out.bwd(g_cls[l], need_dx=False, accumulate=l > 0, x=acts["cls"][l][4])
+            self.reg_out.bwd(g_reg[l], need_dx=False, accumulate=l > 0, x=acts["reg"][l][4])
+            self.cls_out._count(acts["cls"][l][4], 1); self.reg_out._count(acts["reg"][l][4], 1)
+        g_cls = ops.conv_group(g_cls, self.cls_out._packed_grad(), pad=1)
+        g_reg = ops.conv_group(g_reg, self.reg_out._packed_grad(), pad=1)
+        for j in (3, 2, 1, 0):
+            for l in range(5):
+                ops.relu_bwd_(g_cls[l], acts["cls"][l][j + 1]); ops.relu_bwd_(g_reg[l], acts["reg"][l][j + 1])
+                self.cls_tower[j].bwd(g_cls[l], need_dx=False, accumulate=l > 0, x=acts["cls"][l][j])
+                self.reg_tower[j].bwd(g_reg[l], need_dx=False, accumulate=l > 0, x=acts["reg"][l][j])
+                self.cls_tower[j]._count(acts["cls"][l][j], 1); self.reg_tower[j]._count(acts["reg"][l][j], 1)
+            gs = ops.conv_group(g_cls + g_reg, [self.cls_tower[j]._packed_grad()] * 5 + [self.reg_tower[j]._packed_grad()] * 5, pad=1)
+            g_cls, g_reg = gs[:5], gs[5:]
+        gP = [ops.add(g_cls[l], g_reg[l]) for l in range(5)]
         g6 = self.p7.bwd(gP[4], x=L["p6_relu"])
         ops.relu_bwd_(g6, P[3])
         g6 = ops.add(g6, gP[3])

@@ -85,6 +85,28 @@ def conv(x, pk, stride=1, pad=0, relu=False, residual=None, up=None, out=None, o
     return out
 
 
+def conv_group(xs, pks, stride=1, pad=0, relu=False, outs=None, out_ld=None):
+    """The same layer shape on several NHWC tensors in one launch; pks: one PackedConv per tensor (all of one shape) or a single one."""
+    if not isinstance(pks, (list, tuple)):
+        pks = [pks] * len(xs)
+    pk = pks[0]
+    n_out = pk.Cin if pk.mode == 1 else pk.Cout
+    ld = out_ld if out_ld is not None else n_out
+    res = []
+    for i, x in enumerate(xs):
+        _chk(x, "x")
+        assert x.shape[3] == pk.CinK and x.shape[0] == xs[0].shape[0]
+        Ho, Wo = (x.shape[1] + 2 * pad - pk.KH) // stride + 1, (x.shape[2] + 2 * pad - pk.KW) // stride + 1
+        o = outs[i] if outs is not None else (torch.zeros if ld != n_out else torch.empty)((x.shape[0], Ho, Wo, ld), dtype=torch.float32, device=x.device)
+        res.append(o)
+    hw = [v for x in xs for v in (x.shape[1], x.shape[2])]
+    flags = pk.flags | (FLAG_RELU if relu else 0)
+    _ffi.check(_ffi.lib().cald_train_conv_group(get_ctx(xs[0].device.index), len(xs), xs[0].shape[0], _int_array(hw), _ptr_array(xs), pk.CinK,
+                                                _ptr_array([p.buf for p in pks]), pk.Cout, pk.Cin, pk.KH, pk.KW, stride, pad, pk.mode, flags,
+                                                _ptr_array(res), ld))
+    return res
+
+
 def dilate(g, s, Hd, Wd):
     N, Ho, Wo, Cc = g.shape
     out = torch.empty((N, Hd, Wd, Cc), dtype=torch.float32, device=g.device)
