@@ -322,6 +322,18 @@ class _TrainerBase(object):
         num_neg = min(batch - num_pos, neg.numel())
         return pos[choose_k(pos.numel(), num_pos, self.generator)], neg[choose_k(neg.numel(), num_neg, self.generator)]
 
+    def _fpn_out_fwd(self, inner):
+        """The FPN output 3x3 convs (one weight per level) of all levels in one grouped launch."""
+        for cv, x in zip(self.fout, inner):
+            cv.x = x; cv._count(x, 1)
+        return ops.conv_group(inner, [cv._packed() for cv in self.fout], pad=1)
+
+    def _fpn_out_bwd(self, gP):
+        """Weight gradients per level (side stream), data gradients of all levels in one grouped launch."""
+        for cv, g in zip(self.fout, gP):
+            cv.bwd(g, need_dx=False); cv._count(cv.x, 1)
+        return ops.conv_group(gP, [cv._packed_grad() for cv in self.fout], pad=1)
+
     def _mark(self, name):
         if self.timing is not None:
             torch.cuda.synchronize(self.dev); self.timing.append((name, __import__("time").time()))
@@ -508,7 +520,7 @@ class FasterRCNNTrainer(_TrainerBase):
         inner[3] = self.lat[3].fwd(feats[3])
         for i in (2, 1, 0):
             inner[i] = self.lat[i].fwd(feats[i], up=inner[i + 1])
-        P = [self.fout[i].fwd(inner[i]) for i in range(4)]
+        P = self._fpn_out_fwd(inner)
         P.append(ops.subsample2(P[3]))
         assert level_hw == [(p.shape[1], p.shape[2]) for p in P]
         # RPN head on the five levels: outputs in ONE buffer so that the loss kernels address (level, pixel, channel) by offset
@@ -628,11 +640,9 @@ class FasterRCNNTrainer(_TrainerBase):
                 gpool = self.rpn_conv.bwd(gt, accumulate=True, x=P[4])
         gP[3] = ops.add(gP[3], ops.dilate(gpool, 2, P[3].shape[1], P[3].shape[2]))          # LastLevelMaxPool (kernel 1, stride 2)
         # FPN
-        ginner = [None] * 4
-        for i in range(4):
-            ginner[i] = self.fout[i].bwd(gP[i])
-            if i > 0:
-                ops.upsample_bwd_(ginner[i - 1], ginner[i])
+        ginner = self._fpn_out_bwd(gP[:4])
+        for i in range(1, 4):
+            ops.upsample_bwd_(ginner[i - 1], ginner[i])
         gC = [None] * 4
         for i in range(4):
             need = self.layers[i][0]                                                       # the body layer producing feats[i] is trainable
@@ -731,7 +741,7 @@ class RetinaNetTrainer(_TrainerBase):
         inner[2] = self.lat[2].fwd(feats[3])
         for i in (1, 0):
             inner[i] = self.lat[i].fwd(feats[i + 1], up=inner[i + 1])
-        P = [self.fout[i].fwd(inner[i]) for i in range(3)]
+        P = self._fpn_out_fwd(inner)
         P.append(self.p6.fwd(P[2]))
         p6_relu = ops.relu_bwd_(ops.add(P[3]), P[3])                       # relu(p6): x * (x > 0) on a copy
         P.append(self.p7.fwd(p6_relu))
@@ -807,11 +817,9 @@ class RetinaNetTrainer(_TrainerBase):
         ops.relu_bwd_(g6, P[3])
         g6 = ops.add(g6, gP[3])
         gP[2] = ops.add(gP[2], self.p6.bwd(g6, x=P[2]))
-        ginner = [None] * 3
-        for i in range(3):
-            ginner[i] = self.fout[i].bwd(gP[i])
-            if i > 0:
-                ops.upsample_bwd_(ginner[i - 1], ginner[i])
+        ginner = self._fpn_out_bwd(gP[:3])
+        for i in range(1, 3):
+            ops.upsample_bwd_(ginner[i - 1], ginner[i])
         gC = [None] * 4
         for i in range(3):
             gC[i + 1] = self.lat[i].bwd(ginner[i], need_dx=self.layers[i + 1][0])
