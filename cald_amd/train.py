@@ -611,17 +611,29 @@ class FasterRCNNTrainer(_TrainerBase):
         """Gradients of sum_i gscale[i] * loss_i (order: classifier, box_reg, objectness, rpn_box_reg) into the flat gradient buffer."""
         L = self.last
         N, R, P, level_hw = L["N"], L["R"], L["P"], L["level_hw"]
-        # box head
-        gpred = torch.zeros_like(L["pred"])
-        ops.softmax_ce(L["pred"].view(R, -1), L["labels"], self.C, grad=gpred, gscale=gscale[0])
-        ops.smooth_l1(L["pred"], L["pred_idx"], L["box_tgt"], 1.0 / 9, R, grad=gpred, gscale=gscale[1])
-        g7 = self.pred.bwd(gpred)
-        ops.relu_bwd_(g7, L["f7"])
-        g6 = self.fc7.bwd(g7)
-        ops.relu_bwd_(g6, L["f6"])
-        groi = self.fc6.bwd(g6)
-        gP = [torch.zeros_like(p) for p in P[:4]]
-        ops.roi_align_bwd_(gP, L["rois"], groi.view(R, 49, -1))
+        # The box-head branch (predictor -> fc7 -> fc6 -> RoIAlign backward) and the RPN branch meet only at the FPN outputs: the former
+        # is issued on the batch-only stream (idle during the backward pass), the latter on the main stream.
+        import contextlib
+        aux, prev = self.aux, ops._WGRAD_CTX[0]
+        main = torch.cuda.current_stream(self.dev)
+        if aux is not None:
+            aux[0].wait_stream(main)
+        with (torch.cuda.stream(aux[0]) if aux is not None else contextlib.nullcontext()):
+            if aux is not None:
+                ops._WGRAD_CTX[0] = aux[1]
+            try:
+                gpred = torch.zeros_like(L["pred"])
+                ops.softmax_ce(L["pred"].view(R, -1), L["labels"], self.C, grad=gpred, gscale=gscale[0])
+                ops.smooth_l1(L["pred"], L["pred_idx"], L["box_tgt"], 1.0 / 9, R, grad=gpred, gscale=gscale[1])
+                g7 = self.pred.bwd(gpred)
+                ops.relu_bwd_(g7, L["f7"])
+                g6 = self.fc7.bwd(g7)
+                ops.relu_bwd_(g6, L["f6"])
+                groi = self.fc6.bwd(g6)
+                gP_roi = [torch.zeros_like(p) for p in P[:4]]
+                ops.roi_align_bwd_(gP_roi, L["rois"], groi.view(R, 49, -1))
+            finally:
+                ops._WGRAD_CTX[0] = prev
         # RPN head (shared weights: gradients accumulate over the five levels)
         ghead_flat = torch.zeros_like(L["head_flat"])
         ops.bce_logits(L["head_flat"], L["obj_idx"], L["obj_lab"], grad=ghead_flat, gscale=gscale[2])
@@ -632,12 +644,18 @@ class FasterRCNNTrainer(_TrainerBase):
             self.rpn_head.bwd(ghs[i], need_dx=False, accumulate=i > 0, x=L["tl"][i])
             self.rpn_head._count(L["tl"][i], 1)
         gts_ = ops.conv_group(ghs, self.rpn_head._packed_grad())                         # 1x1 head: data gradient of the five levels in one launch
+        gP = [None] * 4
         for i in range(5):
             gt = ops.relu_bwd_(gts_[i], L["tl"][i])
             if i < 4:
-                gP[i] = self.rpn_conv.bwd(gt, residual=gP[i], accumulate=i > 0, x=P[i])
+                gP[i] = self.rpn_conv.bwd(gt, accumulate=i > 0, x=P[i])
             else:
                 gpool = self.rpn_conv.bwd(gt, accumulate=True, x=P[4])
+        if aux is not None:
+            main.wait_stream(aux[0])
+            for t in gP_roi:
+                t.record_stream(main)
+        gP = [ops.add(gP[i], gP_roi[i]) for i in range(4)]
         gP[3] = ops.add(gP[3], ops.dilate(gpool, 2, P[3].shape[1], P[3].shape[2]))          # LastLevelMaxPool (kernel 1, stride 2)
         # FPN
         ginner = self._fpn_out_bwd(gP[:4])

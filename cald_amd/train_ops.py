@@ -80,7 +80,7 @@ def conv(x, pk, stride=1, pad=0, relu=False, residual=None, up=None, out=None, o
         out = (torch.zeros if ld != n_out else torch.empty)((N, Ho, Wo, ld), dtype=torch.float32, device=x.device)
     Hup, Wup = (up.shape[1], up.shape[2]) if up is not None else (0, 0)
     flags = pk.flags | (FLAG_RELU if relu else 0)
-    _ffi.check(_ffi.lib().cald_train_conv(get_ctx(x.device.index), N, H, W, _p(x), pk.CinK, _p(pk.buf), pk.Cout,
+    _ffi.check(_ffi.lib().cald_train_conv(_wctx(x), N, H, W, _p(x), pk.CinK, _p(pk.buf), pk.Cout,
                                           pk.Cin, pk.KH, pk.KW, stride, pad, pk.mode, flags, _p(residual), _p(up), Hup, Wup, _p(out), ld))
     return out
 
@@ -101,7 +101,7 @@ def conv_group(xs, pks, stride=1, pad=0, relu=False, outs=None, out_ld=None):
         res.append(o)
     hw = [v for x in xs for v in (x.shape[1], x.shape[2])]
     flags = pk.flags | (FLAG_RELU if relu else 0)
-    _ffi.check(_ffi.lib().cald_train_conv_group(get_ctx(xs[0].device.index), len(xs), xs[0].shape[0], _int_array(hw), _ptr_array(xs), pk.CinK,
+    _ffi.check(_ffi.lib().cald_train_conv_group(_wctx(xs[0]), len(xs), xs[0].shape[0], _int_array(hw), _ptr_array(xs), pk.CinK,
                                                 _ptr_array([p.buf for p in pks]), pk.Cout, pk.Cin, pk.KH, pk.KW, stride, pad, pk.mode, flags,
                                                 _ptr_array(res), ld))
     return res
@@ -110,7 +110,7 @@ def conv_group(xs, pks, stride=1, pad=0, relu=False, outs=None, out_ld=None):
 def dilate(g, s, Hd, Wd):
     N, Ho, Wo, Cc = g.shape
     out = torch.empty((N, Hd, Wd, Cc), dtype=torch.float32, device=g.device)
-    _ffi.check(_ffi.lib().cald_train_dilate(get_ctx(g.device.index), N, Ho, Wo, Cc, s, Hd, Wd, _p(g), _p(out)))
+    _ffi.check(_ffi.lib().cald_train_dilate(_wctx(g), N, Ho, Wo, Cc, s, Hd, Wd, _p(g), _p(out)))
     return out
 
 
@@ -142,24 +142,24 @@ def linear_wgrad(x, g, Cout, dw, db=None, taps=1, accumulate=False):
 
 def relu_bwd_(g, act=None, scale=None):
     Cc = g.shape[-1]
-    _ffi.check(_ffi.lib().cald_train_relu_bwd(get_ctx(g.device.index), g.numel() // Cc, Cc, _p(g), _p(act), _p(scale)))
+    _ffi.check(_ffi.lib().cald_train_relu_bwd(_wctx(g), g.numel() // Cc, Cc, _p(g), _p(act), _p(scale)))
     return g
 
 
 def add(a, b=None, out=None):
     out = out if out is not None else torch.empty_like(a)
-    _ffi.check(_ffi.lib().cald_train_add(get_ctx(a.device.index), a.numel(), _p(out), _p(a), _p(b)))
+    _ffi.check(_ffi.lib().cald_train_add(_wctx(a), a.numel(), _p(out), _p(a), _p(b)))
     return out
 
 
 def upsample_bwd_(fine, coarse):
     N, Hf, Wf, Cc = fine.shape
-    _ffi.check(_ffi.lib().cald_train_upsample_bwd(get_ctx(fine.device.index), N, Hf, Wf, coarse.shape[1], coarse.shape[2], Cc, _p(fine), _p(coarse)))
+    _ffi.check(_ffi.lib().cald_train_upsample_bwd(_wctx(fine), N, Hf, Wf, coarse.shape[1], coarse.shape[2], Cc, _p(fine), _p(coarse)))
     return coarse
 
 
 def sgd_(param, grad, buf, lr, momentum, weight_decay, first_step):
-    _ffi.check(_ffi.lib().cald_train_sgd(get_ctx(param.device.index), param.numel(), _p(param), _p(grad), _p(buf), lr, momentum, weight_decay,
+    _ffi.check(_ffi.lib().cald_train_sgd(_wctx(param), param.numel(), _p(param), _p(grad), _p(buf), lr, momentum, weight_decay,
                                          int(first_step)))
 
 
@@ -212,13 +212,13 @@ def roi_align(feats, rois):
     R, Cc = rois.shape[0], feats[0].shape[3]
     out = torch.empty((R, 49, Cc), dtype=torch.float32, device=rois.device)
     hw = [v for f in feats for v in (f.shape[1], f.shape[2])]
-    _ffi.check(_ffi.lib().cald_train_roi_align(get_ctx(rois.device.index), _ptr_array(feats), _int_array(hw), Cc, R, _p(rois), _p(out)))
+    _ffi.check(_ffi.lib().cald_train_roi_align(_wctx(rois), _ptr_array(feats), _int_array(hw), Cc, R, _p(rois), _p(out)))
     return out
 
 
 def roi_align_bwd_(gfeats, rois, gout):
     hw = [v for f in gfeats for v in (f.shape[1], f.shape[2])]
-    _ffi.check(_ffi.lib().cald_train_roi_align_bwd(get_ctx(rois.device.index), gfeats[0].shape[0], _ptr_array(gfeats), _int_array(hw), gfeats[0].shape[3],
+    _ffi.check(_ffi.lib().cald_train_roi_align_bwd(_wctx(rois), gfeats[0].shape[0], _ptr_array(gfeats), _int_array(hw), gfeats[0].shape[3],
                                                    rois.shape[0], _p(rois), _p(gout)))
     return gfeats
 
@@ -226,28 +226,28 @@ def roi_align_bwd_(gfeats, rois, gout):
 def softmax_ce(logits, labels, Ccls, grad=None, gscale=1.0):
     """logits [R, ld] (first Ccls columns are the class logits), labels int64 [R].  Returns the loss as a 1-element tensor."""
     loss = torch.empty(1, dtype=torch.float32, device=logits.device)
-    _ffi.check(_ffi.lib().cald_train_softmax_ce(get_ctx(logits.device.index), logits.shape[0], Ccls, logits.shape[1], _p(logits), _p(labels), gscale,
+    _ffi.check(_ffi.lib().cald_train_softmax_ce(_wctx(logits), logits.shape[0], Ccls, logits.shape[1], _p(logits), _p(labels), gscale,
                                                 _p(loss), _p(grad)))
     return loss
 
 
 def smooth_l1(pred, idx, target, beta, denom, grad=None, gscale=1.0, weights=None):
     loss = torch.empty(1, dtype=torch.float32, device=pred.device)
-    _ffi.check(_ffi.lib().cald_train_smooth_l1(get_ctx(pred.device.index), idx.numel(), _p(pred), _p(idx), _p(target), beta, float(denom), _p(weights),
+    _ffi.check(_ffi.lib().cald_train_smooth_l1(_wctx(pred), idx.numel(), _p(pred), _p(idx), _p(target), beta, float(denom), _p(weights),
                                                gscale, _p(loss), _p(grad)))
     return loss
 
 
 def focal_loss(logits_flat, level_pix, N, A, K, ld, matched, gt_labels, gt_off, img_weight, grad=None, gscale=1.0, alpha=0.25):
     loss = torch.empty(1, dtype=torch.float32, device=logits_flat.device)
-    _ffi.check(_ffi.lib().cald_train_focal_loss(get_ctx(logits_flat.device.index), N, _int_array(level_pix), A, K, ld, _p(logits_flat), _p(matched),
+    _ffi.check(_ffi.lib().cald_train_focal_loss(_wctx(logits_flat), N, _int_array(level_pix), A, K, ld, _p(logits_flat), _p(matched),
                                                 _p(gt_labels), _p(gt_off), _p(img_weight), alpha, gscale, _p(loss), _p(grad)))
     return loss
 
 
 def bce_logits(logits, idx, labels, grad=None, gscale=1.0):
     loss = torch.empty(1, dtype=torch.float32, device=logits.device)
-    _ffi.check(_ffi.lib().cald_train_bce_logits(get_ctx(logits.device.index), idx.numel(), _p(logits), _p(idx), _p(labels), gscale, _p(loss), _p(grad)))
+    _ffi.check(_ffi.lib().cald_train_bce_logits(_wctx(logits), idx.numel(), _p(logits), _p(idx), _p(labels), gscale, _p(loss), _p(grad)))
     return loss
 
 
@@ -267,14 +267,14 @@ def preprocess(images_u8, sizes, Hp, Wp, remainders=None):
 def maxpool(x):
     N, H, W, Cc = x.shape
     out = torch.empty((N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, Cc), dtype=torch.float32, device=x.device)
-    _ffi.check(_ffi.lib().cald_train_maxpool(get_ctx(x.device.index), N, H, W, Cc, _p(x), _p(out)))
+    _ffi.check(_ffi.lib().cald_train_maxpool(_wctx(x), N, H, W, Cc, _p(x), _p(out)))
     return out
 
 
 def subsample2(x):
     N, H, W, Cc = x.shape
     out = torch.empty((N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, Cc), dtype=torch.float32, device=x.device)
-    _ffi.check(_ffi.lib().cald_train_subsample2(get_ctx(x.device.index), N, H, W, Cc, _p(x), _p(out)))
+    _ffi.check(_ffi.lib().cald_train_subsample2(_wctx(x), N, H, W, Cc, _p(x), _p(out)))
     return out
 
 
