@@ -90,6 +90,9 @@ class HipDetector:
         'classification' / 'bbox_regression', retinanet_cal.py:50-55)."""
         if not mode:
             return self.eval()
+        if self.cfg.precision != _ffi.PRECISION["fp32"]:
+            raise NotImplementedError("the training step computes in fp32; build the detector with precision='fp32' to train it "
+                                      "(the f16x3 / i8x3 modes are inference-only)")
         self._ensure_trainer()
         self.training = True
         return self
