@@ -107,8 +107,10 @@ def latest_pmc():
     this process (a process cannot attach rocprofv3 to itself): the source file is named next to the number."""
     try:
         cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc.json"))
-        if cands:
-            return json.load(open(os.path.join(ROOT, "profiles", cands[-1])))["conv_mfma"]["hbm_bytes_per_launch"], "profiles/" + cands[-1]
+        for name in reversed(cands):                 # newest summary that holds the GEMM family's HBM bytes
+            d = json.load(open(os.path.join(ROOT, "profiles", name)))
+            if "conv_mfma" in d:
+                return d["conv_mfma"]["hbm_bytes_per_launch"], "profiles/" + name
     except Exception:
         pass
     return None, None
