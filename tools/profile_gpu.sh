@@ -6,7 +6,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$1
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-full-pool --no-f16x3"
+CMD="python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-full-pool --no-f16x3 --no-train"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $CMD > $OUT/stats.log 2>&1
 # counters in their own runs (no other trace domains): HBM traffic of every dispatch
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- $CMD > $OUT/pmc_fetch.log 2>&1
