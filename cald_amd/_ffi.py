@@ -92,9 +92,9 @@ SIGNATURES = {
     "cald_train_packed_floats": (C.c_int, [C.c_int] * 6 + [c_i64]),
     "cald_train_pack_conv": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 6 + [C.c_void_p]),
     "cald_train_conv": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p] + [C.c_int] * 8
-                        + [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]),
+                        + [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
     "cald_train_conv_group": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_i, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p)] + [C.c_int] * 8
-                              + [C.POINTER(C.c_void_p), C.c_int]),
+                              + [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int]),
     "cald_train_conv_wgrad": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                         C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
     "cald_train_linear_wgrad": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,

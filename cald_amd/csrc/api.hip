@@ -742,7 +742,7 @@ static double fill_conv_args(cald_model* m, ConvArgs& a, const ConvLayer& L, con
     a.KH = L.KH; a.KW = L.KW; a.stride = L.stride; a.pad = L.pad; a.relu = relu ? 1 : 0;
     a.total_mtiles = level_tiles(m->plan, lout, V);
     a.out_ld = L.Cout; a.in_relu = in_relu ? 1 : 0; a.zeros = m->ctx->d_zeros; a.exp_flags = 0;
-    a.i8_in = nullptr; a.i8_plane_stride = 0; a.w8 = nullptr; a.w8_unscale = nullptr; a.i8_rowscale = nullptr;
+    a.i8_in = nullptr; a.i8_plane_stride = 0; a.w8 = nullptr; a.w8_unscale = nullptr; a.i8_rowscale = nullptr; a.mask = nullptr;
     if (m->cfg.precision == CALD_PRECISION_I8X3 && L.w8 && !in_relu && m->i8_scratch) {
         // this layer runs on the int8 pipe: write the three digit planes + per-pixel scales of its input, then hand them to conv_i3.hip
         const long long P = level_pix(m->plan, lin, V);

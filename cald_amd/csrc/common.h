@@ -55,6 +55,9 @@ struct ConvArgs {
     const float* i8_rowscale;   // per input pixel 2^(e_p - 22) (e_p = exponent of the pixel's largest |channel|)
     const void* w8;             // weight digits packed [Kpad/32][3][CoutPad][32 B], k-tiles in (kh, kw, 32-channel chunk) order
     const float* w8_unscale;    // [CoutPad] 2^(e_w[n] - 22 + 16)
+    // training backward only (train.hip; honoured by conv_p4.hip): after everything else, out = mask > 0 ? out : 0 -- the ReLU backward
+    // of the layer whose saved post-ReLU output `mask` (same geometry and row stride as out) this data gradient flows into; else null
+    const float* mask;
 };
 
 // Several independent conv problems in ONE launch (the five FPN levels under the shared-weight RPN / RetinaNet heads, the

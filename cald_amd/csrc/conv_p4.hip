@@ -23,8 +23,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // so LDS addresses are register + immediate and the per-tap load offsets are precomputed registers -- the loop body holds
 // no address / mask VALU at all (every VALU instruction beside v_mfma_f32_32x32x2_f32 costs matrix-pipe time: they share the
 // fp32 datapath).  13 = the 7 x 7 stem on the 4-channel input (13 k-tiles, fully unrolled).  0 = generic rolled loop.
-template <int EPI, bool C4, int TN, int TAPS>
+template <int EPIX, bool C4, int TN, int TAPS>
 __device__ __forceinline__ void conv_p4_body(const ConvArgs& a, const int blk) {
+    constexpr int EPI = EPIX & 3;               // 0 none, 1 residual, 2 nearest-upsampled top-down
+    constexpr bool MASK = (EPIX & 4) != 0;      // training backward only: the ReLU-backward mask step is compiled in
     constexpr int BM = 128, BN = 64 * TN, BK = 16, TM = 2, WN = 2;
     constexpr int TILE_A = 2 * BM * 8, TILE_F = TILE_A + 2 * BN * 8;      // floats: 2048 + 2048 (TN = 2)
     __shared__ __attribute__((aligned(16))) float smem[3 * TILE_F];
@@ -353,10 +355,13 @@ __device__ __forceinline__ void conv_p4_body(const ConvArgs& a, const int blk) {
         uph_s = (float)upH / (float)Ho; upw_s = (float)upW / (float)Wo;
     }
     const bool relu = a.relu != 0, has_bias = a.bias != nullptr, has_bn = a.scale != nullptr;
+    constexpr bool has_mask = MASK;
+    const float* __restrict__ mask_v = has_mask ? a.mask + so.pix_off * (long long)out_ld : out_v;
     const bool full_tile = m0 + BM <= Mv && !(a.exp_flags & 1);
     const int row_b = out_ld * 4;
     const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc((void*)out_v, 0, 0x7FFE0000, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)(EPI != 0 ? ex_v : out_v), 0, 0x7FFE0000, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc((void*)mask_v, 0, 0x7FFE0000, 0x00020000);
     // FPN top-down (EPI 2): the nearest-neighbour source pixel of each of the tile's 128 rows is computed ONCE (one thread per
     // row; the LDS tile buffers are free after the k-loop's last barrier) instead of by every lane for each of its 32 rows
     const int Mlast = Mv - 1;
@@ -425,6 +430,24 @@ __device__ __forceinline__ void conv_p4_body(const ConvArgs& a, const int blk) {
 #pragma unroll
                 for (int r = 0; r < 16; r++) val[r] = val[r] > 0.0f ? val[r] : 0.0f;
             }
+            if (has_mask) {      // training backward: ReLU backward of the layer this data gradient flows into (wave-uniform branch)
+                float mk[16];
+                if (full_tile) {
+                    const int vo = nok ? (mbase * out_ld + n) * 4 : 0x7FFF0000;
+#pragma unroll
+                    for (int r = 0; r < 16; r++)
+                        mk[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsM, vo, ((r & 3) + 8 * (r >> 2)) * row_b, 0));
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        int m = mbase + (r & 3) + 8 * (r >> 2);
+                        m = m < Mlast ? m : Mlast;
+                        mk[r] = mask_v[(long long)m * out_ld + nc];
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; r++) val[r] = mk[r] > 0.0f ? val[r] : 0.0f;
+            }
             if (full_tile) {
                 const int vo = nok ? (mbase * out_ld + n) * 4 : 0x7FFF0000;
 #pragma unroll
@@ -469,15 +492,18 @@ bool launch_conv_p4_group(const ConvArgs* p, int n, hipStream_t stream) {
     for (int i = 0; i < n; i++) {
         const ConvArgs& a = p[i];
         if (!a.w4 || a.w16 || a.CoutPad % 64 != 0 || (a.CoutPad % 128 == 0) != wide || a.Cin % 16 != 0 || a.KH * a.KW > 32 || a.residual || a.up) return false;
+        if ((a.mask != nullptr) != (p[0].mask != nullptr)) return false;
         g.blk0[i] = blk; blk += p4_grid_mtiles(a) * (a.CoutPad / (wide ? 128 : 64)); g.p[i] = a; g.p[i].exp_flags = 0;
     }
     g.blk0[n] = blk;
     const int taps = p4_taps(p[0]);
     for (int i = 1; i < n; i++) if (p4_taps(p[i]) != taps) return false;
     const dim3 grid((unsigned)blk), block(256);
-#define P4_GROUP(TNV, TAPSV) hipLaunchKernelGGL((conv_p4_group_kernel<0, false, TNV, TAPSV>), grid, block, 0, stream, g)
-    if (wide) { if (taps == 9) P4_GROUP(2, 9); else if (taps == 1) P4_GROUP(2, 1); else P4_GROUP(2, 0); }
-    else { if (taps == 9) P4_GROUP(1, 9); else if (taps == 1) P4_GROUP(1, 1); else P4_GROUP(1, 0); }
+#define P4_GROUP(EV, TNV, TAPSV) hipLaunchKernelGGL((conv_p4_group_kernel<EV, false, TNV, TAPSV>), grid, block, 0, stream, g)
+#define P4_GROUP_T(EV) { if (wide) { if (taps == 9) P4_GROUP(EV, 2, 9); else if (taps == 1) P4_GROUP(EV, 2, 1); else P4_GROUP(EV, 2, 0); } \
+                         else { if (taps == 9) P4_GROUP(EV, 1, 9); else if (taps == 1) P4_GROUP(EV, 1, 1); else P4_GROUP(EV, 1, 0); } }
+    if (p[0].mask) P4_GROUP_T(4) else P4_GROUP_T(0)
+#undef P4_GROUP_T
 #undef P4_GROUP
     return true;
 }
@@ -514,7 +540,10 @@ bool launch_conv_p4(const ConvArgs& a_in, hipStream_t stream) {
     const int taps = p4_taps(a);
 #define P4_ONE(EPIV, TNV, TAPSV) hipLaunchKernelGGL((conv_p4_kernel<EPIV, false, TNV, TAPSV>), grid, block, pad_lds, stream, a)
 #define P4_TAPS(EPIV, TNV) { if (taps == 9) P4_ONE(EPIV, TNV, 9); else if (taps == 1) P4_ONE(EPIV, TNV, 1); else P4_ONE(EPIV, TNV, 0); }
-    if (wide) {
+    if (a.mask) {                      // training backward (never set by the inference engine)
+        if (a.up) return false;
+        if (wide) { if (a.residual) P4_TAPS(5, 2) else P4_TAPS(4, 2) } else { if (a.residual) P4_TAPS(5, 1) else P4_TAPS(4, 1) }
+    } else if (wide) {
         if (a.residual) P4_TAPS(1, 2) else if (a.up) P4_TAPS(2, 2) else P4_TAPS(0, 2)
     } else {
         if (a.residual) P4_TAPS(1, 1) else if (a.up) P4_TAPS(2, 1) else P4_TAPS(0, 1)

@@ -194,9 +194,11 @@ extern "C" int cald_train_pack_conv(cald_ctx* c, const float* w, const float* bi
 // in  [N][H][W][CinK];  out [N][Ho][Wo][out_ld] (channels >= Cout of a row are not written);  residual: same geometry as out
 // with row stride Cout... (out_ld == Cout required when residual / up is given);  up: [N][Hup][Wup][Cout] nearest-upsampled and added.
 // flags: bit 0 bias, bit 1 scale/shift (FrozenBatchNorm), bit 2 ReLU.  mode as in cald_train_pack_conv (the packed buffer's).
+__global__ void relu_bwd_kernel(float* g, const float* act, const float* scale, long long n4, int C4);
+static bool p4_takes(const PackGeom& g, int taps) { return g.NPad % 64 == 0 && g.cin_conv % 16 == 0 && taps <= 32; }
 extern "C" int cald_train_conv(cald_ctx* c, int N, int H, int W, const float* in, int CinK, const float* packed, int Cout, int Cin,
                                int KH, int KW, int stride, int pad, int mode, int flags, const float* residual, const float* up,
-                               int Hup, int Wup, float* out, int out_ld) {
+                               int Hup, int Wup, const float* mask, float* out, int out_ld) {
     if (!c || !in || !packed || !out) TFAIL(CALD_ERR_INVALID, "null argument");
     if (N < 1 || H < 1 || W < 1 || stride < 1) TFAIL(CALD_ERR_INVALID, "bad geometry");
     THIP(hipSetDevice(cald_internal_device(c)));
@@ -218,7 +220,15 @@ extern "C" int cald_train_conv(cald_ctx* c, int N, int H, int W, const float* in
     a.residual = residual; a.up = up; a.seg_in = si; a.seg_out = so; a.seg_up = up ? su : so;
     a.V = N; a.Cin = g.cin_conv; a.Cout = g.n_true; a.CoutPad = g.NPad; a.Kpad = g.Kpad; a.KH = kh; a.KW = kw; a.stride = stride; a.pad = pad;
     a.relu = (flags & 4) ? 1 : 0; a.total_mtiles = N * ((Ho * Wo + 127) / 128); a.out_ld = out_ld; a.zeros = cald_internal_zeros(c);
+    // mask (ReLU backward of the layer the result flows into): in the epilogue of the tiled kernel where it covers the shape, else a pass
+    const bool fused = mask && p4_takes(g, kh * kw);
+    if (mask && !fused && (out_ld != g.n_true || out_ld % 4)) TFAIL(CALD_ERR_INVALID, "mask on this shape needs a dense output with C %% 4 == 0");
+    a.mask = fused ? mask : nullptr;
     launch_conv(a, cald_internal_stream(c));
+    if (mask && !fused) {
+        const long long n4 = (long long)N * Ho * Wo * out_ld / 4;
+        hipLaunchKernelGGL(relu_bwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, cald_internal_stream(c), out, mask, (const float*)nullptr, n4, out_ld / 4);
+    }
     THIP(hipGetLastError());
     return 0;
 }
@@ -227,13 +237,15 @@ extern "C" int cald_train_conv(cald_ctx* c, int N, int H, int W, const float* in
 // different weights of equal shape, e.g. RetinaNet's two towers): workgroups of the small levels fill the tail of the large ones.
 // Falls back to one launch per problem when the shape does not qualify for the grouped kernel (conv_p4.hip launch_conv_p4_group).
 extern "C" int cald_train_conv_group(cald_ctx* c, int n, int N, const int* hw, const float* const* ins, int CinK, const float* const* packed,
-                                     int Cout, int Cin, int KH, int KW, int stride, int pad, int mode, int flags, float* const* outs, int out_ld) {
+                                     int Cout, int Cin, int KH, int KW, int stride, int pad, int mode, int flags, const float* const* masks,
+                                     float* const* outs, int out_ld) {
     if (!c || !hw || !ins || !packed || !outs) TFAIL(CALD_ERR_INVALID, "null argument");
     if (n < 1 || n > CALD_MAX_GROUP) TFAIL(CALD_ERR_INVALID, "1..%d problems per group", CALD_MAX_GROUP);
     THIP(hipSetDevice(cald_internal_device(c)));
     const PackGeom g = pack_geom(Cout, Cin, KH, KW, CinK, mode);
     const int kh = mode >= 2 ? 1 : KH, kw = mode >= 2 ? 1 : KW;
     if (out_ld < g.n_true) TFAIL(CALD_ERR_INVALID, "out_ld < Cout");
+    if (masks && !p4_takes(g, kh * kw)) TFAIL(CALD_ERR_INVALID, "masks need a shape the tiled kernel covers");
     ConvArgs probs[CALD_MAX_GROUP];
     const long long nw = (long long)g.Kpad * g.NPad;
     for (int i = 0; i < n; i++) {
@@ -250,6 +262,7 @@ extern "C" int cald_train_conv_group(cald_ctx* c, int n, int N, const int* hw, c
         a.seg_in = si; a.seg_out = so; a.seg_up = so;
         a.V = N; a.Cin = g.cin_conv; a.Cout = g.n_true; a.CoutPad = g.NPad; a.Kpad = g.Kpad; a.KH = kh; a.KW = kw; a.stride = stride; a.pad = pad;
         a.relu = (flags & 4) ? 1 : 0; a.total_mtiles = N * ((Ho * Wo + 127) / 128); a.out_ld = out_ld; a.zeros = cald_internal_zeros(c);
+        a.mask = masks ? masks[i] : nullptr;
     }
     launch_conv_group(probs, n, cald_internal_stream(c));
     THIP(hipGetLastError());

@@ -60,7 +60,7 @@ class PackedConv(object):
                                                    self.Cin, self.KH, self.KW, self.CinK, mode, _p(self.buf)))
 
 
-def conv(x, pk, stride=1, pad=0, relu=False, residual=None, up=None, out=None, out_ld=None):
+def conv(x, pk, stride=1, pad=0, relu=False, residual=None, up=None, out=None, out_ld=None, mask=None):
     """Forward conv / linear (pk.mode 0 or 2) or stride-1 data gradient (pk.mode 1) of a dense NHWC batch."""
     _chk(x, "x")
     N, H, W, Cx = x.shape
@@ -81,11 +81,11 @@ def conv(x, pk, stride=1, pad=0, relu=False, residual=None, up=None, out=None, o
     Hup, Wup = (up.shape[1], up.shape[2]) if up is not None else (0, 0)
     flags = pk.flags | (FLAG_RELU if relu else 0)
     _ffi.check(_ffi.lib().cald_train_conv(_wctx(x), N, H, W, _p(x), pk.CinK, _p(pk.buf), pk.Cout,
-                                          pk.Cin, pk.KH, pk.KW, stride, pad, pk.mode, flags, _p(residual), _p(up), Hup, Wup, _p(out), ld))
+                                          pk.Cin, pk.KH, pk.KW, stride, pad, pk.mode, flags, _p(residual), _p(up), Hup, Wup, _p(mask), _p(out), ld))
     return out
 
 
-def conv_group(xs, pks, stride=1, pad=0, relu=False, outs=None, out_ld=None):
+def conv_group(xs, pks, stride=1, pad=0, relu=False, outs=None, out_ld=None, masks=None):
     """The same layer shape on several NHWC tensors in one launch; pks: one PackedConv per tensor (all of one shape) or a single one."""
     if not isinstance(pks, (list, tuple)):
         pks = [pks] * len(xs)
@@ -103,7 +103,7 @@ def conv_group(xs, pks, stride=1, pad=0, relu=False, outs=None, out_ld=None):
     flags = pk.flags | (FLAG_RELU if relu else 0)
     _ffi.check(_ffi.lib().cald_train_conv_group(_wctx(xs[0]), len(xs), xs[0].shape[0], _int_array(hw), _ptr_array(xs), pk.CinK,
                                                 _ptr_array([p.buf for p in pks]), pk.Cout, pk.Cin, pk.KH, pk.KW, stride, pad, pk.mode, flags,
-                                                _ptr_array(res), ld))
+                                                _ptr_array(masks) if masks is not None else None, _ptr_array(res), ld))
     return res
 
 
@@ -114,12 +114,12 @@ def dilate(g, s, Hd, Wd):
     return out
 
 
-def conv_dgrad(g, pk_d, H, W, stride, pad, residual=None):
+def conv_dgrad(g, pk_d, H, W, stride, pad, residual=None, mask=None):
     """dX [N, H, W, Cin] of a conv whose forward had (stride, pad); g [N, Ho, Wo, CinK(pk_d)], pk_d packed with mode 1."""
     K = pk_d.KH
     if stride > 1:
         g = dilate(g, stride, H + 2 * pad - K + 1, W + 2 * pad - pk_d.KW + 1)
-    out = conv(g, pk_d, stride=1, pad=K - 1 - pad, residual=residual)
+    out = conv(g, pk_d, stride=1, pad=K - 1 - pad, residual=residual, mask=mask)
     assert out.shape[1] == H and out.shape[2] == W, (out.shape, H, W)
     return out
 

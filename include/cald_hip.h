@@ -231,14 +231,16 @@ int cald_train_pack_conv(cald_ctx* ctx, const float* weight, const float* bias, 
                          int Cout, int Cin, int KH, int KW, int CinK, int mode, float* packed);
 /* out[N][Ho][Wo][out_ld] = epilogue(conv(in[N][H][W][CinK], packed)); flags: 1 bias, 2 scale/shift, 4 ReLU; residual (same
  * shape as out) and up ([N][Hup][Wup][Cout], nearest-upsampled) are added before the ReLU.  With mode 1 the call computes the
- * data gradient of a stride-1 conv (pad = K - 1 - forward pad); Cout / Cin are always those of the FORWARD weight. */
+ * data gradient of a stride-1 conv (pad = K - 1 - forward pad); Cout / Cin are always those of the FORWARD weight.  mask (or
+ * null; same shape as out): out = mask > 0 ? out : 0 at the very end -- the ReLU backward of the layer whose saved output it is. */
 int cald_train_conv(cald_ctx* ctx, int N, int H, int W, const float* in, int CinK, const float* packed, int Cout, int Cin,
                     int KH, int KW, int stride, int pad, int mode, int flags, const float* residual, const float* up,
-                    int Hup, int Wup, float* out, int out_ld);
+                    int Hup, int Wup, const float* mask, float* out, int out_ld);
 /* cald_train_conv of ONE layer shape on n tensors in one launch (pyramid levels under shared-weight heads; packed[i] may differ per
  * problem as long as the shape is the same).  hw = {H_0, W_0, ...}; no residual / upsample inputs.  n <= 10. */
 int cald_train_conv_group(cald_ctx* ctx, int n, int N, const int* hw, const float* const* ins, int CinK, const float* const* packed,
-                          int Cout, int Cin, int KH, int KW, int stride, int pad, int mode, int flags, float* const* outs, int out_ld);
+                          int Cout, int Cin, int KH, int KW, int stride, int pad, int mode, int flags, const float* const* masks,
+                          float* const* outs, int out_ld);
 /* dw[Cout][Cin][KH][KW] (=, or += when accumulate) sum over output pixels of g[q][co] * x[q @ tap][ci]; db[Cout] likewise (or
  * null).  x [N][H][W][ldx], g [N][Ho][Wo][ldg]; Cin, ldx, ldg multiples of 4.  Deterministic (fixed-order split reduction). */
 int cald_train_conv_wgrad(cald_ctx* ctx, int N, int H, int W, const float* x, int Cin, int ldx, const float* g, int Cout, int ldg,

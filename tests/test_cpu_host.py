@@ -560,6 +560,6 @@ def test_training_operator_host_side_contracts():
     assert L.cald_train_packed_floats(1024, 256, 49, 1, 256, 2, C.byref(n)) == 0 and n.value == 2 * 12544 * 1024 + 3 * 1024
     assert L.cald_train_packed_floats(1024, 256, 49, 1, 256, 7, C.byref(n)) != 0 and b"bad arguments" in L.cald_last_error()
     assert L.cald_train_pack_conv(None, None, None, None, None, 8, 8, 1, 1, 8, 0, None) != 0
-    assert L.cald_train_conv(None, 1, 8, 8, None, 8, None, 8, 8, 1, 1, 1, 0, 0, 0, None, None, 0, 0, None, 8) != 0
+    assert L.cald_train_conv(None, 1, 8, 8, None, 8, None, 8, 8, 1, 1, 1, 0, 0, 0, None, None, 0, 0, None, None, 8) != 0
     assert L.cald_train_sgd(None, 10, None, None, None, 0.1, 0.9, 0.0, 1) != 0
     assert L.cald_train_focal_loss(None, 1, None, 9, 21, 192, None, None, None, None, None, 0.25, 1.0, None, None) != 0

@@ -93,6 +93,30 @@ def test_epilogue_bn_relu_residual_and_relu_backward(T):
     assert torch.equal(got, want)
 
 
+def test_data_gradient_with_fused_relu_backward(T):
+    """The data gradient with the NEXT ReLU's backward fused into its epilogue (out = act > 0 ? out : 0), on the tiled kernel
+    (full and ragged tiles), in a grouped launch, and through the separate pass taken for shapes the tiled kernel does not cover."""
+    torch, ops = T
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(13)
+    for (N, H, W, Cin, Cout, K) in ((2, 19, 23, 64, 128, 3), (1, 16, 16, 256, 64, 1), (2, 9, 11, 48, 80, 3)):
+        w = torch.randn(Cout, Cin, K, K, generator=g) / (Cin * K * K) ** 0.5
+        gy = torch.randn(N, Cout, H, W, generator=g); act = torch.randn(N, Cin, H, W, generator=g); res = torch.randn(N, Cin, H, W, generator=g)
+        want = (F.conv_transpose2d(gy.double(), w.double(), padding=K // 2) + res.double()) * (act.double() > 0)
+        pkd = ops.PackedConv(w.cuda(), CinK=Cout, mode=1)
+        nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().cuda()
+        got = ops.conv_dgrad(nhwc(gy), pkd, H, W, 1, K // 2, residual=nhwc(res), mask=nhwc(act))
+        _close(got.permute(0, 3, 1, 2), want, 2e-5, "dgrad + residual + mask %s" % ((N, H, W, Cin, Cout, K),))
+    w = torch.randn(256, 256, 3, 3, generator=g) / 48
+    pkd = ops.PackedConv(w.cuda(), CinK=256, mode=1)
+    gys = [torch.randn(2, 256, h, ww, generator=g) for h, ww in ((12, 14), (6, 7), (3, 4))]
+    acts = [torch.randn(2, 256, h, ww, generator=g) for h, ww in ((12, 14), (6, 7), (3, 4))]
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().cuda()
+    outs = ops.conv_group([nhwc(t) for t in gys], pkd, pad=1, masks=[nhwc(t) for t in acts])
+    for o, gy, act in zip(outs, gys, acts):
+        _close(o.permute(0, 3, 1, 2), F.conv_transpose2d(gy.double(), w.double(), padding=1) * (act.double() > 0), 2e-5, "grouped dgrad + mask")
+
+
 def test_fc6_on_roi_rows_and_linear_gradients(T):
     """box_head.fc6 applied to RoIAlign rows laid out [R][7*7][256] with the torch weight [1024][256*7*7] (mode 2), its data
     gradient and weight gradient (written back in the torch layout), and a plain linear layer (predictor, 105 outputs)."""
