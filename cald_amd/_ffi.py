@@ -96,7 +96,7 @@ SIGNATURES = {
     "cald_train_conv_group": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_i, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p)] + [C.c_int] * 8
                               + [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int]),
     "cald_train_conv_wgrad": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
-                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
+                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "cald_train_linear_wgrad": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                           C.c_void_p, C.c_void_p, C.c_int]),
     "cald_train_relu_bwd": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -77,7 +77,7 @@ void cald_internal_train_release(cald_ctx* c) {
 // mode 2: forward of a linear layer whose torch weight is [Cout][Cin][taps] (fc6: [1024][256][7*7]) applied to rows laid out
 //         [tap][Cin] (the RoIAlign output [R][49][256]): K rows = tap * Cin + ci
 // mode 3: data gradient of a mode-2 layer: K rows = co of a CinK-channel dY, N = tap * Cin + ci
-struct PackArgs { const float* w; float* wk; float* w4; int Cout, Cin, taps, CinK, Kpad, NPad, mode; };
+struct PackArgs { const float* w; float* wk; float* w4; int Cout, Cin, taps, CinK, Kpad, NPad, mode; const float* rowscale; };
 __global__ void pack_weight_kernel(PackArgs a) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)a.Kpad * a.NPad) return;
@@ -90,9 +90,11 @@ __global__ void pack_weight_kernel(PackArgs a) {
     float v = 0.0f;
     if (a.mode == 1) {
         if (tap < a.taps && ci < a.Cout && n < a.Cin) v = a.w[((long long)ci * a.Cin + n) * a.taps + (a.taps - 1 - tap)];
+        if (a.rowscale && ci < a.Cout) v = v * a.rowscale[ci];       // FrozenBatchNorm scale of the forward layer's output channel
     } else if (a.mode == 3) {
         const int t = n / a.Cin, cc = n - t * a.Cin;
         if (ci < a.Cout && t < a.taps) v = a.w[((long long)ci * a.Cin + cc) * a.taps + t];
+        if (a.rowscale && ci < a.Cout) v = v * a.rowscale[ci];
     } else {
         if (tap < a.taps && ci < a.Cin && n < a.Cout) v = a.w[((long long)n * a.Cin + ci) * a.taps + tap];
     }
@@ -164,7 +166,7 @@ extern "C" int cald_train_pack_conv(cald_ctx* c, const float* w, const float* bi
     if (mode != 2 && (CinK % 4 || CinK < (mode == 0 ? Cin : Cout))) TFAIL(CALD_ERR_INVALID, "CinK must be a multiple of 4 and cover the contracted channels");
     THIP(hipSetDevice(cald_internal_device(c)));
     const PackGeom g = pack_geom(Cout, Cin, KH, KW, CinK, mode);
-    PackArgs a{w, packed, packed + (long long)g.Kpad * g.NPad, Cout, Cin, KH * KW, CinK, g.Kpad, g.NPad, mode};
+    PackArgs a{w, packed, packed + (long long)g.Kpad * g.NPad, Cout, Cin, KH * KW, CinK, g.Kpad, g.NPad, mode, (mode == 1 || mode == 3) ? scale : nullptr};
     hipStream_t st = cald_internal_stream(c);
     const long long n = (long long)g.Kpad * g.NPad;
     if (mode == 0 || mode == 2) {
@@ -419,7 +421,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 }
 // grad[co][ci][tap] (torch layout) (+)= sum over splits, in split order
 __global__ void wgrad_reduce_kernel(const float* partial, int S, long long split_stride, long long ldp, int Cout, int Cin, int taps,
-                                    float* grad, int accumulate) {
+                                    float* grad, int accumulate, const float* row_scale) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long J = (long long)taps * Cin;
     if (i >= (long long)Cout * J) return;
@@ -427,6 +429,7 @@ __global__ void wgrad_reduce_kernel(const float* partial, int S, long long split
     const int tap = j / Cin, ci = j - tap * Cin;
     float s = 0.0f;
     for (int k = 0; k < S; k++) s += partial[(long long)k * split_stride + (long long)co * ldp + j];
+    if (row_scale) s = s * row_scale[co];
     float* dst = grad + ((long long)co * Cin + ci) * taps + tap;
     *dst = accumulate ? *dst + s : s;
 }
@@ -467,7 +470,8 @@ __global__ void colsum_final_kernel(const float* partial, int S, int C, float* o
 // readable).  dw: torch layout [Cout][Cin][KH][KW]; for a tap-major linear layer pass KH*KW = taps, H = W = 1 and x rows
 // [R][taps * Cin] as N = R... (see cald_train_linear_wgrad).  db: [Cout] or null.
 static int wgrad_impl(cald_ctx* c, long long Q, int N, int H, int W, const float* x, int Cin, int ldx, int Ho, int Wo, const float* g,
-                      int Cout, int ldg, int KH, int KW, int stride, int pad, int red_taps, int red_cin, float* dw, float* db, int accumulate) {
+                      int Cout, int ldg, int KH, int KW, int stride, int pad, int red_taps, int red_cin, float* dw, float* db, int accumulate,
+                      const float* row_scale) {
     if (Cin % 4 || ldx % 4 || ldg % 4) TFAIL(CALD_ERR_INVALID, "Cin and the row strides must be multiples of 4");
     THIP(hipSetDevice(cald_internal_device(c)));
     hipStream_t st = cald_internal_stream(c);
@@ -495,7 +499,7 @@ static int wgrad_impl(cald_ctx* c, long long Q, int N, int H, int W, const float
     else hipLaunchKernelGGL((wgrad_kernel<false, 16>), dim3((unsigned)tiles, (unsigned)S), dim3(256), 0, st, a);
     const long long nred = (long long)Cout * a.J;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nred + 255) / 256)), dim3(256), 0, st, a.partial, (int)S, tile_floats,
-                       (long long)a.JT * 128, Cout, red_cin, red_taps, dw, accumulate);
+                       (long long)a.JT * 128, Cout, red_cin, red_taps, dw, accumulate, row_scale);
     if (db) {
         float* cp = a.partial + S * tile_floats;
         const long long rpb = (Q + csplit - 1) / csplit;
@@ -506,11 +510,12 @@ static int wgrad_impl(cald_ctx* c, long long Q, int N, int H, int W, const float
     return 0;
 }
 extern "C" int cald_train_conv_wgrad(cald_ctx* c, int N, int H, int W, const float* x, int Cin, int ldx, const float* g, int Cout, int ldg,
-                                     int KH, int KW, int stride, int pad, float* dw, float* db, int accumulate) {
+                                     int KH, int KW, int stride, int pad, const float* row_scale, float* dw, float* db, int accumulate) {
     if (!c || !x || !g || !dw) TFAIL(CALD_ERR_INVALID, "null argument");
     const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
     if (N < 1 || Ho < 1 || Wo < 1) TFAIL(CALD_ERR_INVALID, "bad geometry");
-    return wgrad_impl(c, (long long)N * Ho * Wo, N, H, W, x, Cin, ldx, Ho, Wo, g, Cout, ldg, KH, KW, stride, pad, KH * KW, Cin, dw, db, accumulate);
+    if (row_scale && db) TFAIL(CALD_ERR_INVALID, "row_scale is for FrozenBatchNorm layers, which carry no bias");
+    return wgrad_impl(c, (long long)N * Ho * Wo, N, H, W, x, Cin, ldx, Ho, Wo, g, Cout, ldg, KH, KW, stride, pad, KH * KW, Cin, dw, db, accumulate, row_scale);
 }
 // linear layer on rows: x [R][K], g [R][ldg] -> dw [Cout][K] torch layout; taps > 1: rows are [tap][K / taps] and the torch
 // weight is [Cout][K / taps][taps] (fc6 on the RoIAlign output)
@@ -518,7 +523,7 @@ extern "C" int cald_train_linear_wgrad(cald_ctx* c, int R, const float* x, int K
                                        float* dw, float* db, int accumulate) {
     if (!c || !x || !g || !dw) TFAIL(CALD_ERR_INVALID, "null argument");
     if (R < 1 || taps < 1 || K % taps) TFAIL(CALD_ERR_INVALID, "bad geometry");
-    return wgrad_impl(c, R, 1, 1, R, x, K, K, 1, R, g, Cout, ldg, 1, 1, 1, 0, taps, K / taps, dw, db, accumulate);
+    return wgrad_impl(c, R, 1, 1, R, x, K, K, 1, R, g, Cout, ldg, 1, 1, 1, 0, taps, K / taps, dw, db, accumulate, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -91,7 +91,8 @@ class _Conv(object):
     def _packed_grad(self):
         if self._pkd is None or self._pkd_version != self.net.version:
             buf = self._pkd.buf if self._pkd is not None else None
-            self._pkd = ops.PackedConv(self.w, CinK=self.out_ld, mode=3 if self.mode == 2 else 1, taps=self.taps, out=buf)
+            # FrozenBatchNorm layers: the scale rides in the packed filter, so the incoming gradient is the one wrt the BN output
+            self._pkd = ops.PackedConv(self.w, scale=self.scale, CinK=self.out_ld, mode=3 if self.mode == 2 else 1, taps=self.taps, out=buf)
             self._pkd_version = self.net.version
         return self._pkd
 
@@ -112,8 +113,10 @@ class _Conv(object):
         self._count(x, 1)
         return ops.conv(x, self._packed(), stride=self.stride, pad=self.pad, relu=relu, residual=residual, up=up, out=out, out_ld=self.out_ld)
 
-    def bwd(self, g, need_dx=True, residual=None, accumulate=False, x=None):
-        """g: gradient wrt this layer's conv output (after the caller applied ReLU mask / BN scale), row stride out_ld."""
+    def bwd(self, g, need_dx=True, residual=None, accumulate=False, x=None, mask=None):
+        """g: gradient wrt this layer's output AFTER its FrozenBatchNorm (if any) and after the ReLU mask, row stride out_ld: the BN
+        scale is folded into the packed data-gradient filter and into the weight-gradient reduction.  mask: the saved post-ReLU
+        activation the returned data gradient flows into (its ReLU backward is applied in the conv epilogue)."""
         x = self.x if x is None else x
         accumulate = accumulate or self.net.accumulate_grads
         self._count(x, 2 if need_dx else 1)
@@ -126,15 +129,16 @@ class _Conv(object):
             if self.mode == 2 or self.w.dim() == 2:
                 ops.linear_wgrad(x.view(g.shape[2], -1), g.view(g.shape[2], -1), self.Cout, self.gw, self.gb, taps=self.taps or 1, accumulate=accumulate)
             else:
-                ops.conv_wgrad(x, g, self.Cin, self.Cout, self.K, self.K, self.stride, self.pad, self.gw, self.gb, accumulate=accumulate)
+                ops.conv_wgrad(x, g, self.Cin, self.Cout, self.K, self.K, self.stride, self.pad, self.gw, self.gb, accumulate=accumulate,
+                               row_scale=self.scale)
         finally:
             ops._WGRAD_CTX[0] = prev
         if not need_dx:
             return None
         pkd = self._packed_grad()
         if self.mode == 2 or self.w.dim() == 2:
-            return ops.conv(g, pkd, residual=residual)
-        return ops.conv_dgrad(g, pkd, x.shape[1], x.shape[2], self.stride, self.pad, residual=residual)
+            return ops.conv(g, pkd, residual=residual, mask=mask)
+        return ops.conv_dgrad(g, pkd, x.shape[1], x.shape[2], self.stride, self.pad, residual=residual, mask=mask)
 
 
 class _Bottleneck(object):
@@ -152,22 +156,21 @@ class _Bottleneck(object):
         self.out = self.c3.fwd(self.a2, relu=True, residual=idt)
         return self.out
 
-    def bwd(self, gout):
-        """gout: gradient wrt the block output (after its ReLU); consumed.  Returns the gradient wrt the block input (or None)."""
-        g = ops.relu_bwd_(gout, self.out)                                   # through the final ReLU: shared by both branches
-        g3 = ops.relu_bwd_(ops.add(g), None, self.c3.scale)                 # bn3 scale
-        ga2 = self.c3.bwd(g3)
-        ops.relu_bwd_(ga2, self.a2, self.c2.scale)
-        ga1 = self.c2.bwd(ga2)
-        ops.relu_bwd_(ga1, self.a1, self.c1.scale)
+    def bwd(self, g, mask_input):
+        """g: gradient wrt the block output with the block's final ReLU already applied backwards (g = dL/dout where out > 0, else 0).
+        Returns the gradient wrt the block input x -- masked by x > 0 when `mask_input` (x is the previous block's post-ReLU output and
+        nothing else is added to its gradient), unmasked otherwise -- or None when the input needs no gradient.  Every ReLU backward
+        and FrozenBatchNorm scale of the block rides in a conv epilogue / packed filter: no elementwise pass."""
+        ga2 = self.c3.bwd(g, mask=self.a2)
+        ga1 = self.c2.bwd(ga2, mask=self.a1)
+        x = self.c1.x
         if self.down is not None:
-            gd = ops.relu_bwd_(g, None, self.down.scale)                    # g is no longer needed unscaled
             if not self.need_dx:
-                self.c1.bwd(ga1, need_dx=False); self.down.bwd(gd, need_dx=False)
+                self.c1.bwd(ga1, need_dx=False); self.down.bwd(g, need_dx=False)
                 return None
-            gx = self.down.bwd(gd)
-            return self.c1.bwd(ga1, residual=gx)
-        return self.c1.bwd(ga1, residual=g)
+            gx = self.down.bwd(g)
+            return self.c1.bwd(ga1, residual=gx, mask=x if mask_input else None)
+        return self.c1.bwd(ga1, residual=g, mask=x if mask_input else None)
 
 
 class _TrainerBase(object):
@@ -410,8 +413,11 @@ class _TrainerBase(object):
                 break
             if gC[li] is not None:
                 g = gC[li] if g is None else ops.add(gC[li], g)
-            for blk in reversed(blocks):
-                g = blk.bwd(g)
+            ops.relu_bwd_(g, blocks[-1].out)                # the layer's last ReLU: the only elementwise pass of the layer
+            for bi in range(len(blocks) - 1, -1, -1):
+                # inside a layer the block input is the previous block's output and receives this gradient only: its ReLU backward is
+                # fused; at the top of a layer the input also feeds an FPN lateral, whose gradient is added first (next iteration)
+                g = blocks[bi].bwd(g, mask_input=bi > 0)
 
     def body_relu_decisions(self):
         out = {}

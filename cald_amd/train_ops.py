@@ -55,7 +55,8 @@ class PackedConv(object):
         n = packed_floats(self.Cout, self.Cin, self.KH, self.KW, self.CinK, mode)
         self.buf = out if out is not None else torch.empty(n, dtype=torch.float32, device=weight.device)
         assert self.buf.numel() >= n
-        self.flags = (FLAG_BIAS if bias is not None else 0) | (FLAG_BN if scale is not None else 0)
+        # gradient packs (modes 1, 3) carry no epilogue vectors: a scale given there is folded into the filter rows
+        self.flags = ((FLAG_BIAS if bias is not None else 0) | (FLAG_BN if scale is not None else 0)) if mode in (0, 2) else 0
         _ffi.check(_ffi.lib().cald_train_pack_conv(_wctx(weight), _p(weight), _p(bias), _p(scale), _p(shift), self.Cout,
                                                    self.Cin, self.KH, self.KW, self.CinK, mode, _p(self.buf)))
 
@@ -124,11 +125,11 @@ def conv_dgrad(g, pk_d, H, W, stride, pad, residual=None, mask=None):
     return out
 
 
-def conv_wgrad(x, g, Cin, Cout, KH, KW, stride, pad, dw, db=None, accumulate=False):
+def conv_wgrad(x, g, Cin, Cout, KH, KW, stride, pad, dw, db=None, accumulate=False, row_scale=None):
     _chk(x, "x"); _chk(g, "g")
     N, H, W, ldx = x.shape
     _ffi.check(_ffi.lib().cald_train_conv_wgrad(_wctx(x), N, H, W, _p(x), Cin, ldx, _p(g), Cout, g.shape[-1], KH, KW, stride,
-                                                pad, _p(dw), _p(db), int(accumulate)))
+                                                pad, _p(row_scale), _p(dw), _p(db), int(accumulate)))
     return dw
 
 

@@ -224,7 +224,8 @@ int cald_profile_dump(cald_ctx* ctx, const char* path);
 int cald_train_packed_floats(int Cout, int Cin, int KH, int KW, int CinK, int mode, int64_t* floats_out);
 /* packs weight (+ optional bias / FrozenBatchNorm scale, shift: [Cout]) for the MFMA conv kernels, on the device.
  *   mode 0  forward over an input whose channel stride is CinK >= Cin (multiple of 4; extra channels must be zero or finite)
- *   mode 1  data gradient: the flipped, transposed filter applied to dY with channel stride CinK >= Cout
+ *   mode 1  data gradient: the flipped, transposed filter applied to dY with channel stride CinK >= Cout; bn_scale (or null) is
+ *           folded in (row co times bn_scale[co]): dY is then the gradient wrt the FrozenBatchNorm output
  *   mode 2  linear layer on rows laid out [tap][Cin] whose torch weight is [Cout][Cin * taps] (box_head.fc6 on RoIAlign rows)
  *   mode 3  data gradient of a mode-2 layer (dY rows with channel stride CinK >= Cout -> rows laid out [tap][Cin]) */
 int cald_train_pack_conv(cald_ctx* ctx, const float* weight, const float* bias, const float* bn_scale, const float* bn_shift,
@@ -242,9 +243,10 @@ int cald_train_conv_group(cald_ctx* ctx, int n, int N, const int* hw, const floa
                           int Cout, int Cin, int KH, int KW, int stride, int pad, int mode, int flags, const float* const* masks,
                           float* const* outs, int out_ld);
 /* dw[Cout][Cin][KH][KW] (=, or += when accumulate) sum over output pixels of g[q][co] * x[q @ tap][ci]; db[Cout] likewise (or
- * null).  x [N][H][W][ldx], g [N][Ho][Wo][ldg]; Cin, ldx, ldg multiples of 4.  Deterministic (fixed-order split reduction). */
+ * null).  x [N][H][W][ldx], g [N][Ho][Wo][ldg]; Cin, ldx, ldg multiples of 4.  Deterministic (fixed-order split reduction).
+ * row_scale (or null): dw[co] is multiplied by row_scale[co] -- g is then the gradient wrt the FrozenBatchNorm OUTPUT of the layer. */
 int cald_train_conv_wgrad(cald_ctx* ctx, int N, int H, int W, const float* x, int Cin, int ldx, const float* g, int Cout, int ldg,
-                          int KH, int KW, int stride, int pad, float* dw, float* db, int accumulate);
+                          int KH, int KW, int stride, int pad, const float* row_scale, float* dw, float* db, int accumulate);
 /* linear layer: x [R][K], g [R][ldg] -> dw [Cout][K]; taps > 1: x rows are [tap][K / taps], dw is [Cout][K / taps][taps] */
 int cald_train_linear_wgrad(cald_ctx* ctx, int R, const float* x, int K, const float* g, int Cout, int ldg, int taps,
                             float* dw, float* db, int accumulate);
