@@ -631,10 +631,8 @@ class FasterRCNNTrainer(_TrainerBase):
                 gpred = torch.zeros_like(L["pred"])
                 ops.softmax_ce(L["pred"].view(R, -1), L["labels"], self.C, grad=gpred, gscale=gscale[0])
                 ops.smooth_l1(L["pred"], L["pred_idx"], L["box_tgt"], 1.0 / 9, R, grad=gpred, gscale=gscale[1])
-                g7 = self.pred.bwd(gpred)
-                ops.relu_bwd_(g7, L["f7"])
-                g6 = self.fc7.bwd(g7)
-                ops.relu_bwd_(g6, L["f6"])
+                g7 = self.pred.bwd(gpred, mask=L["f7"])
+                g6 = self.fc7.bwd(g7, mask=L["f6"])
                 groi = self.fc6.bwd(g6)
                 gP_roi = [torch.zeros_like(p) for p in P[:4]]
                 ops.roi_align_bwd_(gP_roi, L["rois"], groi.view(R, 49, -1))
@@ -649,10 +647,10 @@ class FasterRCNNTrainer(_TrainerBase):
             ghs.append(ghead_flat[o:o + L["head_sizes"][i]].view(N, h, w, 16)); o += L["head_sizes"][i]
             self.rpn_head.bwd(ghs[i], need_dx=False, accumulate=i > 0, x=L["tl"][i])
             self.rpn_head._count(L["tl"][i], 1)
-        gts_ = ops.conv_group(ghs, self.rpn_head._packed_grad())                         # 1x1 head: data gradient of the five levels in one launch
+        gts_ = ops.conv_group(ghs, self.rpn_head._packed_grad(), masks=L["tl"])           # 1x1 head: data gradient of the five levels + ReLU backward, one launch
         gP = [None] * 4
         for i in range(5):
-            gt = ops.relu_bwd_(gts_[i], L["tl"][i])
+            gt = gts_[i]
             if i < 4:
                 gP[i] = self.rpn_conv.bwd(gt, accumulate=i > 0, x=P[i])
             else:
@@ -826,15 +824,18 @@ class RetinaNetTrainer(_TrainerBase):
             self.cls_out.bwd(g_cls[l], need_dx=False, accumulate=l > 0, x=acts["cls"][l][4])
             self.reg_out.bwd(g_reg[l], need_dx=False, accumulate=l > 0, x=acts["reg"][l][4])
             self.cls_out._count(acts["cls"][l][4], 1); self.reg_out._count(acts["reg"][l][4], 1)
-        g_cls = ops.conv_group(g_cls, self.cls_out._packed_grad(), pad=1)
-        g_reg = ops.conv_group(g_reg, self.reg_out._packed_grad(), pad=1)
+        # every ReLU backward of the towers rides in the epilogue of the data gradient that produces its input gradient
+        g_cls = ops.conv_group(g_cls, self.cls_out._packed_grad(), pad=1, masks=[acts["cls"][l][4] for l in range(5)])
+        g_reg = ops.conv_group(g_reg, self.reg_out._packed_grad(), pad=1)              # 36 channels: not a tiled-kernel shape
+        for l in range(5):
+            ops.relu_bwd_(g_reg[l], acts["reg"][l][4])
         for j in (3, 2, 1, 0):
             for l in range(5):
-                ops.relu_bwd_(g_cls[l], acts["cls"][l][j + 1]); ops.relu_bwd_(g_reg[l], acts["reg"][l][j + 1])
                 self.cls_tower[j].bwd(g_cls[l], need_dx=False, accumulate=l > 0, x=acts["cls"][l][j])
                 self.reg_tower[j].bwd(g_reg[l], need_dx=False, accumulate=l > 0, x=acts["reg"][l][j])
                 self.cls_tower[j]._count(acts["cls"][l][j], 1); self.reg_tower[j]._count(acts["reg"][l][j], 1)
-            gs = ops.conv_group(g_cls + g_reg, [self.cls_tower[j]._packed_grad()] * 5 + [self.reg_tower[j]._packed_grad()] * 5, pad=1)
+            masks = ([acts["cls"][l][j] for l in range(5)] + [acts["reg"][l][j] for l in range(5)]) if j > 0 else None
+            gs = ops.conv_group(g_cls + g_reg, [self.cls_tower[j]._packed_grad()] * 5 + [self.reg_tower[j]._packed_grad()] * 5, pad=1, masks=masks)
             g_cls, g_reg = gs[:5], gs[5:]
         gP = [ops.add(g_cls[l], g_reg[l]) for l in range(5)]
         g6 = self.p7.bwd(gP[4], x=L["p6_relu"])
