@@ -173,3 +173,29 @@ def coco_results(predictions):
         out.extend({"image_id": original_id, "category_id": labels[k], "bbox": box, "score": scores[k]}
                    for k, box in enumerate(boxes))
     return out
+
+
+def coco_evaluate(model, data_loader, classwise=True, feature=False, batch_views=64):
+    """detection/engine.py:178-256: forward over the test loader (batched on the GPU), CocoEvaluator update / accumulate / summarize
+    (cald_amd.coco_eval: bbox AP without pycocotools, parity unpinned), optional per-category AP table.  Returns the evaluator."""
+    from .coco_eval import CocoEvaluator, CocoGT
+    if feature:
+        raise NotImplementedError("feature=True (models returning (features, outputs)) belongs to the LL4AL baselines")
+    model.eval()
+    coco = CocoGT.from_dataset(data_loader.dataset)
+    evaluator = CocoEvaluator(coco, ["bbox"])
+    evaluator.update(coco_predictions(model, data_loader, batch_views))
+    evaluator.synchronize_between_processes()
+    evaluator.accumulate()
+    evaluator.summarize()
+    if classwise:                                             # per-category AP (engine.py:225-254)
+        import numpy as np
+        prec = evaluator.coco_eval["bbox"].eval["precision"]
+        rows = []
+        for idx, cat_id in enumerate(coco.get_cat_ids()):
+            p = prec[:, :, idx, 0, -1]
+            p = p[p > -1]
+            rows.append((str(coco.cats[cat_id].get("name", cat_id)), "%0.3f" % (float(np.mean(p)) if p.size else float("nan"))))
+        width = max(len(r[0]) for r in rows) if rows else 8
+        print("\n" + "\n".join("| %-*s | %s |" % (width, n, a) for n, a in [("category", "AP")] + rows))
+    return evaluator

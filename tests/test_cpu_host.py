@@ -604,3 +604,49 @@ def test_coco_dataset_conversion_matches_reference_golden(golden, tmp_path):
     assert 0 < len(train) < n
     labeled = train.label_loader([0, 1])
     assert [int(x) for _, (t,) in labeled for x in t["labels"]] == [int(x) for j in train.indices[:2] for x in g["labels_%d" % (train.dataset.ids[j] - 100)]]
+
+
+def test_coco_bbox_ap_hand_computed_cases(capsys):
+    """cald_amd.coco_eval (the COCO side of the evaluation consumer; pycocotools is absent, parity unpinned): cases whose AP / AR
+    follow from the published definition by hand -- perfect detections, a (TP, FP, TP-at-low-IoU) ranking, a detection absorbed by a
+    crowd region, area ranges, maxDets."""
+    from cald_amd.coco_eval import CocoGT, CocoEvaluator, bbox_iou
+    cats = [{"id": 3, "name": "c3"}, {"id": 7, "name": "c7"}]
+    def run(images, anns, preds):
+        ev = CocoEvaluator(CocoGT(images, anns, cats), ["bbox"])
+        ev.update(preds); ev.accumulate()
+        stats = ev.summarize()
+        capsys.readouterr()
+        return stats, ev
+    img = [{"id": 1, "width": 400, "height": 300}, {"id": 2, "width": 400, "height": 300}]
+    gt = [{"id": 1, "image_id": 1, "category_id": 3, "bbox": [10, 10, 100, 100], "area": 10000, "iscrowd": 0},
+          {"id": 2, "image_id": 1, "category_id": 3, "bbox": [200, 50, 100, 100], "area": 10000, "iscrowd": 0},
+          {"id": 3, "image_id": 2, "category_id": 7, "bbox": [20, 20, 20, 20], "area": 400, "iscrowd": 0}]
+    xyxy = lambda b: [b[0], b[1], b[0] + b[2], b[1] + b[3]]
+    # 1. perfect detections: every AP is 1 where ground truth exists, -1 where an area range is empty; AR@1 = mean(1/2, 1)
+    perfect = {1: {"boxes": np.array([xyxy(gt[0]["bbox"]), xyxy(gt[1]["bbox"])], np.float32), "scores": np.array([0.9, 0.8]), "labels": np.array([3, 3])},
+               2: {"boxes": np.array([xyxy(gt[2]["bbox"])], np.float32), "scores": np.array([0.7]), "labels": np.array([7])}}
+    s, ev = run(img, gt, perfect)
+    np.testing.assert_allclose(s[[0, 1, 2]], 1.0)
+    assert abs(s[3] - 1.0) < 1e-12 and s[4] == -1 and abs(s[5] - 1.0) < 1e-12     # (tp / (tp + fp + eps) as in pycocotools) small: the 400-px box; medium: none; large: the two 10 000-px boxes
+    np.testing.assert_allclose(s[6], 0.75); np.testing.assert_allclose(s[[7, 8]], 1.0)
+    assert ev.coco_eval["bbox"].eval["precision"].shape == (10, 101, 2, 4, 3)
+    # 2. one class: scores .9 (IoU 1 with gt 1), .8 (false positive), .7 (IoU 0.62 with gt 2)
+    d3 = [200, 50, 100, 62]                                              # inside gt 2: IoU = 6200 / 10000
+    assert abs(bbox_iou([d3], [gt[1]["bbox"]], [0])[0, 0] - 0.62) < 1e-12
+    preds = {1: {"boxes": np.array([xyxy(gt[0]["bbox"]), [300, 200, 350, 280], xyxy(d3)], np.float32), "scores": np.array([0.9, 0.8, 0.7]), "labels": np.array([3, 3, 3])}}
+    s, _ = run(img[:1], gt[:2], preds)
+    ap_lo = (51 * 1.0 + 50 * (2.0 / 3.0)) / 101                         # IoU <= 0.60: (TP, FP, TP): precision 1 up to recall 0.5, 2/3 beyond
+    ap_hi = 51 * 1.0 / 101                                              # IoU >= 0.65: the third detection is a false positive, recall stops at 0.5
+    np.testing.assert_allclose(s[1], ap_lo, rtol=1e-12)
+    np.testing.assert_allclose(s[2], ap_hi, rtol=1e-12)
+    np.testing.assert_allclose(s[0], (3 * ap_lo + 7 * ap_hi) / 10, rtol=1e-12)
+    np.testing.assert_allclose(s[8], (3 * 1.0 + 7 * 0.5) / 10, rtol=1e-12)       # AR@100
+    # 3. a detection lying inside a crowd region is ignored (intersection / own area >= 0.5), not counted as a false positive
+    gtc = [dict(gt[0]), {"id": 9, "image_id": 1, "category_id": 3, "bbox": [150, 0, 250, 300], "area": 75000, "iscrowd": 1}]
+    preds = {1: {"boxes": np.array([[200, 100, 260, 160], xyxy(gt[0]["bbox"])], np.float32), "scores": np.array([0.95, 0.5]), "labels": np.array([3, 3])}}
+    s, _ = run(img[:1], gtc, preds)
+    np.testing.assert_allclose(s[[0, 1, 2]], 1.0)
+    preds[1]["boxes"][0] = [100, 100, 160, 160]                          # moved out of the crowd region: now a higher-scored false positive
+    s, _ = run(img[:1], gtc, preds)
+    np.testing.assert_allclose(s[0], 0.5, rtol=1e-12)                   # precision 1/2 at every recall level

