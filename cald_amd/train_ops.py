@@ -118,6 +118,10 @@ def dilate(g, s, Hd, Wd):
 def conv_dgrad(g, pk_d, H, W, stride, pad, residual=None, mask=None):
     """dX [N, H, W, Cin] of a conv whose forward had (stride, pad); g [N, Ho, Wo, CinK(pk_d)], pk_d packed with mode 1."""
     K = pk_d.KH
+    if stride > 1 and K == 1 and pk_d.KW == 1 and pad == 0 and residual is None and mask is None:
+        # strided 1x1 (the bottleneck's downsample path): only every stride-th input pixel receives a gradient -- multiply on the
+        # coarse grid and scatter the result, instead of scattering dY first and multiplying 3/4 zeros
+        return dilate(conv(g, pk_d), stride, H, W)
     if stride > 1:
         g = dilate(g, stride, H + 2 * pad - K + 1, W + 2 * pad - pk_d.KW + 1)
     out = conv(g, pk_d, stride=1, pad=K - 1 - pad, residual=residual, mask=mask)
