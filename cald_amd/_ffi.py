@@ -102,6 +102,7 @@ SIGNATURES = {
     "cald_train_relu_bwd": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cald_train_add": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cald_train_dilate": (C.c_int, [C.c_void_p] + [C.c_int] * 7 + [C.c_void_p, C.c_void_p]),
+    "cald_train_weave2": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), c_i, c_i, C.c_void_p, C.c_void_p]),
     "cald_train_upsample_bwd": (C.c_int, [C.c_void_p] + [C.c_int] * 6 + [C.c_void_p, C.c_void_p]),
     "cald_train_rpn_proposals": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_i, C.POINTER(C.c_void_p), c_i, C.c_int, C.c_int, C.c_int,
                                            C.c_float, C.c_float, C.c_void_p, C.c_void_p]),

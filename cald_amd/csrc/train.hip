@@ -581,6 +581,34 @@ extern "C" int cald_train_dilate(cald_ctx* c, int N, int Ho, int Wo, int C, int 
     THIP(hipGetLastError());
     return 0;
 }
+// stride-2 data gradient, last step: the four phase results (output pixels (2m + a, 2n + b) depend on disjoint filter taps) are woven
+// into dX [N][H][W][C]; phase (a, b) lives in ph[2a + b] = [N][Hp_ab][Wp_ab][C] and its pixel (m + off, n + off) belongs to (2m + a, 2n + b).
+// mask (optional, same shape as dX): ReLU backward of the layer dX flows into.
+struct WeaveArgs { const float* ph[4]; int Hp[4], Wp[4], off[4]; };
+__global__ void weave2_kernel(WeaveArgs a, const float* mask, float* out, int N, int H, int W, int C4) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long n4 = (long long)N * H * W * C4;
+    if (i >= n4) return;
+    const int c = (int)(i % C4); long long p = i / C4;
+    const int x = (int)(p % W); p /= W; const int y = (int)(p % H); const int n = (int)(p / H);
+    const int k = 2 * (y & 1) + (x & 1);
+    const int py = (y >> 1) + a.off[k], px = (x >> 1) + a.off[k];
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (py < a.Hp[k] && px < a.Wp[k]) v = reinterpret_cast<const float4*>(a.ph[k])[(((long long)n * a.Hp[k] + py) * a.Wp[k] + px) * C4 + c];
+    if (mask) { const float4 m = reinterpret_cast<const float4*>(mask)[i]; if (!(m.x > 0.f)) v.x = 0.f; if (!(m.y > 0.f)) v.y = 0.f; if (!(m.z > 0.f)) v.z = 0.f; if (!(m.w > 0.f)) v.w = 0.f; }
+    reinterpret_cast<float4*>(out)[i] = v;
+}
+extern "C" int cald_train_weave2(cald_ctx* c, int N, int H, int W, int C, const float* const* phases, const int* phase_hw, const int* phase_off,
+                                 const float* mask, float* out) {
+    if (!c || !phases || !phase_hw || !phase_off || !out || C % 4) TFAIL(CALD_ERR_INVALID, "bad arguments");
+    THIP(hipSetDevice(cald_internal_device(c)));
+    WeaveArgs a;
+    for (int k = 0; k < 4; k++) { a.ph[k] = phases[k]; a.Hp[k] = phase_hw[2 * k]; a.Wp[k] = phase_hw[2 * k + 1]; a.off[k] = phase_off[k]; if (!phases[k]) TFAIL(CALD_ERR_INVALID, "null phase"); }
+    const long long n4 = (long long)N * H * W * (C / 4);
+    hipLaunchKernelGGL(weave2_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, cald_internal_stream(c), a, mask, out, N, H, W, C / 4);
+    THIP(hipGetLastError());
+    return 0;
+}
 // FPN top-down backward: coarse[n][yc][xc][c] += sum of fine[n][yf][xf][c] over the fine pixels whose nearest source is (yc, xc)
 // (F.interpolate(size=fine, mode='nearest'): source = floor(dst * coarse / fine))
 __global__ void upsample_bwd_kernel(const float* fine, float* coarse, int N, int Hf, int Wf, int Hc, int Wc, int C4) {

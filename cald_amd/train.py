@@ -31,6 +31,11 @@ import torch
 from . import train_ops as ops
 
 
+# 1: 3x3 stride-2 data gradients as four phase convolutions on the un-dilated dY (4x fewer FLOPs; measured SLOWER at batch 4 -- 100.4
+# vs 104.4 images/s on one box -- because the four small launches are latency-bound); default: one conv on the zero-stuffed grid
+_S2_PHASES = __import__("os").environ.get("CALD_TRAIN_S2_PHASES", "0") != "0"
+
+
 def _bn_fold(sd, prefix, eps=1e-5):
     """FrozenBatchNorm2d as y = x * scale + shift (torchvision.ops.misc.FrozenBatchNorm2d, eps 1e-5 in 0.8.x)."""
     w, b = sd[prefix + ".weight"].double(), sd[prefix + ".bias"].double()
@@ -88,7 +93,15 @@ class _Conv(object):
             self._pkd_version = -1
         return self._pk
 
+    def _is_s2(self):
+        return _S2_PHASES and self.stride == 2 and self.K == 3 and self.pad == 1 and self.w.dim() == 4
+
     def _packed_grad(self):
+        if self._is_s2():                                   # four phase sub-filters instead of one filter on the zero-stuffed grid
+            if self._pkd is None or self._pkd_version != self.net.version:
+                self._pkd = ops.pack_s2_grads(self.w, scale=self.scale, CinK=self.out_ld, outs=self._pkd)
+                self._pkd_version = self.net.version
+            return self._pkd
         if self._pkd is None or self._pkd_version != self.net.version:
             buf = self._pkd.buf if self._pkd is not None else None
             # FrozenBatchNorm layers: the scale rides in the packed filter, so the incoming gradient is the one wrt the BN output
@@ -138,6 +151,9 @@ class _Conv(object):
         pkd = self._packed_grad()
         if self.mode == 2 or self.w.dim() == 2:
             return ops.conv(g, pkd, residual=residual, mask=mask)
+        if self._is_s2():
+            assert residual is None
+            return ops.conv_dgrad_s2(g, pkd, x.shape[1], x.shape[2], mask=mask)
         return ops.conv_dgrad(g, pkd, x.shape[1], x.shape[2], self.stride, self.pad, residual=residual, mask=mask)
 
 
@@ -350,9 +366,10 @@ class _TrainerBase(object):
         st.wait_stream(self._main)                          # the optimizer's update of the flat parameter buffer
         prev, ops._WGRAD_CTX[0] = ops._WGRAD_CTX[0], ctx
         try:
-            for cv in self.convs:
-                if cv.trainable:
-                    cv._packed(); cv._packed_grad()
+            with torch.cuda.stream(st):                     # torch-side helpers of the packers (sub-filter gathers) run on this stream too
+                for cv in self.convs:
+                    if cv.trainable:
+                        cv._packed(); cv._packed_grad()
         finally:
             ops._WGRAD_CTX[0] = prev
         self._packs_ready = torch.cuda.Event()

@@ -129,6 +129,34 @@ def conv_dgrad(g, pk_d, H, W, stride, pad, residual=None, mask=None):
     return out
 
 
+_S2_ROWS = ([1], [0, 2])       # filter taps feeding even / odd input positions of a 3-tap, stride-2, pad-1 layer
+
+
+def pack_s2_grads(weight, scale=None, CinK=None, outs=None):
+    """The data gradient of a 3x3 stride-2 pad-1 conv as FOUR small convolutions on the un-dilated dY: input pixels (2m + a, 2n + b)
+    receive contributions from disjoint tap sets (1 tap where the coordinate is even, 2 where it is odd), so each phase gets its own
+    (1 + a) x (1 + b) sub-filter -- 9 taps per dY pixel in all instead of 36 on the zero-stuffed grid."""
+    packs = []
+    for a in (0, 1):
+        for b in (0, 1):
+            sub = weight[:, :, _S2_ROWS[a]][:, :, :, _S2_ROWS[b]].contiguous()
+            packs.append(PackedConv(sub, scale=scale, CinK=CinK, mode=1, out=None if outs is None else outs[2 * a + b].buf))
+    return packs
+
+
+def conv_dgrad_s2(g, packs, H, W, mask=None):
+    """dX [N, H, W, Cin] of a 3x3 stride-2 pad-1 conv from dY g [N, Ho, Wo, CinK]; packs from pack_s2_grads."""
+    N, Ho, Wo, _ = g.shape
+    phases, hw, off = [], [], []
+    for k, pk in enumerate(packs):
+        p = 1 if k else 0
+        o = conv(g, pk, stride=1, pad=p)
+        phases.append(o); hw += [o.shape[1], o.shape[2]]; off.append(p)
+    out = torch.empty((N, H, W, packs[0].Cin), dtype=torch.float32, device=g.device)
+    _ffi.check(_ffi.lib().cald_train_weave2(_wctx(g), N, H, W, packs[0].Cin, _ptr_array(phases), _int_array(hw), _int_array(off), _p(mask), _p(out)))
+    return out
+
+
 def conv_wgrad(x, g, Cin, Cout, KH, KW, stride, pad, dw, db=None, accumulate=False, row_scale=None):
     _chk(x, "x"); _chk(g, "g")
     N, H, W, ldx = x.shape

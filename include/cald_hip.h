@@ -256,6 +256,11 @@ int cald_train_relu_bwd(cald_ctx* ctx, long long rows, int C, float* g, const fl
 int cald_train_add(cald_ctx* ctx, long long n, float* dst, const float* a, const float* b);
 /* scatter g [N][Ho][Wo][C] onto the stride-1 grid out [N][Hd][Wd][C] (zeros elsewhere): first step of a strided data gradient */
 int cald_train_dilate(cald_ctx* ctx, int N, int Ho, int Wo, int C, int s, int Hd, int Wd, const float* g, float* out);
+/* last step of the stride-2 3x3 data gradient computed as four phase convolutions on the un-dilated dY (output pixels (2m + a, 2n + b)
+ * use disjoint filter taps): weaves phases[2a + b] = [N][phase_hw[2k]][phase_hw[2k+1]][C] (pixel (m + phase_off[k], n + phase_off[k]) ->
+ * (2m + a, 2n + b)) into out [N][H][W][C]; mask (or null, same shape): out = mask > 0 ? out : 0 */
+int cald_train_weave2(cald_ctx* ctx, int N, int H, int W, int C, const float* const* phases, const int* phase_hw, const int* phase_off,
+                      const float* mask, float* out);
 /* FPN top-down backward: coarse += sum of the fine pixels that nearest-upsampling reads from each coarse pixel */
 int cald_train_upsample_bwd(cald_ctx* ctx, int N, int Hf, int Wf, int Hc, int Wc, int C, const float* fine, float* coarse);
 /* RegionProposalNetwork.filter_proposals at training sizes (pre / post_nms_top_n <= 2048): heads[l] = [N][Hl][Wl][head_ld] with

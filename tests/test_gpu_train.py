@@ -75,6 +75,29 @@ def test_conv_forward_dgrad_wgrad_vs_autograd(T, case):
     assert torch.equal(dw2, dw + dw), "accumulate adds the same deterministic sum"
 
 
+@pytest.mark.parametrize("hw", [(18, 22), (17, 23), (9, 8)])
+def test_stride2_data_gradient_by_phases(T, hw):
+    """The 3x3 stride-2 data gradient as four phase convolutions on the un-dilated dY + weave (even and odd input sizes), with the
+    FrozenBN scale folded in and the next ReLU's mask applied in the weave == autograd."""
+    torch, ops = T
+    import torch.nn.functional as F
+    H, W = hw
+    g = torch.Generator().manual_seed(H * 31 + W)
+    N, Cin, Cout = 2, 64, 128
+    x = torch.randn(N, Cin, H, W, generator=g); w = torch.randn(Cout, Cin, 3, 3, generator=g) / 24; sc = torch.rand(Cout, generator=g) + 0.5
+    act = torch.randn(N, Cin, H, W, generator=g)
+    xd = x.double().requires_grad_()
+    y = F.conv2d(xd, w.double(), stride=2, padding=1) * sc.double().view(1, -1, 1, 1)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy.double())
+    packs = ops.pack_s2_grads(w.cuda(), scale=sc.cuda(), CinK=Cout)
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().cuda()
+    got = ops.conv_dgrad_s2(nhwc(gy), packs, H, W, mask=nhwc(act))
+    _close(got.permute(0, 3, 1, 2), xd.grad * (act.double() > 0), 2e-5, "stride-2 data gradient by phases")
+    got = ops.conv_dgrad_s2(nhwc(gy), packs, H, W)
+    _close(got.permute(0, 3, 1, 2), xd.grad, 2e-5, "stride-2 data gradient by phases, no mask")
+
+
 def test_epilogue_bn_relu_residual_and_relu_backward(T):
     """conv -> FrozenBatchNorm scale/shift -> + residual -> ReLU in one launch, and its backward mask + scale."""
     torch, ops = T
