@@ -433,6 +433,28 @@ __global__ void wgrad_reduce_kernel(const float* partial, int S, long long split
     float* dst = grad + ((long long)co * Cin + ci) * taps + tap;
     *dst = accumulate ? *dst + s : s;
 }
+// the same for taps > 1 with coalesced stores: one workgroup sums 64 input channels x all taps of one output channel (reads run
+// along ci), turns the [tap][ci] block into the torch [ci][tap] order in LDS and stores it as one contiguous run
+__global__ __launch_bounds__(256) void wgrad_reduce_taps_kernel(const float* partial, int S, long long split_stride, long long ldp, int Cin,
+                                                                int taps, float* grad, int accumulate, const float* row_scale) {
+    extern __shared__ float blk[];     // [64][taps]
+    const int co = blockIdx.y, c0 = blockIdx.x * 64;
+    const int nc = Cin - c0 < 64 ? Cin - c0 : 64;
+    const float* P = partial + (long long)co * ldp + c0;
+    const float sc = row_scale ? row_scale[co] : 1.0f;
+    for (int e = threadIdx.x; e < taps * 64; e += 256) {
+        const int t = e >> 6, cl = e & 63;
+        if (cl >= nc) continue;
+        const float* q = P + (long long)t * Cin + cl;
+        float s = 0.0f;
+        for (int k = 0; k < S; k++) s += q[(long long)k * split_stride];
+        if (row_scale) s = s * sc;
+        blk[cl * taps + t] = s;
+    }
+    __syncthreads();
+    float* dst = grad + ((long long)co * Cin + c0) * taps;
+    for (int e = threadIdx.x; e < taps * nc; e += 256) dst[e] = accumulate ? dst[e] + blk[e] : blk[e];
+}
 // db[c] = sum over rows of g[q][c]: stage 1 partial sums over row blocks (128 channels x 8 row lanes per workgroup, float4
 // loads), stage 2 fixed-order sum over the row blocks
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* g, long long Q, int C, int ld, long long rows_per_block, float* partial) {
@@ -458,12 +480,20 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* g, lon
         if (c + 3 < C) o[c + 3] = s.w;
     }
 }
-__global__ void colsum_final_kernel(const float* partial, int S, int C, float* out, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// 16 channels x 16 split lanes per workgroup: lane l sums splits l, l+16, ... in order, then lane 0 adds the 16 lane sums in order
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* partial, int S, int C, float* out, int accumulate) {
+    __shared__ float red[16][17];
+    const int cl = threadIdx.x & 15, lane = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     float s = 0.0f;
-    for (int k = 0; k < S; k++) s += partial[(long long)k * C + c];
-    out[c] = accumulate ? out[c] + s : s;
+    if (c < C)
+        for (int k = lane; k < S; k += 16) s += partial[(long long)k * C + c];
+    red[lane][cl] = s;
+    __syncthreads();
+    if (lane == 0 && c < C) {
+        for (int l = 1; l < 16; l++) s += red[l][cl];
+        out[c] = accumulate ? out[c] + s : s;
+    }
 }
 
 // x [N][H][W][ldx] (Cin channels used, Cin % 4 == 0), g [N][Ho][Wo][ldg] (Cout channels used; ldg % 4 == 0 and the pad channels
@@ -498,13 +528,17 @@ static int wgrad_impl(cald_ctx* c, long long Q, int N, int H, int W, const float
     else if (fast) hipLaunchKernelGGL((wgrad_kernel<true, 16>), dim3((unsigned)tiles, (unsigned)S), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((wgrad_kernel<false, 16>), dim3((unsigned)tiles, (unsigned)S), dim3(256), 0, st, a);
     const long long nred = (long long)Cout * a.J;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nred + 255) / 256)), dim3(256), 0, st, a.partial, (int)S, tile_floats,
-                       (long long)a.JT * 128, Cout, red_cin, red_taps, dw, accumulate, row_scale);
+    if (red_taps > 1 && red_taps <= 64)
+        hipLaunchKernelGGL(wgrad_reduce_taps_kernel, dim3((unsigned)((red_cin + 63) / 64), (unsigned)Cout), dim3(256), (size_t)red_taps * 64 * 4, st,
+                           a.partial, (int)S, tile_floats, (long long)a.JT * 128, red_cin, red_taps, dw, accumulate, row_scale);
+    else
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nred + 255) / 256)), dim3(256), 0, st, a.partial, (int)S, tile_floats,
+                           (long long)a.JT * 128, Cout, red_cin, red_taps, dw, accumulate, row_scale);
     if (db) {
         float* cp = a.partial + S * tile_floats;
         const long long rpb = (Q + csplit - 1) / csplit;
         hipLaunchKernelGGL(colsum_partial_kernel, dim3((Cout + 127) / 128, (unsigned)csplit), dim3(256), 0, st, g, Q, Cout, ldg, rpb, cp);
-        hipLaunchKernelGGL(colsum_final_kernel, dim3((Cout + 63) / 64), dim3(64), 0, st, cp, (int)csplit, Cout, db, accumulate);
+        hipLaunchKernelGGL(colsum_final_kernel, dim3((Cout + 15) / 16), dim3(256), 0, st, cp, (int)csplit, Cout, db, accumulate);
     }
     THIP(hipGetLastError());
     return 0;
@@ -953,13 +987,14 @@ __device__ inline double fixed_scale(unsigned max_bits) {
     const int e = (int)((max_bits >> 23) & 255) - 127;          // max = 1.f x 2^e  (0 if the tensor is all zero)
     return max_bits ? ldexp(1.0, 40 - (e + 1)) : 1.0;
 }
-__global__ __launch_bounds__(256) void roi_align_bwd_fixed_kernel(RoiTrainArgs a, long long* const* acc, const unsigned* max_bits) {
+struct RoiAccPtrs { long long* p[4]; };
+__global__ __launch_bounds__(256) void roi_align_bwd_fixed_kernel(RoiTrainArgs a, RoiAccPtrs acc, const unsigned* max_bits) {
     __shared__ RoiSample sy[14], sx[14];
     const int r = blockIdx.x, tid = threadIdx.x;
     int n, l;
     roi_setup(a, r, sy, sx, &n, &l);
     const int Hf = a.H[l], Wf = a.W[l], C = a.C;
-    unsigned long long* gf = reinterpret_cast<unsigned long long*>(acc[l]) + (long long)n * Hf * Wf * C;
+    unsigned long long* gf = reinterpret_cast<unsigned long long*>(acc.p[l]) + (long long)n * Hf * Wf * C;
     const double scale = fixed_scale(*max_bits);
     for (int idx = tid; idx < 49 * C; idx += 256) {
         const int bin = idx / C, c = idx - bin * C;
@@ -983,11 +1018,23 @@ __global__ __launch_bounds__(256) void roi_align_bwd_fixed_kernel(RoiTrainArgs a
         }
     }
 }
+// two accumulators per thread; the scale is a power of two, so multiplying by its reciprocal is the exact division
 __global__ void fixed_to_float_kernel(const long long* acc, float* g, long long n, const unsigned* max_bits) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 2;
     if (i >= n) return;
-    const long long v = acc[i];
-    if (v) g[i] = g[i] + (float)((double)v / fixed_scale(*max_bits));
+    const double inv = 1.0 / fixed_scale(*max_bits);
+    if (i + 1 < n) {
+        const longlong2 v = *reinterpret_cast<const longlong2*>(acc + i);
+        if (v.x | v.y) {
+            float2 o = *reinterpret_cast<float2*>(g + i);
+            if (v.x) o.x = o.x + (float)((double)v.x * inv);
+            if (v.y) o.y = o.y + (float)((double)v.y * inv);
+            *reinterpret_cast<float2*>(g + i) = o;
+        }
+    } else {
+        const long long v = acc[i];
+        if (v) g[i] = g[i] + (float)((double)v * inv);
+    }
 }
 /* gfeats[l] += scatter of gout through the bilinear weights.  Deterministic (fixed-point accumulation, see above); CALD_ROI_BWD_FLOAT=1
  * selects plain float atomics (summation in arrival order). */
@@ -1004,23 +1051,19 @@ extern "C" int cald_train_roi_align_bwd(cald_ctx* c, int N, float* const* gfeats
         return 0;
     }
     long long n[4], total = 0;
-    for (int l = 0; l < 4; l++) { n[l] = (long long)N * a.H[l] * a.W[l] * C; total += n[l]; }
+    for (int l = 0; l < 4; l++) { n[l] = (long long)N * a.H[l] * a.W[l] * C; total += (n[l] + 1) & ~1ll; }
     void* scratch = nullptr;
-    if (int rc = cald_internal_scratch(c, (size_t)total * 8 + 4 * sizeof(long long*) + 256, &scratch)) return rc;
+    if (int rc = cald_internal_scratch(c, (size_t)total * 8 + 256, &scratch)) return rc;
     long long* acc = (long long*)scratch;
-    long long** d_ptrs = (long long**)(acc + total);
-    unsigned* d_max = (unsigned*)(d_ptrs + 4);
-    long long* h_ptrs[4]; long long off = 0;
-    for (int l = 0; l < 4; l++) { h_ptrs[l] = acc + off; off += n[l]; }
-    THIP(hipMemsetAsync(acc, 0, (size_t)total * 8, st));
-    THIP(hipMemsetAsync(d_max, 0, 4, st));
-    THIP(hipMemcpyAsync(d_ptrs, h_ptrs, sizeof(h_ptrs), hipMemcpyHostToDevice, st));
-    THIP(hipStreamSynchronize(st));      // h_ptrs is stack storage
+    unsigned* d_max = (unsigned*)(acc + total);
+    RoiAccPtrs ptrs; long long off = 0;
+    for (int l = 0; l < 4; l++) { ptrs.p[l] = acc + off; off += (n[l] + 1) & ~1ll; }     // 16-byte aligned level bases
+    THIP(hipMemsetAsync(acc, 0, (size_t)total * 8 + 4, st));
     const long long ng = (long long)R * 49 * C;
     hipLaunchKernelGGL(absmax_kernel, dim3(1024), dim3(256), 0, st, gout, ng, d_max);
-    hipLaunchKernelGGL(roi_align_bwd_fixed_kernel, dim3(R), dim3(256), 0, st, a, (long long* const*)d_ptrs, (const unsigned*)d_max);
+    hipLaunchKernelGGL(roi_align_bwd_fixed_kernel, dim3(R), dim3(256), 0, st, a, ptrs, (const unsigned*)d_max);
     for (int l = 0; l < 4; l++)
-        hipLaunchKernelGGL(fixed_to_float_kernel, dim3((unsigned)((n[l] + 255) / 256)), dim3(256), 0, st, (const long long*)h_ptrs[l], gfeats[l], n[l], (const unsigned*)d_max);
+        hipLaunchKernelGGL(fixed_to_float_kernel, dim3((unsigned)((n[l] + 511) / 512)), dim3(256), 0, st, (const long long*)ptrs.p[l], gfeats[l], n[l], (const unsigned*)d_max);
     THIP(hipGetLastError());
     return 0;
 }
