@@ -919,15 +919,45 @@ class TrainableDetector(object):
 
 
 class SGD(torch.optim.Optimizer):
-    """torch.optim.SGD(params, lr, momentum, weight_decay) (cald_train.py:397) with the update done by one HIP kernel per tensor.
-    ``param_groups[i]['lr']`` is read every step, so torch's lr schedulers (warmup LambdaLR, MultiStepLR) drive it unchanged."""
+    """torch.optim.SGD(params, lr, momentum, weight_decay) (cald_train.py:397) with the update done by HIP kernels: ONE launch over the
+    trainer's flat parameter / gradient buffers when the optimizer holds exactly the trainer's parameters in one group (the reference's
+    setup), one launch per tensor otherwise.  ``param_groups[i]['lr']`` is read every step, so torch's lr schedulers (warmup LambdaLR,
+    MultiStepLR) drive it unchanged; ``state[p]['momentum_buffer']`` are views of one flat momentum buffer in the fused case."""
 
     def __init__(self, params, lr, momentum=0.0, weight_decay=0.0, net=None):
         super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
         self.net = net
+        self._mflat = None
+
+    def _fused_ok(self):
+        net = self.net
+        if net is None or len(self.param_groups) != 1:
+            return False
+        ps = self.param_groups[0]["params"]
+        if len(ps) != len(net.names):
+            return False
+        for p, k in zip(ps, net.names):
+            if p is not net.params[k] or p.grad is None or p.grad.data_ptr() != net.grads[k].data_ptr():
+                return False
+        started = ["momentum_buffer" in self.state[p] for p in ps]
+        if any(started) and (self._mflat is None or not all(started)):
+            return False                                   # buffers loaded from a checkpoint / a partial first step: per-tensor path
+        return True
 
     @torch.no_grad()
     def step(self, closure=None):
+        if self._fused_ok():
+            grp, net = self.param_groups[0], self.net
+            first = self._mflat is None
+            if first and grp["momentum"] != 0:
+                self._mflat = torch.zeros_like(net.flat)
+                for k in net.names:
+                    p = net.params[k]
+                    self.state[p]["momentum_buffer"] = self._mflat[net._off[k]:net._off[k] + p.numel()].view(p.shape)
+            # the pad words between tensors hold 0 in all three buffers and stay 0 under the update
+            ops.sgd_(net.flat, net.gflat, self._mflat, grp["lr"], grp["momentum"], grp["weight_decay"], first)
+            net.parameters_changed()
+            return
         for grp in self.param_groups:
             for p in grp["params"]:
                 if p.grad is None:

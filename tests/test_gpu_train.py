@@ -403,6 +403,30 @@ def test_drop_in_training_loop_updates_like_torch_sgd(T, oracle):
         assert err <= 1e-5, (k, err)
 
 
+def test_fused_sgd_launch_equals_the_per_tensor_launches(T):
+    """train.SGD over exactly the trainer's parameters updates the flat buffers with one launch; with a parameter subset (or net=None)
+    it launches per tensor.  Both give the same bits after two steps, and state[p]['momentum_buffer'] is readable either way."""
+    torch, ops = T
+    from cald_amd import train
+    sd, images, targets = _train_case(torch, seed=9)
+    flats, moms = [], []
+    for fused in (True, False):
+        net = train.FasterRCNNTrainer(sd, 21, min_size=160, max_size=256, box_batch=64, generator=torch.Generator().manual_seed(2))
+        model = train.TrainableFasterRCNN(net)
+        params = [p for p in model.parameters() if p.requires_grad]
+        opt = train.SGD(params, lr=0.001, momentum=0.9, weight_decay=1e-4, net=net if fused else None)
+        for it in range(2):
+            losses = sum(model(images, targets).values())
+            opt.zero_grad(); losses.backward(); opt.step()
+        assert (opt._mflat is not None) == fused
+        torch.cuda.synchronize()
+        flats.append(net.flat.clone())
+        moms.append([opt.state[p]["momentum_buffer"].clone() for p in params])
+        assert all(m.shape == p.shape for m, p in zip(moms[-1], params))
+    assert torch.equal(flats[0], flats[1])
+    assert all(torch.equal(a, b) for a, b in zip(*moms))
+
+
 @pytest.mark.parametrize("trainable_layers", [0, 4])
 def test_other_trainable_layer_settings_vs_autograd(T, oracle, trainable_layers):
     """resnet_fpn_backbone(trainable_layers=0 / 4): body frozen entirely / layer 1 trained too -- the set of trainable tensors and
