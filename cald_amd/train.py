@@ -471,6 +471,10 @@ class FasterRCNNTrainer(_TrainerBase):
         self.pred_ld = ops.round_up(5 * num_classes, 4)
         self.pred = _Conv(self, self._merge_groups[2], self._merge_groups[3], out_ld=self.pred_ld)
         assert self.pred.Cout == 5 * num_classes, "box predictor does not match num_classes"
+        # the RPN branch of the backward pass is enqueued during the forward's RoI-sampling window (see forward); CALD_TRAIN_SPECULATE=0: off
+        self.speculate = __import__("os").environ.get("CALD_TRAIN_SPECULATE", "1") != "0"
+        self.grad_wanted = True         # TrainableDetector clears it under torch.no_grad()
+        self._spec_grads = None
 
     def forward(self, images, targets, proposals_override=None):
         """Training forward.  Returns the four losses as 1-element device tensors (no autograd) and keeps what backward needs."""
@@ -555,50 +559,80 @@ class FasterRCNNTrainer(_TrainerBase):
             self.rpn_conv._count(P[i], 1); self.rpn_head._count(tl[i], 1)
             o += head_sizes[i]
         mark("fpn+rpn head")
+        spec = None
+        rpn_state = dict(N=N, P=P, tl=tl, head_flat=head_flat, head_sizes=head_sizes, level_hw=level_hw, obj_idx=obj_idx, obj_lab=obj_lab,
+                         box_idx=box_idx, rpn_tgt=rpn_tgt)
+        props_ready = None
         if proposals_override is None:
             props, counts = ops.rpn_proposals(heads, Hp, Wp, img_sizes, cfg["pre_n"], cfg["post_n"], cfg["nms"], 1e-3)
-            counts = counts.cpu().tolist()
+            if self.speculate and aux is not None and self.grad_wanted:
+                # The host now needs the proposals (counts, then the match results) to draw the RoI samples: ~1 ms during which the main
+                # stream would sit empty.  The RPN branch of the backward pass depends on nothing that comes later, so it is enqueued
+                # here, behind the proposal kernels, for unit upstream gradients (losses.backward() of the plain sum, the reference's
+                # loop); backward() uses it when its upstream gradients are 1 and recomputes otherwise.
+                props.record_stream(aux[0])
+                counts_h = torch.empty(counts.shape, dtype=counts.dtype, pin_memory=True)
+                counts_h.copy_(counts, non_blocking=True)
+                props_ready = torch.cuda.Event(); props_ready.record(self._main)
+                spec = self._rpn_branch_backward(rpn_state, 1.0, 1.0, speculative=True)
+                props_ready.synchronize()
+                counts = counts_h.tolist()
+            else:
+                counts = counts.cpu().tolist()
             proposals = [props[i, :counts[i]] for i in range(N)]
         else:
             proposals = [p.to(self.dev).float().contiguous() for p in proposals_override]
         mark("proposals")
-        # ---- RoI sampling ----
-        n_pr = [int(proposals[i].shape[0]) + n_gt[i] for i in range(N)]
-        pr_off = np.cumsum([0] + n_pr)
-        pr_all = torch.cat([t for i in range(N) for t in ((proposals[i], gts[i]) if n_gt[i] else (proposals[i],))]).contiguous()
-        matched_dev = torch.full((int(pr_off[-1]),), -1, dtype=torch.int32, device=self.dev)
-        for i in range(N):
-            if n_gt[i]:
-                ops.match(pr_all[pr_off[i]:pr_off[i + 1]], gts[i], cfg["box_fg"], cfg["box_bg"], False, out=matched_dev[pr_off[i]:pr_off[i + 1]])
-        matched_all = matched_dev.cpu().numpy()
-        keep_all, lab_all, gtsel_all, img_col = [], [], [], []
-        for i in range(N):
-            m = matched_all[pr_off[i]:pr_off[i + 1]]
-            if n_gt[i]:
-                labels = gt_labels[i].numpy()[np.maximum(m, 0)].copy()
-                labels[m == -1] = 0
-                labels[m == -2] = -1
-            else:
-                labels = np.zeros(len(m), np.int64)
-            pos, neg = torch.from_numpy(np.flatnonzero(labels >= 1)), torch.from_numpy(np.flatnonzero(labels == 0))
-            sp, sn = self._sample(pos, neg, cfg["box_batch"], cfg["box_pos"])
-            box_samples.append((np.sort(sp.numpy()), np.sort(sn.numpy())))
-            keep = np.sort(np.concatenate([sp.numpy(), sn.numpy()]))
-            keep_all.append(pr_off[i] + keep); lab_all.append(labels[keep])
-            gtsel_all.append(gt_off[i] + np.maximum(m[keep], 0) if n_gt[i] else np.full(len(keep), gt_off[-1], np.int64))
-            img_col.append(np.full(len(keep), float(i), np.float32))
-        roi_labels_np = np.concatenate(lab_all).astype(np.int64)
-        R = len(roi_labels_np)
-        pos_rows = np.flatnonzero(roi_labels_np > 0)
-        pred_idx_np = pos_rows * self.pred_ld + Ccls + 4 * roi_labels_np[pos_rows]
-        packed = torch.from_numpy(np.concatenate([np.concatenate(keep_all), np.concatenate(gtsel_all), roi_labels_np, pred_idx_np, pos_rows]).astype(np.int64)).to(self.dev)
-        keep_sel, gt_sel2, labels_dev = packed[:R], packed[R:2 * R], packed[2 * R:3 * R]
-        pred_idx, pos_sel = packed[3 * R:3 * R + len(pos_rows)], packed[3 * R + len(pos_rows):]
-        boxes = pr_all[keep_sel]
-        rois = torch.cat([torch.from_numpy(np.concatenate(img_col)).to(self.dev)[:, None], boxes], dim=1).contiguous()
-        roi_gt = gts_all[gt_sel2]
-        box_tgt = ops.box_encode(roi_gt.contiguous(), boxes.contiguous(), cfg["w"])[pos_sel].contiguous()
-        roi_labels = torch.from_numpy(roi_labels_np)
+        # ---- RoI sampling (on the batch-only stream when the main stream is busy with the speculative branch: the device->host copy
+        # of the match results then waits for the match kernels only) ----
+        on_aux = props_ready is not None
+        with (torch.cuda.stream(aux[0]) if on_aux else contextlib.nullcontext()):
+            if on_aux:
+                aux[0].wait_event(props_ready)
+                ops._WGRAD_CTX[0] = aux[1]
+            try:
+                n_pr = [int(proposals[i].shape[0]) + n_gt[i] for i in range(N)]
+                pr_off = np.cumsum([0] + n_pr)
+                pr_all = torch.cat([t for i in range(N) for t in ((proposals[i], gts[i]) if n_gt[i] else (proposals[i],))]).contiguous()
+                matched_dev = torch.full((int(pr_off[-1]),), -1, dtype=torch.int32, device=self.dev)
+                for i in range(N):
+                    if n_gt[i]:
+                        ops.match(pr_all[pr_off[i]:pr_off[i + 1]], gts[i], cfg["box_fg"], cfg["box_bg"], False, out=matched_dev[pr_off[i]:pr_off[i + 1]])
+                matched_all = matched_dev.cpu().numpy()
+                keep_all, lab_all, gtsel_all, img_col = [], [], [], []
+                for i in range(N):
+                    m = matched_all[pr_off[i]:pr_off[i + 1]]
+                    if n_gt[i]:
+                        labels = gt_labels[i].numpy()[np.maximum(m, 0)].copy()
+                        labels[m == -1] = 0
+                        labels[m == -2] = -1
+                    else:
+                        labels = np.zeros(len(m), np.int64)
+                    pos, neg = torch.from_numpy(np.flatnonzero(labels >= 1)), torch.from_numpy(np.flatnonzero(labels == 0))
+                    sp, sn = self._sample(pos, neg, cfg["box_batch"], cfg["box_pos"])
+                    box_samples.append((np.sort(sp.numpy()), np.sort(sn.numpy())))
+                    keep = np.sort(np.concatenate([sp.numpy(), sn.numpy()]))
+                    keep_all.append(pr_off[i] + keep); lab_all.append(labels[keep])
+                    gtsel_all.append(gt_off[i] + np.maximum(m[keep], 0) if n_gt[i] else np.full(len(keep), gt_off[-1], np.int64))
+                    img_col.append(np.full(len(keep), float(i), np.float32))
+                roi_labels_np = np.concatenate(lab_all).astype(np.int64)
+                R = len(roi_labels_np)
+                pos_rows = np.flatnonzero(roi_labels_np > 0)
+                pred_idx_np = pos_rows * self.pred_ld + Ccls + 4 * roi_labels_np[pos_rows]
+                packed2 = torch.from_numpy(np.concatenate([np.concatenate(keep_all), np.concatenate(gtsel_all), roi_labels_np, pred_idx_np, pos_rows]).astype(np.int64)).to(self.dev)
+                keep_sel, gt_sel2, labels_dev = packed2[:R], packed2[R:2 * R], packed2[2 * R:3 * R]
+                pred_idx, pos_sel = packed2[3 * R:3 * R + len(pos_rows)], packed2[3 * R + len(pos_rows):]
+                boxes = pr_all[keep_sel]
+                rois = torch.cat([torch.from_numpy(np.concatenate(img_col)).to(self.dev)[:, None], boxes], dim=1).contiguous()
+                roi_gt = gts_all[gt_sel2]
+                box_tgt = ops.box_encode(roi_gt.contiguous(), boxes.contiguous(), cfg["w"])[pos_sel].contiguous()
+                roi_labels = torch.from_numpy(roi_labels_np)
+            finally:
+                ops._WGRAD_CTX[0] = prev
+        if on_aux:
+            self._main.wait_stream(aux[0])
+            for t in (packed2, rois, box_tgt):
+                t.record_stream(self._main)
         mark("roi sampling")
         # ---- box head ----
         roi_rows = ops.roi_align(P[:4], rois)
@@ -608,7 +642,7 @@ class FasterRCNNTrainer(_TrainerBase):
         self.last = dict(N=N, R=R, feats=feats, inner=inner, P=P, tl=tl, heads=heads, head_flat=head_flat, head_sizes=head_sizes, level_hw=level_hw,
                          obj_idx=obj_idx, obj_lab=obj_lab, box_idx=box_idx, rpn_tgt=rpn_tgt, rois=rois, roi_rows=roi_rows, f6=f6, f7=f7, pred=pred,
                          labels=labels_dev, pred_idx=pred_idx, box_tgt=box_tgt, proposals=proposals, roi_labels=roi_labels,
-                         samples=dict(rpn=rpn_samples, box=box_samples))
+                         samples=dict(rpn=rpn_samples, box=box_samples), spec=spec)
         mark("box head")
         losses = {
             "loss_classifier": ops.softmax_ce(pred.view(R, -1), labels_dev, Ccls),
@@ -628,6 +662,58 @@ class FasterRCNNTrainer(_TrainerBase):
             out["rpn.%d" % i] = nchw(t)
         out["fc6"] = (L["f6"] > 0).view(L["R"], -1).cpu(); out["fc7"] = (L["f7"] > 0).view(L["R"], -1).cpu()
         return out
+
+    def _rpn_branch_backward(self, L, g_obj, g_reg, speculative=False):
+        """RPN losses -> 1x1 head -> 3x3 conv: the gradients wrt the five pyramid levels (four tensors + the pooled level) and the
+        weight gradients of the two layers (shared weights: they accumulate over the levels).  speculative: the weight gradients go
+        to buffers of their own (whether backward() must overwrite or add to the flat gradient buffer is not known yet)."""
+        N, P, level_hw = L["N"], L["P"], L["level_hw"]
+        layers = (self.rpn_head, self.rpn_conv)
+        saved = [(c.gw, c.gb) for c in layers]
+        if speculative:
+            if self._spec_grads is None:
+                self._spec_grads = [(torch.zeros_like(c.gw), torch.zeros_like(c.gb)) for c in layers]
+            for c, (gw, gb) in zip(layers, self._spec_grads):
+                c.gw, c.gb = gw, gb
+        acc_saved, self.accumulate_grads = self.accumulate_grads, (False if speculative else self.accumulate_grads)
+        try:
+            ghead_flat = torch.zeros_like(L["head_flat"])
+            ops.bce_logits(L["head_flat"], L["obj_idx"], L["obj_lab"], grad=ghead_flat, gscale=g_obj)
+            ops.smooth_l1(L["head_flat"], L["box_idx"], L["rpn_tgt"], 1.0 / 9, L["obj_idx"].numel(), grad=ghead_flat, gscale=g_reg)
+            o, gpool, ghs = 0, None, []
+            for i, (h, w) in enumerate(level_hw):
+                ghs.append(ghead_flat[o:o + L["head_sizes"][i]].view(N, h, w, 16)); o += L["head_sizes"][i]
+                self.rpn_head.bwd(ghs[i], need_dx=False, accumulate=i > 0, x=L["tl"][i])
+                self.rpn_head._count(L["tl"][i], 1)
+            gts_ = ops.conv_group(ghs, self.rpn_head._packed_grad(), masks=L["tl"])       # 1x1 head: data gradient of the five levels + ReLU backward, one launch
+            gP = [None] * 4
+            for i in range(5):
+                gt = gts_[i]
+                if i < 4:
+                    gP[i] = self.rpn_conv.bwd(gt, accumulate=i > 0, x=P[i])
+                else:
+                    gpool = self.rpn_conv.bwd(gt, accumulate=True, x=P[4])
+        finally:
+            self.accumulate_grads = acc_saved
+            for c, (gw, gb) in zip(layers, saved):
+                c.gw, c.gb = gw, gb
+        return gP, gpool
+
+    def _commit_speculative(self, spec):
+        """The speculative RPN branch becomes the real one: its weight gradients move (or add) into the flat gradient buffer, on the
+        stream that computed them."""
+        gP, gpool = spec
+        st = self.side[0] if self.side is not None else torch.cuda.current_stream(self.dev)
+        with torch.cuda.stream(st):
+            for c, (gw, gb) in zip((self.rpn_head, self.rpn_conv), self._spec_grads):
+                for dst, src in ((c.gw, gw), (c.gb, gb)):
+                    if dst is None:
+                        continue
+                    if self.accumulate_grads:
+                        dst.add_(src)
+                    else:
+                        dst.copy_(src)
+        return gP, gpool
 
     # ---- backward ----
     def backward(self, gscale=(1.0, 1.0, 1.0, 1.0)):
@@ -655,23 +741,12 @@ class FasterRCNNTrainer(_TrainerBase):
                 ops.roi_align_bwd_(gP_roi, L["rois"], groi.view(R, 49, -1))
             finally:
                 ops._WGRAD_CTX[0] = prev
-        # RPN head (shared weights: gradients accumulate over the five levels)
-        ghead_flat = torch.zeros_like(L["head_flat"])
-        ops.bce_logits(L["head_flat"], L["obj_idx"], L["obj_lab"], grad=ghead_flat, gscale=gscale[2])
-        ops.smooth_l1(L["head_flat"], L["box_idx"], L["rpn_tgt"], 1.0 / 9, L["obj_idx"].numel(), grad=ghead_flat, gscale=gscale[3])
-        o, gpool, ghs = 0, None, []
-        for i, (h, w) in enumerate(level_hw):
-            ghs.append(ghead_flat[o:o + L["head_sizes"][i]].view(N, h, w, 16)); o += L["head_sizes"][i]
-            self.rpn_head.bwd(ghs[i], need_dx=False, accumulate=i > 0, x=L["tl"][i])
-            self.rpn_head._count(L["tl"][i], 1)
-        gts_ = ops.conv_group(ghs, self.rpn_head._packed_grad(), masks=L["tl"])           # 1x1 head: data gradient of the five levels + ReLU backward, one launch
-        gP = [None] * 4
-        for i in range(5):
-            gt = gts_[i]
-            if i < 4:
-                gP[i] = self.rpn_conv.bwd(gt, accumulate=i > 0, x=P[i])
-            else:
-                gpool = self.rpn_conv.bwd(gt, accumulate=True, x=P[4])
+        spec = L.get("spec")
+        if spec is not None and float(gscale[2]) == 1.0 and float(gscale[3]) == 1.0:
+            gP, gpool = self._commit_speculative(spec)
+        else:
+            gP, gpool = self._rpn_branch_backward(L, gscale[2], gscale[3])
+        L["spec"] = None
         if aux is not None:
             main.wait_stream(aux[0])
             for t in gP_roi:
@@ -914,6 +989,7 @@ class TrainableDetector(object):
         return self.net.parameters()
 
     def __call__(self, images, targets):
+        self.net.grad_wanted = torch.is_grad_enabled()
         out = _LossFn.apply(self._anchor, self.net, images, targets)
         return dict(zip(self.net.LOSS_NAMES, out))
 

@@ -403,6 +403,37 @@ def test_drop_in_training_loop_updates_like_torch_sgd(T, oracle):
         assert err <= 1e-5, (k, err)
 
 
+def test_speculative_rpn_branch_equals_the_plain_backward(T):
+    """The RPN branch of the backward pass is enqueued during the forward's RoI-sampling window for unit upstream gradients.  Same
+    losses and the same gradients, bit for bit, as with the speculation off; non-unit upstream gradients fall back to the plain path;
+    a forward under torch.no_grad() does not speculate."""
+    torch, ops = T
+    from cald_amd import train
+    sd, images, targets = _train_case(torch, n_images=3, seed=33)
+    out = {}
+    for spec in (True, False):
+        net = train.FasterRCNNTrainer(sd, 21, min_size=160, max_size=256, box_batch=64, generator=torch.Generator().manual_seed(4))
+        net.speculate = spec
+        losses = net.forward(images, targets)
+        assert (net.last["spec"] is not None) == spec
+        grads = net.backward()
+        torch.cuda.synchronize()
+        out[spec] = ({k: float(v) for k, v in losses.items()}, {k: v.clone() for k, v in grads.items()})
+        if spec:                                            # scaled losses: the speculative result is dropped, the plain path runs
+            net.forward(images, targets)
+            g2 = net.backward((1.0, 1.0, 0.5, 2.0))
+            torch.cuda.synchronize()
+            k = "rpn.head.conv.weight"
+            assert not torch.equal(g2[k], out[True][1][k]) and bool(torch.isfinite(g2[k]).all())
+            model = train.TrainableFasterRCNN(net)
+            with torch.no_grad():
+                model(images, targets)
+            assert net.last["spec"] is None
+    assert out[True][0] == out[False][0]
+    for k in out[True][1]:
+        assert torch.equal(out[True][1][k], out[False][1][k]), k
+
+
 def test_fused_sgd_launch_equals_the_per_tensor_launches(T):
     """train.SGD over exactly the trainer's parameters updates the flat buffers with one launch; with a parameter subset (or net=None)
     it launches per tensor.  Both give the same bits after two steps, and state[p]['momentum_buffer'] is readable either way."""

@@ -24,6 +24,8 @@ for im in imgs:
 rows = []
 for i in range(12):
     if i == 4:
+        if "norepack" in sys.argv:                      # A/B: how much of the step the weight packing costs (weights go stale: timing only)
+            net._repack = lambda: None
         torch.cuda.synchronize(); t_start = time.time()
     t0 = time.time()
     marks = []
