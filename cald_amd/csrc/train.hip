@@ -19,6 +19,7 @@
 //   optimizer                  sgd_kernel: torch.optim.SGD (weight decay, momentum, no dampening / nesterov) over the flat
 //                              parameter buffer
 #include "common.h"
+#include <type_traits>
 #include "kernels.h"
 #include "sortnms.h"
 #include "../../include/cald_hip.h"
@@ -287,8 +288,17 @@ struct WgradArgs {
 // the split gets the out-of-range offset and loads zeros -- no branches, no 64-bit multiplies in the loop (the fp32 MFMA shares its
 // issue slots with the VALU: the first version spent a third of the loop on address arithmetic).
 typedef float f32x4v __attribute__((ext_vector_type(4)));
-template <bool FAST, int BK>
+// PW (1 x 1 filter, stride 1, no padding, or a linear layer; implies FAST): both operands are plain row-major matrices over the pixels,
+// so the cursors are two additions per row and the buffer descriptors end at the tensors' ends -- rows past the last pixel load zeros
+// without a compare (the general path spends ~70 VALU instructions per stage on the pixel cursor and the image-border tests).
+// MODE 2 (filters with a spatial extent / strides, Cin % 128 == 0 so that the 128 columns of a tile are ONE tap; implies FAST): the
+// byte offset of every pixel under that tap -- or the out-of-range offset outside the image -- is computed 1 024 pixels at a time into
+// an LDS table; a stage reads two table words per thread instead of stepping (n, y, x) cursors.
+template <bool FAST, int BK, int MODE = 0>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
+    constexpr bool PW = MODE == 1, TAB = MODE == 2;
+    constexpr int TQ = 1024;                                  // MODE 2: pixels per table fill (a multiple of 2 * BK: every fill starts on stage buffer 0)
+    __shared__ int tab[TAB ? TQ + 2 * BK : 1];
     constexpr int R = BK / 8;                                    // rows of both tiles staged per thread
     __shared__ __attribute__((aligned(16))) float sA[2][BK][128];
     __shared__ __attribute__((aligned(16))) float sB[2][BK][128];
@@ -324,8 +334,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
             for (int r = 0; r < 16; r++) acc[i][jn][r] = 0.0f;
     float4 ra[R], rb[R];
     // FAST-path cursor: byte offsets from the tensor bases, remaining rows of the split, input coordinates of this thread's tap
-    const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc((void*)a.g, 0, 0x7FFE0000, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, 0x7FFE0000, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc((void*)a.g, 0, (PW || TAB) ? (int)(a.Q * a.ldg * 4) : 0x7FFE0000, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, PW ? (int)(a.Q * a.ldx * 4) : 0x7FFE0000, 0x00020000);
     int voffG[R], voffX[R], left[R], fiy[R], fix[R], fpx[R], fpy[R];
     const int stepG = BK * a.ldg * 4, stepX = BK * a.stride * a.ldx * 4, stepI = BK * a.stride;
     const int rowX = (a.stride * a.W - a.Wo * a.stride) * a.ldx * 4, imgX = (a.H - a.Ho * a.stride) * a.W * a.ldx * 4;
@@ -337,9 +347,53 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
             fpy[r] = py[r]; fpx[r] = px[r];
             fiy[r] = py[r] * a.stride + ky - a.pad; fix[r] = px[r] * a.stride + kx - a.pad;
             voffX[r] = (int)(((((long long)pn[r] * a.H + fiy[r]) * a.W + fix[r]) * a.ldx + ci) * 4);
+            if (PW || TAB) {                                 // columns beyond the matrix: the out-of-range offset for the whole kernel
+                if (!mvalid) voffG[r] = 0x7FFF0000;          // (the cursor advances by less than 2 GB in total: no wrap-around)
+                voffX[r] = jvalid ? (int)((pq[r] * a.ldx + ci) * 4) : 0x7FFF0000;
+            }
         }
     }
+    int ti = row;                                            // MODE 2: table index of this thread's first row of the next stage
+    const int ci4 = jvalid ? ci * 4 : 0x7FFF0000;            // added to a table word; any word + 0x7FFF0000 is out of range
+    // table words [0, TQ + 2 BK) <-> pixels sub .. : the BK words past TQ are the first stage of the next fill, which the last stage of
+    // this one prefetches
+    auto fill = [&](long long sub) {
+        const int hw = a.Ho * a.Wo;
+        for (int e = tid; e < TQ + 2 * BK; e += 256) {
+            int off = 0x7FFF0000;
+            const long long q = sub + e;
+            if (q < q1) {
+                const int n = (int)(q / hw), rem = (int)(q - (long long)n * hw);
+                const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+                const int iy = oy * a.stride + ky - a.pad, ix = ox * a.stride + kx - a.pad;
+                if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) off = (int)(((((long long)n * a.H + iy) * a.W + ix) * a.ldx) * 4);
+            }
+            tab[e] = off;
+        }
+        __syncthreads();
+    };
+    if (TAB) fill(q0);
     auto load = [&]() {
+        if (TAB) {
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int vx = tab[ti + 8 * r] + ci4;
+                ra[r] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsG, voffG[r], 0, 0));
+                rb[r] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsX, vx, 0, 0));
+                voffG[r] += stepG;
+            }
+            ti += BK;
+            return;
+        }
+        if (PW) {
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                ra[r] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsG, voffG[r], 0, 0));
+                rb[r] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsX, voffX[r], 0, 0));
+                voffG[r] += stepG; voffX[r] += stepX;
+            }
+            return;
+        }
         if (FAST) {
 #pragma unroll
             for (int r = 0; r < R; r++) {
@@ -383,9 +437,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
     const int stages = (int)((q1 - q0 + BK - 1) / BK);
     load(); store(0);
     __syncthreads();
-    for (int s = 0; s < stages; s++) {
-        const int buf = s & 1;
-        load();                                               // stage s + 1 (zeros past the end)
+    // one stage; the buffer index is a compile-time constant (two stages per loop turn), so every LDS address below is a register +
+    // an immediate -- with a run-time buffer index each of the 16 fragment reads costs a v_add beside the MFMAs
+    auto stage = [&](auto bufc) {
+        constexpr int buf = decltype(bufc)::value;
+        load();                                               // the next stage (zeros past the end)
         // fragments of k-step ks + 1 are read from LDS before the MFMAs of k-step ks issue (the compiler does not hoist them itself)
         float fa0 = sA[buf][kl][wm * 64 + cl], fa1 = sA[buf][kl][wm * 64 + 32 + cl];
         float fb0 = sB[buf][kl][wn * 64 + cl], fb1 = sB[buf][kl][wn * 64 + 32 + cl];
@@ -404,6 +460,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
         }
         store(buf ^ 1);
         __syncthreads();
+    };
+    if (TAB) {
+        for (int s0 = 0; s0 < stages; s0 += TQ / BK) {
+            if (s0) { fill(q0 + (long long)s0 * BK); ti = row + BK; }      // (the stage before ended on a barrier; stage s0 is already staged)
+            const int s1 = s0 + TQ / BK < stages ? s0 + TQ / BK : stages;
+            for (int s = s0; s < s1; s += 2) {
+                stage(std::integral_constant<int, 0>());
+                if (s + 1 < s1) stage(std::integral_constant<int, 1>());
+            }
+        }
+    } else {
+        for (int s = 0; s < stages; s += 2) {
+            stage(std::integral_constant<int, 0>());
+            if (s + 1 < stages) stage(std::integral_constant<int, 1>());
+        }
     }
     // partial tile -> partial[S][MT*128][JT*128]
     const long long ldp = (long long)a.JT * 128;
@@ -510,8 +581,17 @@ static int wgrad_impl(cald_ctx* c, long long Q, int N, int H, int W, const float
     a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.J = KH * KW * Cin; a.JT = (a.J + 127) / 128; a.MT = (Cout + 127) / 128; a.Q = Q;
     const long long tiles = (long long)a.MT * a.JT;
     const long long tile_floats = tiles * 128 * 128;
-    static const long long target = getenv("CALD_WGRAD_TARGET") ? atoll(getenv("CALD_WGRAD_TARGET")) : 2048;     // workgroups aimed at per launch
-    long long S = (target + tiles - 1) / tiles;
+    // workgroups aimed at per launch: one resident round (2 per CU).  Measured on the whole step (the kernel shares the chip with the
+    // data-gradient stream): 512 -> 34.6 / 33.8 ms (Faster R-CNN / RetinaNet), 384 -> 34.3 / 34.7, 1024 -> 34.9, 2048 -> 35.0 / 35.5
+    static const long long target = getenv("CALD_WGRAD_TARGET") ? atoll(getenv("CALD_WGRAD_TARGET")) : 512;
+    const long long bytesG = Q * ldg * 4, bytesX = (long long)N * H * W * ldx * 4;
+    const bool fast = bytesG < 0x7FFE0000ll && bytesX < 0x7FFE0000ll;
+    static const bool pw_env = !(getenv("CALD_WGRAD_PW") && atoi(getenv("CALD_WGRAD_PW")) == 0);
+    static const bool tab_env = !(getenv("CALD_WGRAD_TAB") && atoi(getenv("CALD_WGRAD_TAB")) == 0);
+    // pointwise: every pixel row q of g pairs with row q of x (chunks are multiples of 32 pixels, so only the last split runs past Q)
+    const bool pw = fast && pw_env && KH == 1 && KW == 1 && stride == 1 && pad == 0 && Ho == H && Wo == W && Q == (long long)N * H * W;
+    const bool tabm = fast && tab_env && !pw && Cin % 128 == 0;
+    long long S = target / tiles;                         // rounded down: one workgroup over the resident round costs a second round
     const long long maxS_rows = (Q + 255) / 256; if (S > maxS_rows) S = maxS_rows;
     const long long cap = (512ll << 20) / 4 / tile_floats; if (S > cap) S = cap;
     if (S < 1) S = 1;
@@ -521,10 +601,10 @@ static int wgrad_impl(cald_ctx* c, long long Q, int N, int H, int W, const float
     void* scratch = nullptr;
     if (int rc = cald_internal_scratch(c, (size_t)(S * tile_floats + csplit * Cout + 64) * 4, &scratch)) return rc;
     a.partial = (float*)scratch;
-    const long long bytesG = Q * ldg * 4, bytesX = (long long)N * H * W * ldx * 4;
     static const int bk_env = getenv("CALD_WGRAD_BK") ? atoi(getenv("CALD_WGRAD_BK")) : 16;     // 32-pixel stages measured slower (109 vs 115 TFLOP/s on the largest layer)
-    const bool fast = bytesG < 0x7FFE0000ll && bytesX < 0x7FFE0000ll;
-    if (fast && bk_env == 32) hipLaunchKernelGGL((wgrad_kernel<true, 32>), dim3((unsigned)tiles, (unsigned)S), dim3(256), 0, st, a);
+    if (pw) hipLaunchKernelGGL((wgrad_kernel<true, 16, 1>), dim3((unsigned)tiles, (unsigned)S), dim3(256), 0, st, a);
+    else if (tabm) hipLaunchKernelGGL((wgrad_kernel<true, 16, 2>), dim3((unsigned)tiles, (unsigned)S), dim3(256), 0, st, a);
+    else if (fast && bk_env == 32) hipLaunchKernelGGL((wgrad_kernel<true, 32>), dim3((unsigned)tiles, (unsigned)S), dim3(256), 0, st, a);
     else if (fast) hipLaunchKernelGGL((wgrad_kernel<true, 16>), dim3((unsigned)tiles, (unsigned)S), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((wgrad_kernel<false, 16>), dim3((unsigned)tiles, (unsigned)S), dim3(256), 0, st, a);
     const long long nred = (long long)Cout * a.J;

@@ -32,6 +32,9 @@ CONV_CASES = [   # N, H, W, Cin, Cout, K, stride, pad, bias
     (1, 13, 17, 256, 256, 3, 1, 1, True),
     (2, 12, 10, 256, 15, 1, 1, 0, True),      # merged RPN head (3 logits + 12 deltas): dY rows padded to 16 channels
     (2, 9, 11, 48, 80, 3, 1, 1, True),        # channel counts that are not multiples of 64
+    (2, 18, 22, 128, 64, 3, 2, 1, False),     # Cin % 128 == 0: the weight gradient's offset-table variant, strided
+    (2, 18, 22, 256, 64, 1, 2, 0, True),      # ... the 1x1 stride-2 downsample shape
+    (2, 75, 70, 128, 128, 3, 1, 1, False),    # ... 10 500 pixels: several splits, a ragged last one
 ]
 
 
