@@ -386,6 +386,7 @@ class _TrainerBase(object):
         """Host side of GeneralizedRCNNTransform: sizes, resized ground-truth boxes (device) and labels (host)."""
         sizes = [ops.transform_size(im.shape[0], im.shape[1], self.min_size, self.max_size) for im in u8]
         Hp, Wp = max(s[2] for s in sizes), max(s[3] for s in sizes)
+        self.last_padded_hw = (Hp, Wp)
         img_sizes = [(s[0], s[1]) for s in sizes]
         gts, gt_labels = [], []
         for im, s, t in zip(u8, sizes, targets):                    # resize_boxes: per-axis ratio in float32

@@ -650,3 +650,77 @@ def test_coco_bbox_ap_hand_computed_cases(capsys):
     preds[1]["boxes"][0] = [100, 100, 160, 160]                          # moved out of the crowd region: now a higher-scored false positive
     s, _ = run(img[:1], gtc, preds)
     np.testing.assert_allclose(s[0], 0.5, rtol=1e-12)                   # precision 1/2 at every recall level
+
+
+def test_aspect_ratio_batch_sampler_equals_reference_golden(golden, tmp_path):
+    """cald_amd/group_by_aspect_ratio.py (cald_train.py:326-332: the default batch sampler of the training loop) against what the
+    imported reference produced (oracle/make_golden_group_sampler.py): group ids for k = 0 / 1 / 3, including ratios exactly on bin
+    edges, and every batch of GroupedBatchSampler over sequential and permuted orders, batch sizes 2 / 4 / 7 -- incomplete groups
+    topped up in the reference's order.  Plus the dataset fast paths (COCO image table, VOC JPEG headers, Subset)."""
+    import torch
+    from torch.utils.data.sampler import Sampler
+    from cald_amd import group_by_aspect_ratio as G
+    z = golden("group_sampler")
+
+    class Sizes(object):
+        def __init__(self, hw):
+            self.hw = hw
+
+        def __len__(self):
+            return len(self.hw)
+
+        def get_height_and_width(self, i):
+            return int(self.hw[i][0]), int(self.hw[i][1])
+
+    class Order(Sampler):
+        def __init__(self, order):
+            self.order = list(order)
+
+        def __iter__(self):
+            return iter(self.order)
+
+        def __len__(self):
+            return len(self.order)
+
+    n_batches = 0
+    for name in ("voc", "coco", "edges", "one_group"):
+        hw = z["hw_" + name]
+        for k in (0, 1, 3):
+            groups = G.create_aspect_ratio_groups(Sizes(hw), k=k)
+            assert groups == z["groups_%s_k%d" % (name, k)].tolist(), (name, k)
+            for bs in (2, 4, 7):
+                for oi in (0, 1):
+                    key = "%s_k%d_b%d_o%d" % (name, k, bs, oi)
+                    if "order_" + key not in z.files:
+                        continue
+                    s = G.GroupedBatchSampler(Order(z["order_" + key].tolist()), groups, bs)
+                    got = [list(b) for b in s]
+                    assert len(got) == len(s) == len(hw) // bs
+                    assert got == z["batches_" + key].tolist(), key
+                    assert all(len({groups[i] for i in b}) == 1 for b in got), key     # one group per batch
+                    n_batches += len(got)
+    assert n_batches > 1000
+    with pytest.raises(ValueError):
+        G.GroupedBatchSampler([0, 1, 2], [0, 0, 0], 2)
+    # dataset fast paths: a VOC tree on disk (JPEG headers only), a COCO image table, a Subset of either
+    from PIL import Image
+    from cald_amd import coco_utils, voc_utils
+    base = tmp_path / "VOCdevkit" / "VOC2007"
+    for d in ("JPEGImages", "Annotations", "ImageSets/Main"):
+        (base / d).mkdir(parents=True)
+    sizes = [(375, 500), (500, 375), (333, 500), (500, 500)]
+    for i, (h, w) in enumerate(sizes):
+        Image.fromarray(np.zeros((h, w, 3), np.uint8)).save(str(base / "JPEGImages" / ("%06d.jpg" % i)))
+        (base / "Annotations" / ("%06d.xml" % i)).write_text("<annotation><filename>%06d.jpg</filename></annotation>" % i)
+    (base / "ImageSets" / "Main" / "trainval.txt").write_text("".join("%06d\n" % i for i in range(len(sizes))))
+    ds = voc_utils.VOCDetection(str(tmp_path), "2007", "trainval", None)
+    want = [float(w) / float(h) for h, w in sizes]
+    assert G.compute_aspect_ratios(ds) == want
+    assert G.compute_aspect_ratios(coco_utils.Subset(ds, [2, 0])) == [want[2], want[0]]
+    assert G.create_aspect_ratio_groups(ds, k=3) == G._quantize(want, (2 ** np.linspace(-1, 1, 7)).tolist())
+    import json
+    ann = tmp_path / "instances.json"
+    ann.write_text(json.dumps({"images": [{"id": 7, "width": 640, "height": 480, "file_name": "a.jpg"}, {"id": 3, "width": 427, "height": 640, "file_name": "b.jpg"}],
+                               "annotations": [], "categories": []}))
+    cds = coco_utils.CocoDetection(str(tmp_path), str(ann), None)
+    assert G.compute_aspect_ratios(cds) == [427.0 / 640.0, 640.0 / 480.0]          # ids sorted: 3, 7

@@ -17,7 +17,7 @@ import torch
 from cald_amd import synth, train
 
 
-def measure(batch=4, steps=10, warmup=3, depth=50, verbose=False, model="frcnn"):
+def measure(batch=4, steps=10, warmup=3, depth=50, verbose=False, model="frcnn", mixed=False):
     from types import SimpleNamespace
     a = SimpleNamespace(batch=batch, steps=steps, warmup=warmup, depth=depth)
     if model == "retinanet":
@@ -29,7 +29,15 @@ def measure(batch=4, steps=10, warmup=3, depth=50, verbose=False, model="frcnn")
     arch = model
     model = train.TrainableDetector(net)
     opt = train.SGD([p for p in model.parameters() if p.requires_grad], lr=1e-5, momentum=0.9, weight_decay=1e-4, net=net)
-    imgs = synth.make_pool(a.batch * 2, "voc", 0)
+    if mixed:                       # whatever order the pool comes in: landscape and portrait images share batches (pads to 800 x 800)
+        imgs = synth.make_pool(a.batch * 2, "voc", 0)
+    else:                           # cald_train.py's default sampler (:326-330, --aspect-ratio-group-factor 3): one aspect-ratio group per batch
+        from torch.utils.data.sampler import SequentialSampler
+        from cald_amd.group_by_aspect_ratio import GroupedBatchSampler, _quantize
+        sizes = synth.pool_sizes(16 * a.batch, "voc", 0)
+        groups = _quantize([float(w) / float(h) for h, w in sizes], (2 ** np.linspace(-1, 1, 7)).tolist())
+        picked = [b for _, b in zip(range(2), GroupedBatchSampler(SequentialSampler(sizes), groups, a.batch))]
+        imgs = [synth.synth_image(i, sizes[i][0], sizes[i][1]) for b in picked for i in b]
     rs = np.random.RandomState(0)
     batches = []
     for b in range(2):
@@ -89,6 +97,8 @@ def measure(batch=4, steps=10, warmup=3, depth=50, verbose=False, model="frcnn")
             "backward_gpu_ms": t_all * 1e3,
             "gemm": {"algorithmic_gflop_per_step": flops / 1e9, "achieved_tflops_over_whole_step": flops / dt / 1e12, "peak_tflops": 157.3,
                      "frac_of_fp32_mfma_peak": flops / dt / 1e12 / 157.3, "note": "forward + data-gradient + weight-gradient GEMM FLOPs (true channels, no padding, strided data gradients at their algorithmic cost) / wall-clock of the whole step incl. host work"}, "loss": float(last.detach()), "dtype": "f32",
+            "batch_composition": "mixed orientations" if mixed else "one aspect-ratio group per batch (GroupedBatchSampler, k = 3)",
+            "padded_batch_hw": [list(net.last_padded_hw)] if getattr(net, "last_padded_hw", None) else None,
             "config": "cald_train.py defaults: batch 4, VOC-sized synthetic images, min_size 600 / max_size 1000, SGD momentum 0.9"
                       + (", 2000 proposals, 512 RoIs / image" if arch == "frcnn" else ", 9 anchors / location on P3-P7")}
 
@@ -97,8 +107,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=4); ap.add_argument("--steps", type=int, default=10); ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--depth", type=int, default=50); ap.add_argument("--model", default="frcnn", choices=["frcnn", "retinanet"])
+    ap.add_argument("--mixed", action="store_true", help="landscape and portrait images in one batch instead of the reference's aspect-ratio-grouped batches")
     a = ap.parse_args()
-    print(json.dumps(measure(a.batch, a.steps, a.warmup, a.depth, verbose=True, model=a.model)))
+    print(json.dumps(measure(a.batch, a.steps, a.warmup, a.depth, verbose=True, model=a.model, mixed=a.mixed)))
 
 
 if __name__ == "__main__":
