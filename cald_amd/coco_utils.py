@@ -128,6 +128,16 @@ def label_loader(dataset, indices):
 
 
 CocoDetection.device_pool = device_pool
+
+
+def resident_train_loader(dataset, batch_sampler, indices, pool=None, flip_prob=0.5):
+    """voc_utils.ResidentTrainLoader over a COCO dataset (or Subset): HBM-resident training batches, flip on the device."""
+    from .voc_utils import ResidentTrainLoader
+    return ResidentTrainLoader(dataset, batch_sampler, indices, pool, flip_prob)
+
+
+CocoDetection.resident_train_loader = resident_train_loader
+Subset.resident_train_loader = resident_train_loader
 CocoDetection.label_loader = label_loader
 
 

@@ -144,11 +144,52 @@ class VOCDetection(object):
         """[(None, (target,))] over `indices`: the labeled loader of cald_train.py:434-444 as far as cls_kldiv reads it."""
         return [(None, (self.target(int(i)),)) for i in indices]
 
+    def resident_train_loader(self, batch_sampler, indices, pool=None, flip_prob=0.5):
+        """ResidentTrainLoader over the dataset indices `indices` (the labeled set) -- see the class."""
+        return ResidentTrainLoader(self, batch_sampler, indices, pool, flip_prob)
+
     def resident_loader(self, indices=None, pool=None):
         """A loader over HBM-resident images WITH their targets (batch size 1, the reference's test loader shape), carrying
         ``.dataset`` so voc_evaluate finds root / image_set / CLASSES."""
         idx = list(range(len(self)) if indices is None else indices)
         return _ResidentLoader(self, idx, pool if pool is not None else self.device_pool(idx))
+
+
+class ResidentTrainLoader(object):
+    """The training loader of cald_train.py:333-336 over an HBM-resident pool: for every batch of ``batch_sampler`` (dataset indices,
+    e.g. GroupedBatchSampler over SubsetRandomSampler(labeled_set)) the uint8 HWC device images and their targets -- what
+    ``task_model(images, targets)`` takes in train mode -- with get_transform(train=True)'s RandomHorizontalFlip(``flip_prob``) applied
+    on the device: one draw of Python's ``random`` per image in batch order (detection/transforms.py:27-37), the image mirrored along
+    its width, the boxes mapped to (width - xmax, ymin, width - xmin, ymax).  No file is read or decoded during the epoch."""
+
+    def __init__(self, dataset, batch_sampler, indices, pool=None, flip_prob=0.5):
+        self.dataset, self.batch_sampler, self.flip_prob = dataset, batch_sampler, flip_prob
+        self.indices = [int(i) for i in indices]
+        self.pool = pool if pool is not None else dataset.device_pool(self.indices)
+        self._pos = {i: k for k, i in enumerate(self.indices)}
+
+    def __len__(self):
+        return len(self.batch_sampler)
+
+    def __iter__(self):
+        import random
+        for batch in self.batch_sampler:
+            images, targets = [], []
+            for i in batch:
+                img = self.pool[self._pos[int(i)]]
+                t = dict(self.dataset.target(int(i)))
+                if self.flip_prob and random.random() < self.flip_prob:
+                    width = img.shape[1]
+                    img = img.flip(1)
+                    b = t["boxes"].clone()
+                    b[:, [0, 2]] = width - b[:, [2, 0]]
+                    t["boxes"] = b
+                images.append(img); targets.append(t)
+            yield images, targets
+
+
+def resident_train_loader(dataset, batch_sampler, indices, pool=None, flip_prob=0.5):
+    return ResidentTrainLoader(dataset, batch_sampler, indices, pool, flip_prob)
 
 
 class _ResidentLoader(object):

@@ -545,6 +545,40 @@ def test_training_transform_flip_matches_reference_golden(golden):
     assert isinstance(tr.transforms[0], vu.ToTensor) and isinstance(tr.transforms[1], vu.RandomHorizontalFlip) and len(vu.get_transform(False).transforms) == 1
 
 
+def test_resident_training_loader_flips_like_the_reference_transform(golden):
+    """voc_utils.ResidentTrainLoader (training batches from an HBM-resident pool) applies RandomHorizontalFlip to the uint8 HWC pool
+    image and the boxes: same decisions (one `random` draw per image in batch order) and the same mirrored boxes / pixels as the
+    imported transform produced on its CHW float tensor (ten draws, seed 11); batches follow the batch sampler; targets are copies."""
+    import random
+    import torch
+    from cald_amd import voc_utils as vu
+    g = golden("voc_utils")
+    chw = g["flip_image_in"]                                                     # 3 x 4 x 7 float
+    hwc = torch.from_numpy(np.ascontiguousarray(np.round(chw * 100).astype(np.uint8).transpose(1, 2, 0)))      # same pattern as uint8 HWC
+    boxes0 = torch.from_numpy(g["flip_boxes_in"].copy())
+
+    class DS(object):
+        def target(self, i):
+            return {"boxes": boxes0, "labels": torch.tensor([1, 2]), "image_id": i}
+
+    batches = [[0, 1, 2, 3], [4, 5, 6], [7, 8, 9]]
+    loader = vu.ResidentTrainLoader(DS(), batches, indices=range(10), pool=[hwc] * 10, flip_prob=0.5)
+    assert len(loader) == 3
+    random.seed(11)
+    k = 0
+    for (images, targets), want in zip(loader, batches):
+        assert len(images) == len(targets) == len(want)
+        for img, t, i in zip(images, targets, want):
+            assert t["image_id"] == i
+            np.testing.assert_array_equal(t["boxes"].numpy(), g["flip_boxes_out"][k])
+            np.testing.assert_array_equal(img.permute(2, 0, 1).numpy(), np.round(g["flip_images_out"][k] * 100).astype(np.uint8))
+            k += 1
+    assert k == 10
+    np.testing.assert_array_equal(boxes0.numpy(), g["flip_boxes_in"])            # the dataset's tensors are not modified in place
+    random.seed(11)
+    assert all(torch.equal(im, hwc) for ims, _ in vu.ResidentTrainLoader(DS(), batches, range(10), pool=[hwc] * 10, flip_prob=0.0) for im in ims)
+
+
 def test_training_operator_host_side_contracts():
     """The cald_train_* entry points that need no GPU: packed-weight geometry (what cald_amd/train.py allocates for) and argument
     validation -- a null context / bad mode is an error code with a message, never a crash, and nothing silently falls back."""

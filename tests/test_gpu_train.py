@@ -602,6 +602,59 @@ def test_active_learning_cycle_train_then_sweep_with_the_same_model_object(T, or
     assert after != before
 
 
+def test_training_epoch_from_a_vocdevkit_directory_on_resident_batches(T, tmp_path):
+    """The training input side end to end (cald_train.py:288-336 without torchvision): VOCdevkit tree -> voc_utils dataset ->
+    aspect-ratio groups from the JPEG headers -> GroupedBatchSampler over SubsetRandomSampler(labeled_set) -> ResidentTrainLoader
+    (JPEGs decoded once on the GPU, flip on the device) -> train_one_epoch.  Every batch holds one orientation (so it pads to the
+    tight size), the pool images equal Pillow's decode, flipped images carry mirrored boxes inside the image, the losses are finite
+    and the weights move."""
+    import random
+    from PIL import Image
+    from torch.utils.data.sampler import SubsetRandomSampler
+    torch, ops = T
+    from cald_amd import detector, engine, synth, train, voc_utils as vu
+    from cald_amd.group_by_aspect_ratio import GroupedBatchSampler, create_aspect_ratio_groups
+    base = tmp_path / "VOCdevkit" / "VOC2007"
+    for d in ("ImageSets/Main", "Annotations", "JPEGImages"):
+        (base / d).mkdir(parents=True)
+    sizes = [(120, 160), (160, 120), (120, 160), (160, 120), (120, 160), (160, 120), (120, 160), (160, 120), (110, 160)]
+    stems = ["%06d" % (7 * i + 3) for i in range(len(sizes))]
+    for i, ((H, W), stem) in enumerate(zip(sizes, stems)):
+        Image.fromarray(synth.synth_image(i, H, W)).save(str(base / "JPEGImages" / (stem + ".jpg")), quality=90)
+        objs = "".join("<object><name>%s</name><difficult>0</difficult><bndbox><xmin>%d</xmin><ymin>%d</ymin><xmax>%d</xmax><ymax>%d</ymax></bndbox></object>"
+                       % (vu.VOC_CLASSES[1 + (i + j) % 20], 5 + 9 * j, 8 + 5 * j, 5 + 9 * j + W // 3, 8 + 5 * j + H // 3) for j in range(1 + i % 2))
+        (base / "Annotations" / (stem + ".xml")).write_text("<annotation><filename>%s.jpg</filename>%s</annotation>" % (stem, objs))
+    (base / "ImageSets" / "Main" / "trainval.txt").write_text("".join(s_ + "\n" for s_ in stems))
+    ds = vu.get_voc2007(str(tmp_path), "trainval", None)
+    labeled = list(range(len(ds)))
+    groups = create_aspect_ratio_groups(ds, k=3)
+    assert len(set(groups)) == 2
+    torch.manual_seed(3); random.seed(5)
+    sampler = GroupedBatchSampler(SubsetRandomSampler(labeled), groups, 2)
+    loader = ds.resident_train_loader(sampler, labeled)
+    for k, i in enumerate(labeled):                                   # the resident pool is Pillow's decode
+        np.testing.assert_array_equal(loader.pool[k].cpu().numpy(), np.asarray(Image.open(ds.images[i]).convert("RGB")))
+    seen = []
+    for images, targets in loader:
+        assert len(images) == 2 and len({im.shape[0] > im.shape[1] for im in images}) == 1      # one orientation per batch
+        for im, t in zip(images, targets):
+            assert im.is_cuda and im.dtype == torch.uint8 and im.shape[2] == 3
+            b = t["boxes"]
+            assert bool((b[:, 0] < b[:, 2]).all()) and float(b[:, 2].max()) <= im.shape[1] and float(b[:, 0].min()) >= 0
+            seen.append(tuple(im.shape))
+    assert len(seen) == 2 * len(loader) == 8
+    sd, _, _ = _train_case(torch, n_images=1, seed=2)
+    model = detector.fasterrcnn_resnet50_fpn_feature(num_classes=21, min_size=160, max_size=256).to("cuda")
+    model.load_state_dict(sd)
+    model.train()
+    opt = train.SGD([p for p in model.parameters() if p.requires_grad], lr=2e-4, momentum=0.9, weight_decay=1e-4)
+    history = engine.train_one_epoch(model, opt, loader, "cuda", cycle=0, epoch=0, print_freq=0)
+    assert len(history) == len(loader) == 4 and all(np.isfinite(history))
+    assert model._trainer.last_padded_hw in ((160, 224), (160, 256), (224, 160))      # one orientation per batch: never 224 x 224 / 224 x 256
+    model.eval()
+    assert not np.array_equal(model.state_dict()["roi_heads.box_head.fc7.weight"].numpy(), np.asarray(sd["roi_heads.box_head.fc7.weight"]))
+
+
 def test_training_batch_with_an_image_without_boxes_and_resnet101(T):
     """Edge cases of the training forward: an image with NO ground-truth boxes (torchvision: every anchor / proposal is background,
     zero regression targets), a batch of one, and the ResNet-101 body: finite losses, gradients for all trainable tensors."""
