@@ -126,26 +126,27 @@ class _Conv(object):
         self._count(x, 1)
         return ops.conv(x, self._packed(), stride=self.stride, pad=self.pad, relu=relu, residual=residual, up=up, out=out, out_ld=self.out_ld)
 
-    def bwd(self, g, need_dx=True, residual=None, accumulate=False, x=None, mask=None):
+    def bwd(self, g, need_dx=True, residual=None, accumulate=False, x=None, mask=None, wgrad=True):
         """g: gradient wrt this layer's output AFTER its FrozenBatchNorm (if any) and after the ReLU mask, row stride out_ld: the BN
         scale is folded into the packed data-gradient filter and into the weight-gradient reduction.  mask: the saved post-ReLU
         activation the returned data gradient flows into (its ReLU backward is applied in the conv epilogue)."""
         x = self.x if x is None else x
         accumulate = accumulate or self.net.accumulate_grads
-        self._count(x, 2 if need_dx else 1)
+        self._count(x, int(bool(need_dx)) + int(bool(wgrad)))
         side, prev = self.net.side, ops._WGRAD_CTX[0]
-        if side is not None:            # the weight gradient depends on (x, g) only: issue it beside the data gradient
-            side[0].wait_stream(torch.cuda.current_stream(self.net.dev))
-            x.record_stream(side[0]); g.record_stream(side[0])
-            ops._WGRAD_CTX[0] = side[1]
-        try:
-            if self.mode == 2 or self.w.dim() == 2:
-                ops.linear_wgrad(x.view(g.shape[2], -1), g.view(g.shape[2], -1), self.Cout, self.gw, self.gb, taps=self.taps or 1, accumulate=accumulate)
-            else:
-                ops.conv_wgrad(x, g, self.Cin, self.Cout, self.K, self.K, self.stride, self.pad, self.gw, self.gb, accumulate=accumulate,
-                               row_scale=self.scale)
-        finally:
-            ops._WGRAD_CTX[0] = prev
+        if wgrad:
+            if side is not None:        # the weight gradient depends on (x, g) only: issue it beside the data gradient
+                side[0].wait_stream(torch.cuda.current_stream(self.net.dev))
+                x.record_stream(side[0]); g.record_stream(side[0])
+                ops._WGRAD_CTX[0] = side[1]
+            try:
+                if self.mode == 2 or self.w.dim() == 2:
+                    ops.linear_wgrad(x.view(g.shape[2], -1), g.view(g.shape[2], -1), self.Cout, self.gw, self.gb, taps=self.taps or 1, accumulate=accumulate)
+                else:
+                    ops.conv_wgrad(x, g, self.Cin, self.Cout, self.K, self.K, self.stride, self.pad, self.gw, self.gb, accumulate=accumulate,
+                                   row_scale=self.scale)
+            finally:
+                ops._WGRAD_CTX[0] = prev
         if not need_dx:
             return None
         pkd = self._packed_grad()
@@ -472,8 +473,10 @@ class FasterRCNNTrainer(_TrainerBase):
         self.pred_ld = ops.round_up(5 * num_classes, 4)
         self.pred = _Conv(self, self._merge_groups[2], self._merge_groups[3], out_ld=self.pred_ld)
         assert self.pred.Cout == 5 * num_classes, "box predictor does not match num_classes"
-        # the RPN branch of the backward pass is enqueued during the forward's RoI-sampling window (see forward); CALD_TRAIN_SPECULATE=0: off
-        self.speculate = __import__("os").environ.get("CALD_TRAIN_SPECULATE", "1") != "0"
+        # CALD_TRAIN_SPECULATE=1: the first half of the backward's RPN branch is enqueued during the forward's RoI-sampling window (see
+        # forward).  Off by default: it paid (-0.8 ms) while the weight-gradient stream was the longer one of the backward; since that
+        # stream got faster the step is bound by the data-gradient chain, which wants the RPN branch beside the box-head branch: +0.7 ms
+        self.speculate = __import__("os").environ.get("CALD_TRAIN_SPECULATE", "0") != "0"
         self.grad_wanted = True         # TrainableDetector clears it under torch.no_grad()
         self._spec_grads = None
 
@@ -568,14 +571,16 @@ class FasterRCNNTrainer(_TrainerBase):
             props, counts = ops.rpn_proposals(heads, Hp, Wp, img_sizes, cfg["pre_n"], cfg["post_n"], cfg["nms"], 1e-3)
             if self.speculate and aux is not None and self.grad_wanted:
                 # The host now needs the proposals (counts, then the match results) to draw the RoI samples: ~1 ms during which the main
-                # stream would sit empty.  The RPN branch of the backward pass depends on nothing that comes later, so it is enqueued
-                # here, behind the proposal kernels, for unit upstream gradients (losses.backward() of the plain sum, the reference's
-                # loop); backward() uses it when its upstream gradients are 1 and recomputes otherwise.
+                # stream would sit empty.  The RPN branch of the backward pass depends on nothing that comes later, so its first half
+                # (loss gradients, the head's gradients, the 3x3 conv's weight gradients) is enqueued here, behind the proposal
+                # kernels, for unit upstream gradients (losses.backward() of the plain sum, the reference's loop); backward() uses it
+                # when its upstream gradients are 1 and recomputes otherwise.  The second half (the 3x3 conv's data gradients, ~2 ms)
+                # stays in backward(): there it runs beside the box-head branch, which would otherwise be alone on the chip.
                 props.record_stream(aux[0])
                 counts_h = torch.empty(counts.shape, dtype=counts.dtype, pin_memory=True)
                 counts_h.copy_(counts, non_blocking=True)
                 props_ready = torch.cuda.Event(); props_ready.record(self._main)
-                spec = self._rpn_branch_backward(rpn_state, 1.0, 1.0, speculative=True)
+                spec = self._rpn_branch_weights(rpn_state, 1.0, 1.0, speculative=True)
                 props_ready.synchronize()
                 counts = counts_h.tolist()
             else:
@@ -664,10 +669,11 @@ class FasterRCNNTrainer(_TrainerBase):
         out["fc6"] = (L["f6"] > 0).view(L["R"], -1).cpu(); out["fc7"] = (L["f7"] > 0).view(L["R"], -1).cpu()
         return out
 
-    def _rpn_branch_backward(self, L, g_obj, g_reg, speculative=False):
-        """RPN losses -> 1x1 head -> 3x3 conv: the gradients wrt the five pyramid levels (four tensors + the pooled level) and the
-        weight gradients of the two layers (shared weights: they accumulate over the levels).  speculative: the weight gradients go
-        to buffers of their own (whether backward() must overwrite or add to the flat gradient buffer is not known yet)."""
+    def _rpn_branch_weights(self, L, g_obj, g_reg, speculative=False):
+        """First half of the RPN branch: RPN losses -> gradient of the 1x1 head's output -> the weight gradients of the head and of the
+        3x3 conv (shared weights: they accumulate over the five levels) and the head's data gradient (with the conv's ReLU backward).
+        Returns that gradient per level -- what the 3x3 conv's data gradient (_rpn_branch_data) starts from.  speculative: the weight
+        gradients go to buffers of their own (whether backward() must overwrite or add to the flat buffer is not known yet)."""
         N, P, level_hw = L["N"], L["P"], L["level_hw"]
         layers = (self.rpn_head, self.rpn_conv)
         saved = [(c.gw, c.gb) for c in layers]
@@ -681,29 +687,30 @@ class FasterRCNNTrainer(_TrainerBase):
             ghead_flat = torch.zeros_like(L["head_flat"])
             ops.bce_logits(L["head_flat"], L["obj_idx"], L["obj_lab"], grad=ghead_flat, gscale=g_obj)
             ops.smooth_l1(L["head_flat"], L["box_idx"], L["rpn_tgt"], 1.0 / 9, L["obj_idx"].numel(), grad=ghead_flat, gscale=g_reg)
-            o, gpool, ghs = 0, None, []
+            o, ghs = 0, []
             for i, (h, w) in enumerate(level_hw):
                 ghs.append(ghead_flat[o:o + L["head_sizes"][i]].view(N, h, w, 16)); o += L["head_sizes"][i]
                 self.rpn_head.bwd(ghs[i], need_dx=False, accumulate=i > 0, x=L["tl"][i])
                 self.rpn_head._count(L["tl"][i], 1)
             gts_ = ops.conv_group(ghs, self.rpn_head._packed_grad(), masks=L["tl"])       # 1x1 head: data gradient of the five levels + ReLU backward, one launch
-            gP = [None] * 4
             for i in range(5):
-                gt = gts_[i]
-                if i < 4:
-                    gP[i] = self.rpn_conv.bwd(gt, accumulate=i > 0, x=P[i])
-                else:
-                    gpool = self.rpn_conv.bwd(gt, accumulate=True, x=P[4])
+                self.rpn_conv.bwd(gts_[i], need_dx=False, accumulate=i > 0, x=P[i])
         finally:
             self.accumulate_grads = acc_saved
             for c, (gw, gb) in zip(layers, saved):
                 c.gw, c.gb = gw, gb
+        return gts_
+
+    def _rpn_branch_data(self, L, gts_):
+        """Second half: the 3x3 conv's data gradient on the five levels -> gradients wrt P2..P5 and the pooled level."""
+        P = L["P"]
+        gP = [self.rpn_conv.bwd(gts_[i], x=P[i], wgrad=False) for i in range(4)]
+        gpool = self.rpn_conv.bwd(gts_[4], x=P[4], wgrad=False)
         return gP, gpool
 
-    def _commit_speculative(self, spec):
-        """The speculative RPN branch becomes the real one: its weight gradients move (or add) into the flat gradient buffer, on the
-        stream that computed them."""
-        gP, gpool = spec
+    def _commit_speculative(self):
+        """The speculative weight gradients of the RPN branch become the real ones: moved (or added) into the flat gradient buffer, on
+        the stream that computed them."""
         st = self.side[0] if self.side is not None else torch.cuda.current_stream(self.dev)
         with torch.cuda.stream(st):
             for c, (gw, gb) in zip((self.rpn_head, self.rpn_conv), self._spec_grads):
@@ -714,7 +721,6 @@ class FasterRCNNTrainer(_TrainerBase):
                         dst.add_(src)
                     else:
                         dst.copy_(src)
-        return gP, gpool
 
     # ---- backward ----
     def backward(self, gscale=(1.0, 1.0, 1.0, 1.0)):
@@ -744,10 +750,12 @@ class FasterRCNNTrainer(_TrainerBase):
                 ops._WGRAD_CTX[0] = prev
         spec = L.get("spec")
         if spec is not None and float(gscale[2]) == 1.0 and float(gscale[3]) == 1.0:
-            gP, gpool = self._commit_speculative(spec)
+            self._commit_speculative()
+            gts_ = spec
         else:
-            gP, gpool = self._rpn_branch_backward(L, gscale[2], gscale[3])
+            gts_ = self._rpn_branch_weights(L, gscale[2], gscale[3])
         L["spec"] = None
+        gP, gpool = self._rpn_branch_data(L, gts_)      # on the main stream, beside the box-head branch on the batch-only stream
         if aux is not None:
             main.wait_stream(aux[0])
             for t in gP_roi:
