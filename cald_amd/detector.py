@@ -166,7 +166,7 @@ class HipDetector:
             if self._state is None:
                 raise RuntimeError("no weights: call load_state_dict() first (cald_train.py:356)")
             L = _ffi.lib()
-            ctx = get_ctx(self._device)
+            ctx = self._ctx if getattr(self, "_ctx", None) is not None else get_ctx(self._device)      # _ctx: a context of its own (second stream)
             h = C.c_void_p()
             _ffi.check(L.cald_model_create(ctx, C.byref(self.cfg), C.byref(h)))
             for k, v in self._state.items():

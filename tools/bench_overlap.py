@@ -1,0 +1,94 @@
+"""VERDICT weak 11 / next 9, measured: the sweep's non-GEMM tail (proposals, RoIAlign, post-processing: 4.4 % of a step) overlapped with
+the GEMMs of ANOTHER batch -- two model instances on two library contexts (two HIP streams), two host threads, alternate batches --
+against the one-stream sweep of the same pool.  Prints one JSON object: images/s both ways, the GEMM rate by the per-launch HIP events
+of each context (which now time kernels that share the chip), and whether the scores are identical."""
+import ctypes as C
+import json
+import os
+import sys
+import threading
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+import bench as B
+from cald_amd import _ffi, detector, sweep, synth
+from cald_amd.pool import DevicePool
+
+
+def make_model(sd, ctx=None):
+    m = detector.fasterrcnn_resnet50_fpn_feature(num_classes=21, min_size=600, max_size=1000)
+    m = m.to("cuda:0")
+    m._ctx = ctx
+    m.load_state_dict(sd)
+    m.eval()
+    return m
+
+
+def gemm_rate(L, ctxs):
+    ms = fl = 0.0
+    for c in ctxs:
+        gm, gf, tot = C.c_double(), C.c_double(), C.c_double(); nl = C.c_int64()
+        _ffi.check(L.cald_profile_read(c, C.byref(gm), C.byref(gf), C.byref(nl), C.byref(tot)))
+        ms += gm.value; fl += gf.value
+    return fl / (ms * 1e-3) / 1e12 if ms else 0.0
+
+
+def main():
+    steps, bi = int(os.environ.get("STEPS", "8")), 64
+    torch.cuda.set_device(0)
+    L = _ffi.lib()
+    sd = synth.pseudo_trained_frcnn(21, 50, seed=0)
+    augs = ["flip", "cut_out", "smaller_resize"]
+    n = steps * bi
+    sizes = synth.pool_sizes(n + bi, "voc", 0)
+    blobs = B.make_jpeg_pool(list(range(n + bi)), sizes)
+    pool = DevicePool.from_jpeg_bytes(blobs)
+    pos = list(range(n + bi))
+    main_ctx = detector.get_ctx(0)
+    side_ctx = detector.get_side_ctx(0, torch.cuda.Stream())
+    models = [make_model(sd), make_model(sd, side_ctx)]
+    ctxs = [main_ctx, side_ctx]
+
+    def run_batch(m, s):
+        lo = s * bi
+        return sweep.sweep_device_images(m, [pool[i] for i in range(lo, lo + bi)], pos[lo:lo + bi], augs, bp=1.3, base_seed=0, batch_images=bi)
+
+    for m in models:                                   # warm-up: workspace, code objects
+        run_batch(m, steps)
+    out = {}
+    # ---- one stream ----
+    for c in ctxs:
+        _ffi.check(L.cald_profile_enable(c, 1))
+    torch.cuda.synchronize(); t0 = time.time()
+    seq = [run_batch(models[0], s) for s in range(steps)]
+    torch.cuda.synchronize(); dt = time.time() - t0
+    out["one_stream"] = {"images_per_s": n / dt, "gemm_tflops_by_launch_events": gemm_rate(L, ctxs[:1])}
+    for c in ctxs:
+        _ffi.check(L.cald_profile_enable(c, 0)); _ffi.check(L.cald_profile_enable(c, 1))
+    # ---- two streams, two host threads, alternate batches ----
+    res = [None] * steps
+
+    def worker(k):
+        for s in range(k, steps, 2):
+            res[s] = run_batch(models[k], s)
+    torch.cuda.synchronize(); t0 = time.time()
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    torch.cuda.synchronize(); dt2 = time.time() - t0
+    out["two_streams"] = {"images_per_s": n / dt2, "gemm_tflops_by_launch_events": gemm_rate(L, ctxs)}
+    for c in ctxs:
+        _ffi.check(L.cald_profile_enable(c, 0))
+    out["identical_scores"] = all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for a, b in zip(seq, res))
+    out["speedup"] = dt / dt2
+    out["pool_images"], out["fp32_mfma_peak_tflops"] = n, 157.3
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
