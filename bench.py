@@ -15,9 +15,15 @@ same pool is timed right before it and reported as `from_host_jpeg_bytes` (PCIe-
 `value`).  At N = 1 the headline run additionally sweeps the FULL configs[1] pool (5 217 images: host JPEG bytes ->
 selected 500 indices, everything inside one clock) and reports it as `full_pool`.
 
-    python bench.py --gpus N --steps K --warmup W [--scaling weak|strong]
-For N > 1 launch with torch.distributed.run (one rank per GPU, RCCL); the pool is sharded by position (rank-local inputs,
-no data-path collective) and one all-gather of the score rows closes the timed region.  Prints ONE JSON line on rank 0.
+    python bench.py --gpus N --steps K --warmup W [--scaling strong|weak]
+N > 1: one rank per GPU.  Either launch it with torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
+environment) or call it plainly -- `python bench.py --gpus N ...` then starts its own N ranks (launch_ranks).  Backend =
+RCCL ("nccl") when N GPUs are visible, otherwise the ranks share the visible GPU(s) over gloo (RCCL refuses two ranks
+on one device), which the JSON line says (`rccl`).  The pool is sharded by position (rank-local inputs, no data-path
+collective) and one all-gather of the score rows closes the timed region.  Prints ONE JSON line on rank 0.
+
+--scaling strong (default, SURVEY 8d: a FIXED pool / wall time): K x 64 images in total, split over the N ranks; without
+--steps the pool is the whole configs[1] pool of 5 217 images.  --scaling weak: K x 64 images per GPU.
 """
 import argparse
 import hashlib
@@ -38,6 +44,47 @@ FULL_POOL = 5217               # VOC2012 train 5 717 - 500 initially labeled (ca
 FULL_BUDGET = 500
 
 
+def usable_cpus():
+    """CPUs this process may really use: the scheduler affinity capped by the cgroup quota (the GPU boxes grant 16 of the
+    host's cores through cpu.max, which os.cpu_count() does not show)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (same environment contract as
+    torch.distributed.run: RANK, LOCAL_RANK, WORLD_SIZE, LOCAL_WORLD_SIZE, MASTER_ADDR, MASTER_PORT), rank 0 inherits
+    stdout (the one JSON line), and the first failing rank takes the job down (children are killed by PID)."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", CALD_BENCH_SELF_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc, live = 0, list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in live:
+                    q.terminate()
+    return rc
+
+
 def _jpeg_of(args):
     """(pool position, (H, W)) -> baseline JPEG bytes of the synthetic image (runs in forked host workers)."""
     pos, (H, W) = args
@@ -53,7 +100,7 @@ def make_jpeg_pool(positions, sizes):
     safe then).  Not timed: stands for the files of the dataset directory."""
     import multiprocessing as mp
     jobs = [(p, sizes[p]) for p in positions]
-    nproc = max(1, min(64, (os.cpu_count() or 1) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))))
+    nproc = max(1, min(64, usable_cpus() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))))
     if nproc == 1 or len(jobs) < 8:
         return [_jpeg_of(j) for j in jobs]
     with mp.get_context("fork").Pool(nproc) as pool:
@@ -68,7 +115,7 @@ def synthetic_labeled_set(n=500, num_cls=21, seed=0):
     return [(None, [{"labels": torch.from_numpy(rs.randint(1, num_cls, rs.randint(1, 6)))}]) for _ in range(n)]
 
 
-def cpu_baseline(sd, blobs, augs, budget_s=12.0, max_images=24):
+def cpu_baseline(sd, blobs, augs, budget_s=48.0, max_images=32):
     """The reference-shaped PyTorch-CPU port (oracle/torch_port.py) on a bounded sample of the same workload."""
     import numpy as np
     import torch
@@ -94,7 +141,7 @@ def cpu_baseline(sd, blobs, augs, budget_s=12.0, max_images=24):
     dt = time.time() - t0
     used = torch.get_num_threads()
     torch.set_num_threads(default_threads)
-    return {"value": n / dt, "unit": "images/s", "cores": used,
+    return {"value": n / dt, "unit": "images/s", "cores": used, "images": n,
             "kind": "port (torch-CPU fp32 convs / linears; top-k, NMS, RoIAlign and post-processing in the OpenMP C oracle -- "
                     "stronger than the reference's pure-PyTorch CPU path)",
             "sample": "%d synthetic VOC-shaped image(s) x 4 views, batch-1 sequential torch-CPU fp32 forwards + python/scipy "
@@ -102,28 +149,71 @@ def cpu_baseline(sd, blobs, augs, budget_s=12.0, max_images=24):
 
 
 def latest_pmc():
-    """HBM bytes per GEMM launch from the rocprofv3 PMC passes of this same command (tools/profile_gpu.sh ->
-    tools/summarize_profile.py -> profiles/*_pmc.json; FETCH_SIZE x2 gfx950 correction + WRITE_SIZE).  Not measured in
-    this process (a process cannot attach rocprofv3 to itself): the source file is named next to the number."""
+    """HBM bytes per GEMM launch, achieved HBM GB/s and MFMA-busy fraction of the GEMM family from the rocprofv3 passes of
+    this same command (tools/profile_gpu.sh -> tools/summarize_profile.py -> profiles/*_pmc.json; FETCH_SIZE x2 gfx950
+    correction + WRITE_SIZE).  NOT measured in this process (a process cannot attach rocprofv3 to itself): the bench line
+    marks them `from_file` and names the source file."""
     try:
-        cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc.json"))
-        for name in reversed(cands):                 # newest summary that holds the GEMM family's HBM bytes
+        cands = [f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc.json")]
+        cands.sort(key=lambda f: os.path.getmtime(os.path.join(ROOT, "profiles", f)))
+        for name in reversed(sorted(cands)):         # newest summary (by name: r2c < r3a < ...) that holds the GEMM family
             d = json.load(open(os.path.join(ROOT, "profiles", name)))
             if "conv_mfma" in d:
-                return d["conv_mfma"]["hbm_bytes_per_launch"], "profiles/" + name
+                c = d["conv_mfma"]
+                return {"hbm_bytes_per_launch": c.get("hbm_bytes_per_launch"), "hbm_gbps": c.get("hbm_gbps"),
+                        "mfma_busy": c.get("mfma_busy"), "source": "profiles/" + name}
     except Exception:
         pass
-    return None, None
+    return {"hbm_bytes_per_launch": None, "hbm_gbps": None, "mfma_busy": None, "source": None}
+
+
+def config0_leg(model, sd, B, threads=None):
+    """BASELINE configs[0] (the reference's CPU-runnable plumbing case: 200 synthetic VOC-shaped images, flip only) on the
+    GPU, with the torch-CPU port (an fp32 path that does NOT share the arithmetic contract) scoring a bounded sample of
+    the same images beside it -- a live measurement of 'KL/IoU floats within 1e-4 of the CPU path'."""
+    import numpy as np
+    import torch
+    from cald_amd import synth, sweep
+    from oracle import torch_port
+    n, augs = 200, ["flip"]
+    sizes = synth.pool_sizes(n, "voc", 0)
+    imgs = [synth.synth_image(p, *sizes[p]) for p in range(n)]
+    dev = [torch.from_numpy(im).cuda() for im in imgs]
+    run = lambda: sweep.sweep_device_images(model, dev, list(range(n)), augs, bp=1.3, base_seed=0, batch_images=B)
+    run()
+    torch.cuda.synchronize(); t = time.time()
+    cons, cls = run()
+    torch.cuda.synchronize(); t = time.time() - t
+    cpu = torch_port.TorchFRCNN(sd, 21, 50, 600, 1000)
+    default_threads = torch.get_num_threads()
+    if threads:
+        torch.set_num_threads(threads)         # the count cpu_baseline() found fastest on this host
+    m, t0, ref = 0, time.time(), []
+    while m < 8 and (m == 0 or time.time() - t0 < 8.0):
+        c, _ = torch_port.get_uncertainty(cpu, [imgs[m]], augs, 21, bp=1.3, base_seed=0, positions=[m])
+        ref.append(c[0]); m += 1
+    tc = time.time() - t0
+    torch.set_num_threads(default_threads)
+    d = np.abs(np.asarray(ref) - cons[:m])
+    return {"workload": "BASELINE.json configs[0]: Faster R-CNN ResNet-50 FPN, 200 synthetic VOC2012-shaped images, augs=['flip'] (2 views / image)",
+            "headline": False, "gpu_images_per_s": n / t, "gpu_seconds": t,
+            "scores_sha1": hashlib.sha1(np.ascontiguousarray(cons).tobytes()).hexdigest(),
+            "cpu_port_images_per_s": m / tc, "cpu_port_sample": "%d of the 200 images, torch-CPU fp32 port (oracle/torch_port.py), %.1f s" % (m, tc),
+            "max_abs_consistency_diff_gpu_vs_cpu_port": float(d.max()), "images_beyond_1e-4": int((d > 1e-4).sum()),
+            "images_compared": m}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=None,
+                    help="steps of 64 pool images over the whole job; default: the full configs[1] pool (5 217 images = 82 steps) "
+                         "in strong mode, 8 per GPU in weak mode")
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch-images", type=int, default=64)
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="weak: K x 64 images per GPU (pool grows with N); strong: K x 64 images in total, split over the N GPUs")
+    ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
+                    help="strong (SURVEY 8d: fixed pool / wall time): K x 64 images in total, split over the N GPUs; "
+                         "weak: K x 64 images per GPU (pool grows with N)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-full-pool", action="store_true", help="skip the 5 217-image end-to-end run (N = 1 headline only)")
     ap.add_argument("--no-f16x3", action="store_true")
@@ -136,22 +226,26 @@ def main():
                     help="fp32 = exact (headline, bit-identical to the oracle); f16x3 / i8x3 = informational matrix-pipe modes")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:      # plain `python bench.py --gpus N`: start the N ranks ourselves
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
-    B, K, Wm = args.batch_images, args.steps, args.warmup
+    if args.gpus != world:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    B, Wm = args.batch_images, args.warmup
+    full_default = args.steps is None and args.scaling == "strong"
+    K = args.steps if args.steps is not None else ((FULL_POOL + B - 1) // B if full_default else 8)
     letters = {"F": "flip", "C": "cut_out", "D": "smaller_resize", "R": "rotation", "G": "ga", "S": "sp"}
     augs = [letters[ch] for ch in args.augs]
     ncls = 21 if args.shape == "voc" else 91
     mn, mx = (600, 1000) if args.shape == "voc" else (800, 1333)
     headline = (args.model == "frcnn" and args.shape == "voc" and args.augs == "FCD" and args.precision == "fp32")
-    do_full = headline and world == 1 and not args.no_full_pool
+    do_full = headline and world == 1 and not args.no_full_pool and not full_default   # full_default: the headline IS the full pool
 
     # ---- the pool as files (host JPEG bytes): rank r owns pool positions p % world == r (rank-local inputs) ----
     from cald_amd import synth
-    pool_total = world * K * B if args.scaling == "weak" else K * B
+    pool_total = world * K * B if args.scaling == "weak" else (FULL_POOL if full_default else K * B)
     n_warm = Wm * B
     total_needed = max(pool_total + world * n_warm, FULL_POOL if do_full else 0)
     sizes = synth.pool_sizes(total_needed, args.shape, 0)
@@ -169,18 +263,24 @@ def main():
     import numpy as np
     import torch
     assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback for the product path"
-    # dry-run aid for 1-GPU boxes: CALD_BENCH_SHARE_GPU=1 puts every rank on cuda:0 with the gloo backend
-    share = os.environ.get("CALD_BENCH_SHARE_GPU") == "1"
+    # N ranks on fewer than N visible GPUs (a 1-GPU box): the ranks share the device(s) and the collective goes over gloo,
+    # because RCCL refuses two ranks on one device (tools/nccl_same_gpu_probe.py).  CALD_BENCH_SHARE_GPU=1 forces that.
+    ndev = torch.cuda.device_count()
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    share = world > 1 and (os.environ.get("CALD_BENCH_SHARE_GPU") == "1" or ndev < local_world)
     if share:
-        local_rank = 0
+        local_rank = local_rank % ndev
     torch.cuda.set_device(local_rank)
     dist = None
+    backend = "none"
     if world > 1:
         import torch.distributed as dist
+        backend = "gloo" if share else "nccl"
         if share:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    coll_dev = torch.device("cpu") if (share or world == 1) else torch.device("cuda", local_rank)
 
     from cald_amd import _ffi, detector, sweep
     from cald_amd.pool import DevicePool
@@ -225,23 +325,39 @@ def main():
     _ffi.check(L.cald_profile_enable(ctx, 1))     # HIP events around every conv/linear launch on the launch stream
     n_local = len(positions)
     steps_local = (n_local + B - 1) // B          # == K for weak scaling; K / N (rounded up) for strong scaling
+    # equal-sized batches (strong scaling leaves e.g. 160 images per rank: 54 + 53 + 53, not 64 + 64 + 32)
+    cuts = [(n_local * s) // max(1, steps_local) for s in range(steps_local + 1)]
     barrier()
     t0 = time.time()
     cons_parts, cls_parts = [], []
     for s in range(steps_local):
-        c, k = sweep_batch(dev_pool, positions, s * B, min((s + 1) * B, n_local))
+        c, k = sweep_batch(dev_pool, positions, cuts[s], cuts[s + 1])
         cons_parts.append(c); cls_parts.append(k)
     cons = np.concatenate(cons_parts) if cons_parts else np.zeros(0)
     cls = np.concatenate(cls_parts) if cls_parts else np.zeros((0, ncls - 1))
+    t_local = time.time() - t0                    # this rank's own shard scored (sweep_batch returns host arrays: synchronous)
     if world > 1:   # the one RCCL all-gather of the (consistency, cls_corr) rows of the WHOLE timed pool
         cons, cls = sweep.allgather_scores(positions, cons, cls, pool_total)
     picked = sweep.select(list(cons), [cls[i] for i in range(cls.shape[0])], labeled, budget=budget, mr=1.2)   # every rank, host
     barrier()
     dt = time.time() - t0
+    # who took part: every rank's device identity, shard size and own sweep time, gathered through the SAME process group
+    # (RCCL when `backend` is nccl) -- outside the timed region
+    props = torch.cuda.get_device_properties(local_rank)
+    ident = hashlib.sha1(("%s|%s" % (getattr(props, "uuid", ""), torch.cuda.get_device_name(local_rank))).encode()).digest()[:8]
+    try:
+        bus = int(getattr(props, "pci_bus_id", -1))
+    except Exception:
+        bus = -1
+    row = torch.tensor([float(rank), float(local_rank), float(bus), float(int.from_bytes(ident[:6], "big")),
+                        float(n_local), t_local, dt, t_decode], dtype=torch.float64, device=coll_dev)
+    rows = row[None]
     if world > 1:
-        t = torch.tensor([dt, t_decode], dtype=torch.float64, device="cpu" if share else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt, t_decode = float(t[0].item()), float(t[1].item())
+        rows = torch.empty(world * row.numel(), dtype=torch.float64, device=coll_dev)
+        dist.all_gather_into_tensor(rows, row)
+    rows = rows.cpu().numpy().reshape(world, -1)
+    dt, t_decode = float(rows[:, 6].max()), float(rows[:, 7].max())     # max over ranks
+    uuid_s = str(getattr(props, "uuid", ""))
     import ctypes as C
     gm, gf, tot, mean_r = C.c_double(), C.c_double(), C.c_double(), C.c_double()
     nl, nviews = C.c_int64(), C.c_int64()
@@ -252,12 +368,12 @@ def main():
     _ffi.check(L.cald_profile_enable(ctx, 0))
 
     if rank == 0:
-        traffic, traffic_src = latest_pmc()
+        pmc = latest_pmc()
         achieved = gf.value / (gm.value * 1e-3) / 1e12 if gm.value > 0 else 0.0
         peak = {"fp32": F32_MFMA_PEAK_TFLOPS, "f16x3": F16_MFMA_PEAK_TFLOPS, "i8x3": I8_MFMA_PEAK_TOPS}[args.precision]
         out = {
             "metric": "unlabeled images scored/sec (CALD consistency sweep)", "value": pool_total / dt, "unit": "images/s",
-            "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": dt / max(1, steps_local) * 1e3, "higher_is_better": True,
+            "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": dt / max(1, K) * 1e3, "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None,
             "dtype": {"fp32": "f32", "f16x3": "f16x3 (fp16 hi+lo split operands, fp32 accumulate)",
                       "i8x3": "i8x3 (block floating point per pixel as three int8 digits, exact int32 accumulation per tap)"}[args.precision],
@@ -269,7 +385,18 @@ def main():
                        "timed_region": "HBM-resident decoded pool -> K sweep steps -> all-gather (N>1) -> argsort + cls_kldiv -> selected indices",
                        "selection_budget": budget, "n_selected": int(len(picked)),
                        "selected_sha1": hashlib.sha1(np.asarray(picked, np.int64).tobytes()).hexdigest(),
-                       "parallelism": "pool sharded by position (rank-local inputs), dp%d" % world},
+                       "parallelism": "pool sharded by position (rank-local inputs), dp%d" % world,
+                       "steps_per_rank": steps_local},
+            "rccl": {"backend": backend, "world_size": world, "ranks_seen": int(rows.shape[0]), "visible_gpus": ndev,
+                     "shared_gpu": bool(share),
+                     "collective": ("all_gather_into_tensor over RCCL (device buffers)" if backend == "nccl" else
+                                    "all_gather_into_tensor over gloo: %d ranks on %d visible GPU(s), RCCL refuses two ranks on one device" % (world, ndev)
+                                    if backend == "gloo" else "none (one rank)"),
+                     "per_rank": [{"rank": int(r[0]), "device": int(r[1]), "pci_bus": int(r[2]), "device_id_hash": "%012x" % int(r[3]),
+                                   "images": int(r[4]), "images_per_s": (r[4] / r[5]) if r[5] > 0 else None, "sweep_s": r[5]}
+                                  for r in rows],
+                     "distinct_devices": len({(int(r[2]), int(r[3])) for r in rows}), "rank0_device_uuid": uuid_s,
+                     "host_cpus_usable": usable_cpus()},
             "from_host_jpeg_bytes": {"value": pool_total / (dt + t_decode), "unit": "images/s", "decode_and_h2d_s": t_decode,
                                      "note": "same pool, JPEG decode on the GPU + H2D included (max over ranks); never `value`"},
             "roofline": {"bound": "mfma",
@@ -278,8 +405,12 @@ def main():
                                     "i8x3": "conv_i3_kernel (6 x v_mfma_i32_32x32x32_i8 per product; algorithmic flops counted once; the digit-plane "
                                             "quantiser passes are outside the GEMM timing) + exact kernels for uncovered shapes"}[args.precision],
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": traffic if args.precision == "fp32" else None,
-                         "traffic_source": traffic_src if args.precision == "fp32" else None,
+                         "frac": achieved / peak, "traffic": pmc["hbm_bytes_per_launch"] if args.precision == "fp32" else None,
+                         "hbm_gbps": pmc["hbm_gbps"] if args.precision == "fp32" else None,
+                         "mfma_busy": pmc["mfma_busy"] if args.precision == "fp32" else None,
+                         "counters": {"from_file": True, "source": pmc["source"],
+                                      "note": "traffic / hbm_gbps / mfma_busy come from the committed rocprofv3 PMC summary of this command, "
+                                              "not from this run; achieved / frac / launches are measured live (HIP events)"},
                          "launches": int(nl.value), "avg_launch_ms": gm.value / max(1, nl.value),
                          "gemm_ms_per_step": gm.value / max(1, steps_local), "algorithmic_gflop_per_launch": gf.value / max(1, nl.value) / 1e9,
                          "roi_rows_per_view_measured": mean_r.value,
@@ -303,6 +434,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline and headline:
             out["cpu_baseline"] = cpu_baseline(sd, blobs, augs)
             out["cpu_baseline"]["host_cpus"] = os.cpu_count()
+            out["cpu_baseline"]["host_cpus_usable"] = usable_cpus()
+            out["config0_cpu_plumbing"] = config0_leg(model, sd, B, threads=out["cpu_baseline"]["cores"])
         if world == 1 and headline and not args.no_f16x3:
             # informational second line, NOT the headline: the opt-in split-fp16 MFMA mode (BASELINE configs[4]'s
             # "fp16 MFMA path") on the same workload.  Parity of that mode vs the exact mode on the full pool and vs an
@@ -347,7 +480,9 @@ def main():
             torch.cuda.empty_cache()
             out["training_step"] = dict(bench_train.measure(batch=4, steps=10, warmup=3), headline=False)
         try:
-            out["parity_vs_independent_fp32"] = json.load(open(os.path.join(ROOT, "profiles", "parity_vs_independent_fp32_r2.json")))["summary"]
+            out["parity_vs_independent_fp32"] = dict(
+                json.load(open(os.path.join(ROOT, "profiles", "parity_vs_independent_fp32_r2.json")))["summary"],
+                from_file=True, source="profiles/parity_vs_independent_fp32_r2.json (tools/parity_full_pool.py; not measured in this run)")
         except Exception:
             pass
         print(json.dumps(out))

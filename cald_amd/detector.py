@@ -147,6 +147,8 @@ class HipDetector:
                        for k, v in sd.items() if not k.endswith("num_batches_tracked")}
         self._destroy()
         self._trainer = self._train_fn = None
+        if self.training:          # train mode: a trainer on the new weights (parameters() are NEW tensors -- build the optimizer after
+            self._ensure_trainer()  # loading, as cald_train.py:356 / :396 does)
         return self
 
     # ---- native handle ----

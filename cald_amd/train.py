@@ -23,7 +23,10 @@ torchvision semantics restated here (0.8.2, "TV-mem" in SURVEY Appendix A; in-re
   * RoI heads: proposals + ground truth; Matcher(0.5, 0.5); sampler(512, 0.25); BoxCoder (10, 10, 5, 5); cross-entropy +
     smooth-L1 (beta 1/9) / #sampled                                                                     (frcnn_la.py:160-222)
 The samplers draw from torch's CPU generator (the reference draws ``torch.randperm`` on its CUDA device: a different stream of
-random numbers, the same distribution over subsets).
+random numbers, the same distribution over subsets).  ``sampler="choose_k"`` (default) draws k distinct indices in O(k);
+``sampler="randperm"`` consumes ``torch.randperm(n, generator=g)[:k]`` for the positives, then for the negatives, image by
+image, RPN before the RoI heads -- exactly the calls torchvision's BalancedPositiveNegativeSampler makes, so a seeded CPU
+generator reproduces torchvision's own samples (``tests/test_gpu_train.py::test_randperm_sampler_*``).
 """
 import numpy as np
 import torch
@@ -195,7 +198,10 @@ class _TrainerBase(object):
     LOSS_NAMES = ()
     MERGE_GROUPS = ()
 
-    def _init_common(self, state_dict, num_classes, depth, min_size, max_size, device, trainable_layers, generator):
+    def _init_common(self, state_dict, num_classes, depth, min_size, max_size, device, trainable_layers, generator, sampler="choose_k"):
+        if sampler not in ("choose_k", "randperm"):
+            raise ValueError("sampler must be 'choose_k' or 'randperm', got %r" % (sampler,))
+        self.sampler = sampler
         self.dev = torch.device(device)
         self.C, self.min_size, self.max_size = num_classes, int(min_size), int(max_size)
         self.generator = generator
@@ -340,6 +346,10 @@ class _TrainerBase(object):
         """BalancedPositiveNegativeSampler for one image: index tensors (CPU) of the sampled positives / negatives."""
         num_pos = min(int(batch * frac), pos.numel())
         num_neg = min(batch - num_pos, neg.numel())
+        if self.sampler == "randperm":      # torchvision's own calls, in its order: positives first, then negatives
+            perm_pos = torch.randperm(pos.numel(), generator=self.generator)[:num_pos]
+            perm_neg = torch.randperm(neg.numel(), generator=self.generator)[:num_neg]
+            return pos[perm_pos], neg[perm_neg]
         return pos[choose_k(pos.numel(), num_pos, self.generator)], neg[choose_k(neg.numel(), num_neg, self.generator)]
 
     def _fpn_out_fwd(self, inner):
@@ -390,8 +400,13 @@ class _TrainerBase(object):
         self.last_padded_hw = (Hp, Wp)
         img_sizes = [(s[0], s[1]) for s in sizes]
         gts, gt_labels = [], []
-        for im, s, t in zip(u8, sizes, targets):                    # resize_boxes: per-axis ratio in float32
+        for n_img, (im, s, t) in enumerate(zip(u8, sizes, targets)):      # resize_boxes: per-axis ratio in float32
             b = t["boxes"].detach().float().cpu().reshape(-1, 4)
+            bad = (b[:, 2:] <= b[:, :2]).any(dim=1)                 # GeneralizedRCNN.forward's check (torchvision 0.8.2)
+            if bool(bad.any()):
+                j = int(torch.nonzero(bad)[0])
+                raise ValueError("All bounding boxes should have positive height and width. Found invalid box %s for target at index %d."
+                                 % (b[j].tolist(), n_img))
             rh = torch.tensor(s[0], dtype=torch.float32) / torch.tensor(im.shape[0], dtype=torch.float32)
             rw = torch.tensor(s[1], dtype=torch.float32) / torch.tensor(im.shape[1], dtype=torch.float32)
             gts.append(torch.stack([b[:, 0] * rw, b[:, 1] * rh, b[:, 2] * rw, b[:, 3] * rh], dim=1).to(self.dev).contiguous())
@@ -459,8 +474,8 @@ class FasterRCNNTrainer(_TrainerBase):
     def __init__(self, state_dict, num_classes, depth=50, min_size=600, max_size=1000, device="cuda", trainable_layers=3,
                  rpn_pre_nms_top_n=2000, rpn_post_nms_top_n=2000, rpn_nms_thresh=0.7, rpn_fg_iou=0.7, rpn_bg_iou=0.3,
                  rpn_batch=256, rpn_pos_fraction=0.5, box_fg_iou=0.5, box_bg_iou=0.5, box_batch=512, box_pos_fraction=0.25,
-                 bbox_reg_weights=(10.0, 10.0, 5.0, 5.0), generator=None):
-        self._init_common(state_dict, num_classes, depth, min_size, max_size, device, trainable_layers, generator)
+                 bbox_reg_weights=(10.0, 10.0, 5.0, 5.0), generator=None, sampler="choose_k"):
+        self._init_common(state_dict, num_classes, depth, min_size, max_size, device, trainable_layers, generator, sampler)
         self.cfg = dict(pre_n=rpn_pre_nms_top_n, post_n=rpn_post_nms_top_n, nms=rpn_nms_thresh, rpn_fg=rpn_fg_iou, rpn_bg=rpn_bg_iou,
                         rpn_batch=rpn_batch, rpn_pos=rpn_pos_fraction, box_fg=box_fg_iou, box_bg=box_bg_iou, box_batch=box_batch,
                         box_pos=box_pos_fraction, w=tuple(bbox_reg_weights))
@@ -961,11 +976,18 @@ class _LossFn(torch.autograd.Function):
     def forward(ctx, anchor, net, images, targets):
         ctx.net = net
         d = net.forward(images, targets)
+        ctx.saved = net.last          # this forward's records
+        net.forward_serial = ctx.serial = getattr(net, "forward_serial", 0) + 1
         return tuple(d[k].reshape(()) for k in net.LOSS_NAMES)
 
     @staticmethod
     def backward(ctx, *gs):
         net = ctx.net
+        if net.forward_serial != ctx.serial:
+            # the layers keep ONE set of saved activations (no per-call graph): differentiating an older forward would silently
+            # use the newer one's -- refuse instead
+            raise RuntimeError("backward() of a training forward after a later forward of the same model: its saved activations "
+                               "were replaced; call backward() before the next model(images, targets)")
         gscale = [0.0 if g is None else float(g) for g in gs]
         # autograd semantics: a parameter whose .grad is set (no zero_grad since the last backward, or zero_grad(set_to_none=False))
         # accumulates.  The .grad tensors ARE views of the flat gradient buffer, so accumulation happens inside the kernels.
@@ -976,10 +998,12 @@ class _LossFn(torch.autograd.Function):
         if any(mine) and not all(mine):
             raise RuntimeError("some parameters carry a gradient and some do not: call zero_grad() on all of them")
         net.accumulate_grads = all(mine)
+        current, net.last = net.last, ctx.saved
         try:
             net.backward(gscale)
         finally:
             net.accumulate_grads = False
+            net.last = current
         for k in net.names:
             if net.params[k].grad is None:
                 net.params[k].grad = net.grads[k]
@@ -1025,9 +1049,33 @@ class SGD(torch.optim.Optimizer):
             if p is not net.params[k] or p.grad is None or p.grad.data_ptr() != net.grads[k].data_ptr():
                 return False
         started = ["momentum_buffer" in self.state[p] for p in ps]
-        if any(started) and (self._mflat is None or not all(started)):
-            return False                                   # buffers loaded from a checkpoint / a partial first step: per-tensor path
+        if any(started) and not all(started):
+            return False                                   # a partial first step: per-tensor path
+        if all(started) and ps:
+            self._adopt_momentum(ps)
         return True
+
+    @torch.no_grad()
+    def _adopt_momentum(self, ps):
+        """Every parameter has a momentum buffer.  After ``load_state_dict()`` (resume, cald_train.py:356-360) those are fresh
+        tensors, not views of the flat buffer the fused launch updates: copy them in and re-point ``state`` at the views, so the
+        loaded momentum is what the next step uses (and what ``state_dict()`` saves afterwards)."""
+        net = self.net
+        views_ok = self._mflat is not None
+        if views_ok:
+            base = self._mflat.data_ptr()
+            for p, k in zip(ps, net.names):
+                if self.state[p]["momentum_buffer"].data_ptr() != base + 4 * net._off[k]:
+                    views_ok = False
+                    break
+        if views_ok:
+            return
+        flat = torch.zeros_like(net.flat)
+        for p, k in zip(ps, net.names):
+            view = flat[net._off[k]:net._off[k] + p.numel()].view(p.shape)
+            view.copy_(self.state[p]["momentum_buffer"].to(view.device, torch.float32))
+            self.state[p]["momentum_buffer"] = view
+        self._mflat = flat
 
     @torch.no_grad()
     def step(self, closure=None):

@@ -318,17 +318,26 @@ class TorchTrainRetinaNet(TorchTrainFRCNN):
             anchors.append((torch.stack([xs, ys, xs, ys], dim=-1).reshape(-1, 1, 4).float() + base[None]).reshape(-1, 4))
         anchors = torch.cat(anchors)
         cfg = dict(dict(fg=0.5, bg=0.4), **(cfg or {}))
-        lc, lr, matched = [], [], []
-        for i in range(N):
-            m = matcher(box_iou(gts[i], anchors), cfg["fg"], cfg["bg"], True)
-            matched.append(m)
-            fg = m >= 0
-            nfg = max(1, int(fg.sum()))
-            tgt = torch.zeros_like(cls[i])
-            tgt[fg, targets[i]["labels"].long()[m[fg]]] = 1.0
-            valid = m != -2
-            lc.append(sigmoid_focal_loss_sum(cls[i][valid], tgt[valid]) / nfg)
-            t_reg = encode(gts[i][m.clamp(min=0)][fg].double(), anchors[fg].double(), (1.0, 1.0, 1.0, 1.0))
-            lr.append((reg[i][fg] - t_reg).abs().sum() / nfg)
+        lc, lr, matched = retina_losses(cls, reg, anchors, gts, [t["labels"] for t in targets], cfg["fg"], cfg["bg"])
         rec = dict(anchors=anchors, matched=torch.stack(matched))
-        return {"classification": sum(lc) / N, "bbox_regression": sum(lr) / max(1, N)}, rec
+        return {"classification": lc, "bbox_regression": lr}, rec
+
+
+def retina_losses(cls, reg, anchors, gts, labels, fg_thr=0.5, bg_thr=0.4):
+    """detection/retinanet_cal.py:389-400 (matcher driver), :100-133 (classification) and :185-223 (box regression), restated.
+    cls [N][A][K], reg [N][A][4], anchors [A][4], per-image gt boxes / labels.  Pinned to the reference's own code by
+    tests/golden/train_losses.npz (oracle/make_golden_train_losses.py).  Returns (classification, bbox_regression, matched)."""
+    N = len(gts)
+    lc, lr, matched = [], [], []
+    for i in range(N):
+        m = matcher(box_iou(gts[i], anchors), fg_thr, bg_thr, True)
+        matched.append(m)
+        fg = m >= 0
+        nfg = max(1, int(fg.sum()))
+        tgt = torch.zeros_like(cls[i])
+        tgt[fg, labels[i].long()[m[fg]]] = 1.0
+        valid = m != -2
+        lc.append(sigmoid_focal_loss_sum(cls[i][valid], tgt[valid]) / nfg)
+        t_reg = encode(gts[i][m.clamp(min=0)][fg].double(), anchors[fg].double(), (1.0, 1.0, 1.0, 1.0))
+        lr.append((reg[i][fg] - t_reg).abs().sum() / nfg)
+    return sum(lc) / N, sum(lr) / max(1, N), matched

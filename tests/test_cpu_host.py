@@ -758,3 +758,72 @@ def test_aspect_ratio_batch_sampler_equals_reference_golden(golden, tmp_path):
                                "annotations": [], "categories": []}))
     cds = coco_utils.CocoDetection(str(tmp_path), str(ann), None)
     assert G.compute_aspect_ratios(cds) == [427.0 / 640.0, 640.0 / 480.0]          # ids sorted: 3, 7
+
+
+def _golden_loss_case(g, k, dtype):
+    import torch
+    N = int(g["l%d_N" % k])
+    gts = [torch.from_numpy(g["l%d_gt%d" % (k, i)]).to(dtype) for i in range(N)]
+    labels = [torch.from_numpy(g["l%d_labels%d" % (k, i)]) for i in range(N)]
+    return (N, torch.from_numpy(g["l%d_cls_logits" % k]).to(dtype), torch.from_numpy(g["l%d_bbox_regression" % k]).to(dtype),
+            torch.from_numpy(g["l%d_anchors" % k]).to(dtype), gts, labels)
+
+
+def test_training_checker_retinanet_losses_match_the_reference_code(golden):
+    """SURVEY 8f rank 4 pin: the float64 training checker's RetinaNet losses (oracle/torch_train.retina_losses) against the
+    REFERENCE's own compute_loss bodies (detection/retinanet_cal.py:100-133, :185-223, :389-400, executed by
+    oracle/make_golden_train_losses.py): matched indices identical, both losses to float64 round-off; and to float32
+    round-off of the reference's own float32 run."""
+    import torch
+    from oracle import torch_train as tt
+    g = golden("train_losses")
+    for k in range(int(g["l_n"])):
+        N, cls, reg, anchors, gts, labels = _golden_loss_case(g, k, torch.float64)
+        # matcher decisions are taken on float32 IoUs, as the reference's float32 run takes them
+        lc, lr, matched = tt.retina_losses(cls, reg, anchors.float(), [b.float() for b in gts], labels)
+        assert np.array_equal(torch.stack(matched).numpy(), g["l%d_matched" % k]), k
+        assert abs(float(lc) - float(g["l%d_cls_f64" % k])) <= 1e-12 * abs(float(g["l%d_cls_f64" % k])), (k, float(lc))
+        # the checker encodes targets from the float32 boxes in float64; the reference's f64 run did the same on the same values
+        assert abs(float(lr) - float(g["l%d_reg_f64" % k])) <= 1e-12 * abs(float(g["l%d_reg_f64" % k])), (k, float(lr))
+        assert abs(float(lc) - float(g["l%d_cls_f32" % k])) <= 2e-6 * abs(float(lc))
+        assert abs(float(lr) - float(g["l%d_reg_f32" % k])) <= 2e-6 * abs(float(lr))
+
+
+def test_training_loop_follows_the_reference_loop(golden):
+    """cald_amd.engine.train_one_epoch / warmup_lr_scheduler against cald_train.py:40-74 + detection/utils.py:239-247 run on
+    the same stand-in model (oracle/make_golden_train_losses.py): the learning rate every update is taken with and the
+    parameter trajectory are identical (float64, bit for bit)."""
+    import torch
+    from cald_amd import engine
+    g = golden("train_losses")
+
+    class Toy(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.tensor([0.5, -1.25, 2.0], dtype=torch.float64))
+            self.b = torch.nn.Parameter(torch.tensor([0.1], dtype=torch.float64))
+
+        def forward(self, images, targets):
+            x = torch.stack([im.double().mean() for im in images])
+            t = torch.stack([tg["boxes"].double().sum() for tg in targets])
+            pred = x[:, None] * self.w[None, :] + self.b
+            return {"loss_a": ((pred.sum(1) - t) ** 2).mean() * 0.1, "loss_b": (self.w ** 2).sum() * 0.01 + self.b.abs().sum()}
+
+    for k in range(int(g["t_n"])):
+        n_iter, epochs = int(g["t%d_iters" % k]), int(g["t%d_epochs" % k])
+        data = [([torch.from_numpy(im) for im in g["t%d_im%d" % (k, i)]], [{"boxes": torch.from_numpy(b)} for b in g["t%d_bx%d" % (k, i)]])
+                for i in range(n_iter)]
+        model = Toy()
+        lrs, params = [], []
+
+        class SpySGD(torch.optim.SGD):
+            def step(self, closure=None):
+                lrs.append(self.param_groups[0]["lr"])
+                r = super().step(closure)
+                params.append(np.concatenate([model.w.detach().numpy().copy(), model.b.detach().numpy().copy()]))
+                return r
+        opt = SpySGD(model.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-3)
+        for ep in range(epochs):
+            engine.train_one_epoch(model, opt, data, torch.device("cpu"), 0, ep, 0)
+        assert np.array_equal(np.array(lrs), g["t%d_lrs" % k]), (k, lrs)
+        assert np.array_equal(np.stack(params), g["t%d_params" % k]), k

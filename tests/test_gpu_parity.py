@@ -542,6 +542,45 @@ def _full_size_coco_case(hip, oracle, depth, augs, exact_positions, seed):
     torch.cuda.empty_cache()
 
 
+def test_config2_full_size_retinanet_voc(hip, oracle):
+    """BASELINE.json configs[2] AT SIZE: RetinaNet ResNet-50 FPN (detection/retinanet_cal.py), VOC shapes, min/max 600/1000
+    (cald_train.py:342), flip / cut_out / smaller_resize.  12 images: batch-size and shard invariance; two of them re-scored by
+    the CPU oracle, bit for bit (consistency and cls_corr)."""
+    import os
+    torch = hip["torch"]
+    from cald_amd import synth, sweep
+    sd = synth.pseudo_trained_retinanet(21, 50, seed=0)
+    model = hip["det"].retinanet_resnet50_fpn_cal(num_classes=21, min_size=600, max_size=1000).to("cuda")
+    model.load_state_dict(sd)
+    model.eval()
+    augs = ["flip", "cut_out", "smaller_resize"]
+    pool = synth.make_pool(12, "voc", 0)
+    dev = [torch.from_numpy(im).cuda() for im in pool]
+    pos = list(range(12))
+    c1, k1 = sweep.sweep_device_images(model, dev, pos, augs, base_seed=3, batch_images=64)
+    c2, k2 = sweep.sweep_device_images(model, dev, pos, augs, base_seed=3, batch_images=5)
+    np.testing.assert_array_equal(c1, c2); np.testing.assert_array_equal(k1, k2)
+    cw = np.zeros(12); kw = np.zeros((12, 20))
+    for r in range(2):
+        idx = sweep.shard_positions(12, r, 2)
+        cr, kr = sweep.sweep_device_images(model, [dev[i] for i in idx], idx, augs, base_seed=3)
+        cw[idx] = cr; kw[idx] = kr
+    np.testing.assert_array_equal(c1, cw); np.testing.assert_array_equal(k1, kw)
+    assert np.all(c1 >= 0) and np.all(c1 <= 1.0) and len(np.unique(np.round(c1, 6))) > 6 and (k1 > 0).any()
+    P = oracle.prepare_retinanet(sd, 21, 50)
+    exact = (2, 7)
+    oracle.set_threads(min(128, os.cpu_count() or 1))
+    try:
+        wc, wk = oracle.get_uncertainty(P, [pool[i] for i in exact], augs, 21, bp=1.3, min_size=600, max_size=1000, base_seed=3, positions=list(exact))
+    finally:
+        oracle.set_threads(min(32, os.cpu_count() or 1))
+    for j, i in enumerate(exact):
+        assert c1[i] == wc[j], (i, c1[i], wc[j])
+        np.testing.assert_array_equal(k1[i], wk[j])
+    del model
+    torch.cuda.empty_cache()
+
+
 def test_config3_full_size_frcnn_r50_coco(hip, oracle):
     """BASELINE.json configs[3]: Faster R-CNN ResNet-50 FPN, COCO shapes, 91 classes, 800/1333, flip / cut_out / smaller_resize."""
     _full_size_coco_case(hip, oracle, 50, ["flip", "cut_out", "smaller_resize"], (1, 6), seed=0)

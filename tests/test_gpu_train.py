@@ -317,10 +317,10 @@ def test_losses_value_and_gradient(T, oracle):
     _close(l3, bce.reshape(1), 1e-6, "BCE with logits"); _close(gx, xd.grad, 1e-5, "BCE gradient")
 
 
-def _train_case(torch, n_images=2, seed=0):
+def _train_case(torch, n_images=2, seed=0, scale=0.4):
     from cald_amd import synth
     sd = synth.pseudo_trained_frcnn(21, 50, seed=3)
-    imgs = synth.make_pool(n_images, "voc", seed, scale=0.4)                     # ~150 x 200 uint8 HWC
+    imgs = synth.make_pool(n_images, "voc", seed, scale=scale)                   # scale 0.4: ~150 x 200 uint8 HWC
     images = [torch.from_numpy(im).permute(2, 0, 1).float().div(255) for im in imgs]
     rs = np.random.RandomState(seed + 1)
     targets = []
@@ -765,3 +765,158 @@ def test_retinanet_training_step_vs_autograd_and_drop_in(T, oracle):
     model.eval()
     out = model([images[0]])
     assert set(out[0]) >= {"boxes", "scores", "labels"}
+
+
+def test_retinanet_loss_kernels_match_the_reference_code(T, golden):
+    """The device side of RetinaNet's loss -- `cald_train_match` (0.5 / 0.4, low-quality matches), `cald_train_box_encode`,
+    `focal_loss_kernel`, `smooth_l1_kernel` (beta = 0) -- against the REFERENCE's own compute_loss bodies
+    (detection/retinanet_cal.py:100-133, :185-223, :389-400; tests/golden/train_losses.npz from
+    oracle/make_golden_train_losses.py): matched indices identical, losses within float32 summation noise (2e-6) of the
+    reference's float64 run and 1e-5 of its float32 run."""
+    torch, ops = T
+    g = golden("train_losses")
+    for k in range(int(g["l_n"])):
+        N, K = int(g["l%d_N" % k]), int(g["l%d_K" % k])
+        level_pix = [int(h * w) for h, w in g["l%d_level_hw" % k]]
+        anchors = torch.from_numpy(g["l%d_anchors" % k]).cuda()
+        cls, reg = g["l%d_cls_logits" % k], g["l%d_bbox_regression" % k]
+        ld = (9 * K + 15) // 16 * 16
+        cls_blocks, reg_blocks, reg_off, lvl_start = [], [], [], []
+        o = ro = 0
+        for n in level_pix:
+            blk = np.zeros((N, n, ld), np.float32)
+            blk[:, :, :9 * K] = cls[:, o:o + 9 * n].reshape(N, n, 9 * K)
+            cls_blocks.append(blk.reshape(-1)); reg_blocks.append(reg[:, o:o + 9 * n].reshape(N, n, 36).reshape(-1))
+            reg_off.append(ro); lvl_start.append(o)
+            ro += N * n * 36; o += 9 * n
+        cls_flat = torch.from_numpy(np.concatenate(cls_blocks)).cuda(); reg_flat = torch.from_numpy(np.concatenate(reg_blocks)).cuda()
+        matched, gts, labels = [], [], []
+        for i in range(N):
+            gt = torch.from_numpy(g["l%d_gt%d" % (k, i)]).cuda()
+            gts.append(gt); labels.append(torch.from_numpy(g["l%d_labels%d" % (k, i)]))
+            matched.append(ops.match(anchors, gt, 0.5, 0.4, True))
+        m = torch.stack(matched)
+        assert np.array_equal(m.cpu().numpy().astype(np.int64), g["l%d_matched" % k]), "case %d: matcher decisions" % k
+        mh = m.cpu().numpy()
+        gt_off = np.concatenate([[0], np.cumsum([b.shape[0] for b in gts])]).astype(np.int32)
+        nfg = [(mh[i] >= 0).sum() for i in range(N)]
+        img_w = torch.tensor([1.0 / (max(1, n) * N) for n in nfg], dtype=torch.float32).cuda()
+        got_c = ops.focal_loss(cls_flat, level_pix, N, 9, K, ld, m.contiguous(), torch.cat(labels).cuda(), torch.from_numpy(gt_off).cuda(), img_w)
+        box_idx, anc, gsel, wts = [], [], [], []
+        ls = np.array(lvl_start)
+        for i in range(N):
+            fg = np.nonzero(mh[i] >= 0)[0]
+            l = np.searchsorted(ls, fg, side="right") - 1
+            rel = fg - ls[l]
+            pix, a = rel // 9, rel % 9
+            box_idx.append(np.array(reg_off)[l] + (i * np.array(level_pix)[l] + pix) * 36 + 4 * a)
+            anc.append(fg); gsel.append(gt_off[i] + mh[i][fg]); wts.append(np.full(len(fg), 1.0 / (max(1, len(fg)) * N), np.float32))
+        box_idx, anc, gsel = [torch.from_numpy(np.concatenate(v).astype(np.int64)).cuda() for v in (box_idx, anc, gsel)]
+        tgt = ops.box_encode(torch.cat(gts)[gsel].contiguous(), anchors[anc].contiguous(), (1.0, 1.0, 1.0, 1.0))
+        got_r = ops.smooth_l1(reg_flat, box_idx, tgt, 0.0, 1.0, weights=torch.from_numpy(np.concatenate(wts)).cuda())
+        for got, name in ((got_c, "cls"), (got_r, "reg")):
+            w64, w32 = float(g["l%d_%s_f64" % (k, name)]), float(g["l%d_%s_f32" % (k, name)])
+            assert abs(float(got) - w64) <= 2e-6 * abs(w64), (k, name, float(got), w64)
+            assert abs(float(got) - w32) <= 1e-5 * abs(w32), (k, name, float(got), w32)
+
+
+def test_randperm_sampler_reproduces_torchvision_draws(T, oracle):
+    """sampler="randperm": the trainer consumes ``torch.randperm(n, generator=g)[:k]`` exactly as torchvision's
+    BalancedPositiveNegativeSampler does (positives then negatives, image by image, RPN before the RoI heads), so the float64
+    checker -- which draws ITS OWN samples from an equally seeded generator (oracle/torch_train.sample) -- lands on the same
+    anchors and the same RoIs without anything being handed over, and on the same losses."""
+    torch, ops = T
+    from cald_amd import train
+    from oracle import torch_train as tt
+    sd, images, targets = _train_case(torch, n_images=3, seed=4)
+    net = train.FasterRCNNTrainer(sd, 21, min_size=160, max_size=256, box_batch=64, generator=torch.Generator().manual_seed(11), sampler="randperm")
+    losses = net.forward(images, targets)
+    props = [p.cpu() for p in net.last["proposals"]]
+    ref = tt.TorchTrainFRCNN(sd, 21, min_size=160, max_size=256)
+    ref.masks = net.relu_decisions()
+    want, rec = ref.losses(images, targets, props, torch.Generator().manual_seed(11), cfg=dict(box_batch=64), samples=None)
+    A = rec["anchors"].shape[0]
+    got_pos = np.concatenate([i * A + sp for i, (sp, sn) in enumerate(net.last["samples"]["rpn"])])
+    got_neg = np.concatenate([i * A + sn for i, (sp, sn) in enumerate(net.last["samples"]["rpn"])])
+    assert np.array_equal(got_pos, rec["rpn_pos"].numpy()) and np.array_equal(got_neg, rec["rpn_neg"].numpy()), "RPN samples"
+    assert torch.equal(rec["roi_labels"], net.last["roi_labels"]), "sampled RoIs"
+    for k in want:
+        got, w = float(losses[k]), float(want[k].detach())
+        assert abs(got - w) <= 1e-4 * max(1.0, abs(w)), (k, got, w)
+    # the default sampler draws differently from the same seed (it never permutes all candidates)
+    other = train.FasterRCNNTrainer(sd, 21, min_size=160, max_size=256, box_batch=64, generator=torch.Generator().manual_seed(11))
+    other.forward(images, targets)
+    assert not all(np.array_equal(a[1], b[1]) for a, b in zip(other.last["samples"]["rpn"], net.last["samples"]["rpn"]))
+    with pytest.raises(ValueError):
+        train.FasterRCNNTrainer(sd, 21, min_size=160, max_size=256, sampler="nope")
+
+
+def test_full_size_training_step_gradients_vs_autograd(T, oracle):
+    """cald_train.py's training defaults AT SIZE: batch 4, min_size 600 / max_size 1000, 2 000 proposals, 512 sampled RoIs per
+    image.  The four losses and the gradient of every one of the 72 trainable tensors against float64 torch-CPU autograd
+    (oracle/torch_train.py), randperm sampler so the checker draws its own samples.  Tolerance 1e-4 (float32 vs float64)."""
+    import time
+    torch, ops = T
+    from cald_amd import train
+    from oracle import torch_train as tt
+    t0 = time.time()
+    sd, images, targets = _train_case(torch, n_images=4, seed=9, scale=1.0)
+    assert max(max(im.shape[1:]) for im in images) == 500
+    net = train.FasterRCNNTrainer(sd, 21, min_size=600, max_size=1000, generator=torch.Generator().manual_seed(21), sampler="randperm")
+    losses = net.forward(images, targets)
+    props = [p.cpu() for p in net.last["proposals"]]
+    assert all(p.shape[0] > 1000 for p in props)
+    grads = {k: v.clone() for k, v in net.backward().items()}
+    assert net.last["roi_labels"].numel() == 4 * 512
+    ref = tt.TorchTrainFRCNN(sd, 21, min_size=600, max_size=1000)
+    ref.masks = net.relu_decisions()
+    want, rec = ref.losses(images, targets, props, torch.Generator().manual_seed(21))
+    assert torch.equal(rec["roi_labels"], net.last["roi_labels"]), "same sampled RoIs"
+    for k in want:
+        got, w = float(losses[k]), float(want[k].detach())
+        assert abs(got - w) <= 1e-4 * max(1.0, abs(w)), (k, got, w)
+    sum(want.values()).backward()
+    tr = ref.trainable()
+    assert sorted(tr) == sorted(grads) and len(grads) == 72
+    worst = ("", 0.0)
+    for k, g in grads.items():
+        w = tr[k].grad
+        err = float((g.double().cpu() - w).abs().max()) / float(w.abs().max())
+        if err > worst[1]:
+            worst = (k, err)
+    assert worst[1] <= 1e-4, "largest gradient error %.3g at %s" % (worst[1], worst[0])
+    print("full-size training parity: worst gradient error %.3g at %s, %.0f s" % (worst[1], worst[0], time.time() - t0))
+
+
+def test_sgd_resume_uses_the_loaded_momentum(T):
+    """optimizer.load_state_dict() after fused steps (resume): the loaded momentum buffers are what the next fused step uses,
+    i.e. the trajectory equals torch.optim.SGD resumed from the same state."""
+    torch, ops = T
+    from cald_amd import train
+    sd, images, targets = _train_case(torch)
+    net = train.FasterRCNNTrainer(sd, 21, min_size=160, max_size=256, box_batch=64, generator=torch.Generator().manual_seed(7))
+    params = list(net.parameters())
+    opt = train.SGD(params, lr=1e-3, momentum=0.9, weight_decay=1e-4, net=net)
+    mirror = [torch.nn.Parameter(p.detach().clone()) for p in params]
+    ref = torch.optim.SGD(mirror, lr=1e-3, momentum=0.9, weight_decay=1e-4)
+    g = torch.Generator().manual_seed(0)
+
+    def step_both(seed_scale):
+        for p, m in zip(params, mirror):
+            gr = torch.randn(p.shape, generator=g).to(p.device) * seed_scale
+            if p.grad is None:
+                p.grad = net.grads[[k for k in net.names if net.params[k] is p][0]]
+            p.grad.copy_(gr); m.grad = gr.clone()
+        opt.step(); ref.step()
+    step_both(1.0); step_both(0.5)
+    assert opt._mflat is not None                       # the fused path ran
+    state = ref.state_dict()
+    # "resume": momentum from a checkpoint that differs from what the optimizer currently holds
+    for st in state["state"].values():
+        st["momentum_buffer"] = st["momentum_buffer"] * 3.0 + 0.25
+    ref.load_state_dict(state); opt.load_state_dict({"state": {i: {"momentum_buffer": v["momentum_buffer"].clone()} for i, v in state["state"].items()},
+                                                      "param_groups": opt.state_dict()["param_groups"]})
+    step_both(0.25)
+    for p, m in zip(params, mirror):
+        _close(p, m, 1e-6, "parameter after the resumed step")
+    assert all(opt.state[p]["momentum_buffer"].data_ptr() == opt._mflat.data_ptr() + 4 * net._off[k] for p, k in zip(params, net.names))
