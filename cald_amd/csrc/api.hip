@@ -364,6 +364,7 @@ extern "C" int cald_op_augment(cald_ctx* c, int kind, double param, uint64_t see
 struct HostTensor { std::vector<float> data; std::vector<int64_t> shape; };
 struct ConvLayer {
     float *w = nullptr, *w4 = nullptr, *bias = nullptr, *scale = nullptr, *shift = nullptr;
+    float* wstem = nullptr;                              // conv_stem.hip packing (the 7 x 7 / 2, 3 -> 64 stem only)
     uint16_t* w16 = nullptr; float w16_unscale = 1.0f;   // CALD_PRECISION_F16X3 only
     signed char* w8 = nullptr; float* w8_unscale = nullptr;   // CALD_PRECISION_I8X3 only (layers conv_i3.hip covers)
     int Cin = 0, Cout = 0, CoutPad = 0, K = 0, Kpad = 0, KH = 1, KW = 1, stride = 1, pad = 0;
@@ -547,6 +548,17 @@ static int make_conv(cald_model* m, ConvLayer& L, const std::vector<std::string>
         std::vector<float> w4 = pack_w4(w, L.Kpad, L.CoutPad);
         if ((rc = upload(m, w4, &L.w4))) return rc;
     }
+    if (kh == 7 && kw == 7 && cin == 3 && cinp == 4 && cout == 64 && stride == 2 && pad == 3 && ws.size() == 1) {   // conv_stem.hip layout
+        // chain slot S = 22 kh + f, f = 3 kw + c for f < 21, f = 21 a zero-weight slot; k-pair j = S >> 1 (77 pairs -> 20 quads), h = S & 1
+        std::vector<float> wsm((size_t)20 * 2 * 64 * 4, 0.0f);
+        for (int y = 0; y < 7; y++)
+            for (int f = 0; f < 21; f++) {
+                const int S = 22 * y + f, j = S >> 1, h = S & 1, q = j >> 2, e = j & 3, x = f / 3, ci = f % 3;
+                for (int co = 0; co < 64; co++)
+                    wsm[(((size_t)q * 2 + h) * 64 + co) * 4 + e] = ws[0]->data[(((size_t)co * 3 + ci) * 7 + y) * 7 + x];
+            }
+        if ((rc = upload(m, wsm, &L.wstem))) return rc;
+    }
     if (m->cfg.precision == CALD_PRECISION_I8X3 && i8_covers(L.Cin, L.Cout, kh * kw)) {   // conv_i3.hip digits
         std::vector<float> un; std::vector<signed char> w8 = pack_w8(w, L.CoutPad, kh * kw, L.Cin, un);
         if ((rc = upload(m, w8, &L.w8)) || (rc = upload(m, un, &L.w8_unscale))) return rc;
@@ -721,7 +733,7 @@ static int level_tiles(const BatchPlan& P, int l, int V) { return P.seg[l][V].ti
 struct FwdBufs {
     float *in0, *c1, *p1, *X[2], *T1, *T2, *D, *Cf[4], *inner[4], *Pf[5], *rpn_h[5];
     unsigned long long* cand_key; float *cand_box, *sorted_box, *sorted_raw; int* sorted_count;
-    float* proposals; int* prop_count;
+    float* proposals; int* prop_count; int* roi_order;
     float *roi, *f6, *f7, *pr, *prob, *pmax; unsigned long long* keys; float* cbox; int* key_count;
     // RetinaNet
     float *ret_t[2][2][5], *cls_h[5], *reg_h[5], *rcand_box, *kept_box; unsigned long long* rcand_key;   // ret_t[tower][ping-pong][level]
@@ -743,6 +755,15 @@ static double fill_conv_args(cald_model* m, ConvArgs& a, const ConvLayer& L, con
     a.total_mtiles = level_tiles(m->plan, lout, V);
     a.out_ld = L.Cout; a.in_relu = in_relu ? 1 : 0; a.zeros = m->ctx->d_zeros; a.exp_flags = 0;
     a.i8_in = nullptr; a.i8_plane_stride = 0; a.w8 = nullptr; a.w8_unscale = nullptr; a.i8_rowscale = nullptr; a.mask = nullptr;
+    a.wstem = nullptr;
+    if (L.wstem) {       // conv_stem.hip wants every view's output to be an exact grid of 8 x 16 pixel blocks (padded sizes are multiples of 32)
+        bool exact = true;
+        for (int v = 0; v < V && exact; v++) {
+            const LevelSeg& s = m->plan.seg[lout][v];
+            exact = s.H % 8 == 0 && s.W % 16 == 0 && m->plan.seg[lout][v + 1].tile_start - s.tile_start == (s.H / 8) * (s.W / 16);
+        }
+        if (exact) a.wstem = L.wstem;
+    }
     if (m->cfg.precision == CALD_PRECISION_I8X3 && L.w8 && !in_relu && m->i8_scratch) {
         // this layer runs on the int8 pipe: write the three digit planes + per-pixel scales of its input, then hand them to conv_i3.hip
         const long long P = level_pix(m->plan, lin, V);
@@ -837,6 +858,7 @@ static void fwd_layout(cald_model* m, Bump& B, FwdBufs& F, int V) {
     F.sorted_count = B.get<int>(V);
     F.proposals = B.get<float>((size_t)V * CALD_ROI_CAP * 4);
     F.prop_count = B.get<int>(V);
+    F.roi_order = B.get<int>((size_t)V * 1024);
     F.roi = B.get<float>((size_t)V * CALD_ROI_CAP * 12544);
     F.f6 = B.get<float>((size_t)V * CALD_ROI_CAP * 1024);
     F.f7 = B.get<float>((size_t)V * CALD_ROI_CAP * 1024);
@@ -995,7 +1017,7 @@ static int forward_model(cald_model* m, int V, ViewDesc* views, const DetBuffers
     // ---- box head (rows A18, A19, A20) ----
     RoiArgs ro;
     for (int i = 0; i < 4; i++) { ro.feat[i] = F.Pf[i]; ro.seg[i] = dp->seg[2 + i]; }
-    ro.C = 256; ro.V = V; ro.proposals = F.proposals; ro.prop_count = F.prop_count; ro.out = F.roi;
+    ro.C = 256; ro.V = V; ro.proposals = F.proposals; ro.prop_count = F.prop_count; ro.out = F.roi; ro.order = F.roi_order;
     launch_roi_align(ro, st);
     m->dbg["roi"] = {F.roi, 7, 12544, 1};
     const double fl_before_roi = c->prof_flops;

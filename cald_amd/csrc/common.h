@@ -58,6 +58,9 @@ struct ConvArgs {
     // training backward only (train.hip; honoured by conv_p4.hip): after everything else, out = mask > 0 ? out : 0 -- the ReLU backward
     // of the layer whose saved post-ReLU output `mask` (same geometry and row stride as out) this data gradient flows into; else null
     const float* mask;
+    // conv_stem.hip: the 7 x 7 / 2 stem's weights packed [20 quads of k-pairs][2 h][64 n][4] over the 154-slot chain (7 filter rows x
+    // (21 (kw, c) taps + 1 zero slot)); set only when every view's output is an exact grid of 8 x 16 blocks, else null
+    const float* wstem;
 };
 
 // Several independent conv problems in ONE launch (the five FPN levels under the shared-weight RPN / RetinaNet heads, the

@@ -280,6 +280,7 @@ static void launch_cfg(const ConvArgs& a, int bn, hipStream_t stream) {
 }
 
 bool launch_conv_p4(const ConvArgs& a, hipStream_t stream);   // conv_p4.hip
+bool launch_conv_stem(const ConvArgs& a, hipStream_t stream); // conv_stem.hip (only when a.wstem is set)
 bool launch_conv_h3(const ConvArgs& a, hipStream_t stream);   // conv_h3.hip (opt-in split-fp16 mode: only when a.w16 is set)
 bool launch_conv_i3(const ConvArgs& a, hipStream_t stream);   // conv_i3.hip (opt-in exact-integer int8 mode: only when a.w8 and a.i8_in are set)
 bool launch_conv_i3_group(const ConvArgs* p, int n, hipStream_t stream);
@@ -303,6 +304,8 @@ void launch_conv(const ConvArgs& a, hipStream_t stream) {
     static const int p4 = conv_env("CALD_CONV_P4", 1);   // conv_p4.hip: 3-buffer pipelined schedule, 128-bit LDS fragment reads; 0 = this file only
     if (a.w8 && a.i8_in && launch_conv_i3(a, stream)) return;
     if (a.w16 && launch_conv_h3(a, stream)) return;
+    static const int stem = conv_env("CALD_CONV_STEM", 1);   // 0: the stem runs on the generic kernels (same bits)
+    if (stem && a.wstem && launch_conv_stem(a, stream)) return;
     if (p4 && launch_conv_p4(a, stream)) return;
     if (a.CoutPad % 128 == 0) launch_cfg<2, 2, 2, 2, 16>(a, 128, stream);
     else if (a.CoutPad % 64 == 0) launch_cfg<2, 2, 2, 1, 16>(a, 64, stream);

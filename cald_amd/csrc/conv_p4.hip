@@ -377,6 +377,50 @@ __device__ __forceinline__ void conv_p4_body(const ConvArgs& a, const int blk) {
         }
         __syncthreads();
     }
+    // Vectorised epilogue (EPI 0 / 1, full tiles, every column real): each 32 x 32 accumulator tile goes through a wave-private LDS
+    // patch (the tile buffers are free after the k-loop's last barrier) and comes back row-major, so a lane owns four consecutive
+    // columns of a row: residual loads and output stores are 16-byte buffer operations -- a quarter of the VMEM instructions of the
+    // dword path below, which is what the short 1 x 1 chains (K = 64 ... 256) spend their life issuing.  Same per-element arithmetic.
+    if (EPI != 2 && !MASK && full_tile && (a.exp_flags & 4) && n0 + BN <= a.Cout) {
+        constexpr int PITCH = 36;                                    // floats; 16-byte aligned rows
+        float* const patch = smem + wave * (3 * TILE_F / 4);         // 12 KB (TN = 2) / 9 KB (TN = 1) per wave >= 32 * 36 * 4 B
+        const int rrow = lane >> 3, c4 = lane & 7;
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            const int nb = n0 + wn * TN * 32 + j * 32 + 4 * c4;     // first of this lane's four columns
+            f32x4 bs4 = {0.f, 0.f, 0.f, 0.f}, sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
+            if (has_bias) bs4 = *reinterpret_cast<const f32x4*>(a.bias + nb);
+            if (has_bn) { sc4 = *reinterpret_cast<const f32x4*>(a.scale + nb); sh4 = *reinterpret_cast<const f32x4*>(a.shift + nb); }
+#pragma unroll
+            for (int i = 0; i < TM; i++) {
+                const int mrow = m0 + wm * TM * 32 + i * 32;
+#pragma unroll
+                for (int r = 0; r < 16; r++) patch[(4 * kh_lane + (r & 3) + 8 * (r >> 2)) * PITCH + l31] = acc[i][j][r];
+                const int vo = ((mrow + rrow) * out_ld + nb) * 4;
+                f32x4 ex[4];
+                if (EPI == 1) {
+#pragma unroll
+                    for (int it = 0; it < 4; it++)
+                        ex[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, vo, it * 8 * row_b, 0));
+                }
+#pragma unroll
+                for (int it = 0; it < 4; it++) {
+                    f32x4 val = *reinterpret_cast<const f32x4*>(patch + (rrow + 8 * it) * PITCH + 4 * c4);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        float x = val[q];
+                        if (has_bias) x = x + bs4[q];
+                        if (has_bn) { x = x * sc4[q]; x = x + sh4[q]; }
+                        if (EPI == 1) x = x + ex[it][q];
+                        if (relu) x = x > 0.0f ? x : 0.0f;
+                        val[q] = x;
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, val), rsO, vo, it * 8 * row_b, 0);
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TN; j++) {
         const int n = n0 + wn * TN * 32 + j * 32 + l31;

@@ -74,6 +74,7 @@ struct RoiArgs {
     const float* proposals;  // [V][ROI_CAP][4]
     const int* prop_count;   // [V]
     float* out;              // [V][ROI_CAP][49][C]
+    int* order;              // [V][1024] scratch: the view's RoIs sorted by (pyramid level, row band, column) -- processing order only
 };
 void launch_roi_align(const RoiArgs& a, hipStream_t st);
 

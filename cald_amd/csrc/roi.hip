@@ -9,14 +9,44 @@
 #include "kernels.h"
 #include "sortnms.h"
 
-// grid = (ROI_CAP, V), block = 256.  The 14 sample rows and 14 sample columns of the RoI (7 bins x 2 samples,
+// Processing order of a view's RoIs.  Proposals arrive in score order, i.e. scattered over the image and the pyramid: with one
+// workgroup per RoI in that order every XCD's L2 (4 MB) kept re-fetching the whole 40 MB pyramid of the view (8.3 GB raw L2->fabric
+// fetch per 64-view forward for 2.6 GB of features).  One workgroup per view sorts (level, 16-pixel row band, column) keys in LDS;
+// roi_align_kernel then walks a view's RoIs in that order ON ONE XCD, so RoIs in flight together overlap in the feature map.
+// Results do not depend on the order (every RoI is computed alone and written to its own slot r).
+__global__ __launch_bounds__(1024) void roi_order_kernel(RoiArgs a) {
+    __shared__ unsigned long long keys[1024];
+    const int v = blockIdx.x, tid = threadIdx.x;
+    const int n = a.prop_count[v];
+    unsigned long long key = 0ull;
+    if (tid < n && tid < CALD_ROI_CAP) {
+        const float4 box = reinterpret_cast<const float4*>(a.proposals)[(long long)v * CALD_ROI_CAP + tid];
+        const int l = roi_level(box);
+        const float scale = 1.0f / (float)(4 << l);
+        const float cy = (box.y + box.w) * 0.5f * scale, cx = (box.x + box.z) * 0.5f * scale;
+        int yb = (int)(cy * (1.0f / 16.0f)), xb = (int)cx;
+        yb = yb < 0 ? 0 : (yb > 1023 ? 1023 : yb); xb = xb < 0 ? 0 : (xb > 4095 ? 4095 : xb);
+        // descending sort: complement so that level 0 / top rows come first; + 1 keeps valid keys above the padding zeros
+        const unsigned pos = ((unsigned)l << 22) | ((unsigned)yb << 12) | (unsigned)xb;
+        key = ((unsigned long long)(0x0FFFFFFFu - pos + 1u) << 32) | (unsigned long long)tid;
+    }
+    keys[tid] = key;
+    __syncthreads();
+    block_bitonic_sort_desc(keys, 1024);
+    a.order[v * 1024 + tid] = (int)(keys[tid] & 0xFFFFFFFFull);
+}
+
+// One workgroup per RoI, block = 256; workgroup b runs on XCD b % 8 and XCD x owns views x, x + 8, ... (all RoIs of a view on one
+// L2, in roi_order_kernel's order).  The 14 sample rows and 14 sample columns of the RoI (7 bins x 2 samples,
 // separable) are set up once per workgroup in LDS; then a thread owns (bin, 4 consecutive channels): 16 float4
 // gathers in flight per bin and one float4 store, 1 KB contiguous per wavefront.  Arithmetic order per channel is
 // the oracle's: acc += ((w1*v1 + w2*v2) + w3*v3) + w4*v4 over samples (iy, ix), then / 4.
 __global__ __launch_bounds__(256) void roi_align_kernel(RoiArgs a) {
     __shared__ RoiSample sy[14], sx[14];
-    const int r = blockIdx.x, v = blockIdx.y, tid = threadIdx.x;
-    if (r >= a.prop_count[v]) return;
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3, tid = threadIdx.x;
+    const int v = xcd + 8 * (seq / CALD_ROI_CAP), slot = seq % CALD_ROI_CAP;
+    if (v >= a.V || slot >= a.prop_count[v]) return;
+    const int r = a.order[v * 1024 + slot];
     const float4 box = reinterpret_cast<const float4*>(a.proposals)[(long long)v * CALD_ROI_CAP + r];
     const int l = roi_level(box);
     const LevelSeg sg = a.seg[l][v];
@@ -59,7 +89,8 @@ __global__ __launch_bounds__(256) void roi_align_kernel(RoiArgs a) {
     }
 }
 void launch_roi_align(const RoiArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(roi_align_kernel, dim3(CALD_ROI_CAP, a.V), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(roi_order_kernel, dim3(a.V), dim3(1024), 0, st, a);
+    hipLaunchKernelGGL(roi_align_kernel, dim3(8 * ((a.V + 7) / 8) * CALD_ROI_CAP), dim3(256), 0, st, a);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -23,6 +23,27 @@ def _gpu_tests_need_a_gpu(request):
             pytest.skip("needs an MI355X")
 
 
+def usable_cpus():
+    """CPUs this process may really use: affinity capped by the cgroup quota (a GPU box shows 256 CPUs and grants 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _torch_threads_fit_the_cgroup():
+    """The float64 torch-CPU checkers (oracle/torch_train.py, oracle/torch_port.py) run 10x slower when torch starts one thread
+    per visible CPU on a box whose cgroup grants a sixteenth of them."""
+    import torch
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), usable_cpus())))
+    yield
+
+
 @pytest.fixture(scope="session")
 def oracle():
     """The CPU oracle (test infrastructure).  Built on demand with gcc."""
