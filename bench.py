@@ -115,7 +115,7 @@ def synthetic_labeled_set(n=500, num_cls=21, seed=0):
     return [(None, [{"labels": torch.from_numpy(rs.randint(1, num_cls, rs.randint(1, 6)))}]) for _ in range(n)]
 
 
-def cpu_baseline(sd, blobs, augs, budget_s=48.0, max_images=32):
+def cpu_baseline(sd, blobs, augs, positions, gpu_scores, budget_s=48.0, max_images=32):
     """The reference-shaped PyTorch-CPU port (oracle/torch_port.py) on a bounded sample of the same workload."""
     import numpy as np
     import torch
@@ -134,14 +134,20 @@ def cpu_baseline(sd, blobs, augs, budget_s=48.0, max_images=32):
         if t < best[1]:
             best = (nt, t)
     torch.set_num_threads(best[0])
-    n, t0 = 0, time.time()
+    n, t0, scores = 0, time.time(), []
     while n < len(pool) and (n == 0 or time.time() - t0 < budget_s):
-        torch_port.get_uncertainty(model, [pool[n]], augs, 21, bp=1.3, base_seed=0, positions=[n])
+        c, _ = torch_port.get_uncertainty(model, [pool[n]], augs, 21, bp=1.3, base_seed=0, positions=[positions[n]])
+        scores.append(float(c[0]))
         n += 1
     dt = time.time() - t0
     used = torch.get_num_threads()
     torch.set_num_threads(default_threads)
-    return {"value": n / dt, "unit": "images/s", "cores": used, "images": n,
+    d = np.abs(np.asarray(scores) - np.asarray(gpu_scores[:n], np.float64))
+    live = {"images_compared": n, "max_abs_consistency_diff": float(d.max()), "median_abs_consistency_diff": float(np.median(d)),
+            "images_beyond_1e-4": int((d > 1e-4).sum()),
+            "note": "measured in THIS run: the same pool images scored by the MI355X sweep and by the torch-CPU fp32 port (oneDNN "
+                    "summation order, not the oracle's arithmetic contract); north_star's float tolerance is 1e-4"}
+    return {"value": n / dt, "unit": "images/s", "cores": used, "images": n, "gpu_vs_cpu_port_live": live,
             "kind": "port (torch-CPU fp32 convs / linears; top-k, NMS, RoIAlign and post-processing in the OpenMP C oracle -- "
                     "stronger than the reference's pure-PyTorch CPU path)",
             "sample": "%d synthetic VOC-shaped image(s) x 4 views, batch-1 sequential torch-CPU fp32 forwards + python/scipy "
@@ -432,7 +438,7 @@ def main():
                                 "timed_region": "host JPEG bytes -> GPU decode -> get_uncertainty -> argsort + cls_kldiv -> 500 indices"}
             dev_pool = fp
         if world == 1 and not args.no_cpu_baseline and headline:
-            out["cpu_baseline"] = cpu_baseline(sd, blobs, augs)
+            out["cpu_baseline"] = cpu_baseline(sd, blobs, augs, positions, cons)
             out["cpu_baseline"]["host_cpus"] = os.cpu_count()
             out["cpu_baseline"]["host_cpus_usable"] = usable_cpus()
             out["config0_cpu_plumbing"] = config0_leg(model, sd, B, threads=out["cpu_baseline"]["cores"])

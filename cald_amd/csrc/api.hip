@@ -708,6 +708,9 @@ extern "C" int cald_model_destroy(cald_model* m) {
 // =============================================================================================
 // forward
 // =============================================================================================
+// Rows of the RoI-head GEMMs are grouped 32 views to a segment: 32 000 rows = exactly 250 tiles of 128, and the segment's fc6 operand
+// (32 000 x 12 544 floats = 1.6 GB) stays inside the 2 GB a buffer resource / a 32-bit byte offset can address.
+#define ROI_DENSE_VIEWS 32
 static void build_plan(BatchPlan& P, int V, const ViewDesc* views, const int (*hp)[2], bool retina) {
     memset(&P, 0, sizeof(P));
     for (int l = 0; l < CALD_MAX_LEVELS; l++) {
@@ -719,6 +722,10 @@ static void build_plan(BatchPlan& P, int V, const ViewDesc* views, const int (*h
             int H, W;
             if (l == 7 && retina) { int h6 = (hp[v][0] / 32 - 1) / 2 + 1, w6 = (hp[v][1] / 32 - 1) / 2 + 1; H = (h6 - 1) / 2 + 1; W = (w6 - 1) / 2 + 1; }
             else if (l == 7) { H = 1; W = CALD_ROI_CAP; }
+            else if (l == 8) {   // the RoI-head GEMMs' view of level 7: dense rows, in segments of ROI_DENSE_VIEWS views (see forward_model)
+                const int first = v * ROI_DENSE_VIEWS, cnt = first < V ? (V - first < ROI_DENSE_VIEWS ? V - first : ROI_DENSE_VIEWS) : 0;
+                H = cnt ? 1 : 0; W = cnt * CALD_ROI_CAP;
+            }
             else if (l == 6) { H = (hp[v][0] / 32 - 1) / 2 + 1; W = (hp[v][1] / 32 - 1) / 2 + 1; }
             else { H = hp[v][0] >> l; W = hp[v][1] >> l; }
             s.H = H; s.W = W;
@@ -785,6 +792,35 @@ static int conv_on(cald_model* m, const ConvLayer& L, const float* in, float* ou
     m->i8_off = 0;
     const double flops = fill_conv_args(m, a, L, in, out, lin, lout, V, relu, residual, up, lup, dyn, in_relu);
     return run_conv(m->ctx, a, flops);
+}
+// Bottleneck conv2 (3 x 3) + conv3 (1 x 1 expand, + residual) of one block: ONE launch when conv_p4.hip's fused kernel covers the
+// shapes (the 64-channel blocks of layer 1, exact fp32 mode) -- the 64-channel tensor `mid` is then never written -- else two launches.
+bool launch_conv_p4_fused(const ConvArgs& c2, const ConvArgs& c3, hipStream_t stream);   // conv_p4.hip
+static int conv_pair_on(cald_model* m, const ConvLayer& L2, const ConvLayer& L3, const float* in, float* mid, float* out, int lin, int lout,
+                        int V, const float* residual) {
+    cald_ctx* c = m->ctx;
+    if (m->cfg.precision == CALD_PRECISION_FP32 && L2.stride == 1 && lin == lout) {
+        ConvArgs a2, a3;
+        m->i8_off = 0;
+        const double f2 = fill_conv_args(m, a2, L2, in, mid, lin, lout, V, true);
+        const double f3 = fill_conv_args(m, a3, L3, mid, out, lout, lout, V, true, residual);
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (c->prof) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, c->stream)); }
+        const bool done = launch_conv_p4_fused(a2, a3, c->stream);
+        if (done) {
+            if (c->prof) {
+                HIPCHK(hipEventRecord(e1, c->stream));
+                c->ev0.push_back(e0); c->ev1.push_back(e1); c->prof_flops += f2 + f3;
+                char d[160]; snprintf(d, sizeof(d), "mt=%d,Cin=%d,Cout=%d,k=3x3+1x1,s=1,fused->%d", a2.total_mtiles, a2.Cin, a2.Cout, a3.Cout);
+                c->prof_desc.push_back(d); c->prof_fl.push_back(f2 + f3);
+            }
+            return 0;
+        }
+        if (c->prof) { hipEventDestroy(e0); hipEventDestroy(e1); }
+    }
+    int rc = conv_on(m, L2, in, mid, lin, lout, V, true);
+    if (rc) return rc;
+    return conv_on(m, L3, mid, out, lout, lout, V, true, residual);
 }
 // independent convolutions (bias / BN / ReLU epilogue only) issued as ONE launch when they fit the same tiled kernel
 struct ConvSpec { const ConvLayer* L; const float* in; float* out; int level; bool relu; };
@@ -927,9 +963,8 @@ static int forward_model(cald_model* m, int V, ViewDesc* views, const DetBuffers
         const float* idn = cur;
         if (B.has_down) { if ((rc = conv_on(m, B.down, cur, F.D, lvl, lout, V, false))) return rc; idn = F.D; }
         if ((rc = conv_on(m, B.c1, cur, F.T1, lvl, lvl, V, true))) return rc;
-        if ((rc = conv_on(m, B.c2, F.T1, F.T2, lvl, lout, V, true))) return rc;
         float* dst = B.layer_end ? F.Cf[layer] : F.X[xi];
-        if ((rc = conv_on(m, B.c3, F.T2, dst, lout, lout, V, true, idn))) return rc;
+        if ((rc = conv_pair_on(m, B.c2, B.c3, F.T1, F.T2, dst, lvl, lout, V, idn))) return rc;
         cur = dst; lvl = lout;
         if (B.layer_end) layer++; else xi ^= 1;
     }
@@ -1021,9 +1056,16 @@ static int forward_model(cald_model* m, int V, ViewDesc* views, const DetBuffers
     launch_roi_align(ro, st);
     m->dbg["roi"] = {F.roi, 7, 12544, 1};
     const double fl_before_roi = c->prof_flops;
-    if ((rc = conv_on(m, m->fc6, F.roi, F.f6, 7, 7, V, true, nullptr, nullptr, 0, F.prop_count))) return rc;
-    if ((rc = conv_on(m, m->fc7, F.f6, F.f7, 7, 7, V, true, nullptr, nullptr, 0, F.prop_count))) return rc;
-    if ((rc = conv_on(m, m->pred, F.f7, F.pr, 7, 7, V, false, nullptr, nullptr, 0, F.prop_count))) return rc;
+    // The RoI buffers are dense [V][1000][C]; as per-view problems every view pads its 1 000 rows to eight 128-row tiles (2.4 % idle
+    // rows in fc6).  Rows of a GEMM are independent, so the three layers run as ONE problem of V * 1000 rows (level 8: 500 tiles for
+    // 64 views, a tile may straddle two views; segments of 32 views keep byte offsets inside 31 bits).  Rows beyond a view's proposal count hold stale finite-or-not data and are never
+    // read downstream (post-processing walks r < count); the profile counts FLOPs on the measured rows as before.
+    static const bool roi_dense = !(getenv("CALD_ROI_DENSE") && atoi(getenv("CALD_ROI_DENSE")) == 0);
+    const int lr = roi_dense ? 8 : 7, Vr = roi_dense ? (V + ROI_DENSE_VIEWS - 1) / ROI_DENSE_VIEWS : V;
+    const int* dynr = roi_dense ? nullptr : F.prop_count;
+    if ((rc = conv_on(m, m->fc6, F.roi, F.f6, lr, lr, Vr, true, nullptr, nullptr, 0, dynr))) return rc;
+    if ((rc = conv_on(m, m->fc7, F.f6, F.f7, lr, lr, Vr, true, nullptr, nullptr, 0, dynr))) return rc;
+    if ((rc = conv_on(m, m->pred, F.f7, F.pr, lr, lr, Vr, false, nullptr, nullptr, 0, dynr))) return rc;
     if (c->prof) {
         hipLaunchKernelGGL(accumulate_rows_kernel, dim3(1), dim3(64), 0, st, F.prop_count, V, c->d_roi_rows);
         c->prof_roi_rows_cap += (double)V * CALD_ROI_CAP; c->prof_roi_flops_cap += c->prof_flops - fl_before_roi; c->prof_roi_views += V;
@@ -1493,10 +1535,12 @@ extern "C" int cald_sweep(cald_model* m, int n_images, const uint8_t* const* ima
             launch_noise_stream(d_jobs, (int)jobs.size(), c->stream);
         }
         if (rc) break;
-        // ---- phase 2: augmented views (chunks of <= 64) ----
+        // ---- phase 2: augmented views in forwards of <= 64 views, evenly sized (159 views run as 53 + 53 + 53, not 64 + 64 + 31:
+        // a short last forward leaves most of its launches under-filled; results do not depend on the split) ----
         const int na = (int)aviews.size();
-        for (int a0 = 0; a0 < na && !rc; a0 += CALD_MAX_VIEWS) {
-            const int nv = (na - a0 < CALD_MAX_VIEWS) ? na - a0 : CALD_MAX_VIEWS;
+        const int n_fw = (na + CALD_MAX_VIEWS - 1) / CALD_MAX_VIEWS;
+        for (int f = 0; f < n_fw && !rc; f++) {
+            const int a0 = (int)(((long long)na * f) / n_fw), nv = (int)(((long long)na * (f + 1)) / n_fw) - a0;
             DetBuffers d2 = D; const size_t o = (size_t)(nb + a0);
             d2.boxes += o * cap * 4; d2.scores += o * cap; d2.labels += o * cap; d2.props += o * cap * 4;
             d2.prob_max += o * cap; d2.scores_cls += o * cap * C; d2.count += o;

@@ -16,6 +16,142 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// ---- fused epilogue (shared by the plain kernels and by the bottleneck-fused kernel's second GEMM) ----
+template <int EPI, bool MASK, int TM, int TN>
+__device__ __forceinline__ void p4_epilogue(const ConvArgs& a, const f32x16 (&acc)[TM][TN], float* smem, const int v, const LevelSeg& so,
+                                            const int m0, const int Mv, const int n0) {
+    constexpr int BM = 128, WN = 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int kh_lane = lane >> 5, l31 = lane & 31;
+    const int Ho = so.H, Wo = so.W;
+    // (same arithmetic as conv_mfma.hip): (+bias) -> (*bn_scale, +bn_shift) -> (+residual | +upsampled) -> ReLU ----
+    // VALU instructions issued here take matrix-pipe time away from the two other workgroups of the CU, and for the short 1 x 1
+    // chains (K = 64 ... 256) the epilogue is a large part of a workgroup's life: addresses are therefore kept off the VALU --
+    // one byte offset per lane and accumulator tile, the 16 rows of a tile reached through the scalar offset of the buffer
+    // instruction -- and absent bias / BN terms are skipped by wave-uniform branches instead of neutral operands.
+    const int out_ld = a.out_ld;
+    float* __restrict__ out_v = a.out + so.pix_off * (long long)out_ld;
+    const float* __restrict__ ex_v = nullptr;
+    int upH = 1, upW = 1;
+    float uph_s = 0.f, upw_s = 0.f;
+    if (EPI == 1) ex_v = a.residual + so.pix_off * (long long)out_ld;
+    if (EPI == 2) {
+        const LevelSeg su = a.seg_up[v];
+        ex_v = a.up + su.pix_off * (long long)out_ld;
+        upH = su.H; upW = su.W;
+        uph_s = (float)upH / (float)Ho; upw_s = (float)upW / (float)Wo;
+    }
+    const bool relu = a.relu != 0, has_bias = a.bias != nullptr, has_bn = a.scale != nullptr;
+    constexpr bool has_mask = MASK;
+    const float* __restrict__ mask_v = has_mask ? a.mask + so.pix_off * (long long)out_ld : out_v;
+    const bool full_tile = m0 + BM <= Mv && !(a.exp_flags & 1);
+    const int row_b = out_ld * 4;
+    const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc((void*)out_v, 0, 0x7FFE0000, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)(EPI != 0 ? ex_v : out_v), 0, 0x7FFE0000, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc((void*)mask_v, 0, 0x7FFE0000, 0x00020000);
+    // FPN top-down (EPI 2): the nearest-neighbour source pixel of each of the tile's 128 rows is computed ONCE (one thread per
+    // row; the LDS tile buffers are free after the k-loop's last barrier) instead of by every lane for each of its 32 rows
+    const int Mlast = Mv - 1;
+    int* const s_src = reinterpret_cast<int*>(smem);
+    if (EPI == 2) {
+        if (tid < BM) {
+            int m = m0 + tid;
+            m = m < Mlast ? m : Mlast;
+            const int oy = m / Wo, ox = m - oy * Wo;
+            int sy = (int)floorf((float)oy * uph_s); sy = sy > upH - 1 ? upH - 1 : sy;
+            int sx = (int)floorf((float)ox * upw_s); sx = sx > upW - 1 ? upW - 1 : sx;
+            s_src[tid] = (sy * upW + sx) * out_ld * 4;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+        const int n = n0 + wn * TN * 32 + j * 32 + l31;
+        const bool nok = n < a.Cout;
+        const int nc = nok ? n : 0;
+        const float bs = has_bias ? a.bias[nc] : 0.0f;
+        const float sc = has_bn ? a.scale[nc] : 1.0f;
+        const float sh = has_bn ? a.shift[nc] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+            const int mbase = m0 + wm * TM * 32 + i * 32 + 4 * kh_lane;
+            float extra[16];
+            if (EPI == 1 && full_tile) {
+                const int vo = nok ? (mbase * out_ld + n) * 4 : 0x7FFF0000;
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    extra[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsX, vo, ((r & 3) + 8 * (r >> 2)) * row_b, 0));
+            } else if (EPI == 2) {
+                const int rl = wm * TM * 32 + i * 32 + 4 * kh_lane;          // tile-local row of accumulator register 0
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const i32x4 so4 = *reinterpret_cast<const i32x4*>(s_src + rl + 8 * q);
+#pragma unroll
+                    for (int jj = 0; jj < 4; jj++)
+                        extra[4 * q + jj] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsX, so4[jj] + nc * 4, 0, 0));
+                }
+            } else if (EPI == 1) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    int m = mbase + (r & 3) + 8 * (r >> 2);
+                    m = m < Mlast ? m : Mlast;
+                    extra[r] = ex_v[(long long)m * out_ld + nc];
+                }
+            }
+            float val[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) val[r] = acc[i][j][r];
+            if (has_bias) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) val[r] = val[r] + bs;
+            }
+            if (has_bn) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) { val[r] = val[r] * sc; val[r] = val[r] + sh; }
+            }
+            if (EPI != 0) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) val[r] = val[r] + extra[r];
+            }
+            if (relu) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) val[r] = val[r] > 0.0f ? val[r] : 0.0f;
+            }
+            if (has_mask) {      // training backward: ReLU backward of the layer this data gradient flows into (wave-uniform branch)
+                float mk[16];
+                if (full_tile) {
+                    const int vo = nok ? (mbase * out_ld + n) * 4 : 0x7FFF0000;
+#pragma unroll
+                    for (int r = 0; r < 16; r++)
+                        mk[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsM, vo, ((r & 3) + 8 * (r >> 2)) * row_b, 0));
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        int m = mbase + (r & 3) + 8 * (r >> 2);
+                        m = m < Mlast ? m : Mlast;
+                        mk[r] = mask_v[(long long)m * out_ld + nc];
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; r++) val[r] = mk[r] > 0.0f ? val[r] : 0.0f;
+            }
+            if (full_tile) {
+                const int vo = nok ? (mbase * out_ld + n) * 4 : 0x7FFF0000;
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val[r]), rsO, vo, ((r & 3) + 8 * (r >> 2)) * row_b, 0);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int m = mbase + (r & 3) + 8 * (r >> 2);
+                    if (m < Mv && nok && !((a.exp_flags & 1) && val[r] != 12345.678f)) out_v[(long long)m * out_ld + n] = val[r];
+                }
+            }
+        }
+    }
+}
+
 // C4: Cin == 4 (the stem conv on the NHWC4 input).  A thread's four consecutive k are one filter tap, so the tap and its
 // validity are per-thread quantities; the k order (tap, channel) is the contract's (kh, kw, cin) order unchanged.
 // TN = 2: 128 x 128 tiles; TN = 1: 128 x 64 tiles (64 x 32 per wave) for the 64-wide layers.
@@ -24,12 +160,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // no address / mask VALU at all (every VALU instruction beside v_mfma_f32_32x32x2_f32 costs matrix-pipe time: they share the
 // fp32 datapath).  13 = the 7 x 7 stem on the 4-channel input (13 k-tiles, fully unrolled).  0 = generic rolled loop.
 template <int EPIX, bool C4, int TN, int TAPS>
-__device__ __forceinline__ void conv_p4_body(const ConvArgs& a, const int blk) {
+__device__ __forceinline__ void conv_p4_body(const ConvArgs& a, const int blk, const ConvArgs* a3 = nullptr) {
     constexpr int EPI = EPIX & 3;               // 0 none, 1 residual, 2 nearest-upsampled top-down
     constexpr bool MASK = (EPIX & 4) != 0;      // training backward only: the ReLU-backward mask step is compiled in
+    constexpr bool FUSE = (EPIX & 8) != 0;      // bottleneck conv2 (3 x 3, 64 -> 64) + conv3 (1 x 1, 64 -> 256, + residual) in one workgroup
     constexpr int BM = 128, BN = 64 * TN, BK = 16, TM = 2, WN = 2;
     constexpr int TILE_A = 2 * BM * 8, TILE_F = TILE_A + 2 * BN * 8;      // floats: 2048 + 2048 (TN = 2)
-    __shared__ __attribute__((aligned(16))) float smem[3 * TILE_F];
+    constexpr int FUSE_T = 4 * TILE_A;          // floats: conv2's 128 x 64 output tile as the A operand of four k-tiles (32 KB)
+    __shared__ __attribute__((aligned(16))) float smem[FUSE ? 2 * FUSE_T : 3 * TILE_F];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -337,174 +475,93 @@ __device__ __forceinline__ void conv_p4_body(const ConvArgs& a, const int blk) {
 #undef P4_MFMA
 #undef P4_TILE
 
-    // ---- fused epilogue (same arithmetic as conv_mfma.hip): (+bias) -> (*bn_scale, +bn_shift) -> (+residual | +upsampled) -> ReLU ----
-    // VALU instructions issued here take matrix-pipe time away from the two other workgroups of the CU, and for the short 1 x 1
-    // chains (K = 64 ... 256) the epilogue is a large part of a workgroup's life: addresses are therefore kept off the VALU --
-    // one byte offset per lane and accumulator tile, the 16 rows of a tile reached through the scalar offset of the buffer
-    // instruction -- and absent bias / BN terms are skipped by wave-uniform branches instead of neutral operands.
-    const int out_ld = a.out_ld;
-    float* __restrict__ out_v = a.out + so.pix_off * (long long)out_ld;
-    const float* __restrict__ ex_v = nullptr;
-    int upH = 1, upW = 1;
-    float uph_s = 0.f, upw_s = 0.f;
-    if (EPI == 1) ex_v = a.residual + so.pix_off * (long long)out_ld;
-    if (EPI == 2) {
-        const LevelSeg su = a.seg_up[v];
-        ex_v = a.up + su.pix_off * (long long)out_ld;
-        upH = su.H; upW = su.W;
-        uph_s = (float)upH / (float)Ho; upw_s = (float)upW / (float)Wo;
-    }
-    const bool relu = a.relu != 0, has_bias = a.bias != nullptr, has_bn = a.scale != nullptr;
-    constexpr bool has_mask = MASK;
-    const float* __restrict__ mask_v = has_mask ? a.mask + so.pix_off * (long long)out_ld : out_v;
-    const bool full_tile = m0 + BM <= Mv && !(a.exp_flags & 1);
-    const int row_b = out_ld * 4;
-    const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc((void*)out_v, 0, 0x7FFE0000, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)(EPI != 0 ? ex_v : out_v), 0, 0x7FFE0000, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc((void*)mask_v, 0, 0x7FFE0000, 0x00020000);
-    // FPN top-down (EPI 2): the nearest-neighbour source pixel of each of the tile's 128 rows is computed ONCE (one thread per
-    // row; the LDS tile buffers are free after the k-loop's last barrier) instead of by every lane for each of its 32 rows
-    const int Mlast = Mv - 1;
-    int* const s_src = reinterpret_cast<int*>(smem);
-    if (EPI == 2) {
-        if (tid < BM) {
-            int m = m0 + tid;
-            m = m < Mlast ? m : Mlast;
-            const int oy = m / Wo, ox = m - oy * Wo;
-            int sy = (int)floorf((float)oy * uph_s); sy = sy > upH - 1 ? upH - 1 : sy;
-            int sx = (int)floorf((float)ox * upw_s); sx = sx > upW - 1 ? upW - 1 : sx;
-            s_src[tid] = (sy * upW + sx) * out_ld * 4;
-        }
-        __syncthreads();
-    }
-    // Vectorised epilogue (EPI 0 / 1, full tiles, every column real): each 32 x 32 accumulator tile goes through a wave-private LDS
-    // patch (the tile buffers are free after the k-loop's last barrier) and comes back row-major, so a lane owns four consecutive
-    // columns of a row: residual loads and output stores are 16-byte buffer operations -- a quarter of the VMEM instructions of the
-    // dword path below, which is what the short 1 x 1 chains (K = 64 ... 256) spend their life issuing.  Same per-element arithmetic.
-    if (EPI != 2 && !MASK && full_tile && (a.exp_flags & 4) && n0 + BN <= a.Cout) {
-        constexpr int PITCH = 36;                                    // floats; 16-byte aligned rows
-        float* const patch = smem + wave * (3 * TILE_F / 4);         // 12 KB (TN = 2) / 9 KB (TN = 1) per wave >= 32 * 36 * 4 B
-        const int rrow = lane >> 3, c4 = lane & 7;
+    if constexpr (FUSE) {
+        // ---- bottleneck tail: T = relu(bn2(acc)) (conv2's own epilogue arithmetic, bit for bit what the unfused kernel stores) never
+        // leaves the CU -- it is laid down in LDS as the A operand of conv3 (plain channel order = conv3's chain order), conv3's weights
+        // come in 128-column chunks, and each chunk runs the ordinary residual epilogue.  The 64-channel tensor is neither written nor
+        // read back, and conv3's HBM-bound epilogue (residual in, 256 channels out) overlaps the other workgroup's 3 x 3 k-loop. ----
+        const ConvArgs& b = *a3;
+        float* const Tl = smem;
+        float* const Wl = smem + FUSE_T;
+        {
+            const int c = wn * 32 + l31;                        // conv2 output channel of this lane (TN == 1, BN == 64 == Cout)
+            const float sc = a.scale ? a.scale[c] : 1.0f, sh = a.scale ? a.shift[c] : 0.0f, bs = a.bias ? a.bias[c] : 0.0f;
+            const bool relu2 = a.relu != 0, has_bias2 = a.bias != nullptr, has_bn2 = a.scale != nullptr;
+            float* const tc = Tl + (c >> 4) * TILE_A + ((c >> 3) & 1) * BM * 8 + ((c & 7) >> 1);
+            const int hsw = c & 1;
 #pragma unroll
-        for (int j = 0; j < TN; j++) {
-            const int nb = n0 + wn * TN * 32 + j * 32 + 4 * c4;     // first of this lane's four columns
-            f32x4 bs4 = {0.f, 0.f, 0.f, 0.f}, sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
-            if (has_bias) bs4 = *reinterpret_cast<const f32x4*>(a.bias + nb);
-            if (has_bn) { sc4 = *reinterpret_cast<const f32x4*>(a.scale + nb); sh4 = *reinterpret_cast<const f32x4*>(a.shift + nb); }
-#pragma unroll
-            for (int i = 0; i < TM; i++) {
-                const int mrow = m0 + wm * TM * 32 + i * 32;
-#pragma unroll
-                for (int r = 0; r < 16; r++) patch[(4 * kh_lane + (r & 3) + 8 * (r >> 2)) * PITCH + l31] = acc[i][j][r];
-                const int vo = ((mrow + rrow) * out_ld + nb) * 4;
-                f32x4 ex[4];
-                if (EPI == 1) {
-#pragma unroll
-                    for (int it = 0; it < 4; it++)
-                        ex[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, vo, it * 8 * row_b, 0));
-                }
-#pragma unroll
-                for (int it = 0; it < 4; it++) {
-                    f32x4 val = *reinterpret_cast<const f32x4*>(patch + (rrow + 8 * it) * PITCH + 4 * c4);
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        float x = val[q];
-                        if (has_bias) x = x + bs4[q];
-                        if (has_bn) { x = x * sc4[q]; x = x + sh4[q]; }
-                        if (EPI == 1) x = x + ex[it][q];
-                        if (relu) x = x > 0.0f ? x : 0.0f;
-                        val[q] = x;
-                    }
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, val), rsO, vo, it * 8 * row_b, 0);
-                }
-            }
-        }
-        return;
-    }
-#pragma unroll
-    for (int j = 0; j < TN; j++) {
-        const int n = n0 + wn * TN * 32 + j * 32 + l31;
-        const bool nok = n < a.Cout;
-        const int nc = nok ? n : 0;
-        const float bs = has_bias ? a.bias[nc] : 0.0f;
-        const float sc = has_bn ? a.scale[nc] : 1.0f;
-        const float sh = has_bn ? a.shift[nc] : 0.0f;
-#pragma unroll
-        for (int i = 0; i < TM; i++) {
-            const int mbase = m0 + wm * TM * 32 + i * 32 + 4 * kh_lane;
-            float extra[16];
-            if (EPI == 1 && full_tile) {
-                const int vo = nok ? (mbase * out_ld + n) * 4 : 0x7FFF0000;
-#pragma unroll
-                for (int r = 0; r < 16; r++)
-                    extra[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsX, vo, ((r & 3) + 8 * (r >> 2)) * row_b, 0));
-            } else if (EPI == 2) {
-                const int rl = wm * TM * 32 + i * 32 + 4 * kh_lane;          // tile-local row of accumulator register 0
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const i32x4 so4 = *reinterpret_cast<const i32x4*>(s_src + rl + 8 * q);
-#pragma unroll
-                    for (int jj = 0; jj < 4; jj++)
-                        extra[4 * q + jj] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsX, so4[jj] + nc * 4, 0, 0));
-                }
-            } else if (EPI == 1) {
+            for (int i = 0; i < TM; i++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
-                    int m = mbase + (r & 3) + 8 * (r >> 2);
-                    m = m < Mlast ? m : Mlast;
-                    extra[r] = ex_v[(long long)m * out_ld + nc];
+                    const int row = wm * 64 + i * 32 + 4 * kh_lane + (r & 3) + 8 * (r >> 2);
+                    float val = acc[i][0][r];
+                    if (has_bias2) val = val + bs;
+                    if (has_bn2) { val = val * sc; val = val + sh; }
+                    if (relu2) val = val > 0.0f ? val : 0.0f;
+                    tc[(row * 2 + (hsw ^ ((row >> 3) & 1))) * 4] = val;
                 }
-            }
-            float val[16];
-#pragma unroll
-            for (int r = 0; r < 16; r++) val[r] = acc[i][j][r];
-            if (has_bias) {
-#pragma unroll
-                for (int r = 0; r < 16; r++) val[r] = val[r] + bs;
-            }
-            if (has_bn) {
-#pragma unroll
-                for (int r = 0; r < 16; r++) { val[r] = val[r] * sc; val[r] = val[r] + sh; }
-            }
-            if (EPI != 0) {
-#pragma unroll
-                for (int r = 0; r < 16; r++) val[r] = val[r] + extra[r];
-            }
-            if (relu) {
-#pragma unroll
-                for (int r = 0; r < 16; r++) val[r] = val[r] > 0.0f ? val[r] : 0.0f;
-            }
-            if (has_mask) {      // training backward: ReLU backward of the layer this data gradient flows into (wave-uniform branch)
-                float mk[16];
-                if (full_tile) {
-                    const int vo = nok ? (mbase * out_ld + n) * 4 : 0x7FFF0000;
-#pragma unroll
-                    for (int r = 0; r < 16; r++)
-                        mk[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsM, vo, ((r & 3) + 8 * (r >> 2)) * row_b, 0));
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 16; r++) {
-                        int m = mbase + (r & 3) + 8 * (r >> 2);
-                        m = m < Mlast ? m : Mlast;
-                        mk[r] = mask_v[(long long)m * out_ld + nc];
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < 16; r++) val[r] = mk[r] > 0.0f ? val[r] : 0.0f;
-            }
-            if (full_tile) {
-                const int vo = nok ? (mbase * out_ld + n) * 4 : 0x7FFF0000;
-#pragma unroll
-                for (int r = 0; r < 16; r++)
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val[r]), rsO, vo, ((r & 3) + 8 * (r >> 2)) * row_b, 0);
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int m = mbase + (r & 3) + 8 * (r >> 2);
-                    if (m < Mv && nok && !((a.exp_flags & 1) && val[r] != 12345.678f)) out_v[(long long)m * out_ld + n] = val[r];
-                }
-            }
         }
+        const int CoutPad3 = b.CoutPad;
+        const LevelSeg so3 = b.seg_out[v];
+        // conv3 operand geometry: 128 x 128 chunks, waves 2 x 2 of 64 x 64
+        int foa2[2], fob2[2];
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const int m = wm * 64 + t * 32 + l31; foa2[t] = (m * 2 + (kh_lane ^ ((m >> 3) & 1))) * 4;
+            const int n = wn * 64 + t * 32 + l31; fob2[t] = (n * 2 + (kh_lane ^ ((n >> 3) & 1))) * 4;
+        }
+        const int w_nl = tid >> 1, w_h = tid & 1;
+        const int wvoff0 = (w_nl * 8 + w_h * 4) * 4, wvoff1 = wvoff0 + CoutPad3 * 8 * 4;
+        const int ww_off0 = (w_nl * 2 + (w_h ^ ((w_nl >> 3) & 1))) * 4, ww_off1 = ww_off0 + 128 * 8;
+        for (int n0c = 0; n0c < CoutPad3; n0c += 128) {
+            const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(b.w4 + (long long)n0c * 8), 0, 0x7FFE0000, 0x00020000);
+            f32x4 wr[8];
+#pragma unroll
+            for (int kt = 0; kt < 4; kt++) {
+                wr[2 * kt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, wvoff0, kt * 2 * CoutPad3 * 8 * 4, 0));
+                wr[2 * kt + 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, wvoff1, kt * 2 * CoutPad3 * 8 * 4, 0));
+            }
+            if (n0c > 0) __syncthreads();                       // the previous chunk's fragment reads are done
+#pragma unroll
+            for (int kt = 0; kt < 4; kt++) {
+                *reinterpret_cast<f32x4*>(Wl + kt * 2048 + ww_off0) = wr[2 * kt];
+                *reinterpret_cast<f32x4*>(Wl + kt * 2048 + ww_off1) = wr[2 * kt + 1];
+            }
+            __syncthreads();                                    // T (first chunk) and this chunk's weights are in LDS
+            f32x16 acc2[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) acc2[i][j][r] = 0.0f;
+#pragma unroll
+            for (int kt = 0; kt < 4; kt++) {
+                f32x4 ga0[2], ga1[2], gb0[2], gb1[2];
+#pragma unroll
+                for (int t = 0; t < 2; t++) {
+                    ga0[t] = *reinterpret_cast<const f32x4*>(Tl + kt * TILE_A + foa2[t]);
+                    ga1[t] = *reinterpret_cast<const f32x4*>(Tl + kt * TILE_A + foa2[t] + BM * 8);
+                    gb0[t] = *reinterpret_cast<const f32x4*>(Wl + kt * 2048 + fob2[t]);
+                    gb1[t] = *reinterpret_cast<const f32x4*>(Wl + kt * 2048 + fob2[t] + 128 * 8);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+#pragma unroll
+                    for (int i = 0; i < 2; i++)
+#pragma unroll
+                        for (int j = 0; j < 2; j++) acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga0[i][q], gb0[j][q], acc2[i][j], 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+#pragma unroll
+                    for (int i = 0; i < 2; i++)
+#pragma unroll
+                        for (int j = 0; j < 2; j++) acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga1[i][q], gb1[j][q], acc2[i][j], 0, 0, 0);
+            }
+            p4_epilogue<1, false, 2, 2>(b, acc2, smem, v, so3, m0, Mv, n0c);
+        }
+    } else {
+        p4_epilogue<EPI, MASK, TM, TN>(a, acc, smem, v, so, m0, Mv, n0);
     }
 }
 
@@ -516,6 +573,9 @@ __global__ __launch_bounds__(256, 3) void conv_p4_group_kernel(const ConvGroup g
     while (i + 1 < g.n && g.blk0[i + 1] <= (int)blockIdx.x) i++;
     conv_p4_body<EPI, C4, TN, TAPS>(g.p[i], (int)blockIdx.x - g.blk0[i]);
 }
+// bottleneck conv2 + conv3 in one launch (the two problems of a ConvGroup: p[0] = conv2, p[1] = conv3); 64 KB of LDS -> 2 workgroups / CU
+__global__ __launch_bounds__(256, 2) void conv_p4_fused_kernel(const ConvGroup g) { conv_p4_body<8, false, 1, 9>(g.p[0], blockIdx.x, &g.p[1]); }
+
 // filter shape -> k-loop variant
 static inline int p4_taps(const ConvArgs& a) {
     static const int unroll_env = getenv("CALD_P4_UNROLL") ? atoi(getenv("CALD_P4_UNROLL")) : 1;      // 0: generic rolled loop everywhere
@@ -549,6 +609,21 @@ bool launch_conv_p4_group(const ConvArgs* p, int n, hipStream_t stream) {
     if (p[0].mask) P4_GROUP_T(4) else P4_GROUP_T(0)
 #undef P4_GROUP_T
 #undef P4_GROUP
+    return true;
+}
+
+// conv2 (3 x 3, stride 1, 64 -> 64, BN + ReLU) followed by conv3 (1 x 1, 64 -> 128 k channels, BN + residual + ReLU) on the same pixels:
+// returns true if the fused kernel took both (same bits as the two separate launches)
+bool launch_conv_p4_fused(const ConvArgs& c2, const ConvArgs& c3, hipStream_t stream) {
+    static const int on = getenv("CALD_P4_FUSE") ? atoi(getenv("CALD_P4_FUSE")) : 1;
+    if (!on || !c2.w4 || !c3.w4 || c2.w16 || c3.w16 || (c2.w8 && c2.i8_in) || (c3.w8 && c3.i8_in)) return false;
+    if (c2.KH != 3 || c2.KW != 3 || c2.stride != 1 || c2.pad != 1 || c2.Cin % 16 || c2.Cout != 64 || c2.CoutPad != 64 || c2.out_ld != 64) return false;
+    if (c2.residual || c2.up || c2.mask || c2.dyn_rows || c2.in_relu || p4_taps(c2) != 9) return false;
+    if (c3.KH != 1 || c3.KW != 1 || c3.stride != 1 || c3.pad != 0 || c3.Cin != 64 || c3.Kpad != 64 || c3.CoutPad % 128 || c3.Cout != c3.CoutPad) return false;
+    if (!c3.residual || c3.up || c3.mask || c3.dyn_rows || c3.in_relu || c3.in != c2.out || c3.total_mtiles != c2.total_mtiles || c3.V != c2.V) return false;
+    ConvGroup g; g.n = 2; g.blk0[0] = 0; g.p[0] = c2; g.p[1] = c3; g.p[0].exp_flags = 0; g.p[1].exp_flags = 0;
+    const unsigned grid = (unsigned)p4_grid_mtiles(c2);          // one workgroup per 128-row tile (conv2's only N tile)
+    hipLaunchKernelGGL(conv_p4_fused_kernel, dim3(grid), dim3(256), 0, stream, g);
     return true;
 }
 

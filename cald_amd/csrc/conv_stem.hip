@@ -59,24 +59,34 @@ __global__ __launch_bounds__(256, 3) void conv_stem_kernel(const ConvArgs a, con
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
     const int t_end = min(a.total_mtiles, (xcd + 1) * tiles_per_xcd);
     int v = 0;
-    for (int tile = xcd * tiles_per_xcd + idx; tile < t_end; tile += per_xcd) {
+    // the patch of tile t + 1 is fetched into registers before the MFMAs of tile t (global latency under the matrix work)
+    f32x4 px[4];
+    int vn = 0;
+    auto fetch = [&](int tile) {
+        while (vn + 1 < a.V && a.seg_out[vn + 1].tile_start <= tile) vn++;
+        const LevelSeg so = a.seg_out[vn];
+        const LevelSeg si = a.seg_in[vn];
+        const int tcols = so.W / STEM_TW, t_in = tile - so.tile_start;
+        const int tr = t_in / tcols, tc = t_in - tr * tcols;
+        const int iy0 = 2 * tr * STEM_TH - 3, ix0 = 2 * tc * STEM_TW - 3;
+        const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + si.pix_off * 4), 0, 0x7FFE0000, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int iy = iy0 + p_row[i], ix = ix0 + p_col[i];
+            const bool ok = p_row[i] >= 0 && (unsigned)iy < (unsigned)si.H && (unsigned)ix < (unsigned)si.W;
+            px[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, ok ? (iy * si.W + ix) * 16 : 0x7FFF0000, 0, 0));
+        }
+    };
+    const int t_first = xcd * tiles_per_xcd + idx;
+    if (t_first < t_end) fetch(t_first);
+    for (int tile = t_first; tile < t_end; tile += per_xcd) {
         while (v + 1 < a.V && a.seg_out[v + 1].tile_start <= tile) v++;
         const LevelSeg so = a.seg_out[v];
-        const LevelSeg si = a.seg_in[v];
-        const int Wo = so.W, Hi = si.H, Wi = si.W;
+        const int Wo = so.W;
         const int tcols = Wo / STEM_TW;
         const int t_in = tile - so.tile_start;
         const int tr = t_in / tcols, tc = t_in - tr * tcols;
         const int oy0 = tr * STEM_TH, ox0 = tc * STEM_TW;
-        const int iy0 = 2 * oy0 - 3, ix0 = 2 * ox0 - 3;
-        const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + si.pix_off * 4), 0, 0x7FFE0000, 0x00020000);
-        f32x4 px[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int iy = iy0 + p_row[i], ix = ix0 + p_col[i];
-            const bool ok = p_row[i] >= 0 && (unsigned)iy < (unsigned)Hi && (unsigned)ix < (unsigned)Wi;
-            px[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, ok ? (iy * Wi + ix) * 16 : 0x7FFF0000, 0, 0));
-        }
         __syncthreads();                       // the previous tile's fragment reads are done (first pass: weights / zero fill are in)
 #pragma unroll
         for (int i = 0; i < 4; i++)
@@ -85,6 +95,7 @@ __global__ __launch_bounds__(256, 3) void conv_stem_kernel(const ConvArgs a, con
                 d[0] = px[i][0]; d[1] = px[i][1]; d[2] = px[i][2];
             }
         __syncthreads();
+        if (tile + per_xcd < t_end) fetch(tile + per_xcd);
 
         f32x16 acc0, acc1;
 #pragma unroll

@@ -17,7 +17,7 @@ __global__ __launch_bounds__(1024) void rpn_topk_kernel(RpnArgs a) {
     __shared__ unsigned long long sel[CAP];
     __shared__ int hist[256];
     __shared__ unsigned long long s_prefix, s_mask;
-    __shared__ int s_remaining, s_cnt;
+    __shared__ int s_remaining, s_cnt, s_done;
     const int l = blockIdx.x, v = blockIdx.y, tid = threadIdx.x;
     const LevelSeg sg = a.seg[l][v];
     const int A = a.A, n = sg.H * sg.W * A;
@@ -29,7 +29,7 @@ __global__ __launch_bounds__(1024) void rpn_topk_kernel(RpnArgs a) {
         return ((unsigned long long)det_orderable(lg) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
     };
     for (int i = tid; i < CAP; i += 1024) sel[i] = 0ull;
-    if (tid == 0) { s_prefix = 0ull; s_mask = 0ull; s_remaining = k; s_cnt = 0; }
+    if (tid == 0) { s_prefix = 0ull; s_mask = 0ull; s_remaining = k; s_cnt = 0; s_done = 0; }
     __syncthreads();
     if (n > k) {
         for (int pass = 0; pass < 8; pass++) {
@@ -50,15 +50,19 @@ __global__ __launch_bounds__(1024) void rpn_topk_kernel(RpnArgs a) {
                         s_remaining = rem - cum;
                         s_prefix = prefix | ((unsigned long long)b << shift);
                         s_mask = mask | (255ull << shift);
+                        // the bucket holds exactly as many keys as are still wanted: all of them are in, and the k-th largest key is
+                        // >= this prefix with zeros below -- the remaining digits (mostly the index half of the key) need no pass
+                        if (h == rem - cum) s_done = 1;
                         break;
                     }
                     cum += h;
                 }
             }
             __syncthreads();
+            if (s_done) break;
         }
     }
-    const unsigned long long thresh = (n > k) ? s_prefix : 0ull;   // k-th largest key (keys are unique)
+    const unsigned long long thresh = (n > k) ? s_prefix : 0ull;   // lower bound of the k largest keys (keys are unique)
     for (int i = tid; i < n; i += 1024) {
         const unsigned long long key = key_of(i);
         if (key >= thresh) { const int slot = atomicAdd(&s_cnt, 1); if (slot < CAP) sel[slot] = key; }

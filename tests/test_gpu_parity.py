@@ -470,6 +470,29 @@ def test_ragged_batch_equals_batch1_and_eval_consumer(hip, small_model):
     assert n == sum(int(o["boxes"].shape[0]) for o in together)
 
 
+def test_full_batches_of_64_views_equal_small_batches_and_the_oracle(hip, oracle, small_model):
+    """A sweep step at its real width: 70 images -> a 64-view reference forward, three 64-view augmented forwards and a ragged
+    6-image step.  Every image must score exactly as in 7-image steps (whose small forwards the other tests pin to the oracle), and
+    images from the END of the 64-view batch are re-scored by the oracle directly: anything that addresses by (view index x rows),
+    e.g. the RoI-head GEMMs that treat all views' rows as one problem, breaks first for the last views of a full batch."""
+    torch = hip["torch"]
+    from cald_amd import synth, sweep
+    model, P = small_model
+    pool = synth.make_pool(70, "voc", 0, scale=0.5)
+    dev = [torch.from_numpy(im).cuda() for im in pool]
+    augs = ["flip", "cut_out", "smaller_resize"]
+    pos = list(range(70))
+    c64, k64 = sweep.sweep_device_images(model, dev, pos, augs, bp=1.3, base_seed=9, batch_images=64)
+    c7, k7 = sweep.sweep_device_images(model, dev, pos, augs, bp=1.3, base_seed=9, batch_images=7)
+    np.testing.assert_array_equal(c64, c7); np.testing.assert_array_equal(k64, k7)
+    assert (c64 > 0).sum() >= 60
+    tail = [45, 63]
+    wc, wk = oracle.get_uncertainty(P, [pool[i] for i in tail], augs, 21, bp=1.3, min_size=300, max_size=500, base_seed=9, positions=tail)
+    for j, i in enumerate(tail):
+        assert c64[i] == wc[j], (i, c64[i], wc[j])
+        np.testing.assert_array_equal(k64[i], wk[j])
+
+
 def test_full_size_properties_and_oracle_spot_check(hip, oracle):
     """BASELINE.json's full VOC sizes (600/1000): determinism, batch-size invariance and rank-count invariance of
     the sweep over 12 images, plus one image checked against the oracle bit for bit."""
