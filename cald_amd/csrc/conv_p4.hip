@@ -167,7 +167,7 @@ __device__ __forceinline__ void conv_p4_body(const ConvArgs& a, const int blk, c
     constexpr int BM = 128, BN = 64 * TN, BK = 16, TM = 2, WN = 2;
     constexpr int TILE_A = 2 * BM * 8, TILE_F = TILE_A + 2 * BN * 8;      // floats: 2048 + 2048 (TN = 2)
     constexpr int FUSE_T = 4 * TILE_A;          // floats: conv2's 128 x 64 output tile as the A operand of four k-tiles (32 KB)
-    __shared__ __attribute__((aligned(16))) float smem[FUSE ? 2 * FUSE_T : 3 * TILE_F];
+    __shared__ __attribute__((aligned(16))) float smem[FUSE ? FUSE_T + 4096 : 3 * TILE_F];      // fused: T + a 64-column weight chunk (48 KB)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -487,78 +487,98 @@ __device__ __forceinline__ void conv_p4_body(const ConvArgs& a, const int blk, c
             const int c = wn * 32 + l31;                        // conv2 output channel of this lane (TN == 1, BN == 64 == Cout)
             const float sc = a.scale ? a.scale[c] : 1.0f, sh = a.scale ? a.shift[c] : 0.0f, bs = a.bias ? a.bias[c] : 0.0f;
             const bool relu2 = a.relu != 0, has_bias2 = a.bias != nullptr, has_bn2 = a.scale != nullptr;
-            float* const tc = Tl + (c >> 4) * TILE_A + ((c >> 3) & 1) * BM * 8 + ((c & 7) >> 1);
-            const int hsw = c & 1;
+            // element (row, c) of T sits at k-tile c >> 4, kq (c >> 3) & 1, j (c & 7) >> 1, h c & 1 (XOR-swizzled with bit 3 of the row).
+            // row = R0 + 32 i + (r & 3) + 8 (r >> 2) with R0 = 64 wm + 4 kh_lane, so bit 3 of the row is bit 2 of r: two lane bases, the
+            // rest is an immediate
+            float* const tc = Tl + (c >> 4) * TILE_A + ((c >> 3) & 1) * BM * 8 + ((c & 7) >> 1) + (wm * 64 + 4 * kh_lane) * 8;
+            float* const tcb[2] = {tc + (c & 1) * 4, tc + ((c & 1) ^ 1) * 4};
 #pragma unroll
             for (int i = 0; i < TM; i++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
-                    const int row = wm * 64 + i * 32 + 4 * kh_lane + (r & 3) + 8 * (r >> 2);
                     float val = acc[i][0][r];
                     if (has_bias2) val = val + bs;
                     if (has_bn2) { val = val * sc; val = val + sh; }
                     if (relu2) val = val > 0.0f ? val : 0.0f;
-                    tc[(row * 2 + (hsw ^ ((row >> 3) & 1))) * 4] = val;
+                    tcb[(r >> 2) & 1][(i * 32 + (r & 3) + 8 * (r >> 2)) * 8] = val;
                 }
         }
         const int CoutPad3 = b.CoutPad;
         const LevelSeg so3 = b.seg_out[v];
-        // conv3 operand geometry: 128 x 128 chunks, waves 2 x 2 of 64 x 64
-        int foa2[2], fob2[2];
+        const int ld3 = b.out_ld;
+        const bool relu3 = b.relu != 0;
+        const __amdgpu_buffer_rsrc_t rsO3 = __builtin_amdgcn_make_buffer_rsrc((void*)(b.out + so3.pix_off * (long long)ld3), 0, Mv * ld3 * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsX3 = __builtin_amdgcn_make_buffer_rsrc((void*)(b.residual + so3.pix_off * (long long)ld3), 0, Mv * ld3 * 4, 0x00020000);
+        // conv3 in 64-column chunks (T 32 KB + a chunk's weights 16 KB = 48 KB of LDS: three workgroups per CU, like the plain
+        // kernels); waves 2 x 2 over the 128 x 64 chunk, 64 x 32 each.  The next chunk's weights are fetched into registers while
+        // this chunk multiplies and stores.
+        int foa2[2], fob2;
 #pragma unroll
-        for (int t = 0; t < 2; t++) {
-            const int m = wm * 64 + t * 32 + l31; foa2[t] = (m * 2 + (kh_lane ^ ((m >> 3) & 1))) * 4;
-            const int n = wn * 64 + t * 32 + l31; fob2[t] = (n * 2 + (kh_lane ^ ((n >> 3) & 1))) * 4;
-        }
-        const int w_nl = tid >> 1, w_h = tid & 1;
-        const int wvoff0 = (w_nl * 8 + w_h * 4) * 4, wvoff1 = wvoff0 + CoutPad3 * 8 * 4;
-        const int ww_off0 = (w_nl * 2 + (w_h ^ ((w_nl >> 3) & 1))) * 4, ww_off1 = ww_off0 + 128 * 8;
-        for (int n0c = 0; n0c < CoutPad3; n0c += 128) {
+        for (int t = 0; t < 2; t++) { const int m = wm * 64 + t * 32 + l31; foa2[t] = (m * 2 + (kh_lane ^ ((m >> 3) & 1))) * 4; }
+        { const int n = wn * 32 + l31; fob2 = (n * 2 + (kh_lane ^ ((n >> 3) & 1))) * 4; }
+        const int w_t = tid & 127, w_kq = tid >> 7, w_nl = w_t >> 1, w_h = w_t & 1;
+        const int wvoff = (w_kq * CoutPad3 * 8 + w_nl * 8 + w_h * 4) * 4;
+        const int ww_off = ((w_kq * 64 + w_nl) * 2 + (w_h ^ ((w_nl >> 3) & 1))) * 4;
+        f32x4 wr[4];
+        auto fetch_w = [&](int n0c) {
             const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(b.w4 + (long long)n0c * 8), 0, 0x7FFE0000, 0x00020000);
-            f32x4 wr[8];
 #pragma unroll
-            for (int kt = 0; kt < 4; kt++) {
-                wr[2 * kt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, wvoff0, kt * 2 * CoutPad3 * 8 * 4, 0));
-                wr[2 * kt + 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, wvoff1, kt * 2 * CoutPad3 * 8 * 4, 0));
-            }
+            for (int kt = 0; kt < 4; kt++)
+                wr[kt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, wvoff, kt * 2 * CoutPad3 * 8 * 4, 0));
+        };
+        fetch_w(0);
+        for (int n0c = 0; n0c < CoutPad3; n0c += 64) {
             if (n0c > 0) __syncthreads();                       // the previous chunk's fragment reads are done
 #pragma unroll
-            for (int kt = 0; kt < 4; kt++) {
-                *reinterpret_cast<f32x4*>(Wl + kt * 2048 + ww_off0) = wr[2 * kt];
-                *reinterpret_cast<f32x4*>(Wl + kt * 2048 + ww_off1) = wr[2 * kt + 1];
-            }
+            for (int kt = 0; kt < 4; kt++) *reinterpret_cast<f32x4*>(Wl + kt * 1024 + ww_off) = wr[kt];
             __syncthreads();                                    // T (first chunk) and this chunk's weights are in LDS
-            f32x16 acc2[2][2];
+            if (n0c + 64 < CoutPad3) fetch_w(n0c + 64);
+            f32x16 acc2[2][1];
 #pragma unroll
             for (int i = 0; i < 2; i++)
 #pragma unroll
-                for (int j = 0; j < 2; j++)
-#pragma unroll
-                    for (int r = 0; r < 16; r++) acc2[i][j][r] = 0.0f;
+                for (int r = 0; r < 16; r++) acc2[i][0][r] = 0.0f;
 #pragma unroll
             for (int kt = 0; kt < 4; kt++) {
-                f32x4 ga0[2], ga1[2], gb0[2], gb1[2];
+                f32x4 ga0[2], ga1[2];
 #pragma unroll
                 for (int t = 0; t < 2; t++) {
                     ga0[t] = *reinterpret_cast<const f32x4*>(Tl + kt * TILE_A + foa2[t]);
                     ga1[t] = *reinterpret_cast<const f32x4*>(Tl + kt * TILE_A + foa2[t] + BM * 8);
-                    gb0[t] = *reinterpret_cast<const f32x4*>(Wl + kt * 2048 + fob2[t]);
-                    gb1[t] = *reinterpret_cast<const f32x4*>(Wl + kt * 2048 + fob2[t] + 128 * 8);
                 }
+                const f32x4 gb0 = *reinterpret_cast<const f32x4*>(Wl + kt * 1024 + fob2);
+                const f32x4 gb1 = *reinterpret_cast<const f32x4*>(Wl + kt * 1024 + fob2 + 64 * 8);
 #pragma unroll
                 for (int q = 0; q < 4; q++)
 #pragma unroll
-                    for (int i = 0; i < 2; i++)
-#pragma unroll
-                        for (int j = 0; j < 2; j++) acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga0[i][q], gb0[j][q], acc2[i][j], 0, 0, 0);
+                    for (int i = 0; i < 2; i++) acc2[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga0[i][q], gb0[q], acc2[i][0], 0, 0, 0);
 #pragma unroll
                 for (int q = 0; q < 4; q++)
 #pragma unroll
-                    for (int i = 0; i < 2; i++)
-#pragma unroll
-                        for (int j = 0; j < 2; j++) acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga1[i][q], gb1[j][q], acc2[i][j], 0, 0, 0);
+                    for (int i = 0; i < 2; i++) acc2[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga1[i][q], gb1[q], acc2[i][0], 0, 0, 0);
             }
-            p4_epilogue<1, false, 2, 2>(b, acc2, smem, v, so3, m0, Mv, n0c);
+            // conv3's epilogue, BN -> + residual -> ReLU as in p4_epilogue<1>: the buffer resources end at the view's last valid row, so
+            // the rows of a partial tile need no per-element test (loads beyond the end return 0, stores are dropped)
+            {
+                const int n = n0c + wn * 32 + l31;
+                const float sc3 = b.scale[n], sh3 = b.shift[n];
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+                    const int vo = ((m0 + wm * 64 + i * 32 + 4 * kh_lane) * ld3 + n) * 4;
+                    float ex[16];
+#pragma unroll
+                    for (int r = 0; r < 16; r++)
+                        ex[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsX3, vo, ((r & 3) + 8 * (r >> 2)) * ld3 * 4, 0));
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        float val = acc2[i][0][r] * sc3;
+                        val = val + sh3;
+                        val = val + ex[r];
+                        if (relu3) val = val > 0.0f ? val : 0.0f;
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rsO3, vo, ((r & 3) + 8 * (r >> 2)) * ld3 * 4, 0);
+                    }
+                }
+            }
         }
     } else {
         p4_epilogue<EPI, MASK, TM, TN>(a, acc, smem, v, so, m0, Mv, n0);
@@ -573,8 +593,8 @@ __global__ __launch_bounds__(256, 3) void conv_p4_group_kernel(const ConvGroup g
     while (i + 1 < g.n && g.blk0[i + 1] <= (int)blockIdx.x) i++;
     conv_p4_body<EPI, C4, TN, TAPS>(g.p[i], (int)blockIdx.x - g.blk0[i]);
 }
-// bottleneck conv2 + conv3 in one launch (the two problems of a ConvGroup: p[0] = conv2, p[1] = conv3); 64 KB of LDS -> 2 workgroups / CU
-__global__ __launch_bounds__(256, 2) void conv_p4_fused_kernel(const ConvGroup g) { conv_p4_body<8, false, 1, 9>(g.p[0], blockIdx.x, &g.p[1]); }
+// bottleneck conv2 + conv3 in one launch (the two problems of a ConvGroup: p[0] = conv2, p[1] = conv3); 48 KB of LDS -> 3 workgroups / CU
+__global__ __launch_bounds__(256, 3) void conv_p4_fused_kernel(const ConvGroup g) { conv_p4_body<8, false, 1, 9>(g.p[0], blockIdx.x, &g.p[1]); }
 
 // filter shape -> k-loop variant
 static inline int p4_taps(const ConvArgs& a) {
@@ -619,8 +639,8 @@ bool launch_conv_p4_fused(const ConvArgs& c2, const ConvArgs& c3, hipStream_t st
     if (!on || !c2.w4 || !c3.w4 || c2.w16 || c3.w16 || (c2.w8 && c2.i8_in) || (c3.w8 && c3.i8_in)) return false;
     if (c2.KH != 3 || c2.KW != 3 || c2.stride != 1 || c2.pad != 1 || c2.Cin % 16 || c2.Cout != 64 || c2.CoutPad != 64 || c2.out_ld != 64) return false;
     if (c2.residual || c2.up || c2.mask || c2.dyn_rows || c2.in_relu || p4_taps(c2) != 9) return false;
-    if (c3.KH != 1 || c3.KW != 1 || c3.stride != 1 || c3.pad != 0 || c3.Cin != 64 || c3.Kpad != 64 || c3.CoutPad % 128 || c3.Cout != c3.CoutPad) return false;
-    if (!c3.residual || c3.up || c3.mask || c3.dyn_rows || c3.in_relu || c3.in != c2.out || c3.total_mtiles != c2.total_mtiles || c3.V != c2.V) return false;
+    if (c3.KH != 1 || c3.KW != 1 || c3.stride != 1 || c3.pad != 0 || c3.Cin != 64 || c3.Kpad != 64 || c3.CoutPad % 64 || c3.Cout != c3.CoutPad) return false;
+    if (!c3.residual || !c3.scale || c3.bias || c3.out_ld != c3.Cout || c3.up || c3.mask || c3.dyn_rows || c3.in_relu || c3.in != c2.out || c3.total_mtiles != c2.total_mtiles || c3.V != c2.V) return false;
     ConvGroup g; g.n = 2; g.blk0[0] = 0; g.p[0] = c2; g.p[1] = c3; g.p[0].exp_flags = 0; g.p[1].exp_flags = 0;
     const unsigned grid = (unsigned)p4_grid_mtiles(c2);          // one workgroup per 128-row tile (conv2's only N tile)
     hipLaunchKernelGGL(conv_p4_fused_kernel, dim3(grid), dim3(256), 0, stream, g);
