@@ -386,6 +386,11 @@ struct cald_model {
     std::vector<void*> owned;
     std::map<std::string, DebugEntry> dbg;
     BatchPlan plan; int last_V = 0;
+    // CALD_PRECISION_F16X3: activation tensors that also (or only) exist in conv_h3.hip's split form (ConvArgs::in16 / out16), keyed by
+    // the fp32 buffer of the running forward.  fp32_dead: every consumer is a conv_h3 layer -- the fp32 tensor is not written at all
+    // and the split words live in the same buffer.
+    struct SplitFmt { unsigned* s16; bool fp32_dead; };
+    std::map<const float*, SplitFmt> split;
     std::vector<ViewDesc> last_views;
     // batch-level detection buffers used by cald_sweep
     DetBuffers sweep_det; int sweep_det_views = 0;
@@ -747,6 +752,7 @@ struct FwdBufs {
     float* rpn_tl[5];
     int *cand_count, *kept_anchor, *kept_count; int cand_cap; int max_anchors; unsigned char* cand_skip;
     signed char* i8_planes; size_t i8_cap, i8_off;   // CALD_PRECISION_I8X3: digit planes of the conv input(s) being consumed
+    unsigned* Pf16[5];   // CALD_PRECISION_F16X3: split twins of the tensors that stay fp32 as well
 };
 
 static double fill_conv_args(cald_model* m, ConvArgs& a, const ConvLayer& L, const float* in, float* out, int lin, int lout, int V, bool relu,
@@ -762,6 +768,20 @@ static double fill_conv_args(cald_model* m, ConvArgs& a, const ConvLayer& L, con
     a.total_mtiles = level_tiles(m->plan, lout, V);
     a.out_ld = L.Cout; a.in_relu = in_relu ? 1 : 0; a.zeros = m->ctx->d_zeros; a.exp_flags = 0;
     a.i8_in = nullptr; a.i8_plane_stride = 0; a.w8 = nullptr; a.w8_unscale = nullptr; a.i8_rowscale = nullptr; a.mask = nullptr;
+    a.in16 = nullptr; a.out16 = nullptr;
+    if (!m->split.empty()) {
+        auto fi = m->split.find(in);
+        if (fi != m->split.end()) {
+            if (a.w16 && !in_relu) a.in16 = fi->second.s16;
+            else if (fi->second.fp32_dead) { fail(CALD_ERR_STATE, "a layer outside conv_h3 reads a tensor kept in split form only"); return -1.0; }
+        }
+        auto fo = m->split.find(out);
+        if (fo != m->split.end()) {
+            if (!a.w16) { fail(CALD_ERR_STATE, "a layer outside conv_h3 writes a tensor with a split twin"); return -1.0; }
+            a.out16 = fo->second.s16;
+            if (fo->second.fp32_dead) a.out = nullptr;
+        }
+    }
     a.wstem = nullptr;
     if (L.wstem) {       // conv_stem.hip wants every view's output to be an exact grid of 8 x 16 pixel blocks (padded sizes are multiples of 32)
         bool exact = true;
@@ -791,6 +811,7 @@ static int conv_on(cald_model* m, const ConvLayer& L, const float* in, float* ou
     ConvArgs a;
     m->i8_off = 0;
     const double flops = fill_conv_args(m, a, L, in, out, lin, lout, V, relu, residual, up, lup, dyn, in_relu);
+    if (flops < 0.0) return CALD_ERR_STATE;
     return run_conv(m->ctx, a, flops);
 }
 // Bottleneck conv2 (3 x 3) + conv3 (1 x 1 expand, + residual) of one block: ONE launch when conv_p4.hip's fused kernel covers the
@@ -828,7 +849,11 @@ static int conv_group_on(cald_model* m, const ConvSpec* sp, int n, int V) {
     ConvArgs a[CALD_MAX_GROUP];
     double flops = 0.0; int tiles = 0;
     m->i8_off = 0;
-    for (int i = 0; i < n; i++) { flops += fill_conv_args(m, a[i], *sp[i].L, sp[i].in, sp[i].out, sp[i].level, sp[i].level, V, sp[i].relu); tiles += a[i].total_mtiles; }
+    for (int i = 0; i < n; i++) {
+        const double f = fill_conv_args(m, a[i], *sp[i].L, sp[i].in, sp[i].out, sp[i].level, sp[i].level, V, sp[i].relu);
+        if (f < 0.0) return CALD_ERR_STATE;
+        flops += f; tiles += a[i].total_mtiles;
+    }
     cald_ctx* c = m->ctx;
     if (c->prof) {
         hipEvent_t e0, e1;
@@ -856,6 +881,11 @@ static void fwd_layout(cald_model* m, Bump& B, FwdBufs& F, int V) {
         F.i8_cap = 3 * (need + 4096) + (size_t)px[2] * 4 * 2 + (size_t)V * CALD_ROI_CAP * 4 + (1 << 16);
         F.i8_planes = B.get<signed char>(F.i8_cap);
     }
+    m->split.clear();
+    static const bool split_on = !(getenv("CALD_H3_S16") && atoi(getenv("CALD_H3_S16")) == 0);
+    const bool sp16 = m->cfg.precision == CALD_PRECISION_F16X3 && split_on;
+    auto both = [&](float* t, unsigned*& twin, size_t n) { if (sp16) { twin = B.get<unsigned>(n); m->split[t] = {twin, false}; } };
+    auto only = [&](float* t) { if (sp16) m->split[t] = {reinterpret_cast<unsigned*>(t), true}; };
     F.in0 = B.get<float>(px[0] * 4);
     F.c1 = B.get<float>(px[1] * 64);
     F.p1 = B.get<float>(px[2] * 64);
@@ -863,11 +893,19 @@ static void fwd_layout(cald_model* m, Bump& B, FwdBufs& F, int V) {
     F.T1 = B.get<float>(px[2] * 128); F.T2 = B.get<float>(px[2] * 64); F.D = B.get<float>(px[2] * 256);
     const int cch[4] = {256, 512, 1024, 2048};
     for (int i = 0; i < 4; i++) F.Cf[i] = B.get<float>(px[2 + i] * cch[i]);
+    // split forms (F16X3): the pooled stem output and the two inner tensors of a bottleneck feed conv_h3 layers only.  Block outputs stay
+    // fp32 only: a twin would add 4 B / element to the HBM-bound expand layers (measured: 64->256 +23 %, 128->512 +27 %, 256->1024 +22 %)
+    // for a few percent on the 1 x 1 reduce layers that read them.
+    only(F.p1); only(F.T1); only(F.T2);
     if (m->cfg.arch == CALD_ARCH_RETINANET) {
         const int K = m->cfg.num_classes, per = m->cfg.detections_per_img;
         for (int i = 0; i < 3; i++) F.inner[i] = B.get<float>(px[3 + i] * 256);
         for (int i = 0; i < 5; i++) F.Pf[i] = B.get<float>(px[3 + i] * 256);
         for (int h = 0; h < 2; h++) for (int q = 0; q < 2; q++) for (int i = 0; i < 5; i++) F.ret_t[h][q][i] = B.get<float>(px[3 + i] * 256);
+        // RetinaNet: P3..P5 and P7 feed conv_h3 layers only; P6 is also read through a ReLU by p7 (fp32 path); the tower tensors go from
+        // conv_h3 layer to conv_h3 layer.  (Laterals stay fp32: their twin cost the 1 x 1 lateral what it saved the 3 x 3 output conv.)
+        only(F.Pf[0]); only(F.Pf[1]); only(F.Pf[2]); both(F.Pf[3], F.Pf16[3], px[6] * 256); only(F.Pf[4]);
+        for (int h = 0; h < 2; h++) for (int q = 0; q < 2; q++) for (int i = 0; i < 5; i++) only(F.ret_t[h][q][i]);
         for (int i = 0; i < 5; i++) { F.cls_h[i] = B.get<float>(px[3 + i] * m->cls_out.Cout); F.reg_h[i] = B.get<float>(px[3 + i] * 36); }
         int maxa = 0;
         for (int v = 0; v < V; v++) { int t = 0; for (int l = 3; l < 8; l++) t += P.seg[l][v].H * P.seg[l][v].W * 9; if (t > maxa) maxa = t; }
@@ -885,6 +923,9 @@ static void fwd_layout(cald_model* m, Bump& B, FwdBufs& F, int V) {
     for (int i = 0; i < 4; i++) F.inner[i] = B.get<float>(px[2 + i] * 256);
     for (int i = 0; i < 5; i++) F.Pf[i] = B.get<float>(px[2 + i] * 256);
     for (int i = 0; i < 5; i++) F.rpn_tl[i] = B.get<float>(px[2 + i] * 256);
+    // Faster R-CNN: P2..P5 -> RPN conv (split form) + RoIAlign (fp32): both forms, written by the MFMA-bound 3 x 3 output convs.  P6 (a
+    // strided copy of P5) stays fp32: the grouped RPN conv splits it in its loader, as before.  Laterals stay fp32 (see RetinaNet above).
+    for (int i = 0; i < 4; i++) both(F.Pf[i], F.Pf16[i], px[2 + i] * 256);
     for (int i = 0; i < 5; i++) F.rpn_h[i] = B.get<float>(px[2 + i] * 15);
     const int pre = m->cfg.rpn_pre_nms_top_n;
     F.cand_key = B.get<unsigned long long>((size_t)V * 5 * pre);
@@ -898,6 +939,7 @@ static void fwd_layout(cald_model* m, Bump& B, FwdBufs& F, int V) {
     F.roi = B.get<float>((size_t)V * CALD_ROI_CAP * 12544);
     F.f6 = B.get<float>((size_t)V * CALD_ROI_CAP * 1024);
     F.f7 = B.get<float>((size_t)V * CALD_ROI_CAP * 1024);
+    only(F.roi); only(F.f6); only(F.f7);           // RoIAlign -> fc6 -> fc7 -> predictor: conv_h3 layers all the way
     F.pr = B.get<float>((size_t)V * CALD_ROI_CAP * m->pred.Cout);
     F.prob = B.get<float>((size_t)V * CALD_ROI_CAP * m->cfg.num_classes);
     F.pmax = B.get<float>((size_t)V * CALD_ROI_CAP);
@@ -954,7 +996,7 @@ static int forward_model(cald_model* m, int V, ViewDesc* views, const DetBuffers
     m->dbg["input"] = {F.in0, 0, 4, 0};
     if ((rc = conv_on(m, m->conv1, F.in0, F.c1, 0, 1, V, true))) return rc;
     m->dbg["conv1"] = {F.c1, 1, 64, 0};
-    launch_maxpool(F.c1, F.p1, dp->seg[1], dp->seg[2], 64, V, max_pix2, st);
+    launch_maxpool(F.c1, F.p1, dp->seg[1], dp->seg[2], 64, V, max_pix2, st, m->split.count(F.p1) != 0);
     m->dbg["pool1"] = {F.p1, 2, 64, 0};
     const float* cur = F.p1; int lvl = 2, layer = 0, xi = 0;
     for (size_t b = 0; b < m->blocks.size(); b++) {
@@ -1053,6 +1095,7 @@ static int forward_model(cald_model* m, int V, ViewDesc* views, const DetBuffers
     RoiArgs ro;
     for (int i = 0; i < 4; i++) { ro.feat[i] = F.Pf[i]; ro.seg[i] = dp->seg[2 + i]; }
     ro.C = 256; ro.V = V; ro.proposals = F.proposals; ro.prop_count = F.prop_count; ro.out = F.roi; ro.order = F.roi_order;
+    ro.out16 = m->split.count(F.roi) ? 1 : 0;
     launch_roi_align(ro, st);
     m->dbg["roi"] = {F.roi, 7, 12544, 1};
     const double fl_before_roi = c->prof_flops;

@@ -61,6 +61,11 @@ struct ConvArgs {
     // conv_stem.hip: the 7 x 7 / 2 stem's weights packed [20 quads of k-pairs][2 h][64 n][4] over the 154-slot chain (7 filter rows x
     // (21 (kw, c) taps + 1 zero slot)); set only when every view's output is an exact grid of 8 x 16 blocks, else null
     const float* wstem;
+    // CALD_PRECISION_F16X3 only (conv_h3.hip): the split form of an activation tensor, element for element beside (or instead of) the
+    // fp32 one: one 32-bit word per element = fp16 hi | fp16 lo << 16 of 16 x (the kernel's operand scale).  A producer that writes it
+    // (out16; `out` may then be null) saves every consumer (in16) the split arithmetic in its k-loop.  Null = fp32 only.
+    const unsigned* in16;
+    unsigned* out16;
 };
 
 // Several independent conv problems in ONE launch (the five FPN levels under the shared-weight RPN / RetinaNet heads, the
@@ -173,6 +178,20 @@ __host__ __device__ inline void det_sincosf(float x, float* s, float* c) {
 }
 __host__ __device__ inline float det_log2f(float x) { return det_logf(x) * 1.44269504f; }
 __host__ __device__ inline float det_sigmoidf(float x) { return 1.0f / (1.0f + det_expf(-x)); }
+
+#ifdef __HIPCC__
+// The split of one activation: 16 x = hi + lo (+ 2^-22 relative); the word a producer stores for its consumers (ConvArgs::out16).
+// The same two conversions the loader performs on an fp32 input, so a pre-split tensor gives bit-identical products.
+__device__ __forceinline__ unsigned split16_word(const float x) {
+    const float s = x * 16.0f;
+    const _Float16 hi = (_Float16)s;
+    const _Float16 lo = (_Float16)(s - (float)hi);
+    return (unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
+}
+__device__ __forceinline__ uint4 split16_word4(const float4 v) {
+    return make_uint4(split16_word(v.x), split16_word(v.y), split16_word(v.z), split16_word(v.w));
+}
+#endif
 
 #define BBOX_XFORM_CLIP_F 4.135166556742356f  /* (float)math.log(1000/16) */
 

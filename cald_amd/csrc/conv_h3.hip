@@ -60,7 +60,9 @@ __device__ __forceinline__ void conv_h3_body(const ConvArgs& a, const int blk) {
     if (a.dyn_rows) { const int d = a.dyn_rows[v]; Mv = d < Mv ? d : Mv; }
     const int m0 = (mt - so.tile_start) * BM;
     if (m0 >= Mv) return;
-    const float* __restrict__ in_v = a.in + si.pix_off * (long long)a.Cin;
+    // pre-split input (one word per element, same indexing as fp32): the loader fetches the same offsets from the other tensor
+    const bool in16 = !C4 && a.in16 != nullptr;
+    const float* __restrict__ in_v = (in16 ? reinterpret_cast<const float*>(a.in16) : a.in) + si.pix_off * (long long)a.Cin;
     const int Cin = a.Cin, KW = a.KW, KH = a.KH, CoutPad = a.CoutPad;
     const bool in_relu = a.in_relu != 0;
 
@@ -138,6 +140,19 @@ __device__ __forceinline__ void conv_h3_body(const ConvArgs& a, const int blk) {
             _Pragma("unroll") for (int q = 0; q < 4; q++) { ra0[q] = ra0[q] < 0.f ? 0.f : ra0[q]; ra1[q] = ra1[q] < 0.f ? 0.f : ra1[q]; } \
         }                                                                                                  \
         unsigned char* tb = smem + (BUF) * TILE_B;                                                         \
+        if (in16) {   /* words {hi, lo} of four consecutive channels -> the hi quad and the lo quad: four byte permutes */ \
+            const i32x4 w0 = __builtin_bit_cast(i32x4, ra0), w1 = __builtin_bit_cast(i32x4, ra1);          \
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));                                    \
+            u32x2 hi0, lo0, hi1, lo1;                                                                      \
+            hi0[0] = __builtin_amdgcn_perm(w0[1], w0[0], 0x05040100u); hi0[1] = __builtin_amdgcn_perm(w0[3], w0[2], 0x05040100u); \
+            lo0[0] = __builtin_amdgcn_perm(w0[1], w0[0], 0x07060302u); lo0[1] = __builtin_amdgcn_perm(w0[3], w0[2], 0x07060302u); \
+            hi1[0] = __builtin_amdgcn_perm(w1[1], w1[0], 0x05040100u); hi1[1] = __builtin_amdgcn_perm(w1[3], w1[2], 0x05040100u); \
+            lo1[0] = __builtin_amdgcn_perm(w1[1], w1[0], 0x07060302u); lo1[1] = __builtin_amdgcn_perm(w1[3], w1[2], 0x07060302u); \
+            *reinterpret_cast<u32x2*>(tb + aw_off[0]) = hi0;                                               \
+            *reinterpret_cast<u32x2*>(tb + PLANE + aw_off[0]) = lo0;                                       \
+            *reinterpret_cast<u32x2*>(tb + aw_off[1]) = hi1;                                               \
+            *reinterpret_cast<u32x2*>(tb + PLANE + aw_off[1]) = lo1;                                       \
+        } else {                                                                                           \
         ra0 = ra0 * 16.0f; ra1 = ra1 * 16.0f;                                                              \
         const h4 hi0 = __builtin_convertvector(ra0, h4), hi1 = __builtin_convertvector(ra1, h4);           \
         const h4 lo0 = __builtin_convertvector(ra0 - __builtin_convertvector(hi0, f32x4), h4);             \
@@ -146,6 +161,7 @@ __device__ __forceinline__ void conv_h3_body(const ConvArgs& a, const int blk) {
         *reinterpret_cast<h4*>(tb + PLANE + aw_off[0]) = lo0;                                              \
         *reinterpret_cast<h4*>(tb + aw_off[1]) = hi1;                                                      \
         *reinterpret_cast<h4*>(tb + PLANE + aw_off[1]) = lo1;                                              \
+        }                                                                                                  \
         *reinterpret_cast<i32x4*>(tb + bw_off0) = rb0;                                                     \
         if (TN == 2) *reinterpret_cast<i32x4*>(tb + bw_off1) = rb1;                                        \
     }
@@ -220,7 +236,8 @@ __device__ __forceinline__ void conv_h3_body(const ConvArgs& a, const int blk) {
 
     // ---- fused fp32 epilogue: the same operations as conv_p4.hip ----
     const int out_ld = a.out_ld;
-    float* __restrict__ out_v = a.out + so.pix_off * (long long)out_ld;
+    float* __restrict__ out_v = a.out ? a.out + so.pix_off * (long long)out_ld : nullptr;
+    unsigned* __restrict__ out16_v = a.out16 ? a.out16 + so.pix_off * (long long)out_ld : nullptr;
     const float* __restrict__ ex_v = nullptr;
     int upH = 1, upW = 1;
     float uph_s = 0.f, upw_s = 0.f;
@@ -270,7 +287,10 @@ __device__ __forceinline__ void conv_h3_body(const ConvArgs& a, const int blk) {
                 val = val + sh;
                 if (EPI != 0) val = val + extra[r];
                 if (relu) val = val > 0.0f ? val : 0.0f;
-                if (m < Mv && nok) out_v[(long long)m * out_ld + n] = val;
+                if (m < Mv && nok) {
+                    if (out_v) out_v[(long long)m * out_ld + n] = val;
+                    if (out16_v) out16_v[(long long)m * out_ld + n] = split16_word(val);
+                }
             }
         }
     }

@@ -123,7 +123,8 @@ void launch_pil_vertical(const uint8_t* src, int H, int W, uint8_t* dst, int oh,
 // max_pool2d(3, 2, 1) NHWC, C % 4 == 0; grid = (ceil(maxHo*maxWo*C/4/256), V)
 // ---------------------------------------------------------------------------------------------
 __device__ inline float nanmax(float m, float v) { return (v > m || v != v) ? v : m; }
-__global__ __launch_bounds__(256) void maxpool_kernel(const float* in, float* out, const LevelSeg* sin, const LevelSeg* sout, int C) {
+// out16 != 0: the pooled tensor is stored in the split form conv_h3.hip consumes (one word per element, ConvArgs::in16) instead of fp32
+__global__ __launch_bounds__(256) void maxpool_kernel(const float* in, float* out, const LevelSeg* sin, const LevelSeg* sout, int C, int out16) {
     const int v = blockIdx.y;
     const LevelSeg si = sin[v], so = sout[v];
     const int C4 = C >> 2;
@@ -143,12 +144,13 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const float* in, float* ou
             const float4 t = ip[(long long)(iy * si.W + ix) * C4 + c4];
             m.x = nanmax(m.x, t.x); m.y = nanmax(m.y, t.y); m.z = nanmax(m.z, t.z); m.w = nanmax(m.w, t.w);
         }
-    reinterpret_cast<float4*>(out + so.pix_off * C)[e] = m;
+    if (out16) reinterpret_cast<uint4*>(out + so.pix_off * C)[e] = split16_word4(m);
+    else reinterpret_cast<float4*>(out + so.pix_off * C)[e] = m;
 }
 void launch_maxpool(const float* in, float* out, const LevelSeg* sin, const LevelSeg* sout, int C, int V, int max_out_pix,
-                    hipStream_t st) {
+                    hipStream_t st, bool out16) {
     dim3 grid((unsigned)(((long long)max_out_pix * (C / 4) + 255) / 256), V);
-    hipLaunchKernelGGL(maxpool_kernel, grid, dim3(256), 0, st, in, out, sin, sout, C);
+    hipLaunchKernelGGL(maxpool_kernel, grid, dim3(256), 0, st, in, out, sin, sout, C, out16 ? 1 : 0);
 }
 
 // LastLevelMaxPool = max_pool2d(x, 1, 2, 0): every second pixel of P5.

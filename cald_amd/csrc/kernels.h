@@ -31,7 +31,8 @@ struct DetBuffers {
 void launch_preprocess(const ViewDesc* views, const LevelSeg* seg0, float* out, int V, int max_pix, hipStream_t st);
 void launch_pil_horizontal(const uint8_t* src, int H, int W, uint8_t* dst, int ow, const int* bounds, const int* kk, int ksize, hipStream_t st);
 void launch_pil_vertical(const uint8_t* src, int H, int W, uint8_t* dst, int oh, const int* bounds, const int* kk, int ksize, hipStream_t st);
-void launch_maxpool(const float* in, float* out, const LevelSeg* sin, const LevelSeg* sout, int C, int V, int max_out_pix, hipStream_t st);
+void launch_maxpool(const float* in, float* out, const LevelSeg* sin, const LevelSeg* sout, int C, int V, int max_out_pix, hipStream_t st,
+                    bool out16 = false);   // out16: store the split form of conv_h3.hip (same buffer, one word per element)
 void launch_subsample2(const float* in, float* out, const LevelSeg* sin, const LevelSeg* sout, int C, int V, int max_out_pix, hipStream_t st);
 
 void launch_affine_nearest(const uint8_t* src, int H, int W, uint8_t* dst, int oh, int ow, const int* a, hipStream_t st);
@@ -75,6 +76,7 @@ struct RoiArgs {
     const int* prop_count;   // [V]
     float* out;              // [V][ROI_CAP][49][C]
     int* order;              // [V][1024] scratch: the view's RoIs sorted by (pyramid level, row band, column) -- processing order only
+    int out16;               // CALD_PRECISION_F16X3: store the split form conv_h3.hip consumes (one word per element) instead of fp32
 };
 void launch_roi_align(const RoiArgs& a, hipStream_t st);
 

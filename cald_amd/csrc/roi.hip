@@ -85,7 +85,9 @@ __global__ __launch_bounds__(256) void roi_align_kernel(RoiArgs a) {
                 acc.w = acc.w + (((w1 * v1.w + w2 * v2.w) + w3 * v3.w) + w4 * v4.w);
             }
         }
-        out[idx] = make_float4(acc.x / 4.0f, acc.y / 4.0f, acc.z / 4.0f, acc.w / 4.0f);
+        const float4 res = make_float4(acc.x / 4.0f, acc.y / 4.0f, acc.z / 4.0f, acc.w / 4.0f);
+        if (a.out16) reinterpret_cast<uint4*>(out)[idx] = split16_word4(res);
+        else out[idx] = res;
     }
 }
 void launch_roi_align(const RoiArgs& a, hipStream_t st) {

@@ -391,6 +391,27 @@ def test_f16x3_mode_close_to_exact_on_96_images(hip):
         np.abs(ce - ch).max(), np.median(np.abs(le - lh)[le > 0]), np.abs(le - lh).max()))
 
 
+@pytest.mark.parametrize("arch", ["frcnn", "retinanet"])
+def test_f16x3_split_producers_equal_the_in_kernel_split(hip, tmp_path, arch):
+    """f16x3: producers (conv_h3 epilogues, maxpool, RoIAlign) store the split (hi, lo) words their consumers multiply, instead of every
+    consumer splitting fp32 in its k-loop.  It is the same two conversions of the same value, so the sweep's scores must not move by
+    a single bit against CALD_H3_S16=0 (the in-kernel split)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for flag in ("1", "0"):
+        out = str(tmp_path / ("s16_%s.npz" % flag))
+        env = dict(os.environ, CALD_H3_S16=flag)
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "_h3_split_probe.py"), out, root, arch], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(out))
+    np.testing.assert_array_equal(outs[0]["cons"], outs[1]["cons"])
+    np.testing.assert_array_equal(outs[0]["cls"], outs[1]["cls"])
+    assert (outs[0]["cons"] > 0).sum() >= 15
+
+
 def test_f16x3_mode_retinanet_close_to_exact(hip):
     """The split-fp16 mode on the other detector (RetinaNet towers, sigmoid scores, class-grouped output)."""
     torch = hip["torch"]
