@@ -10,8 +10,9 @@
 //   * A workgroup owns an 8 x 16 block of output pixels (the padded sizes are multiples of 32, so every view splits exactly).  Its
 //     21 x 37 input patch is staged ONCE in LDS, three channels packed (12 bytes per pixel): for an output pixel the 21 taps of a
 //     filter row are then 21 CONSECUTIVE floats, and the A fragment of k-pair jj is one ds_read_b32 at base + immediate
-//     (base = patch + ((2 ty) * pitch + 2 tx * 3 + h) * 4: no address arithmetic in the loop, no tap validity logic at all -- pixels
-//     outside the image are zeros in the patch).
+//     (base = patch + (row(2 ty) + 2 tx * 3 + h) * 4: no address arithmetic in the loop, no tap validity logic at all -- pixels
+//     outside the image are zeros in the patch).  Patch rows are laid out in pairs of 225 floats (STEM_PAIR): the two tile rows a
+//     wave's 32 lanes read are then one bank apart and the stride-6 column reads are conflict-free.
 //   * The weights [20 quads][2 h][64 n][4] (40 KB) are LDS-resident for the whole life of the workgroup, which walks several
 //     tiles (persistent grid of 3 workgroups per CU); a B fragment read is one ds_read_b128 per four k-pairs.
 //   * No k-loop over global memory: per tile one patch load (9.3 KB), 2 x 77 MFMAs per wave, the epilogue.
@@ -26,11 +27,14 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 #define STEM_PR (2 * STEM_TH + 5)      // 21 patch rows
 #define STEM_PC (2 * STEM_TW + 5)      // 37 patch columns
 #define STEM_PITCH 112                 // floats per patch row: 37 * 3 = 111 + the slot the zero-weight tap of the last pixel reads
+#define STEM_PAIR 225                  // floats per PAIR of patch rows (2 * 112 + 1): the two tile rows a wave's 32 lanes cover are two patch
+                                       // rows apart = 225 floats = 1 (mod 32 banks), so their stride-6 column reads use the odd banks
+#define STEM_ROW(r) (((r) >> 1) * STEM_PAIR + ((r) & 1) * STEM_PITCH)
 #define STEM_WFLOATS (20 * 2 * 64 * 4)
 
 __global__ __launch_bounds__(256, 3) void conv_stem_kernel(const ConvArgs a, const float* __restrict__ wstem, const int tiles_per_xcd) {
     __shared__ __attribute__((aligned(16))) float s_w[STEM_WFLOATS];
-    __shared__ __attribute__((aligned(16))) float s_patch[STEM_PR * STEM_PITCH];
+    __shared__ __attribute__((aligned(16))) float s_patch[((STEM_PR + 1) / 2) * STEM_PAIR];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
 
@@ -38,7 +42,7 @@ __global__ __launch_bounds__(256, 3) void conv_stem_kernel(const ConvArgs a, con
 #pragma unroll
     for (int i = 0; i < STEM_WFLOATS / 4 / 256; i++)
         reinterpret_cast<f32x4*>(s_w)[tid + 256 * i] = reinterpret_cast<const f32x4*>(wstem)[tid + 256 * i];
-    for (int i = tid; i < STEM_PR * STEM_PITCH; i += 256) s_patch[i] = 0.0f;     // incl. float 111 of every row, never written again
+    for (int i = tid; i < ((STEM_PR + 1) / 2) * STEM_PAIR; i += 256) s_patch[i] = 0.0f;   // incl. float 111 of every row, never written again
 
     // patch pixels this thread stages: p = tid + 256 i  ->  (row, column)
     int p_row[4], p_col[4];
@@ -50,7 +54,7 @@ __global__ __launch_bounds__(256, 3) void conv_stem_kernel(const ConvArgs a, con
     }
     // fragment addresses
     const int m_l = wave * 32 + l31, ty = m_l >> 4, tx = m_l & 15;
-    const float* const fa = s_patch + (2 * ty) * STEM_PITCH + 6 * tx + h;
+    const float* const fa = s_patch + ty * STEM_PAIR + 6 * tx + h;            // patch row 2 ty
     const float* const fb0 = s_w + (h * 64 + l31) * 4;
     const float* const fb1 = fb0 + 32 * 4;
     const float sc0 = a.scale[l31], sh0 = a.shift[l31], sc1 = a.scale[32 + l31], sh1 = a.shift[32 + l31];
@@ -91,7 +95,7 @@ __global__ __launch_bounds__(256, 3) void conv_stem_kernel(const ConvArgs a, con
 #pragma unroll
         for (int i = 0; i < 4; i++)
             if (p_row[i] >= 0) {
-                float* d = s_patch + p_row[i] * STEM_PITCH + 3 * p_col[i];
+                float* d = s_patch + STEM_ROW(p_row[i]) + 3 * p_col[i];
                 d[0] = px[i][0]; d[1] = px[i][1]; d[2] = px[i][2];
             }
         __syncthreads();
@@ -110,7 +114,7 @@ __global__ __launch_bounds__(256, 3) void conv_stem_kernel(const ConvArgs a, con
                 const int j = 4 * q + e;
                 if (j < 77) {
                     const int kh = j / 11, jj = j - kh * 11;
-                    const float av = fa[kh * STEM_PITCH + 2 * jj];
+                    const float av = fa[STEM_ROW(kh) + 2 * jj];
                     acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0[e], acc0, 0, 0, 0);
                     acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1[e], acc1, 0, 0, 0);
                 }

@@ -4,7 +4,7 @@ against rocprofv3's kernel-trace duration of the very same launches.
 
     rocprofv3 --kernel-trace --output-format csv -d DIR -- env CALD_PROFILE_DUMP=launches.csv python bench.py --steps 2 \
         --warmup 1 --no-cpu-baseline --no-full-pool --no-f16x3 --no-train
-    python tools/event_vs_trace.py launches.csv DIR out.json
+    python tools/event_vs_trace.py launches.csv DIR out.json        (tools/profile_event_vs_trace.sh runs both on the GPU box)
 
 The timed region is the last thing that launches GEMM kernels in that command, so the last len(csv) GEMM dispatches of the
 trace are the csv's rows, in order (a grouped launch is one dispatch)."""
@@ -23,10 +23,7 @@ def main():
     f = glob.glob(os.path.join(trace_dir, "**", "*kernel_trace.csv"), recursive=True)[0]
     tr = [r for r in csv.DictReader(open(f)) if any(t in r["Kernel_Name"] for t in ("conv_p4", "conv_mfma", "conv_stem", "conv_fused"))]
     tr.sort(key=lambda r: int(r["Start_Timestamp"]))
-    # an event region of a grouped launch holds ONE dispatch when the grouped kernel took it, else one dispatch per problem
-    def width(e, first_name):
-        m = re.search(r"group=(\d+)", e["desc"])
-        return 1 if (not m or "group_kernel" in first_name) else int(m.group(1))
+    # an event region of a grouped launch holds ONE dispatch when the grouped kernel took it, else one dispatch per problem;
     # walk backwards from the end of the trace: the last event row ends at the last GEMM dispatch
     pos = len(tr)
     spans = []

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): same-run HIP-event vs kernel-trace comparison of the GEMM launches (tools/event_vs_trace.py),
-# then the usual stats + PMC passes (tools/profile_gpu.sh).  Usage: tools/profile_r3.sh <tag>
+# Usage: tools/profile_event_vs_trace.sh <tag>   (tools/profile_gpu.sh <tag> takes the stats + PMC passes)
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=$1
