@@ -51,6 +51,13 @@ static int dense_seg(cald_ctx* c, int N, int H, int W, const LevelSeg** out) {
     auto key = std::make_tuple(c, N, H, W);
     auto it = g_seg.find(key);
     if (it == g_seg.end()) {
+        if (g_seg.size() >= 1024) {
+            // bound the cache (a long run over variable padded sizes x pyramid levels x contexts would otherwise keep allocating): drop
+            // everything once the launches that may still read a table have drained -- a rare, synchronous event
+            THIP(hipDeviceSynchronize());
+            for (auto& kv : g_seg) hipFree(kv.second);
+            g_seg.clear();
+        }
         std::vector<LevelSeg> h(N + 1);
         const int tiles = (H * W + 127) / 128;
         for (int v = 0; v <= N; v++) { h[v].pix_off = (long long)v * H * W; h[v].H = H; h[v].W = W; h[v].tile_start = v * tiles; h[v].pad_ = 0; }
