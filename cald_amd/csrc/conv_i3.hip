@@ -238,59 +238,71 @@ __device__ __forceinline__ void conv_i3_body(const ConvArgs& a, const int blk) {
     _Pragma("unroll") for (int i = 0; i < TM; i++) ACC[i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(FA[i], FB, ACC[i], 0, 0, 0);
 #define I3_MFMA0(ACC, FA, FB)      /* first product of a tap into this accumulator set: starts from zero */  \
     _Pragma("unroll") for (int i = 0; i < TM; i++) ACC[i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(FA[i], FB, zero16, 0, 0, 0);
-    int cur = 0, c_cc = 0, c_tap = 0;           // the tile being computed: (tap c_tap, chunk c_cc)
-    for (int kt = 0; kt < KT; kt++) {
-        const unsigned char* tc = smem + cur * TILE_B;
-        const bool has1 = kt + 1 < KT, has2 = kt + 2 < KT;
-        i32x4 a0[TM], a1[TM], a2[TM], b0, b1, b2;
-#pragma unroll
-        for (int t = 0; t < TM; t++) {
-            a2[t] = *reinterpret_cast<const i32x4*>(tc + 2 * PLANE_A + fo_a[t]);
-            a1[t] = *reinterpret_cast<const i32x4*>(tc + PLANE_A + fo_a[t]);
-            a0[t] = *reinterpret_cast<const i32x4*>(tc + fo_a[t]);
-        }
-        b2 = *reinterpret_cast<const i32x4*>(tc + 2 * PLANE_B + fo_b);
-        b1 = *reinterpret_cast<const i32x4*>(tc + PLANE_B + fo_b);
-        b0 = *reinterpret_cast<const i32x4*>(tc + fo_b);
-        if (c_cc == 0) {
-            I3_MFMA0(acc2, a2, b2)
-            I3_MFMA0(acc1, a2, b1)
-            if (has1) I3_STORE(cur ^ 1)
-            I3_MFMA(acc1, a1, b2)
-            I3_MFMA0(acc0, a2, b0)
-        } else {
-            I3_MFMA(acc2, a2, b2)
-            I3_MFMA(acc1, a2, b1)
-            if (has1) I3_STORE(cur ^ 1)
-            I3_MFMA(acc1, a1, b2)
-            I3_MFMA(acc0, a2, b0)
-        }
-        if (has2) I3_LOAD()
-        I3_MFMA(acc0, a0, b2)
-        I3_MFMA(acc0, a1, b1)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        cur ^= 1;
-        if (++c_cc == CC) {
-            // the tap is complete: fold its exact integer sums into the float accumulators with the per-row scales
-            const float* sp = s_scale[c_tap & 1];
-#pragma unroll
-            for (int i = 0; i < TM; i++) {
-                const int rb = wm * 64 + i * 32 + 4 * kh_lane;
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const f32x4 s4 = *reinterpret_cast<const f32x4*>(sp + rb + 8 * q);
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const int r = 4 * q + j;
-                        const float T = fmaf((float)acc2[i][r], 65536.0f, fmaf((float)acc1[i][r], 256.0f, (float)acc0[i][r]));
-                        accf[i][r] = fmaf(T, s4[j], accf[i][r]);
-                    }
-                }
-            }
-            c_cc = 0; c_tap++;
-        }
+    int cur = 0, c_cc = 0, c_tap = 0, kt = 0;   // the tile being computed: (tap c_tap, chunk c_cc)
+    // Fragments of tile kt + 1 are read right after the barrier of tile kt, under its last MFMA group and the tap fold, instead of at
+    // the top of the next iteration (where every wave of the workgroup waited out the LDS latency together); two fragment sets, the
+    // loop unrolled by two so that no register is copied.
+#define I3_READ(A0, A1, A2, B0, B1, B2, TB)                                                                \
+    {                                                                                                      \
+        _Pragma("unroll") for (int t = 0; t < TM; t++) {                                                   \
+            A2[t] = *reinterpret_cast<const i32x4*>((TB) + 2 * PLANE_A + fo_a[t]);                         \
+            A1[t] = *reinterpret_cast<const i32x4*>((TB) + PLANE_A + fo_a[t]);                             \
+            A0[t] = *reinterpret_cast<const i32x4*>((TB) + fo_a[t]);                                       \
+        }                                                                                                  \
+        B2 = *reinterpret_cast<const i32x4*>((TB) + 2 * PLANE_B + fo_b);                                   \
+        B1 = *reinterpret_cast<const i32x4*>((TB) + PLANE_B + fo_b);                                       \
+        B0 = *reinterpret_cast<const i32x4*>((TB) + fo_b);                                                 \
     }
+#define I3_TILE(A0, A1, A2, B0, B1, B2, NA0, NA1, NA2, NB0, NB1, NB2)                                      \
+    {                                                                                                      \
+        const bool has1 = kt + 1 < KT, has2 = kt + 2 < KT;                                                 \
+        if (c_cc == 0) {                                                                                   \
+            I3_MFMA0(acc2, A2, B2)                                                                         \
+            I3_MFMA0(acc1, A2, B1)                                                                         \
+            if (has1) I3_STORE(cur ^ 1)                                                                    \
+            I3_MFMA(acc1, A1, B2)                                                                          \
+            I3_MFMA0(acc0, A2, B0)                                                                         \
+        } else {                                                                                           \
+            I3_MFMA(acc2, A2, B2)                                                                          \
+            I3_MFMA(acc1, A2, B1)                                                                          \
+            if (has1) I3_STORE(cur ^ 1)                                                                    \
+            I3_MFMA(acc1, A1, B2)                                                                          \
+            I3_MFMA(acc0, A2, B0)                                                                          \
+        }                                                                                                  \
+        if (has2) I3_LOAD()                                                                                \
+        I3_MFMA(acc0, A0, B2)                                                                              \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                 \
+        __builtin_amdgcn_s_barrier();                                                                      \
+        cur ^= 1;                                                                                          \
+        if (has1) I3_READ(NA0, NA1, NA2, NB0, NB1, NB2, smem + cur * TILE_B)                               \
+        I3_MFMA(acc0, A1, B1)                                                                              \
+        if (++c_cc == CC) {                                                                                \
+            /* the tap is complete: fold its exact integer sums into the float accumulators with the per-row scales */ \
+            const float* sp = s_scale[c_tap & 1];                                                          \
+            _Pragma("unroll") for (int i = 0; i < TM; i++) {                                               \
+                const int rb = wm * 64 + i * 32 + 4 * kh_lane;                                             \
+                _Pragma("unroll") for (int q = 0; q < 4; q++) {                                            \
+                    const f32x4 s4 = *reinterpret_cast<const f32x4*>(sp + rb + 8 * q);                     \
+                    _Pragma("unroll") for (int j = 0; j < 4; j++) {                                        \
+                        const int r = 4 * q + j;                                                           \
+                        const float T = fmaf((float)acc2[i][r], 65536.0f, fmaf((float)acc1[i][r], 256.0f, (float)acc0[i][r])); \
+                        accf[i][r] = fmaf(T, s4[j], accf[i][r]);                                           \
+                    }                                                                                      \
+                }                                                                                          \
+            }                                                                                              \
+            c_cc = 0; c_tap++;                                                                             \
+        }                                                                                                  \
+        kt++;                                                                                              \
+    }
+    i32x4 fa0[TM], fa1[TM], fa2[TM], fb0, fb1, fb2, ga0[TM], ga1[TM], ga2[TM], gb0, gb1, gb2;
+    I3_READ(fa0, fa1, fa2, fb0, fb1, fb2, smem)
+    while (kt + 1 < KT) {
+        I3_TILE(fa0, fa1, fa2, fb0, fb1, fb2, ga0, ga1, ga2, gb0, gb1, gb2)
+        I3_TILE(ga0, ga1, ga2, gb0, gb1, gb2, fa0, fa1, fa2, fb0, fb1, fb2)
+    }
+    if (kt < KT) I3_TILE(fa0, fa1, fa2, fb0, fb1, fb2, ga0, ga1, ga2, gb0, gb1, gb2)
+#undef I3_READ
+#undef I3_TILE
 #undef I3_LOAD
 #undef I3_STORE
 #undef I3_MFMA
