@@ -1578,10 +1578,14 @@ extern "C" int cald_sweep(cald_model* m, int n_images, const uint8_t* const* ima
             launch_noise_stream(d_jobs, (int)jobs.size(), c->stream);
         }
         if (rc) break;
-        // ---- phase 2: augmented views in forwards of <= 64 views, evenly sized (159 views run as 53 + 53 + 53, not 64 + 64 + 31:
+        // ---- phase 2: augmented views in forwards of <= fwd_views views, evenly sized (159 views run as 80 + 79, not 96 + 63:
         // a short last forward leaves most of its launches under-filled; results do not depend on the split) ----
         const int na = (int)aviews.size();
-        const int n_fw = (na + CALD_MAX_VIEWS - 1) / CALD_MAX_VIEWS;
+        // 96 views per augmented forward: the mid-size layers and fc6 then fill whole rounds of the 768 workgroup slots (fc6 6 000
+        // workgroups = 7.8 rounds, layer-3 3 x 3 3 042 = 3.96) where 64 views leave 5.2 / 2.6 -- measured +1.0 % on the sweep
+        static const int fwd_views_env = getenv("CALD_FWD_VIEWS") ? atoi(getenv("CALD_FWD_VIEWS")) : 96;
+        const int fwd_views = fwd_views_env < 1 ? 1 : (fwd_views_env > CALD_MAX_VIEWS ? CALD_MAX_VIEWS : fwd_views_env);
+        const int n_fw = (na + fwd_views - 1) / fwd_views;
         for (int f = 0; f < n_fw && !rc; f++) {
             const int a0 = (int)(((long long)na * f) / n_fw), nv = (int)(((long long)na * (f + 1)) / n_fw) - a0;
             DetBuffers d2 = D; const size_t o = (size_t)(nb + a0);

@@ -5,7 +5,7 @@
 #include <stdint.h>
 #include <math.h>
 
-#define CALD_MAX_VIEWS 64      // views (image x augmentation) per batched launch
+#define CALD_MAX_VIEWS 128     // views (image x augmentation) per batched launch (hard cap; the sweep issues forwards of <= fwd_views)
 #define CALD_MAX_LEVELS 9      // spatial levels: 0 input, 1 /2, 2 /4 (P2) ... 6 /64 (pool), 7 roi rows per view, 8 all roi rows as ONE segment
 #define CALD_ROI_CAP 1000      // rpn_post_nms_top_n: fixed row capacity per view in the roi GEMMs
 #define CALD_MAX_CUT 4

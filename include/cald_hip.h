@@ -108,7 +108,7 @@ typedef struct cald_dets {
     int cap;
 } cald_dets;
 
-/* model(list_of_images) in eval mode, for up to 64 views at once (batch-1 semantics per view). */
+/* model(list_of_images) in eval mode, for up to 128 views at once (batch-1 semantics per view). */
 int cald_forward(cald_model* m, int n_views, const cald_view* views, const cald_dets* out);
 
 /* get_uncertainty(task_model, unlabeled_loader, augs, num_cls) (cald_train.py:91-231) over
