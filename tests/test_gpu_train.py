@@ -920,3 +920,35 @@ def test_sgd_resume_uses_the_loaded_momentum(T):
     for p, m in zip(params, mirror):
         _close(p, m, 1e-6, "parameter after the resumed step")
     assert all(opt.state[p]["momentum_buffer"].data_ptr() == opt._mflat.data_ptr() + 4 * net._off[k] for p, k in zip(params, net.names))
+
+
+def test_full_size_retinanet_training_step_gradients_vs_autograd(T, oracle):
+    """RetinaNet at the reference's training size (min 600 / max 1000, cald_train.py:342), two images: both losses, the anchor
+    matching and the gradient of every one of the 78 trainable tensors against float64 torch-CPU autograd whose loss code is pinned to
+    the reference's own (tests/golden/train_losses.npz).  Tolerance 1e-4 (float32 vs float64)."""
+    torch, ops = T
+    from cald_amd import synth, train
+    from oracle import torch_train as tt
+    _, images, targets = _train_case(torch, n_images=2, seed=12, scale=1.0)
+    sd = synth.pseudo_trained_retinanet(21, 50, seed=2)
+    net = train.RetinaNetTrainer(sd, 21, min_size=600, max_size=1000)
+    losses = net.forward(images, targets)
+    grads = {k: v.clone() for k, v in net.backward().items()}
+    ref = tt.TorchTrainRetinaNet(sd, 21, min_size=600, max_size=1000)
+    ref.masks = net.relu_decisions()
+    want, rec = ref.losses(images, targets)
+    assert torch.equal(rec["matched"].int(), torch.from_numpy(net.last["matched_host"])), "same anchor matching"
+    assert int((rec["matched"] >= 0).sum()) > 50
+    for k in want:
+        got, w = float(losses[k]), float(want[k].detach())
+        assert abs(got - w) <= 1e-4 * max(1.0, abs(w)), (k, got, w)
+    sum(want.values()).backward()
+    tr = ref.trainable()
+    assert sorted(tr) == sorted(grads) and len(grads) == 78
+    worst = ("", 0.0)
+    for k, g in grads.items():
+        w = tr[k].grad
+        err = float((g.double().cpu() - w).abs().max()) / float(w.abs().max())
+        if err > worst[1]:
+            worst = (k, err)
+    assert worst[1] <= 1e-4, "largest gradient error %.3g at %s" % (worst[1], worst[0])
