@@ -768,16 +768,24 @@ static double fill_conv_args(cald_model* m, ConvArgs& a, const ConvLayer& L, con
     a.total_mtiles = level_tiles(m->plan, lout, V);
     a.out_ld = L.Cout; a.in_relu = in_relu ? 1 : 0; a.zeros = m->ctx->d_zeros; a.exp_flags = 0;
     a.i8_in = nullptr; a.i8_plane_stride = 0; a.w8 = nullptr; a.w8_unscale = nullptr; a.i8_rowscale = nullptr; a.mask = nullptr;
+    // the kernels address a view's tensor through a buffer resource / 32-bit byte offsets: a view (or a dense RoI-row segment) must stay
+    // below 2 GB per operand -- refuse loudly instead of reading zeros past the end (as a 64-view fc6 operand in one segment once did)
+    for (int v = 0; v < V; v++) {
+        const long long pin = (long long)m->plan.seg[lin][v].H * m->plan.seg[lin][v].W, pout = (long long)m->plan.seg[lout][v].H * m->plan.seg[lout][v].W;
+        if (pin * L.Cin * 4 > 0x7FFE0000LL || pout * L.Cout * 4 > 0x7FFE0000LL) {
+            return (double)fail(CALD_ERR_UNSUPPORTED, "a view's activation tensor exceeds 2 GB (level %d -> %d, %lld x %d / %lld x %d elements)", lin, lout, pin, L.Cin, pout, L.Cout);
+        }
+    }
     a.in16 = nullptr; a.out16 = nullptr;
     if (!m->split.empty()) {
         auto fi = m->split.find(in);
         if (fi != m->split.end()) {
             if (a.w16 && !in_relu) a.in16 = fi->second.s16;
-            else if (fi->second.fp32_dead) { fail(CALD_ERR_STATE, "a layer outside conv_h3 reads a tensor kept in split form only"); return -1.0; }
+            else if (fi->second.fp32_dead) return (double)fail(CALD_ERR_STATE, "a layer outside conv_h3 reads a tensor kept in split form only");
         }
         auto fo = m->split.find(out);
         if (fo != m->split.end()) {
-            if (!a.w16) { fail(CALD_ERR_STATE, "a layer outside conv_h3 writes a tensor with a split twin"); return -1.0; }
+            if (!a.w16) return (double)fail(CALD_ERR_STATE, "a layer outside conv_h3 writes a tensor with a split twin");
             a.out16 = fo->second.s16;
             if (fo->second.fp32_dead) a.out = nullptr;
         }
@@ -811,7 +819,7 @@ static int conv_on(cald_model* m, const ConvLayer& L, const float* in, float* ou
     ConvArgs a;
     m->i8_off = 0;
     const double flops = fill_conv_args(m, a, L, in, out, lin, lout, V, relu, residual, up, lup, dyn, in_relu);
-    if (flops < 0.0) return CALD_ERR_STATE;
+    if (flops < 0.0) return (int)flops;            // fill_conv_args failed: the (negative) status code
     return run_conv(m->ctx, a, flops);
 }
 // Bottleneck conv2 (3 x 3) + conv3 (1 x 1 expand, + residual) of one block: ONE launch when conv_p4.hip's fused kernel covers the
@@ -825,6 +833,7 @@ static int conv_pair_on(cald_model* m, const ConvLayer& L2, const ConvLayer& L3,
         m->i8_off = 0;
         const double f2 = fill_conv_args(m, a2, L2, in, mid, lin, lout, V, true);
         const double f3 = fill_conv_args(m, a3, L3, mid, out, lout, lout, V, true, residual);
+        if (f2 < 0.0 || f3 < 0.0) return (int)(f2 < 0.0 ? f2 : f3);
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (c->prof) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, c->stream)); }
         const bool done = launch_conv_p4_fused(a2, a3, c->stream);
@@ -851,7 +860,7 @@ static int conv_group_on(cald_model* m, const ConvSpec* sp, int n, int V) {
     m->i8_off = 0;
     for (int i = 0; i < n; i++) {
         const double f = fill_conv_args(m, a[i], *sp[i].L, sp[i].in, sp[i].out, sp[i].level, sp[i].level, V, sp[i].relu);
-        if (f < 0.0) return CALD_ERR_STATE;
+        if (f < 0.0) return (int)f;
         flops += f; tiles += a[i].total_mtiles;
     }
     cald_ctx* c = m->ctx;
