@@ -21,6 +21,15 @@ __device__ inline int color_perm(int k, int c) {
     return (int)((packed[k] >> (2 * c)) & 3u);
 }
 __global__ __launch_bounds__(256) void preprocess_kernel(const ViewDesc* views, const LevelSeg* seg0, float* out) {
+    // (byte / 255 - mean) / std has 256 x 3 possible values: two IEEE divisions per tap and channel (24 per output pixel) become one
+    // LDS lookup of the same two divisions done once per workgroup -- the same bits.  (Views with additive noise divide per tap.)
+    __shared__ float s_norm[3][256];
+    {
+        const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+#pragma unroll
+        for (int c = 0; c < 3; c++) s_norm[c][threadIdx.x] = ((float)threadIdx.x / 255.0f - mean[c]) / stdv[c];
+    }
+    __syncthreads();
     const int v = blockIdx.y;
     const ViewDesc& vd = views[v];   // by reference: a by-value copy puts rects[] (dynamically indexed) in scratch
     const LevelSeg s = seg0[v];
@@ -54,9 +63,13 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const ViewDesc* views, 
                 const uint8_t* p = vd.src + ((long long)yy * W + sx) * 3;
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
-                    float u = cut ? 0.0f : (float)p[color_perm(swap, c)] / 255.0f;
-                    if (vd.noise) u = u + vd.noise[((long long)c * H + yy) * W + sx];
-                    val[a][b][c] = (u - mean[c]) / stdv[c];
+                    if (vd.noise) {
+                        float u = cut ? 0.0f : (float)p[color_perm(swap, c)] / 255.0f;
+                        u = u + vd.noise[((long long)c * H + yy) * W + sx];
+                        val[a][b][c] = (u - mean[c]) / stdv[c];
+                    } else {
+                        val[a][b][c] = s_norm[c][cut ? 0 : (int)p[color_perm(swap, c)]];
+                    }
                 }
             }
         float r3[3];
