@@ -15,8 +15,8 @@ os.makedirs(dst, exist_ok=True)
 
 
 def find(pattern):
-    g = glob.glob(os.path.join(src, pattern), recursive=True)
-    return g[0] if g else None
+    g = glob.glob(os.path.join(src, pattern), recursive=True)      # several runs may have merged into one directory: the newest wins
+    return max(g, key=os.path.getmtime) if g else None
 
 
 stats = find("stats/**/*kernel_stats.csv")
