@@ -387,7 +387,8 @@ def main():
             "config": {"workload": ("BASELINE.json configs[1]: Faster R-CNN ResNet-50 FPN, VOC2012-shaped synthetic pool (baseline JPEG files), "
                                     "3 augs (flip/cut_out/smaller_resize), 21 classes, min/max 600/1000, seeded pseudo-trained weights")
                        if headline else "informational: model=%s shape=%s augs=%s classes=%d min/max %d/%d precision=%s" % (args.model, args.shape, args.augs, ncls, mn, mx, args.precision),
-                       "images_per_step_per_gpu": B, "views_per_image": 1 + len(sweep.expand_augs(augs)), "pool_images": pool_total,
+                       "images_per_step": B, "images_per_step_note": "weak scaling: per GPU; strong scaling: over the whole job (steps_per_rank says how many batches a rank ran)",
+                       "views_per_image": 1 + len(sweep.expand_augs(augs)), "pool_images": pool_total,
                        "timed_region": "HBM-resident decoded pool -> K sweep steps -> all-gather (N>1) -> argsort + cls_kldiv -> selected indices",
                        "selection_budget": budget, "n_selected": int(len(picked)),
                        "selected_sha1": hashlib.sha1(np.asarray(picked, np.int64).tobytes()).hexdigest(),
