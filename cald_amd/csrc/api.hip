@@ -395,6 +395,9 @@ struct cald_model {
     // batch-level detection buffers used by cald_sweep
     DetBuffers sweep_det; int sweep_det_views = 0;
     signed char* i8_scratch = nullptr; size_t i8_cap = 0, i8_off = 0;   // digit-plane scratch of the running forward
+    // the tensor whose digit planes sit at the start of the scratch (the previous single-conv launch's input); a caller that knows the
+    // tensor was not rewritten since (a block's downsample conv followed by its conv1 on the same input) may ask to reuse them
+    const float* i8_last_in = nullptr; long long i8_last_P = 0; int i8_last_Cin = 0; bool i8_reuse_hint = false;
     int key_cap = 32768;   // FRCNN candidate (proposal, class) list capacity per view, sized from box_score_thresh at create
 };
 
@@ -806,8 +809,10 @@ static double fill_conv_args(cald_model* m, ConvArgs& a, const ConvLayer& L, con
         if (m->i8_off + 3 * stride + rs_bytes <= m->i8_cap) {
             signed char* pl = m->i8_scratch + m->i8_off;
             float* rs = reinterpret_cast<float*>(pl + 3 * stride);
+            const bool reuse = m->i8_reuse_hint && m->i8_off == 0 && m->i8_last_in == in && m->i8_last_P == P && m->i8_last_Cin == L.Cin;
+            if (m->i8_off == 0) { m->i8_last_in = in; m->i8_last_P = P; m->i8_last_Cin = L.Cin; } else m->i8_last_in = nullptr;
             m->i8_off += 3 * stride + rs_bytes;
-            launch_quantize_pixels(in, P, L.Cin, pl, (long long)stride, rs, m->ctx->stream);
+            if (!reuse) launch_quantize_pixels(in, P, L.Cin, pl, (long long)stride, rs, m->ctx->stream);
             a.i8_in = pl; a.i8_plane_stride = (long long)stride; a.w8 = L.w8; a.w8_unscale = L.w8_unscale; a.i8_rowscale = rs;
         }   // (no room: cannot happen with fwd_layout's sizing; the exact kernel would run)
     }
@@ -985,7 +990,7 @@ static int forward_model(cald_model* m, int V, ViewDesc* views, const DetBuffers
     FwdBufs F;
     { Bump dry(nullptr, true); fwd_layout(m, dry, F, V); int rc = arena_reserve(c, dry.off); if (rc) return rc; }
     { Bump real(c->arena, false); fwd_layout(m, real, F, V); }
-    m->i8_scratch = F.i8_planes; m->i8_cap = F.i8_cap; m->i8_off = 0;
+    m->i8_scratch = F.i8_planes; m->i8_cap = F.i8_cap; m->i8_off = 0; m->i8_last_in = nullptr; m->i8_reuse_hint = false;
     {
         const int si = c->stage_i; c->stage_i = (si + 1) % cald_ctx::NSTAGE;
         HIPCHK(hipEventSynchronize(c->stage_ev[si]));
@@ -1013,7 +1018,11 @@ static int forward_model(cald_model* m, int V, ViewDesc* views, const DetBuffers
         const int lout = lvl + (B.c2.stride == 2 ? 1 : 0);
         const float* idn = cur;
         if (B.has_down) { if ((rc = conv_on(m, B.down, cur, F.D, lvl, lout, V, false))) return rc; idn = F.D; }
-        if ((rc = conv_on(m, B.c1, cur, F.T1, lvl, lvl, V, true))) return rc;
+        static const bool i8_reuse_env = !(getenv("CALD_I8_REUSE") && atoi(getenv("CALD_I8_REUSE")) == 0);
+        m->i8_reuse_hint = B.has_down && i8_reuse_env;          // i8x3: conv1 reads the tensor the downsample conv just quantised
+        rc = conv_on(m, B.c1, cur, F.T1, lvl, lvl, V, true);
+        m->i8_reuse_hint = false;
+        if (rc) return rc;
         float* dst = B.layer_end ? F.Cf[layer] : F.X[xi];
         if ((rc = conv_pair_on(m, B.c2, B.c3, F.T1, F.T2, dst, lvl, lout, V, idn))) return rc;
         cur = dst; lvl = lout;
