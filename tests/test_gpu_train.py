@@ -952,3 +952,31 @@ def test_full_size_retinanet_training_step_gradients_vs_autograd(T, oracle):
         if err > worst[1]:
             worst = (k, err)
     assert worst[1] <= 1e-4, "largest gradient error %.3g at %s" % (worst[1], worst[0])
+
+
+def test_training_input_and_ordering_errors_are_loud(T):
+    """torchvision's GeneralizedRCNN.forward rejects degenerate target boxes with a ValueError naming the box; the layers keep ONE set of
+    saved activations, so backward() of a forward that a later forward has replaced must refuse instead of differentiating the wrong
+    tensors; load_state_dict() in train mode leaves a working trainer behind."""
+    torch, ops = T
+    from cald_amd import detector, train
+    sd, images, targets = _train_case(torch)
+    net = train.FasterRCNNTrainer(sd, 21, min_size=160, max_size=256, box_batch=64, generator=torch.Generator().manual_seed(7))
+    bad = [dict(t) for t in targets]
+    bad[1] = {"boxes": bad[1]["boxes"].clone(), "labels": bad[1]["labels"]}
+    bad[1]["boxes"][0, 2] = bad[1]["boxes"][0, 0]                      # zero width
+    with pytest.raises(ValueError, match="positive height and width"):
+        net.forward(images, bad)
+    model = train.TrainableDetector(net)
+    first = sum(model(images, targets).values())
+    second = sum(model(images, targets).values())
+    with pytest.raises(RuntimeError, match="later forward"):
+        first.backward()
+    second.backward()                                                   # the latest forward differentiates normally
+    assert all(p.grad is not None for p in model.parameters() if p.requires_grad)
+    det = detector.fasterrcnn_resnet50_fpn_feature(num_classes=21, min_size=160, max_size=256).to("cuda")
+    det.load_state_dict(sd)
+    det.train()
+    det.load_state_dict(sd)                                             # in train mode: the trainer is rebuilt, the next call works
+    out = det(images, targets)
+    assert sorted(out) == ["loss_box_reg", "loss_classifier", "loss_objectness", "loss_rpn_box_reg"]
