@@ -90,9 +90,132 @@ __global__ __launch_bounds__(256) void roi_align_kernel(RoiArgs a) {
         else out[idx] = res;
     }
 }
+
+// C = 256 (every FPN box head here): one workgroup per RoI, SEVEN waves -- wave = bin row ph, lane = channel quad.  The kernel above
+// is bound by the texture-address path: 16 float4 gathers per (bin, quad), 784 KB of L1 requests for a 50 KB RoI, although a
+// 7 x 7 / 2 x 2 sample grid over a ~14-pixel RoI touches each feature pixel several times.  Here every sample index of a wave is
+// wave-uniform (readfirstlane -> scalar branches): the wave walks its 14 sample columns left to right keeping the pixel columns
+// (lo, hi) of the previous sample for its (up to) four pixel rows in registers, and loads a column only when the sample moves on
+// to a new one (hi of one sample is usually lo of the next; the two sample rows of a bin usually share a pixel row).  Loads per
+// bin row: (unique rows <= 4) x (unique columns ~ RoI width + 2) instead of 7 x 16.  The arithmetic per output is the kernel
+// above's, term for term; an out-of-range sample has zero weights in both kernels (which finite pixel it multiplies is immaterial:
+// acc starts at +0 and x + (+-0) = x).
+__device__ __forceinline__ float4 roi_bilinear(const float4 acc, const float w1, const float w2, const float w3, const float w4,
+                                               const float4 v1, const float4 v2, const float4 v3, const float4 v4) {
+    float4 r;
+    r.x = acc.x + (((w1 * v1.x + w2 * v2.x) + w3 * v3.x) + w4 * v4.x);
+    r.y = acc.y + (((w1 * v1.y + w2 * v2.y) + w3 * v3.y) + w4 * v4.y);
+    r.z = acc.z + (((w1 * v1.z + w2 * v2.z) + w3 * v3.z) + w4 * v4.z);
+    r.w = acc.w + (((w1 * v1.w + w2 * v2.w) + w3 * v3.w) + w4 * v4.w);
+    return r;
+}
+// NR = number of distinct pixel rows the two sample rows of this bin row touch, PAT the way they share them:
+//   PAT 0: (Y0.lo, Y0.hi, Y1.lo, Y1.hi) loaded as four rows (no sharing assumed)
+//   PAT 1: Y1.lo == Y0.hi            -> rows (Y0.lo, Y0.hi, Y1.hi), sample row 1 uses rows (1, 2)
+//   PAT 2: Y1 on the same pixel rows -> rows (Y0.lo, Y0.hi), both sample rows use (0, 1)
+template <int PAT>
+__device__ __forceinline__ void roi_rows_walk(const float4* const f, const int Wf, const RoiSample* const sx, const RoiSample Y0,
+                                              const RoiSample Y1, const int ph, const int q, float4* const out, const bool out16) {
+    constexpr int NR = PAT == 0 ? 4 : (PAT == 1 ? 3 : 2);
+    const int r0 = __builtin_amdgcn_readfirstlane(Y0.lo), r1 = __builtin_amdgcn_readfirstlane(Y0.hi);
+    const int r2 = __builtin_amdgcn_readfirstlane(Y1.lo), r3 = __builtin_amdgcn_readfirstlane(Y1.hi);
+    const float4* const p0 = f + (long long)r0 * Wf * 64 + q;
+    const float4* const p1 = f + (long long)r1 * Wf * 64 + q;
+    const float4* const p2 = f + (long long)(PAT == 0 ? r2 : r3) * Wf * 64 + q;
+    const float4* const p3 = f + (long long)r3 * Wf * 64 + q;
+    // four pixel-column slots per bin: (L0, H0) = sample 2 pw, (L1, H1) = sample 2 pw + 1, each NR rows.  Every load a bin needs is
+    // issued before its arithmetic starts (up to 4 NR float4 in flight per lane; a walk that loaded sample by sample was bound by
+    // the latency of its 14 dependent steps).
+#define ROI_COPY(D, S) { D##0 = S##0; D##1 = S##1; if (NR > 2) D##2 = S##2; if (NR > 3) D##3 = S##3; }
+#define ROI_LOAD(D, X) { D##0 = p0[(X) * 64]; D##1 = p1[(X) * 64]; if (NR > 2) D##2 = p2[(X) * 64]; if (NR > 3) D##3 = p3[(X) * 64]; }
+#define ROI_SAMPLE(X, A, B, T0, T1)                                                                                              \
+    {                                                                                                                            \
+        const bool ok0 = Y0.valid && X.valid, ok1 = Y1.valid && X.valid;                                                         \
+        const float u1 = ok0 ? Y0.h * X.h : 0.0f, u2 = ok0 ? Y0.h * X.l : 0.0f, u3 = ok0 ? Y0.l * X.h : 0.0f, u4 = ok0 ? Y0.l * X.l : 0.0f; \
+        const float w1 = ok1 ? Y1.h * X.h : 0.0f, w2 = ok1 ? Y1.h * X.l : 0.0f, w3 = ok1 ? Y1.l * X.h : 0.0f, w4 = ok1 ? Y1.l * X.l : 0.0f; \
+        T0 = roi_bilinear(zero, u1, u2, u3, u4, A##0, B##0, A##1, B##1);                                                         \
+        if (PAT == 0) T1 = roi_bilinear(zero, w1, w2, w3, w4, A##2, B##2, A##3, B##3);                                           \
+        else if (PAT == 1) T1 = roi_bilinear(zero, w1, w2, w3, w4, A##1, B##1, A##2, B##2);                                      \
+        else T1 = roi_bilinear(zero, w1, w2, w3, w4, A##0, B##0, A##1, B##1);                                                    \
+    }
+    float4 L00, L01, L02, L03, H00, H01, H02, H03, L10, L11, L12, L13, H10, H11, H12, H13;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    L00 = L01 = L02 = L03 = H00 = H01 = H02 = H03 = L10 = L11 = L12 = L13 = H10 = H11 = H12 = H13 = zero;
+    int plo = -1, phi = -1;              // columns held by (L1, H1) = the previous bin's second sample
+#pragma unroll
+    for (int pw = 0; pw < 7; pw++) {
+        const RoiSample X0 = sx[pw * 2], X1 = sx[pw * 2 + 1];
+        const int c0l = __builtin_amdgcn_readfirstlane(X0.lo), c0h = __builtin_amdgcn_readfirstlane(X0.hi);
+        const int c1l = __builtin_amdgcn_readfirstlane(X1.lo), c1h = __builtin_amdgcn_readfirstlane(X1.hi);
+        // 1. what the previous bin already holds
+        const bool h0_alias = c0h == c0l;
+        const bool l0_prev = c0l == plo || c0l == phi, h0_prev = !h0_alias && (c0h == phi || c0h == plo);
+        if (l0_prev) { if (c0l == plo) ROI_COPY(L0, L1) else ROI_COPY(L0, H1) }
+        if (h0_prev) { if (c0h == phi) ROI_COPY(H0, H1) else ROI_COPY(H0, L1) }
+        // 2. every column that has to come from memory
+        const bool l1_alias = c1l == c0l || c1l == c0h;
+        const bool h1_alias = c1h == c1l || c1h == c0h || c1h == c0l;
+        if (!l0_prev) ROI_LOAD(L0, c0l)
+        if (!h0_prev && !h0_alias) ROI_LOAD(H0, c0h)
+        if (!l1_alias) ROI_LOAD(L1, c1l)
+        if (!h1_alias) ROI_LOAD(H1, c1h)
+        // 3. columns shared inside the bin
+        if (h0_alias) ROI_COPY(H0, L0)
+        if (l1_alias) { if (c1l == c0l) ROI_COPY(L1, L0) else ROI_COPY(L1, H0) }
+        if (h1_alias) { if (c1h == c1l) ROI_COPY(H1, L1) else if (c1h == c0h) ROI_COPY(H1, H0) else ROI_COPY(H1, L0) }
+        plo = c1l; phi = c1h;
+        float4 s00, s01, s10, s11;
+        ROI_SAMPLE(X0, L0, H0, s00, s10)
+        ROI_SAMPLE(X1, L1, H1, s01, s11)
+        // the kernel above adds the four samples in (iy, ix) order: (0,0), (0,1), (1,0), (1,1)
+        float4 acc = s00;
+        acc.x = acc.x + s01.x; acc.y = acc.y + s01.y; acc.z = acc.z + s01.z; acc.w = acc.w + s01.w;
+        acc.x = acc.x + s10.x; acc.y = acc.y + s10.y; acc.z = acc.z + s10.z; acc.w = acc.w + s10.w;
+        acc.x = acc.x + s11.x; acc.y = acc.y + s11.y; acc.z = acc.z + s11.z; acc.w = acc.w + s11.w;
+        const float4 res = make_float4(acc.x / 4.0f, acc.y / 4.0f, acc.z / 4.0f, acc.w / 4.0f);
+        const int idx = (ph * 7 + pw) * 64 + q;
+        if (out16) reinterpret_cast<uint4*>(out)[idx] = split16_word4(res);
+        else out[idx] = res;
+    }
+#undef ROI_COPY
+#undef ROI_LOAD
+#undef ROI_SAMPLE
+}
+__global__ __launch_bounds__(448, 4) void roi_align_rows_kernel(RoiArgs a) {
+    __shared__ RoiSample sy[14], sx[14];
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3, tid = threadIdx.x;
+    const int v = xcd + 8 * (seq / CALD_ROI_CAP), slot = seq % CALD_ROI_CAP;
+    if (v >= a.V || slot >= a.prop_count[v]) return;
+    const int r = a.order[v * 1024 + slot];
+    const float4 box = reinterpret_cast<const float4*>(a.proposals)[(long long)v * CALD_ROI_CAP + r];
+    const int l = roi_level(box);
+    const LevelSeg sg = a.seg[l][v];
+    const int Hf = sg.H, Wf = sg.W;
+    const float4* f = reinterpret_cast<const float4*>(a.feat[l] + sg.pix_off * 256ll);
+    if (tid < 28) {
+        const float scale = 1.0f / (float)(4 << l);
+        const float x1 = box.x * scale, y1 = box.y * scale, x2 = box.z * scale, y2 = box.w * scale;
+        float rw = x2 - x1; if (!(rw >= 1.0f)) rw = 1.0f;
+        float rh = y2 - y1; if (!(rh >= 1.0f)) rh = 1.0f;
+        const float bw = rw / 7.0f, bh = rh / 7.0f;
+        if (tid < 14) sy[tid] = roi_sample(y1, bh, tid >> 1, tid & 1, Hf);
+        else sx[tid - 14] = roi_sample(x1, bw, (tid - 14) >> 1, (tid - 14) & 1, Wf);
+    }
+    __syncthreads();
+    const int ph = __builtin_amdgcn_readfirstlane(tid >> 6), q = tid & 63;
+    const RoiSample Y0 = sy[ph * 2], Y1 = sy[ph * 2 + 1];
+    float4* out = reinterpret_cast<float4*>(a.out + ((long long)v * CALD_ROI_CAP + r) * 49 * 256);
+    const int r0 = __builtin_amdgcn_readfirstlane(Y0.lo), r1 = __builtin_amdgcn_readfirstlane(Y0.hi);
+    const int r2 = __builtin_amdgcn_readfirstlane(Y1.lo), r3 = __builtin_amdgcn_readfirstlane(Y1.hi);
+    if (r2 == r0 && r3 == r1) roi_rows_walk<2>(f, Wf, sx, Y0, Y1, ph, q, out, a.out16 != 0);
+    else if (r2 == r1) roi_rows_walk<1>(f, Wf, sx, Y0, Y1, ph, q, out, a.out16 != 0);
+    else roi_rows_walk<0>(f, Wf, sx, Y0, Y1, ph, q, out, a.out16 != 0);
+}
 void launch_roi_align(const RoiArgs& a, hipStream_t st) {
+    static const bool rows = !(getenv("CALD_ROI_ROWS") && atoi(getenv("CALD_ROI_ROWS")) == 0);
     hipLaunchKernelGGL(roi_order_kernel, dim3(a.V), dim3(1024), 0, st, a);
-    hipLaunchKernelGGL(roi_align_kernel, dim3(8 * ((a.V + 7) / 8) * CALD_ROI_CAP), dim3(256), 0, st, a);
+    if (rows && a.C == 256) hipLaunchKernelGGL(roi_align_rows_kernel, dim3(8 * ((a.V + 7) / 8) * CALD_ROI_CAP), dim3(448), 0, st, a);
+    else hipLaunchKernelGGL(roi_align_kernel, dim3(8 * ((a.V + 7) / 8) * CALD_ROI_CAP), dim3(256), 0, st, a);
 }
 
 // ---------------------------------------------------------------------------------------------

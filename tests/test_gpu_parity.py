@@ -412,6 +412,28 @@ def test_f16x3_split_producers_equal_the_in_kernel_split(hip, tmp_path, arch):
     assert (outs[0]["cons"] > 0).sum() >= 15
 
 
+@pytest.mark.parametrize("prec,mn,mx", [("fp32", 600, 1000), ("f16x3", 300, 500)])
+def test_row_walk_roi_align_equals_the_gather_kernel(hip, tmp_path, prec, mn, mx):
+    """roi.hip has two RoIAlign kernels: one gather per (bin, channel quad) and the row walk (a wave per bin row that keeps pixel
+    columns in registers).  Same arithmetic per output, so CALD_ROI_ROWS=0/1 must give byte-identical scores -- at full size, and
+    at half size where clamped edge samples and one-pixel bins are common (f16x3: the split-word output path)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for flag in ("1", "0"):
+        out = str(tmp_path / ("rows_%s.npz" % flag))
+        env = dict(os.environ, CALD_ROI_ROWS=flag)
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "_h3_split_probe.py"), out, root, "frcnn", prec, str(mn), str(mx)],
+                           env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(out))
+    assert outs[0]["cons"].tobytes() == outs[1]["cons"].tobytes()
+    assert outs[0]["cls"].tobytes() == outs[1]["cls"].tobytes()
+    assert (outs[0]["cons"] > 0).sum() >= 15
+
+
 def test_f16x3_mode_retinanet_close_to_exact(hip):
     """The split-fp16 mode on the other detector (RetinaNet towers, sigmoid scores, class-grouped output)."""
     torch = hip["torch"]
