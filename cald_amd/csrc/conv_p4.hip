@@ -533,6 +533,21 @@ __device__ __forceinline__ void conv_p4_body(const ConvArgs& a, const int blk, c
             for (int kt = 0; kt < 4; kt++) *reinterpret_cast<f32x4*>(Wl + kt * 1024 + ww_off) = wr[kt];
             __syncthreads();                                    // T (first chunk) and this chunk's weights are in LDS
             if (n0c + 64 < CoutPad3) fetch_w(n0c + 64);
+            // the chunk's residual values are requested BEFORE its 64 MFMAs (their HBM latency hides under ~4 000 matrix cycles)
+            const int n3 = n0c + wn * 32 + l31;
+            int vo3[2];
+            float ex[2][16];
+#pragma unroll
+            for (int i = 0; i < 2; i++) vo3[i] = ((m0 + wm * 64 + i * 32 + 4 * kh_lane) * ld3 + n3) * 4;
+            const bool late = (b.exp_flags & 2) != 0;           // tuning experiment (CALD_P4_FUSE_LATE=1): load them after the MFMAs instead
+            if (!late) {
+#pragma unroll
+                for (int i = 0; i < 2; i++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++)
+                        ex[i][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsX3, vo3[i], ((r & 3) + 8 * (r >> 2)) * ld3 * 4, 0));
+            }
+            __builtin_amdgcn_sched_barrier(0);                  // keep the scheduler from sinking them to their first use
             f32x16 acc2[2][1];
 #pragma unroll
             for (int i = 0; i < 2; i++)
@@ -560,22 +575,23 @@ __device__ __forceinline__ void conv_p4_body(const ConvArgs& a, const int blk, c
             // conv3's epilogue, BN -> + residual -> ReLU as in p4_epilogue<1>: the buffer resources end at the view's last valid row, so
             // the rows of a partial tile need no per-element test (loads beyond the end return 0, stores are dropped)
             {
-                const int n = n0c + wn * 32 + l31;
-                const float sc3 = b.scale[n], sh3 = b.shift[n];
+                const float sc3 = b.scale[n3], sh3 = b.shift[n3];
+                if (late) {
+#pragma unroll
+                    for (int i = 0; i < 2; i++)
+#pragma unroll
+                        for (int r = 0; r < 16; r++)
+                            ex[i][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsX3, vo3[i], ((r & 3) + 8 * (r >> 2)) * ld3 * 4, 0));
+                }
 #pragma unroll
                 for (int i = 0; i < 2; i++) {
-                    const int vo = ((m0 + wm * 64 + i * 32 + 4 * kh_lane) * ld3 + n) * 4;
-                    float ex[16];
-#pragma unroll
-                    for (int r = 0; r < 16; r++)
-                        ex[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsX3, vo, ((r & 3) + 8 * (r >> 2)) * ld3 * 4, 0));
 #pragma unroll
                     for (int r = 0; r < 16; r++) {
                         float val = acc2[i][0][r] * sc3;
                         val = val + sh3;
-                        val = val + ex[r];
+                        val = val + ex[i][r];
                         if (relu3) val = val > 0.0f ? val : 0.0f;
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rsO3, vo, ((r & 3) + 8 * (r >> 2)) * ld3 * 4, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rsO3, vo3[i], ((r & 3) + 8 * (r >> 2)) * ld3 * 4, 0);
                     }
                 }
             }
@@ -641,7 +657,9 @@ bool launch_conv_p4_fused(const ConvArgs& c2, const ConvArgs& c3, hipStream_t st
     if (c2.residual || c2.up || c2.mask || c2.dyn_rows || c2.in_relu || p4_taps(c2) != 9) return false;
     if (c3.KH != 1 || c3.KW != 1 || c3.stride != 1 || c3.pad != 0 || c3.Cin != 64 || c3.Kpad != 64 || c3.CoutPad % 64 || c3.Cout != c3.CoutPad) return false;
     if (!c3.residual || !c3.scale || c3.bias || c3.out_ld != c3.Cout || c3.up || c3.mask || c3.dyn_rows || c3.in_relu || c3.in != c2.out || c3.total_mtiles != c2.total_mtiles || c3.V != c2.V) return false;
-    ConvGroup g; g.n = 2; g.blk0[0] = 0; g.p[0] = c2; g.p[1] = c3; g.p[0].exp_flags = 0; g.p[1].exp_flags = 0;
+    ConvGroup g; g.n = 2; g.blk0[0] = 0; g.p[0] = c2; g.p[1] = c3; g.p[0].exp_flags = 0;
+    static const int late_env = getenv("CALD_P4_FUSE_LATE") ? atoi(getenv("CALD_P4_FUSE_LATE")) : 0;
+    g.p[1].exp_flags = late_env ? 2 : 0;
     const unsigned grid = (unsigned)p4_grid_mtiles(c2);          // one workgroup per 128-row tile (conv2's only N tile)
     hipLaunchKernelGGL(conv_p4_fused_kernel, dim3(grid), dim3(256), 0, stream, g);
     return true;
