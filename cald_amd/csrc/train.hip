@@ -1125,6 +1125,75 @@ __global__ __launch_bounds__(256) void roi_align_bwd_fixed_kernel(RoiTrainArgs a
         }
     }
 }
+// C == 256: the 16 contributions of a (bin, channel) -- 2 x 2 samples x 4 bilinear taps -- fall on far fewer than 16 feature pixels
+// (the two samples of a bin are half a bin apart: usually they share a pixel row / column or sit on the same ones).  The integer
+// contributions are summed per distinct pixel in registers first -- exact, the accumulation is integer -- and one atomic goes out per
+// pixel.  Which samples share rows / columns is the same for the whole workgroup (one bin per pass), so the sharing pattern is a
+// scalar branch:  P 0: slots (lo0, hi0, lo1, hi1);  P 1: lo1 == hi0 -> (lo0, hi0, hi1);  P 2: sample 1 on sample 0's pair -> (lo0, hi0).
+template <int PR, int PC>
+__device__ __forceinline__ void roi_bwd_bin(unsigned long long* const gf, const int Wf, const int c, const float go, const double scale,
+                                            const RoiSample Y0, const RoiSample Y1, const RoiSample X0, const RoiSample X1) {
+    constexpr int NRS = PR == 0 ? 4 : (PR == 1 ? 3 : 2), NCS = PC == 0 ? 4 : (PC == 1 ? 3 : 2);
+    long long acc[NRS][NCS];
+#pragma unroll
+    for (int i = 0; i < NRS; i++)
+#pragma unroll
+        for (int j = 0; j < NCS; j++) acc[i][j] = 0;
+#pragma unroll
+    for (int iy = 0; iy < 2; iy++) {
+        const RoiSample Y = iy ? Y1 : Y0;
+        const int rl = iy == 0 ? 0 : (PR == 0 ? 2 : (PR == 1 ? 1 : 0)), rh = iy == 0 ? 1 : (PR == 0 ? 3 : (PR == 1 ? 2 : 1));
+#pragma unroll
+        for (int ix = 0; ix < 2; ix++) {
+            const RoiSample X = ix ? X1 : X0;
+            const int cl = ix == 0 ? 0 : (PC == 0 ? 2 : (PC == 1 ? 1 : 0)), ch = ix == 0 ? 1 : (PC == 0 ? 3 : (PC == 1 ? 2 : 1));
+            if (!(Y.valid && X.valid)) continue;
+            acc[rl][cl] += (long long)rint((double)((Y.h * X.h) * go) * scale);
+            acc[rl][ch] += (long long)rint((double)((Y.h * X.l) * go) * scale);
+            acc[rh][cl] += (long long)rint((double)((Y.l * X.h) * go) * scale);
+            acc[rh][ch] += (long long)rint((double)((Y.l * X.l) * go) * scale);
+        }
+    }
+    const int rows[4] = {Y0.lo, Y0.hi, PR == 1 ? Y1.hi : Y1.lo, Y1.hi};
+    const int cols[4] = {X0.lo, X0.hi, PC == 1 ? X1.hi : X1.lo, X1.hi};
+#pragma unroll
+    for (int i = 0; i < NRS; i++)
+#pragma unroll
+        for (int j = 0; j < NCS; j++)
+            if (acc[i][j]) atomicAdd(gf + (long long)(rows[i] * Wf + cols[j]) * 256 + c, (unsigned long long)acc[i][j]);
+}
+__global__ __launch_bounds__(256) void roi_align_bwd_fixed_merge_kernel(RoiTrainArgs a, RoiAccPtrs acc, const unsigned* max_bits) {
+    __shared__ RoiSample sy[14], sx[14];
+    const int r = blockIdx.x, tid = threadIdx.x;
+    int n, l;
+    roi_setup(a, r, sy, sx, &n, &l);
+    const int Hf = a.H[l], Wf = a.W[l];
+    unsigned long long* gf = reinterpret_cast<unsigned long long*>(acc.p[l]) + (long long)n * Hf * Wf * 256;
+    const double scale = fixed_scale(*max_bits);
+    for (int bin = 0; bin < 49; bin++) {
+        const int ph = bin / 7, pw = bin - ph * 7;
+        float go = a.gout[((long long)r * 49 + bin) * 256 + tid] * 0.25f;
+        if (!(go == go) || fabsf(go) == INFINITY) go = 0.0f;          // non-finite gradients are reported by the loss check, not spread
+        const RoiSample Y0 = sy[ph * 2], Y1 = sy[ph * 2 + 1], X0 = sx[pw * 2], X1 = sx[pw * 2 + 1];
+        const int y0l = __builtin_amdgcn_readfirstlane(Y0.lo), y0h = __builtin_amdgcn_readfirstlane(Y0.hi);
+        const int y1l = __builtin_amdgcn_readfirstlane(Y1.lo), y1h = __builtin_amdgcn_readfirstlane(Y1.hi);
+        const int x0l = __builtin_amdgcn_readfirstlane(X0.lo), x0h = __builtin_amdgcn_readfirstlane(X0.hi);
+        const int x1l = __builtin_amdgcn_readfirstlane(X1.lo), x1h = __builtin_amdgcn_readfirstlane(X1.hi);
+        const int pr = (y1l == y0l && y1h == y0h) ? 2 : (y1l == y0h ? 1 : 0);
+        const int pc = (x1l == x0l && x1h == x0h) ? 2 : (x1l == x0h ? 1 : 0);
+        switch (pr * 3 + pc) {
+            case 0: roi_bwd_bin<0, 0>(gf, Wf, tid, go, scale, Y0, Y1, X0, X1); break;
+            case 1: roi_bwd_bin<0, 1>(gf, Wf, tid, go, scale, Y0, Y1, X0, X1); break;
+            case 2: roi_bwd_bin<0, 2>(gf, Wf, tid, go, scale, Y0, Y1, X0, X1); break;
+            case 3: roi_bwd_bin<1, 0>(gf, Wf, tid, go, scale, Y0, Y1, X0, X1); break;
+            case 4: roi_bwd_bin<1, 1>(gf, Wf, tid, go, scale, Y0, Y1, X0, X1); break;
+            case 5: roi_bwd_bin<1, 2>(gf, Wf, tid, go, scale, Y0, Y1, X0, X1); break;
+            case 6: roi_bwd_bin<2, 0>(gf, Wf, tid, go, scale, Y0, Y1, X0, X1); break;
+            case 7: roi_bwd_bin<2, 1>(gf, Wf, tid, go, scale, Y0, Y1, X0, X1); break;
+            default: roi_bwd_bin<2, 2>(gf, Wf, tid, go, scale, Y0, Y1, X0, X1); break;
+        }
+    }
+}
 // two accumulators per thread; the scale is a power of two, so multiplying by its reciprocal is the exact division
 __global__ void fixed_to_float_kernel(const long long* acc, float* g, long long n, const unsigned* max_bits) {
     const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 2;
@@ -1168,7 +1237,9 @@ extern "C" int cald_train_roi_align_bwd(cald_ctx* c, int N, float* const* gfeats
     THIP(hipMemsetAsync(acc, 0, (size_t)total * 8 + 4, st));
     const long long ng = (long long)R * 49 * C;
     hipLaunchKernelGGL(absmax_kernel, dim3(1024), dim3(256), 0, st, gout, ng, d_max);
-    hipLaunchKernelGGL(roi_align_bwd_fixed_kernel, dim3(R), dim3(256), 0, st, a, ptrs, (const unsigned*)d_max);
+    static const bool merge = !(getenv("CALD_ROI_BWD_MERGE") && atoi(getenv("CALD_ROI_BWD_MERGE")) == 0);
+    if (merge && C == 256) hipLaunchKernelGGL(roi_align_bwd_fixed_merge_kernel, dim3(R), dim3(256), 0, st, a, ptrs, (const unsigned*)d_max);
+    else hipLaunchKernelGGL(roi_align_bwd_fixed_kernel, dim3(R), dim3(256), 0, st, a, ptrs, (const unsigned*)d_max);
     for (int l = 0; l < 4; l++)
         hipLaunchKernelGGL(fixed_to_float_kernel, dim3((unsigned)((n[l] + 511) / 512)), dim3(256), 0, st, (const long long*)ptrs.p[l], gfeats[l], n[l], (const unsigned*)d_max);
     THIP(hipGetLastError());
