@@ -48,30 +48,57 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const ViewDesc* views, 
         const float ly = fy - (float)y0, hy = 1.0f - ly, lx = fx - (float)x0, hx = 1.0f - lx;
         const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
         float val[2][2][3];
+        const int nrect = vd.nrect;
 #pragma unroll
-        for (int a = 0; a < 2; a++)
+        for (int a = 0; a < 2; a++) {
+            const int yy = a ? y1 : y0;
+            bool cut[2];
+            int sxb[2];
 #pragma unroll
             for (int b = 0; b < 2; b++) {
-                const int yy = a ? y1 : y0, xx = b ? x1 : x0;
-                bool cut = false;
-                const int nrect = vd.nrect;
+                const int xx = b ? x1 : x0;
+                bool ct = false;
                 for (int r = 0; r < nrect; r++) {
                     const int* q = vd.rects + 4 * r;
-                    cut |= (xx >= q[0] && xx < q[2] && yy >= q[1] && yy < q[3]);
+                    ct |= (xx >= q[0] && xx < q[2] && yy >= q[1] && yy < q[3]);
                 }
-                const int sx = vd.flip ? (W - 1 - xx) : xx;
-                const uint8_t* p = vd.src + ((long long)yy * W + sx) * 3;
+                cut[b] = ct;
+                sxb[b] = vd.flip ? (W - 1 - xx) : xx;
+            }
+            if (vd.noise) {
 #pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    if (vd.noise) {
-                        float u = cut ? 0.0f : (float)p[color_perm(swap, c)] / 255.0f;
-                        u = u + vd.noise[((long long)c * H + yy) * W + sx];
+                for (int b = 0; b < 2; b++) {
+                    const uint8_t* p = vd.src + ((long long)yy * W + sxb[b]) * 3;
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        float u = cut[b] ? 0.0f : (float)p[color_perm(swap, c)] / 255.0f;
+                        u = u + vd.noise[((long long)c * H + yy) * W + sxb[b]];
                         val[a][b][c] = (u - mean[c]) / stdv[c];
-                    } else {
-                        val[a][b][c] = s_norm[c][cut ? 0 : (int)p[color_perm(swap, c)]];
                     }
                 }
+            } else {
+                // the two taps of a row are adjacent pixels = six consecutive bytes: read as the (up to three) ALIGNED dwords that hold
+                // them -- a dword that holds a requested byte lies inside the image buffer's pages -- and shifted into place, instead of
+                // six byte loads (the kernel was bound by its twelve byte-load instructions per pixel, not by HBM)
+                const int lo = sxb[0] < sxb[1] ? sxb[0] : sxb[1];
+                const int nb = x1 != x0 ? 6 : 3;
+                const uintptr_t ad = (uintptr_t)(vd.src + ((long long)yy * W + lo) * 3);
+                const int bsh = (int)(ad & 3);
+                const unsigned* q = reinterpret_cast<const unsigned*>(ad - bsh);
+                const unsigned d0 = q[0];
+                const unsigned d1 = bsh + nb > 4 ? q[1] : 0u;
+                const unsigned d2 = bsh + nb > 8 ? q[2] : 0u;
+                const unsigned w0 = __builtin_amdgcn_alignbyte(d1, d0, bsh), w1 = __builtin_amdgcn_alignbyte(d2, d1, bsh);
+                const unsigned tap_lo = w0, tap_hi = (w0 >> 24) | (w1 << 8);          // three bytes each, in the low 24 bits
+#pragma unroll
+                for (int b = 0; b < 2; b++) {
+                    const unsigned t = sxb[b] == lo ? tap_lo : tap_hi;
+#pragma unroll
+                    for (int c = 0; c < 3; c++)
+                        val[a][b][c] = s_norm[c][cut[b] ? 0 : (int)((t >> (8 * color_perm(swap, c))) & 255u)];
+                }
             }
+        }
         float r3[3];
 #pragma unroll
         for (int c = 0; c < 3; c++)
