@@ -114,7 +114,7 @@ __device__ __forceinline__ float4 roi_bilinear(const float4 acc, const float w1,
 //   PAT 1: Y1.lo == Y0.hi            -> rows (Y0.lo, Y0.hi, Y1.hi), sample row 1 uses rows (1, 2)
 //   PAT 2: Y1 on the same pixel rows -> rows (Y0.lo, Y0.hi), both sample rows use (0, 1)
 template <int PAT>
-__device__ __forceinline__ void roi_rows_walk(const float4* const f, const int Wf, const RoiSample* const sx, const RoiSample Y0,
+__device__ __forceinline__ void roi_rows_walk(const float4* const f, const int Wf, const RoiSample* const sx, const float4* const wt, const RoiSample Y0,
                                               const RoiSample Y1, const int ph, const int q, float4* const out, const bool out16) {
     constexpr int NR = PAT == 0 ? 4 : (PAT == 1 ? 3 : 2);
     const int r0 = __builtin_amdgcn_readfirstlane(Y0.lo), r1 = __builtin_amdgcn_readfirstlane(Y0.hi);
@@ -126,17 +126,19 @@ __device__ __forceinline__ void roi_rows_walk(const float4* const f, const int W
     // four pixel-column slots per bin: (L0, H0) = sample 2 pw, (L1, H1) = sample 2 pw + 1, each NR rows.  Every load a bin needs is
     // issued before its arithmetic starts (up to 4 NR float4 in flight per lane; a walk that loaded sample by sample was bound by
     // the latency of its 14 dependent steps).
-#define ROI_COPY(D, S) { D##0 = S##0; D##1 = S##1; if (NR > 2) D##2 = S##2; if (NR > 3) D##3 = S##3; }
+    // (the empty asm keeps each copy inside its wave-uniform branch: the compiler otherwise flattens the branches into per-lane selects,
+    // 45 v_cndmask per bin against 76 packed multiplies / adds of bilinear arithmetic)
+#define ROI_COPY(D, S) { asm volatile(""); D##0 = S##0; D##1 = S##1; if (NR > 2) D##2 = S##2; if (NR > 3) D##3 = S##3; }
 #define ROI_LOAD(D, X) { D##0 = p0[(X) * 64]; D##1 = p1[(X) * 64]; if (NR > 2) D##2 = p2[(X) * 64]; if (NR > 3) D##3 = p3[(X) * 64]; }
-#define ROI_SAMPLE(X, A, B, T0, T1)                                                                                              \
+    // the four bilinear weight products of every (sample row, sample column) pair are set up once per workgroup in LDS (wt): a
+    // wave-uniform ds_read_b128 per sample instead of the products and validity selects on every lane
+#define ROI_SAMPLE(SX, A, B, T0, T1)                                                                                             \
     {                                                                                                                            \
-        const bool ok0 = Y0.valid && X.valid, ok1 = Y1.valid && X.valid;                                                         \
-        const float u1 = ok0 ? Y0.h * X.h : 0.0f, u2 = ok0 ? Y0.h * X.l : 0.0f, u3 = ok0 ? Y0.l * X.h : 0.0f, u4 = ok0 ? Y0.l * X.l : 0.0f; \
-        const float w1 = ok1 ? Y1.h * X.h : 0.0f, w2 = ok1 ? Y1.h * X.l : 0.0f, w3 = ok1 ? Y1.l * X.h : 0.0f, w4 = ok1 ? Y1.l * X.l : 0.0f; \
-        T0 = roi_bilinear(zero, u1, u2, u3, u4, A##0, B##0, A##1, B##1);                                                         \
-        if (PAT == 0) T1 = roi_bilinear(zero, w1, w2, w3, w4, A##2, B##2, A##3, B##3);                                           \
-        else if (PAT == 1) T1 = roi_bilinear(zero, w1, w2, w3, w4, A##1, B##1, A##2, B##2);                                      \
-        else T1 = roi_bilinear(zero, w1, w2, w3, w4, A##0, B##0, A##1, B##1);                                                    \
+        const float4 u = wt[(ph * 2) * 14 + (SX)], w = wt[(ph * 2 + 1) * 14 + (SX)];                                             \
+        T0 = roi_bilinear(zero, u.x, u.y, u.z, u.w, A##0, B##0, A##1, B##1);                                                     \
+        if (PAT == 0) T1 = roi_bilinear(zero, w.x, w.y, w.z, w.w, A##2, B##2, A##3, B##3);                                       \
+        else if (PAT == 1) T1 = roi_bilinear(zero, w.x, w.y, w.z, w.w, A##1, B##1, A##2, B##2);                                  \
+        else T1 = roi_bilinear(zero, w.x, w.y, w.z, w.w, A##0, B##0, A##1, B##1);                                                \
     }
     float4 L00, L01, L02, L03, H00, H01, H02, H03, L10, L11, L12, L13, H10, H11, H12, H13;
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -165,8 +167,8 @@ __device__ __forceinline__ void roi_rows_walk(const float4* const f, const int W
         if (h1_alias) { if (c1h == c1l) ROI_COPY(H1, L1) else if (c1h == c0h) ROI_COPY(H1, H0) else ROI_COPY(H1, L0) }
         plo = c1l; phi = c1h;
         float4 s00, s01, s10, s11;
-        ROI_SAMPLE(X0, L0, H0, s00, s10)
-        ROI_SAMPLE(X1, L1, H1, s01, s11)
+        ROI_SAMPLE(pw * 2, L0, H0, s00, s10)
+        ROI_SAMPLE(pw * 2 + 1, L1, H1, s01, s11)
         // the kernel above adds the four samples in (iy, ix) order: (0,0), (0,1), (1,0), (1,1)
         float4 acc = s00;
         acc.x = acc.x + s01.x; acc.y = acc.y + s01.y; acc.z = acc.z + s01.z; acc.w = acc.w + s01.w;
@@ -183,6 +185,7 @@ __device__ __forceinline__ void roi_rows_walk(const float4* const f, const int W
 }
 __global__ __launch_bounds__(448, 4) void roi_align_rows_kernel(RoiArgs a) {
     __shared__ RoiSample sy[14], sx[14];
+    __shared__ float4 s_wt[196];             // [sample row][sample column] -> (w1, w2, w3, w4)
     const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3, tid = threadIdx.x;
     const int v = xcd + 8 * (seq / CALD_ROI_CAP), slot = seq % CALD_ROI_CAP;
     if (v >= a.V || slot >= a.prop_count[v]) return;
@@ -202,14 +205,21 @@ __global__ __launch_bounds__(448, 4) void roi_align_rows_kernel(RoiArgs a) {
         else sx[tid - 14] = roi_sample(x1, bw, (tid - 14) >> 1, (tid - 14) & 1, Wf);
     }
     __syncthreads();
+    if (tid < 196) {
+        const int iy = tid / 14, ix = tid - iy * 14;
+        const RoiSample Y = sy[iy], X = sx[ix];
+        const bool ok = Y.valid && X.valid;
+        s_wt[tid] = make_float4(ok ? Y.h * X.h : 0.0f, ok ? Y.h * X.l : 0.0f, ok ? Y.l * X.h : 0.0f, ok ? Y.l * X.l : 0.0f);
+    }
+    __syncthreads();
     const int ph = __builtin_amdgcn_readfirstlane(tid >> 6), q = tid & 63;
     const RoiSample Y0 = sy[ph * 2], Y1 = sy[ph * 2 + 1];
     float4* out = reinterpret_cast<float4*>(a.out + ((long long)v * CALD_ROI_CAP + r) * 49 * 256);
     const int r0 = __builtin_amdgcn_readfirstlane(Y0.lo), r1 = __builtin_amdgcn_readfirstlane(Y0.hi);
     const int r2 = __builtin_amdgcn_readfirstlane(Y1.lo), r3 = __builtin_amdgcn_readfirstlane(Y1.hi);
-    if (r2 == r0 && r3 == r1) roi_rows_walk<2>(f, Wf, sx, Y0, Y1, ph, q, out, a.out16 != 0);
-    else if (r2 == r1) roi_rows_walk<1>(f, Wf, sx, Y0, Y1, ph, q, out, a.out16 != 0);
-    else roi_rows_walk<0>(f, Wf, sx, Y0, Y1, ph, q, out, a.out16 != 0);
+    if (r2 == r0 && r3 == r1) roi_rows_walk<2>(f, Wf, sx, s_wt, Y0, Y1, ph, q, out, a.out16 != 0);
+    else if (r2 == r1) roi_rows_walk<1>(f, Wf, sx, s_wt, Y0, Y1, ph, q, out, a.out16 != 0);
+    else roi_rows_walk<0>(f, Wf, sx, s_wt, Y0, Y1, ph, q, out, a.out16 != 0);
 }
 void launch_roi_align(const RoiArgs& a, hipStream_t st) {
     static const bool rows = !(getenv("CALD_ROI_ROWS") && atoi(getenv("CALD_ROI_ROWS")) == 0);
