@@ -779,8 +779,16 @@ static double fill_conv_args(cald_model* m, ConvArgs& a, const ConvLayer& L, con
             return (double)fail(CALD_ERR_UNSUPPORTED, "a view's activation tensor exceeds 2 GB (level %d -> %d, %lld x %d / %lld x %d elements)", lin, lout, pin, L.Cin, pout, L.Cout);
         }
     }
-    a.in16 = nullptr; a.out16 = nullptr;
+    a.in16 = nullptr; a.out16 = nullptr; a.ex16 = 0;
     if (!m->split.empty()) {
+        const float* ex = residual ? residual : up;
+        if (ex) {
+            auto fe = m->split.find(ex);
+            if (fe != m->split.end() && fe->second.fp32_dead) {
+                if (!a.w16) return (double)fail(CALD_ERR_STATE, "a layer outside conv_h3 / conv_h4 adds a tensor kept in split form only");
+                a.ex16 = 1;          // same buffer, split form: the epilogue reads it through h16.h
+            }
+        }
         auto fi = m->split.find(in);
         if (fi != m->split.end()) {
             if (a.w16 && !in_relu) a.in16 = fi->second.s16;
@@ -907,17 +915,21 @@ static void fwd_layout(cald_model* m, Bump& B, FwdBufs& F, int V) {
     F.T1 = B.get<float>(px[2] * 128); F.T2 = B.get<float>(px[2] * 64); F.D = B.get<float>(px[2] * 256);
     const int cch[4] = {256, 512, 1024, 2048};
     for (int i = 0; i < 4; i++) F.Cf[i] = B.get<float>(px[2 + i] * cch[i]);
-    // split forms (F16X3): the pooled stem output and the two inner tensors of a bottleneck feed conv_h3 layers only.  Block outputs stay
-    // fp32 only: a twin would add 4 B / element to the HBM-bound expand layers (measured: 64->256 +23 %, 128->512 +27 %, 256->1024 +22 %)
-    // for a few percent on the 1 x 1 reduce layers that read them.
-    only(F.p1); only(F.T1); only(F.T2);
+    // split forms (F16X3, h16.h): every tensor whose readers are conv_h3 / conv_h4 layers lives in split form ONLY, in the buffer the fp32
+    // tensor would have used (same 4 bytes per element): the pooled stem output, the inner tensors of a bottleneck, the block outputs
+    // (read as a GEMM operand by the next block's conv1 / downsample conv / the FPN lateral, and as the residual by conv3's epilogue,
+    // which joins hi + lo again), the downsample branch, the laterals (operand of the 3 x 3 output conv, top-down term of the next
+    // lateral's epilogue).  22 significant bits instead of 24 on those tensors -- the precision every GEMM operand of this mode has.
+    only(F.p1); only(F.T1); only(F.T2); only(F.X[0]); only(F.X[1]); only(F.D);
+    for (int i = 0; i < 4; i++) only(F.Cf[i]);
     if (m->cfg.arch == CALD_ARCH_RETINANET) {
         const int K = m->cfg.num_classes, per = m->cfg.detections_per_img;
         for (int i = 0; i < 3; i++) F.inner[i] = B.get<float>(px[3 + i] * 256);
         for (int i = 0; i < 5; i++) F.Pf[i] = B.get<float>(px[3 + i] * 256);
         for (int h = 0; h < 2; h++) for (int q = 0; q < 2; q++) for (int i = 0; i < 5; i++) F.ret_t[h][q][i] = B.get<float>(px[3 + i] * 256);
-        // RetinaNet: P3..P5 and P7 feed conv_h3 layers only; P6 is also read through a ReLU by p7 (fp32 path); the tower tensors go from
-        // conv_h3 layer to conv_h3 layer.  (Laterals stay fp32: their twin cost the 1 x 1 lateral what it saved the 3 x 3 output conv.)
+        // RetinaNet: laterals, P3..P5 and P7 feed conv_h3 / conv_h4 layers only; P6 is also read through a ReLU by p7 (fp32 input path of
+        // conv_h3); the tower tensors go from matrix-pipe layer to matrix-pipe layer.
+        for (int i = 0; i < 3; i++) only(F.inner[i]);
         only(F.Pf[0]); only(F.Pf[1]); only(F.Pf[2]); both(F.Pf[3], F.Pf16[3], px[6] * 256); only(F.Pf[4]);
         for (int h = 0; h < 2; h++) for (int q = 0; q < 2; q++) for (int i = 0; i < 5; i++) only(F.ret_t[h][q][i]);
         for (int i = 0; i < 5; i++) { F.cls_h[i] = B.get<float>(px[3 + i] * m->cls_out.Cout); F.reg_h[i] = B.get<float>(px[3 + i] * 36); }
@@ -937,9 +949,12 @@ static void fwd_layout(cald_model* m, Bump& B, FwdBufs& F, int V) {
     for (int i = 0; i < 4; i++) F.inner[i] = B.get<float>(px[2 + i] * 256);
     for (int i = 0; i < 5; i++) F.Pf[i] = B.get<float>(px[2 + i] * 256);
     for (int i = 0; i < 5; i++) F.rpn_tl[i] = B.get<float>(px[2 + i] * 256);
-    // Faster R-CNN: P2..P5 -> RPN conv (split form) + RoIAlign (fp32): both forms, written by the MFMA-bound 3 x 3 output convs.  P6 (a
-    // strided copy of P5) stays fp32: the grouped RPN conv splits it in its loader, as before.  Laterals stay fp32 (see RetinaNet above).
+    // Faster R-CNN: P2..P5 -> RPN conv (split form) + RoIAlign (fp32): both forms, written by the MFMA-bound 3 x 3 output convs.  P6 is a
+    // strided pixel copy of P5 -- a pixel's 1 KB is copied whole, so the copy of the split twin IS the split form of P6 (only the RPN
+    // conv reads it).  Laterals: split form only.
+    for (int i = 0; i < 4; i++) only(F.inner[i]);
     for (int i = 0; i < 4; i++) both(F.Pf[i], F.Pf16[i], px[2 + i] * 256);
+    only(F.Pf[4]);
     for (int i = 0; i < 5; i++) F.rpn_h[i] = B.get<float>(px[2 + i] * 15);
     const int pre = m->cfg.rpn_pre_nms_top_n;
     F.cand_key = B.get<unsigned long long>((size_t)V * 5 * pre);
@@ -1087,7 +1102,11 @@ static int forward_model(cald_model* m, int V, ViewDesc* views, const DetBuffers
         for (int i = 0; i < 4; i++) sp[i] = {&m->fpn_layer[i], F.inner[i], F.Pf[i], 2 + i, false};
         if ((rc = conv_group_on(m, sp, 4, V))) return rc;
     }
-    launch_subsample2(F.Pf[3], F.Pf[4], dp->seg[5], dp->seg[6], 256, V, max_pix6, st);
+    {   // LastLevelMaxPool: max_pool2d(P5, 1, 2) = every other pixel of every other row; in F16X3 the copy runs on P5's split twin
+        auto tw = m->split.find(F.Pf[3]);
+        const bool p6_split = m->split.count(F.Pf[4]) != 0 && tw != m->split.end();
+        launch_subsample2(p6_split ? reinterpret_cast<const float*>(tw->second.s16) : F.Pf[3], F.Pf[4], dp->seg[5], dp->seg[6], 256, V, max_pix6, st);
+    }
     const char* pn[5] = {"P2", "P3", "P4", "P5", "P6"};
     for (int i = 0; i < 5; i++) m->dbg[pn[i]] = {F.Pf[i], 2 + i, 256, 0};
     // ---- RPN (row A17) ----
@@ -1177,6 +1196,21 @@ extern "C" int cald_debug_tensor(cald_model* m, const char* name, int view, floa
     if (n > capacity) return fail(CALD_ERR_INVALID, "buffer too small: need %lld floats", (long long)n);
     HIPCHK(hipStreamSynchronize(m->ctx->stream));
     HIPCHK(hipMemcpy(host_out, e.ptr + s.pix_off * e.C, n * sizeof(float), hipMemcpyDeviceToHost));
+    auto sp = m->split.find(e.ptr);
+    if (sp != m->split.end() && sp->second.fp32_dead) {
+        // CALD_PRECISION_F16X3: the tensor exists in split form only (h16.h: per 16-channel chunk [16 fp16 hi | 16 fp16 lo] of 16 x, in
+        // the buffer the fp32 tensor would have used) -- hand out the values, not the raw words
+        if (e.C % 16) return fail(CALD_ERR_STATE, "split-form tensor '%s' with %d channels", name, e.C);
+        std::vector<float> dec((size_t)n);
+        const unsigned char* raw = reinterpret_cast<const unsigned char*>(host_out);
+        for (int64_t p = 0; p < n / e.C; p++)
+            for (int c = 0; c < e.C; c++) {
+                const unsigned char* b = raw + ((size_t)p * e.C + (c & ~15)) * 4 + (c & 15) * 2;
+                _Float16 hi, lo; memcpy(&hi, b, 2); memcpy(&lo, b + 32, 2);
+                dec[(size_t)p * e.C + c] = ((float)hi + (float)lo) * 0.0625f;
+            }
+        memcpy(host_out, dec.data(), (size_t)n * sizeof(float));
+    }
     return 0;
 }
 

@@ -61,11 +61,13 @@ struct ConvArgs {
     // conv_stem.hip: the 7 x 7 / 2 stem's weights packed [20 quads of k-pairs][2 h][64 n][4] over the 154-slot chain (7 filter rows x
     // (21 (kw, c) taps + 1 zero slot)); set only when every view's output is an exact grid of 8 x 16 blocks, else null
     const float* wstem;
-    // CALD_PRECISION_F16X3 only (conv_h3.hip): the split form of an activation tensor, element for element beside (or instead of) the
-    // fp32 one: one 32-bit word per element = fp16 hi | fp16 lo << 16 of 16 x (the kernel's operand scale).  A producer that writes it
-    // (out16; `out` may then be null) saves every consumer (in16) the split arithmetic in its k-loop.  Null = fp32 only.
+    // CALD_PRECISION_F16X3 only (conv_h3.hip / conv_h4.hip): the split form of an activation tensor (h16.h: per 16-channel chunk
+    // [16 fp16 hi | 16 fp16 lo] of 16 x, the same 4 bytes per element as fp32), beside or instead of the fp32 one.  A producer that
+    // writes it (out16; `out` may then be null) saves every consumer (in16) the split arithmetic in its k-loop, and lets conv_h4.hip
+    // move operands HBM -> LDS with buffer_load ... lds.  Null = fp32 only.
     const unsigned* in16;
     unsigned* out16;
+    int ex16;              // `residual` / `up` point at a split-form tensor (same element count) instead of an fp32 one
 };
 
 // Several independent conv problems in ONE launch (the five FPN levels under the shared-weight RPN / RetinaNet heads, the

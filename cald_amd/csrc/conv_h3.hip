@@ -24,7 +24,7 @@
 // row) is one ds_read_b128, 16-byte halves XOR-swizzled with bit 3 of the row (conflict-free).  Two tile buffers,
 // one barrier per k-tile: the fragments of tile t+1 are read right after the barrier of tile t, under the
 // a_hi*b_hi MFMAs of tile t.
-#include "common.h"
+#include "h16.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -60,7 +60,8 @@ __device__ __forceinline__ void conv_h3_body(const ConvArgs& a, const int blk) {
     if (a.dyn_rows) { const int d = a.dyn_rows[v]; Mv = d < Mv ? d : Mv; }
     const int m0 = (mt - so.tile_start) * BM;
     if (m0 >= Mv) return;
-    // pre-split input (one word per element, same indexing as fp32): the loader fetches the same offsets from the other tensor
+    // pre-split input (h16.h: [16 hi | 16 lo] per 16-channel chunk, the fp32 tensor's byte offsets): the loader fetches the same offsets;
+    // its 16 bytes are then one 16-byte half of the hi or the lo plane of the LDS tile -- no arithmetic, one ds_write_b128
     const bool in16 = !C4 && a.in16 != nullptr;
     const float* __restrict__ in_v = (in16 ? reinterpret_cast<const float*>(a.in16) : a.in) + si.pix_off * (long long)a.Cin;
     const int Cin = a.Cin, KW = a.KW, KH = a.KH, CoutPad = a.CoutPad;
@@ -97,6 +98,12 @@ __device__ __forceinline__ void conv_h3_body(const ConvArgs& a, const int blk) {
     for (int p = 0; p < 2; p++) {
         const int r = arow + 64 * p;
         aw_off[p] = r * 32 + (((g >> 1) ^ ((r >> 3) & 1)) * 16) + (g & 1) * 8;
+    }
+    int aw16_off[2];   // pre-split input: piece g -> plane g >> 1, 16-byte half g & 1 (same swizzle)
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        const int r = arow + 64 * p;
+        aw16_off[p] = (g >> 1) * PLANE + r * 32 + (((g & 1) ^ ((r >> 3) & 1)) * 16);
     }
     // B: plane p (hi, lo) x n_l x 16-byte half.  TN = 2: two 16-byte pieces per thread (plane 0 and 1);
     // TN = 1: one piece per thread (plane = tid >> 7)
@@ -140,18 +147,9 @@ __device__ __forceinline__ void conv_h3_body(const ConvArgs& a, const int blk) {
             _Pragma("unroll") for (int q = 0; q < 4; q++) { ra0[q] = ra0[q] < 0.f ? 0.f : ra0[q]; ra1[q] = ra1[q] < 0.f ? 0.f : ra1[q]; } \
         }                                                                                                  \
         unsigned char* tb = smem + (BUF) * TILE_B;                                                         \
-        if (in16) {   /* words {hi, lo} of four consecutive channels -> the hi quad and the lo quad: four byte permutes */ \
-            const i32x4 w0 = __builtin_bit_cast(i32x4, ra0), w1 = __builtin_bit_cast(i32x4, ra1);          \
-            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));                                    \
-            u32x2 hi0, lo0, hi1, lo1;                                                                      \
-            hi0[0] = __builtin_amdgcn_perm(w0[1], w0[0], 0x05040100u); hi0[1] = __builtin_amdgcn_perm(w0[3], w0[2], 0x05040100u); \
-            lo0[0] = __builtin_amdgcn_perm(w0[1], w0[0], 0x07060302u); lo0[1] = __builtin_amdgcn_perm(w0[3], w0[2], 0x07060302u); \
-            hi1[0] = __builtin_amdgcn_perm(w1[1], w1[0], 0x05040100u); hi1[1] = __builtin_amdgcn_perm(w1[3], w1[2], 0x05040100u); \
-            lo1[0] = __builtin_amdgcn_perm(w1[1], w1[0], 0x07060302u); lo1[1] = __builtin_amdgcn_perm(w1[3], w1[2], 0x07060302u); \
-            *reinterpret_cast<u32x2*>(tb + aw_off[0]) = hi0;                                               \
-            *reinterpret_cast<u32x2*>(tb + PLANE + aw_off[0]) = lo0;                                       \
-            *reinterpret_cast<u32x2*>(tb + aw_off[1]) = hi1;                                               \
-            *reinterpret_cast<u32x2*>(tb + PLANE + aw_off[1]) = lo1;                                       \
+        if (in16) {   /* split form (h16.h): this thread's 16 bytes are piece g of the row's 64-byte chunk = half g & 1 of plane g >> 1 */ \
+            *reinterpret_cast<f32x4*>(tb + aw16_off[0]) = ra0;                                             \
+            *reinterpret_cast<f32x4*>(tb + aw16_off[1]) = ra1;                                             \
         } else {                                                                                           \
         ra0 = ra0 * 16.0f; ra1 = ra1 * 16.0f;                                                              \
         const h4 hi0 = __builtin_convertvector(ra0, h4), hi1 = __builtin_convertvector(ra1, h4);           \
@@ -234,66 +232,8 @@ __device__ __forceinline__ void conv_h3_body(const ConvArgs& a, const int blk) {
 #undef H3_MFMA
 #undef H3_TILE
 
-    // ---- fused fp32 epilogue: the same operations as conv_p4.hip ----
-    const int out_ld = a.out_ld;
-    float* __restrict__ out_v = a.out ? a.out + so.pix_off * (long long)out_ld : nullptr;
-    unsigned* __restrict__ out16_v = a.out16 ? a.out16 + so.pix_off * (long long)out_ld : nullptr;
-    const float* __restrict__ ex_v = nullptr;
-    int upH = 1, upW = 1;
-    float uph_s = 0.f, upw_s = 0.f;
-    if (EPI == 1) ex_v = a.residual + so.pix_off * (long long)out_ld;
-    if (EPI == 2) {
-        const LevelSeg su = a.seg_up[v];
-        ex_v = a.up + su.pix_off * (long long)out_ld;
-        upH = su.H; upW = su.W;
-        uph_s = (float)upH / (float)Ho; upw_s = (float)upW / (float)Wo;
-    }
-    const bool relu = a.relu != 0;
-    const int Mlast = Mv - 1;
-    const float unscale = a.w16_unscale;
-#pragma unroll
-    for (int j = 0; j < TN; j++) {
-        const int n = n0 + wn * TN * 32 + j * 32 + l31;
-        const bool nok = n < a.Cout;
-        const int nc = nok ? n : 0;
-        const float bs = a.bias ? a.bias[nc] : 0.0f;
-        const float sc = a.scale ? a.scale[nc] : 1.0f;
-        const float sh = a.scale ? a.shift[nc] : 0.0f;
-#pragma unroll
-        for (int i = 0; i < TM; i++) {
-            const int mbase = m0 + wm * TM * 32 + i * 32 + 4 * kh_lane;
-            float extra[16];
-            if (EPI != 0) {
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    int m = mbase + (r & 3) + 8 * (r >> 2);
-                    m = m < Mlast ? m : Mlast;
-                    if (EPI == 1) {
-                        extra[r] = ex_v[(long long)m * out_ld + nc];
-                    } else {
-                        const int oy = m / Wo, ox = m - oy * Wo;
-                        int sy = (int)floorf((float)oy * uph_s); sy = sy > upH - 1 ? upH - 1 : sy;
-                        int sx = (int)floorf((float)ox * upw_s); sx = sx > upW - 1 ? upW - 1 : sx;
-                        extra[r] = ex_v[(long long)(sy * upW + sx) * out_ld + nc];
-                    }
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int m = mbase + (r & 3) + 8 * (r >> 2);
-                float val = acc[i][j][r] * unscale;
-                val = val + bs;
-                val = val * sc;
-                val = val + sh;
-                if (EPI != 0) val = val + extra[r];
-                if (relu) val = val > 0.0f ? val : 0.0f;
-                if (m < Mv && nok) {
-                    if (out_v) out_v[(long long)m * out_ld + n] = val;
-                    if (out16_v) out16_v[(long long)m * out_ld + n] = split16_word(val);
-                }
-            }
-        }
-    }
+    // ---- fused fp32 epilogue (h16.h): the same operations as conv_p4.hip, fp32 and / or split-form stores ----
+    h16_epilogue<EPI, TM, TN>(a, acc, so, v, m0 + wm * TM * 32, n0 + wn * TN * 32, Mv, lane);
 }
 
 template <int EPI, int TN, bool C4>
@@ -322,7 +262,7 @@ bool launch_conv_h3_group(const ConvArgs* p, int n, hipStream_t stream) {
 
 // returns true if this variant handled the launch
 bool launch_conv_h3(const ConvArgs& a, hipStream_t stream) {
-    if (!a.w16 || a.CoutPad % 64 != 0) return false;
+    if (!a.w16 || a.CoutPad % 64 != 0 || (a.in16 && a.in_relu)) return false;
     dim3 block(256);
     if (a.Cin == 4) {      // stem conv (7 x 7, NHWC4 input): per-thread taps
         if (a.residual || a.up || a.in_relu) return false;

@@ -287,12 +287,15 @@ bool launch_conv_i3_group(const ConvArgs* p, int n, hipStream_t stream);
 
 bool launch_conv_p4_group(const ConvArgs* p, int n, hipStream_t stream);
 bool launch_conv_h3_group(const ConvArgs* p, int n, hipStream_t stream);
+bool launch_conv_h4(const ConvArgs& a, hipStream_t stream);   // conv_h4.hip (the 256 x 256 LDS-DMA kernel of the same mode, where it fills the chip)
+bool launch_conv_h4_group(const ConvArgs* p, int n, hipStream_t stream);
 void launch_conv(const ConvArgs& a, hipStream_t stream);
 int launch_conv_group(const ConvArgs* probs, int n, hipStream_t stream) {   // returns the number of kernel launches issued
     static const int grp = conv_env("CALD_CONV_GROUP", 1);
     static const int p4 = conv_env("CALD_CONV_P4", 1);
     if (grp && n > 1) {
         if (probs[0].w8 && probs[0].i8_in && launch_conv_i3_group(probs, n, stream)) return 1;
+        if (probs[0].w16 && launch_conv_h4_group(probs, n, stream)) return 1;
         if (probs[0].w16 && launch_conv_h3_group(probs, n, stream)) return 1;
         if (!probs[0].w16 && !(probs[0].w8 && probs[0].i8_in) && p4 && launch_conv_p4_group(probs, n, stream)) return 1;
     }
@@ -303,6 +306,7 @@ int launch_conv_group(const ConvArgs* probs, int n, hipStream_t stream) {   // r
 void launch_conv(const ConvArgs& a, hipStream_t stream) {
     static const int p4 = conv_env("CALD_CONV_P4", 1);   // conv_p4.hip: 3-buffer pipelined schedule, 128-bit LDS fragment reads; 0 = this file only
     if (a.w8 && a.i8_in && launch_conv_i3(a, stream)) return;
+    if (a.w16 && launch_conv_h4(a, stream)) return;
     if (a.w16 && launch_conv_h3(a, stream)) return;
     static const int stem = conv_env("CALD_CONV_STEM", 1);   // 0: the stem runs on the generic kernels (same bits)
     if (stem && a.wstem && launch_conv_stem(a, stream)) return;

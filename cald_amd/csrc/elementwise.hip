@@ -7,6 +7,7 @@
 // GeneralizedRCNNTransform constructed at detection/frcnn_la.py:230-234.
 #include "common.h"
 #include "kernels.h"
+#include "h16.h"
 
 // ---------------------------------------------------------------------------------------------
 // One view: uint8 HWC source -> (flip | cutout rectangles) -> /255 -> (x-mean)/std -> bilinear
@@ -163,7 +164,7 @@ void launch_pil_vertical(const uint8_t* src, int H, int W, uint8_t* dst, int oh,
 // max_pool2d(3, 2, 1) NHWC, C % 4 == 0; grid = (ceil(maxHo*maxWo*C/4/256), V)
 // ---------------------------------------------------------------------------------------------
 __device__ inline float nanmax(float m, float v) { return (v > m || v != v) ? v : m; }
-// out16 != 0: the pooled tensor is stored in the split form conv_h3.hip consumes (one word per element, ConvArgs::in16) instead of fp32
+// out16 != 0: the pooled tensor is stored in the split form conv_h3.hip / conv_h4.hip consume (h16.h, ConvArgs::in16) instead of fp32
 __global__ __launch_bounds__(256) void maxpool_kernel(const float* in, float* out, const LevelSeg* sin, const LevelSeg* sout, int C, int out16) {
     const int v = blockIdx.y;
     const LevelSeg si = sin[v], so = sout[v];
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const float* in, float* ou
             const float4 t = ip[(long long)(iy * si.W + ix) * C4 + c4];
             m.x = nanmax(m.x, t.x); m.y = nanmax(m.y, t.y); m.z = nanmax(m.z, t.z); m.w = nanmax(m.w, t.w);
         }
-    if (out16) reinterpret_cast<uint4*>(out + so.pix_off * C)[e] = split16_word4(m);
+    if (out16) h16_store4(reinterpret_cast<unsigned char*>(out + (so.pix_off + pix) * C), 4 * c4, m);
     else reinterpret_cast<float4*>(out + so.pix_off * C)[e] = m;
 }
 void launch_maxpool(const float* in, float* out, const LevelSeg* sin, const LevelSeg* sout, int C, int V, int max_out_pix,

@@ -7,6 +7,7 @@
 //     gather of scores_cls / prob_max / props, rescale to the original image.
 #include "common.h"
 #include "kernels.h"
+#include "h16.h"
 #include "sortnms.h"
 
 // Processing order of a view's RoIs.  Proposals arrive in score order, i.e. scattered over the image and the pyramid: with one
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(256) void roi_align_kernel(RoiArgs a) {
             }
         }
         const float4 res = make_float4(acc.x / 4.0f, acc.y / 4.0f, acc.z / 4.0f, acc.w / 4.0f);
-        if (a.out16) reinterpret_cast<uint4*>(out)[idx] = split16_word4(res);
+        if (a.out16) h16_store4(reinterpret_cast<unsigned char*>(out + (long long)bin * Cq), 4 * q, res);
         else out[idx] = res;
     }
 }
@@ -176,7 +177,7 @@ __device__ __forceinline__ void roi_rows_walk(const float4* const f, const int W
         acc.x = acc.x + s11.x; acc.y = acc.y + s11.y; acc.z = acc.z + s11.z; acc.w = acc.w + s11.w;
         const float4 res = make_float4(acc.x / 4.0f, acc.y / 4.0f, acc.z / 4.0f, acc.w / 4.0f);
         const int idx = (ph * 7 + pw) * 64 + q;
-        if (out16) reinterpret_cast<uint4*>(out)[idx] = split16_word4(res);
+        if (out16) h16_store4(reinterpret_cast<unsigned char*>(out + (ph * 7 + pw) * 64), 4 * q, res);
         else out[idx] = res;
     }
 #undef ROI_COPY

@@ -46,18 +46,31 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // ---------------------------------------------------------------------------------------------------------------------
 static std::mutex g_seg_mu;
 static std::map<std::tuple<cald_ctx*, int, int, int>, LevelSeg*> g_seg;
+static bool g_seg_evict = false;      // the cache went over its bound: empty it at the NEXT entry point, never inside one
+static size_t seg_cache_cap() {       // CALD_SEG_CACHE_CAP: tests lower it to exercise the eviction
+    static const size_t cap = [] { const char* e = getenv("CALD_SEG_CACHE_CAP"); const long v = e ? atol(e) : 0; return (size_t)(v > 0 ? v : 1024); }();
+    return cap;
+}
+// A public entry point takes several tables from consecutive dense_seg() calls (input / output / up-sampling geometry, s0 plus five
+// pyramid levels, ...) before it launches anything, so a table must never be freed while an entry point is running: dense_seg() only
+// flags the overflow (the cache then exceeds its bound by the few tables of one call), and the NEXT entry point that uses tables
+// empties the cache first thing -- after the launches that may still read the old tables have drained; a rare, synchronous event.
+static int seg_entry() {
+    std::lock_guard<std::mutex> lk(g_seg_mu);
+    if (!g_seg_evict) return 0;
+    THIP(hipDeviceSynchronize());
+    for (auto& kv : g_seg) hipFree(kv.second);
+    g_seg.clear();
+    g_seg_evict = false;
+    return 0;
+}
+#define SEG_ENTRY() do { const int rc_ = seg_entry(); if (rc_) return rc_; } while (0)
 static int dense_seg(cald_ctx* c, int N, int H, int W, const LevelSeg** out) {
     std::lock_guard<std::mutex> lk(g_seg_mu);
     auto key = std::make_tuple(c, N, H, W);
     auto it = g_seg.find(key);
     if (it == g_seg.end()) {
-        if (g_seg.size() >= 1024) {
-            // bound the cache (a long run over variable padded sizes x pyramid levels x contexts would otherwise keep allocating): drop
-            // everything once the launches that may still read a table have drained -- a rare, synchronous event
-            THIP(hipDeviceSynchronize());
-            for (auto& kv : g_seg) hipFree(kv.second);
-            g_seg.clear();
-        }
+        if (g_seg.size() >= seg_cache_cap()) g_seg_evict = true;   // a long run over variable padded sizes x pyramid levels x contexts
         std::vector<LevelSeg> h(N + 1);
         const int tiles = (H * W + 127) / 128;
         for (int v = 0; v <= N; v++) { h[v].pix_off = (long long)v * H * W; h[v].H = H; h[v].W = W; h[v].tile_start = v * tiles; h[v].pad_ = 0; }
@@ -70,6 +83,7 @@ static int dense_seg(cald_ctx* c, int N, int H, int W, const LevelSeg** out) {
     return 0;
 }
 
+extern "C" int cald_train_seg_cache_size(void) { std::lock_guard<std::mutex> lk(g_seg_mu); return (int)g_seg.size(); }
 void cald_internal_train_release(cald_ctx* c) {
     std::lock_guard<std::mutex> lk(g_seg_mu);
     for (auto it = g_seg.begin(); it != g_seg.end();) {
@@ -212,6 +226,7 @@ extern "C" int cald_train_conv(cald_ctx* c, int N, int H, int W, const float* in
     if (!c || !in || !packed || !out) TFAIL(CALD_ERR_INVALID, "null argument");
     if (N < 1 || H < 1 || W < 1 || stride < 1) TFAIL(CALD_ERR_INVALID, "bad geometry");
     THIP(hipSetDevice(cald_internal_device(c)));
+    SEG_ENTRY();
     const PackGeom g = pack_geom(Cout, Cin, KH, KW, CinK, mode);
     const int kh = mode >= 2 ? 1 : KH, kw = mode >= 2 ? 1 : KW;
     const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
@@ -252,6 +267,7 @@ extern "C" int cald_train_conv_group(cald_ctx* c, int n, int N, const int* hw, c
     if (!c || !hw || !ins || !packed || !outs) TFAIL(CALD_ERR_INVALID, "null argument");
     if (n < 1 || n > CALD_MAX_GROUP) TFAIL(CALD_ERR_INVALID, "1..%d problems per group", CALD_MAX_GROUP);
     THIP(hipSetDevice(cald_internal_device(c)));
+    SEG_ENTRY();
     const PackGeom g = pack_geom(Cout, Cin, KH, KW, CinK, mode);
     const int kh = mode >= 2 ? 1 : KH, kw = mode >= 2 ? 1 : KW;
     if (out_ld < g.n_true) TFAIL(CALD_ERR_INVALID, "out_ld < Cout");
@@ -811,6 +827,7 @@ extern "C" int cald_train_rpn_proposals(cald_ctx* c, int N, int Hp, int Wp, cons
     if (!c || !image_sizes || !heads || !level_hw || !proposals_out || !counts_out) TFAIL(CALD_ERR_INVALID, "null argument");
     if (N < 1 || N > CALD_MAX_VIEWS || pre_n < 1 || pre_n > 2048 || post_n < 1 || post_n > 2048) TFAIL(CALD_ERR_INVALID, "N <= %d, pre/post top-n <= 2048", CALD_MAX_VIEWS);
     THIP(hipSetDevice(cald_internal_device(c)));
+    SEG_ENTRY();
     hipStream_t st = cald_internal_stream(c);
     RpnArgs ra; memset(&ra, 0, sizeof(ra));
     const LevelSeg* s0;
@@ -1346,6 +1363,7 @@ extern "C" int cald_train_preprocess(cald_ctx* c, int N, const uint8_t* const* i
     if (!c || !images || !hw || !out) TFAIL(CALD_ERR_INVALID, "null argument");
     if (N < 1 || N > CALD_MAX_VIEWS) TFAIL(CALD_ERR_INVALID, "N must be 1..%d", CALD_MAX_VIEWS);
     THIP(hipSetDevice(cald_internal_device(c)));
+    SEG_ENTRY();
     hipStream_t st = cald_internal_stream(c);
     std::vector<ViewDesc> hv(N);
     memset(hv.data(), 0, sizeof(ViewDesc) * N);
@@ -1369,6 +1387,7 @@ extern "C" int cald_train_preprocess(cald_ctx* c, int N, const uint8_t* const* i
 extern "C" int cald_train_maxpool(cald_ctx* c, int N, int H, int W, int C, const float* in, float* out) {
     if (!c || !in || !out || C % 4) TFAIL(CALD_ERR_INVALID, "bad arguments");
     THIP(hipSetDevice(cald_internal_device(c)));
+    SEG_ENTRY();
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     const LevelSeg *si, *so;
     if (int rc = dense_seg(c, N, H, W, &si)) return rc;
@@ -1381,6 +1400,7 @@ extern "C" int cald_train_maxpool(cald_ctx* c, int N, int H, int W, int C, const
 extern "C" int cald_train_subsample2(cald_ctx* c, int N, int H, int W, int C, const float* in, float* out) {
     if (!c || !in || !out || C % 4) TFAIL(CALD_ERR_INVALID, "bad arguments");
     THIP(hipSetDevice(cald_internal_device(c)));
+    SEG_ENTRY();
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     const LevelSeg *si, *so;
     if (int rc = dense_seg(c, N, H, W, &si)) return rc;

@@ -315,6 +315,9 @@ int cald_train_subsample2(cald_ctx* ctx, int N, int H, int W, int C, const float
 /* torch.optim.SGD step over a flat buffer: d = grad + wd * p; buf = first_step ? d : momentum * buf + d; p -= lr * buf */
 int cald_train_sgd(cald_ctx* ctx, long long n, float* param, const float* grad, float* momentum_buf, float lr, float momentum,
                    float weight_decay, int first_step);
+/* Number of dense-batch geometry tables the training operators keep cached on the device (all contexts).  The cache is bounded
+ * (1024 tables, CALD_SEG_CACHE_CAP overrides); it is emptied between operator calls, never inside one.  Diagnostic. */
+int cald_train_seg_cache_size(void);
 
 #ifdef __cplusplus
 }

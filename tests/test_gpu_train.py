@@ -980,3 +980,46 @@ def test_training_input_and_ordering_errors_are_loud(T):
     det.load_state_dict(sd)                                             # in train mode: the trainer is rebuilt, the next call works
     out = det(images, targets)
     assert sorted(out) == ["loss_box_reg", "loss_classifier", "loss_objectness", "loss_rpn_box_reg"]
+
+
+_SEG_CAP_SCRIPT = r"""
+import sys, json
+import numpy as np, torch
+sys.path.insert(0, %r)
+sys.path.insert(0, %r)
+from cald_amd import train, _ffi
+import test_gpu_train as tg
+out = []
+for scale, seed in ((0.4, 21), (0.3, 22), (0.4, 21)):      # three geometries' worth of tables, then the first one again
+    sd, images, targets = tg._train_case(torch, n_images=2, seed=seed, scale=scale)
+    net = train.FasterRCNNTrainer(sd, 21, min_size=160, max_size=256, generator=torch.Generator().manual_seed(5))
+    losses = net.forward(images, targets)
+    grads = net.backward()
+    torch.cuda.synchronize()
+    out.append([float(v) for v in losses.values()] + [float(g.double().abs().sum()) for g in grads.values()])
+print("RESULT " + json.dumps({"runs": out, "tables": _ffi.lib().cald_train_seg_cache_size()}))
+"""
+
+
+def test_geometry_table_cache_eviction_never_frees_inside_an_operator(T):
+    """the bounded cache of dense-batch geometry tables used to free every table from INSIDE dense_seg(), while the
+    operator that called it still held pointers from its earlier dense_seg() calls.  Eviction now happens only at the next operator's
+    entry.  With the bound lowered to 2 tables (every operator with more than two geometries overflows it) three training steps give
+    exactly the losses and gradient sums of the default bound."""
+    import json, os, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__)); root = os.path.dirname(here)
+    script = _SEG_CAP_SCRIPT % (root, here)
+
+    def run(cap):
+        env = dict(os.environ)
+        env.pop("CALD_SEG_CACHE_CAP", None)
+        if cap:
+            env["CALD_SEG_CACHE_CAP"] = str(cap)
+        r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1]
+        return json.loads(line[len("RESULT "):])
+    base, small = run(0), run(2)
+    assert small["runs"] == base["runs"]
+    assert small["runs"][0] == small["runs"][2]          # same inputs before and after the evictions in between
+    assert small["tables"] <= 16 < base["tables"]        # the bound holds up to the tables of one operator call
