@@ -826,6 +826,17 @@ ORC_API void orc_roi_align(int L, const float* const* feat, const int* fh, const
  * Outputs (<= det_max rows): boxes/props scaled back to the original image, scores, labels,
  * prob_max, scores_cls [n][C].  Returns n.
  * ------------------------------------------------------------------------------------- */
+/* frcnn_la.py:307-315 resize_boxes (called by GeneralizedRCNNTransform.postprocess :292-304 on `boxes` and `props`): the ratios are
+ * python floats (float64 quotients of the integer sizes); multiplying a float32 tensor by a python float rounds the scalar to float32
+ * first, then multiplies in float32.  Pinned to the executed reference function by tests/golden/resize_boxes.npz. */
+ORC_API void orc_resize_boxes(const float* boxes, int n, int Hr, int Wr, int Ho, int Wo, float* out) {
+    const float rh = (float)((double)Ho / (double)Hr), rw = (float)((double)Wo / (double)Wr);
+    for (int i = 0; i < n; i++) {
+        out[4 * i + 0] = boxes[4 * i + 0] * rw; out[4 * i + 1] = boxes[4 * i + 1] * rh;
+        out[4 * i + 2] = boxes[4 * i + 2] * rw; out[4 * i + 3] = boxes[4 * i + 3] * rh;
+    }
+}
+
 ORC_API int orc_frcnn_postprocess(int R, int C, const float* logits, const float* deltas, const float* proposals,
                                   int Hr, int Wr, int Ho, int Wo, float score_thr, float nms_thr, int det_max,
                                   float* o_boxes, float* o_scores, int64_t* o_labels, float* o_props,
@@ -861,13 +872,10 @@ ORC_API int orc_frcnn_postprocess(int R, int C, const float* logits, const float
         }
     int* keep = (int*)malloc(sizeof(int) * ((size_t)nc + 1));
     int nk = orc_batched_nms(cb, cs, cg, nc, nms_thr, det_max, keep);
-    float rh = (float)((double)Ho / (double)Hr), rw = (float)((double)Wo / (double)Wr);
     for (int i = 0; i < nk; i++) {
         int k = keep[i], r = cr[k];
-        o_boxes[4 * i + 0] = cb[4 * k + 0] * rw; o_boxes[4 * i + 1] = cb[4 * k + 1] * rh;
-        o_boxes[4 * i + 2] = cb[4 * k + 2] * rw; o_boxes[4 * i + 3] = cb[4 * k + 3] * rh;
-        o_props[4 * i + 0] = proposals[4 * r + 0] * rw; o_props[4 * i + 1] = proposals[4 * r + 1] * rh;
-        o_props[4 * i + 2] = proposals[4 * r + 2] * rw; o_props[4 * i + 3] = proposals[4 * r + 3] * rh;
+        orc_resize_boxes(cb + 4 * k, 1, Hr, Wr, Ho, Wo, o_boxes + 4 * i);
+        orc_resize_boxes(proposals + 4 * r, 1, Hr, Wr, Ho, Wo, o_props + 4 * i);
         o_scores[i] = cs[k]; o_labels[i] = cg[k]; o_pm[i] = pmax[r];
         memcpy(o_scls + (size_t)i * C, prob + (size_t)r * C, sizeof(float) * C);
     }

@@ -329,6 +329,14 @@ def roi_align(feats, rois):
     return out
 
 
+def resize_boxes(boxes, Hr, Wr, Ho, Wo):
+    """frcnn_la.py:307-315 (resized (Hr, Wr) -> original (Ho, Wo)); the function orc_frcnn_postprocess applies to boxes and props."""
+    boxes = f32(boxes).reshape(-1, 4)
+    out = np.empty_like(boxes)
+    lib().orc_resize_boxes(_p(boxes), C.c_int(boxes.shape[0]), C.c_int(Hr), C.c_int(Wr), C.c_int(Ho), C.c_int(Wo), _p(out))
+    return out
+
+
 def frcnn_postprocess(logits, deltas, proposals, Hr, Wr, Ho, Wo, score_thr=0.05, nms_thr=0.5, det_max=100):
     logits = f32(logits); deltas = f32(deltas); proposals = f32(proposals).reshape(-1, 4)
     R, Cc = logits.shape

@@ -1144,3 +1144,78 @@ def test_coco_evaluate_on_a_coco_tree(hip, oracle, small_model, tmp_path, capsys
     assert all(abs(float(rec[:, cat_ids.index(c)].min()) - 1.0) < 1e-12 for c in annotated)
     stats = ev.coco_eval["bbox"].stats
     assert stats[0] > 0.0 and np.all(np.isfinite(stats))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The HIP kernels against the fixtures captured from the reference's OWN detector code (oracle/make_golden_rpn.py)
+# ---------------------------------------------------------------------------------------------------------------------------
+def test_rpn_kernels_match_the_reference_filter_proposals(hip, golden):
+    """rpn.hip (anchors, decode, per-level top-k, clip, small-box removal, level-batched NMS, first post_n) against the outputs of
+    detection/frcnn_ll.py:284-374 executed from the reference tree: the selection (raw logits in order) exactly, boxes to 1e-4."""
+    torch = hip["torch"]
+    from cald_amd import train_ops
+    g = golden("rpn_filter")
+    seen = 0
+    for name in [str(n) for n in g["names"]]:
+        Hp, Wp, Hr, Wr, pre, post = [int(v) for v in g[name + "_cfg"]]
+        if name == "pad":
+            continue                                                   # frcnn_ll's zero padding: not on the hot path (see the CPU test)
+        heads = []
+        for l in range(5):
+            h = g["%s_head%d" % (name, l)]
+            h16 = np.zeros(h.shape[:2] + (16,), np.float32); h16[:, :, :15] = h
+            heads.append(torch.from_numpy(h16)[None].cuda().contiguous())
+        props, counts = train_ops.rpn_proposals(heads, Hp, Wp, [(Hr, Wr)], pre_n=pre, post_n=post, nms_thr=0.7, min_size=1e-3)
+        n = int(counts[0])
+        want = g[name + "_boxes"]
+        assert n == len(want), (name, n, len(want))
+        np.testing.assert_allclose(props[0, :n].cpu().numpy(), want, rtol=0, atol=1e-4, err_msg=name)
+        seen += 1
+    assert seen >= 6
+
+
+def test_retinanet_head_convs_match_the_reference_modules(hip, golden):
+    """The tower / output convolutions of RetinaNet's heads on the HIP conv kernels against the reference's nn.Modules
+    (retinanet_cal.py:57-62, :135-151, :225-241) run as they lie: layout (y, x, a) x k and the tower order."""
+    ffi, L = hip["ffi"], hip["L"]
+    g = golden("retina_heads")
+
+    def conv(x, w, b, relu):
+        H, W_, Cin = x.shape
+        Cout = w.shape[0]
+        cin_p = (Cin + 3) // 4 * 4
+        out = np.empty((H, W_, Cout), np.float32)
+        xp = np.zeros((H, W_, cin_p), np.float32); xp[:, :, :Cin] = x
+        wp = np.zeros((Cout, cin_p, 3, 3), np.float32); wp[:, :Cin] = w
+        ffi.check(L.cald_op_conv2d(hip["ctx"], ffi.ptr(xp), H, W_, cin_p, ffi.ptr(wp), Cout, 3, 3, 1, 1, ffi.ptr(np.ascontiguousarray(b, np.float32)),
+                                   None, None, None, int(relu), ffi.ptr(out)))
+        return out
+    for k in range(int(g["n"])):
+        cin, K, nl = [int(v) for v in g["h%d_cfg" % k]]
+        W = lambda n: g["h%d_w_%s" % (k, n)]
+        cls_rows, reg_rows = [], []
+        for l in range(nl):
+            x = np.ascontiguousarray(g["h%d_feat%d" % (k, l)][1].transpose(1, 2, 0))        # image 1 of the batch
+            t = x
+            for i in range(4):
+                t = conv(t, W("classification_head.conv.%d.weight" % (2 * i)), W("classification_head.conv.%d.bias" % (2 * i)), True)
+            cls_rows.append(conv(t, W("classification_head.cls_logits.weight"), W("classification_head.cls_logits.bias"), False).reshape(-1, K))
+            t = x
+            for i in range(4):
+                t = conv(t, W("regression_head.conv.%d.weight" % (2 * i)), W("regression_head.conv.%d.bias" % (2 * i)), True)
+            reg_rows.append(conv(t, W("regression_head.bbox_reg.weight"), W("regression_head.bbox_reg.bias"), False).reshape(-1, 4))
+        want_c, want_r = g["h%d_cls_logits" % k][1], g["h%d_bbox_regression" % k][1]
+        np.testing.assert_allclose(np.concatenate(cls_rows), want_c, rtol=0, atol=1e-5 * float(np.abs(want_c).max()))
+        np.testing.assert_allclose(np.concatenate(reg_rows), want_r, rtol=0, atol=1e-5 * float(np.abs(want_r).max()))
+    # the anchor table the library builds at finalize (api.hip) from the sizes of retinanet_cal.py:346-351
+    torch = hip["torch"]
+    from cald_amd import train_ops
+    sizes = g["anchor_sizes"]
+    got = train_ops.anchors(64, 64, [(1, 1)] * 5, torch.device("cuda", 0), kind=1).cpu().numpy().reshape(5, 9, 4)
+    for l in range(5):
+        for r, ratio in enumerate((0.5, 1.0, 2.0)):
+            hr = np.sqrt(np.float32(ratio)); wr = np.float32(1.0) / hr
+            for s in range(3):
+                ws, hs = wr * np.float32(sizes[l, s]), hr * np.float32(sizes[l, s])
+                want = np.array([np.rint(-ws / 2), np.rint(-hs / 2), np.rint(ws / 2), np.rint(hs / 2)], np.float32)
+                np.testing.assert_array_equal(got[l, r * 3 + s], want)

@@ -153,3 +153,79 @@ def test_postprocess_bookkeeping_matches_reference_bodies(oracle, golden):
         for n in ("scores", "prob_max", "scores_cls"):
             np.testing.assert_allclose(got[n], want[n].reshape(got[n].shape), rtol=0, atol=1e-5)
         np.testing.assert_allclose(got["boxes"], want["boxes"], rtol=0, atol=1e-3)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Detector code that lives in the reference repo itself, executed under the stub harness (oracle/make_golden_rpn.py): the RPN's
+# concat / filter / forward (detection/frcnn_ll.py:207-238, :284-321, :323-374), RetinaNet's heads and default anchor sizes
+# (detection/retinanet_cal.py:57-62, :135-151, :225-241, :346-351), resize_boxes (detection/frcnn_la.py:292-315).
+# ---------------------------------------------------------------------------------------------------------------------------
+def _rpn_cases(g):
+    for name in [str(n) for n in g["names"]]:
+        Hp, Wp, Hr, Wr, pre, post = [int(v) for v in g[name + "_cfg"]]
+        yield name, [g["%s_head%d" % (name, l)] for l in range(5)], (Hp, Wp, Hr, Wr, pre, post)
+
+
+def test_rpn_layout_and_filter_match_the_reference_code(oracle, golden):
+    g = golden("rpn_filter")
+    base = g["base"].reshape(5, 3, 4)
+    seen = 0
+    for name, heads, (Hp, Wp, Hr, Wr, pre, post) in _rpn_cases(g):
+        # concat_box_prediction_layers: row (level, y, x, a) of the flattened tensors is channel a / 3 + 4 a + j of the NHWC head the
+        # oracle (and rpn.hip) read -- the (N, A * C, H, W) -> (N * HWA, C) permutation, by the reference's own function
+        flat_l = np.concatenate([h[:, :, :3].reshape(-1) for h in heads]); flat_d = np.concatenate([h[:, :, 3:].reshape(-1, 4) for h in heads])
+        np.testing.assert_array_equal(g[name + "_flat_logits"].reshape(-1), flat_l)
+        np.testing.assert_array_equal(g[name + "_flat_deltas"], flat_d)
+        boxes, scores = oracle.rpn_proposals(heads, base, Hp, Wp, Hr, Wr, A=3, pre_n=pre, post_n=post, nms_thr=0.7, min_size=1e-3)
+        want_b, want_s = g[name + "_boxes"], g[name + "_scores"]
+        if name == "pad":
+            # frcnn_ll.py:314-316 (the learning-loss baseline's copy) returns post_nms_top_n all-zero boxes when fewer survive; stock
+            # torchvision -- what the hot path's frcnn_la.py instantiates -- returns the survivors.  The oracle follows the hot path.
+            assert want_b.shape == (post, 4) and not want_b.any() and 0 < len(boxes) < post
+            continue
+        assert len(boxes) == len(want_b) == min(post, len(want_b)), name
+        np.testing.assert_array_equal(scores, want_s, err_msg=name)            # raw logits gathered in selection order: same anchors, same order
+        np.testing.assert_allclose(boxes, want_b, rtol=0, atol=1e-4, err_msg=name)   # exp(): fixed polynomial here, libm there
+        seen += 1
+    assert seen >= 6
+
+
+def test_retinanet_heads_match_the_reference_modules(oracle, golden):
+    g = golden("retina_heads")
+    kmaj = lambda w: np.ascontiguousarray(w.transpose(2, 3, 1, 0).reshape(-1, w.shape[0]))
+    for k in range(int(g["n"])):
+        cin, K, L = [int(v) for v in g["h%d_cfg" % k]]
+        W = lambda n: g["h%d_w_%s" % (k, n)]
+        cls_rows, reg_rows = [[], []], [[], []]
+        for l in range(L):
+            feats = g["h%d_feat%d" % (k, l)]                                   # [N][C][H][W]
+            for n in range(feats.shape[0]):
+                x = np.ascontiguousarray(feats[n].transpose(1, 2, 0))
+                t = x
+                for i in range(4):
+                    t = oracle.conv2d(t, kmaj(W("classification_head.conv.%d.weight" % (2 * i))), 3, 3, 1, 1, bias=W("classification_head.conv.%d.bias" % (2 * i)), relu=True)
+                c = oracle.conv2d(t, kmaj(W("classification_head.cls_logits.weight")), 3, 3, 1, 1, bias=W("classification_head.cls_logits.bias"))
+                t = x
+                for i in range(4):
+                    t = oracle.conv2d(t, kmaj(W("regression_head.conv.%d.weight" % (2 * i))), 3, 3, 1, 1, bias=W("regression_head.conv.%d.bias" % (2 * i)), relu=True)
+                r = oracle.conv2d(t, kmaj(W("regression_head.bbox_reg.weight")), 3, 3, 1, 1, bias=W("regression_head.bbox_reg.bias"))
+                cls_rows[n].append(c.reshape(-1, K)); reg_rows[n].append(r.reshape(-1, 4))      # NHWC channel a * K + k  ->  row (y, x, a), column k
+        for n in range(2):
+            got_c, got_r = np.concatenate(cls_rows[n]), np.concatenate(reg_rows[n])
+            want_c, want_r = g["h%d_cls_logits" % k][n], g["h%d_bbox_regression" % k][n]
+            assert got_c.shape == want_c.shape and got_r.shape == want_r.shape
+            np.testing.assert_allclose(got_c, want_c, rtol=0, atol=1e-5 * float(np.abs(want_c).max()))
+            np.testing.assert_allclose(got_r, want_r, rtol=0, atol=1e-5 * float(np.abs(want_r).max()))
+    # RetinaNet.__init__ (retinanet_cal.py:346-355): anchor sizes, nine anchors per location, K * 9 classification outputs
+    assert [tuple(int(v) for v in row) for row in g["anchor_sizes"]] == [tuple(s) for s in oracle.retina_anchor_sizes()]
+    assert g["aspect_ratios"].tolist() == [[0.5, 1.0, 2.0]] * 5 and g["anchors_per_location"].tolist() == [9] * 5
+    assert int(g["init_cls_out_channels"]) == 9 * 4 and g["init_thresholds"].tolist() == [0.05, 0.5, 300.0]
+
+
+def test_resize_boxes_matches_the_reference_function(oracle, golden):
+    g = golden("resize_boxes")
+    for k in range(int(g["n"])):
+        Hr, Wr, Ho, Wo = [int(v) for v in g["r%d_sizes" % k]]
+        assert (Hr, Wr) != (Ho, Wo)
+        np.testing.assert_array_equal(oracle.resize_boxes(g["r%d_boxes" % k], Hr, Wr, Ho, Wo), g["r%d_out_boxes" % k])
+        np.testing.assert_array_equal(oracle.resize_boxes(g["r%d_props" % k], Hr, Wr, Ho, Wo), g["r%d_out_props" % k])
