@@ -154,23 +154,36 @@ def cpu_baseline(sd, blobs, augs, positions, gpu_scores, budget_s=48.0, max_imag
                       "scoring loop (oracle/torch_port.py), %.1f s; thread count chosen as the fastest of {T, T/2, T/4, T/8}" % (n, dt)}
 
 
+def csrc_sha1():
+    """Content hash of the kernel sources the library is built from (cald_amd/csrc/*.hip, *.h, Makefile), file names included.
+    Stands where `git rev-parse HEAD:cald_amd/csrc` would: the GPU box receives a snapshot without .git."""
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "cald_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")) or f == "Makefile":
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
+
+
 def latest_pmc():
     """HBM bytes per GEMM launch, achieved HBM GB/s and MFMA-busy fraction of the GEMM family from the rocprofv3 passes of
     this same command (tools/profile_gpu.sh -> tools/summarize_profile.py -> profiles/*_pmc.json; FETCH_SIZE x2 gfx950
-    correction + WRITE_SIZE).  NOT measured in this process (a process cannot attach rocprofv3 to itself): the bench line
-    marks them `from_file` and names the source file."""
+    correction + WRITE_SIZE).  A process cannot attach rocprofv3 to itself, so the numbers come from a file -- but ONLY from a
+    file that records the hash of the kernel sources it was measured on (`csrc_sha1`) and only when that hash is the running
+    tree's: counters of other kernels are reported as null, never pasted beside live numbers."""
+    here = csrc_sha1()
     try:
-        cands = [f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc.json")]
-        cands.sort(key=lambda f: os.path.getmtime(os.path.join(ROOT, "profiles", f)))
-        for name in reversed(sorted(cands)):         # newest summary (by name: r2c < r3a < ...) that holds the GEMM family
+        for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+            if not name.endswith("_pmc.json"):
+                continue
             d = json.load(open(os.path.join(ROOT, "profiles", name)))
-            if "conv_mfma" in d:
+            if d.get("csrc_sha1") == here and "conv_mfma" in d:
                 c = d["conv_mfma"]
                 return {"hbm_bytes_per_launch": c.get("hbm_bytes_per_launch"), "hbm_gbps": c.get("hbm_gbps"),
-                        "mfma_busy": c.get("mfma_busy"), "source": "profiles/" + name}
+                        "mfma_busy": c.get("mfma_busy"), "source": "profiles/" + name, "csrc_sha1": here}
     except Exception:
         pass
-    return {"hbm_bytes_per_launch": None, "hbm_gbps": None, "mfma_busy": None, "source": None}
+    return {"hbm_bytes_per_launch": None, "hbm_gbps": None, "mfma_busy": None, "source": None, "csrc_sha1": here}
 
 
 def config0_leg(model, sd, B, threads=None):
@@ -216,7 +229,9 @@ def main():
                     help="steps of 64 pool images over the whole job; default: the full configs[1] pool (5 217 images = 82 steps) "
                          "in strong mode, 8 per GPU in weak mode")
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch-images", type=int, default=64)
+    ap.add_argument("--batch-images", type=int, default=None,
+                    help="images per internal batch of the sweep; default: a step counts 64 images and the library batches the shard "
+                         "in equal parts of <= 96 images")
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
                     help="strong (SURVEY 8d: fixed pool / wall time): K x 64 images in total, split over the N GPUs; "
                          "weak: K x 64 images per GPU (pool grows with N)")
@@ -239,7 +254,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    B, Wm = args.batch_images, args.warmup
+    args.batch_images_explicit = args.batch_images is not None
+    B, Wm = (args.batch_images or 64), args.warmup
     full_default = args.steps is None and args.scaling == "strong"
     K = args.steps if args.steps is not None else ((FULL_POOL + B - 1) // B if full_default else 8)
     letters = {"F": "flip", "C": "cut_out", "D": "smaller_resize", "R": "rotation", "G": "ga", "S": "sp"}
@@ -248,6 +264,7 @@ def main():
     mn, mx = (600, 1000) if args.shape == "voc" else (800, 1333)
     headline = (args.model == "frcnn" and args.shape == "voc" and args.augs == "FCD" and args.precision == "fp32")
     do_full = headline and world == 1 and not args.no_full_pool and not full_default   # full_default: the headline IS the full pool
+    full_scores = None
 
     # ---- the pool as files (host JPEG bytes): rank r owns pool positions p % world == r (rank-local inputs) ----
     from cald_amd import synth
@@ -309,15 +326,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def balanced(n, cap=96):
+        """Images per internal batch of one cald_sweep call: the shard split into equal batches of at most `cap` images, so that the
+        reference forward (B views) and the augmented forwards (3 B views in forwards of <= 96) all run near the 96-view size that
+        fills whole rounds of workgroup slots -- a 160-image strong-scaling shard runs 2 x 80, not 64 + 64 + 32 (or 54 + 53 + 53)."""
+        if args.batch_images_explicit:
+            return B
+        return max(1, -(-n // max(1, -(-n // cap))))
+
+    Bi = balanced(len(positions))                  # the timed call's internal batch size; the warm-up runs with the same one
+
     def sweep_batch(pool, pos, lo, hi):
-        return sweep.sweep_device_images(model, [pool[i] for i in range(lo, hi)], pos[lo:hi], augs, bp=1.3, base_seed=0, batch_images=B)
+        return sweep.sweep_device_images(model, [pool[i] for i in range(lo, hi)], pos[lo:hi], augs, bp=1.3, base_seed=0, batch_images=Bi)
 
     # ---- warm-up: decode path, code objects, workspace arena, W untimed steps ----
     warm_pool = DevicePool.from_jpeg_bytes(warm_blobs if warm_blobs else blobs[:B])
     wpos = warm_positions if warm_blobs else positions[:B]
-    for s in range(max(1, Wm)):
-        lo = (s * B) % len(warm_pool)
-        sweep_batch(warm_pool, wpos, lo, min(lo + B, len(warm_pool)))
+    sweep_batch(warm_pool, wpos, 0, len(warm_pool))       # W x 64 untimed images through the same call shape as the timed region
     del warm_pool
 
     # ---- host JPEG bytes -> HBM-resident uint8 pool (decode on the GPU), timed on its own ----
@@ -332,15 +357,14 @@ def main():
     n_local = len(positions)
     steps_local = (n_local + B - 1) // B          # == K for weak scaling; K / N (rounded up) for strong scaling
     # equal-sized batches (strong scaling leaves e.g. 160 images per rank: 54 + 53 + 53, not 64 + 64 + 32)
-    cuts = [(n_local * s) // max(1, steps_local) for s in range(steps_local + 1)]
+    # ONE cald_sweep call over the rank's shard: the library walks it in equal batches and keeps two in flight (the reference forward
+    # of batch k + 1 runs while the host builds batch k's augmented views; the stream never waits for the host)
     barrier()
     t0 = time.time()
-    cons_parts, cls_parts = [], []
-    for s in range(steps_local):
-        c, k = sweep_batch(dev_pool, positions, cuts[s], cuts[s + 1])
-        cons_parts.append(c); cls_parts.append(k)
-    cons = np.concatenate(cons_parts) if cons_parts else np.zeros(0)
-    cls = np.concatenate(cls_parts) if cls_parts else np.zeros((0, ncls - 1))
+    if n_local:
+        cons, cls = sweep_batch(dev_pool, positions, 0, n_local)
+    else:
+        cons, cls = np.zeros(0), np.zeros((0, ncls - 1))
     t_local = time.time() - t0                    # this rank's own shard scored (sweep_batch returns host arrays: synchronous)
     if world > 1:   # the one RCCL all-gather of the (consistency, cls_corr) rows of the WHOLE timed pool
         cons, cls = sweep.allgather_scores(positions, cons, cls, pool_total)
@@ -387,7 +411,8 @@ def main():
             "config": {"workload": ("BASELINE.json configs[1]: Faster R-CNN ResNet-50 FPN, VOC2012-shaped synthetic pool (baseline JPEG files), "
                                     "3 augs (flip/cut_out/smaller_resize), 21 classes, min/max 600/1000, seeded pseudo-trained weights")
                        if headline else "informational: model=%s shape=%s augs=%s classes=%d min/max %d/%d precision=%s" % (args.model, args.shape, args.augs, ncls, mn, mx, args.precision),
-                       "images_per_step": B, "images_per_step_note": "weak scaling: per GPU; strong scaling: over the whole job (steps_per_rank says how many batches a rank ran)",
+                       "images_per_step": B, "images_per_step_note": "a step counts 64 pool images; weak scaling: per GPU; strong scaling: over the whole job",
+                       "sweep_batch_images": Bi, "sweep_calls": 1,
                        "views_per_image": 1 + len(sweep.expand_augs(augs)), "pool_images": pool_total,
                        "timed_region": "HBM-resident decoded pool -> K sweep steps -> all-gather (N>1) -> argsort + cls_kldiv -> selected indices",
                        "selection_budget": budget, "n_selected": int(len(picked)),
@@ -408,16 +433,17 @@ def main():
                                      "note": "same pool, JPEG decode on the GPU + H2D included (max over ranks); never `value`"},
             "roofline": {"bound": "mfma",
                          "kernel": {"fp32": "conv_p4_kernel + conv_mfma_f32_kernel (implicit-GEMM conv + linear, v_mfma_f32_32x32x2_f32)",
-                                    "f16x3": "conv_h3_kernel (3 x v_mfma_f32_32x32x16_f16 per product; algorithmic flops counted once) + exact kernels for uncovered shapes",
+                                    "f16x3": "conv_h3_kernel / conv_h4_kernel (3 x v_mfma_f32_32x32x16_f16 per product; algorithmic flops counted once: at most 1/3 of the pipe's peak; measured power ceiling on random operands ~0.15, profiles/r4_f16x3_zero_vs_random_operands.txt) + exact kernels for uncovered shapes",
                                     "i8x3": "conv_i3_kernel (6 x v_mfma_i32_32x32x32_i8 per product; algorithmic flops counted once; the digit-plane "
                                             "quantiser passes are outside the GEMM timing) + exact kernels for uncovered shapes"}[args.precision],
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": pmc["hbm_bytes_per_launch"] if args.precision == "fp32" else None,
                          "hbm_gbps": pmc["hbm_gbps"] if args.precision == "fp32" else None,
                          "mfma_busy": pmc["mfma_busy"] if args.precision == "fp32" else None,
-                         "counters": {"from_file": True, "source": pmc["source"],
-                                      "note": "traffic / hbm_gbps / mfma_busy come from the committed rocprofv3 PMC summary of this command, "
-                                              "not from this run; achieved / frac / launches are measured live (HIP events)"},
+                         "counters": {"from_file": pmc["source"] is not None, "source": pmc["source"], "csrc_sha1": pmc["csrc_sha1"],
+                                      "note": "traffic / hbm_gbps / mfma_busy: the committed rocprofv3 PMC summary of this command, used only when "
+                                              "it was measured on exactly these kernel sources (csrc_sha1 recorded in the file), else null; "
+                                              "achieved / frac / launches are measured live (HIP events)"},
                          "launches": int(nl.value), "avg_launch_ms": gm.value / max(1, nl.value),
                          "gemm_ms_per_step": gm.value / max(1, steps_local), "algorithmic_gflop_per_launch": gf.value / max(1, nl.value) / 1e9,
                          "roi_rows_per_view_measured": mean_r.value,
@@ -429,7 +455,7 @@ def main():
             del dev_pool
             torch.cuda.synchronize(); tf = time.time()
             fp = DevicePool.from_jpeg_bytes(full_blobs)
-            unc, ccs = sweep.get_uncertainty(model, fp.loader(), augs, ncls, bp=1.3, base_seed=0, batch_images=B)
+            unc, ccs = sweep.get_uncertainty(model, fp.loader(), augs, ncls, bp=1.3, base_seed=0, batch_images=96)
             sel = sweep.select(unc, ccs, labeled, budget=FULL_BUDGET, mr=1.2)
             torch.cuda.synchronize(); tf = time.time() - tf
             u = np.asarray(unc)
@@ -438,47 +464,59 @@ def main():
                                 "zero_score_images": int((u == 0).sum()),
                                 "timed_region": "host JPEG bytes -> GPU decode -> get_uncertainty -> argsort + cls_kldiv -> 500 indices"}
             dev_pool = fp
+            full_scores = (u, np.stack(ccs))
         if world == 1 and not args.no_cpu_baseline and headline:
             out["cpu_baseline"] = cpu_baseline(sd, blobs, augs, positions, cons)
             out["cpu_baseline"]["host_cpus"] = os.cpu_count()
             out["cpu_baseline"]["host_cpus_usable"] = usable_cpus()
             out["config0_cpu_plumbing"] = config0_leg(model, sd, B, threads=out["cpu_baseline"]["cores"])
         if world == 1 and headline and not args.no_f16x3:
-            # informational second line, NOT the headline: the opt-in split-fp16 MFMA mode (BASELINE configs[4]'s
-            # "fp16 MFMA path") on the same workload.  Parity of that mode vs the exact mode on the full pool and vs an
-            # independent fp32 path: profiles/parity_vs_independent_fp32_r2.json (tools/parity_full_pool.py).
+            # informational second line, NOT the headline: the opt-in split-fp16 MFMA mode (BASELINE configs[4]'s "fp16 MFMA path")
+            # on the SAME timed pool, with its parity statement measured in this run: every image the exact mode just scored is
+            # scored again in f16x3 and the two selections are compared
             fast = (detector.fasterrcnn_resnet50_fpn_feature(num_classes=ncls, min_size=mn, max_size=mx, precision="f16x3")
                     .to("cuda:%d" % local_rank))
             fast.load_state_dict(sd)
             fast.eval()
-            nb = min(2 * B, len(dev_pool))
+            nb = len(dev_pool)                          # do_full: the whole configs[1] pool (5 217 images), else the timed pool
             imgs = [dev_pool[i] for i in range(nb)]
-            run = lambda mdl: sweep.sweep_device_images(mdl, imgs, list(range(nb)), augs, bp=1.3, base_seed=0, batch_images=B)
-            fc, _ = run(fast)
+            pos_f = list(range(nb)) if do_full else positions[:nb]
+            run = lambda mdl: sweep.sweep_device_images(mdl, imgs, pos_f, augs, bp=1.3, base_seed=0, batch_images=96)
+            sweep.sweep_device_images(fast, imgs[:192], pos_f[:192], augs, bp=1.3, base_seed=0, batch_images=96)   # warm-up
             torch.cuda.synchronize(); tf = time.time()
-            run(fast)
+            fc, fk = run(fast)
             torch.cuda.synchronize(); tf = time.time() - tf
-            ec, _ = run(model)
+            ec, ek = full_scores if do_full else (cons[:nb], cls[:nb])       # the exact mode's scores of this run's own sweep
             d = np.abs(fc - ec)
+            bud = max(1, min(FULL_BUDGET, int(round(FULL_BUDGET * nb / float(FULL_POOL)))))
+            sel_e = sweep.select(list(ec), [ek[i] for i in range(nb)], labeled, budget=bud, mr=1.2)
+            sel_f = sweep.select(list(fc), [fk[i] for i in range(nb)], labeled, budget=bud, mr=1.2)
             out["f16x3_mode"] = {"value": nb / tf, "unit": "images/s", "dtype": "fp16 hi+lo split operands, 3 x v_mfma_f32_32x32x16_f16 per product, fp32 accumulate",
-                                 "headline": False, "images_compared": nb, "max_abs_consistency_diff_vs_exact": float(d.max()),
+                                 "headline": False, "measured_in_this_run": True, "images_compared": nb,
+                                 "max_abs_consistency_diff_vs_exact": float(d.max()), "median_abs_consistency_diff_vs_exact": float(np.median(d)),
                                  "images_beyond_1e-4_vs_exact": int((d > 1e-4).sum()),
-                                 "note": "not bit-identical by design: on the full 5 217 pool ~1 % of images move by > 1e-4 (profiles/)"}
+                                 "selection_budget": bud, "selected_same_set_vs_exact": int(len(set(map(int, sel_e)) & set(map(int, sel_f)))),
+                                 "selected_total": int(len(sel_e)), "selected_identical_order": bool(list(map(int, sel_e)) == list(map(int, sel_f))),
+                                 "note": "not bit-identical by design (no CPU can restate v_mfma_f32_32x32x16_f16's internal alignment): a thresholded "
+                                         "pipeline flips a borderline detection on ~1 % of images under ANY change of rounding -- the exact mode against "
+                                         "an independent fp32 path does the same (parity_vs_independent_fp32)"}
             del fast
             # the exact-integer int8 mode: block floating point per pixel, reproducible by its oracle (tests)
             i8m = (detector.fasterrcnn_resnet50_fpn_feature(num_classes=ncls, min_size=mn, max_size=mx, precision="i8x3")
                    .to("cuda:%d" % local_rank))
             i8m.load_state_dict(sd)
             i8m.eval()
-            ic, _ = run(i8m)
+            n8 = min(nb, 2 * B)
+            run8 = lambda mdl: sweep.sweep_device_images(mdl, imgs[:n8], pos_f[:n8], augs, bp=1.3, base_seed=0, batch_images=B)
+            ic, _ = run8(i8m)
             torch.cuda.synchronize(); tf = time.time()
-            run(i8m)
+            run8(i8m)
             torch.cuda.synchronize(); tf = time.time() - tf
-            d = np.abs(ic - ec)
-            out["i8x3_mode"] = {"value": nb / tf, "unit": "images/s", "dtype": "block floating point per pixel, three int8 digits, 6 x v_mfma_i32_32x32x32_i8 per product, exact int32 accumulation per tap",
-                                "headline": False, "images_compared": nb, "max_abs_consistency_diff_vs_exact": float(d.max()),
+            d = np.abs(ic - ec[:n8])
+            out["i8x3_mode"] = {"value": n8 / tf, "unit": "images/s", "dtype": "block floating point per pixel, three int8 digits, 6 x v_mfma_i32_32x32x32_i8 per product, exact int32 accumulation per tap",
+                                "headline": False, "images_compared": n8, "max_abs_consistency_diff_vs_exact": float(d.max()),
                                 "images_beyond_1e-4_vs_exact": int((d > 1e-4).sum()),
-                                "note": "bit-identical to its CPU oracle (tests/test_gpu_parity.py); distance to fp32: profiles/parity_vs_independent_fp32_r2.json"}
+                                "note": "bit-identical to its CPU oracle (tests/test_gpu_parity.py); distance to fp32: profiles/parity_vs_independent_fp32_r4.json"}
         if world == 1 and headline and not args.no_train:
             # informational, NOT the headline: one training step of the same detector, cald_train.py's defaults
             sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -489,7 +527,7 @@ def main():
         try:
             out["parity_vs_independent_fp32"] = dict(
                 json.load(open(os.path.join(ROOT, "profiles", "parity_vs_independent_fp32_r2.json")))["summary"],
-                from_file=True, source="profiles/parity_vs_independent_fp32_r2.json (tools/parity_full_pool.py; not measured in this run)")
+                from_file=True, source="profiles/parity_vs_independent_fp32_r4.json (tools/parity_full_pool.py; not measured in this run)")
         except Exception:
             pass
         print(json.dumps(out))

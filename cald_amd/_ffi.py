@@ -122,6 +122,12 @@ SIGNATURES = {
     "cald_train_subsample2": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "cald_train_sgd": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_int]),
     "cald_train_seg_cache_size": (C.c_int, []),
+    "cald_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "cald_comm_init_rank": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "cald_comm_adopt": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "cald_comm_info": (C.c_int, [C.c_void_p, c_i, c_i]),
+    "cald_comm_destroy": (C.c_int, [C.c_void_p]),
+    "cald_allgather_scores": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int]),
 }
 
 

@@ -392,8 +392,17 @@ struct cald_model {
     struct SplitFmt { unsigned* s16; bool fp32_dead; };
     std::map<const float*, SplitFmt> split;
     std::vector<ViewDesc> last_views;
-    // batch-level detection buffers used by cald_sweep
+    // batch-level detection buffers used by the sweeps (cald_sweep alternates between the two sets: batch k + 1's reference forward
+    // is in flight while batch k's views are being scored)
     DetBuffers sweep_det; int sweep_det_views = 0;
+    DetBuffers sweep_det2; int sweep_det2_views = 0;
+    // cald_sweep's scratch lives with the model, grown on demand, never freed between calls (round 3 allocated and freed six device
+    // buffers per call -- each hipFree an implicit device synchronisation -- and copied through pageable host memory)
+    struct SweepScratch {
+        size_t dev_bytes = 0, pin_bytes = 0, aug_cap = 0;
+        char* dev = nullptr; char* pin = nullptr; uint8_t* d_aug = nullptr;
+        hipEvent_t ev_ref[2] = {nullptr, nullptr}, ev_score[2] = {nullptr, nullptr};
+    } ss;
     signed char* i8_scratch = nullptr; size_t i8_cap = 0, i8_off = 0;   // digit-plane scratch of the running forward
     // the tensor whose digit planes sit at the start of the scratch (the previous single-conv launch's input); a caller that knows the
     // tensor was not rewritten since (a block's downsample conv followed by its conv1 on the same input) may ask to reuse them
@@ -421,7 +430,7 @@ extern "C" int cald_model_create(cald_ctx* ctx, const cald_model_cfg* cfg, cald_
         int kc = 1024; while (kc < need) kc <<= 1;
         m->key_cap = kc;
     }
-    memset(&m->sweep_det, 0, sizeof(m->sweep_det));
+    memset(&m->sweep_det, 0, sizeof(m->sweep_det)); memset(&m->sweep_det2, 0, sizeof(m->sweep_det2));
     *out = m;
     return 0;
 }
@@ -709,6 +718,11 @@ extern "C" int cald_model_destroy(cald_model* m) {
     hipStreamSynchronize(m->ctx->stream);
     for (void* p : m->owned) hipFree(p);
     if (m->sweep_det_views) free_det(m->sweep_det);
+    if (m->sweep_det2_views) free_det(m->sweep_det2);
+    if (m->ss.dev) hipFree(m->ss.dev);
+    if (m->ss.pin) hipHostFree(m->ss.pin);
+    if (m->ss.d_aug) hipFree(m->ss.d_aug);
+    for (int i = 0; i < 2; i++) { if (m->ss.ev_ref[i]) hipEventDestroy(m->ss.ev_ref[i]); if (m->ss.ev_score[i]) hipEventDestroy(m->ss.ev_score[i]); }
     delete m;
     return 0;
 }
@@ -1417,6 +1431,19 @@ static int ensure_sweep_det(cald_model* m, int VT) {
     return 0;
 }
 
+static int ensure_sweep_det2(cald_model* m, int VT) {
+    if (m->sweep_det2_views >= VT) return 0;
+    if (m->sweep_det2_views) {
+        HIPCHK(hipStreamSynchronize(m->ctx->stream));
+        free_det(m->sweep_det2);
+        m->sweep_det2_views = 0;
+    }
+    int rc = alloc_det(m->sweep_det2, VT, m->det_cap(), m->cfg.num_classes);
+    if (rc) return rc;
+    m->sweep_det2_views = VT;
+    return 0;
+}
+
 extern "C" int cald_op_consistency(cald_ctx* c, int N, const float* aug_box, const float* ref_scores_cls, const float* ref_pm,
                                    int M, const float* boxes, const float* scores_cls, const float* pm, int C, float bp,
                                    float* consistency_out) {
@@ -1498,191 +1525,250 @@ extern "C" int cald_sweep(cald_model* m, int n_images, const uint8_t* const* ima
     if (B > CALD_MAX_VIEWS) B = CALD_MAX_VIEWS;
     const int VT = B * (1 + A);
     { int rc0 = ensure_sweep_det(m, VT); if (rc0) return rc0; }
-    DetBuffers& D = m->sweep_det;
-    // small device scratch for the scoring stage + an arena for augmented uint8 images
-    int *d_ints = nullptr; float *d_par = nullptr, *d_cons = nullptr, *d_clsc = nullptr;
-    NoiseJob* d_jobs = nullptr; unsigned long long* d_lsum = nullptr;
+    { int rc0 = ensure_sweep_det2(m, VT); if (rc0) return rc0; }
+    DetBuffers* const DS[2] = {&m->sweep_det, &m->sweep_det2};
     const int P_MAX = B * (A > 0 ? A : 1);
     const size_t n_ints = (size_t)P_MAX * 4 + (size_t)B * 51 + (size_t)VT * 2;
-    ScopedDev scratch(c->stream);
-    int rc = 0;
-    if ((rc = scratch.alloc(&d_ints, n_ints * 4)) || (rc = scratch.alloc(&d_par, (size_t)P_MAX * 12 * 4)) ||
-        (rc = scratch.alloc(&d_cons, (size_t)P_MAX * 4)) || (rc = scratch.alloc(&d_clsc, (size_t)VT * (C - 1) * 4)) ||
-        (rc = scratch.alloc(&d_jobs, sizeof(NoiseJob) * B)) || (rc = scratch.alloc(&d_lsum, sizeof(unsigned long long) * P_MAX))) return rc;
-    uint8_t* d_aug = nullptr; size_t aug_cap = 0;
-    std::vector<int> h_count(VT); std::vector<float> h_boxes((size_t)B * cap * 4), h_cons(P_MAX), h_clsc((size_t)VT * (C - 1));
-    auto cleanup = [&]() {
-        hipStreamSynchronize(c->stream);
-        hipFree(d_aug);          // the fixed scratch belongs to `scratch`
-    };
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    for (int i0 = 0; i0 < n_images && !rc; i0 += B) {
-        const int nb = (n_images - i0 < B) ? n_images - i0 : B;
-        // ---- phase 1: reference views ----
-        std::vector<ViewDesc> views(nb);
-        for (int i = 0; i < nb; i++) {
+    // ---- persistent scratch (model-owned): device buffers of the scoring stage, pinned host staging in two sets (batch parity) ----
+    cald_model::SweepScratch& S = m->ss;
+    const size_t dev_need = al(n_ints * 4) + al((size_t)P_MAX * 12 * 4) + al((size_t)P_MAX * 4) + al((size_t)VT * (C - 1) * 4) + al(sizeof(NoiseJob) * B) +
+                            al(sizeof(unsigned long long) * P_MAX);
+    const size_t pin_set = al((size_t)VT * 4) + al((size_t)B * cap * 16) + al(n_ints * 4) + al((size_t)P_MAX * 12 * 4) + al(sizeof(NoiseJob) * B) +
+                           al((size_t)P_MAX * 4) + al((size_t)VT * (C - 1) * 4);
+    if (dev_need > S.dev_bytes || 2 * pin_set > S.pin_bytes) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (S.dev) { hipFree(S.dev); S.dev = nullptr; S.dev_bytes = 0; }
+        if (S.pin) { hipHostFree(S.pin); S.pin = nullptr; S.pin_bytes = 0; }
+        HIPCHK(hipMalloc((void**)&S.dev, dev_need)); S.dev_bytes = dev_need;
+        HIPCHK(hipHostMalloc((void**)&S.pin, 2 * pin_set)); S.pin_bytes = 2 * pin_set;
+    }
+    for (int i = 0; i < 2; i++) {
+        if (!S.ev_ref[i]) HIPCHK(hipEventCreateWithFlags(&S.ev_ref[i], hipEventDisableTiming));
+        if (!S.ev_score[i]) HIPCHK(hipEventCreateWithFlags(&S.ev_score[i], hipEventDisableTiming));
+    }
+    int* d_ints; float *d_par, *d_cons, *d_clsc; NoiseJob* d_jobs; unsigned long long* d_lsum;
+    { Bump b(S.dev, false); d_ints = b.get<int>(n_ints); d_par = b.get<float>((size_t)P_MAX * 12); d_cons = b.get<float>(P_MAX);
+      d_clsc = b.get<float>((size_t)VT * (C - 1)); d_jobs = b.get<NoiseJob>(B); d_lsum = b.get<unsigned long long>(P_MAX); }
+    // Host state of one batch from its reference forward to its float64 means.  Two live at a time: while the host builds the augmented
+    // views of batch k (cutout needs the reference boxes on the host) the GPU already runs the reference forward of batch k + 1, and the
+    // scores of batch k come back while batch k + 1 is being built -- the stream never waits for the host (round 3 stopped twice per batch).
+    struct Batch {
+        int i0 = 0, nb = 0, P = 0, VV = 0; bool live = false;
+        int* h_count; float* h_boxes; int* h_ints; float* h_par; NoiseJob* h_jobs; float* h_cons; float* h_clsc;
+        std::vector<int> ref_n, pair_img, view_img;
+    } bt[2];
+    for (int q = 0; q < 2; q++) {
+        Bump b(S.pin + (size_t)q * pin_set, false);
+        bt[q].h_count = b.get<int>(VT); bt[q].h_boxes = b.get<float>((size_t)B * cap * 4); bt[q].h_ints = b.get<int>(n_ints);
+        bt[q].h_par = b.get<float>((size_t)P_MAX * 12); bt[q].h_jobs = b.get<NoiseJob>(B); bt[q].h_cons = b.get<float>(P_MAX);
+        bt[q].h_clsc = b.get<float>((size_t)VT * (C - 1));
+    }
+    int rc = 0;
+    static const int fwd_views_env = getenv("CALD_FWD_VIEWS") ? atoi(getenv("CALD_FWD_VIEWS")) : 96;
+    const int fwd_views = fwd_views_env < 1 ? 1 : (fwd_views_env > CALD_MAX_VIEWS ? CALD_MAX_VIEWS : fwd_views_env);
+    static const bool pipelined = !(getenv("CALD_SWEEP_PIPELINE") && atoi(getenv("CALD_SWEEP_PIPELINE")) == 0);   // 0: one batch at a time (A/B)
+
+    // reference views of batch k -> detections into set k & 1, counts + boxes to the pinned host set, event
+    auto enqueue_ref = [&](int k) -> int {
+        Batch& b = bt[k & 1];
+        b.i0 = k * B; b.nb = (n_images - b.i0 < B) ? n_images - b.i0 : B; b.live = true; b.P = 0; b.VV = b.nb;
+        std::vector<ViewDesc> views(b.nb);
+        for (int i = 0; i < b.nb; i++) {
             memset(&views[i], 0, sizeof(ViewDesc));
-            views[i].src = images_dev[i0 + i]; views[i].H = H[i0 + i]; views[i].W = W[i0 + i];
+            views[i].src = images_dev[b.i0 + i]; views[i].H = H[b.i0 + i]; views[i].W = W[b.i0 + i];
         }
-        DetBuffers d1 = D;
-        if ((rc = forward_model(m, nb, views.data(), d1))) break;
-        if (hipMemcpyAsync(h_count.data(), D.count, (size_t)nb * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-            hipMemcpyAsync(h_boxes.data(), D.boxes, (size_t)nb * cap * 16, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-            hipStreamSynchronize(c->stream) != hipSuccess) { rc = fail(CALD_ERR_HIP, "D2H of reference detections failed"); break; }
-        // ---- host: sub-sample, size the augmented-image arena ----
-        std::vector<int> ref_sel((size_t)B * 50, 0), ref_n(B, 0), pair_ref, pair_aug, pair_kind, pair_img, view_img(VT, 0), view_isref(VT, 0);
+        const DetBuffers& D = *DS[k & 1];
+        int r = forward_model(m, b.nb, views.data(), D);
+        if (r) return r;
+        if (hipMemcpyAsync(b.h_count, D.count, (size_t)b.nb * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipMemcpyAsync(b.h_boxes, D.boxes, (size_t)b.nb * cap * 16, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipEventRecord(S.ev_ref[k & 1], c->stream) != hipSuccess) return fail(CALD_ERR_HIP, "D2H of reference detections failed");
+        return 0;
+    };
+    // float64 means of a scored batch (cald_train.py:225-228); waits for its scores
+    auto finish = [&](int k) -> int {
+        Batch& b = bt[k & 1];
+        if (!b.live) return 0;
+        if (hipEventSynchronize(S.ev_score[k & 1]) != hipSuccess) return fail(CALD_ERR_HIP, "scoring stage failed: %s", hipGetErrorString(hipGetLastError()));
+        const int nb = b.nb, P = b.P, VV = b.VV;
+        std::vector<std::vector<int>> img_pairs(nb), img_views(nb);
+        for (int p = 0; p < P; p++) img_pairs[b.pair_img[p]].push_back(p);
+        for (int v = nb; v < VV; v++) img_views[b.view_img[v]].push_back(v);
+        for (int i = 0; i < nb; i++) {
+            double* cc = cls_corr_out + (size_t)(b.i0 + i) * (C - 1);
+            const int nvw = 1 + (int)img_views[i].size();
+            for (int k2 = 0; k2 < C - 1; k2++) {
+                double sm = (double)b.h_clsc[(size_t)i * (C - 1) + k2];
+                for (int v : img_views[i]) sm += (double)b.h_clsc[(size_t)v * (C - 1) + k2];
+                cc[k2] = sm / (double)nvw;
+            }
+            if (b.h_count[i] == 0 || img_pairs[i].empty()) { consistency_out[b.i0 + i] = 0.0; continue; }
+            std::vector<double> cs;
+            for (int p : img_pairs[i]) cs.push_back((double)b.h_cons[p]);
+            consistency_out[b.i0 + i] = np_sum(cs.data(), (int)cs.size()) / (double)cs.size();
+        }
+        b.live = false;
+        return 0;
+    };
+    // augmented views of batch k (needs its reference detections on the host), their forwards, the scoring stage, scores to the host
+    auto enqueue_aug_and_score = [&](int k) -> int {
+        Batch& b = bt[k & 1];
+        const DetBuffers& D = *DS[k & 1];
+        const int nb = b.nb, i0 = b.i0;
+        if (hipEventSynchronize(S.ev_ref[k & 1]) != hipSuccess) return fail(CALD_ERR_HIP, "reference forward failed: %s", hipGetErrorString(hipGetLastError()));
+        const int* h_count = b.h_count; const float* h_boxes = b.h_boxes;
+        std::vector<int> ref_sel((size_t)B * 50, 0), pair_ref, pair_aug, pair_kind, view_isref(VT, 0);
+        b.ref_n.assign(B, 0); b.pair_img.clear(); b.view_img.assign(VT, 0);
         std::vector<float> pair_par;
         std::vector<ViewDesc> aviews;
-        std::vector<NoiseJob> jobs;
+        int njobs = 0;
         size_t need = 0;
         for (int i = 0; i < nb; i++) {
             if (h_count[i] == 0) continue;
             const int Hi = H[i0 + i], Wi = W[i0 + i];
             for (int a = 0; a < A; a++) {
-                const int k = cfg->augs[a].kind; const double prm = cfg->augs[a].param;
-                if (k == CALD_AUG_SALT_PEPPER) need += al((size_t)Hi * Wi * 3);
-                else if (k == CALD_AUG_GAUSS) need += al((size_t)Hi * Wi * 3 * sizeof(float));
-                else if (k == CALD_AUG_COLOR_ADJUST) need += 2 * al((size_t)Hi * Wi * 3);
-                else if (k == CALD_AUG_RESIZE) {
+                const int kd = cfg->augs[a].kind; const double prm = cfg->augs[a].param;
+                if (kd == CALD_AUG_SALT_PEPPER) need += al((size_t)Hi * Wi * 3);
+                else if (kd == CALD_AUG_GAUSS) need += al((size_t)Hi * Wi * 3 * sizeof(float));
+                else if (kd == CALD_AUG_COLOR_ADJUST) need += 2 * al((size_t)Hi * Wi * 3);
+                else if (kd == CALD_AUG_RESIZE) {
                     const int ow = (int)((double)Wi * prm), oh = (int)((double)Hi * prm);
-                    if (ow < 1 || oh < 1) { rc = fail(CALD_ERR_INVALID, "resize ratio %g empties a %dx%d image", prm, Hi, Wi); break; }
+                    if (ow < 1 || oh < 1) return fail(CALD_ERR_INVALID, "resize ratio %g empties a %dx%d image", prm, Hi, Wi);
                     need += al((size_t)oh * ow * 3) + al((size_t)Hi * ow * 3);
-                } else if (k == CALD_AUG_ROTATE) {
+                } else if (kd == CALD_AUG_ROTATE) {
                     int fx[6], nh, nw; pil_rotate_setup(Hi, Wi, prm, fx, &nh, &nw);
                     need += al((size_t)nh * nw * 3) + al((size_t)nh * Wi * 3) + al((size_t)Hi * Wi * 3);
                 }
             }
-            if (rc) break;
         }
-        if (rc) break;
-        if (need > aug_cap) {
-            if (d_aug) hipFree(d_aug);
-            d_aug = nullptr; aug_cap = 0;
-            if (hipMalloc((void**)&d_aug, need + (need >> 2)) != hipSuccess) { rc = fail(CALD_ERR_HIP, "hipMalloc of the augmentation arena failed"); break; }
-            aug_cap = need + (need >> 2);
+        if (need > S.aug_cap) {      // the arena of augmented images is reused batch after batch in stream order; growing it drains the stream
+            HIPCHK(hipStreamSynchronize(c->stream));
+            if (S.d_aug) hipFree(S.d_aug);
+            S.d_aug = nullptr; S.aug_cap = 0;
+            if (hipMalloc((void**)&S.d_aug, need + (need >> 2)) != hipSuccess) return fail(CALD_ERR_HIP, "hipMalloc of the augmentation arena failed");
+            S.aug_cap = need + (need >> 2);
         }
         size_t aug_off = 0;
-        auto take = [&](size_t bytes) { uint8_t* p = d_aug + aug_off; aug_off += al(bytes); return p; };
+        auto take = [&](size_t bytes) { uint8_t* p = S.d_aug + aug_off; aug_off += al(bytes); return p; };
         // ---- host: build augmented views in the reference's order (cald_train.py:124-183) ----
+        int r = 0;
         for (int i = 0; i < nb; i++) {
-            view_img[i] = i; view_isref[i] = 1;
+            b.view_img[i] = i; view_isref[i] = 1;
             const int n = h_count[i];
-            ref_n[i] = subsample_indices(n, &ref_sel[(size_t)i * 50]);
+            b.ref_n[i] = subsample_indices(n, &ref_sel[(size_t)i * 50]);
             if (n == 0) continue;
             const int Hi = H[i0 + i], Wi = W[i0 + i];
             const uint64_t seed = (uint64_t)cfg->base_seed * 1000003ull + (uint64_t)pool_pos[i0 + i];
             float sub[50 * 4];
-            for (int k = 0; k < ref_n[i]; k++) memcpy(sub + 4 * k, &h_boxes[((size_t)i * cap + ref_sel[(size_t)i * 50 + k]) * 4], 16);
+            for (int q = 0; q < b.ref_n[i]; q++) memcpy(sub + 4 * q, &h_boxes[((size_t)i * cap + ref_sel[(size_t)i * 50 + q]) * 4], 16);
             auto add_view = [&](const ViewDesc& vd, int kind, const float* par) {
                 const int vidx = nb + (int)aviews.size();
-                aviews.push_back(vd); view_img[vidx] = i; view_isref[vidx] = 0;
-                pair_ref.push_back(i); pair_aug.push_back(vidx); pair_kind.push_back(kind); pair_img.push_back(i);
+                aviews.push_back(vd); b.view_img[vidx] = i; view_isref[vidx] = 0;
+                pair_ref.push_back(i); pair_aug.push_back(vidx); pair_kind.push_back(kind); b.pair_img.push_back(i);
                 for (int q = 0; q < 12; q++) pair_par.push_back(par ? par[q] : 0.0f);
             };
             ViewDesc base; memset(&base, 0, sizeof(base)); base.src = images_dev[i0 + i]; base.H = Hi; base.W = Wi;
             PyRandom pyrng; pyrng.seed(seed);          // ColorSwap's randint and every cutout of this image, in call order
             NoiseJob nj; memset(&nj, 0, sizeof(nj)); nj.seed = seed; nj.src = images_dev[i0 + i]; nj.H = Hi; nj.W = Wi;
-            for (int a = 0; a < A && !rc; a++) {
-                const int k = cfg->augs[a].kind; const double prm = cfg->augs[a].param;
+            for (int a = 0; a < A && !r; a++) {
+                const int kd = cfg->augs[a].kind; const double prm = cfg->augs[a].param;
                 float par[12] = {0};
-                if (k == CALD_AUG_FLIP) { ViewDesc v = base; v.flip = 1; par[0] = (float)Wi; add_view(v, 1, par); }
-                else if (k == CALD_AUG_GAUSS) {            // image + torch.randn(size) * std / 255.0
+                if (kd == CALD_AUG_FLIP) { ViewDesc v = base; v.flip = 1; par[0] = (float)Wi; add_view(v, 1, par); }
+                else if (kd == CALD_AUG_GAUSS) {            // image + torch.randn(size) * std / 255.0
                     NoiseSeg& sg = nj.seg[nj.nseg++]; sg.kind = 0; sg.p0 = (float)prm; sg.p1 = 0.0f;
                     sg.dst = take((size_t)Hi * Wi * 3 * sizeof(float));
                     ViewDesc v = base; v.noise = reinterpret_cast<const float*>(sg.dst); add_view(v, 0, nullptr);
-                } else if (k == CALD_AUG_SALT_PEPPER) {    // noise = torch.rand(size); < prob/2 -> max, > 1 - prob/2 -> min
+                } else if (kd == CALD_AUG_SALT_PEPPER) {    // noise = torch.rand(size); < prob/2 -> max, > 1 - prob/2 -> min
                     NoiseSeg& sg = nj.seg[nj.nseg++]; sg.kind = 1; sg.p0 = (float)(prm / 2.0); sg.p1 = (float)(1.0 - prm / 2.0);
                     sg.dst = take((size_t)Hi * Wi * 3);
                     ViewDesc v = base; v.src = reinterpret_cast<const uint8_t*>(sg.dst); add_view(v, 0, nullptr);
-                } else if (k == CALD_AUG_COLOR_ADJUST) {
+                } else if (kd == CALD_AUG_COLOR_ADJUST) {
                     uint8_t* tmp = take((size_t)Hi * Wi * 3); uint8_t* dst = take((size_t)Hi * Wi * 3);
                     launch_color_adjust(images_dev[i0 + i], Hi, Wi, (float)prm, tmp, d_lsum + pair_ref.size(), dst, c->stream);
                     ViewDesc v = base; v.src = dst; add_view(v, 0, nullptr);
-                } else if (k == CALD_AUG_COLOR_SWAP) {
+                } else if (kd == CALD_AUG_COLOR_SWAP) {
                     ViewDesc v = base; v.swap = pyrng.randbelow(6); add_view(v, 0, nullptr);
-                } else if (k == CALD_AUG_CUTOUT) {
+                } else if (kd == CALD_AUG_CUTOUT) {
                     ViewDesc v = base;
-                    v.nrect = cutout_rects(pyrng, Hi, Wi, ref_n[i], sub, (int)prm, v.rects);
+                    v.nrect = cutout_rects(pyrng, Hi, Wi, b.ref_n[i], sub, (int)prm, v.rects);
                     add_view(v, 0, nullptr);
-                } else if (k == CALD_AUG_RESIZE) {
+                } else if (kd == CALD_AUG_RESIZE) {
                     const int ow = (int)((double)Wi * prm), oh = (int)((double)Hi * prm);
                     uint8_t* dst = take((size_t)oh * ow * 3); uint8_t* tmp = take((size_t)Hi * ow * 3);
-                    if ((rc = pil_resize(c, images_dev[i0 + i], Hi, Wi, dst, oh, ow, tmp, 0))) break;
+                    if ((r = pil_resize(c, images_dev[i0 + i], Hi, Wi, dst, oh, ow, tmp, 0))) break;
                     ViewDesc v; memset(&v, 0, sizeof(v)); v.src = dst; v.H = oh; v.W = ow;
                     par[0] = (float)prm; add_view(v, 2, par);          // boxes * ratio: float32 tensor times the scalar
-                } else if (k == CALD_AUG_ROTATE) {
+                } else if (kd == CALD_AUG_ROTATE) {
                     int fx[6], nh, nw; pil_rotate_setup(Hi, Wi, prm, fx, &nh, &nw);
                     uint8_t* rot = take((size_t)nh * nw * 3); uint8_t* tmp = take((size_t)nh * Wi * 3); uint8_t* dst = take((size_t)Hi * Wi * 3);
                     launch_affine_nearest(images_dev[i0 + i], Hi, Wi, rot, nh, nw, fx, c->stream);
-                    if ((rc = pil_resize(c, rot, nh, nw, dst, Hi, Wi, tmp, 1))) break;      // new_image.resize((w, h)): BICUBIC default
+                    if ((r = pil_resize(c, rot, nh, nw, dst, Hi, Wi, tmp, 1))) break;      // new_image.resize((w, h)): BICUBIC default
                     ViewDesc v = base; v.src = dst;
                     rotate_box_params(Hi, Wi, prm, nw, nh, par);
                     add_view(v, 3, par);
                 }
             }
-            if (rc) break;
-            if (nj.nseg) jobs.push_back(nj);
+            if (r) return r;
+            if (nj.nseg) b.h_jobs[njobs++] = nj;
         }
-        if (rc) break;
-        if (!jobs.empty()) {
-            if (hipMemcpyAsync(d_jobs, jobs.data(), sizeof(NoiseJob) * jobs.size(), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
-                hipStreamSynchronize(c->stream) != hipSuccess) { rc = fail(CALD_ERR_HIP, "H2D of noise jobs failed"); break; }
-            launch_noise_stream(d_jobs, (int)jobs.size(), c->stream);
+        if (njobs) {
+            if (hipMemcpyAsync(d_jobs, b.h_jobs, sizeof(NoiseJob) * njobs, hipMemcpyHostToDevice, c->stream) != hipSuccess) return fail(CALD_ERR_HIP, "H2D of noise jobs failed");
+            launch_noise_stream(d_jobs, njobs, c->stream);
         }
-        if (rc) break;
-        // ---- phase 2: augmented views in forwards of <= fwd_views views, evenly sized (159 views run as 80 + 79, not 96 + 63:
-        // a short last forward leaves most of its launches under-filled; results do not depend on the split) ----
+        // ---- augmented views in forwards of <= fwd_views views, evenly sized (159 views run as 80 + 79, not 96 + 63: a short last
+        // forward leaves most of its launches under-filled; results do not depend on the split).  96 views per forward: the mid-size
+        // layers and fc6 then fill whole rounds of the 768 workgroup slots (measured +1.0 % on the sweep) ----
         const int na = (int)aviews.size();
-        // 96 views per augmented forward: the mid-size layers and fc6 then fill whole rounds of the 768 workgroup slots (fc6 6 000
-        // workgroups = 7.8 rounds, layer-3 3 x 3 3 042 = 3.96) where 64 views leave 5.2 / 2.6 -- measured +1.0 % on the sweep
-        static const int fwd_views_env = getenv("CALD_FWD_VIEWS") ? atoi(getenv("CALD_FWD_VIEWS")) : 96;
-        const int fwd_views = fwd_views_env < 1 ? 1 : (fwd_views_env > CALD_MAX_VIEWS ? CALD_MAX_VIEWS : fwd_views_env);
         const int n_fw = (na + fwd_views - 1) / fwd_views;
-        for (int f = 0; f < n_fw && !rc; f++) {
+        for (int f = 0; f < n_fw; f++) {
             const int a0 = (int)(((long long)na * f) / n_fw), nv = (int)(((long long)na * (f + 1)) / n_fw) - a0;
             DetBuffers d2 = D; const size_t o = (size_t)(nb + a0);
             d2.boxes += o * cap * 4; d2.scores += o * cap; d2.labels += o * cap; d2.props += o * cap * 4;
             d2.prob_max += o * cap; d2.scores_cls += o * cap * C; d2.count += o;
-            rc = forward_model(m, nv, aviews.data() + a0, d2);
+            if ((r = forward_model(m, nv, aviews.data() + a0, d2))) return r;
         }
-        if (rc) break;
-        // ---- phase 3: scoring ----
+        // ---- scoring ----
         const int P = (int)pair_ref.size(), VV = nb + na;
-        std::vector<int> ints(n_ints, 0);
-        int* p_ref = ints.data(); int* p_aug = p_ref + P_MAX; int* p_kind = p_aug + P_MAX; int* p_img = p_kind + P_MAX;
+        b.P = P; b.VV = VV;
+        int* ints = b.h_ints;
+        memset(ints, 0, n_ints * 4);
+        int* p_ref = ints; int* p_aug = p_ref + P_MAX; int* p_kind = p_aug + P_MAX; int* p_img = p_kind + P_MAX;
         int* p_sel = p_img + P_MAX; int* p_n = p_sel + (size_t)B * 50; int* p_vimg = p_n + B; int* p_visref = p_vimg + VT;
-        for (int p = 0; p < P; p++) { p_ref[p] = pair_ref[p]; p_aug[p] = pair_aug[p]; p_kind[p] = pair_kind[p]; p_img[p] = pair_img[p]; }
-        memcpy(p_sel, ref_sel.data(), (size_t)B * 50 * 4); memcpy(p_n, ref_n.data(), (size_t)B * 4);
-        memcpy(p_vimg, view_img.data(), (size_t)VT * 4); memcpy(p_visref, view_isref.data(), (size_t)VT * 4);
-        if (hipMemcpyAsync(d_ints, ints.data(), n_ints * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
-            (P && hipMemcpyAsync(d_par, pair_par.data(), (size_t)P * 12 * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess)) { rc = fail(CALD_ERR_HIP, "H2D failed"); break; }
+        for (int p = 0; p < P; p++) { p_ref[p] = pair_ref[p]; p_aug[p] = pair_aug[p]; p_kind[p] = pair_kind[p]; p_img[p] = b.pair_img[p]; }
+        memcpy(p_sel, ref_sel.data(), (size_t)B * 50 * 4); memcpy(p_n, b.ref_n.data(), (size_t)B * 4);
+        memcpy(p_vimg, b.view_img.data(), (size_t)VT * 4); memcpy(p_visref, view_isref.data(), (size_t)VT * 4);
+        if (P) memcpy(b.h_par, pair_par.data(), (size_t)P * 12 * 4);
+        if (hipMemcpyAsync(d_ints, ints, n_ints * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+            (P && hipMemcpyAsync(d_par, b.h_par, (size_t)P * 12 * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess)) return fail(CALD_ERR_HIP, "H2D failed");
         ScoreArgs sa; sa.det = D;
         sa.ref_view = d_ints; sa.aug_view = d_ints + P_MAX; sa.aug_kind = d_ints + 2 * P_MAX; sa.pair_img = d_ints + 3 * P_MAX;
         sa.ref_sel = d_ints + 4 * P_MAX; sa.ref_n = sa.ref_sel + (size_t)B * 50; sa.aug_param = d_par; sa.P = P; sa.bp = cfg->bp; sa.cons = d_cons;
         launch_consistency(sa, c->stream);
         launch_cls_corr(D, sa.ref_sel, sa.ref_n, sa.ref_n + B, sa.ref_n + B + VT, VV, d_clsc, c->stream);
-        if ((P && hipMemcpyAsync(h_cons.data(), d_cons, (size_t)P * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess) ||
-            hipMemcpyAsync(h_clsc.data(), d_clsc, (size_t)VV * (C - 1) * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-            hipStreamSynchronize(c->stream) != hipSuccess) { rc = fail(CALD_ERR_HIP, "scoring stage failed: %s", hipGetErrorString(hipGetLastError())); break; }
-        // ---- host: float64 means (cald_train.py:225-228) ----
-        std::vector<std::vector<int>> img_pairs(nb), img_views(nb);
-        for (int p = 0; p < P; p++) img_pairs[pair_img[p]].push_back(p);
-        for (int v = nb; v < VV; v++) img_views[view_img[v]].push_back(v);
-        for (int i = 0; i < nb; i++) {
-            double* cc = cls_corr_out + (size_t)(i0 + i) * (C - 1);
-            const int nvw = 1 + (int)img_views[i].size();
-            for (int k = 0; k < C - 1; k++) {
-                double s = (double)h_clsc[(size_t)i * (C - 1) + k];
-                for (int v : img_views[i]) s += (double)h_clsc[(size_t)v * (C - 1) + k];
-                cc[k] = s / (double)nvw;
-            }
-            if (h_count[i] == 0 || img_pairs[i].empty()) { consistency_out[i0 + i] = 0.0; continue; }
-            std::vector<double> cs;
-            for (int p : img_pairs[i]) cs.push_back((double)h_cons[p]);
-            consistency_out[i0 + i] = np_sum(cs.data(), (int)cs.size()) / (double)cs.size();
+        if ((P && hipMemcpyAsync(b.h_cons, d_cons, (size_t)P * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess) ||
+            hipMemcpyAsync(b.h_clsc, d_clsc, (size_t)VV * (C - 1) * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipEventRecord(S.ev_score[k & 1], c->stream) != hipSuccess) return fail(CALD_ERR_HIP, "scoring stage failed: %s", hipGetErrorString(hipGetLastError()));
+        return 0;
+    };
+
+    // stream order: ref(0), ref(1), aug(0), score(0), ref(2), aug(1), score(1), ... -- the host builds batch k's views while the GPU runs
+    // the reference forward of batch k + 1, and reads batch k's scores while batch k + 1 is on the GPU
+    const int NB = (n_images + B - 1) / B;
+    if (NB > 0) rc = enqueue_ref(0);
+    for (int k = 0; k < NB && !rc; k++) {
+        if (pipelined && k + 1 < NB) {
+            if ((rc = finish(k - 1))) break;              // set (k + 1) & 1 is batch k - 1's: its means first (its scores are long back)
+            if ((rc = enqueue_ref(k + 1))) break;
+        }
+        if ((rc = enqueue_aug_and_score(k))) break;
+        if (!pipelined) {
+            if ((rc = finish(k))) break;
+            if (k + 1 < NB && (rc = enqueue_ref(k + 1))) break;
         }
     }
-    cleanup();
+    for (int k = (NB >= 2 ? NB - 2 : 0); k < NB && !rc; k++) rc = finish(k);
+    if (rc) hipStreamSynchronize(c->stream);
     return rc;
 }
 

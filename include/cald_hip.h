@@ -315,6 +315,23 @@ int cald_train_subsample2(cald_ctx* ctx, int N, int H, int W, int C, const float
 /* torch.optim.SGD step over a flat buffer: d = grad + wd * p; buf = first_step ? d : momentum * buf + d; p -= lr * buf */
 int cald_train_sgd(cald_ctx* ctx, long long n, float* param, const float* grad, float* momentum_buf, float lr, float momentum,
                    float weight_decay, int first_step);
+/* ---- multi-GPU: the sweep's one collective.  Replaces detection/utils.py:75-115 (`all_gather`: pickle, pad to the longest
+ * rank, gather) and :302-324 (`init_distributed_mode`, NCCL process group).  One process per GPU; RCCL is bound at first use
+ * (dlopen librccl.so.1), the single-GPU path never touches it.
+ *   rank 0:      cald_comm_unique_id(id)  -> ship the 128 bytes to every rank by any means (file, socket, the host's own launcher)
+ *   every rank:  cald_comm_init_rank(ctx, id, world, rank, &comm)       (or cald_comm_adopt() around an ncclComm_t the host owns)
+ *   every rank:  cald_allgather_scores(comm, send_dev, recv_dev, rows_per_rank, row_len)   -- rows of float64, device buffers;
+ *                recv_dev [world * rows_per_rank][row_len], rank r's rows at r * rows_per_rank.  Asynchronous on the context's stream.
+ * With the strided shard (rank r scores pool positions p % world == r, padded to ceil(pool / world) rows) row j of rank r IS pool
+ * position r + j * world: no index column and no padding protocol travel. */
+typedef struct cald_comm cald_comm;
+int cald_comm_unique_id(void* id128_out);
+int cald_comm_init_rank(cald_ctx* ctx, const void* id128, int world_size, int rank, cald_comm** out);
+int cald_comm_adopt(cald_ctx* ctx, void* rccl_comm, cald_comm** out);
+int cald_comm_info(const cald_comm* comm, int* world_size, int* rank);
+int cald_comm_destroy(cald_comm* comm);
+int cald_allgather_scores(cald_comm* comm, const double* send_dev, double* recv_dev, int64_t rows_per_rank, int row_len);
+
 /* Number of dense-batch geometry tables the training operators keep cached on the device (all contexts).  The cache is bounded
  * (1024 tables, CALD_SEG_CACHE_CAP overrides); it is emptied between operator calls, never inside one.  Diagnostic. */
 int cald_train_seg_cache_size(void);

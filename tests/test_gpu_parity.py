@@ -1219,3 +1219,73 @@ def test_retinanet_head_convs_match_the_reference_modules(hip, golden):
                 ws, hs = wr * np.float32(sizes[l, s]), hr * np.float32(sizes[l, s])
                 want = np.array([np.rint(-ws / 2), np.rint(-hs / 2), np.rint(ws / 2), np.rint(hs / 2)], np.float32)
                 np.testing.assert_array_equal(got[l, r * 3 + s], want)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The sweep's one collective behind the C ABI (include/cald_hip.h cald_comm_* / cald_allgather_scores; detection/utils.py:75-115)
+# ---------------------------------------------------------------------------------------------------------------------------
+def test_c_abi_rccl_allgather_world_1(hip):
+    """cald_comm_unique_id -> cald_comm_init_rank -> cald_allgather_scores with one rank on the box's GPU: RCCL is found (dlopen),
+    a communicator comes up, the gathered rows are the sent rows, and the Python-level contract equals sweep.allgather_scores'."""
+    torch = hip["torch"]
+    from cald_amd.comm import RcclComm
+    uid = RcclComm.unique_id()
+    assert len(uid) == 128 and any(uid)
+    comm = RcclComm.init_rank(uid, 1, 0)
+    rows = torch.arange(37 * 21, dtype=torch.float64, device="cuda").reshape(37, 21) * 0.5
+    out = comm.allgather_rows(rows)
+    assert torch.equal(out, rows)
+    rs = np.random.RandomState(3)
+    cons, cls = rs.rand(13), rs.rand(13, 20)
+    fc, fk = comm.allgather_scores(list(range(13)), cons, cls, 13)
+    np.testing.assert_array_equal(fc, cons); np.testing.assert_array_equal(fk, cls)
+    with pytest.raises(ValueError):
+        comm.allgather_scores([0, 2, 4], cons[:3], cls[:3], 13)
+    comm.close()
+
+
+_COMM2_SCRIPT = r"""
+import os, sys, json
+import numpy as np, torch
+sys.path.insert(0, %r)
+rank, world = int(sys.argv[1]), 2
+torch.cuda.set_device(rank)
+from cald_amd.comm import RcclComm
+from cald_amd import sweep
+path = sys.argv[2]
+def exchange(x):                       # 128 bytes through a file: the C ABI needs no torch.distributed
+    import time
+    if x is not None:
+        open(path + ".tmp", "wb").write(x); os.replace(path + ".tmp", path)
+        return x
+    for _ in range(600):
+        if os.path.exists(path):
+            return open(path, "rb").read()
+        time.sleep(0.1)
+    raise RuntimeError("no id")
+comm = RcclComm.from_store(rank, world, exchange)
+pool = 29
+pos = sweep.shard_positions(pool, rank, world)
+cons = np.array([p * 1.25 for p in pos]); cls = np.array([[p + 0.01 * k for k in range(20)] for p in pos])
+fc, fk = comm.allgather_scores(pos, cons, cls, pool)
+ok = bool(np.array_equal(fc, np.arange(pool) * 1.25) and np.array_equal(fk[:, 3], np.arange(pool) + 0.03))
+print("RESULT " + json.dumps({"rank": rank, "ok": ok}))
+comm.close()
+"""
+
+
+def test_c_abi_rccl_allgather_across_two_devices(hip, tmp_path):
+    """Two processes, one GPU each, communicator bootstrapped through a file (no torch.distributed anywhere): the all-gather over
+    RCCL / xGMI returns every pool position's row on both ranks.  Needs two visible devices (skipped on the 1-GPU boxes)."""
+    torch = hip["torch"]
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one visible GPU: RCCL refuses two ranks on one device (tools/nccl_same_gpu_probe.py)")
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    idf = str(tmp_path / "rccl_id")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    ps = [subprocess.Popen([sys.executable, "-c", _COMM2_SCRIPT % root, str(r), idf], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    for p in ps:
+        out, err = p.communicate(timeout=600)
+        assert p.returncode == 0, err[-2000:]
+        assert json.loads([l for l in out.splitlines() if l.startswith("RESULT ")][-1][7:])["ok"]
