@@ -827,3 +827,29 @@ def test_training_loop_follows_the_reference_loop(golden):
             engine.train_one_epoch(model, opt, data, torch.device("cpu"), 0, ep, 0)
         assert np.array_equal(np.array(lrs), g["t%d_lrs" % k]), (k, lrs)
         assert np.array_equal(np.stack(params), g["t%d_params" % k]), k
+
+
+def test_training_checker_frcnn_losses_match_the_reference_repo_copies(golden):
+    """The float64 training checker's loss arithmetic (oracle/torch_train.py: smooth_l1_sum, cross entropy, BCE with logits) against the
+    reference tree's own copies of torchvision's Faster R-CNN losses, executed from it (detection/frcnn_ll.py:28-63, :245-281 ->
+    tests/golden/frcnn_losses.npz): 1e-12 in float64.  The copies use beta = 1 / L1 where torchvision (the hot path) uses 1/9."""
+    import torch
+    import torch.nn.functional as F
+    from oracle import torch_train as tt
+    g = golden("frcnn_losses")
+    for k in range(int(g["b_n"])):
+        logits, deltas = torch.from_numpy(g["b%d_logits" % k]).double(), torch.from_numpy(g["b%d_deltas" % k]).double()
+        labels, tgt = torch.from_numpy(g["b%d_labels" % k]), torch.from_numpy(g["b%d_targets" % k]).double()
+        R, Cc = logits.shape
+        pos = torch.nonzero(labels > 0).squeeze(1)
+        cls = F.cross_entropy(logits, labels)
+        box = tt.smooth_l1_sum(deltas.view(R, Cc, 4)[pos, labels[pos]], tgt[pos], 1.0) / R
+        assert abs(float(cls) - float(g["b%d_cls_f64" % k])) <= 1e-12 and abs(float(box) - float(g["b%d_box_f64" % k])) <= 1e-12
+    for k in range(int(g["r_n"])):
+        obj, deltas, tgt = [torch.from_numpy(g["r%d_%s" % (k, n)]).double() for n in ("obj", "deltas", "targets")]
+        pos, neg = torch.from_numpy(g["r%d_pos" % k]), torch.from_numpy(g["r%d_neg" % k])
+        samp = torch.cat([pos, neg])
+        lab = torch.cat([torch.ones(len(pos)), torch.zeros(len(neg))]).double()
+        o = F.binary_cross_entropy_with_logits(obj.flatten()[samp], lab)
+        b = tt.smooth_l1_sum(deltas[pos], tgt[pos], 0.0) / len(samp)
+        assert abs(float(o) - float(g["r%d_obj_f64" % k])) <= 1e-12 and abs(float(b) - float(g["r%d_box_f64" % k])) <= 1e-12

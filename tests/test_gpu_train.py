@@ -1023,3 +1023,39 @@ def test_geometry_table_cache_eviction_never_frees_inside_an_operator(T):
     assert small["runs"] == base["runs"]
     assert small["runs"][0] == small["runs"][2]          # same inputs before and after the evictions in between
     assert small["tables"] < base["tables"]              # the cache was emptied on the way (the bound holds up to the tables of one operator call)
+
+
+def test_frcnn_loss_kernels_match_the_reference_repo_copies(T, golden):
+    """`softmax_ce_kernel`, `smooth_l1_kernel` and `bce_logits_kernel` against the copies of torchvision's Faster R-CNN losses that the
+    reference tree itself holds and that were executed from it (detection/frcnn_ll.py:28-63 `_fastrcnn_loss`, :245-281
+    `RegionProposalNetwork._compute_loss`; tests/golden/frcnn_losses.npz from oracle/make_golden_frcnn_losses.py): the gather of the
+    class-specific deltas of the positive rows, the normalisers (all rows / all sampled anchors), the objectness labels.  Single-image
+    cases, where the copies' per-image losses ARE the batch losses; run at the copies' beta (1 for the box head, L1 for the RPN -- the
+    hot path's torchvision uses 1/9 for both, the kernels take beta as an argument).  2e-6 of the float64 run, 1e-5 of the float32 run."""
+    torch, ops = T
+    g = golden("frcnn_losses")
+
+    def close(got, key):
+        w64, w32 = float(g[key + "_f64"]), float(g[key + "_f32"])
+        assert abs(float(got) - w64) <= 2e-6 * max(abs(w64), 1e-3), (key, float(got), w64)
+        assert abs(float(got) - w32) <= 1e-5 * max(abs(w32), 1e-3), (key, float(got), w32)
+    for k in range(int(g["b_n"])):
+        logits, deltas, labels, tgt = g["b%d_logits" % k], g["b%d_deltas" % k], g["b%d_labels" % k], g["b%d_targets" % k]
+        R, Cc = logits.shape
+        pred = torch.from_numpy(np.concatenate([logits, deltas], axis=1)).cuda().contiguous()          # the fused predictor's rows: C logits, 4 C deltas
+        ld = pred.shape[1]
+        close(ops.softmax_ce(pred, torch.from_numpy(labels).cuda(), Cc), "b%d_cls" % k)
+        pos = np.flatnonzero(labels > 0)
+        idx = torch.from_numpy((pos * ld + Cc + 4 * labels[pos]).astype(np.int64)).cuda()
+        got = ops.smooth_l1(pred, idx, torch.from_numpy(tgt[pos]).cuda().contiguous(), 1.0, R) if len(pos) else torch.zeros(1)
+        close(got, "b%d_box" % k)
+    for k in range(int(g["r_n"])):
+        obj, deltas, tgt, pos, neg = g["r%d_obj" % k], g["r%d_deltas" % k], g["r%d_targets" % k], g["r%d_pos" % k], g["r%d_neg" % k]
+        A = obj.shape[0]
+        head = torch.from_numpy(np.concatenate([obj, deltas], axis=1)).cuda().contiguous()               # [A][1 logit + 4 deltas]
+        samp = np.concatenate([pos, neg])
+        lab = torch.from_numpy(np.concatenate([np.ones(len(pos), np.float32), np.zeros(len(neg), np.float32)])).cuda()
+        close(ops.bce_logits(head, torch.from_numpy((samp * 5).astype(np.int64)).cuda(), lab), "r%d_obj" % k)
+        got = (ops.smooth_l1(head, torch.from_numpy((pos * 5 + 1).astype(np.int64)).cuda(), torch.from_numpy(tgt[pos]).cuda().contiguous(), 0.0, len(samp))
+               if len(pos) else torch.zeros(1))
+        close(got, "r%d_box" % k)
