@@ -1502,6 +1502,11 @@ extern "C" int cald_op_cls_corr(cald_ctx* c, int n, const float* scores, const i
 // =============================================================================================
 // the sweep (get_uncertainty, cald_train.py:91-231)
 // =============================================================================================
+// views per augmented forward: 96 fills whole rounds of the 768 workgroup slots in the mid-size layers and fc6 (CALD_FWD_VIEWS overrides)
+static int sweep_fwd_views() {
+    static const int env = getenv("CALD_FWD_VIEWS") ? atoi(getenv("CALD_FWD_VIEWS")) : 96;
+    return env < 1 ? 1 : (env > CALD_MAX_VIEWS ? CALD_MAX_VIEWS : env);
+}
 extern "C" int cald_sweep(cald_model* m, int n_images, const uint8_t* const* images_dev, const int* H, const int* W,
                           const int64_t* pool_pos, const cald_sweep_cfg* cfg, double* consistency_out, double* cls_corr_out) {
     if (!m || !images_dev || !H || !W || !pool_pos || !cfg || !consistency_out || !cls_corr_out) return fail(CALD_ERR_INVALID, "null argument");
@@ -1565,8 +1570,7 @@ extern "C" int cald_sweep(cald_model* m, int n_images, const uint8_t* const* ima
         bt[q].h_clsc = b.get<float>((size_t)VT * (C - 1));
     }
     int rc = 0;
-    static const int fwd_views_env = getenv("CALD_FWD_VIEWS") ? atoi(getenv("CALD_FWD_VIEWS")) : 96;
-    const int fwd_views = fwd_views_env < 1 ? 1 : (fwd_views_env > CALD_MAX_VIEWS ? CALD_MAX_VIEWS : fwd_views_env);
+    const int fwd_views = sweep_fwd_views();
     static const bool pipelined = !(getenv("CALD_SWEEP_PIPELINE") && atoi(getenv("CALD_SWEEP_PIPELINE")) == 0);   // 0: one batch at a time (A/B)
 
     // reference views of batch k -> detections into set k & 1, counts + boxes to the pinned host set, event
@@ -1874,8 +1878,10 @@ extern "C" int cald_sweep_lsc(cald_model* m, int n_images, const uint8_t* const*
             launch_noise_stream(d_gjobs, (int)gjobs.size(), c->stream);
         }
         const int na = (int)aviews.size();
-        for (int a0 = 0; a0 < na && !rc; a0 += CALD_MAX_VIEWS) {
-            const int nv = (na - a0 < CALD_MAX_VIEWS) ? na - a0 : CALD_MAX_VIEWS;
+        // evenly sized forwards of <= 96 views, as cald_sweep issues them (192 views run 96 + 96, not 128 + 64; CALD_MAX_VIEWS is the hard cap)
+        const int lsc_fw = sweep_fwd_views(), n_fw = (na + lsc_fw - 1) / lsc_fw;
+        for (int f = 0; f < n_fw && !rc; f++) {
+            const int a0 = (int)(((long long)na * f) / n_fw), nv = (int)(((long long)na * (f + 1)) / n_fw) - a0;
             DetBuffers d2 = D; const size_t o = (size_t)(nb + a0);
             d2.boxes += o * cap * 4; d2.scores += o * cap; d2.labels += o * cap; d2.props += o * cap * 4;
             d2.prob_max += o * cap; d2.scores_cls += o * cap * C; d2.count += o;

@@ -976,7 +976,8 @@ class _LossFn(torch.autograd.Function):
     def forward(ctx, anchor, net, images, targets):
         ctx.net = net
         d = net.forward(images, targets)
-        ctx.saved = net.last          # this forward's records
+        # every forward of the model -- with or without grad -- replaces the layers' ONE set of saved activations, so it bumps the serial:
+        # a loss evaluation under no_grad between a forward and its backward invalidates that backward too
         net.forward_serial = ctx.serial = getattr(net, "forward_serial", 0) + 1
         return tuple(d[k].reshape(()) for k in net.LOSS_NAMES)
 
@@ -998,12 +999,10 @@ class _LossFn(torch.autograd.Function):
         if any(mine) and not all(mine):
             raise RuntimeError("some parameters carry a gradient and some do not: call zero_grad() on all of them")
         net.accumulate_grads = all(mine)
-        current, net.last = net.last, ctx.saved
         try:
-            net.backward(gscale)
+            net.backward(gscale)                    # net.last IS this forward's record (the serial check above)
         finally:
             net.accumulate_grads = False
-            net.last = current
         for k in net.names:
             if net.params[k].grad is None:
                 net.params[k].grad = net.grads[k]
