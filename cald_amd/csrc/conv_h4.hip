@@ -92,17 +92,20 @@ __device__ __forceinline__ void conv_h4_body(const ConvArgs& a, const int blk) {
     const int lds_l = (ldA ? 0 : 16384) + lw * 4096;             // this wave's 4 KB of a stage
     int u_kh = 0, u_kw = 0, u_ci = 0, u_kt = 0;                   // wave-uniform k cursor: (16-channel chunk, kh, kw), kw fastest
 
+    // (branch-free on purpose: the steady-state k-step must be ONE basic block, or the scheduler cannot interleave the DMA issues and
+    // the next step's fragment reads with the MFMAs -- all operands of the selects are wave-uniform, so they are s_cselect)
 #define H4_ISSUE(SLOT)                                                                                                       \
     {                                                                                                                        \
-        int soff; unsigned bit;                                                                                              \
-        if (ldA) { soff = ((u_kh * Wi_l + u_kw) * Cin + u_ci) * 4; bit = 1u << (u_kh * KW + u_kw); }                         \
-        else { soff = u_kt * 2 * CoutPad * 32; bit = 1u; }                                                                   \
+        const int soffA = ((u_kh * Wi_l + u_kw) * Cin + u_ci) * 4, soffB = u_kt * (2 * CoutPad * 32);                        \
+        const int soff = ldA ? soffA : soffB;                                                                                \
+        const unsigned bit = ldA ? (1u << (u_kh * KW + u_kw)) : 1u;                                                          \
         _Pragma("unroll") for (int i = 0; i < 4; i++) {                                                                      \
             const int vo = (rowmask[i] & bit) ? voff[i] : 0x7FFF0000;                                                        \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(smem + (SLOT) * H4_STAGE + lds_l + i * 1024), 16, vo, soff, 0, 0); \
         }                                                                                                                    \
         u_kt++; u_kw++;                                                                                                      \
-        if (u_kw == KW) { u_kw = 0; u_kh++; if (u_kh == KH) { u_kh = 0; u_ci += 16; } }                                      \
+        const bool ww = u_kw == KW; u_kw = ww ? 0 : u_kw; u_kh += ww ? 1 : 0;                                                \
+        const bool wh = u_kh == KH; u_kh = wh ? 0 : u_kh; u_ci += wh ? 16 : 0;                                               \
     }
 
     // ---------------- compute role: wave (wm, wn) owns rows [128 wm, +128) x columns [64 wn, +64) of the tile ----------------
@@ -159,12 +162,56 @@ __device__ __forceinline__ void conv_h4_body(const ConvArgs& a, const int blk) {
         _Pragma("unroll") for (int i = 0; i < 4; i++)                                                                        \
             _Pragma("unroll") for (int j = 0; j < 2; j++)                                                                    \
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH[i], BH[j], acc[i][j], 0, 0, 0);                        \
-        /* interleave: one LDS read per two MFMAs, the DMA pieces and their address selects spread over the rest */          \
-        _Pragma("unroll") for (int q = 0; q < 12; q++) {                                                                     \
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                               \
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                               \
-            if (q % 3 == 0) { __builtin_amdgcn_sched_group_barrier(0x002, 3, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); } \
+        kt++;                                                                                                                \
+    }
+
+    // Steady-state k-step (kt + 4 < KT): no conditionals.  Issue order asked of the scheduler: per DMA piece { its address select, the
+    // piece, 6 MFMAs with one fragment read of the NEXT step after every second one } x 4 -- a DMA issue costs the wave ~60-180 cycles
+    // (MI355X_MICROARCH.md), which the partner wave of the SIMD covers only if it is not issuing its own pieces at the same moment:
+    // with the four pieces back to back right after the barrier (both waves of a SIMD in lockstep) the matrix pipe measured 57-59 % busy.
+#ifndef H4_VARIANT
+#define H4_VARIANT 5
+#endif
+#define H4_MFMA4(AX, BX, I0)                                                                                                 \
+        _Pragma("unroll") for (int i = (I0); i < (I0) + 2; i++)                                                              \
+            _Pragma("unroll") for (int j = 0; j < 2; j++)                                                                    \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AX[i], BX[j], acc[i][j], 0, 0, 0);
+#define H4_PIECE(SLOT, I, SOFF, BIT)                                                                                         \
+        {                                                                                                                    \
+            const int vo = (rowmask[I] & (BIT)) ? voff[I] : 0x7FFF0000;                                                      \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(smem + (SLOT) * H4_STAGE + lds_l + (I) * 1024), 16, vo, (SOFF), 0, 0); \
+        }
+#define H4_STEPF(SLOT, AH, AL, BH, BL, NAH, NAL, NBH, NBL)                                                                   \
+    {                                                                                                                        \
+        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");                                                          \
+        if (H4_VARIANT != 3) __builtin_amdgcn_s_barrier();                                                                   \
+        const int soffA = ((u_kh * Wi_l + u_kw) * Cin + u_ci) * 4, soffB = u_kt * (2 * CoutPad * 32);                        \
+        const int soff = ldA ? soffA : soffB;                                                                                \
+        const unsigned bit = ldA ? (1u << (u_kh * KW + u_kw)) : 1u;                                                          \
+        if (H4_VARIANT != 4) H4_READ(NAH, NAL, NBH, NBL, ((SLOT) + 1) & 3)                                                   \
+        if (H4_VARIANT == 5) {                                                                                               \
+            /* pieces in program order BETWEEN the MFMAs: the two waves of a SIMD leave the barrier together, and with the  */ \
+            /* four pieces up front both sit in their (60-180 cycle) DMA issues at once while the matrix pipe idles          */ \
+            H4_MFMA4(AL, BH, 0) __builtin_amdgcn_sched_barrier(0); H4_PIECE(SLOT, 0, soff, bit) __builtin_amdgcn_sched_barrier(0);   \
+            H4_MFMA4(AL, BH, 2) __builtin_amdgcn_sched_barrier(0); H4_PIECE(SLOT, 1, soff, bit) __builtin_amdgcn_sched_barrier(0);   \
+            H4_MFMA4(AH, BL, 0) __builtin_amdgcn_sched_barrier(0); H4_PIECE(SLOT, 2, soff, bit) __builtin_amdgcn_sched_barrier(0);   \
+            H4_MFMA4(AH, BL, 2) __builtin_amdgcn_sched_barrier(0); H4_PIECE(SLOT, 3, soff, bit) __builtin_amdgcn_sched_barrier(0);   \
+            H4_MFMA4(AH, BH, 0) H4_MFMA4(AH, BH, 2)                                                                          \
+        } else {                                                                                                             \
+            if (H4_VARIANT != 2) { H4_PIECE(SLOT, 0, soff, bit) H4_PIECE(SLOT, 1, soff, bit) H4_PIECE(SLOT, 2, soff, bit) H4_PIECE(SLOT, 3, soff, bit) } \
+            _Pragma("unroll") for (int i = 0; i < 4; i++)                                                                    \
+                _Pragma("unroll") for (int j = 0; j < 2; j++)                                                                \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AL[i], BH[j], acc[i][j], 0, 0, 0);                    \
+            _Pragma("unroll") for (int i = 0; i < 4; i++)                                                                    \
+                _Pragma("unroll") for (int j = 0; j < 2; j++)                                                                \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH[i], BL[j], acc[i][j], 0, 0, 0);                    \
+            _Pragma("unroll") for (int i = 0; i < 4; i++)                                                                    \
+                _Pragma("unroll") for (int j = 0; j < 2; j++)                                                                \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH[i], BH[j], acc[i][j], 0, 0, 0);                    \
         }                                                                                                                    \
+        u_kt++; u_kw++;                                                                                                      \
+        const bool ww = u_kw == KW; u_kw = ww ? 0 : u_kw; u_kh += ww ? 1 : 0;                                                \
+        const bool wh = u_kh == KH; u_kh = wh ? 0 : u_kh; u_ci += wh ? 16 : 0;                                               \
         kt++;                                                                                                                \
     }
 
@@ -176,19 +223,21 @@ __device__ __forceinline__ void conv_h4_body(const ConvArgs& a, const int blk) {
     __builtin_amdgcn_s_barrier();
     H4_READ(ah0, al0, bh0, bl0, 0)
     int kt = 0;
-    while (kt + 4 <= KT) {
-        H4_STEP(0, ah0, al0, bh0, bl0, ah1, al1, bh1, bl1)
-        H4_STEP(1, ah1, al1, bh1, bl1, ah0, al0, bh0, bl0)
-        H4_STEP(2, ah0, al0, bh0, bl0, ah1, al1, bh1, bl1)
-        H4_STEP(3, ah1, al1, bh1, bl1, ah0, al0, bh0, bl0)
+    while (kt + 8 <= KT) {                      // every step of the body has kt + 4 < KT
+        H4_STEPF(0, ah0, al0, bh0, bl0, ah1, al1, bh1, bl1)
+        H4_STEPF(1, ah1, al1, bh1, bl1, ah0, al0, bh0, bl0)
+        H4_STEPF(2, ah0, al0, bh0, bl0, ah1, al1, bh1, bl1)
+        H4_STEPF(3, ah1, al1, bh1, bl1, ah0, al0, bh0, bl0)
     }
-    if (kt < KT) {
-        H4_STEP(0, ah0, al0, bh0, bl0, ah1, al1, bh1, bl1)
-        if (kt < KT) {
-            H4_STEP(1, ah1, al1, bh1, bl1, ah0, al0, bh0, bl0)
-            if (kt < KT) H4_STEP(2, ah0, al0, bh0, bl0, ah1, al1, bh1, bl1)
-        }
+    for (int u = 0; u < 2; u++) {               // the last (up to seven) steps: the general form
+        if (kt < KT) H4_STEP(0, ah0, al0, bh0, bl0, ah1, al1, bh1, bl1)
+        if (kt < KT) H4_STEP(1, ah1, al1, bh1, bl1, ah0, al0, bh0, bl0)
+        if (kt < KT) H4_STEP(2, ah0, al0, bh0, bl0, ah1, al1, bh1, bl1)
+        if (kt < KT) H4_STEP(3, ah1, al1, bh1, bl1, ah0, al0, bh0, bl0)
     }
+#undef H4_STEPF
+#undef H4_PIECE
+#undef H4_MFMA4
 #undef H4_READ
 #undef H4_ISSUE
 #undef H4_STEP

@@ -115,6 +115,7 @@ __device__ __forceinline__ void h16_epilogue(const ConvArgs& a, const h16_f32x16
             const int vo32 = nok ? vrow + n * 4 : 0x7FFF0000, vo16 = nok ? vrow + poff : 0x7FFF0000;
             float extra[16];
             if (EPI == 1) {
+                // (issuing tile t + 1's loads before tile t is processed was measured: no gain on the HBM-bound expand layers, round 4)
                 unsigned raw[16];
 #pragma unroll
                 for (int r = 0; r < 16; r++)
