@@ -332,6 +332,7 @@ def main():
         fills whole rounds of workgroup slots -- a 160-image strong-scaling shard runs 2 x 80, not 64 + 64 + 32 (or 54 + 53 + 53)."""
         if args.batch_images_explicit:
             return B
+        cap = int(os.environ.get("CALD_BENCH_BATCH_CAP", cap))      # e.g. 40 when eight ranks rehearse on ONE GPU (eight arenas in one HBM)
         return max(1, -(-n // max(1, -(-n // cap))))
 
     Bi = balanced(len(positions))                  # the timed call's internal batch size; the warm-up runs with the same one
