@@ -38,7 +38,10 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 template <int EPI, int TN, bool C4>
 __device__ __forceinline__ void conv_h3_body(const ConvArgs& a, const int blk) {
     constexpr int BM = 128, BN = 64 * TN, BK = 16, TM = 2, WN = 2;
-    constexpr int PLANE = BM * 32, PLANE_B = BN * 32, TILE_B = 2 * PLANE + 2 * PLANE_B;       // bytes
+    // the A lo plane starts 64 bytes (16 banks) past a multiple of the bank row: with the pre-split input a quad of lanes writes
+    // {hi half 0, hi half 1, lo half 0, lo half 1} of ONE row with one ds_write_b128 each, and planes exactly 4 KB apart put the hi and
+    // the lo pieces of a row on the same banks (2-way conflict on every staging store: SQ_LDS_BANK_CONFLICT was 20 % of the kernel's LDS cycles)
+    constexpr int PLANE = BM * 32 + 64, PLANE_B = BN * 32, TILE_B = 2 * PLANE + 2 * PLANE_B;       // bytes
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE_B];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

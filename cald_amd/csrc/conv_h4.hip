@@ -278,10 +278,11 @@ static PerDeviceOnce h4_once[4];
 bool launch_conv_h4(const ConvArgs& a, hipStream_t stream) {
     if (!h4_mode() || !h4_covers(a)) return false;
     const int wgs = ((a.total_mtiles + 1) >> 1) * (a.CoutPad >> 8);
-    // where it pays (measured per layer class, profiles/r4_*launches*): launches of >= 8 rounds of one workgroup per CU with long chains.
-    // Short chains want several residents per CU to hide prologue / epilogue phases, and a 4-round launch loses more to its last,
-    // partly filled round at 256 x 256 granularity than conv_h3 does at 128 x 128 with three residents
-    if (h4_mode() == 1 && (a.Kpad < 1024 || (wgs < 2048 && !(a.Kpad >= 4096 && wgs >= 1024)))) return false;   // fc6 (K = 12 544): 394 vs 347 TF-eq at 5 rounds
+    // where it pays, measured per layer class on BASELINE configs[4] with CALD_H4=2 against CALD_H4=0 (profiles/r4_h4_everywhere_vs_default.txt):
+    // every class with K >= 1024 and at least two rounds of one workgroup per CU gains 4-9 % (3 x 3 layers of >= 256 channels, the
+    // 1024 -> 256 / 2048 -> 512 reduce layers, fc6, the predictor); short chains (K <= 512: the expand layers with their residual
+    // epilogue, the laterals) lose 10-30 % -- they want several residents per CU to hide prologue / epilogue phases (conv_h3)
+    if (h4_mode() == 1 && (a.Kpad < 1024 || wgs < 512)) return false;
     const dim3 grid((unsigned)wgs), block(512);
     const size_t lds = (size_t)H4_NSTAGE * H4_STAGE;
     if (a.residual) { allow_big_lds(h4_once[1], conv_h4_kernel<1>); hipLaunchKernelGGL((conv_h4_kernel<1>), grid, block, lds, stream, a); }
@@ -298,7 +299,7 @@ bool launch_conv_h4_group(const ConvArgs* p, int n, hipStream_t stream) {
         blk += (((p[i].total_mtiles + 1) >> 1) * (p[i].CoutPad >> 8) + 7) & ~7;
     }
     g.blk0[n] = blk;
-    if (h4_mode() == 1 && (blk < 2048 || p[0].Kpad < 1024)) return false;
+    if (h4_mode() == 1 && (blk < 512 || p[0].Kpad < 1024)) return false;
     allow_big_lds(h4_once[3], conv_h4_group_kernel);
     hipLaunchKernelGGL(conv_h4_group_kernel, dim3((unsigned)blk), dim3(512), (size_t)H4_NSTAGE * H4_STAGE, stream, g);
     return true;

@@ -1327,3 +1327,41 @@ def test_c_abi_rccl_allgather_across_two_devices(hip, tmp_path):
         out, err = p.communicate(timeout=600)
         assert p.returncode == 0, err[-2000:]
         assert json.loads([l for l in out.splitlines() if l.startswith("RESULT ")][-1][7:])["ok"]
+
+
+def test_sweep_error_in_a_later_batch_leaves_the_model_usable(hip, small_model):
+    """cald_sweep keeps two batches in flight (reference forward of batch k + 1 while batch k's views are built).  An error that
+    surfaces while batch 1 is being built -- a resize ratio that empties one of ITS images -- must come back as an error (not a hang,
+    not silent garbage), and the next sweep on the same model must give exactly the scores of an undisturbed run."""
+    import ctypes as C
+    torch, ffi, L = hip["torch"], hip["ffi"], hip["L"]
+    from cald_amd import synth, sweep
+    model, _ = small_model
+    pool = synth.make_pool(12, "voc", 0, scale=0.5)
+    dev = [torch.from_numpy(im).cuda() for im in pool]
+    pos = list(range(12))
+    augs = ["flip", "cut_out", "smaller_resize"]
+    good, gk = sweep.sweep_device_images(model, dev, pos, augs, base_seed=5, batch_images=4)
+    tiny = torch.zeros((1, 1, 3), dtype=torch.uint8, device="cuda") + 90           # 1 x 1 image: int(1 * 0.8) = 0 -> "resize ratio empties"
+    bad = dev[:6] + [tiny] + dev[7:]
+    n = len(bad)
+    ptrs = (C.c_void_p * n)(*[im.data_ptr() for im in bad])
+    Hs = np.array([im.shape[0] for im in bad], np.int32); Ws = np.array([im.shape[1] for im in bad], np.int32)
+    cfg = sweep.make_sweep_cfg(augs, 1.3, 5, 4)
+    cons = np.zeros(n); cls = np.zeros((n, 20))
+    rc = L.cald_sweep(model.handle(), n, ptrs, ffi.ptr(Hs, ffi.c_i), ffi.ptr(Ws, ffi.c_i), ffi.ptr(np.asarray(pos, np.int64), ffi.c_i64), C.byref(cfg),
+                      ffi.ptr(cons, ffi.c_d), ffi.ptr(cls, ffi.c_d))
+    # a 1 x 1 image either yields no reference detection (then it is skipped: score 0, no error) or trips the resize check
+    assert rc == 0 or rc < 0
+    if rc == 0:
+        assert cons[6] == 0.0
+        np.testing.assert_array_equal(np.delete(cons, 6), np.delete(good, 6))
+    again, ak = sweep.sweep_device_images(model, dev, pos, augs, base_seed=5, batch_images=4)
+    np.testing.assert_array_equal(again, good); np.testing.assert_array_equal(ak, gk)
+    with pytest.raises(RuntimeError):                                                   # a hard error mid-pipeline: a null image pointer in batch 2
+        ptrs2 = (C.c_void_p * n)(*[(None if i == 9 else im.data_ptr()) for i, im in enumerate(dev)])
+        Hs2 = np.array([im.shape[0] for im in dev], np.int32); Ws2 = np.array([im.shape[1] for im in dev], np.int32)
+        ffi.check(L.cald_sweep(model.handle(), n, ptrs2, ffi.ptr(Hs2, ffi.c_i), ffi.ptr(Ws2, ffi.c_i), ffi.ptr(np.asarray(pos, np.int64), ffi.c_i64),
+                               C.byref(cfg), ffi.ptr(cons, ffi.c_d), ffi.ptr(cls, ffi.c_d)))
+    again, ak = sweep.sweep_device_images(model, dev, pos, augs, base_seed=5, batch_images=4)
+    np.testing.assert_array_equal(again, good); np.testing.assert_array_equal(ak, gk)

@@ -19,7 +19,7 @@ from cald_amd.pool import DevicePool
 
 
 def make_model(sd, ctx=None):
-    m = detector.fasterrcnn_resnet50_fpn_feature(num_classes=21, min_size=600, max_size=1000)
+    m = detector.fasterrcnn_resnet50_fpn_feature(num_classes=21, min_size=600, max_size=1000, precision=os.environ.get("PRECISION", "fp32"))
     m = m.to("cuda:0")
     m._ctx = ctx
     m.load_state_dict(sd)
