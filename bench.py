@@ -333,6 +333,8 @@ def main():
         if args.batch_images_explicit:
             return B
         cap = int(os.environ.get("CALD_BENCH_BATCH_CAP", cap))      # e.g. 40 when eight ranks rehearse on ONE GPU (eight arenas in one HBM)
+        if os.environ.get("CALD_BENCH_BALANCE", "equal") == "cap":   # batches of exactly `cap` images and one remainder batch
+            return max(1, min(cap, n))
         return max(1, -(-n // max(1, -(-n // cap))))
 
     Bi = balanced(len(positions))                  # the timed call's internal batch size; the warm-up runs with the same one

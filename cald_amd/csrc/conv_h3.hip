@@ -6,7 +6,7 @@
 // fp32-input one (32 cycles per 32x32x16 vs 64 cycles per 32x32x2), so three passes are ~5x faster than
 // conv_p4.hip's exact v_mfma_f32_32x32x2_f32 chain.  NOT bit-identical to the oracle (different rounding, ~1e-6
 // end to end like any other fp32 implementation, so ~1 % of images change through a flipped borderline detection;
-// DESIGN.md section 4b) -- this mode is opt-in (cald_model_cfg.precision = 1); the default mode stays the exact one.
+// DESIGN.md section 6) -- this mode is opt-in (cald_model_cfg.precision = 1); the default mode stays the exact one.
 // fp16 has a narrow exponent range: the lo part of a small operand would be subnormal (absolute step 2^-24, e.g.
 // only ~1e-6 relative for a weight of 0.03).  Both operands are therefore scaled by exact powers of two before the
 // split -- weights by 2^S per layer at finalize (max |w| * 2^S <= 2^14), activations by 2^4 while staging -- and the
@@ -18,8 +18,10 @@
 // layer on P2 moves 74 GB per launch from L2, 10.6 TB/s).
 //
 // Same implicit-GEMM structure as conv_p4.hip: 128 x 128 x 16 tiles, 4 waves (64 x 64 each), buffer loads with
-// hardware zero fill for out-of-image taps, XCD-aware tile map, fused fp32 epilogue.  Activations stay fp32 in HBM
-// (split while staging into LDS); weights are split and packed at model finalize (ConvArgs::w16).
+// hardware zero fill for out-of-image taps, XCD-aware tile map, fused fp32 epilogue (h16.h).  Activations arrive in split form
+// (h16.h, written so by their producer: the loader's 16 bytes go to LDS with one ds_write_b128) or as fp32 (split while staging:
+// the stem's input, tensors that also have fp32 readers); weights are split and packed at model finalize (ConvArgs::w16).
+// Large launches with long chains run on conv_h4.hip instead (same arithmetic, bit for bit).
 // LDS tile (16 KB): planes A_hi, A_lo, B_hi, B_lo of [128][16] fp16; a lane's MFMA operand (8 consecutive k of one
 // row) is one ds_read_b128, 16-byte halves XOR-swizzled with bit 3 of the row (conflict-free).  Two tile buffers,
 // one barrier per k-tile: the fragments of tile t+1 are read right after the barrier of tile t, under the

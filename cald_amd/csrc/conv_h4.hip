@@ -1,7 +1,7 @@
 // conv_h4.hip -- the large-tile kernel of the "fp16 MFMA path" (CALD_PRECISION_F16X3, BASELINE.json configs[4]).
 //
 // Same arithmetic as conv_h3.hip (every fp32 operand split into two fp16 values, a * b = a_lo b_hi + a_hi b_lo + a_hi b_hi on
-// v_mfma_f32_32x32x16_f16 into one fp32 accumulator; DESIGN.md section 4b), different data movement.  conv_h3's 128 x 128 tiles
+// v_mfma_f32_32x32x16_f16 into one fp32 accumulator; DESIGN.md section 6), different data movement.  conv_h3's 128 x 128 tiles
 // at three workgroups per CU pull 42 B / clk / CU through L2 -> VGPR -> LDS (16 KB per workgroup and k-step, each MFMA triple
 // paying for its own operand bytes) and its matrix pipe idles 40 % of the time waiting for them.  Here:
 //   * 256 x 256 x 16 tiles, ONE 512-thread workgroup per CU, 8 waves as 2 (M) x 4 (N), 128 x 64 outputs per wave = 24 MFMAs
@@ -12,11 +12,13 @@
 //     (the swizzle is applied on the SOURCE address -- the DMA's LDS image is lane-linear) so that every ds_read_b128 fragment
 //     read is bank-conflict-free;
 //   * a ring of four 32 KB stages (128 KB LDS), three k-steps of DMA in flight across the raw s_barrier of each step, counted
-//     s_waitcnt vmcnt -- the ring is what hides the L2 latency, not occupancy;
+//     s_waitcnt vmcnt -- the ring is what hides the L2 latency, not occupancy; the four DMA pieces a wave issues per step sit
+//     BETWEEN its MFMAs (a piece costs the wave 60-180 cycles of issue, which only the SIMD's other wave can cover);
 //   * out-of-image taps: the buffer descriptor's range check returns zeros to the LDS for lanes whose offset is out of range.
 // A workgroup covers two consecutive 128-row M tiles of the ragged batch (each lies inside one view; the halves may belong to
-// different views), so the batch plan is the one every other kernel uses.  Layers it does not cover (Cout % 256, fp32-only input,
-// in_relu, fewer workgroups than CUs) run on conv_h3.hip.
+// different views), so the batch plan is the one every other kernel uses.  Bit-identical to conv_h3.hip (same MFMAs, same order).
+// Layers it does not cover or does not pay for (Cout % 256, fp32-only input, in_relu, K < 1024, fewer than two rounds of
+// workgroups) run on conv_h3.hip.
 #include "h16.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -169,6 +171,8 @@ __device__ __forceinline__ void conv_h4_body(const ConvArgs& a, const int blk) {
     // piece, 6 MFMAs with one fragment read of the NEXT step after every second one } x 4 -- a DMA issue costs the wave ~60-180 cycles
     // (MI355X_MICROARCH.md), which the partner wave of the SIMD covers only if it is not issuing its own pieces at the same moment:
     // with the four pieces back to back right after the barrier (both waves of a SIMD in lockstep) the matrix pipe measured 57-59 % busy.
+// H4_VARIANT (compile time, tools/h4_dev.hip): 5 = shipped; 1 = the four pieces up front; 2 / 3 / 4 = TIMING ablations without the DMA /
+// the barrier / the fragment reads -- their results are wrong by construction (profiles/r4_conv_h4_ablations.txt)
 #ifndef H4_VARIANT
 #define H4_VARIANT 5
 #endif

@@ -63,7 +63,7 @@ class HipDetector:
                  rpn_nms_thresh=0.7, arch=0, precision="fp32", **unused):
         """precision: "fp32" (exact, bit-identical to the oracle; default), "f16x3" (split-fp16 MFMA path, 2x faster, fp32-grade
         but not reproducible on a CPU) or "i8x3" (exact-integer int8 MFMA path: block floating point per pixel, bit-identical to
-        ITS oracle) -- include/cald_hip.h, DESIGN.md section 4b / 4c.  Neither matrix-pipe mode is bit-identical to fp32."""
+        ITS oracle) -- include/cald_hip.h, DESIGN.md section 6.  Neither matrix-pipe mode is bit-identical to fp32."""
         self.arch = arch
         self.cfg = _ffi.ModelCfg(self.arch, depth, num_classes, int(min_size), int(max_size), box_score_thresh,
                                  box_nms_thresh, box_detections_per_img, rpn_pre_nms_top_n_test, rpn_post_nms_top_n_test,
