@@ -42,7 +42,9 @@ __device__ __forceinline__ void conv_h3_body(const ConvArgs& a, const int blk) {
     constexpr int BM = 128, BN = 64 * TN, BK = 16, TM = 2, WN = 2;
     // the A lo plane starts 64 bytes (16 banks) past a multiple of the bank row: with the pre-split input a quad of lanes writes
     // {hi half 0, hi half 1, lo half 0, lo half 1} of ONE row with one ds_write_b128 each, and planes exactly 4 KB apart put the hi and
-    // the lo pieces of a row on the same banks (2-way conflict on every staging store: SQ_LDS_BANK_CONFLICT was 20 % of the kernel's LDS cycles)
+    // the lo pieces of a row on the same banks.  Measured +1.5 % on the 3 x 3 256 -> 256 layer (345-349 -> 353 TF-eq); the kernel's
+    // SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE still reads 0.20 -- it does for every kernel here that stores 16 bytes per lane to
+    // LDS (conv_h4, which has no LDS stores, reads 0), so that figure is how the wide stores are accounted, not this pattern
     constexpr int PLANE = BM * 32 + 64, PLANE_B = BN * 32, TILE_B = 2 * PLANE + 2 * PLANE_B;       // bytes
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE_B];
 
