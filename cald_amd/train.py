@@ -598,9 +598,12 @@ class FasterRCNNTrainer(_TrainerBase):
                 spec = self._rpn_branch_weights(rpn_state, 1.0, 1.0, speculative=True)
                 props_ready.synchronize()
                 counts = counts_h.tolist()
+                proposals = [props[i, :counts[i]] for i in range(N)]
             else:
-                counts = counts.cpu().tolist()
-            proposals = [props[i, :counts[i]] for i in range(N)]
+                # ONE host stop instead of two: the proposal counts are not waited for.  The RoI candidates are matched in a fixed-row
+                # table (image i: its post_n proposal slots, used or not, then its ground truth) and the counts travel to the host in
+                # the same copy as the match results; unused slots are dropped there.  Same candidates, same draws, same rows.
+                proposals = None
         else:
             proposals = [p.to(self.dev).float().contiguous() for p in proposals_override]
         mark("proposals")
@@ -612,17 +615,29 @@ class FasterRCNNTrainer(_TrainerBase):
                 aux[0].wait_event(props_ready)
                 ops._WGRAD_CTX[0] = aux[1]
             try:
-                n_pr = [int(proposals[i].shape[0]) + n_gt[i] for i in range(N)]
+                fixed_rows = proposals is None
+                slots = [(int(props.shape[1]) if fixed_rows else int(proposals[i].shape[0])) for i in range(N)]
+                n_pr = [slots[i] + n_gt[i] for i in range(N)]
                 pr_off = np.cumsum([0] + n_pr)
-                pr_all = torch.cat([t for i in range(N) for t in ((proposals[i], gts[i]) if n_gt[i] else (proposals[i],))]).contiguous()
-                matched_dev = torch.full((int(pr_off[-1]),), -1, dtype=torch.int32, device=self.dev)
+                src = [props[i] for i in range(N)] if fixed_rows else proposals
+                pr_all = torch.cat([t for i in range(N) for t in ((src[i], gts[i]) if n_gt[i] else (src[i],))]).contiguous()
+                matched_dev = torch.full((int(pr_off[-1]) + (N if fixed_rows else 0),), -1, dtype=torch.int32, device=self.dev)
                 for i in range(N):
                     if n_gt[i]:
                         ops.match(pr_all[pr_off[i]:pr_off[i + 1]], gts[i], cfg["box_fg"], cfg["box_bg"], False, out=matched_dev[pr_off[i]:pr_off[i + 1]])
+                if fixed_rows:
+                    matched_dev[int(pr_off[-1]):] = counts.to(torch.int32)
                 matched_all = matched_dev.cpu().numpy()
+                if fixed_rows:
+                    counts = [int(v) for v in matched_all[int(pr_off[-1]):]]
+                    proposals = [props[i, :counts[i]] for i in range(N)]
+                    # compact candidate number -> row of the fixed-row table (the used proposal slots, then the ground truth)
+                    rowmap = [np.concatenate([np.arange(counts[i]), slots[i] + np.arange(n_gt[i])]).astype(np.int64) for i in range(N)]
+                else:
+                    rowmap = [np.arange(n_pr[i], dtype=np.int64) for i in range(N)]
                 keep_all, lab_all, gtsel_all, img_col = [], [], [], []
                 for i in range(N):
-                    m = matched_all[pr_off[i]:pr_off[i + 1]]
+                    m = matched_all[pr_off[i]:pr_off[i + 1]][rowmap[i]]
                     if n_gt[i]:
                         labels = gt_labels[i].numpy()[np.maximum(m, 0)].copy()
                         labels[m == -1] = 0
@@ -633,7 +648,7 @@ class FasterRCNNTrainer(_TrainerBase):
                     sp, sn = self._sample(pos, neg, cfg["box_batch"], cfg["box_pos"])
                     box_samples.append((np.sort(sp.numpy()), np.sort(sn.numpy())))
                     keep = np.sort(np.concatenate([sp.numpy(), sn.numpy()]))
-                    keep_all.append(pr_off[i] + keep); lab_all.append(labels[keep])
+                    keep_all.append(pr_off[i] + rowmap[i][keep]); lab_all.append(labels[keep])
                     gtsel_all.append(gt_off[i] + np.maximum(m[keep], 0) if n_gt[i] else np.full(len(keep), gt_off[-1], np.int64))
                     img_col.append(np.full(len(keep), float(i), np.float32))
                 roi_labels_np = np.concatenate(lab_all).astype(np.int64)
