@@ -712,7 +712,7 @@ def test_config3_full_size_frcnn_r50_coco(hip, oracle):
 def test_config4_full_size_frcnn_r101_coco_five_augs(hip, oracle):
     """BASELINE.json configs[4]: Faster R-CNN ResNet-101 FPN, COCO shapes, 5 augmentations (FCDR + G: flip, ga, cut_out,
     smaller_resize, rotation -> 6 views per image), exact fp32."""
-    _full_size_coco_case(hip, oracle, 101, ["flip", "ga", "cut_out", "smaller_resize", "rotation"], (0, 2, 3, 5, 7, 8, 9, 10), seed=1)
+    _full_size_coco_case(hip, oracle, 101, ["flip", "ga", "cut_out", "smaller_resize", "rotation"], (0, 3, 5, 7, 8, 10), seed=1)   # 6 of 12: a ResNet-101 image with six views costs the CPU oracle ~20 s
 
 
 def test_float_inputs_reach_the_kernels_exactly(hip, oracle, small_model):
