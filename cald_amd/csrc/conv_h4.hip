@@ -167,10 +167,11 @@ __device__ __forceinline__ void conv_h4_body(const ConvArgs& a, const int blk) {
         kt++;                                                                                                                \
     }
 
-    // Steady-state k-step (kt + 4 < KT): no conditionals.  Issue order asked of the scheduler: per DMA piece { its address select, the
-    // piece, 6 MFMAs with one fragment read of the NEXT step after every second one } x 4 -- a DMA issue costs the wave ~60-180 cycles
-    // (MI355X_MICROARCH.md), which the partner wave of the SIMD covers only if it is not issuing its own pieces at the same moment:
-    // with the four pieces back to back right after the barrier (both waves of a SIMD in lockstep) the matrix pipe measured 57-59 % busy.
+    // Steady-state k-step (kt + 4 < KT): no conditionals, one basic block.  The 12 fragment reads of the NEXT step go out right after the
+    // barrier; the four DMA pieces of stage kt + 4 are placed in program order after the 4th, 8th, 12th and 16th of the step's 24 MFMAs
+    // (pinned with sched_barrier).  A piece costs the issuing wave ~60-180 cycles (MI355X_MICROARCH.md), which only the SIMD's other wave
+    // can cover -- and with all four pieces right after the barrier both waves of a SIMD, which leave the barrier together, sit in
+    // their DMA issues at the same time: SQ_VALU_MFMA_BUSY_CYCLES 73 of 128 per XCD-cycle then, 88 now (group launches).
 // H4_VARIANT (compile time, tools/h4_dev.hip): 5 = shipped; 1 = the four pieces up front; 2 / 3 / 4 = TIMING ablations without the DMA /
 // the barrier / the fragment reads -- their results are wrong by construction (profiles/r4_conv_h4_ablations.txt)
 #ifndef H4_VARIANT
