@@ -39,7 +39,6 @@ if ROOT not in sys.path:
 
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
 F16_MFMA_PEAK_TFLOPS = 2516.6  # v_mfma_f32_32x32x16_f16: 32 cycles / SIMD -> 16 x the f32-input rate (dense)
-I8_MFMA_PEAK_TOPS = 5033.2     # v_mfma_i32_32x32x32_i8: 2 x the f16 rate (dense); one algorithmic MAC costs six digit MACs
 FULL_POOL = 5217               # VOC2012 train 5 717 - 500 initially labeled (cald_train.py:299-300)
 FULL_BUDGET = 500
 
@@ -186,6 +185,65 @@ def latest_pmc():
     return {"hbm_bytes_per_launch": None, "hbm_gbps": None, "mfma_busy": None, "source": None, "csrc_sha1": here}
 
 
+def parity_file():
+    """Whole-pool parity against the torch-CPU fp32 path (tools/parity_full_pool.py -> profiles/parity_vs_independent_fp32_r*.json).
+    Not measured in this run (the CPU path takes hours), so -- like the PMC counters -- it is reported only from a file that
+    records the hash of exactly the running kernel sources; otherwise the field says which file is the latest and that it is stale."""
+    here, latest = csrc_sha1(), None
+    d = os.path.join(ROOT, "profiles")
+    for name in sorted((f for f in os.listdir(d) if f.startswith("parity_vs_independent_fp32_r") and f.endswith(".json")), reverse=True):
+        try:
+            j = json.load(open(os.path.join(d, name)))
+        except Exception:
+            continue
+        latest = latest or name
+        if j.get("csrc_sha1") == here:
+            return dict(j["summary"], from_file=True, measured_in_this_run=False, source="profiles/" + name, csrc_sha1=here)
+    return {"from_file": False, "source": None, "csrc_sha1": here,
+            "note": "no parity file was measured on exactly these kernel sources (latest: %s); figures of other kernels are not "
+                    "pasted here" % (("profiles/" + latest) if latest else "none")}
+
+
+def cfg4_f16x3_leg(local_rank, n=128):
+    """BASELINE configs[4] on one GPU in ITS precision: Faster R-CNN ResNet-101 FPN, COCO-shaped synthetic images, 91 classes,
+    min/max 800/1333, five augmentations (flip, ga, cut_out, smaller_resize, rotation: 6 views per image), precision f16x3 (the
+    "fp16 MFMA path").  images/s of one cald_sweep call over n HBM-resident images, and the GEMM family's algorithmic FLOP rate
+    (HIP events on the launch stream) against the dense fp16 MFMA peak.  Its parity gate is tests/test_gpu_parity.py::
+    test_config4_full_size_f16x3_vs_exact (same workload against the exact mode)."""
+    import ctypes as C
+    import torch
+    from cald_amd import _ffi, detector, sweep, synth
+    augs = ["flip", "ga", "cut_out", "smaller_resize", "rotation"]
+    sd = synth.pseudo_trained_frcnn(91, 101, seed=1)
+    m = detector.fasterrcnn_resnet101_fpn_feature(num_classes=91, min_size=800, max_size=1333, precision="f16x3").to("cuda:%d" % local_rank)
+    m.load_state_dict(sd)
+    m.eval()
+    dev = [torch.from_numpy(im).cuda() for im in synth.make_pool(n, "coco", 0)]
+    pos = list(range(n))
+    Bi = 64                                                  # 64 reference views, then 5 x 64 augmented views in forwards of <= 96
+    sweep.sweep_device_images(m, dev[:Bi], pos[:Bi], augs, bp=1.3, base_seed=0, batch_images=Bi)      # warm-up: code objects, arena
+    L, ctx = _ffi.lib(), detector.get_ctx(local_rank)
+    _ffi.check(L.cald_profile_enable(ctx, 1))
+    torch.cuda.synchronize(); t = time.time()
+    cons, _ = sweep.sweep_device_images(m, dev, pos, augs, bp=1.3, base_seed=0, batch_images=Bi)
+    torch.cuda.synchronize(); t = time.time() - t
+    gm, gf, tot, nl = C.c_double(), C.c_double(), C.c_double(), C.c_int64()
+    _ffi.check(L.cald_profile_read(ctx, C.byref(gm), C.byref(gf), C.byref(nl), C.byref(tot)))
+    _ffi.check(L.cald_profile_enable(ctx, 0))
+    del m
+    torch.cuda.empty_cache()
+    ach = gf.value / (gm.value * 1e-3) / 1e12 if gm.value > 0 else 0.0
+    return {"workload": "BASELINE.json configs[4] (per GPU): Faster R-CNN ResNet-101 FPN, COCO-shaped synthetic images, 91 classes, min/max 800/1333, "
+                        "5 augs (flip/ga/cut_out/smaller_resize/rotation = 6 views per image)",
+            "headline": False, "value": n / t, "unit": "images/s", "images": n, "seconds": t, "sweep_batch_images": Bi,
+            "dtype": "f16x3 (fp16 hi+lo split operands, 3 x v_mfma_f32_32x32x16_f16 per product, fp32 accumulate)",
+            "scores_sha1": hashlib.sha1(cons.tobytes()).hexdigest(),
+            "roofline": {"bound": "mfma", "achieved": ach, "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / F16_MFMA_PEAK_TFLOPS,
+                         "launches": int(nl.value), "gemm_ms": gm.value,
+                         "note": "algorithmic FLOPs counted once per product (three MFMAs issue per product: at most 1/3 of the pipe)"},
+            "parity_gate": "tests/test_gpu_parity.py::test_config4_full_size_f16x3_vs_exact"}
+
+
 def config0_leg(model, sd, B, threads=None):
     """BASELINE configs[0] (the reference's CPU-runnable plumbing case: 200 synthetic VOC-shaped images, flip only) on the
     GPU, with the torch-CPU port (an fp32 path that does NOT share the arithmetic contract) scoring a bounded sample of
@@ -238,13 +296,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-full-pool", action="store_true", help="skip the 5 217-image end-to-end run (N = 1 headline only)")
     ap.add_argument("--no-f16x3", action="store_true")
+    ap.add_argument("--no-cfg4", action="store_true", help="skip the configs[4] leg (ResNet-101, COCO shapes, 5 augs, f16x3)")
     ap.add_argument("--no-train", action="store_true", help="skip the training-step leg (SURVEY 8f rank 4, informational)")
     ap.add_argument("--model", default="frcnn", choices=["frcnn", "frcnn101", "retinanet"],
                     help="frcnn = the headline workload (BASELINE configs[1]); others are informational runs of configs[2]/[4]")
     ap.add_argument("--shape", default="voc", choices=["voc", "coco"])
     ap.add_argument("--augs", default="FCD", help="letters of cald_train.py --augs (F C D R G S)")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "f16x3", "i8x3"],
-                    help="fp32 = exact (headline, bit-identical to the oracle); f16x3 / i8x3 = informational matrix-pipe modes")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "f16x3"],
+                    help="fp32 = exact (headline, bit-identical to the oracle); f16x3 = the opt-in split-fp16 matrix-pipe mode")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:      # plain `python bench.py --gpus N`: start the N ranks ourselves
@@ -403,13 +462,12 @@ def main():
     if rank == 0:
         pmc = latest_pmc()
         achieved = gf.value / (gm.value * 1e-3) / 1e12 if gm.value > 0 else 0.0
-        peak = {"fp32": F32_MFMA_PEAK_TFLOPS, "f16x3": F16_MFMA_PEAK_TFLOPS, "i8x3": I8_MFMA_PEAK_TOPS}[args.precision]
+        peak = {"fp32": F32_MFMA_PEAK_TFLOPS, "f16x3": F16_MFMA_PEAK_TFLOPS}[args.precision]
         out = {
             "metric": "unlabeled images scored/sec (CALD consistency sweep)", "value": pool_total / dt, "unit": "images/s",
             "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": dt / max(1, K) * 1e3, "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None,
-            "dtype": {"fp32": "f32", "f16x3": "f16x3 (fp16 hi+lo split operands, fp32 accumulate)",
-                      "i8x3": "i8x3 (block floating point per pixel as three int8 digits, exact int32 accumulation per tap)"}[args.precision],
+            "dtype": {"fp32": "f32", "f16x3": "f16x3 (fp16 hi+lo split operands, fp32 accumulate)"}[args.precision],
             "data": "synthetic",
             "config": {"workload": ("BASELINE.json configs[1]: Faster R-CNN ResNet-50 FPN, VOC2012-shaped synthetic pool (baseline JPEG files), "
                                     "3 augs (flip/cut_out/smaller_resize), 21 classes, min/max 600/1000, seeded pseudo-trained weights")
@@ -436,9 +494,7 @@ def main():
                                      "note": "same pool, JPEG decode on the GPU + H2D included (max over ranks); never `value`"},
             "roofline": {"bound": "mfma",
                          "kernel": {"fp32": "conv_p4_kernel + conv_mfma_f32_kernel (implicit-GEMM conv + linear, v_mfma_f32_32x32x2_f32)",
-                                    "f16x3": "conv_h3_kernel / conv_h4_kernel (3 x v_mfma_f32_32x32x16_f16 per product; algorithmic flops counted once: at most 1/3 of the pipe's peak; measured power ceiling on random operands ~0.15, profiles/r4_f16x3_zero_vs_random_operands.txt) + exact kernels for uncovered shapes",
-                                    "i8x3": "conv_i3_kernel (6 x v_mfma_i32_32x32x32_i8 per product; algorithmic flops counted once; the digit-plane "
-                                            "quantiser passes are outside the GEMM timing) + exact kernels for uncovered shapes"}[args.precision],
+                                    "f16x3": "conv_h3_kernel / conv_h4_kernel (3 x v_mfma_f32_32x32x16_f16 per product; algorithmic flops counted once: at most 1/3 of the pipe's peak; measured power ceiling on random operands ~0.15, profiles/r4_f16x3_zero_vs_random_operands.txt) + exact kernels for uncovered shapes"}[args.precision],
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": pmc["hbm_bytes_per_launch"] if args.precision == "fp32" else None,
                          "hbm_gbps": pmc["hbm_gbps"] if args.precision == "fp32" else None,
@@ -504,22 +560,8 @@ def main():
                                          "pipeline flips a borderline detection on ~1 % of images under ANY change of rounding -- the exact mode against "
                                          "an independent fp32 path does the same (parity_vs_independent_fp32)"}
             del fast
-            # the exact-integer int8 mode: block floating point per pixel, reproducible by its oracle (tests)
-            i8m = (detector.fasterrcnn_resnet50_fpn_feature(num_classes=ncls, min_size=mn, max_size=mx, precision="i8x3")
-                   .to("cuda:%d" % local_rank))
-            i8m.load_state_dict(sd)
-            i8m.eval()
-            n8 = min(nb, 2 * B)
-            run8 = lambda mdl: sweep.sweep_device_images(mdl, imgs[:n8], pos_f[:n8], augs, bp=1.3, base_seed=0, batch_images=B)
-            ic, _ = run8(i8m)
-            torch.cuda.synchronize(); tf = time.time()
-            run8(i8m)
-            torch.cuda.synchronize(); tf = time.time() - tf
-            d = np.abs(ic - ec[:n8])
-            out["i8x3_mode"] = {"value": n8 / tf, "unit": "images/s", "dtype": "block floating point per pixel, three int8 digits, 6 x v_mfma_i32_32x32x32_i8 per product, exact int32 accumulation per tap",
-                                "headline": False, "images_compared": n8, "max_abs_consistency_diff_vs_exact": float(d.max()),
-                                "images_beyond_1e-4_vs_exact": int((d > 1e-4).sum()),
-                                "note": "bit-identical to its CPU oracle (tests/test_gpu_parity.py); distance to fp32: profiles/parity_vs_independent_fp32_r4.json"}
+        if world == 1 and headline and not args.no_cfg4:
+            out["cfg4_f16x3"] = cfg4_f16x3_leg(local_rank)
         if world == 1 and headline and not args.no_train:
             # informational, NOT the headline: one training step of the same detector, cald_train.py's defaults
             sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -527,12 +569,7 @@ def main():
             del model
             torch.cuda.empty_cache()
             out["training_step"] = dict(bench_train.measure(batch=4, steps=10, warmup=3), headline=False)
-        try:
-            out["parity_vs_independent_fp32"] = dict(
-                json.load(open(os.path.join(ROOT, "profiles", "parity_vs_independent_fp32_r2.json")))["summary"],
-                from_file=True, source="profiles/parity_vs_independent_fp32_r4.json (tools/parity_full_pool.py; not measured in this run)")
-        except Exception:
-            pass
+        out["parity_vs_independent_fp32"] = parity_file()
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

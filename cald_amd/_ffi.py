@@ -25,7 +25,7 @@ class ModelCfg(C.Structure):
                 ("rpn_nms_thresh", C.c_float), ("precision", C.c_int)]
 
 
-PRECISION = {"fp32": 0, "f16x3": 1, "i8x3": 2}
+PRECISION = {"fp32": 0, "f16x3": 1}
 
 
 class View(C.Structure):
@@ -75,8 +75,6 @@ SIGNATURES = {
                                   C.c_void_p, c_f, c_i]),
     "cald_op_conv2d": (C.c_int, [C.c_void_p, c_f, C.c_int, C.c_int, C.c_int, c_f, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_int, c_f, c_f, c_f, c_f, C.c_int, c_f]),
-    "cald_op_conv2d_i8x3": (C.c_int, [C.c_void_p, c_f, C.c_int, C.c_int, C.c_int, c_f, C.c_int, C.c_int, C.c_int, C.c_int,
-                                      C.c_int, c_f, c_f, c_f, c_f, C.c_int, c_f]),
     "cald_op_conv2d_f16x3": (C.c_int, [C.c_void_p, c_f, C.c_int, C.c_int, C.c_int, c_f, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_int, c_f, c_f, c_f, c_f, C.c_int, c_f]),
     "cald_op_conv_bench": (C.c_int, [C.c_void_p] + [C.c_int] * 12 + [c_d, c_d]),

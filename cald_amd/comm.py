@@ -50,7 +50,9 @@ class RcclComm:
         """rows: float64 device tensor [n][row_len], the same n on every rank -> [world * n][row_len] on every rank."""
         assert rows.is_cuda and rows.dtype == torch.float64 and rows.is_contiguous() and rows.dim() == 2
         out = torch.empty((self.world * rows.shape[0], rows.shape[1]), dtype=torch.float64, device=rows.device)
-        # the context is bound to torch's current stream of the device: the collective is ordered after whatever produced `rows`
+        # the collective runs on the CONTEXT's stream (bound when the context was created), which need not be torch's current stream
+        # here: finish whatever produced `rows` (and torch.empty's allocation) first -- once per sweep, microseconds
+        torch.cuda.current_stream(rows.device).synchronize()
         _ffi.check(_ffi.lib().cald_allgather_scores(self.handle, C.c_void_p(rows.data_ptr()), C.c_void_p(out.data_ptr()), rows.shape[0], rows.shape[1]))
         _ffi.check(_ffi.lib().cald_ctx_sync(get_ctx(self.device)))
         return out

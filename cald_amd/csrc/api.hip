@@ -366,7 +366,6 @@ struct ConvLayer {
     float *w = nullptr, *w4 = nullptr, *bias = nullptr, *scale = nullptr, *shift = nullptr;
     float* wstem = nullptr;                              // conv_stem.hip packing (the 7 x 7 / 2, 3 -> 64 stem only)
     uint16_t* w16 = nullptr; float w16_unscale = 1.0f;   // CALD_PRECISION_F16X3 only
-    signed char* w8 = nullptr; float* w8_unscale = nullptr;   // CALD_PRECISION_I8X3 only (layers conv_i3.hip covers)
     int Cin = 0, Cout = 0, CoutPad = 0, K = 0, Kpad = 0, KH = 1, KW = 1, stride = 1, pad = 0;
     int CinTrue = 0;   // un-padded input channels (algorithmic FLOP accounting)
 };
@@ -403,10 +402,6 @@ struct cald_model {
         char* dev = nullptr; char* pin = nullptr; uint8_t* d_aug = nullptr;
         hipEvent_t ev_ref[2] = {nullptr, nullptr}, ev_score[2] = {nullptr, nullptr};
     } ss;
-    signed char* i8_scratch = nullptr; size_t i8_cap = 0, i8_off = 0;   // digit-plane scratch of the running forward
-    // the tensor whose digit planes sit at the start of the scratch (the previous single-conv launch's input); a caller that knows the
-    // tensor was not rewritten since (a block's downsample conv followed by its conv1 on the same input) may ask to reuse them
-    const float* i8_last_in = nullptr; long long i8_last_P = 0; int i8_last_Cin = 0; bool i8_reuse_hint = false;
     int key_cap = 32768;   // FRCNN candidate (proposal, class) list capacity per view, sized from box_score_thresh at create
 };
 
@@ -418,7 +413,7 @@ extern "C" int cald_model_create(cald_ctx* ctx, const cald_model_cfg* cfg, cald_
     if (cfg->rpn_pre_nms_top_n > 1024 || cfg->rpn_post_nms_top_n > CALD_ROI_CAP || cfg->rpn_pre_nms_top_n < 1 || cfg->rpn_post_nms_top_n < 1)
         return fail(CALD_ERR_INVALID, "rpn top-n out of range (pre <= 1024, post <= %d)", CALD_ROI_CAP);
     if (cfg->detections_per_img < 1 || cfg->detections_per_img > 1024) return fail(CALD_ERR_INVALID, "detections_per_img out of range");
-    if (cfg->precision != CALD_PRECISION_FP32 && cfg->precision != CALD_PRECISION_F16X3 && cfg->precision != CALD_PRECISION_I8X3) return fail(CALD_ERR_INVALID, "unknown precision %d", cfg->precision);
+    if (cfg->precision != CALD_PRECISION_FP32 && cfg->precision != CALD_PRECISION_F16X3) return fail(CALD_ERR_INVALID, "unknown precision %d", cfg->precision);
     cald_model* m = new cald_model();
     m->ctx = ctx; m->cfg = *cfg;
     {   // softmax rows sum to 1, so fewer than 1/thr classes of one proposal can pass `score > thr` (frcnn_la.py:72):
@@ -483,43 +478,6 @@ static std::vector<uint16_t> pack_w16(const std::vector<float>& w, int Kpad, int
     return o;
 }
 
-// CALD_PRECISION_I8X3 (conv_i3.hip): per output channel n the weights are quantised to fixed point,
-// q = rint(w * 2^(22 - e_w[n])) with max_k |w[k][n]| = f * 2^e_w[n], f in [0.5, 1) (|q| <= 2^22), and written as three balanced signed
-// base-256 digits.  Packed [K/32][3 planes][CoutPad][32 B]; k-tiles in (kh, kw, 32-channel chunk) order, byte j of a tile = channel
-// 32 * chunk + j of that tap.  unscale[n] = 2^(e_w[n] - 22 + 16).  `w` is the K-major matrix in conv_k_index order.
-static bool i8_covers(int Cin, int Cout, int taps) { return Cin % 32 == 0 && Cin >= 64 && Cout >= 64 && taps <= 32; }
-static void i8_digits(long long q, int* d) {
-    d[0] = (int)(signed char)(q & 255); const long long q1 = (q - d[0]) >> 8;
-    d[1] = (int)(signed char)(q1 & 255); d[2] = (int)((q1 - d[1]) >> 8);
-}
-static std::vector<signed char> pack_w8(const std::vector<float>& w, int CoutPad, int taps, int Cin, std::vector<float>& unscale) {
-    const int K8 = taps * Cin, KT = K8 / 32, CC = Cin / 32;
-    std::vector<signed char> o((size_t)KT * 3 * CoutPad * 32, 0);
-    unscale.assign(CoutPad, 1.0f);
-    std::vector<int> ew(CoutPad, 0);
-    for (int n = 0; n < CoutPad; n++) {
-        float mx = 0.0f;
-        for (int k = 0; k < K8; k++) { const float ax = std::fabs(w[(size_t)k * CoutPad + n]); if (ax > mx) mx = ax; }
-        int e = 0;
-        if (mx > 0.0f && std::isfinite(mx)) { std::frexp(mx, &e); }          // mx = f * 2^e, f in [0.5, 1): |w| < 2^e
-        if (e > 60) e = 60; if (e < -60) e = -60;
-        ew[n] = e; unscale[n] = std::ldexp(1.0f, e - 22 + 16);
-    }
-    for (int tap = 0; tap < taps; tap++)
-        for (int cc = 0; cc < CC; cc++) {
-            const int kt = tap * CC + cc;
-            for (int j = 0; j < 32; j++) {
-                const int k = conv_k_index(tap, cc * 32 + j, taps, Cin);
-                for (int n = 0; n < CoutPad; n++) {
-                    const double t = std::nearbyint((double)std::ldexp(w[(size_t)k * CoutPad + n], 22 - ew[n]));
-                    int d[3]; i8_digits((long long)t, d);
-                    for (int pl = 0; pl < 3; pl++) o[(((size_t)kt * 3 + pl) * CoutPad + n) * 32 + j] = (signed char)d[pl];
-                }
-            }
-        }
-    return o;
-}
-
 static int get_t(cald_model* m, const std::string& key, const HostTensor** t) {
     auto it = m->sd.find(key);
     if (it == m->sd.end()) return fail(CALD_ERR_MISSING_WEIGHT, "missing tensor '%s' in state dict", key.c_str());
@@ -575,10 +533,6 @@ static int make_conv(cald_model* m, ConvLayer& L, const std::vector<std::string>
                     wsm[(((size_t)q * 2 + h) * 64 + co) * 4 + e] = ws[0]->data[(((size_t)co * 3 + ci) * 7 + y) * 7 + x];
             }
         if ((rc = upload(m, wsm, &L.wstem))) return rc;
-    }
-    if (m->cfg.precision == CALD_PRECISION_I8X3 && i8_covers(L.Cin, L.Cout, kh * kw)) {   // conv_i3.hip digits
-        std::vector<float> un; std::vector<signed char> w8 = pack_w8(w, L.CoutPad, kh * kw, L.Cin, un);
-        if ((rc = upload(m, w8, &L.w8)) || (rc = upload(m, un, &L.w8_unscale))) return rc;
     }
     if (m->cfg.precision == CALD_PRECISION_F16X3 && L.CoutPad % 64 == 0 && ((L.Cin % 16 == 0 && kh * kw <= 32) || L.Cin == 4)) {   // conv_h3.hip layout
         std::vector<uint16_t> w16 = pack_w16(w, L.Kpad, L.CoutPad, &L.w16_unscale, kh, kw, L.Cin);
@@ -768,7 +722,6 @@ struct FwdBufs {
     float *ret_t[2][2][5], *cls_h[5], *reg_h[5], *rcand_box, *kept_box; unsigned long long* rcand_key;   // ret_t[tower][ping-pong][level]
     float* rpn_tl[5];
     int *cand_count, *kept_anchor, *kept_count; int cand_cap; int max_anchors; unsigned char* cand_skip;
-    signed char* i8_planes; size_t i8_cap, i8_off;   // CALD_PRECISION_I8X3: digit planes of the conv input(s) being consumed
     unsigned* Pf16[5];   // CALD_PRECISION_F16X3: split twins of the tensors that stay fp32 as well
 };
 
@@ -784,7 +737,7 @@ static double fill_conv_args(cald_model* m, ConvArgs& a, const ConvLayer& L, con
     a.KH = L.KH; a.KW = L.KW; a.stride = L.stride; a.pad = L.pad; a.relu = relu ? 1 : 0;
     a.total_mtiles = level_tiles(m->plan, lout, V);
     a.out_ld = L.Cout; a.in_relu = in_relu ? 1 : 0; a.zeros = m->ctx->d_zeros; a.exp_flags = 0;
-    a.i8_in = nullptr; a.i8_plane_stride = 0; a.w8 = nullptr; a.w8_unscale = nullptr; a.i8_rowscale = nullptr; a.mask = nullptr;
+    a.mask = nullptr;
     // the kernels address a view's tensor through a buffer resource / 32-bit byte offsets: a view (or a dense RoI-row segment) must stay
     // below 2 GB per operand -- refuse loudly instead of reading zeros past the end (as a 64-view fc6 operand in one segment once did)
     for (int v = 0; v < V; v++) {
@@ -824,27 +777,12 @@ static double fill_conv_args(cald_model* m, ConvArgs& a, const ConvLayer& L, con
         }
         if (exact) a.wstem = L.wstem;
     }
-    if (m->cfg.precision == CALD_PRECISION_I8X3 && L.w8 && !in_relu && m->i8_scratch) {
-        // this layer runs on the int8 pipe: write the three digit planes + per-pixel scales of its input, then hand them to conv_i3.hip
-        const long long P = level_pix(m->plan, lin, V);
-        const size_t stride = ((size_t)P * L.Cin + 15) & ~(size_t)15, rs_bytes = ((size_t)P * 4 + 255) & ~(size_t)255;
-        if (m->i8_off + 3 * stride + rs_bytes <= m->i8_cap) {
-            signed char* pl = m->i8_scratch + m->i8_off;
-            float* rs = reinterpret_cast<float*>(pl + 3 * stride);
-            const bool reuse = m->i8_reuse_hint && m->i8_off == 0 && m->i8_last_in == in && m->i8_last_P == P && m->i8_last_Cin == L.Cin;
-            if (m->i8_off == 0) { m->i8_last_in = in; m->i8_last_P = P; m->i8_last_Cin = L.Cin; } else m->i8_last_in = nullptr;
-            m->i8_off += 3 * stride + rs_bytes;
-            if (!reuse) launch_quantize_pixels(in, P, L.Cin, pl, (long long)stride, rs, m->ctx->stream);
-            a.i8_in = pl; a.i8_plane_stride = (long long)stride; a.w8 = L.w8; a.w8_unscale = L.w8_unscale; a.i8_rowscale = rs;
-        }   // (no room: cannot happen with fwd_layout's sizing; the exact kernel would run)
-    }
     return 2.0 * (double)level_pix(m->plan, lout, V) * (double)L.Cout * (double)(L.KH * L.KW * L.CinTrue);
 }
 static int conv_on(cald_model* m, const ConvLayer& L, const float* in, float* out, int lin, int lout, int V, bool relu,
                    const float* residual = nullptr, const float* up = nullptr, int lup = 0, const int* dyn = nullptr,
                    bool in_relu = false) {
     ConvArgs a;
-    m->i8_off = 0;
     const double flops = fill_conv_args(m, a, L, in, out, lin, lout, V, relu, residual, up, lup, dyn, in_relu);
     if (flops < 0.0) return (int)flops;            // fill_conv_args failed: the (negative) status code
     return run_conv(m->ctx, a, flops);
@@ -857,8 +795,7 @@ static int conv_pair_on(cald_model* m, const ConvLayer& L2, const ConvLayer& L3,
     cald_ctx* c = m->ctx;
     if (m->cfg.precision == CALD_PRECISION_FP32 && L2.stride == 1 && lin == lout) {
         ConvArgs a2, a3;
-        m->i8_off = 0;
-        const double f2 = fill_conv_args(m, a2, L2, in, mid, lin, lout, V, true);
+            const double f2 = fill_conv_args(m, a2, L2, in, mid, lin, lout, V, true);
         const double f3 = fill_conv_args(m, a3, L3, mid, out, lout, lout, V, true, residual);
         if (f2 < 0.0 || f3 < 0.0) return (int)(f2 < 0.0 ? f2 : f3);
         hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -884,7 +821,6 @@ struct ConvSpec { const ConvLayer* L; const float* in; float* out; int level; bo
 static int conv_group_on(cald_model* m, const ConvSpec* sp, int n, int V) {
     ConvArgs a[CALD_MAX_GROUP];
     double flops = 0.0; int tiles = 0;
-    m->i8_off = 0;
     for (int i = 0; i < n; i++) {
         const double f = fill_conv_args(m, a[i], *sp[i].L, sp[i].in, sp[i].out, sp[i].level, sp[i].level, V, sp[i].relu);
         if (f < 0.0) return (int)f;
@@ -910,13 +846,6 @@ static void fwd_layout(cald_model* m, Bump& B, FwdBufs& F, int V) {
     const BatchPlan& P = m->plan;
     const long long px[8] = {level_pix(P, 0, V), level_pix(P, 1, V), level_pix(P, 2, V), level_pix(P, 3, V),
                              level_pix(P, 4, V), level_pix(P, 5, V), level_pix(P, 6, V), level_pix(P, 7, V)};
-    F.i8_planes = nullptr; F.i8_cap = 0; F.i8_off = 0;
-    if (m->cfg.precision == CALD_PRECISION_I8X3) {     // largest set of tensors one (grouped) launch consumes: the FPN / tower levels, or the RoI rows
-        size_t need = (size_t)px[2] * 256 * 3 / 2;
-        if (m->cfg.arch == CALD_ARCH_FRCNN && (size_t)V * CALD_ROI_CAP * 12544 > need) need = (size_t)V * CALD_ROI_CAP * 12544;
-        F.i8_cap = 3 * (need + 4096) + (size_t)px[2] * 4 * 2 + (size_t)V * CALD_ROI_CAP * 4 + (1 << 16);
-        F.i8_planes = B.get<signed char>(F.i8_cap);
-    }
     m->split.clear();
     static const bool split_on = !(getenv("CALD_H3_S16") && atoi(getenv("CALD_H3_S16")) == 0);
     const bool sp16 = m->cfg.precision == CALD_PRECISION_F16X3 && split_on;
@@ -1019,7 +948,6 @@ static int forward_model(cald_model* m, int V, ViewDesc* views, const DetBuffers
     FwdBufs F;
     { Bump dry(nullptr, true); fwd_layout(m, dry, F, V); int rc = arena_reserve(c, dry.off); if (rc) return rc; }
     { Bump real(c->arena, false); fwd_layout(m, real, F, V); }
-    m->i8_scratch = F.i8_planes; m->i8_cap = F.i8_cap; m->i8_off = 0; m->i8_last_in = nullptr; m->i8_reuse_hint = false;
     {
         const int si = c->stage_i; c->stage_i = (si + 1) % cald_ctx::NSTAGE;
         HIPCHK(hipEventSynchronize(c->stage_ev[si]));
@@ -1047,11 +975,7 @@ static int forward_model(cald_model* m, int V, ViewDesc* views, const DetBuffers
         const int lout = lvl + (B.c2.stride == 2 ? 1 : 0);
         const float* idn = cur;
         if (B.has_down) { if ((rc = conv_on(m, B.down, cur, F.D, lvl, lout, V, false))) return rc; idn = F.D; }
-        static const bool i8_reuse_env = !(getenv("CALD_I8_REUSE") && atoi(getenv("CALD_I8_REUSE")) == 0);
-        m->i8_reuse_hint = B.has_down && i8_reuse_env;          // i8x3: conv1 reads the tensor the downsample conv just quantised
-        rc = conv_on(m, B.c1, cur, F.T1, lvl, lvl, V, true);
-        m->i8_reuse_hint = false;
-        if (rc) return rc;
+        if ((rc = conv_on(m, B.c1, cur, F.T1, lvl, lvl, V, true))) return rc;
         float* dst = B.layer_end ? F.Cf[layer] : F.X[xi];
         if ((rc = conv_pair_on(m, B.c2, B.c3, F.T1, F.T2, dst, lvl, lout, V, idn))) return rc;
         cur = dst; lvl = lout;
@@ -1268,16 +1192,6 @@ static int op_conv2d(cald_ctx* c, int precision, const float* in, int H, int W, 
         HIPCHK(hipMalloc((void**)&d_w16, w16.size() * 2));
         HIPCHK(hipMemcpy(d_w16, w16.data(), w16.size() * 2, hipMemcpyHostToDevice));
     }
-    signed char *d_w8 = nullptr, *d_planes = nullptr; float *d_w8u = nullptr, *d_rs = nullptr; long long plane_stride = 0;
-    if (precision == CALD_PRECISION_I8X3) {
-        if (!i8_covers(Cin, Cout, KH * KW)) return fail(CALD_ERR_UNSUPPORTED, "i8x3 covers Cin %% 32 == 0 (>= 64), Cout >= 64, <= 32 taps");
-        std::vector<float> un; std::vector<signed char> w8 = pack_w8(w, CoutPad, KH * KW, Cin, un);
-        plane_stride = (((long long)H * W * Cin) + 15) & ~15ll;
-        HIPCHK(hipMalloc((void**)&d_w8, w8.size())); HIPCHK(hipMalloc((void**)&d_w8u, un.size() * 4)); HIPCHK(hipMalloc((void**)&d_planes, (size_t)plane_stride * 3));
-        HIPCHK(hipMalloc((void**)&d_rs, (size_t)H * W * 4));
-        HIPCHK(hipMemcpy(d_w8, w8.data(), w8.size(), hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(d_w8u, un.data(), un.size() * 4, hipMemcpyHostToDevice));
-        launch_quantize_pixels(d_in, (long long)H * W, Cin, d_planes, plane_stride, d_rs, c->stream);
-    }
     HIPCHK(hipMemcpy(d_b, b.data(), b.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_sc, sc.data(), sc.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_sh, sh.data(), sh.size() * 4, hipMemcpyHostToDevice));
@@ -1288,12 +1202,10 @@ static int op_conv2d(cald_ctx* c, int precision, const float* in, int H, int W, 
     a.residual = d_res; a.up = nullptr; a.seg_in = d_p->seg[0]; a.seg_out = d_p->seg[1]; a.seg_up = d_p->seg[1]; a.dyn_rows = nullptr;
     a.V = 1; a.Cin = Cin; a.Cout = Cout; a.CoutPad = CoutPad; a.Kpad = Kpad; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
     a.relu = relu; a.total_mtiles = (Ho * Wo + 127) / 128; a.out_ld = Cout; a.in_relu = 0; a.zeros = c->d_zeros;
-    a.i8_in = d_planes; a.i8_plane_stride = plane_stride; a.w8 = d_w8; a.w8_unscale = d_w8u; a.i8_rowscale = d_rs;
     launch_conv(a, c->stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemcpy(out, d_out, (size_t)Ho * Wo * Cout * 4, hipMemcpyDeviceToHost));
-    if (d_w8) { hipFree(d_w8); hipFree(d_w8u); hipFree(d_planes); hipFree(d_rs); }
     if (d_w4) hipFree(d_w4);
     if (d_w16) hipFree(d_w16);
     hipFree(d_in); hipFree(d_out); hipFree(d_w); hipFree(d_b); hipFree(d_sc); hipFree(d_sh); hipFree(d_p); if (d_res) hipFree(d_res);
@@ -1303,11 +1215,6 @@ extern "C" int cald_op_conv2d(cald_ctx* c, const float* in, int H, int W, int Ci
                               int stride, int pad, const float* bias, const float* bn_scale, const float* bn_shift,
                               const float* residual, int relu, float* out) {
     return op_conv2d(c, CALD_PRECISION_FP32, in, H, W, Cin, weight, Cout, KH, KW, stride, pad, bias, bn_scale, bn_shift, residual, relu, out);
-}
-extern "C" int cald_op_conv2d_i8x3(cald_ctx* c, const float* in, int H, int W, int Cin, const float* weight, int Cout, int KH, int KW,
-                                   int stride, int pad, const float* bias, const float* bn_scale, const float* bn_shift,
-                                   const float* residual, int relu, float* out) {
-    return op_conv2d(c, CALD_PRECISION_I8X3, in, H, W, Cin, weight, Cout, KH, KW, stride, pad, bias, bn_scale, bn_shift, residual, relu, out);
 }
 extern "C" int cald_op_conv2d_f16x3(cald_ctx* c, const float* in, int H, int W, int Cin, const float* weight, int Cout, int KH, int KW,
                                     int stride, int pad, const float* bias, const float* bn_scale, const float* bn_shift,
@@ -1357,22 +1264,9 @@ extern "C" int cald_op_conv_bench(cald_ctx* c, int V, int H, int W, int Cin, int
     }
     HIPCHK(hipMemcpy(d_b, b.data(), b.size() * 4, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(d_sc, sc.data(), sc.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_sh, sh.data(), sh.size() * 4, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(d_p, &P, sizeof(P), hipMemcpyHostToDevice));
-    // relu bit 1 (value 2 / 3): run the layer in CALD_PRECISION_I8X3 (digit planes prepared outside the timed region)
-    const bool i8 = (relu & 2) != 0; relu &= 1;
-    signed char *d_w8 = nullptr, *d_planes = nullptr; float *d_w8u = nullptr, *d_rs = nullptr; long long plane_stride = 0;
-    if (i8) {
-        if (!i8_covers(Cin, Cout, KH * KW)) return fail(CALD_ERR_UNSUPPORTED, "i8x3 does not cover this shape");
-        std::vector<float> un; std::vector<signed char> w8 = pack_w8(w, CoutPad, KH * KW, Cin, un);
-        plane_stride = ((long long)n_in + 15) & ~15ll;
-        if ((rc = sd.alloc(&d_w8, w8.size())) || (rc = sd.alloc(&d_w8u, un.size() * 4)) || (rc = sd.alloc(&d_planes, (size_t)plane_stride * 3)) ||
-            (rc = sd.alloc(&d_rs, (size_t)V * H * W * 4))) return rc;
-        HIPCHK(hipMemcpy(d_w8, w8.data(), w8.size(), hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(d_w8u, un.data(), un.size() * 4, hipMemcpyHostToDevice));
-        launch_quantize_pixels(d_in, (long long)V * H * W, Cin, d_planes, plane_stride, d_rs, c->stream);
-    }
     ConvArgs a[CALD_MAX_GROUP];
     for (int gi = 0; gi < group; gi++) {
         memset(&a[gi], 0, sizeof(ConvArgs));
-        a[gi].i8_in = d_planes; a[gi].i8_plane_stride = plane_stride; a[gi].w8 = d_w8; a[gi].w8_unscale = d_w8u; a[gi].i8_rowscale = d_rs;
         a[gi].in = d_in; a[gi].out = d_out + (size_t)gi * n_out; a[gi].w = d_w; a[gi].w4 = d_w4; a[gi].bias = d_b; a[gi].scale = d_sc; a[gi].shift = d_sh; a[gi].residual = d_res;
         a[gi].seg_in = d_p->seg[0]; a[gi].seg_out = d_p->seg[1]; a[gi].seg_up = d_p->seg[1]; a[gi].V = V; a[gi].Cin = Cin; a[gi].Cout = Cout; a[gi].CoutPad = CoutPad; a[gi].Kpad = Kpad;
         a[gi].KH = KH; a[gi].KW = KW; a[gi].stride = stride; a[gi].pad = pad; a[gi].relu = relu; a[gi].total_mtiles = V * ((Ho * Wo + 127) / 128); a[gi].out_ld = Cout; a[gi].zeros = c->d_zeros;
@@ -1529,9 +1423,14 @@ extern "C" int cald_sweep(cald_model* m, int n_images, const uint8_t* const* ima
     int B = cfg->batch_images > 0 ? cfg->batch_images : 64;
     if (B > CALD_MAX_VIEWS) B = CALD_MAX_VIEWS;
     const int VT = B * (1 + A);
+    static const bool pipelined = !(getenv("CALD_SWEEP_PIPELINE") && atoi(getenv("CALD_SWEEP_PIPELINE")) == 0);   // 0: one batch at a time (A/B)
+    const int NB = (n_images + B - 1) / B;
+    // the second set of detection buffers exists only when two batches are really in flight (a one-batch shard, or several ranks
+    // rehearsing on one GPU with the pipeline off, would pay VT x cap x C floats of HBM for nothing)
+    const bool two_sets = pipelined && NB > 1;
     { int rc0 = ensure_sweep_det(m, VT); if (rc0) return rc0; }
-    { int rc0 = ensure_sweep_det2(m, VT); if (rc0) return rc0; }
-    DetBuffers* const DS[2] = {&m->sweep_det, &m->sweep_det2};
+    if (two_sets) { int rc0 = ensure_sweep_det2(m, VT); if (rc0) return rc0; }
+    DetBuffers* const DS[2] = {&m->sweep_det, two_sets ? &m->sweep_det2 : &m->sweep_det};
     const int P_MAX = B * (A > 0 ? A : 1);
     const size_t n_ints = (size_t)P_MAX * 4 + (size_t)B * 51 + (size_t)VT * 2;
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
@@ -1571,7 +1470,6 @@ extern "C" int cald_sweep(cald_model* m, int n_images, const uint8_t* const* ima
     }
     int rc = 0;
     const int fwd_views = sweep_fwd_views();
-    static const bool pipelined = !(getenv("CALD_SWEEP_PIPELINE") && atoi(getenv("CALD_SWEEP_PIPELINE")) == 0);   // 0: one batch at a time (A/B)
 
     // reference views of batch k -> detections into set k & 1, counts + boxes to the pinned host set, event
     auto enqueue_ref = [&](int k) -> int {
@@ -1758,7 +1656,6 @@ extern "C" int cald_sweep(cald_model* m, int n_images, const uint8_t* const* ima
 
     // stream order: ref(0), ref(1), aug(0), score(0), ref(2), aug(1), score(1), ... -- the host builds batch k's views while the GPU runs
     // the reference forward of batch k + 1, and reads batch k's scores while batch k + 1 is on the GPU
-    const int NB = (n_images + B - 1) / B;
     if (NB > 0) rc = enqueue_ref(0);
     for (int k = 0; k < NB && !rc; k++) {
         if (pipelined && k + 1 < NB) {

@@ -56,7 +56,8 @@ const Rccl& rccl() {
 const char* rccl_str(int code) { const Rccl& r = rccl(); return r.GetErrorString ? r.GetErrorString(code) : "?"; }
 }   // namespace
 
-struct cald_comm { rcclComm_t comm; cald_ctx* ctx; int world, rank; };
+// owned: the communicator was created by cald_comm_init_rank and dies with the wrapper; an adopted one belongs to the host framework
+struct cald_comm { rcclComm_t comm; cald_ctx* ctx; int world, rank; bool owned; };
 
 extern "C" int cald_comm_unique_id(void* id128_out) {
     if (!id128_out) return cald_internal_fail(CALD_ERR_INVALID, "null argument");
@@ -79,7 +80,7 @@ extern "C" int cald_comm_init_rank(cald_ctx* ctx, const void* id128, int world_s
     rcclComm_t comm = nullptr;
     const int rc = r.CommInitRank(&comm, world_size, id, rank);      // one process per GPU: the communicator lives on the context's device
     if (rc) return cald_internal_fail(CALD_ERR_HIP, "ncclCommInitRank(world %d, rank %d) failed: %s", world_size, rank, rccl_str(rc));
-    cald_comm* c = new cald_comm{comm, ctx, world_size, rank};
+    cald_comm* c = new cald_comm{comm, ctx, world_size, rank, true};
     *out = c;
     return 0;
 }
@@ -89,8 +90,8 @@ extern "C" int cald_comm_destroy(cald_comm* comm) {
     const Rccl& r = rccl();
     if (!r.err && comm->comm) {
         hipSetDevice(cald_internal_device(comm->ctx));
-        hipStreamSynchronize(cald_internal_stream(comm->ctx));
-        r.CommDestroy(comm->comm);
+        hipStreamSynchronize(cald_internal_stream(comm->ctx));      // a collective of ours may still be in flight on the context's stream
+        if (comm->owned) r.CommDestroy(comm->comm);                 // an adopted communicator stays alive: the host framework owns it
     }
     delete comm;
     return 0;
@@ -105,8 +106,7 @@ extern "C" int cald_comm_adopt(cald_ctx* ctx, void* rccl_comm, cald_comm** out) 
     int world = 0, rank = 0;
     int rc = r.CommCount(rccl_comm, &world); if (!rc) rc = r.CommUserRank(rccl_comm, &rank);
     if (rc) return cald_internal_fail(CALD_ERR_HIP, "not a usable RCCL communicator: %s", rccl_str(rc));
-    *out = new cald_comm{nullptr, ctx, world, rank};
-    (*out)->comm = rccl_comm;
+    *out = new cald_comm{rccl_comm, ctx, world, rank, false};
     return 0;
 }
 

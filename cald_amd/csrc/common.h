@@ -49,12 +49,6 @@ struct ConvArgs {
     const float* zeros;    // >= 16 bytes of zeros, 16-byte aligned (source of out-of-image taps)
     int in_relu;           // apply ReLU to the input while gathering (LastLevelP6P7: p7(relu(p6)))
     int exp_flags;         // kernel-tuning experiments only (0 in the product path): bit 0 = skip the output stores
-    // CALD_PRECISION_I8X3 (conv_i3.hip); all null / 0 otherwise
-    const signed char* i8_in;   // three int8 digit planes of the (whole ragged-batch) input tensor [pixel][Cin]; plane p at + p * i8_plane_stride
-    long long i8_plane_stride;
-    const float* i8_rowscale;   // per input pixel 2^(e_p - 22) (e_p = exponent of the pixel's largest |channel|)
-    const void* w8;             // weight digits packed [Kpad/32][3][CoutPad][32 B], k-tiles in (kh, kw, 32-channel chunk) order
-    const float* w8_unscale;    // [CoutPad] 2^(e_w[n] - 22 + 16)
     // training backward only (train.hip; honoured by conv_p4.hip): after everything else, out = mask > 0 ? out : 0 -- the ReLU backward
     // of the layer whose saved post-ReLU output `mask` (same geometry and row stride as out) this data gradient flows into; else null
     const float* mask;

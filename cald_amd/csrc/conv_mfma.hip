@@ -282,8 +282,6 @@ static void launch_cfg(const ConvArgs& a, int bn, hipStream_t stream) {
 bool launch_conv_p4(const ConvArgs& a, hipStream_t stream);   // conv_p4.hip
 bool launch_conv_stem(const ConvArgs& a, hipStream_t stream); // conv_stem.hip (only when a.wstem is set)
 bool launch_conv_h3(const ConvArgs& a, hipStream_t stream);   // conv_h3.hip (opt-in split-fp16 mode: only when a.w16 is set)
-bool launch_conv_i3(const ConvArgs& a, hipStream_t stream);   // conv_i3.hip (opt-in exact-integer int8 mode: only when a.w8 and a.i8_in are set)
-bool launch_conv_i3_group(const ConvArgs* p, int n, hipStream_t stream);
 
 bool launch_conv_p4_group(const ConvArgs* p, int n, hipStream_t stream);
 bool launch_conv_h3_group(const ConvArgs* p, int n, hipStream_t stream);
@@ -294,10 +292,9 @@ int launch_conv_group(const ConvArgs* probs, int n, hipStream_t stream) {   // r
     static const int grp = conv_env("CALD_CONV_GROUP", 1);
     static const int p4 = conv_env("CALD_CONV_P4", 1);
     if (grp && n > 1) {
-        if (probs[0].w8 && probs[0].i8_in && launch_conv_i3_group(probs, n, stream)) return 1;
         if (probs[0].w16 && launch_conv_h4_group(probs, n, stream)) return 1;
         if (probs[0].w16 && launch_conv_h3_group(probs, n, stream)) return 1;
-        if (!probs[0].w16 && !(probs[0].w8 && probs[0].i8_in) && p4 && launch_conv_p4_group(probs, n, stream)) return 1;
+        if (!probs[0].w16 && p4 && launch_conv_p4_group(probs, n, stream)) return 1;
     }
     for (int i = 0; i < n; i++) launch_conv(probs[i], stream);
     return n;
@@ -305,7 +302,6 @@ int launch_conv_group(const ConvArgs* probs, int n, hipStream_t stream) {   // r
 
 void launch_conv(const ConvArgs& a, hipStream_t stream) {
     static const int p4 = conv_env("CALD_CONV_P4", 1);   // conv_p4.hip: 3-buffer pipelined schedule, 128-bit LDS fragment reads; 0 = this file only
-    if (a.w8 && a.i8_in && launch_conv_i3(a, stream)) return;
     if (a.w16 && launch_conv_h4(a, stream)) return;
     if (a.w16 && launch_conv_h3(a, stream)) return;
     static const int stem = conv_env("CALD_CONV_STEM", 1);   // 0: the stem runs on the generic kernels (same bits)

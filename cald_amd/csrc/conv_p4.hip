@@ -652,7 +652,7 @@ bool launch_conv_p4_group(const ConvArgs* p, int n, hipStream_t stream) {
 // returns true if the fused kernel took both (same bits as the two separate launches)
 bool launch_conv_p4_fused(const ConvArgs& c2, const ConvArgs& c3, hipStream_t stream) {
     static const int on = getenv("CALD_P4_FUSE") ? atoi(getenv("CALD_P4_FUSE")) : 1;
-    if (!on || !c2.w4 || !c3.w4 || c2.w16 || c3.w16 || (c2.w8 && c2.i8_in) || (c3.w8 && c3.i8_in)) return false;
+    if (!on || !c2.w4 || !c3.w4 || c2.w16 || c3.w16) return false;
     if (c2.KH != 3 || c2.KW != 3 || c2.stride != 1 || c2.pad != 1 || c2.Cin % 16 || c2.Cout != 64 || c2.CoutPad != 64 || c2.out_ld != 64) return false;
     if (c2.residual || c2.up || c2.mask || c2.dyn_rows || c2.in_relu || p4_taps(c2) != 9) return false;
     if (c3.KH != 1 || c3.KW != 1 || c3.stride != 1 || c3.pad != 0 || c3.Cin != 64 || c3.Kpad != 64 || c3.CoutPad % 64 || c3.Cout != c3.CoutPad) return false;

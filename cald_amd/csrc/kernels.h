@@ -165,7 +165,3 @@ void launch_retina_postprocess(const RetinaArgs& a, int max_anchors, hipStream_t
 // baseline sweeps
 void launch_lt_uncertainty(const DetBuffers& det, int V, float* out, hipStream_t st);
 void launch_max_iou(const ScoreArgs& a, float* out /*[P][50]*/, hipStream_t st);
-
-// conv_i3.hip (CALD_PRECISION_I8X3): fp32 tensor [P][C] -> three balanced base-256 digit planes of rint(x * 2^(22 - e_p)) with one
-// exponent e_p per pixel (its largest |channel|), and rowscale[p] = 2^(e_p - 22)
-void launch_quantize_pixels(const float* src, long long P, int C, signed char* dst, long long plane_stride, float* rowscale, hipStream_t st);

@@ -61,9 +61,8 @@ class HipDetector:
     def __init__(self, num_classes, depth=50, min_size=800, max_size=1333, box_score_thresh=0.05, box_nms_thresh=0.5,
                  box_detections_per_img=100, rpn_pre_nms_top_n_test=1000, rpn_post_nms_top_n_test=1000,
                  rpn_nms_thresh=0.7, arch=0, precision="fp32", **unused):
-        """precision: "fp32" (exact, bit-identical to the oracle; default), "f16x3" (split-fp16 MFMA path, 2x faster, fp32-grade
-        but not reproducible on a CPU) or "i8x3" (exact-integer int8 MFMA path: block floating point per pixel, bit-identical to
-        ITS oracle) -- include/cald_hip.h, DESIGN.md section 6.  Neither matrix-pipe mode is bit-identical to fp32."""
+        """precision: "fp32" (exact, bit-identical to the oracle; default) or "f16x3" (split-fp16 MFMA path, 2x faster, fp32-grade
+        but not bit-identical to fp32 and not reproducible on a CPU) -- include/cald_hip.h, DESIGN.md section 6."""
         self.arch = arch
         self.cfg = _ffi.ModelCfg(self.arch, depth, num_classes, int(min_size), int(max_size), box_score_thresh,
                                  box_nms_thresh, box_detections_per_img, rpn_pre_nms_top_n_test, rpn_post_nms_top_n_test,
@@ -92,7 +91,7 @@ class HipDetector:
             return self.eval()
         if self.cfg.precision != _ffi.PRECISION["fp32"]:
             raise NotImplementedError("the training step computes in fp32; build the detector with precision='fp32' to train it "
-                                      "(the f16x3 / i8x3 modes are inference-only)")
+                                      "(the f16x3 mode is inference-only)")
         self._ensure_trainer()
         self.training = True
         return self

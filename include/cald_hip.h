@@ -40,12 +40,6 @@ typedef struct cald_model cald_model;
  *          bar is met only by FP32; |activations| must stay below 4094. */
 #define CALD_PRECISION_FP32 0
 #define CALD_PRECISION_F16X3 1
-/*   I8X3   exact-integer int8 mode (conv_i3.hip): block floating point -- one exponent per input PIXEL (from its largest
- *          |channel|, computed on the fly: no calibration, no saturation) and per output channel of the weights; operands as three
- *          balanced base-256 digits, six digit products per filter tap on v_mfma_i32_32x32x32_i8 with exact int32 accumulation,
- *          taps folded into one float32 accumulator in (kh, kw) order, then the exact mode's fp32 epilogue.  Reproducible bit
- *          for bit on a CPU (the C oracle under oracle/); ~19-20 significant bits on typical activations. */
-#define CALD_PRECISION_I8X3 2
 
 #define CALD_ARCH_FRCNN 0      /* detection/frcnn_la.py FRCNN_Feature */
 #define CALD_ARCH_RETINANET 1  /* detection/retinanet_cal.py RetinaNet */
@@ -135,7 +129,7 @@ typedef struct cald_aug_spec {
 typedef struct cald_sweep_cfg {
     uint64_t base_seed;
     float bp;              /* args.bp, 1.3 */
-    int batch_images;      /* images per batched launch sequence (0 = default 64, max 64) */
+    int batch_images;      /* images per batched launch sequence (0 = default 64; capped at CALD_MAX_VIEWS = 128) */
     int n_augs;
     cald_aug_spec augs[CALD_MAX_AUGS];
 } cald_sweep_cfg;
@@ -174,11 +168,6 @@ int cald_op_augment(cald_ctx* ctx, int kind, double param, uint64_t seed, const 
 int cald_op_conv2d(cald_ctx* ctx, const float* in, int H, int W, int Cin, const float* weight, int Cout, int KH, int KW,
                    int stride, int pad, const float* bias, const float* bn_scale, const float* bn_shift,
                    const float* residual, int relu, float* out);
-/* the same convolution in CALD_PRECISION_I8X3 (conv_i3.hip); shapes outside Cin % 32 == 0 (>= 64), Cout >= 64, <= 32 taps
- * return CALD_ERR_UNSUPPORTED */
-int cald_op_conv2d_i8x3(cald_ctx* ctx, const float* in, int H, int W, int Cin, const float* weight, int Cout, int KH, int KW,
-                        int stride, int pad, const float* bias, const float* bn_scale, const float* bn_shift,
-                        const float* residual, int relu, float* out);
 /* the same convolution in CALD_PRECISION_F16X3 (conv_h3.hip); falls back to the exact kernels for shapes it does not
  * cover (Cin % 16 != 0 or Cout not tiled by 128), exactly as inside a model */
 int cald_op_conv2d_f16x3(cald_ctx* ctx, const float* in, int H, int W, int Cin, const float* weight, int Cout, int KH, int KW,
@@ -187,7 +176,7 @@ int cald_op_conv2d_f16x3(cald_ctx* ctx, const float* in, int H, int W, int Cin, 
 /* kernel-tuning aid (tools/bench_conv.py): average time of ONE conv layer shape (the model's own kernel selection) over a
  * ragged batch of n_views equal views filled with pseudo-random data; `group` > 1 issues that many independent copies as one
  * grouped launch (FPN / RPN style).  tflops_out counts algorithmic FLOPs (2 * M * Cout * KH*KW*Cin).  relu: bit 0 = ReLU in the
- * epilogue, bit 1 = time the CALD_PRECISION_I8X3 kernel instead of the exact one (digit planes prepared outside the timed region). */
+ * epilogue. */
 int cald_op_conv_bench(cald_ctx* ctx, int n_views, int H, int W, int Cin, int Cout, int KH, int stride, int pad, int residual,
                        int relu, int iters, int group, double* ms_out, double* tflops_out);
 /* detector-transform size (GeneralizedRCNNTransform): resized and padded sizes */

@@ -498,111 +498,6 @@ ORC_API void orc_conv2d_nhwc(const float* in, int H, int W, int Cin, const float
     free(zero);
 }
 
-/* -------------------------------------------------------------------------------------
- * CALD_PRECISION_I8X3 (cald_amd/csrc/conv_i3.hip): block floating point + exact integer accumulation.
- *   per input pixel p: max_c |x| = f * 2^e_p (f in [0.5, 1); all zero: e_p = 0; e_p clamped to [-100, 100]),
- *                      q_x = rint(x * 2^(22 - e_p));   per output channel n: e_w likewise over its K weights, q_w = rint(w * 2^(22 - e_w));
- *   q = d0 + 256 d1 + 65536 d2 with balanced digits in [-128, 127];
- *   per filter tap (kh, kw), summed over the tap's Cin channels (exact integers, any order):
- *       S2 = sum d2.d2, S1 = sum (d2.d1 + d1.d2), S0 = sum (d2.d0 + d0.d2 + d1.d1)
- *   float accumulator over the taps in (kh, kw) order:
- *       T = fmaf((float)S2, 65536, fmaf((float)S1, 256, (float)S0));  acc = fmaf(T, 2^(e_p - 22), acc)   (out-of-image tap: skipped)
- *   val = acc * 2^(e_w - 22 + 16); then the fp32 epilogue of the exact mode.
- * ------------------------------------------------------------------------------------- */
-static void orc_i8_digits(long long q, int* d) {
-    d[0] = (int)(signed char)(q & 255); long long q1 = (q - d[0]) >> 8;
-    d[1] = (int)(signed char)(q1 & 255); d[2] = (int)((q1 - d[1]) >> 8);
-}
-ORC_API void orc_conv2d_i8x3(const float* in, int H, int W, int Cin, const float* wk, int Cout, int KH, int KW,
-                             int stride, int pad, const float* bias, const float* bn_scale, const float* bn_shift,
-                             const float* residual, const float* up, int upH, int upW, int relu,
-                             float* out, int Ho, int Wo) {
-    const long npx = (long)H * W, nin = npx * Cin; const int K = KH * KW * Cin;
-    signed char* xa = (signed char*)malloc((size_t)nin * 3);
-    float* rowscale = (float*)malloc(sizeof(float) * (size_t)npx);
-    signed char* wd = (signed char*)malloc((size_t)K * Cout * 3);
-    float* wun = (float*)malloc(sizeof(float) * Cout);
-#pragma omp parallel for schedule(static) num_threads(orc_threads)
-    for (long p = 0; p < npx; p++) {
-        const float* x = in + (size_t)p * Cin;
-        float mx = 0.0f;
-        for (int c = 0; c < Cin; c++) { float ax = fabsf(x[c]); if (ax > mx) mx = ax; }     /* fmaxf semantics on finite data */
-        unsigned bits; memcpy(&bits, &mx, 4);
-        int e = (int)((bits >> 23) & 255u) - 126;
-        if (mx == 0.0f) e = 0;
-        if (e < -100) e = -100; if (e > 100) e = 100;
-        const float qs = ldexpf(1.0f, 22 - e);
-        for (int c = 0; c < Cin; c++) {
-            int d[3]; orc_i8_digits((long long)rintf(x[c] * qs), d);
-            xa[(size_t)p * Cin + c] = (signed char)d[0]; xa[nin + (size_t)p * Cin + c] = (signed char)d[1]; xa[2 * nin + (size_t)p * Cin + c] = (signed char)d[2];
-        }
-        rowscale[p] = ldexpf(1.0f, e - 22);
-    }
-    for (int co = 0; co < Cout; co++) {
-        float mx = 0.0f;
-        for (int k = 0; k < K; k++) { float ax = fabsf(wk[(size_t)k * Cout + co]); if (ax > mx) mx = ax; }
-        int e = 0;
-        if (mx > 0.0f && isfinite(mx)) frexpf(mx, &e);
-        if (e > 60) e = 60; if (e < -60) e = -60;
-        wun[co] = ldexpf(1.0f, e - 22 + 16);
-        for (int k = 0; k < K; k++) {
-            int d[3]; orc_i8_digits((long long)nearbyint((double)ldexpf(wk[(size_t)k * Cout + co], 22 - e)), d);
-            for (int pl = 0; pl < 3; pl++) wd[((size_t)pl * K + k) * Cout + co] = (signed char)d[pl];
-        }
-    }
-    const signed char *w0 = wd, *w1 = wd + (size_t)K * Cout, *w2 = wd + 2 * (size_t)K * Cout;
-    long npix = (long)Ho * Wo;
-    float uph_scale = up ? (float)upH / (float)Ho : 0.0f, upw_scale = up ? (float)upW / (float)Wo : 0.0f;
-#pragma omp parallel for schedule(dynamic, 4) num_threads(orc_threads)
-    for (long pp = 0; pp < npix; pp++) {
-        int* S = (int*)malloc((size_t)3 * Cout * sizeof(int));
-        float* acc = (float*)calloc((size_t)Cout, sizeof(float));
-        int *S0 = S, *S1 = S + Cout, *S2 = S + 2 * Cout;
-        int oy = (int)(pp / Wo), ox = (int)(pp % Wo);
-        for (int kh = 0; kh < KH; kh++)
-            for (int kw = 0; kw < KW; kw++) {
-                int iy = oy * stride - pad + kh, ix = ox * stride - pad + kw;
-                if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
-                const size_t px = (size_t)iy * W + ix, xo = px * Cin;
-                memset(S, 0, (size_t)3 * Cout * sizeof(int));
-                for (int ci = 0; ci < Cin; ci++) {
-                    const int a0 = xa[xo + ci], a1 = xa[nin + xo + ci], a2 = xa[2 * nin + xo + ci];
-                    if (!(a0 | a1 | a2)) continue;
-                    const size_t wo = ((size_t)(kh * KW + kw) * Cin + ci) * Cout;
-                    const signed char *r0 = w0 + wo, *r1 = w1 + wo, *r2 = w2 + wo;
-#pragma omp simd
-                    for (int co = 0; co < Cout; co++) {
-                        S2[co] += a2 * r2[co];
-                        S1[co] += a2 * r1[co] + a1 * r2[co];
-                        S0[co] += a2 * r0[co] + a0 * r2[co] + a1 * r1[co];
-                    }
-                }
-                const float rs = rowscale[px];
-                for (int co = 0; co < Cout; co++) {
-                    const float T = __builtin_fmaf((float)S2[co], 65536.0f, __builtin_fmaf((float)S1[co], 256.0f, (float)S0[co]));
-                    acc[co] = __builtin_fmaf(T, rs, acc[co]);
-                }
-            }
-        const float* upr = NULL;
-        if (up) {
-            int sy = (int)floorf((float)oy * uph_scale); if (sy > upH - 1) sy = upH - 1;
-            int sx = (int)floorf((float)ox * upw_scale); if (sx > upW - 1) sx = upW - 1;
-            upr = up + ((size_t)sy * upW + sx) * Cout;
-        }
-        for (int co = 0; co < Cout; co++) {
-            float r = acc[co] * wun[co];
-            if (bias) r = r + bias[co];
-            if (bn_scale) { r = r * bn_scale[co]; r = r + bn_shift[co]; }
-            if (residual) r = r + residual[(size_t)pp * Cout + co];
-            if (upr) r = r + upr[co];
-            if (relu) r = r > 0.0f ? r : 0.0f;
-            out[(size_t)pp * Cout + co] = r;
-        }
-        free(S); free(acc);
-    }
-    free(xa); free(rowscale); free(wd); free(wun);
-}
-
 /* Linear: out[m][n] = relu?(chain_k(in[m][k]*w[n][k]) + bias[n]);  wk given K-major [K][N]. */
 ORC_API void orc_linear(const float* in, int M, int K, const float* wk, int N, const float* bias, int relu, float* out) {
     orc_conv2d_nhwc(in, 1, M, K, wk, N, 1, 1, 1, 0, bias, NULL, NULL, NULL, NULL, 0, 0, relu, out, 1, M);

@@ -241,25 +241,6 @@ def conv2d(x, wk, KH, KW, stride, pad, bias=None, bn=None, residual=None, up=Non
     return out
 
 
-def conv2d_i8x3(x, wk, KH, KW, stride, pad, bias=None, bn=None, residual=None, up=None, relu=False):
-    """CALD_PRECISION_I8X3 convolution (block floating point per pixel / per output channel, exact integer accumulation per tap,
-    cald_amd/csrc/conv_i3.hip); same argument layout as conv2d."""
-    x = f32(x); wk = f32(wk)
-    H, W, Cin = x.shape
-    Cout = wk.shape[1]
-    Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
-    out = np.empty((Ho, Wo, Cout), np.float32)
-    b = f32(bias) if bias is not None else None
-    sc, sh = (f32(bn[0]), f32(bn[1])) if bn is not None else (None, None)
-    r = f32(residual) if residual is not None else None
-    u = f32(up) if up is not None else None
-    lib().orc_conv2d_i8x3(_p(x), C.c_int(H), C.c_int(W), C.c_int(Cin), _p(wk), C.c_int(Cout), C.c_int(KH), C.c_int(KW),
-                          C.c_int(stride), C.c_int(pad), _p(b), _p(sc), _p(sh), _p(r), _p(u),
-                          C.c_int(u.shape[0] if u is not None else 0), C.c_int(u.shape[1] if u is not None else 0),
-                          C.c_int(int(relu)), _p(out), C.c_int(Ho), C.c_int(Wo))
-    return out
-
-
 def linear(x, wk, bias=None, relu=False):
     x = f32(x); M, K = x.shape
     N = wk.shape[1]
@@ -405,16 +386,11 @@ def prepare_frcnn(sd, num_classes, depth=50):
 
 
 def _conv(P, name, x, wk, KH, KW, stride, pad, **kw):
-    """A conv layer in the model's precision: CALD_PRECISION_I8X3 when P["i8"] is set and conv_i3.hip covers the shape
-    (Cin % 32 == 0 and >= 64, Cout >= 64, <= 32 taps), else the exact fp32 chain."""
-    if P.get("i8") and x.shape[2] % 32 == 0 and x.shape[2] >= 64 and wk.shape[1] >= 64 and KH * KW <= 32:
-        return conv2d_i8x3(x, wk, KH, KW, stride, pad, **kw)
+    """A conv layer of the model: the exact fp32 chain."""
     return conv2d(x, wk, KH, KW, stride, pad, **kw)
 
 
 def _linear(P, name, x, wk, bias=None, relu=False):
-    if P.get("i8") and x.shape[1] % 32 == 0 and x.shape[1] >= 64 and wk.shape[1] >= 64:
-        return conv2d_i8x3(x[None], wk, 1, 1, 1, 0, bias=bias, relu=relu)[0]
     return linear(x, wk, bias, relu)
 
 

@@ -183,49 +183,6 @@ def test_conv_f16x3_within_split_precision_of_exact(hip, oracle, case):
     assert np.all(err <= bound), "max err %g, max err/bound %g" % (float(err.max()), float((err / bound).max()))
 
 
-I8_CASES = [c for c in CONV_CASES if c[2] % 32 == 0 and c[3] >= 64] + [
-    (30, 44, 64, 64, 3, 1, 1, False, True, False, True),       # layer1 conv2 (one 32-channel chunk pair)
-    (21, 33, 96, 192, 3, 2, 1, True, False, True, False),      # odd sizes, stride 2, bias + residual
-]
-
-
-@pytest.mark.parametrize("case", I8_CASES)
-def test_conv_i8x3_bit_exact(hip, oracle, case):
-    """CALD_PRECISION_I8X3 (conv_i3.hip): block floating point (one exponent per pixel / per output channel), six int8 digit
-    products per tap with exact int32 accumulation, taps folded in float32 in a fixed order -> tobytes()-equal to the C oracle;
-    and close to the exact fp32 chain: per term 2^-22 of (pixel max x channel max)."""
-    H, W, Cin, Cout, K, stride, pad, bias, bn, res, relu = case
-    ffi, L = hip["ffi"], hip["L"]
-    rs = np.random.RandomState(H * 1000 + Cout + 7)
-    x = rs.randn(H, W, Cin).astype(np.float32) * 3.0
-    x[rs.rand(H, W, Cin) < 0.3] = 0.0
-    xf = x.reshape(-1, Cin)                                                     # (view) an outlier pixel, an all-zero pixel, a tiny pixel
-    xf[0, 0] = 1e4; xf[min(7, len(xf) - 1), :] = 0.0; xf[min(13, len(xf) - 1), :] *= 1e-6
-    w = (rs.randn(Cout, Cin, K, K) * np.sqrt(2.0 / (Cin * K * K))).astype(np.float32)
-    w[1] *= 37.0; w[2] = 0.0                                                    # per-channel exponents differ; an all-zero channel
-    b = rs.randn(Cout).astype(np.float32) if bias else None
-    sc = (0.5 + rs.rand(Cout)).astype(np.float32) if bn else None
-    sh = rs.randn(Cout).astype(np.float32) if bn else None
-    Ho, Wo = (H + 2 * pad - K) // stride + 1, (W + 2 * pad - K) // stride + 1
-    r = rs.randn(Ho, Wo, Cout).astype(np.float32) if res else None
-    out = np.empty((Ho, Wo, Cout), np.float32)
-    ffi.check(L.cald_op_conv2d_i8x3(hip["ctx"], ffi.ptr(x), H, W, Cin, ffi.ptr(w), Cout, K, K, stride, pad, ffi.ptr(b),
-                                    ffi.ptr(sc), ffi.ptr(sh), ffi.ptr(r), int(relu), ffi.ptr(out)))
-    wk = np.ascontiguousarray(w.transpose(2, 3, 1, 0).reshape(-1, Cout))
-    want = oracle.conv2d_i8x3(x, wk, K, K, stride, pad, bias=b, bn=(sc, sh) if bn else None, residual=r, relu=relu)
-    assert out.tobytes() == want.tobytes(), "max abs diff %g" % float(np.abs(out - want).max())
-    exact = oracle.conv2d(x, wk, K, K, stride, pad, bias=b, bn=(sc, sh) if bn else None, residual=r, relu=relu)
-    # error per output <= sum over taps of Cin * (pixel max * 2^-23 * |w|max_n + |x| * w-step) + fp32 rounding of the fold
-    pmax = np.abs(x).max(axis=2, keepdims=True)                                  # [H][W][1]
-    wmax = np.abs(wk).max(axis=0)
-    ones = np.ones((K * K * 1, 1), np.float32)
-    reach = oracle.conv2d(np.ascontiguousarray(np.repeat(pmax, 4, axis=2)), np.ascontiguousarray(np.repeat(ones, 4, axis=0) / 4.0), K, K, stride, pad)[:, :, 0:1]
-    mag = oracle.conv2d(np.abs(x), np.abs(wk), K, K, stride, pad)
-    bound = (np.abs(sc) if bn else 1.0) * (reach * Cin * wmax[None, None, :] * 2.0 ** -21 + mag * 2.0 ** -20) + 1e-5
-    err = np.abs(out - exact)
-    assert np.all(err <= bound), "max err %g, max err/bound %g" % (float(err.max()), float((err / bound).max()))
-
-
 @pytest.fixture(scope="module")
 def small_model(hip, oracle):
     from cald_amd import synth
@@ -581,7 +538,7 @@ def test_full_size_properties_and_oracle_spot_check(hip, oracle):
         np.testing.assert_array_equal(c1, cw); np.testing.assert_array_equal(k1, kw)
     assert np.all(c1 >= 0) and np.all(c1 <= 1.0) and len(np.unique(np.round(c1, 6))) > 6
     P = oracle.prepare_frcnn(sd, 21, 50)
-    exact = [0, 1, 3, 4, 6, 8, 9, 11]                                                             # 8 of the 12 images, bit for bit
+    exact = [0, 3, 4, 8, 9, 11]                                                                   # 6 of the 12 images, bit for bit
     import os
     oracle.set_threads(min(128, os.cpu_count() or 1))
     try:
@@ -667,7 +624,7 @@ def _full_size_coco_case(hip, oracle, depth, augs, exact_positions, seed):
 
 def test_config2_full_size_retinanet_voc(hip, oracle):
     """BASELINE.json configs[2] AT SIZE: RetinaNet ResNet-50 FPN (detection/retinanet_cal.py), VOC shapes, min/max 600/1000
-    (cald_train.py:342), flip / cut_out / smaller_resize.  12 images: batch-size and shard invariance; eight of them re-scored by
+    (cald_train.py:342), flip / cut_out / smaller_resize.  12 images: batch-size and shard invariance; six of them re-scored by
     the CPU oracle, bit for bit (consistency and cls_corr)."""
     import os
     torch = hip["torch"]
@@ -691,7 +648,7 @@ def test_config2_full_size_retinanet_voc(hip, oracle):
     np.testing.assert_array_equal(c1, cw); np.testing.assert_array_equal(k1, kw)
     assert np.all(c1 >= 0) and np.all(c1 <= 1.0) and len(np.unique(np.round(c1, 6))) > 6 and (k1 > 0).any()
     P = oracle.prepare_retinanet(sd, 21, 50)
-    exact = (0, 2, 4, 5, 7, 8, 10, 11)                  # 8 of the 12 images
+    exact = (0, 2, 5, 7, 8, 11)                         # 6 of the 12 images (the GPU suite has a 20-minute budget)
     oracle.set_threads(min(128, os.cpu_count() or 1))
     try:
         wc, wk = oracle.get_uncertainty(P, [pool[i] for i in exact], augs, 21, bp=1.3, min_size=600, max_size=1000, base_seed=3, positions=list(exact))
@@ -706,13 +663,49 @@ def test_config2_full_size_retinanet_voc(hip, oracle):
 
 def test_config3_full_size_frcnn_r50_coco(hip, oracle):
     """BASELINE.json configs[3]: Faster R-CNN ResNet-50 FPN, COCO shapes, 91 classes, 800/1333, flip / cut_out / smaller_resize."""
-    _full_size_coco_case(hip, oracle, 50, ["flip", "cut_out", "smaller_resize"], (0, 1, 3, 5, 6, 8, 9, 11), seed=0)
+    _full_size_coco_case(hip, oracle, 50, ["flip", "cut_out", "smaller_resize"], (0, 3, 5, 6, 8, 11), seed=0)
 
 
 def test_config4_full_size_frcnn_r101_coco_five_augs(hip, oracle):
     """BASELINE.json configs[4]: Faster R-CNN ResNet-101 FPN, COCO shapes, 5 augmentations (FCDR + G: flip, ga, cut_out,
     smaller_resize, rotation -> 6 views per image), exact fp32."""
-    _full_size_coco_case(hip, oracle, 101, ["flip", "ga", "cut_out", "smaller_resize", "rotation"], (0, 3, 5, 7, 8, 10), seed=1)   # 6 of 12: a ResNet-101 image with six views costs the CPU oracle ~20 s
+    _full_size_coco_case(hip, oracle, 101, ["flip", "ga", "cut_out", "smaller_resize", "rotation"], (0, 5, 7, 10), seed=1)   # 4 of 12: a ResNet-101 image with six views costs the CPU oracle ~20 s
+
+
+def test_config4_full_size_f16x3_vs_exact(hip):
+    """BASELINE.json configs[4] IN ITS OWN PRECISION: Faster R-CNN ResNet-101 FPN, COCO shapes, 91 classes, 800/1333, five
+    augmentations (6 views per image), precision="f16x3" (the "fp16 MFMA path": conv_h3.hip / conv_h4.hip) against the exact fp32
+    mode on the same 128 images -- the exact mode itself is tied to the CPU oracle bit for bit by the test above.  The bar is the
+    sweep's: floats within 1e-4 on (almost) every image, the same selection.  f16x3 is not bit-identical by construction
+    (DESIGN.md section 6), so the statement is statistical: median |d consistency| <= 2e-6, at most 2 % of the images beyond 1e-4 (a
+    flipped borderline detection each), >= 98 % of the selected set in common."""
+    torch = hip["torch"]
+    from cald_amd import synth, sweep
+    n, augs = 128, ["flip", "ga", "cut_out", "smaller_resize", "rotation"]
+    sd = synth.pseudo_trained_frcnn(91, 101, seed=1)
+    dev = [torch.from_numpy(im).cuda() for im in synth.make_pool(n, "coco", 0)]
+    pos = list(range(n))
+    res = {}
+    for prec in ("fp32", "f16x3"):
+        m = hip["det"].fasterrcnn_resnet101_fpn_feature(num_classes=91, min_size=800, max_size=1333, precision=prec).to("cuda")
+        m.load_state_dict(sd); m.eval()
+        res[prec] = sweep.sweep_device_images(m, dev, pos, augs, bp=1.3, base_seed=4, batch_images=64)
+        del m
+        torch.cuda.empty_cache()
+    (ce, ke), (ch, kh) = res["fp32"], res["f16x3"]
+    d = np.abs(ce - ch)
+    rs = np.random.RandomState(0)
+    labeled = [(None, [{"labels": torch.from_numpy(rs.randint(1, 91, rs.randint(1, 6)))}]) for _ in range(100)]
+    budget = 50                                                        # candidates = first int(1.2 * 50) = 60 of argsort, then cls_kldiv
+    se = sweep.select(list(ce), [ke[i] for i in range(n)], labeled, budget=budget, mr=1.2)
+    sh = sweep.select(list(ch), [kh[i] for i in range(n)], labeled, budget=budget, mr=1.2)
+    common = len(set(map(int, se)) & set(map(int, sh)))
+    print("configs[4] f16x3 vs exact, %d images: median |d| %.3g, max %.3g, beyond 1e-4: %d, selected in common %d / %d"
+          % (n, np.median(d), d.max(), int((d > 1e-4).sum()), common, len(se)))
+    assert float(np.median(d)) <= 2e-6, float(np.median(d))
+    assert int((d > 1e-4).sum()) <= int(0.02 * n), d[d > 1e-4]
+    assert common >= int(np.ceil(0.98 * len(se))), (common, len(se))
+    assert np.all(ch >= 0) and np.all(ch <= 1.0) and (kh > 0).any()
 
 
 def test_float_inputs_reach_the_kernels_exactly(hip, oracle, small_model):
@@ -969,104 +962,6 @@ def test_voc_evaluate_files_equal_oracle_files_and_ap(hip, oracle, small_model, 
     # classes without ground truth have npos == 0 -> AP is nan in the reference too (voc_eval.py:181); look at the annotated ones
     annotated = [a for a in res["ap_per_class"] if a == a]
     assert len(res["ap_per_class"]) == 20 and len(annotated) >= 2 and max(annotated) > 0.5, res["ap_per_class"]
-
-
-def test_i8x3_mode_is_bit_identical_to_its_oracle(hip, oracle):
-    """CALD_PRECISION_I8X3 end to end (BASELINE configs[4]'s matrix-pipe path with a PINNED oracle): every stage of a forward and
-    a whole 3-augmentation sweep equal the C oracle in the same mode, bit for bit -- and stay close to the exact fp32 mode."""
-    torch = hip["torch"]
-    from cald_amd import synth, sweep
-    sd = synth.pseudo_trained_frcnn(21, 50, seed=0)
-    model = hip["det"].fasterrcnn_resnet50_fpn_feature(num_classes=21, min_size=300, max_size=500, precision="i8x3").to("cuda")
-    model.load_state_dict(sd)
-    pool = synth.make_pool(4, "voc", 0, scale=0.5)
-    P = oracle.prepare_frcnn(sd, 21, 50)
-    P["i8"] = True                                                      # stem / < 64-channel heads stay on the exact chain on both sides
-    keep = {}
-    want = oracle.frcnn_forward(P, pool[1], 300, 500, keep=keep)
-    got = model.forward_views([(torch.from_numpy(pool[1]).cuda(), False, None)])[0]
-    stages = [("C%d" % (i + 2), keep["C"][i]) for i in range(4)] + [("P%d" % (i + 2), keep["fpn"][i]) for i in range(5)]
-    stages += [("rpn%d" % i, keep["rpn_head"][i]) for i in range(5)]
-    for name, w in stages:
-        g = model.debug_tensor(name, 0)
-        assert g.tobytes() == w.tobytes(), "stage %s differs: max abs %g" % (name, float(np.abs(g - w).max()))
-    n = keep["proposals"].shape[0]
-    for name in ("roi", "fc7", "pred"):
-        g = model.debug_tensor(name, 0).reshape(1000, -1)[:n]
-        assert g.tobytes() == keep[name].reshape(n, -1).tobytes(), "stage %s differs" % name
-    assert want["boxes"].shape[0] > 0
-    for k in ("boxes", "scores", "labels", "props", "prob_max", "scores_cls"):
-        assert got[k].cpu().numpy().tobytes() == want[k].tobytes(), "output %s differs" % k
-    augs = ["flip", "cut_out", "smaller_resize"]
-    dev = [torch.from_numpy(im).cuda() for im in pool[:3]]
-    cons, cls = sweep.sweep_device_images(model, dev, [0, 1, 2], augs, bp=1.3, base_seed=3, batch_images=2)
-    wc, wcls = oracle.get_uncertainty(P, pool[:3], augs, 21, bp=1.3, min_size=300, max_size=500, base_seed=3)
-    np.testing.assert_array_equal(cons, np.array(wc))
-    np.testing.assert_array_equal(cls, np.stack(wcls))
-    # distance to the exact fp32 mode: fp32-grade (24-bit fixed point per layer), not bit-identical
-    exact = hip["det"].fasterrcnn_resnet50_fpn_feature(num_classes=21, min_size=300, max_size=500).to("cuda")
-    exact.load_state_dict(sd)
-    ce, _ = sweep.sweep_device_images(exact, dev, [0, 1, 2], augs, bp=1.3, base_seed=3)
-    assert float(np.abs(cons - ce).max()) < 1e-3, (cons, ce)
-
-
-def test_i8x3_mode_retinanet_forward_bit_exact(hip, oracle):
-    """The int8 mode on the other detector: FPN + P6 + both towers on the int8 pipe (P7, the 36-channel box head on the exact
-    kernels), per-class post-processing -- bit-identical to the oracle."""
-    torch = hip["torch"]
-    from cald_amd import synth
-    sd = synth.pseudo_trained_retinanet(21, 50, seed=0)
-    model = hip["det"].retinanet_resnet50_fpn_cal(num_classes=21, min_size=300, max_size=500, precision="i8x3").to("cuda")
-    model.load_state_dict(sd)
-    pool = synth.make_pool(3, "voc", 0, scale=0.5)
-    P = oracle.prepare_retinanet(sd, 21, 50)
-    P["i8"] = True
-    want = oracle.retina_forward(P, pool[2], 300, 500, flip=True)
-    got = model.forward_views([(torch.from_numpy(pool[2]).cuda(), True, None)])[0]
-    assert want["boxes"].shape[0] > 0
-    for k in ("boxes", "scores", "labels", "prob_max", "scores_cls"):
-        assert got[k].cpu().numpy().tobytes() == want[k].tobytes(), "output %s differs" % k
-
-
-def test_config4_full_size_i8x3_matrix_pipe_mode(hip, oracle):
-    """BASELINE.json configs[4] as written -- Faster R-CNN ResNet-101 FPN, COCO shapes (800/1333, 91 classes), 5 augmentations,
-    matrix-pipe arithmetic -- at FULL size in the mode an oracle can pin: one image (6 views) re-scored by the CPU oracle in
-    CALD_PRECISION_I8X3, bit for bit; batch / shard invariance over 8 images; and the distance to the exact fp32 mode."""
-    import os
-    torch = hip["torch"]
-    from cald_amd import synth, sweep
-    sd = synth.pseudo_trained_frcnn(91, 101, seed=1)
-    model = hip["det"].fasterrcnn_resnet101_fpn_feature(num_classes=91, min_size=800, max_size=1333, precision="i8x3").to("cuda")
-    model.load_state_dict(sd)
-    pool = synth.make_pool(8, "coco", 0)
-    augs = ["flip", "ga", "cut_out", "smaller_resize", "rotation"]
-    dev = [torch.from_numpy(im).cuda() for im in pool]
-    pos = list(range(8))
-    c1, k1 = sweep.sweep_device_images(model, dev, pos, augs, base_seed=4, batch_images=64)
-    c2, k2 = sweep.sweep_device_images(model, dev, pos, augs, base_seed=4, batch_images=3)
-    np.testing.assert_array_equal(c1, c2); np.testing.assert_array_equal(k1, k2)
-    cw = np.zeros(8); kw = np.zeros((8, 90))
-    for r in range(2):
-        idx = sweep.shard_positions(8, r, 2)
-        cr, kr = sweep.sweep_device_images(model, [dev[i] for i in idx], idx, augs, base_seed=4)
-        cw[idx] = cr; kw[idx] = kr
-    np.testing.assert_array_equal(c1, cw); np.testing.assert_array_equal(k1, kw)
-    P = oracle.prepare_frcnn(sd, 91, 101)
-    P["i8"] = True
-    oracle.set_threads(min(128, os.cpu_count() or 1))
-    try:
-        wc, wk = oracle.get_uncertainty(P, [pool[5]], augs, 91, bp=1.3, min_size=800, max_size=1333, base_seed=4, positions=[5])
-    finally:
-        oracle.set_threads(min(32, os.cpu_count() or 1))
-    assert c1[5] == wc[0], (c1[5], wc[0])
-    np.testing.assert_array_equal(k1[5], wk[0])
-    exact = hip["det"].fasterrcnn_resnet101_fpn_feature(num_classes=91, min_size=800, max_size=1333).to("cuda")
-    exact.load_state_dict(sd)
-    ce, _ = sweep.sweep_device_images(exact, dev, pos, augs, base_seed=4)
-    d = np.abs(c1 - ce)
-    print("i8x3 vs exact fp32, configs[4] shapes, 8 images: max |d consistency| %.3g, median %.3g" % (d.max(), np.median(d)))
-    # not bit-identical to fp32 (nothing but the exact mode is): a borderline detection that flips moves an image by ~1e-2
-    assert float(np.median(d)) < 1e-2 and float(d.max()) < 0.5, d
 
 
 def test_selection_cycle_from_a_vocdevkit_directory(hip, oracle, small_model, tmp_path):
@@ -1327,6 +1222,52 @@ def test_c_abi_rccl_allgather_across_two_devices(hip, tmp_path):
         out, err = p.communicate(timeout=600)
         assert p.returncode == 0, err[-2000:]
         assert json.loads([l for l in out.splitlines() if l.startswith("RESULT ")][-1][7:])["ok"]
+
+
+_ADOPT_SCRIPT = r"""
+import ctypes as C, sys, json
+import numpy as np, torch
+sys.path.insert(0, %r)
+torch.cuda.set_device(0)
+from cald_amd import _ffi
+from cald_amd.detector import get_ctx
+L = _ffi.lib()
+class Id(C.Structure):
+    _fields_ = [("b", C.c_char * 128)]
+R = C.CDLL("librccl.so.1", mode=C.RTLD_GLOBAL)                        # the host framework's own communicator, made outside the C ABI
+R.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, Id, C.c_int]
+R.ncclCommCount.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+R.ncclCommDestroy.argtypes = [C.c_void_p]
+uid = Id(); assert R.ncclGetUniqueId(C.byref(uid)) == 0
+raw = C.c_void_p(); assert R.ncclCommInitRank(C.byref(raw), 1, uid, 0) == 0
+rows = torch.arange(14, dtype=torch.float64, device="cuda").reshape(7, 2)
+ok = True
+for rnd in range(2):                                                   # adopt -> gather -> destroy the WRAPPER, twice, on the same ncclComm_t
+    h = C.c_void_p()
+    _ffi.check(L.cald_comm_adopt(get_ctx(0), raw, C.byref(h)))
+    out = torch.empty_like(rows)
+    torch.cuda.current_stream().synchronize()
+    _ffi.check(L.cald_allgather_scores(h, C.c_void_p(rows.data_ptr()), C.c_void_p(out.data_ptr()), 7, 2))
+    _ffi.check(L.cald_ctx_sync(get_ctx(0)))
+    ok = ok and bool(torch.equal(out, rows))
+    _ffi.check(L.cald_comm_destroy(h))
+    n = C.c_int(-1)
+    ok = ok and R.ncclCommCount(raw, C.byref(n)) == 0 and n.value == 1   # the adopted communicator is still alive and usable
+assert R.ncclCommDestroy(raw) == 0                                     # ... and is destroyed exactly once, by its owner
+print("RESULT " + json.dumps({"ok": ok}))
+"""
+
+
+def test_c_abi_adopted_communicator_survives_its_wrapper(hip):
+    """cald_comm_adopt() takes ownership of nothing but the wrapper (include/cald_hip.h): destroying the wrapper must leave the host
+    framework's ncclComm_t alive (round 4 called ncclCommDestroy on it -> double destroy / use after free on the host's next
+    collective).  World of one rank on the box's GPU, in a subprocess (RCCL state is per process)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _ADOPT_SCRIPT % root], env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])["ok"]
 
 
 def test_sweep_error_in_a_later_batch_leaves_the_model_usable(hip, small_model):

@@ -30,7 +30,6 @@ LAYERS = [
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "base"
     only = sys.argv[2] if len(sys.argv) > 2 else None
-    i8 = os.environ.get("CALD_BENCH_I8") == "1"       # time the CALD_PRECISION_I8X3 kernel instead (shapes it covers)
     L, ctx = _ffi.lib(), detector.get_ctx(0)
     res = {}
     for (name, V, H, W, Cin, Cout, K, s, p, resid, relu, grp) in LAYERS:
@@ -38,9 +37,7 @@ def main():
             continue
         ms, tf = C.c_double(), C.c_double()
         iters = 3 if (H * W * Cin * Cout * K * K > 2e10) else 8
-        if i8 and (Cin % 32 or Cout < 64):
-            continue
-        _ffi.check(L.cald_op_conv_bench(ctx, V, H, W, Cin, Cout, K, s, p, resid, relu | (2 if i8 else 0), iters, grp, C.byref(ms), C.byref(tf)))
+        _ffi.check(L.cald_op_conv_bench(ctx, V, H, W, Cin, Cout, K, s, p, resid, relu, iters, grp, C.byref(ms), C.byref(tf)))
         res[name] = {"ms": ms.value, "tflops": tf.value}
         print("%-40s %8.3f ms  %6.1f TF" % (name, ms.value, tf.value), flush=True)
     print(json.dumps({"tag": tag, "env": {k: v for k, v in os.environ.items() if k.startswith("CALD_")}, "layers": res}))

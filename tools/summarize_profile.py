@@ -42,7 +42,7 @@ for key, pat in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write"), ("MFM
         for c in agg[name]:
             summary.setdefault(name, {})[c] = {"sum": agg[name][c], "dispatches": cnt[name][c], "avg": agg[name][c] / cnt[name][c]}
 def is_gemm(name):
-    return any(t in name for t in ("conv_mfma", "conv_p4", "conv_fused", "conv_stem", "conv_h3", "conv_h4", "conv_i3"))
+    return any(t in name for t in ("conv_mfma", "conv_p4", "conv_fused", "conv_stem", "conv_h3", "conv_h4"))
 
 
 gemm_ns = gemm_calls = 0
