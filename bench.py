@@ -84,6 +84,42 @@ def launch_ranks(n, argv):
     return rc
 
 
+def exchange_id_over_tcp(rank, world, uid, timeout_s=120.0):
+    """Ships the 128-byte RCCL unique id from rank 0 to every rank over a plain TCP socket on MASTER_ADDR : MASTER_PORT + 29 (the
+    launcher's rendezvous port stays torch's).  Stands for "any means" of include/cald_hip.h -- a C host would do the same."""
+    import socket
+    host = os.environ.get("MASTER_ADDR", "127.0.0.1")
+    port = int(os.environ.get("MASTER_PORT", "29500")) + 29
+    if rank == 0:
+        srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+        srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        srv.bind((host, port)); srv.listen(world); srv.settimeout(timeout_s)
+        try:
+            for _ in range(world - 1):
+                c, _addr = srv.accept()
+                c.sendall(uid); c.close()
+        finally:
+            srv.close()
+        return uid
+    t0 = time.time()
+    while True:
+        try:
+            c = socket.create_connection((host, port), timeout=5.0)
+            break
+        except OSError:
+            if time.time() - t0 > timeout_s:
+                raise
+            time.sleep(0.05)
+    buf = b""
+    while len(buf) < 128:
+        chunk = c.recv(128 - len(buf))
+        if not chunk:
+            raise RuntimeError("rank 0 closed the id socket early")
+        buf += chunk
+    c.close()
+    return buf
+
+
 def _jpeg_of(args):
     """(pool position, (H, W)) -> baseline JPEG bytes of the synthetic image (runs in forked host workers)."""
     pos, (H, W) = args
@@ -293,6 +329,11 @@ def main():
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
                     help="strong (SURVEY 8d: fixed pool / wall time): K x 64 images in total, split over the N GPUs; "
                          "weak: K x 64 images per GPU (pool grows with N)")
+    ap.add_argument("--comm", default="auto", choices=["auto", "cabi", "torch"],
+                    help="who carries the one all-gather of the score rows (N > 1): cabi = cald_allgather_scores of the C ABI (RCCL, device "
+                         "buffers, communicator bootstrapped over a TCP socket next to MASTER_PORT: no torch.distributed in the data path); "
+                         "torch = torch.distributed.all_gather_into_tensor; auto = cabi when every rank has a GPU of its own, torch (gloo) when "
+                         "ranks share a device (RCCL refuses two ranks on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-full-pool", action="store_true", help="skip the 5 217-image end-to-end run (N = 1 headline only)")
     ap.add_argument("--no-f16x3", action="store_true")
@@ -363,6 +404,8 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     coll_dev = torch.device("cpu") if (share or world == 1) else torch.device("cuda", local_rank)
+    use_cabi = world > 1 and (args.comm == "cabi" or (args.comm == "auto" and not share))
+    cabi_comm, cabi_info = None, None
 
     from cald_amd import _ffi, detector, sweep
     from cald_amd.pool import DevicePool
@@ -377,6 +420,17 @@ def main():
     model = model.to("cuda:%d" % local_rank)
     model.load_state_dict(sd)
     model.eval()
+    if use_cabi:
+        # the C ABI's own communicator (cald_comm_init_rank): one per process, on the context's device and stream
+        from cald_amd.comm import RcclComm
+        cabi_comm = RcclComm.from_store(rank, world, lambda uid: exchange_id_over_tcp(rank, world, uid), device=local_rank)
+        import ctypes as C_
+        w_, r_ = C_.c_int(), C_.c_int()
+        _ffi.check(_ffi.lib().cald_comm_info(cabi_comm.handle, C_.byref(w_), C_.byref(r_)))
+        cabi_info = (w_.value, r_.value)
+        assert cabi_info == (world, rank), cabi_info
+        wp = sweep.shard_positions(world * 3, rank, world)            # warm-up on a 3-rows-per-rank pool: RCCL's first collective builds its rings
+        cabi_comm.allgather_scores(wp, np.zeros(len(wp)), np.zeros((len(wp), ncls - 1)), world * 3)
     labeled = synthetic_labeled_set(500, ncls, 0)
     budget = max(1, min(FULL_BUDGET, int(round(FULL_BUDGET * pool_total / float(FULL_POOL)))))
 
@@ -429,7 +483,8 @@ def main():
         cons, cls = np.zeros(0), np.zeros((0, ncls - 1))
     t_local = time.time() - t0                    # this rank's own shard scored (sweep_batch returns host arrays: synchronous)
     if world > 1:   # the one RCCL all-gather of the (consistency, cls_corr) rows of the WHOLE timed pool
-        cons, cls = sweep.allgather_scores(positions, cons, cls, pool_total)
+        cons, cls = (cabi_comm.allgather_scores(positions, cons, cls, pool_total) if cabi_comm is not None else
+                     sweep.allgather_scores(positions, cons, cls, pool_total))
     picked = sweep.select(list(cons), [cls[i] for i in range(cls.shape[0])], labeled, budget=budget, mr=1.2)   # every rank, host
     barrier()
     dt = time.time() - t0
@@ -482,7 +537,9 @@ def main():
                        "steps_per_rank": steps_local},
             "rccl": {"backend": backend, "world_size": world, "ranks_seen": int(rows.shape[0]), "visible_gpus": ndev,
                      "shared_gpu": bool(share),
-                     "collective": ("all_gather_into_tensor over RCCL (device buffers)" if backend == "nccl" else
+                     "cabi": None if cabi_comm is None else {"world_size": cabi_info[0], "rank0": cabi_info[1], "bootstrap": "128-byte id over TCP (MASTER_PORT + 29)"},
+                     "collective": ("cald_allgather_scores (C ABI: RCCL on the context's stream, device buffers, communicator from cald_comm_init_rank)" if cabi_comm is not None else
+                                    "all_gather_into_tensor over RCCL (device buffers)" if backend == "nccl" else
                                     "all_gather_into_tensor over gloo: %d ranks on %d visible GPU(s), RCCL refuses two ranks on one device" % (world, ndev)
                                     if backend == "gloo" else "none (one rank)"),
                      "per_rank": [{"rank": int(r[0]), "device": int(r[1]), "pci_bus": int(r[2]), "device_id_hash": "%012x" % int(r[3]),
@@ -571,6 +628,8 @@ def main():
             out["training_step"] = dict(bench_train.measure(batch=4, steps=10, warmup=3), headline=False)
         out["parity_vs_independent_fp32"] = parity_file()
         print(json.dumps(out))
+    if cabi_comm is not None:
+        cabi_comm.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -40,6 +40,12 @@ class Dets(C.Structure):
 
 
 MAX_AUGS = 32
+N_MARGINS = 16          # CALD_N_MARGINS
+MARGIN_NAMES = ['rpn_topk', 'rpn_iou', 'rpn_order', 'rpn_trunc', 'rpn_small', 'roi_level', 'roi_edge', 'post_thr', 'post_iou', 'post_order',
+                'post_cap', 'ref_subsample', 'argmax', 'zero_row', 'cutout', 'reserved']
+# Rounding noise of precision="f16x3" against the exact mode on each margin's scale, calibrated on 1 536 configs[1] images
+# (tools/cascade_margins.py, profiles/r5_cascade_margins.txt): about the 90th percentile of |margin_exact - margin_f16x3|.
+MARGIN_NOISE_F16X3 = [2e-5, 2e-6, 2e-5, 2e-5, 1e-5, 1e-6, 1e-4, 5e-6, 2e-6, 5e-6, 5e-6, 5e-6, 2e-6, 5e-6, 2e-6, 0.0]
 AUG_FLIP, AUG_GAUSS, AUG_COLOR_ADJUST, AUG_COLOR_SWAP, AUG_SALT_PEPPER, AUG_CUTOUT, AUG_RESIZE, AUG_ROTATE = range(1, 9)
 
 
@@ -65,6 +71,7 @@ SIGNATURES = {
     "cald_model_destroy": (C.c_int, [C.c_void_p]),
     "cald_forward": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(View), C.POINTER(Dets)]),
     "cald_sweep": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), c_i, c_i, c_i64, C.POINTER(SweepCfg), c_d, c_d]),
+    "cald_sweep_audit": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), c_i, c_i, c_i64, C.POINTER(SweepCfg), c_d, c_d, c_f]),
     "cald_sweep_ltc": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), c_i, c_i, C.c_int, c_d]),
     "cald_sweep_lsc": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), c_i, c_i, c_i64, C.c_uint64, C.c_int, c_d]),
     "cald_op_consistency": (C.c_int, [C.c_void_p, C.c_int, c_f, c_f, c_f, C.c_int, c_f, c_f, c_f, C.c_int, C.c_float, c_f]),
@@ -73,6 +80,9 @@ SIGNATURES = {
     "cald_op_cutout_rects": (C.c_int, [C.c_uint64, C.c_int, C.c_int, C.c_int, c_f, C.c_int, c_i, c_i]),
     "cald_op_augment": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_uint64, C.c_void_p, C.c_int, C.c_int, C.c_int, c_f,
                                   C.c_void_p, c_f, c_i]),
+    "cald_op_frcnn_postprocess": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
+                                            C.c_int, c_f, c_f, c_i64, c_f, c_f, c_f, c_i]),
+    "cald_op_roi_align": (C.c_int, [C.c_void_p, C.POINTER(c_f), c_i, C.c_int, C.c_int, c_f, c_f]),
     "cald_op_conv2d": (C.c_int, [C.c_void_p, c_f, C.c_int, C.c_int, C.c_int, c_f, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_int, c_f, c_f, c_f, c_f, C.c_int, c_f]),
     "cald_op_conv2d_f16x3": (C.c_int, [C.c_void_p, c_f, C.c_int, C.c_int, C.c_int, c_f, C.c_int, C.c_int, C.c_int, C.c_int,

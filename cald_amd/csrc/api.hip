@@ -723,6 +723,8 @@ struct FwdBufs {
     float* rpn_tl[5];
     int *cand_count, *kept_anchor, *kept_count; int cand_cap; int max_anchors; unsigned char* cand_skip;
     unsigned* Pf16[5];   // CALD_PRECISION_F16X3: split twins of the tensors that stay fp32 as well
+    // decision-margin audit (audit.hip): what the RPN / post-processing kernels leave behind for it
+    unsigned long long *next_key, *trunc_key, *kept_key; float* post_maxc;
 };
 
 static double fill_conv_args(cald_model* m, ConvArgs& a, const ConvLayer& L, const float* in, float* out, int lin, int lout, int V, bool relu,
@@ -918,10 +920,12 @@ static void fwd_layout(cald_model* m, Bump& B, FwdBufs& F, int V) {
     F.keys = B.get<unsigned long long>((size_t)V * m->key_cap);
     F.cbox = B.get<float>((size_t)V * 2 * m->key_cap * 4);
     F.key_count = B.get<int>(V);
+    F.next_key = B.get<unsigned long long>((size_t)V * 10); F.trunc_key = B.get<unsigned long long>((size_t)V * 2);
+    F.kept_key = B.get<unsigned long long>((size_t)V * m->det_cap()); F.post_maxc = B.get<float>(V);
 }
 
 // views: host descriptors with src/H/W/flip/rects filled; Hr/Wr/Ho/Wo are filled here.
-static int forward_model(cald_model* m, int V, ViewDesc* views, const DetBuffers& det) {
+static int forward_model(cald_model* m, int V, ViewDesc* views, const DetBuffers& det, float* audit_out = nullptr) {
     cald_ctx* c = m->ctx;
     if (!m->finalized) return fail(CALD_ERR_STATE, "model not finalized (call cald_model_finalize)");
     if (V < 1 || V > CALD_MAX_VIEWS) return fail(CALD_ERR_INVALID, "n_views must be 1..%d", CALD_MAX_VIEWS);
@@ -939,6 +943,8 @@ static int forward_model(cald_model* m, int V, ViewDesc* views, const DetBuffers
         if (Hp * Wp > max_pix0) max_pix0 = Hp * Wp;
     }
     const bool retina = m->cfg.arch == CALD_ARCH_RETINANET;
+    if (audit_out && (retina || m->cfg.rpn_pre_nms_top_n > 1024 || m->det_cap() > 512))
+        return fail(CALD_ERR_UNSUPPORTED, "the decision-margin audit covers Faster R-CNN with rpn_pre_nms_top_n <= 1024 and <= 512 detections per image");
     build_plan(m->plan, V, views, hp, retina);
     m->last_V = V; m->last_views.assign(views, views + V);
     for (int v = 0; v < V; v++) {
@@ -1064,6 +1070,7 @@ static int forward_model(cald_model* m, int V, ViewDesc* views, const DetBuffers
     ra.nms_thr = m->cfg.rpn_nms_thresh; ra.min_size = 1e-3f;
     ra.cand_key = F.cand_key; ra.cand_box = F.cand_box; ra.sorted_box = F.sorted_box; ra.sorted_raw = F.sorted_raw;
     ra.sorted_count = F.sorted_count; ra.proposals = F.proposals; ra.prop_stride = CALD_ROI_CAP; ra.prop_count = F.prop_count;
+    ra.next_key = audit_out ? F.next_key : nullptr; ra.trunc_key = audit_out ? F.trunc_key : nullptr;
     launch_rpn(ra, st);
     m->dbg["proposals"] = {F.proposals, 7, 4, 1};
     // ---- box head (rows A18, A19, A20) ----
@@ -1095,7 +1102,20 @@ static int forward_model(cald_model* m, int V, ViewDesc* views, const DetBuffers
     pa.score_thr = m->cfg.box_score_thresh; pa.nms_thr = m->cfg.box_nms_thresh;
     pa.prob = F.prob; pa.pmax = F.pmax; pa.keys = F.keys; pa.cbox = F.cbox; pa.key_count = F.key_count; pa.key_cap = m->key_cap;
     pa.det = det;
+    pa.kept_key = audit_out ? F.kept_key : nullptr; pa.post_maxc = audit_out ? F.post_maxc : nullptr;
     launch_frcnn_postprocess(pa, st);
+    if (audit_out) {
+        AuditArgs au;
+        au.cand_key = F.cand_key; au.cand_box = F.cand_box; au.sorted_box = F.sorted_box; au.flags = reinterpret_cast<const unsigned char*>(F.sorted_raw);
+        au.next_key = F.next_key; au.trunc_key = F.trunc_key; au.pre_n = ra.pre_n; au.post_n = ra.post_n; au.rpn_nms_thr = ra.nms_thr; au.min_size = ra.min_size;
+        au.proposals = F.proposals; au.prop_count = F.prop_count;
+        for (int i = 0; i < 4; i++) au.seg[i] = dp->seg[2 + i];
+        au.prob = F.prob; au.pred = F.pr; au.pred_ld = m->pred.Cout; au.C = m->cfg.num_classes; au.views = c->d_views;
+        au.keys = F.keys; au.key_count = F.key_count; au.key_cap = m->key_cap; au.kept_key = F.kept_key; au.post_maxc = F.post_maxc;
+        au.det_count = det.count; au.cap = det.cap; au.score_thr = pa.score_thr; au.post_nms_thr = pa.nms_thr;
+        au.V = V; au.delta = 1e-2f; au.out = audit_out;
+        launch_audit(au, st);
+    }
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1376,6 +1396,88 @@ extern "C" int cald_op_consistency(cald_ctx* c, int N, const float* aug_box, con
     return 0;
 }
 
+// RoIHeads.postprocess_detections + transform.postprocess of ONE view on the kernels of the forward (roi.hip post_softmax_kernel /
+// post_nms_kernel): host arrays in, host arrays out.  Parity hook for detection/frcnn_la.py:32-87, :292-315.
+extern "C" int cald_op_frcnn_postprocess(cald_ctx* c, int R, int C, const float* logits, const float* deltas, const float* proposals,
+                                         int Hr, int Wr, int Ho, int Wo, float score_thr, float nms_thr, int det_max,
+                                         float* boxes_out, float* scores_out, int64_t* labels_out, float* props_out, float* prob_max_out,
+                                         float* scores_cls_out, int* n_out) {
+    if (!c || !logits || !deltas || !proposals || !boxes_out || !scores_out || !labels_out || !props_out || !prob_max_out || !scores_cls_out || !n_out)
+        return fail(CALD_ERR_INVALID, "null argument");
+    if (R < 0 || R > CALD_ROI_CAP || C < 2 || C > 256 || det_max < 1 || det_max > 512) return fail(CALD_ERR_INVALID, "bad geometry (R <= %d, 2 <= C <= 256, det_max <= 512)", CALD_ROI_CAP);
+    HIPCHK(hipSetDevice(c->device));
+    ScopedDev sd(c->stream);
+    const int ld = 5 * C;
+    int key_cap = 1024; while (key_cap < R * (C - 1)) key_cap <<= 1;
+    std::vector<float> pred((size_t)CALD_ROI_CAP * ld, 0.0f);
+    for (int r = 0; r < R; r++) {
+        memcpy(&pred[(size_t)r * ld], logits + (size_t)r * C, (size_t)C * 4);
+        memcpy(&pred[(size_t)r * ld + C], deltas + (size_t)r * 4 * C, (size_t)4 * C * 4);
+    }
+    ViewDesc vd; memset(&vd, 0, sizeof(vd)); vd.Hr = Hr; vd.Wr = Wr; vd.Ho = Ho; vd.Wo = Wo;
+    PostArgs pa; float *d_pred, *d_props, *d_prob, *d_pmax, *d_cbox; unsigned long long* d_keys; int *d_kc, *d_pc; ViewDesc* d_vd;
+    int rc;
+    if ((rc = sd.alloc(&d_pred, pred.size() * 4)) || (rc = sd.alloc(&d_props, (size_t)CALD_ROI_CAP * 16)) || (rc = sd.alloc(&d_prob, (size_t)CALD_ROI_CAP * C * 4)) ||
+        (rc = sd.alloc(&d_pmax, (size_t)CALD_ROI_CAP * 4)) || (rc = sd.alloc(&d_cbox, (size_t)2 * key_cap * 16)) || (rc = sd.alloc(&d_keys, (size_t)key_cap * 8)) ||
+        (rc = sd.alloc(&d_kc, 4)) || (rc = sd.alloc(&d_pc, 4)) || (rc = sd.alloc(&d_vd, sizeof(ViewDesc)))) return rc;
+    DetBuffers det; if ((rc = alloc_det(det, 1, det_max, C))) return rc;
+    HIPCHK(hipMemcpy(d_pred, pred.data(), pred.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(d_props, 0, (size_t)CALD_ROI_CAP * 16));
+    if (R) HIPCHK(hipMemcpy(d_props, proposals, (size_t)R * 16, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_pc, &R, 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_vd, &vd, sizeof(vd), hipMemcpyHostToDevice));
+    pa.pred = d_pred; pa.pred_ld = ld; pa.C = C; pa.V = 1; pa.proposals = d_props; pa.prop_count = d_pc; pa.views = d_vd;
+    pa.score_thr = score_thr; pa.nms_thr = nms_thr; pa.prob = d_prob; pa.pmax = d_pmax; pa.keys = d_keys; pa.cbox = d_cbox; pa.key_count = d_kc;
+    pa.key_cap = key_cap; pa.det = det;
+    launch_frcnn_postprocess(pa, c->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    int n = 0;
+    HIPCHK(hipMemcpy(&n, det.count, 4, hipMemcpyDeviceToHost));
+    *n_out = n;
+    if (n) {
+        HIPCHK(hipMemcpy(boxes_out, det.boxes, (size_t)n * 16, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(scores_out, det.scores, (size_t)n * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(labels_out, det.labels, (size_t)n * 8, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(props_out, det.props, (size_t)n * 16, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(prob_max_out, det.prob_max, (size_t)n * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(scores_cls_out, det.scores_cls, (size_t)n * C * 4, hipMemcpyDeviceToHost));
+    }
+    free_det(det);
+    return 0;
+}
+
+// MultiScaleRoIAlign(7, sampling_ratio 2) of ONE view on the inference kernels (roi.hip): feats[l] = host [H_l][W_l][C] for the four
+// levels P2..P5 (level_hw = {H0, W0, ..., H3, W3}), rois [R][4] in image coordinates, out [R][49][C] (host).  C == 256 runs the
+// row-walk kernel, other C (multiple of 4) the gather kernel.  Parity hook for detection/frcnn_la.py:205-209.
+extern "C" int cald_op_roi_align(cald_ctx* c, const float* const* feats, const int* level_hw, int C, int R, const float* rois, float* out) {
+    if (!c || !feats || !level_hw || !rois || !out) return fail(CALD_ERR_INVALID, "null argument");
+    if (R < 1 || R > CALD_ROI_CAP || C < 4 || C % 4) return fail(CALD_ERR_INVALID, "bad geometry (1 <= R <= %d, C a positive multiple of 4)", CALD_ROI_CAP);
+    HIPCHK(hipSetDevice(c->device));
+    ScopedDev sd(c->stream);
+    BatchPlan P; memset(&P, 0, sizeof(P));
+    RoiArgs ro; float* d_f[4]; BatchPlan* d_p; float *d_rois, *d_out; int *d_pc, *d_order;
+    int rc;
+    for (int l = 0; l < 4; l++) {
+        const int H = level_hw[2 * l], W = level_hw[2 * l + 1];
+        if (H < 1 || W < 1 || !feats[l]) return fail(CALD_ERR_INVALID, "level %d is malformed", l);
+        P.seg[2 + l][0].H = H; P.seg[2 + l][0].W = W; P.seg[2 + l][1].pix_off = (long long)H * W;
+        if ((rc = sd.alloc(&d_f[l], (size_t)H * W * C * 4))) return rc;
+        HIPCHK(hipMemcpy(d_f[l], feats[l], (size_t)H * W * C * 4, hipMemcpyHostToDevice));
+    }
+    if ((rc = sd.alloc(&d_p, sizeof(BatchPlan))) || (rc = sd.alloc(&d_rois, (size_t)CALD_ROI_CAP * 16)) || (rc = sd.alloc(&d_out, (size_t)CALD_ROI_CAP * 49 * C * 4)) ||
+        (rc = sd.alloc(&d_pc, 4)) || (rc = sd.alloc(&d_order, 1024 * 4))) return rc;
+    HIPCHK(hipMemcpy(d_p, &P, sizeof(P), hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(d_rois, 0, (size_t)CALD_ROI_CAP * 16));
+    HIPCHK(hipMemcpy(d_rois, rois, (size_t)R * 16, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_pc, &R, 4, hipMemcpyHostToDevice));
+    for (int l = 0; l < 4; l++) { ro.feat[l] = d_f[l]; ro.seg[l] = d_p->seg[2 + l]; }
+    ro.C = C; ro.V = 1; ro.proposals = d_rois; ro.prop_count = d_pc; ro.out = d_out; ro.order = d_order; ro.out16 = 0;
+    launch_roi_align(ro, c->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(out, d_out, (size_t)R * 49 * C * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 extern "C" int cald_op_cls_corr(cald_ctx* c, int n, const float* scores, const int64_t* labels, int C, float* out) {
     if (!c || !out || n < 0 || C < 2 || C > 256) return fail(CALD_ERR_INVALID, "bad arguments");
     HIPCHK(hipSetDevice(c->device));
@@ -1401,9 +1503,10 @@ static int sweep_fwd_views() {
     static const int env = getenv("CALD_FWD_VIEWS") ? atoi(getenv("CALD_FWD_VIEWS")) : 96;
     return env < 1 ? 1 : (env > CALD_MAX_VIEWS ? CALD_MAX_VIEWS : env);
 }
-extern "C" int cald_sweep(cald_model* m, int n_images, const uint8_t* const* images_dev, const int* H, const int* W,
-                          const int64_t* pool_pos, const cald_sweep_cfg* cfg, double* consistency_out, double* cls_corr_out) {
+static int sweep_impl(cald_model* m, int n_images, const uint8_t* const* images_dev, const int* H, const int* W,
+                      const int64_t* pool_pos, const cald_sweep_cfg* cfg, double* consistency_out, double* cls_corr_out, float* margins_out) {
     if (!m || !images_dev || !H || !W || !pool_pos || !cfg || !consistency_out || !cls_corr_out) return fail(CALD_ERR_INVALID, "null argument");
+    const bool audit = margins_out != nullptr;
     if (!m->finalized) return fail(CALD_ERR_STATE, "model not finalized");
     cald_ctx* c = m->ctx;
     HIPCHK(hipSetDevice(c->device));
@@ -1437,9 +1540,9 @@ extern "C" int cald_sweep(cald_model* m, int n_images, const uint8_t* const* ima
     // ---- persistent scratch (model-owned): device buffers of the scoring stage, pinned host staging in two sets (batch parity) ----
     cald_model::SweepScratch& S = m->ss;
     const size_t dev_need = al(n_ints * 4) + al((size_t)P_MAX * 12 * 4) + al((size_t)P_MAX * 4) + al((size_t)VT * (C - 1) * 4) + al(sizeof(NoiseJob) * B) +
-                            al(sizeof(unsigned long long) * P_MAX);
+                            al(sizeof(unsigned long long) * P_MAX) + 2 * al((size_t)VT * CALD_VM * 4) + al((size_t)P_MAX * 2 * 4);
     const size_t pin_set = al((size_t)VT * 4) + al((size_t)B * cap * 16) + al(n_ints * 4) + al((size_t)P_MAX * 12 * 4) + al(sizeof(NoiseJob) * B) +
-                           al((size_t)P_MAX * 4) + al((size_t)VT * (C - 1) * 4);
+                           al((size_t)P_MAX * 4) + al((size_t)VT * (C - 1) * 4) + al((size_t)VT * CALD_VM * 4) + al((size_t)P_MAX * 2 * 4);
     if (dev_need > S.dev_bytes || 2 * pin_set > S.pin_bytes) {
         HIPCHK(hipStreamSynchronize(c->stream));
         if (S.dev) { hipFree(S.dev); S.dev = nullptr; S.dev_bytes = 0; }
@@ -1452,21 +1555,25 @@ extern "C" int cald_sweep(cald_model* m, int n_images, const uint8_t* const* ima
         if (!S.ev_score[i]) HIPCHK(hipEventCreateWithFlags(&S.ev_score[i], hipEventDisableTiming));
     }
     int* d_ints; float *d_par, *d_cons, *d_clsc; NoiseJob* d_jobs; unsigned long long* d_lsum;
+    float *d_vm[2], *d_pm;     // decision-margin audit: per-view records of the two detection-buffer sets, per-pair records
     { Bump b(S.dev, false); d_ints = b.get<int>(n_ints); d_par = b.get<float>((size_t)P_MAX * 12); d_cons = b.get<float>(P_MAX);
-      d_clsc = b.get<float>((size_t)VT * (C - 1)); d_jobs = b.get<NoiseJob>(B); d_lsum = b.get<unsigned long long>(P_MAX); }
+      d_clsc = b.get<float>((size_t)VT * (C - 1)); d_jobs = b.get<NoiseJob>(B); d_lsum = b.get<unsigned long long>(P_MAX);
+      d_vm[0] = b.get<float>((size_t)VT * CALD_VM); d_vm[1] = b.get<float>((size_t)VT * CALD_VM); d_pm = b.get<float>((size_t)P_MAX * 2); }
     // Host state of one batch from its reference forward to its float64 means.  Two live at a time: while the host builds the augmented
     // views of batch k (cutout needs the reference boxes on the host) the GPU already runs the reference forward of batch k + 1, and the
     // scores of batch k come back while batch k + 1 is being built -- the stream never waits for the host (round 3 stopped twice per batch).
     struct Batch {
         int i0 = 0, nb = 0, P = 0, VV = 0; bool live = false;
-        int* h_count; float* h_boxes; int* h_ints; float* h_par; NoiseJob* h_jobs; float* h_cons; float* h_clsc;
-        std::vector<int> ref_n, pair_img, view_img;
+        int* h_count; float* h_boxes; int* h_ints; float* h_par; NoiseJob* h_jobs; float* h_cons; float* h_clsc; float* h_vm; float* h_pm;
+        std::vector<int> ref_n, pair_img, view_img, pair_aug;
+        std::vector<float> cut_margin;
     } bt[2];
     for (int q = 0; q < 2; q++) {
         Bump b(S.pin + (size_t)q * pin_set, false);
         bt[q].h_count = b.get<int>(VT); bt[q].h_boxes = b.get<float>((size_t)B * cap * 4); bt[q].h_ints = b.get<int>(n_ints);
         bt[q].h_par = b.get<float>((size_t)P_MAX * 12); bt[q].h_jobs = b.get<NoiseJob>(B); bt[q].h_cons = b.get<float>(P_MAX);
         bt[q].h_clsc = b.get<float>((size_t)VT * (C - 1));
+        bt[q].h_vm = b.get<float>((size_t)VT * CALD_VM); bt[q].h_pm = b.get<float>((size_t)P_MAX * 2);
     }
     int rc = 0;
     const int fwd_views = sweep_fwd_views();
@@ -1481,7 +1588,7 @@ extern "C" int cald_sweep(cald_model* m, int n_images, const uint8_t* const* ima
             views[i].src = images_dev[b.i0 + i]; views[i].H = H[b.i0 + i]; views[i].W = W[b.i0 + i];
         }
         const DetBuffers& D = *DS[k & 1];
-        int r = forward_model(m, b.nb, views.data(), D);
+        int r = forward_model(m, b.nb, views.data(), D, audit ? d_vm[k & 1] : nullptr);
         if (r) return r;
         if (hipMemcpyAsync(b.h_count, D.count, (size_t)b.nb * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
             hipMemcpyAsync(b.h_boxes, D.boxes, (size_t)b.nb * cap * 16, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
@@ -1510,6 +1617,25 @@ extern "C" int cald_sweep(cald_model* m, int n_images, const uint8_t* const* ima
             for (int p : img_pairs[i]) cs.push_back((double)b.h_cons[p]);
             consistency_out[b.i0 + i] = np_sum(cs.data(), (int)cs.size()) / (double)cs.size();
         }
+        if (audit) {
+            // per image: the smallest margin of each decision kind over its views / pairs (include/cald_hip.h CALD_MARGIN_*)
+            for (int i = 0; i < nb; i++) {
+                float* mg = margins_out + (size_t)(b.i0 + i) * CALD_N_MARGINS;
+                for (int q = 0; q < CALD_N_MARGINS; q++) mg[q] = INFINITY;
+                auto take_view = [&](int v) { for (int q = 0; q <= VM_POST_CAP; q++) { const float t = b.h_vm[(size_t)v * CALD_VM + q]; if (t < mg[q]) mg[q] = t; } };
+                take_view(i);
+                for (int v : img_views[i]) take_view(v);
+                mg[CALD_MARGIN_REF_SUBSAMPLE] = b.h_vm[(size_t)i * CALD_VM + VM_POST_SUBORDER];
+                for (int p : img_pairs[i]) {
+                    if (b.h_pm[2 * p] < mg[CALD_MARGIN_ARGMAX]) mg[CALD_MARGIN_ARGMAX] = b.h_pm[2 * p];
+                    if (b.h_pm[2 * p + 1] != 0.0f) {
+                        const float t = b.h_vm[(size_t)b.pair_aug[p] * CALD_VM + VM_POST_TOP2];
+                        if (t < mg[CALD_MARGIN_ZERO_ROW]) mg[CALD_MARGIN_ZERO_ROW] = t;
+                    }
+                }
+                mg[CALD_MARGIN_CUTOUT] = b.cut_margin[i];
+            }
+        }
         b.live = false;
         return 0;
     };
@@ -1521,7 +1647,7 @@ extern "C" int cald_sweep(cald_model* m, int n_images, const uint8_t* const* ima
         if (hipEventSynchronize(S.ev_ref[k & 1]) != hipSuccess) return fail(CALD_ERR_HIP, "reference forward failed: %s", hipGetErrorString(hipGetLastError()));
         const int* h_count = b.h_count; const float* h_boxes = b.h_boxes;
         std::vector<int> ref_sel((size_t)B * 50, 0), pair_ref, pair_aug, pair_kind, view_isref(VT, 0);
-        b.ref_n.assign(B, 0); b.pair_img.clear(); b.view_img.assign(VT, 0);
+        b.ref_n.assign(B, 0); b.pair_img.clear(); b.view_img.assign(VT, 0); b.cut_margin.assign(B, INFINITY);
         std::vector<float> pair_par;
         std::vector<ViewDesc> aviews;
         int njobs = 0;
@@ -1593,7 +1719,9 @@ extern "C" int cald_sweep(cald_model* m, int n_images, const uint8_t* const* ima
                     ViewDesc v = base; v.swap = pyrng.randbelow(6); add_view(v, 0, nullptr);
                 } else if (kd == CALD_AUG_CUTOUT) {
                     ViewDesc v = base;
-                    v.nrect = cutout_rects(pyrng, Hi, Wi, b.ref_n[i], sub, (int)prm, v.rects);
+                    float cm = INFINITY;
+                    v.nrect = cutout_rects(pyrng, Hi, Wi, b.ref_n[i], sub, (int)prm, v.rects, &cm);
+                    if (cm < b.cut_margin[i]) b.cut_margin[i] = cm;
                     add_view(v, 0, nullptr);
                 } else if (kd == CALD_AUG_RESIZE) {
                     const int ow = (int)((double)Wi * prm), oh = (int)((double)Hi * prm);
@@ -1628,11 +1756,11 @@ extern "C" int cald_sweep(cald_model* m, int n_images, const uint8_t* const* ima
             DetBuffers d2 = D; const size_t o = (size_t)(nb + a0);
             d2.boxes += o * cap * 4; d2.scores += o * cap; d2.labels += o * cap; d2.props += o * cap * 4;
             d2.prob_max += o * cap; d2.scores_cls += o * cap * C; d2.count += o;
-            if ((r = forward_model(m, nv, aviews.data() + a0, d2))) return r;
+            if ((r = forward_model(m, nv, aviews.data() + a0, d2, audit ? d_vm[k & 1] + o * CALD_VM : nullptr))) return r;
         }
         // ---- scoring ----
         const int P = (int)pair_ref.size(), VV = nb + na;
-        b.P = P; b.VV = VV;
+        b.P = P; b.VV = VV; b.pair_aug = pair_aug;
         int* ints = b.h_ints;
         memset(ints, 0, n_ints * 4);
         int* p_ref = ints; int* p_aug = p_ref + P_MAX; int* p_kind = p_aug + P_MAX; int* p_img = p_kind + P_MAX;
@@ -1648,6 +1776,11 @@ extern "C" int cald_sweep(cald_model* m, int n_images, const uint8_t* const* ima
         sa.ref_sel = d_ints + 4 * P_MAX; sa.ref_n = sa.ref_sel + (size_t)B * 50; sa.aug_param = d_par; sa.P = P; sa.bp = cfg->bp; sa.cons = d_cons;
         launch_consistency(sa, c->stream);
         launch_cls_corr(D, sa.ref_sel, sa.ref_n, sa.ref_n + B, sa.ref_n + B + VT, VV, d_clsc, c->stream);
+        if (audit) {
+            launch_pair_audit(sa, d_pm, c->stream);
+            if (hipMemcpyAsync(b.h_vm, d_vm[k & 1], (size_t)VV * CALD_VM * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                (P && hipMemcpyAsync(b.h_pm, d_pm, (size_t)P * 2 * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess)) return fail(CALD_ERR_HIP, "D2H of the audit records failed");
+        }
         if ((P && hipMemcpyAsync(b.h_cons, d_cons, (size_t)P * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess) ||
             hipMemcpyAsync(b.h_clsc, d_clsc, (size_t)VV * (C - 1) * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
             hipEventRecord(S.ev_score[k & 1], c->stream) != hipSuccess) return fail(CALD_ERR_HIP, "scoring stage failed: %s", hipGetErrorString(hipGetLastError()));
@@ -1671,6 +1804,16 @@ extern "C" int cald_sweep(cald_model* m, int n_images, const uint8_t* const* ima
     for (int k = (NB >= 2 ? NB - 2 : 0); k < NB && !rc; k++) rc = finish(k);
     if (rc) hipStreamSynchronize(c->stream);
     return rc;
+}
+extern "C" int cald_sweep(cald_model* m, int n_images, const uint8_t* const* images_dev, const int* H, const int* W,
+                          const int64_t* pool_pos, const cald_sweep_cfg* cfg, double* consistency_out, double* cls_corr_out) {
+    return sweep_impl(m, n_images, images_dev, H, W, pool_pos, cfg, consistency_out, cls_corr_out, nullptr);
+}
+extern "C" int cald_sweep_audit(cald_model* m, int n_images, const uint8_t* const* images_dev, const int* H, const int* W,
+                                const int64_t* pool_pos, const cald_sweep_cfg* cfg, double* consistency_out, double* cls_corr_out,
+                                float* margins_out) {
+    if (!margins_out) return fail(CALD_ERR_INVALID, "null argument");
+    return sweep_impl(m, n_images, images_dev, H, W, pool_pos, cfg, consistency_out, cls_corr_out, margins_out);
 }
 
 

@@ -76,8 +76,11 @@ struct PyRandom {
 // the preprocess kernel.  boxes: sub-sampled reference detections, original image coordinates.
 // The generator is the caller's: get_uncertainty draws ColorSwap's randint and every cutout call of one image from the
 // same global Python generator, in call order (cald_train.py:140-166).
-static inline int cutout_rects(PyRandom& rng, int H, int W, int N, const float* boxes, int cut_num, int* rects) {
+// margin (optional): the smallest distance of any trial's largest overlap ratio to the two accept thresholds (0.4, 0.1) -- the only
+// place where the reference boxes decide something discrete here (audit.hip).
+static inline int cutout_rects(PyRandom& rng, int H, int W, int N, const float* boxes, int cut_num, int* rects, float* margin = nullptr) {
     int count = 0;
+    if (margin) *margin = INFINITY;
     for (int t = 0; t < 50; t++) {
         double sh = rng.uniform(0.05 * H, 0.2 * H);
         double sw = rng.uniform(0.05 * W, 0.2 * W);
@@ -95,6 +98,7 @@ static inline int cutout_rects(PyRandom& rng, int H, int W, int N, const float* 
             if (ratio != ratio) any_nan = true;
             if (i == 0 || ratio > rmax) rmax = ratio;
         }
+        if (margin && !any_nan) { const float d = std::fmin(std::fabs(rmax - 0.4f), std::fabs(rmax - 0.1f)); if (d < *margin) *margin = d; }
         if (!any_nan && (rmax > 0.4f || rmax < 0.1f)) continue;
         rects[4 * count] = il; rects[4 * count + 1] = it; rects[4 * count + 2] = ir; rects[4 * count + 3] = ib;
         if (++count >= cut_num) break;

@@ -64,6 +64,9 @@ struct RpnArgs {
     float* proposals;              // [V][prop_stride][4]
     int prop_stride;               // rows per view in `proposals` (>= post_n)
     int* prop_count;               // [V]
+    // decision-margin audit (audit.hip), both null in a plain forward:
+    unsigned long long* next_key = nullptr;  // [V][5][2]: per level the k-th selected key and the best key left out by the top-k (0 = level has <= k anchors)
+    unsigned long long* trunc_key = nullptr; // [V][2]: the post_n-th and (post_n + 1)-th key of the merged post-NMS order (0 = fewer kept)
 };
 void launch_rpn(const RpnArgs& a, hipStream_t st);
 
@@ -118,6 +121,9 @@ struct PostArgs {
     int* key_count;           // [V] scratch counter
     int key_cap;              // power of two >= ROI_CAP * min(C-1, 19)
     DetBuffers det;
+    // decision-margin audit (audit.hip), both null in a plain forward:
+    unsigned long long* kept_key = nullptr;   // [V][det.cap]: candidate key of every detection kept, in output order
+    float* post_maxc = nullptr;               // [V]: largest clipped coordinate over the view's candidates (the class offset's scale)
 };
 void launch_frcnn_postprocess(const PostArgs& a, hipStream_t st);
 
@@ -138,6 +144,33 @@ struct ScoreArgs {
 void launch_consistency(const ScoreArgs& a, hipStream_t st);
 void launch_cls_corr(const DetBuffers& det, const int* ref_sel, const int* ref_n, const int* view_img, const int* view_is_ref,
                      int V, float* out /*[V][C-1]*/, hipStream_t st);
+
+// audit.hip -- decision margins of one Faster R-CNN forward (cascade mode: which images may differ from the exact mode by more than
+// continuous rounding).  Every discrete decision of the forward (top-k cut, NMS IoU test, score threshold, RoI level, sort
+// order where the order matters) leaves its distance to the flip point; a view's record keeps the minimum per kind.
+#define CALD_VM 16
+enum { VM_RPN_TOPK = 0, VM_RPN_IOU, VM_RPN_ORDER, VM_RPN_TRUNC, VM_RPN_SMALL, VM_ROI_LEVEL, VM_ROI_EDGE, VM_POST_THR, VM_POST_IOU,
+       VM_POST_ORDER, VM_POST_CAP, VM_POST_SUBORDER, VM_POST_TOP2 };
+struct AuditArgs {
+    // RPN stage (buffers of launch_rpn)
+    const unsigned long long* cand_key; const float* cand_box; const float* sorted_box; const unsigned char* flags;
+    const unsigned long long* next_key; const unsigned long long* trunc_key;
+    int pre_n, post_n; float rpn_nms_thr, min_size;
+    // RoI stage
+    const float* proposals; const int* prop_count; const LevelSeg* seg[4];
+    // box-head post-processing
+    const float* prob; const float* pred; int pred_ld, C; const ViewDesc* views;
+    const unsigned long long* keys; const int* key_count; int key_cap;
+    const unsigned long long* kept_key; const float* post_maxc; const int* det_count; int cap;
+    float score_thr, post_nms_thr;
+    int V;
+    float delta;      // relevance slack on scores (>> the fast mode's score error): decisions about boxes more than delta below a cut are ignored
+    float* out;       // [V][CALD_VM]
+};
+void launch_audit(const AuditArgs& a, hipStream_t st);
+// per (reference, augmentation) pair: out[2 p] = min over reference boxes of (best IoU - best IoU among detections of ANOTHER proposal),
+// out[2 p + 1] = 1 if some reference box overlaps no detection at all (argmax falls on detection 0), else 0
+void launch_pair_audit(const ScoreArgs& a, float* out, hipStream_t st);
 
 // retina.hip
 struct RetinaArgs {

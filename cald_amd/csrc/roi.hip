@@ -340,8 +340,9 @@ __global__ __launch_bounds__(1024) void post_nms_kernel(PostArgs a) {
         a.det.labels[o] = c;
         a.det.prob_max[o] = a.pmax[(long long)v * CALD_ROI_CAP + r];
         for (int q = 0; q < C; q++) a.det.scores_cls[o * C + q] = pr[q];
+        if (a.kept_key) a.kept_key[o] = key;
     }
-    if (tid == 0) a.det.count[v] = nk;
+    if (tid == 0) { a.det.count[v] = nk; if (a.post_maxc) a.post_maxc[v] = maxc; }
 }
 
 void launch_frcnn_postprocess(const PostArgs& a, hipStream_t st) {

@@ -63,12 +63,24 @@ __global__ __launch_bounds__(1024) void rpn_topk_kernel(RpnArgs a) {
         }
     }
     const unsigned long long thresh = (n > k) ? s_prefix : 0ull;   // lower bound of the k largest keys (keys are unique)
+    unsigned long long below = 0ull;                                // audit only: the best key the cut leaves out
     for (int i = tid; i < n; i += 1024) {
         const unsigned long long key = key_of(i);
         if (key >= thresh) { const int slot = atomicAdd(&s_cnt, 1); if (slot < CAP) sel[slot] = key; }
+        else if (key > below) below = key;
     }
     __syncthreads();
     block_bitonic_sort_desc(sel, CAP);
+    if (a.next_key) {       // decision-margin audit: the k-th key and the (k + 1)-th (0 when the level has no more than k anchors)
+        if (tid == 0) s_prefix = 0ull;
+        __syncthreads();
+        if (below) atomicMax(&s_prefix, below);
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long* nk = a.next_key + ((long long)v * 5 + l) * 2;
+            nk[0] = (n > k && k > 0) ? sel[k - 1] : 0ull; nk[1] = (n > k) ? s_prefix : 0ull;
+        }
+    }
     // decode the t-th best anchor
     for (int t = tid; t < a.pre_n; t += 1024) {
         unsigned long long outkey = 0ull;
@@ -163,7 +175,13 @@ __global__ __launch_bounds__(1024) void rpn_merge_kernel(RpnArgs a, int NP) {
     int nk = s_nk; if (nk > a.post_n) nk = a.post_n;
     float4* pr = reinterpret_cast<float4*>(a.proposals) + (long long)v * a.prop_stride;
     for (int i = tid; i < nk; i += 1024) pr[i] = cb[(int)(0xFFFFFFFFu - (unsigned)(keys[i] & 0xFFFFFFFFull))];
-    if (tid == 0) a.prop_count[v] = nk;
+    if (tid == 0) {
+        a.prop_count[v] = nk;
+        if (a.trunc_key) {   // decision-margin audit: the last key inside the post-NMS cut and the first one outside
+            const bool cut = s_nk > a.post_n;
+            a.trunc_key[2 * v] = cut ? keys[a.post_n - 1] : 0ull; a.trunc_key[2 * v + 1] = cut ? keys[a.post_n] : 0ull;
+        }
+    }
 }
 
 void launch_rpn(const RpnArgs& a, hipStream_t st) {

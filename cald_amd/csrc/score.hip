@@ -43,6 +43,28 @@ __device__ inline bool better(float v1, int j1, float v2, int j2) {
     return v1 > v2 || (v1 == v2 && j1 < j2);
 }
 
+// the reference box as the augmented view sees it (cald_helper.HorizontalFlip :29, resize :53, rotate :160-222)
+__device__ inline float4 aug_box(float4 ab, const int kind, const float* prmv) {
+    const float prm = prmv[0];
+    if (kind == 1) { float x0 = prm - ab.z, x2 = prm - ab.x; ab.x = x0; ab.z = x2; }   // cald_helper.py:29
+    else if (kind == 2) { ab.x = ab.x * prm; ab.y = ab.y * prm; ab.z = ab.z * prm; ab.w = ab.w * prm; }  // :53
+    else if (kind == 3) {   // cald_helper.rotate box transform, cald_helper.py:160-222
+        const float bw = ab.z - ab.x, bh = ab.w - ab.y;
+        const float xs[4] = {ab.x, ab.x + bw, ab.x, ab.z}, ys[4] = {ab.y, ab.y, ab.y + bh, ab.w};
+        float xmin = 0.f, xmax = 0.f, ymin = 0.f, ymax = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float X = (prmv[0] * xs[q] + prmv[1] * ys[q]) + prmv[2] * 1.0f;
+            const float Y = (prmv[3] * xs[q] + prmv[4] * ys[q]) + prmv[5] * 1.0f;
+            if (q == 0 || X < xmin) xmin = X; if (q == 0 || X > xmax) xmax = X;
+            if (q == 0 || Y < ymin) ymin = Y; if (q == 0 || Y > ymax) ymax = Y;
+        }
+        ab.x = det_clamp(xmin / prmv[6], 0.0f, prmv[8]); ab.y = det_clamp(ymin / prmv[7], 0.0f, prmv[9]);
+        ab.z = det_clamp(xmax / prmv[6], 0.0f, prmv[8]); ab.w = det_clamp(ymax / prmv[7], 0.0f, prmv[9]);
+    }
+    return ab;
+}
+
 #define SCORE_LDS_BOXES 2048      /* 32 KB: Faster R-CNN lists (<= 100) fit whole; RetinaNet's (<= classes x 300) go through in chunks */
 __global__ __launch_bounds__(256) void consistency_kernel(ScoreArgs a) {
     __shared__ float wmin[4];
@@ -58,7 +80,6 @@ __global__ __launch_bounds__(256) void consistency_kernel(ScoreArgs a) {
     const float4* aboxes = reinterpret_cast<const float4*>(a.det.boxes) + (long long)av * cap;
     const int kind = a.aug_kind[p];
     const float* prmv = a.aug_param + (long long)p * 12;
-    const float prm = prmv[0];
     float cur = 1.0f;
     // N <= 50 reference boxes over 4 waves: every wave runs the same number of rounds so that the staging barriers line up
     const int rounds = (N + 3) / 4;
@@ -67,23 +88,7 @@ __global__ __launch_bounds__(256) void consistency_kernel(ScoreArgs a) {
         const int i = rd * 4 + wave;
         const bool live = i < N;
         const int ri = live ? a.ref_sel[img * 50 + i] : 0;
-        float4 ab = rboxes[ri];
-        if (kind == 1) { float x0 = prm - ab.z, x2 = prm - ab.x; ab.x = x0; ab.z = x2; }   // cald_helper.py:29
-        else if (kind == 2) { ab.x = ab.x * prm; ab.y = ab.y * prm; ab.z = ab.z * prm; ab.w = ab.w * prm; }  // :53
-        else if (kind == 3) {   // cald_helper.rotate box transform, cald_helper.py:160-222
-            const float bw = ab.z - ab.x, bh = ab.w - ab.y;
-            const float xs[4] = {ab.x, ab.x + bw, ab.x, ab.z}, ys[4] = {ab.y, ab.y, ab.y + bh, ab.w};
-            float xmin = 0.f, xmax = 0.f, ymin = 0.f, ymax = 0.f;
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const float X = (prmv[0] * xs[q] + prmv[1] * ys[q]) + prmv[2] * 1.0f;
-                const float Y = (prmv[3] * xs[q] + prmv[4] * ys[q]) + prmv[5] * 1.0f;
-                if (q == 0 || X < xmin) xmin = X; if (q == 0 || X > xmax) xmax = X;
-                if (q == 0 || Y < ymin) ymin = Y; if (q == 0 || Y > ymax) ymax = Y;
-            }
-            ab.x = det_clamp(xmin / prmv[6], 0.0f, prmv[8]); ab.y = det_clamp(ymin / prmv[7], 0.0f, prmv[9]);
-            ab.z = det_clamp(xmax / prmv[6], 0.0f, prmv[8]); ab.w = det_clamp(ymax / prmv[7], 0.0f, prmv[9]);
-        }
+        const float4 ab = aug_box(rboxes[ri], kind, prmv);
         float best = -INFINITY; int bj = 0x7fffffff;
         for (int ch = 0; ch < nchunk; ch++) {
             const int j0 = ch * SCORE_LDS_BOXES, nj = (M - j0 < SCORE_LDS_BOXES) ? M - j0 : SCORE_LDS_BOXES;
@@ -139,6 +144,59 @@ __global__ __launch_bounds__(256) void consistency_kernel(ScoreArgs a) {
 void launch_consistency(const ScoreArgs& a, hipStream_t st) {
     if (a.P <= 0) return;
     hipLaunchKernelGGL(consistency_kernel, dim3(a.P), dim3(256), 0, st, a);
+}
+
+// Decision-margin audit of the scoring loop (audit.hip explains the idea): the only discrete step is q = scores_cls[argmax(iou)].
+// Per pair: the smallest (best IoU - best IoU among detections that stem from ANOTHER proposal) over the reference boxes -- two
+// detections of one proposal carry the same scores_cls / prob_max row (frcnn_la.py:55-56, :64-65), so a flip between them changes
+// nothing but the IoU itself, continuously -- and whether some row is all zero (argmax = 0: the FIRST detection is taken, whichever
+// that is).  One workgroup per pair, one wavefront per reference box.
+__global__ __launch_bounds__(256) void pair_audit_kernel(ScoreArgs a, float* out) {
+    __shared__ float wgap[4];
+    __shared__ int wzero[4];
+    const int p = blockIdx.x;
+    const int rv = a.ref_view[p], av = a.aug_view[p], img = a.pair_img[p];
+    const int N = a.ref_n[img], M = a.det.count[av];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, cap = a.det.cap;
+    if (M == 0) { if (threadIdx.x == 0) { out[2 * p] = INFINITY; out[2 * p + 1] = 0.0f; } return; }
+    const float4* rboxes = reinterpret_cast<const float4*>(a.det.boxes) + (long long)rv * cap;
+    const float4* aboxes = reinterpret_cast<const float4*>(a.det.boxes) + (long long)av * cap;
+    const float4* aprops = reinterpret_cast<const float4*>(a.det.props) + (long long)av * cap;
+    const int kind = a.aug_kind[p];
+    const float* prmv = a.aug_param + (long long)p * 12;
+    float gap = INFINITY; int zero = 0;
+    for (int i = wave; i < N; i += 4) {
+        const float4 ab = aug_box(rboxes[a.ref_sel[img * 50 + i]], kind, prmv);
+        float best = -INFINITY; int bj = 0x7fffffff;
+        for (int j = lane; j < M; j += 64) { const float v = cald_iou(ab, aboxes[j]); if (better(v, j, best, bj)) { best = v; bj = j; } }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float ov = __shfl_xor(best, off, 64); const int oj = __shfl_xor(bj, off, 64);
+            if (better(ov, oj, best, bj)) { best = ov; bj = oj; }
+        }
+        if (!(best > 0.0f)) { zero = 1; continue; }        // all-zero (or NaN) row
+        const float4 pb = aprops[bj];
+        float second = 0.0f;
+        for (int j = lane; j < M; j += 64) {
+            const float4 pj = aprops[j];
+            if (pj.x == pb.x && pj.y == pb.y && pj.z == pb.z && pj.w == pb.w) continue;
+            const float v = cald_iou(ab, aboxes[j]);
+            if (v > second) second = v;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) second = fmaxf(second, __shfl_xor(second, off, 64));
+        gap = fminf(gap, best - second);
+    }
+    if (lane == 0) { wgap[wave] = gap; wzero[wave] = zero; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[2 * p] = fminf(fminf(wgap[0], wgap[1]), fminf(wgap[2], wgap[3]));
+        out[2 * p + 1] = (wzero[0] | wzero[1] | wzero[2] | wzero[3]) ? 1.0f : 0.0f;
+    }
+}
+void launch_pair_audit(const ScoreArgs& a, float* out, hipStream_t st) {
+    if (a.P <= 0) return;
+    hipLaunchKernelGGL(pair_audit_kernel, dim3(a.P), dim3(256), 0, st, a, out);
 }
 
 // cls_corr[l-1] = max(cls_corr[l-1], score) with python negative indexing for label 0 (RetinaNet).

@@ -78,8 +78,9 @@ def _to_u8_cuda(image, device):
     return t.contiguous().to(device, non_blocking=True)
 
 
-def sweep_device_images(task_model, images, positions, augs, bp=1.3, base_seed=0, batch_images=64):
-    """Scores uint8 HWC CUDA tensors already resident in HBM.  Returns (consistency [n] f64, cls_corr [n][C-1] f64)."""
+def sweep_device_images(task_model, images, positions, augs, bp=1.3, base_seed=0, batch_images=64, margins=False):
+    """Scores uint8 HWC CUDA tensors already resident in HBM.  Returns (consistency [n] f64, cls_corr [n][C-1] f64); with
+    margins=True also the decision-margin records [n][N_MARGINS] float32 of cald_sweep_audit (include/cald_hip.h)."""
     for aug in augs:
         if aug not in KNOWN_AUGS:
             print('{} is not in the pre-set augmentations!'.format(aug))   # cald_train.py:92-95
@@ -88,13 +89,18 @@ def sweep_device_images(task_model, images, positions, augs, bp=1.3, base_seed=0
     Cn = task_model.num_classes
     cons = np.zeros(n, np.float64)
     cls = np.zeros((n, Cn - 1), np.float64)
+    mg = np.full((n, _ffi.N_MARGINS), np.inf, np.float32) if margins else None
     if n == 0:
-        return cons, cls
+        return (cons, cls, mg) if margins else (cons, cls)
     ptrs = (C.c_void_p * n)(*[im.data_ptr() for im in images])
     Hs = np.array([im.shape[0] for im in images], np.int32)
     Ws = np.array([im.shape[1] for im in images], np.int32)
     pos = np.ascontiguousarray(positions, dtype=np.int64)
     cfg = make_sweep_cfg(augs, bp, base_seed, batch_images)
+    if margins:
+        _ffi.check(L.cald_sweep_audit(task_model.handle(), n, ptrs, _ffi.ptr(Hs, _ffi.c_i), _ffi.ptr(Ws, _ffi.c_i), _ffi.ptr(pos, _ffi.c_i64),
+                                      C.byref(cfg), _ffi.ptr(cons, _ffi.c_d), _ffi.ptr(cls, _ffi.c_d), _ffi.ptr(mg, _ffi.c_f)))
+        return cons, cls, mg
     _ffi.check(L.cald_sweep(task_model.handle(), n, ptrs, _ffi.ptr(Hs, _ffi.c_i), _ffi.ptr(Ws, _ffi.c_i),
                             _ffi.ptr(pos, _ffi.c_i64), C.byref(cfg), _ffi.ptr(cons, _ffi.c_d), _ffi.ptr(cls, _ffi.c_d)))
     return cons, cls

@@ -80,7 +80,13 @@ def pseudo_trained_frcnn(num_classes=21, depth=50, seed=0, cls_gain=1.0, rpn_gai
             p = "backbone.body.layer%d.%d" % (li + 1, bi)
             sd[p + ".conv1.weight"] = _he(rs, (planes, inplanes, 1, 1)); _bn(rs, sd, p + ".bn1", planes)
             sd[p + ".conv2.weight"] = _he(rs, (planes, planes, 3, 3)); _bn(rs, sd, p + ".bn2", planes)
-            sd[p + ".conv3.weight"] = _he(rs, (planes * 4, planes, 1, 1)); _bn(rs, sd, p + ".bn3", planes * 4, gamma=0.5)
+            # A frozen BN with a synthetic running_var does not normalise: each residual branch adds variance PROPORTIONAL to its input's,
+            # so the activation scale grows geometrically with the number of blocks of a stage.  gamma 0.5 keeps ResNet-50 at the O(10)
+            # scale of a trained network; ResNet-101's 23-block stage would reach |x| ~ 600 and RPN logits of +-800 (round 4's
+            # generator did), which no trained detector has -- the branch gain is therefore scaled so that a stage's total growth is
+            # ResNet-50's whatever its depth (gamma^2 x blocks constant).  ResNet-50 weights are unchanged.
+            g3 = 0.5 * float(np.sqrt(RESNET_LAYERS[50][li] / float(nb)))
+            sd[p + ".conv3.weight"] = _he(rs, (planes * 4, planes, 1, 1)); _bn(rs, sd, p + ".bn3", planes * 4, gamma=g3)
             if bi == 0:
                 sd[p + ".downsample.0.weight"] = _he(rs, (planes * 4, inplanes, 1, 1), gain=1.0)
                 _bn(rs, sd, p + ".downsample.1", planes * 4)

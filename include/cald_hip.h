@@ -136,6 +136,34 @@ typedef struct cald_sweep_cfg {
 int cald_sweep(cald_model* m, int n_images, const uint8_t* const* images_dev, const int* H, const int* W,
                const int64_t* pool_pos, const cald_sweep_cfg* cfg, double* consistency_out, double* cls_corr_out);
 
+/* ---- cascade support: cald_sweep plus a record of how close every discrete decision of the path came to flipping ----
+ * get_uncertainty's result is a continuous function of the detector's GEMM outputs except at its discrete decisions (RPN top-k /
+ * NMS / post-NMS cut, RoI level, score threshold, class NMS, top-100, argmax over the IoU row, the linspace sub-sample, cutout's
+ * accept test; cald_train.py:110-113, :158-166, :214, detection/frcnn_la.py:72-80, detection/frcnn_ll.py:284-321).  margins_out
+ * [n_images][CALD_N_MARGINS] receives, per image and per kind of decision, the smallest distance of any decision THAT CAN REACH THE
+ * OUTPUT to its flip point, over all views of the image (+inf where the kind did not occur).  An image whose margins all exceed the
+ * rounding noise of a faster precision took the same decisions there as in CALD_PRECISION_FP32, and its scores differ by rounding
+ * only; the others are re-scored exactly (cald_amd/sweep.py get_uncertainty_cascade, cald_cascade_plan).  Faster R-CNN only. */
+#define CALD_N_MARGINS 16
+#define CALD_MARGIN_RPN_TOPK 0       /* logit: k-th vs (k+1)-th objectness of a level's top-k cut */
+#define CALD_MARGIN_RPN_IOU 1        /* IoU:   |max IoU with the kept boxes before it - rpn_nms_thresh| */
+#define CALD_MARGIN_RPN_ORDER 2      /* logit: score gap of a (suppressor, suppressed) pair */
+#define CALD_MARGIN_RPN_TRUNC 3      /* logit: post_nms_top_n-th vs next kept proposal */
+#define CALD_MARGIN_RPN_SMALL 4      /* pixel: |w or h - 1e-3| of a clipped candidate */
+#define CALD_MARGIN_ROI_LEVEL 5      /* log2:  distance of 4 + log2(sqrt(area) / 224) + 1e-6 to 3, 4 or 5 */
+#define CALD_MARGIN_ROI_EDGE 6       /* feature pixel: distance of a RoIAlign sample to -1 or to the map size */
+#define CALD_MARGIN_POST_THR 7       /* prob:  |class score - box_score_thresh| of a box NMS would keep */
+#define CALD_MARGIN_POST_IOU 8       /* IoU:   |max IoU with kept same-class detections before it - box_nms_thresh| */
+#define CALD_MARGIN_POST_ORDER 9     /* prob:  score gap of a (suppressor, suppressed) pair */
+#define CALD_MARGIN_POST_CAP 10      /* prob:  detections_per_img-th detection vs the best candidate behind it */
+#define CALD_MARGIN_REF_SUBSAMPLE 11 /* prob:  score gap of neighbours of which np.round(np.linspace(0, n - 1, 50)) picks one (n > 40) */
+#define CALD_MARGIN_ARGMAX 12        /* IoU:   best vs best-of-another-proposal in a reference box's IoU row */
+#define CALD_MARGIN_ZERO_ROW 13      /* prob:  score gap of an augmented view's first two detections when a row is all zero */
+#define CALD_MARGIN_CUTOUT 14        /* ratio: |largest overlap ratio - 0.4 or 0.1| of a cutout trial */
+int cald_sweep_audit(cald_model* m, int n_images, const uint8_t* const* images_dev, const int* H, const int* W,
+                     const int64_t* pool_pos, const cald_sweep_cfg* cfg, double* consistency_out, double* cls_corr_out,
+                     float* margins_out);
+
 /* ---- the baseline sweeps of the same repo that share the detector forward ---- */
 /* lt_c_train.py:105-121 get_uncertainty(task_model, unlabeled_loader) -> one float per image */
 int cald_sweep_ltc(cald_model* m, int n_images, const uint8_t* const* images_dev, const int* H, const int* W,
@@ -164,6 +192,16 @@ int cald_op_cutout_rects(uint64_t seed, int H, int W, int N, const float* boxes,
  *   CALD_AUG_ROTATE       rotate :135-223         dst_dev = uint8 [H][W][3], boxes_out[n_boxes][4] (host) */
 int cald_op_augment(cald_ctx* ctx, int kind, double param, uint64_t seed, const uint8_t* src_dev, int H, int W,
                     int n_boxes, const float* boxes, void* dst_dev, float* boxes_out, int* aux_out);
+/* RoIHeads.postprocess_detections + GeneralizedRCNNTransform.postprocess of one view (detection/frcnn_la.py:32-87, :292-315) on the
+ * forward's own kernels: logits [R][C], deltas [R][4C] (class-major), proposals [R][4] in resized-image coordinates (host); outputs
+ * (host, det_max rows each; scores_cls [det_max][C]) and the number of detections.  R <= 1000. */
+int cald_op_frcnn_postprocess(cald_ctx* ctx, int R, int C, const float* logits, const float* deltas, const float* proposals,
+                              int Hr, int Wr, int Ho, int Wo, float score_thr, float nms_thr, int det_max,
+                              float* boxes_out, float* scores_out, int64_t* labels_out, float* props_out, float* prob_max_out,
+                              float* scores_cls_out, int* n_out);
+/* MultiScaleRoIAlign(output 7, sampling_ratio 2, aligned=False; detection/frcnn_la.py:205-209) of one view on the forward's own
+ * kernels: feats[l] = [H_l][W_l][C] (host) for P2..P5, level_hw = {H0, W0, ..., H3, W3}, rois [R][4]; out [R][49][C] (host) */
+int cald_op_roi_align(cald_ctx* ctx, const float* const* feats, const int* level_hw, int C, int R, const float* rois, float* out);
 /* NHWC convolution on the MFMA kernel; weights in torch layout [Cout][Cin][KH][KW] (host) */
 int cald_op_conv2d(cald_ctx* ctx, const float* in, int H, int W, int Cin, const float* weight, int Cout, int KH, int KW,
                    int stride, int pad, const float* bias, const float* bn_scale, const float* bn_shift,

@@ -10,7 +10,7 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FAST = ["--no-cpu-baseline", "--no-full-pool", "--no-f16x3", "--no-train"]
+FAST = ["--no-cpu-baseline", "--no-full-pool", "--no-f16x3", "--no-train", "--no-cfg4"]
 
 
 def _run(argv, env=None, timeout=900):
@@ -56,8 +56,10 @@ def test_bench_two_ranks_self_launched_equals_one_rank():
     import torch
     if torch.cuda.device_count() >= 2:
         assert r["backend"] == "nccl" and r["distinct_devices"] == 2 and not r["shared_gpu"]
+        # with a GPU per rank the score rows travel through the C ABI's own collective (cald_allgather_scores), not torch.distributed
+        assert r["cabi"]["world_size"] == 2 and "cald_allgather_scores" in r["collective"]
     else:
-        assert r["backend"] == "gloo" and r["shared_gpu"]
+        assert r["backend"] == "gloo" and r["shared_gpu"] and r["cabi"] is None
     assert abs(two["ms_per_step"] * two["steps"] - 128 / two["value"] * 1e3) < 1e-3 * two["ms_per_step"] * two["steps"] + 1e-6
 
 

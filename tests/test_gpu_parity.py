@@ -1181,7 +1181,7 @@ _COMM2_SCRIPT = r"""
 import os, sys, json
 import numpy as np, torch
 sys.path.insert(0, %r)
-rank, world = int(sys.argv[1]), 2
+rank, world = int(sys.argv[1]), int(sys.argv[3])
 torch.cuda.set_device(rank)
 from cald_amd.comm import RcclComm
 from cald_amd import sweep
@@ -1207,17 +1207,20 @@ comm.close()
 """
 
 
-def test_c_abi_rccl_allgather_across_two_devices(hip, tmp_path):
-    """Two processes, one GPU each, communicator bootstrapped through a file (no torch.distributed anywhere): the all-gather over
-    RCCL / xGMI returns every pool position's row on both ranks.  Needs two visible devices (skipped on the 1-GPU boxes)."""
+@pytest.mark.parametrize("world", [2, 8])
+def test_c_abi_rccl_allgather_across_devices(hip, tmp_path, world):
+    """`world` processes, one GPU each, communicator bootstrapped through a file (no torch.distributed anywhere): the all-gather over
+    RCCL / xGMI returns every pool position's row on every rank.  Runs wherever `world` devices are visible (skipped on the 1-GPU
+    boxes: RCCL refuses two ranks on one device, tools/nccl_same_gpu_probe.py)."""
     torch = hip["torch"]
-    if torch.cuda.device_count() < 2:
-        pytest.skip("one visible GPU: RCCL refuses two ranks on one device (tools/nccl_same_gpu_probe.py)")
+    if torch.cuda.device_count() < world:
+        pytest.skip("%d visible GPU(s), %d needed" % (torch.cuda.device_count(), world))
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     idf = str(tmp_path / "rccl_id")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    ps = [subprocess.Popen([sys.executable, "-c", _COMM2_SCRIPT % root, str(r), idf], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    ps = [subprocess.Popen([sys.executable, "-c", _COMM2_SCRIPT % root, str(r), idf, str(world)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+          for r in range(world)]
     for p in ps:
         out, err = p.communicate(timeout=600)
         assert p.returncode == 0, err[-2000:]
@@ -1306,3 +1309,153 @@ def test_sweep_error_in_a_later_batch_leaves_the_model_usable(hip, small_model):
                                C.byref(cfg), ffi.ptr(cons, ffi.c_d), ffi.ptr(cls, ffi.c_d)))
     again, ak = sweep.sweep_device_images(model, dev, pos, augs, base_seed=5, batch_images=4)
     np.testing.assert_array_equal(again, good); np.testing.assert_array_equal(ak, gk)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# torchvision 0.8.2 primitives: the HIP kernels of the forward against known answers derived in float64 by
+# oracle/make_known_answers.py (independent of the oracle's code; the oracle is checked against the same file on the CPU).
+# ---------------------------------------------------------------------------------------------------------------------------
+def _ramp_feats(level_hw, C):
+    c = np.arange(C)
+    a, b, g = (c % 7 - 3) / 8.0, (c % 5 - 2) / 4.0, c / 16.0
+    feats = []
+    for l, (H, W) in enumerate(level_hw):
+        yy, xx = np.mgrid[0:H, 0:W]
+        feats.append(np.ascontiguousarray((a[None, None, :] * xx[:, :, None] + b[None, None, :] * yy[:, :, None] + g[None, None, :] + 10.0 * l).astype(np.float32)))
+    return feats
+
+
+def _gpu_roi_align(hip, feats, rois):
+    import ctypes as C
+    ffi, L = hip["ffi"], hip["L"]
+    rois = np.ascontiguousarray(rois, np.float32)
+    Cc, R = feats[0].shape[2], len(rois)
+    fp = (ffi.c_f * 4)(*[ffi.ptr(f) for f in feats])
+    hw = np.array([v for f in feats for v in f.shape[:2]], np.int32)
+    out = np.empty((R, 49, Cc), np.float32)
+    ffi.check(L.cald_op_roi_align(hip["ctx"], fp, ffi.ptr(hw, ffi.c_i), Cc, R, ffi.ptr(rois), ffi.ptr(out)))
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C", [8, 256])
+def test_tv_known_answers_roi_align_on_affine_ramps(hip, golden, C):
+    """roi.hip (C = 256: the row-walk kernel of the forward; C = 8: the gather kernel) on affine ramps, every border case."""
+    g = golden("tv_known_answers")
+    level_hw = [tuple(int(v) for v in hw) for hw in g["roi_level_hw"]]
+    got = _gpu_roi_align(hip, _ramp_feats(level_hw, C), g["roi_rois"])
+    np.testing.assert_allclose(got, g["roi_expected_c%d" % C], rtol=0, atol=2e-3)
+
+
+@pytest.mark.gpu
+def test_tv_known_answers_level_mapper_edges(hip, golden):
+    """roi_level() inside the RoIAlign kernels: level l holds the constant l + 1, the pooled value names the level taken."""
+    g = golden("tv_known_answers")
+    feats = [np.full((1024 >> (2 + l), 1024 >> (2 + l), 4), float(l + 1), np.float32) for l in range(4)]
+    got = _gpu_roi_align(hip, feats, g["level_rois"])
+    # boxes start at (0, 0): every sample of the first bin lies inside the map on every level
+    assert [int(round(float(v))) - 1 for v in got[:, 0, 0]] == [int(v) for v in g["level_expected"]]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["nms_a", "nms_b", "decode"])
+def test_tv_known_answers_nms_and_box_decode(hip, golden, case):
+    """post_softmax_kernel / post_nms_kernel (the forward's own) on the threshold / tie / class / chain cases, the float32 class
+    offset near 2e4, and the log(1000 / 16) clamp of BoxCoder.decode."""
+    import ctypes as C
+    ffi, L = hip["ffi"], hip["L"]
+    g = golden("tv_known_answers")
+    Hr, Wr = [int(v) for v in g[case + "_hw"]]
+    logits, deltas, props = [np.ascontiguousarray(g[case + k], np.float32) for k in ("_logits", "_deltas", "_props")]
+    R, Cn = logits.shape
+    ob = np.empty((100, 4), np.float32); osc = np.empty(100, np.float32); ol = np.empty(100, np.int64); op = np.empty((100, 4), np.float32)
+    opm = np.empty(100, np.float32); ocl = np.empty((100, Cn), np.float32); n = C.c_int(0)
+    ffi.check(L.cald_op_frcnn_postprocess(hip["ctx"], R, Cn, ffi.ptr(logits), ffi.ptr(deltas), ffi.ptr(props), Hr, Wr, Hr, Wr, 0.05, 0.5, 100,
+                                          ffi.ptr(ob), ffi.ptr(osc), ffi.ptr(ol, ffi.c_i64), ffi.ptr(op), ffi.ptr(opm), ffi.ptr(ocl), C.byref(n)))
+    k = n.value
+    assert k == len(g[case + "_boxes"])
+    np.testing.assert_array_equal(ol[:k], g[case + "_labels"])
+    np.testing.assert_allclose(ob[:k], g[case + "_boxes"], rtol=0, atol=2e-3)
+    np.testing.assert_allclose(osc[:k], g[case + "_scores"], rtol=0, atol=1e-6)
+    np.testing.assert_array_equal(op[:k], props[g[case + "_src"]])
+
+
+@pytest.mark.gpu
+def test_tv_known_answers_base_anchor_table(hip, golden):
+    """cald_train_anchors (the AnchorGenerator of both detectors): the anchors of pixel (0, 0) of each level are the base anchors."""
+    torch = hip["torch"]
+    from cald_amd import train_ops
+    g = golden("tv_known_answers")
+    level_hw = [(64, 80), (32, 40), (16, 20), (8, 10), (4, 5)]
+    a = train_ops.anchors(256, 320, level_hw, torch.device("cuda", 0), kind=0).cpu().numpy()
+    off, got = 0, []
+    for (h, w) in level_hw:
+        got.append(a[off:off + 3]); off += h * w * 3
+    np.testing.assert_array_equal(np.stack(got), g["base_anchors"].astype(np.float32))
+
+
+@pytest.mark.gpu
+def test_frcnn_postprocess_kernels_match_the_reference_method_body(hip, oracle, golden):
+    """A19 on the GPU: post_softmax_kernel / post_nms_kernel against the outputs of the reference's OWN postprocess_detections
+    (frcnn_la.py:32-87 executed under the stub harness, tests/golden/postprocess.npz) -- count, labels, order and props exactly,
+    floats to 1e-5 / 1e-3 -- and bit for bit against the oracle."""
+    import ctypes as C
+    ffi, L = hip["ffi"], hip["L"]
+    g = golden("postprocess")
+    assert int(g["f_n"]) >= 1
+    for k in range(int(g["f_n"])):
+        H, W = [int(v) for v in g["f%d_hw" % k]]
+        logits, deltas, props = [np.ascontiguousarray(g["f%d_%s" % (k, n)], np.float32) for n in ("logits", "deltas", "props")]
+        R, Cn = logits.shape
+        ob = np.empty((100, 4), np.float32); osc = np.empty(100, np.float32); ol = np.empty(100, np.int64); op = np.empty((100, 4), np.float32)
+        opm = np.empty(100, np.float32); ocl = np.empty((100, Cn), np.float32); n = C.c_int(0)
+        ffi.check(L.cald_op_frcnn_postprocess(hip["ctx"], R, Cn, ffi.ptr(logits), ffi.ptr(deltas), ffi.ptr(props.reshape(-1, 4)), H, W, H, W, 0.05, 0.5, 100,
+                                              ffi.ptr(ob), ffi.ptr(osc), ffi.ptr(ol, ffi.c_i64), ffi.ptr(op), ffi.ptr(opm), ffi.ptr(ocl), C.byref(n)))
+        m = n.value
+        want = {q: g["f%d_out_%s" % (k, q)] for q in ("boxes", "scores", "labels", "props", "prob_max", "scores_cls")}
+        assert m == len(want["labels"]), (k, m, len(want["labels"]))
+        np.testing.assert_array_equal(ol[:m], want["labels"])
+        np.testing.assert_array_equal(op[:m], want["props"].reshape(-1, 4))
+        np.testing.assert_allclose(osc[:m], want["scores"], rtol=0, atol=1e-5)
+        np.testing.assert_allclose(opm[:m], want["prob_max"], rtol=0, atol=1e-5)
+        np.testing.assert_allclose(ocl[:m], want["scores_cls"].reshape(m, Cn), rtol=0, atol=1e-5)
+        np.testing.assert_allclose(ob[:m], want["boxes"].reshape(-1, 4), rtol=0, atol=1e-3)
+        orc = oracle.frcnn_postprocess(logits, deltas, props, H, W, H, W)
+        assert ob[:m].tobytes() == orc["boxes"].tobytes() and osc[:m].tobytes() == orc["scores"].tobytes() and ocl[:m].tobytes() == orc["scores_cls"].tobytes()
+
+
+@pytest.mark.gpu
+def test_sweep_audit_records_the_decisions_that_flip_between_precisions(hip):
+    """cald_sweep_audit (audit.hip): (i) the audit reads, it never changes a score; (ii) in the EXACT mode an image's margins are those
+    of the decisions the oracle-checked kernels took -- finite where the decision kind occurs, non-negative; (iii) every image whose
+    f16x3 score differs from the exact one by more than 1e-5 has a decision within 4 x the calibrated f16x3 rounding noise of its flip
+    point (nothing flips without the audit seeing a near-tie), and the margins of the two modes agree where nothing flipped.
+    The margins are NOT selective enough to drive a selection-exact cascade on this workload -- DESIGN.md section 6b has the numbers."""
+    torch, ffi = hip["torch"], hip["ffi"]
+    from cald_amd import synth, sweep
+    n, augs = 192, ["flip", "cut_out", "smaller_resize"]
+    sd = synth.pseudo_trained_frcnn(21, 50, seed=0)
+    dev = [torch.from_numpy(im).cuda() for im in synth.make_pool(n, "voc", 0)]
+    pos = list(range(n))
+    res = {}
+    for prec in ("fp32", "f16x3"):
+        m = hip["det"].fasterrcnn_resnet50_fpn_feature(num_classes=21, min_size=600, max_size=1000, precision=prec).to("cuda")
+        m.load_state_dict(sd); m.eval()
+        plain = sweep.sweep_device_images(m, dev, pos, augs, bp=1.3, base_seed=0, batch_images=96)
+        c, k, mg = sweep.sweep_device_images(m, dev, pos, augs, bp=1.3, base_seed=0, batch_images=64, margins=True)
+        np.testing.assert_array_equal(plain[0], c); np.testing.assert_array_equal(plain[1], k)        # (i), and batch-size invariant
+        assert mg.shape == (n, ffi.N_MARGINS) and not np.isnan(mg).any() and (mg >= 0).all()
+        res[prec] = (c, mg)
+        del m
+        torch.cuda.empty_cache()
+    (ce, me), (ch, mh) = res["fp32"], res["f16x3"]
+    for q in (0, 1, 2, 3, 5, 8, 12, 14):                             # kinds every image of this workload exercises
+        assert np.isfinite(me[:, q]).all(), ffi.MARGIN_NAMES[q]
+    noise = np.array(ffi.MARGIN_NOISE_F16X3, np.float32)
+    changed = np.abs(ce - ch) > 1e-5
+    near = (mh[:, :15] < 4.0 * noise[None, :15]).any(axis=1)
+    print("audit: %d of %d images changed beyond 1e-5; %d have a decision within 4 x noise" % (int(changed.sum()), n, int(near.sum())))
+    assert near[changed].all(), np.where(changed & ~near)[0]
+    same = ~changed
+    d = np.abs(me[same][:, [1, 5, 8, 12]] - mh[same][:, [1, 5, 8, 12]])      # IoU / level margins: smooth functions of the boxes
+    assert float(np.median(d[np.isfinite(d)])) < 1e-5

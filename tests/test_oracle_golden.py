@@ -229,3 +229,60 @@ def test_resize_boxes_matches_the_reference_function(oracle, golden):
         assert (Hr, Wr) != (Ho, Wo)
         np.testing.assert_array_equal(oracle.resize_boxes(g["r%d_boxes" % k], Hr, Wr, Ho, Wo), g["r%d_out_boxes" % k])
         np.testing.assert_array_equal(oracle.resize_boxes(g["r%d_props" % k], Hr, Wr, Ho, Wo), g["r%d_out_props" % k])
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# torchvision 0.8.2 primitives whose source is not in /root/reference: known answers derived in float64 by
+# oracle/make_known_answers.py (which calls none of the oracle's code) -- the oracle is checked here, the HIP kernels in
+# tests/test_gpu_parity.py::test_tv_known_answers_*.
+# ---------------------------------------------------------------------------------------------------------------------------
+def _ramp_feats(level_hw, C):
+    c = np.arange(C)
+    a, b, g = (c % 7 - 3) / 8.0, (c % 5 - 2) / 4.0, c / 16.0
+    feats = []
+    for l, (H, W) in enumerate(level_hw):
+        yy, xx = np.mgrid[0:H, 0:W]
+        feats.append((a[None, None, :] * xx[:, :, None] + b[None, None, :] * yy[:, :, None] + g[None, None, :] + 10.0 * l).astype(np.float32))
+    return feats
+
+
+@pytest.mark.parametrize("C", [8, 256])
+def test_tv_known_answers_roi_align_on_affine_ramps(oracle, golden, C):
+    """MultiScaleRoIAlign (frcnn_la.py:205-209) on affine feature ramps: bilinear sampling is exact there, so every bin is the ramp at
+    the bin's (clamped) sample points -- boxes inside, hanging off each edge, narrower than a pixel, empty, in the far corner."""
+    g = golden("tv_known_answers")
+    level_hw = [tuple(int(v) for v in hw) for hw in g["roi_level_hw"]]
+    got = oracle.roi_align(_ramp_feats(level_hw, C), g["roi_rois"])
+    np.testing.assert_allclose(got, g["roi_expected_c%d" % C], rtol=0, atol=2e-3)
+
+
+def test_tv_known_answers_level_mapper_edges(oracle, golden):
+    """LevelMapper at 112 * 2^j +- float32 steps and at both clamps (the + 1e-6 keeps a side one step below a boundary on the upper level)."""
+    import ctypes as C
+    g = golden("tv_known_answers")
+    f = oracle.lib().orc_roi_level
+    f.restype = C.c_int
+    got = [f(np.ascontiguousarray(b, np.float32).ctypes.data_as(C.POINTER(C.c_float))) for b in g["level_rois"]]
+    assert got == [int(v) for v in g["level_expected"]]
+
+
+@pytest.mark.parametrize("case", ["nms_a", "nms_b", "decode"])
+def test_tv_known_answers_nms_and_box_decode(oracle, golden, case):
+    """nms / batched_nms / BoxCoder.decode through postprocess_detections (frcnn_la.py:32-87): IoU exactly at the threshold is kept and
+    a hair above is dropped, equal scores keep the lower index, classes do not suppress each other, a suppressed box suppresses
+    nothing; coordinates near 2e4 with label 90 (the float32 class offset decides); dw clamped at log(1000 / 16)."""
+    g = golden("tv_known_answers")
+    Hr, Wr = [int(v) for v in g[case + "_hw"]]
+    got = oracle.frcnn_postprocess(g[case + "_logits"], g[case + "_deltas"], g[case + "_props"], Hr, Wr, Hr, Wr)
+    assert len(got["boxes"]) == len(g[case + "_boxes"])
+    np.testing.assert_array_equal(got["labels"], g[case + "_labels"])
+    np.testing.assert_allclose(got["boxes"], g[case + "_boxes"], rtol=0, atol=2e-3)
+    np.testing.assert_allclose(got["scores"], g[case + "_scores"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(got["props"], g[case + "_props"][g[case + "_src"]], rtol=0, atol=0)
+
+
+def test_tv_known_answers_base_anchor_table(oracle, golden):
+    """AnchorGenerator base anchors for sizes 32..512 x ratios (0.5, 1, 2): the published table ([-23, -11, 23, 11], ...)."""
+    g = golden("tv_known_answers")
+    got = np.stack([oracle.base_anchors([s], [0.5, 1.0, 2.0]) for s in (32, 64, 128, 256, 512)])
+    np.testing.assert_array_equal(got, g["base_anchors"].astype(np.float32))

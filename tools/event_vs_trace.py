@@ -3,7 +3,7 @@
 against rocprofv3's kernel-trace duration of the very same launches.
 
     rocprofv3 --kernel-trace --output-format csv -d DIR -- env CALD_PROFILE_DUMP=launches.csv python bench.py --steps 2 \
-        --warmup 1 --no-cpu-baseline --no-full-pool --no-f16x3 --no-train
+        --warmup 1 --no-cpu-baseline --no-full-pool --no-f16x3 --no-train --no-cfg4
     python tools/event_vs_trace.py launches.csv DIR out.json        (tools/profile_event_vs_trace.sh runs both on the GPU box)
 
 The timed region is the last thing that launches GEMM kernels in that command, so the last len(csv) GEMM dispatches of the
