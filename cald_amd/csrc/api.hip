@@ -734,7 +734,7 @@ static double fill_conv_args(cald_model* m, ConvArgs& a, const ConvLayer& L, con
     a.in = in; a.out = out; a.w = L.w; a.w4 = L.w4; a.w16 = L.w16; a.w16_unscale = L.w16_unscale; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift;
     a.residual = residual; a.up = up;
     a.seg_in = dp->seg[lin]; a.seg_out = dp->seg[lout]; a.seg_up = dp->seg[lup];
-    a.dyn_rows = dyn; a.V = V;
+    a.dyn_rows = dyn; a.row_map = nullptr; a.V = V;
     a.Cin = L.Cin; a.Cout = L.Cout; a.CoutPad = L.CoutPad; a.Kpad = L.Kpad;
     a.KH = L.KH; a.KW = L.KW; a.stride = L.stride; a.pad = L.pad; a.relu = relu ? 1 : 0;
     a.total_mtiles = level_tiles(m->plan, lout, V);

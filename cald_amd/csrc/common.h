@@ -40,6 +40,8 @@ struct ConvArgs {
     const LevelSeg* seg_out;
     const LevelSeg* seg_up;
     const int* dyn_rows;   // optional per-view dynamic row count (roi GEMMs), else null
+    const int* row_map;    // optional (conv_p4.hip, EPI 0): output row m of a view is computed at input-grid pixel row_map[view's pix_off + m] and stored
+                           // at row m -- the gathered launches of the certified RPN pruning (rpn_prune.hip); needs dyn_rows; else null
     int V;
     int Cin, Cout, CoutPad, Kpad;
     int KH, KW, stride, pad;

@@ -206,7 +206,10 @@ __device__ __forceinline__ void conv_p4_body(const ConvArgs& a, const int blk, c
 #pragma unroll
     for (int p = 0; p < 2; p++) {
         const int m = m0 + arow + 64 * p;
-        const int oy = m / Wo, ox = m - oy * Wo;
+        // gathered rows (ConvArgs::row_map): row m is the output pixel row_map[m] of the view's grid; everything below addresses the INPUT
+        // from (oy, ox), the epilogue stores at row m
+        const int mp = (a.row_map && m < Mv) ? a.row_map[so.pix_off + m] : m;
+        const int oy = mp / Wo, ox = mp - oy * Wo;
         const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
         unsigned msk = 0;
         if (!C4 && m < Mv)
