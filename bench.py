@@ -510,6 +510,8 @@ def main():
     nl, nviews = C.c_int64(), C.c_int64()
     _ffi.check(L.cald_profile_read(ctx, C.byref(gm), C.byref(gf), C.byref(nl), C.byref(tot)))
     _ffi.check(L.cald_profile_roi_rows(ctx, C.byref(mean_r), C.byref(nviews)))
+    look_ms, look_fl = C.c_double(), C.c_double(); sel_frac = (C.c_double * 2)()
+    _ffi.check(L.cald_profile_prune(ctx, C.byref(look_ms), C.byref(look_fl), sel_frac))
     if os.environ.get("CALD_PROFILE_DUMP"):
         _ffi.check(L.cald_profile_dump(ctx, os.environ["CALD_PROFILE_DUMP"].encode()))
     _ffi.check(L.cald_profile_enable(ctx, 0))
@@ -563,7 +565,16 @@ def main():
                          "launches": int(nl.value), "avg_launch_ms": gm.value / max(1, nl.value),
                          "gemm_ms_per_step": gm.value / max(1, steps_local), "algorithmic_gflop_per_launch": gf.value / max(1, nl.value) / 1e9,
                          "roi_rows_per_view_measured": mean_r.value,
-                         "note": "rank 0's launches, HIP events on the launch stream; RoI-head FLOPs counted on the measured proposal rows"},
+                         "rpn_prune": None if look_ms.value <= 0 else {
+                             "what": "certified RPN pruning of the exact sweep (cald_amd/csrc/rpn_prune.hip): the RPN head of P2 / P3 is evaluated exactly only "
+                                     "at the pixels that can hold a top-1000 anchor, found by a split-fp16 look-ahead with an error bound; detections bit-identical",
+                             "lookahead_ms_per_step": look_ms.value / max(1, steps_local), "lookahead_tflops_eq": look_fl.value / max(look_ms.value, 1e-9) / 1e9,
+                             "pixels_recomputed_exactly": {"P2": sel_frac[0], "P3": sel_frac[1]},
+                             "note": "achieved / frac / launches above count the fp32 kernels only, the gathered launches on their selected rows; "
+                                     "the look-ahead launches (fp16 matrix pipe) are booked here"},
+                         "reference_algorithmic_tflops": (0.8416e12 if headline else 0.0) * pool_total / dt / 1e12 if headline else None,
+                         "note": "rank 0's launches, HIP events on the launch stream; RoI-head FLOPs counted on the measured proposal rows; "
+                                 "reference_algorithmic_tflops = images/s x 0.84 TFLOP per image (4 views x 105.2 GMAC, SURVEY 8d), what the reference's dense graph would cost"},
         }
         if do_full:
             # BASELINE configs[1] at its full size, one clock around everything: host JPEG bytes -> decode on the GPU ->

@@ -68,6 +68,7 @@ SIGNATURES = {
     "cald_model_create": (C.c_int, [C.c_void_p, C.POINTER(ModelCfg), C.POINTER(C.c_void_p)]),
     "cald_model_load_tensor": (C.c_int, [C.c_void_p, C.c_char_p, c_f, c_i64, C.c_int]),
     "cald_model_finalize": (C.c_int, [C.c_void_p]),
+    "cald_model_set_rpn_prune": (C.c_int, [C.c_void_p, C.c_int, c_i]),
     "cald_model_destroy": (C.c_int, [C.c_void_p]),
     "cald_forward": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(View), C.POINTER(Dets)]),
     "cald_sweep": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), c_i, c_i, c_i64, C.POINTER(SweepCfg), c_d, c_d]),
@@ -94,6 +95,7 @@ SIGNATURES = {
     "cald_jpeg_decode_batch": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p)]),
     "cald_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "cald_profile_read": (C.c_int, [C.c_void_p, c_d, c_d, c_i64, c_d]),
+    "cald_profile_prune": (C.c_int, [C.c_void_p, c_d, c_d, c_d]),
     "cald_profile_roi_rows": (C.c_int, [C.c_void_p, c_d, c_i64]),
     "cald_profile_dump": (C.c_int, [C.c_void_p, C.c_char_p]),
     # training step (device pointers as c_void_p)

@@ -59,9 +59,12 @@ struct cald_ctx {
     std::vector<hipEvent_t> ev0, ev1;
     double prof_flops = 0.0; int64_t prof_extra_launches = 0;
     std::vector<std::string> prof_desc; std::vector<double> prof_fl;
+    std::vector<int> prof_tag;                      // 0: the model's own arithmetic; 1: the split-fp16 look-ahead pass of rpn_prune.hip (booked apart)
+    double prof_prune_flops_cap[2] = {0.0, 0.0};    // FLOPs the gathered P2 / P3 launches would do on every pixel (rescaled to the selected rows at read time)
     hipEvent_t tot0 = nullptr, tot1 = nullptr; bool tot_open = false; double tot_ms = 0.0;
     // RoI-head GEMMs run on a device-side row count (proposals after NMS): the profile counts their algorithmic FLOPs on the
     // MEASURED rows, accumulated on the device while profiling (no host sync inside a forward)
+    unsigned long long* d_prune_stat = nullptr;   // rpn_prune.hip: selected / total pixels of P2, P3 while profiling
     unsigned long long* d_roi_rows = nullptr; double prof_roi_rows_cap = 0.0, prof_roi_flops_cap = 0.0; long long prof_roi_views = 0;
     std::map<PilKey, PilCoef> pil;
     char* train_scratch = nullptr; size_t train_scratch_cap = 0;   // train.hip: split-K partial tiles of the weight gradients
@@ -144,6 +147,8 @@ extern "C" int cald_ctx_create(int device, void* stream, cald_ctx** out) {
     HIPCHK(hipMemset(c->d_zeros, 0, 256));
     HIPCHK(hipMalloc((void**)&c->d_roi_rows, 8));
     HIPCHK(hipMemset(c->d_roi_rows, 0, 8));
+    HIPCHK(hipMalloc((void**)&c->d_prune_stat, 32));
+    HIPCHK(hipMemset(c->d_prune_stat, 0, 32));
     for (int i = 0; i < cald_ctx::NSTAGE; i++) {
         HIPCHK(hipHostMalloc((void**)&c->h_stage[i], sizeof(BatchPlan) + sizeof(ViewDesc) * CALD_MAX_VIEWS));
         HIPCHK(hipEventCreateWithFlags(&c->stage_ev[i], hipEventDisableTiming));
@@ -169,7 +174,7 @@ extern "C" int cald_ctx_destroy(cald_ctx* c) {
     if (c->train_scratch) hipFree(c->train_scratch);
     cald_internal_train_release(c);
     for (int i = 0; i < cald_ctx::NSTAGE; i++) { if (c->h_stage[i]) hipHostFree(c->h_stage[i]); if (c->stage_ev[i]) hipEventDestroy(c->stage_ev[i]); }
-    hipFree(c->d_plan); hipFree(c->d_views); hipFree(c->d_zeros); hipFree(c->d_roi_rows);
+    hipFree(c->d_plan); hipFree(c->d_views); hipFree(c->d_zeros); hipFree(c->d_roi_rows); hipFree(c->d_prune_stat);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
     return 0;
@@ -181,26 +186,48 @@ extern "C" int cald_profile_enable(cald_ctx* c, int on) {
     c->prof = on != 0;
     for (auto e : c->ev0) hipEventDestroy(e);
     for (auto e : c->ev1) hipEventDestroy(e);
-    c->ev0.clear(); c->ev1.clear(); c->prof_flops = 0.0; c->prof_extra_launches = 0; c->tot_ms = 0.0; c->tot_open = false; c->prof_desc.clear(); c->prof_fl.clear();
+    c->ev0.clear(); c->ev1.clear(); c->prof_flops = 0.0; c->prof_extra_launches = 0; c->tot_ms = 0.0; c->tot_open = false; c->prof_desc.clear(); c->prof_fl.clear(); c->prof_tag.clear();
+    c->prof_prune_flops_cap[0] = c->prof_prune_flops_cap[1] = 0.0;
     c->prof_roi_rows_cap = 0.0; c->prof_roi_flops_cap = 0.0; c->prof_roi_views = 0;
     HIPCHK(hipMemsetAsync(c->d_roi_rows, 0, 8, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_prune_stat, 0, 32, c->stream));
     if (on && !c->tot0) { HIPCHK(hipEventCreate(&c->tot0)); HIPCHK(hipEventCreate(&c->tot1)); }
     return 0;
 }
 extern "C" int cald_profile_read(cald_ctx* c, double* gemm_ms, double* gemm_flops, int64_t* launches, double* total_ms) {
     if (!c) return fail(CALD_ERR_INVALID, "ctx is null");
     HIPCHK(hipStreamSynchronize(c->stream));
-    double ms = 0.0;
-    for (size_t i = 0; i < c->ev0.size(); i++) { float t = 0.f; HIPCHK(hipEventElapsedTime(&t, c->ev0[i], c->ev1[i])); ms += t; }
+    double ms = 0.0, look_fl = 0.0; int64_t look_n = 0;
+    for (size_t i = 0; i < c->ev0.size(); i++) {
+        if (c->prof_tag[i]) { look_fl += c->prof_fl[i]; look_n++; continue; }       // the fp16 look-ahead of rpn_prune.hip: cald_profile_prune()
+        float t = 0.f; HIPCHK(hipEventElapsedTime(&t, c->ev0[i], c->ev1[i])); ms += t;
+    }
     if (gemm_ms) *gemm_ms = ms;
     // RoI-head layers were booked at the row capacity (CALD_ROI_CAP per view); rescale them to the measured rows
     unsigned long long rows = 0;
     HIPCHK(hipMemcpy(&rows, c->d_roi_rows, 8, hipMemcpyDeviceToHost));
-    double fl = c->prof_flops;
+    double fl = c->prof_flops - look_fl;
     if (c->prof_roi_rows_cap > 0.0) fl -= c->prof_roi_flops_cap * (1.0 - (double)rows / c->prof_roi_rows_cap);
+    unsigned long long st[4] = {0, 0, 0, 0};     // the gathered RPN launches were booked on every pixel of P2 / P3: rescale to the selected rows
+    HIPCHK(hipMemcpy(st, c->d_prune_stat, 32, hipMemcpyDeviceToHost));
+    for (int l = 0; l < 2; l++) if (st[2 * l + 1]) fl -= c->prof_prune_flops_cap[l] * (1.0 - (double)st[2 * l] / (double)st[2 * l + 1]);
     if (gemm_flops) *gemm_flops = fl;
-    if (launches) *launches = (int64_t)c->ev0.size() + c->prof_extra_launches;   // a timed region can hold several kernel launches
+    if (launches) *launches = (int64_t)c->ev0.size() - look_n + c->prof_extra_launches;   // a timed region can hold several kernel launches
     if (total_ms) *total_ms = c->tot_ms;
+    return 0;
+}
+
+extern "C" int cald_profile_prune(cald_ctx* c, double* look_ms, double* look_flops, double* selected_frac2) {
+    if (!c) return fail(CALD_ERR_INVALID, "ctx is null");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    double ms = 0.0, fl = 0.0;
+    for (size_t i = 0; i < c->ev0.size(); i++)
+        if (c->prof_tag[i]) { float t = 0.f; HIPCHK(hipEventElapsedTime(&t, c->ev0[i], c->ev1[i])); ms += t; fl += c->prof_fl[i]; }
+    unsigned long long st[4] = {0, 0, 0, 0};
+    HIPCHK(hipMemcpy(st, c->d_prune_stat, 32, hipMemcpyDeviceToHost));
+    if (look_ms) *look_ms = ms;
+    if (look_flops) *look_flops = fl;
+    if (selected_frac2) for (int l = 0; l < 2; l++) selected_frac2[l] = st[2 * l + 1] ? (double)st[2 * l] / (double)st[2 * l + 1] : 0.0;
     return 0;
 }
 
@@ -222,12 +249,13 @@ extern "C" int cald_profile_dump(cald_ctx* c, const char* path) {
     fprintf(f, "launch,desc,gflop,ms,tflops\n");
     for (size_t i = 0; i < c->ev0.size(); i++) {
         float t = 0.f; hipEventElapsedTime(&t, c->ev0[i], c->ev1[i]);
-        fprintf(f, "%zu,\"%s\",%.3f,%.4f,%.2f\n", i, c->prof_desc[i].c_str(), c->prof_fl[i] / 1e9, t, c->prof_fl[i] / (t * 1e-3) / 1e12);
+        fprintf(f, "%zu,\"%s%s\",%.3f,%.4f,%.2f\n", i, c->prof_desc[i].c_str(), c->prof_tag[i] ? ",f16x3-lookahead" : "", c->prof_fl[i] / 1e9, t, c->prof_fl[i] / (t * 1e-3) / 1e12);
     }
     fclose(f);
     return 0;
 }
 
+static int prof_tag_now = 0;      // set around the look-ahead launches of rpn_prune.hip (single-threaded per context, like the rest of the profile)
 // conv launch with optional event bracketing
 static int run_conv(cald_ctx* c, const ConvArgs& a, double flops) {
     if (c->prof) {
@@ -238,7 +266,7 @@ static int run_conv(cald_ctx* c, const ConvArgs& a, double flops) {
         HIPCHK(hipEventRecord(e1, c->stream));
         c->ev0.push_back(e0); c->ev1.push_back(e1); c->prof_flops += flops;
         char d[160]; snprintf(d, sizeof(d), "mt=%d,Cin=%d,Cout=%d,k=%dx%d,s=%d", a.total_mtiles, a.Cin, a.Cout, a.KH, a.KW, a.stride);
-        c->prof_desc.push_back(d); c->prof_fl.push_back(flops);
+        c->prof_desc.push_back(d); c->prof_fl.push_back(flops); c->prof_tag.push_back(prof_tag_now);
     } else {
         launch_conv(a, c->stream);
     }
@@ -379,6 +407,8 @@ struct cald_model {
     bool finalized = false;
     ConvLayer conv1; std::vector<Bottleneck> blocks;
     ConvLayer fpn_inner[4], fpn_layer[4], rpn_conv, rpn_head, fc6, fc7, pred;
+    // certified RPN pruning of the exact sweep (rpn_prune.hip): the 3 x 3 RPN conv once more with split-fp16 weights, the bound's constants
+    ConvLayer rpn_conv16; bool prune = false; float prune_c1[3] = {0, 0, 0}, prune_c0[3] = {0, 0, 0};
     ConvLayer p6, p7, cls_tower[4], reg_tower[4], cls_out, reg_out;   // RetinaNet
     int det_cap() const { return cfg.arch == CALD_ARCH_RETINANET ? cfg.num_classes * cfg.detections_per_img : cfg.detections_per_img; }
     float* d_anchors = nullptr;
@@ -493,7 +523,7 @@ template <typename T> static int upload(cald_model* m, const std::vector<T>& h, 
 // torch conv weight [Cout][Cin][KH][KW] (optionally several tensors concatenated along Cout)
 // -> K-major [Kpad][CoutPad], k = conv_k_index(kh*KW + kw, ci)
 static int make_conv(cald_model* m, ConvLayer& L, const std::vector<std::string>& wkeys, const std::vector<std::string>& bkeys,
-                     const std::string& bn_prefix, int stride, int pad, int cin_pad_to = 0) {
+                     const std::string& bn_prefix, int stride, int pad, int cin_pad_to = 0, bool force16 = false) {
     std::vector<const HostTensor*> ws;
     int cout = 0, cin = -1, kh = -1, kw = -1;
     for (auto& k : wkeys) {
@@ -534,7 +564,7 @@ static int make_conv(cald_model* m, ConvLayer& L, const std::vector<std::string>
             }
         if ((rc = upload(m, wsm, &L.wstem))) return rc;
     }
-    if (m->cfg.precision == CALD_PRECISION_F16X3 && L.CoutPad % 64 == 0 && ((L.Cin % 16 == 0 && kh * kw <= 32) || L.Cin == 4)) {   // conv_h3.hip layout
+    if ((m->cfg.precision == CALD_PRECISION_F16X3 || force16) && L.CoutPad % 64 == 0 && ((L.Cin % 16 == 0 && kh * kw <= 32) || L.Cin == 4)) {   // conv_h3.hip layout
         std::vector<uint16_t> w16 = pack_w16(w, L.Kpad, L.CoutPad, &L.w16_unscale, kh, kw, L.Cin);
         if ((rc = upload(m, w16, &L.w16))) return rc;
     }
@@ -594,6 +624,32 @@ extern "C" int cald_model_finalize(cald_model* m) {
         if ((rc = make_conv(m, m->rpn_conv, {"rpn.head.conv.weight"}, {"rpn.head.conv.bias"}, "", 1, 1))) return rc;
         if ((rc = make_conv(m, m->rpn_head, {"rpn.head.cls_logits.weight", "rpn.head.bbox_pred.weight"},
                             {"rpn.head.cls_logits.bias", "rpn.head.bbox_pred.bias"}, "", 1, 0))) return rc;
+        static const bool prune_env = !(getenv("CALD_RPN_PRUNE") && atoi(getenv("CALD_RPN_PRUNE")) == 0);
+        if (prune_env && m->cfg.precision == CALD_PRECISION_FP32 && m->rpn_conv.Cin == 256 && m->rpn_conv.Cout == 256 && m->rpn_head.Cout == 15 &&
+            m->cfg.rpn_pre_nms_top_n <= 1024) {
+            // certified RPN pruning (rpn_prune.hip): split-fp16 copy of the 3 x 3 conv's weights and the two constants per anchor of the
+            // bound |L~ - L| <= c1 |patch|_2 + c0 -- all in double, inflated by 2 % for the float32 evaluation on the device
+            if ((rc = make_conv(m, m->rpn_conv16, {"rpn.head.conv.weight"}, {"rpn.head.conv.bias"}, "", 1, 1, 0, true))) return rc;
+            const HostTensor *wc, *bc, *wl;
+            if ((rc = get_t(m, "rpn.head.conv.weight", &wc)) || (rc = get_t(m, "rpn.head.conv.bias", &bc)) || (rc = get_t(m, "rpn.head.cls_logits.weight", &wl))) return rc;
+            const int K = 2304;
+            const double u = std::ldexp(1.0, -24);
+            const double g_e = K * u / (1.0 - K * u);                                        // the exact mode's fp32 fma chain of K terms
+            const double g_f = 3.0 * std::ldexp(1.0, -22) + (3.0 * K / 16.0) * std::ldexp(1.0, -23);   // split operands + 3K/16 accumulating MFMA instructions
+            const double g_h = 256 * u / (1.0 - 256 * u);                                    // the 1 x 1 head's chain (same kernel on both hidden vectors)
+            static const double slack = getenv("CALD_RPN_PRUNE_SLACK") ? atof(getenv("CALD_RPN_PRUNE_SLACK")) : 1.0;      // tuning experiments: scales the bound
+            std::vector<double> wn(256, 0.0);
+            for (int c = 0; c < 256; c++) { double q = 0.0; for (int k = 0; k < K; k++) { const double t = wc->data[(size_t)c * K + k]; q += t * t; } wn[c] = std::sqrt(q); }
+            bool finite = true;
+            for (int a = 0; a < 3; a++) {
+                double kap = 0.0, bet = 0.0;
+                for (int c = 0; c < 256; c++) { const double v = std::fabs((double)wl->data[(size_t)a * 256 + c]); kap += v * wn[c]; bet += v * std::fabs((double)bc->data[c]); }
+                m->prune_c1[a] = (float)(1.02 * slack * (g_e + g_f + 2.0 * g_h) * kap);
+                m->prune_c0[a] = (float)(1.02 * slack * 2.0 * g_h * bet + 1e-6);
+                finite = finite && std::isfinite(m->prune_c1[a]) && std::isfinite(m->prune_c0[a]);
+            }
+            m->prune = finite && m->rpn_conv16.w16 != nullptr;
+        }
         {   // fc6: torch K order is (c, bin); the RoIAlign kernel writes (bin, c) -> permute the weight's K axis
             const HostTensor* t; if ((rc = get_t(m, "roi_heads.box_head.fc6.weight", &t))) return rc;
             if (t->shape.size() != 2 || t->shape[1] != 256 * 49) return fail(CALD_ERR_INVALID, "fc6 weight must be [N][12544]");
@@ -666,6 +722,15 @@ extern "C" int cald_model_finalize(cald_model* m) {
 }
 static void free_det(DetBuffers& d);
 static int alloc_det(DetBuffers& d, int V, int cap, int C);
+// Certified RPN pruning (rpn_prune.hip) is on by default in the exact sweeps of a Faster R-CNN model (CALD_RPN_PRUNE=0 disables it for the
+// process); this switch turns it off / on for one model -- the A/B of the tests and of bench.py.  Returns the previous state in *was.
+extern "C" int cald_model_set_rpn_prune(cald_model* m, int on, int* was) {
+    if (!m) return fail(CALD_ERR_INVALID, "model is null");
+    if (!m->finalized) return fail(CALD_ERR_STATE, "model not finalized");
+    if (was) *was = m->prune ? 1 : 0;
+    m->prune = on != 0 && m->rpn_conv16.w16 != nullptr && m->cfg.precision == CALD_PRECISION_FP32;
+    return 0;
+}
 extern "C" int cald_model_destroy(cald_model* m) {
     if (!m) return 0;
     hipSetDevice(m->ctx->device);
@@ -725,6 +790,8 @@ struct FwdBufs {
     unsigned* Pf16[5];   // CALD_PRECISION_F16X3: split twins of the tensors that stay fp32 as well
     // decision-margin audit (audit.hip): what the RPN / post-processing kernels leave behind for it
     unsigned long long *next_key, *trunc_key, *kept_key; float* post_maxc;
+    // certified RPN pruning (rpn_prune.hip), levels P2 / P3
+    float *prune_energy[2], *prune_rows[2]; int *prune_map[2], *prune_nsel;
 };
 
 static double fill_conv_args(cald_model* m, ConvArgs& a, const ConvLayer& L, const float* in, float* out, int lin, int lout, int V, bool relu,
@@ -808,7 +875,7 @@ static int conv_pair_on(cald_model* m, const ConvLayer& L2, const ConvLayer& L3,
                 HIPCHK(hipEventRecord(e1, c->stream));
                 c->ev0.push_back(e0); c->ev1.push_back(e1); c->prof_flops += f2 + f3;
                 char d[160]; snprintf(d, sizeof(d), "mt=%d,Cin=%d,Cout=%d,k=3x3+1x1,s=1,fused->%d", a2.total_mtiles, a2.Cin, a2.Cout, a3.Cout);
-                c->prof_desc.push_back(d); c->prof_fl.push_back(f2 + f3);
+                c->prof_desc.push_back(d); c->prof_fl.push_back(f2 + f3); c->prof_tag.push_back(0);
             }
             return 0;
         }
@@ -819,13 +886,14 @@ static int conv_pair_on(cald_model* m, const ConvLayer& L2, const ConvLayer& L3,
     return conv_on(m, L3, mid, out, lout, lout, V, true, residual);
 }
 // independent convolutions (bias / BN / ReLU epilogue only) issued as ONE launch when they fit the same tiled kernel
-struct ConvSpec { const ConvLayer* L; const float* in; float* out; int level; bool relu; };
+struct ConvSpec { const ConvLayer* L; const float* in; float* out; int level; bool relu; const int* dyn = nullptr; const int* row_map = nullptr; };
 static int conv_group_on(cald_model* m, const ConvSpec* sp, int n, int V) {
     ConvArgs a[CALD_MAX_GROUP];
     double flops = 0.0; int tiles = 0;
     for (int i = 0; i < n; i++) {
-        const double f = fill_conv_args(m, a[i], *sp[i].L, sp[i].in, sp[i].out, sp[i].level, sp[i].level, V, sp[i].relu);
+        const double f = fill_conv_args(m, a[i], *sp[i].L, sp[i].in, sp[i].out, sp[i].level, sp[i].level, V, sp[i].relu, nullptr, nullptr, 0, sp[i].dyn);
         if (f < 0.0) return (int)f;
+        a[i].row_map = sp[i].row_map;
         flops += f; tiles += a[i].total_mtiles;
     }
     cald_ctx* c = m->ctx;
@@ -837,7 +905,7 @@ static int conv_group_on(cald_model* m, const ConvSpec* sp, int n, int V) {
         HIPCHK(hipEventRecord(e1, c->stream));
         c->ev0.push_back(e0); c->ev1.push_back(e1); c->prof_flops += flops;
         char d[160]; snprintf(d, sizeof(d), "mt=%d,Cin=%d,Cout=%d,k=%dx%d,s=%d,group=%d", tiles, a[0].Cin, a[0].Cout, a[0].KH, a[0].KW, a[0].stride, n);
-        c->prof_desc.push_back(d); c->prof_fl.push_back(flops);
+        c->prof_desc.push_back(d); c->prof_fl.push_back(flops); c->prof_tag.push_back(prof_tag_now);
     } else {
         launch_conv_group(a, n, c->stream);
     }
@@ -920,12 +988,16 @@ static void fwd_layout(cald_model* m, Bump& B, FwdBufs& F, int V) {
     F.keys = B.get<unsigned long long>((size_t)V * m->key_cap);
     F.cbox = B.get<float>((size_t)V * 2 * m->key_cap * 4);
     F.key_count = B.get<int>(V);
+    for (int i = 0; i < 2; i++) {
+        F.prune_energy[i] = B.get<float>(px[2 + i]); F.prune_rows[i] = B.get<float>(px[2 + i] * 15); F.prune_map[i] = B.get<int>(px[2 + i]);
+    }
+    F.prune_nsel = B.get<int>((size_t)2 * V);
     F.next_key = B.get<unsigned long long>((size_t)V * 10); F.trunc_key = B.get<unsigned long long>((size_t)V * 2);
     F.kept_key = B.get<unsigned long long>((size_t)V * m->det_cap()); F.post_maxc = B.get<float>(V);
 }
 
 // views: host descriptors with src/H/W/flip/rects filled; Hr/Wr/Ho/Wo are filled here.
-static int forward_model(cald_model* m, int V, ViewDesc* views, const DetBuffers& det, float* audit_out = nullptr) {
+static int forward_model(cald_model* m, int V, ViewDesc* views, const DetBuffers& det, float* audit_out = nullptr, bool prune_ok = false) {
     cald_ctx* c = m->ctx;
     if (!m->finalized) return fail(CALD_ERR_STATE, "model not finalized (call cald_model_finalize)");
     if (V < 1 || V > CALD_MAX_VIEWS) return fail(CALD_ERR_INVALID, "n_views must be 1..%d", CALD_MAX_VIEWS);
@@ -1055,7 +1127,36 @@ static int forward_model(cald_model* m, int V, ViewDesc* views, const DetBuffers
     for (int i = 0; i < 5; i++) m->dbg[pn[i]] = {F.Pf[i], 2 + i, 256, 0};
     // ---- RPN (row A17) ----
     const char* rn[5] = {"rpn0", "rpn1", "rpn2", "rpn3", "rpn4"};
-    {   // the shared-weight RPN head over the five levels: one launch for the 3x3 conv, one for the fused 1x1 heads
+    if (m->prune && prune_ok) {
+        // certified pruning (rpn_prune.hip): P2 / P3 first on the fp16 matrix pipe, then exactly at the pixels that can hold one of the
+        // level's pre_nms_top_n anchors; P4..P6 dense as ever.  Same bits at every anchor the top-k can select.
+        ConvSpec sp[5];
+        prof_tag_now = 1;
+        for (int i = 0; i < 2; i++) sp[i] = {&m->rpn_conv16, F.Pf[i], F.rpn_tl[i], 2 + i, true};
+        rc = conv_group_on(m, sp, 2, V);
+        for (int i = 0; i < 2; i++) sp[i] = {&m->rpn_head, F.rpn_tl[i], F.rpn_h[i], 2 + i, false};
+        if (!rc) rc = conv_group_on(m, sp, 2, V);
+        prof_tag_now = 0;
+        if (rc) return rc;
+        if (c->prof) for (int i = 0; i < 2; i++) c->prof_prune_flops_cap[i] += 2.0 * (double)level_pix(m->plan, 2 + i, V) * (2304.0 * 256.0 + 256.0 * 15.0);
+        RpnPruneArgs pr;
+        for (int i = 0; i < 2; i++) {
+            pr.feat[i] = F.Pf[i]; pr.seg[i] = dp->seg[2 + i]; pr.energy[i] = F.prune_energy[i]; pr.head[i] = F.rpn_h[i]; pr.head_out[i] = F.rpn_h[i];
+            pr.head_rows[i] = F.prune_rows[i]; pr.row_map[i] = F.prune_map[i];
+        }
+        pr.nsel = F.prune_nsel; pr.stat = c->prof ? c->d_prune_stat : nullptr;
+        for (int q = 0; q < 3; q++) { pr.c1[q] = m->prune_c1[q]; pr.c0[q] = m->prune_c0[q]; }
+        pr.head_ld = 15; pr.pre_n = m->cfg.rpn_pre_nms_top_n; pr.V = V;
+        launch_rpn_prune_select(pr, max_pix2, st);
+        for (int i = 0; i < 5; i++) sp[i] = {&m->rpn_conv, F.Pf[i], F.rpn_tl[i], 2 + i, true};
+        for (int i = 0; i < 2; i++) { sp[i].dyn = F.prune_nsel + i * V; sp[i].row_map = F.prune_map[i]; }      // gathered rows, compact output
+        if ((rc = conv_group_on(m, sp, 5, V))) return rc;
+        for (int i = 0; i < 5; i++) sp[i] = {&m->rpn_head, F.rpn_tl[i], i < 2 ? F.prune_rows[i] : F.rpn_h[i], 2 + i, false};
+        for (int i = 0; i < 2; i++) sp[i].dyn = F.prune_nsel + i * V;
+        if ((rc = conv_group_on(m, sp, 5, V))) return rc;
+        launch_rpn_prune_scatter(pr, st);
+        for (int i = 2; i < 5; i++) m->dbg[rn[i]] = {F.rpn_h[i], 2 + i, 15, 0};      // (P2 / P3 head maps are exact only where selected: no debug view)
+    } else {   // the shared-weight RPN head over the five levels: one launch for the 3x3 conv, one for the fused 1x1 heads
         ConvSpec sp[5];
         for (int i = 0; i < 5; i++) sp[i] = {&m->rpn_conv, F.Pf[i], F.rpn_tl[i], 2 + i, true};
         if ((rc = conv_group_on(m, sp, 5, V))) return rc;
@@ -1588,7 +1689,7 @@ static int sweep_impl(cald_model* m, int n_images, const uint8_t* const* images_
             views[i].src = images_dev[b.i0 + i]; views[i].H = H[b.i0 + i]; views[i].W = W[b.i0 + i];
         }
         const DetBuffers& D = *DS[k & 1];
-        int r = forward_model(m, b.nb, views.data(), D, audit ? d_vm[k & 1] : nullptr);
+        int r = forward_model(m, b.nb, views.data(), D, audit ? d_vm[k & 1] : nullptr, true);
         if (r) return r;
         if (hipMemcpyAsync(b.h_count, D.count, (size_t)b.nb * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
             hipMemcpyAsync(b.h_boxes, D.boxes, (size_t)b.nb * cap * 16, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
@@ -1756,7 +1857,7 @@ static int sweep_impl(cald_model* m, int n_images, const uint8_t* const* images_
             DetBuffers d2 = D; const size_t o = (size_t)(nb + a0);
             d2.boxes += o * cap * 4; d2.scores += o * cap; d2.labels += o * cap; d2.props += o * cap * 4;
             d2.prob_max += o * cap; d2.scores_cls += o * cap * C; d2.count += o;
-            if ((r = forward_model(m, nv, aviews.data() + a0, d2, audit ? d_vm[k & 1] + o * CALD_VM : nullptr))) return r;
+            if ((r = forward_model(m, nv, aviews.data() + a0, d2, audit ? d_vm[k & 1] + o * CALD_VM : nullptr, true))) return r;
         }
         // ---- scoring ----
         const int P = (int)pair_ref.size(), VV = nb + na;

@@ -145,6 +145,23 @@ void launch_consistency(const ScoreArgs& a, hipStream_t st);
 void launch_cls_corr(const DetBuffers& det, const int* ref_sel, const int* ref_n, const int* view_img, const int* view_is_ref,
                      int V, float* out /*[V][C-1]*/, hipStream_t st);
 
+// rpn_prune.hip -- certified pruning of the RPN head on P2 / P3 in the exact sweep (the file's header has the argument)
+struct RpnPruneArgs {
+    const float* feat[2];        // P2, P3: fp32 [pixel][256]
+    const LevelSeg* seg[2];
+    float* energy[2];            // [pixel] scratch: sum of squares over the 256 channels
+    const float* head[2];        // approximate head maps [pixel][head_ld] (logits = channels 0..2)
+    float* head_out[2];          // the same buffers: unselected pixels get logit -FLT_MAX, selected ones their exact rows
+    const float* head_rows[2];   // exact head rows of the selected pixels, compact [n_selected][head_ld] per view (at the view's pixel offset)
+    int* row_map[2];             // [pixel] -> selected pixel index, compact per view
+    int* nsel;                   // [2][V] selected pixels per (level, view): the dyn_rows of the gathered launches
+    unsigned long long* stat;    // optional [4]: selected / total pixels of P2 and P3 accumulated over the calls (profiling), or null
+    float c1[3], c0[3];          // bound per anchor: c1 * |patch|_2 + c0
+    int head_ld, pre_n, V;
+};
+void launch_rpn_prune_select(const RpnPruneArgs& a, int max_pix, hipStream_t st);
+void launch_rpn_prune_scatter(const RpnPruneArgs& a, hipStream_t st);
+
 // audit.hip -- decision margins of one Faster R-CNN forward (cascade mode: which images may differ from the exact mode by more than
 // continuous rounding).  Every discrete decision of the forward (top-k cut, NMS IoU test, score threshold, RoI level, sort
 // order where the order matters) leaves its distance to the flip point; a view's record keeps the minimum per kind.

@@ -1,0 +1,169 @@
+// rpn_prune.hip -- certified pruning of the RPN head in the exact (CALD_PRECISION_FP32) sweep.
+//
+// RegionProposalNetwork.filter_proposals (detection/frcnn_ll.py:284-321) keeps, per pyramid level, the pre_nms_top_n anchors with the
+// largest objectness logit -- 1 000 of 91 200 on P2, 1 000 of 22 800 on P3 at VOC size -- and nothing downstream ever reads another
+// anchor's logit or deltas.  The RPN head (3 x 3 conv 256 -> 256 + ReLU, 1 x 1 -> 15; frcnn_la.py:199-203) is 23 % of a view's FLOPs and
+// P2 + P3 carry 94 % of its pixels.  The exact sweep therefore computes the head in two steps on those two levels:
+//   1. everywhere, cheaply: the 3 x 3 conv on the fp16 matrix pipe (conv_h3.hip, 3 MFMAs per product, ~2.5 x the fp32 rate), the 1 x 1 head on
+//      the exact kernel -> approximate logits L~ with a PROVEN error bound B(anchor) against the exact mode's own value L (below);
+//   2. only where it can matter, exactly: tau = the k-th largest LOWER bound L~ - B.  At least k anchors have L >= tau, so an anchor with
+//      L~ + B < tau is not among the k largest of L, whatever the rounding did.  The pixels that hold a surviving anchor (7 - 10 % of P2,
+//      ~half of P3) are recomputed by the exact kernels as gathered rows (ConvArgs::row_map) -- per output element the same k-ordered
+//      fp32 fma chain as the dense launch, hence the same bits -- and scattered back; all other anchors get logit -FLT_MAX.
+// The top-k, decode, NMS and everything after see the exact mode's values at every anchor that can be selected: the detections, and
+// with them scores and selection, are bit-identical to the unpruned sweep (tests: every sweep-vs-oracle test runs through this path;
+// test_certified_rpn_pruning_* compares pruned and dense proposals at full size).
+//
+// The bound.  z = sum_k P_k w_kc over the 2 304 taps of hidden channel c.  The exact mode computes an fp32 fma chain z_e with
+// |z_e - z| <= g_e S, S = sum_k |P_k w_kc|, g_e = K u / (1 - K u), u = 2^-24 (Higham, Accuracy and Stability, sect. 3.1); the matrix-pipe
+// pass computes z_f with |z_f - z| <= g_f S: operands split into fp16 hi + lo (relative error <= 2^-22 each, the lo x lo term 2^-22 more)
+// and 3 K / 16 accumulating MFMA instructions, each rounding (and aligning) once at <= 2^-23 of the running magnitude: g_f = 3 * 2^-22 +
+// (3 K / 16) 2^-23.  ReLU and the bias are 1-Lipschitz / exact, so |h_e - h_f| <= (g_e + g_f) S <= (g_e + g_f) |patch|_2 |w_c|_2
+// (Cauchy-Schwarz; |patch|_2 from the 3 x 3 box sum of the per-pixel channel energy).  The 1 x 1 head is evaluated by the SAME exact kernel on
+// both hidden vectors: |L~ - L| <= sum_c |v_ac| |h_e - h_f| + 2 g_h sum_c |v_ac| max(|h_e|, |h_f|), g_h = 256 u / (1 - 256 u), and
+// |h| <= |patch|_2 |w_c|_2 + |b_c|.  Per anchor a this is  B_a(p) = c1_a |patch(p)|_2 + c0_a  with two constants fixed at model finalize
+// (api.hip); both are inflated by 2 % for the float32 evaluation of the bound itself.
+#include "common.h"
+#include "kernels.h"
+#include <cfloat>
+
+namespace {
+// per pixel: sum over the 256 channels of P^2.  One wavefront per pixel (float4 per lane), 4 pixels per workgroup.
+__global__ __launch_bounds__(256) void prune_energy_kernel(RpnPruneArgs a, int l) {
+    const int v = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const LevelSeg sg = a.seg[l][v];
+    const int n = sg.H * sg.W;
+    const float4* f = reinterpret_cast<const float4*>(a.feat[l] + sg.pix_off * 256ll);
+    for (int p = blockIdx.x * 4 + wave; p < n; p += gridDim.x * 4) {
+        const float4 x = f[(long long)p * 64 + lane];
+        float s = (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) s = s + __shfl_xor(s, off, 64);
+        if (lane == 0) a.energy[l][sg.pix_off + p] = s;
+    }
+}
+
+// per (level, view): tau by radix select over the lower bounds, the pixel mask, the ordered list of selected pixels.
+// grid = (2, V), block = 1024, dynamic LDS = one bit per pixel.
+__device__ __forceinline__ float prune_patch_norm(const float* e, int y, int x, int H, int W) {
+    float s = 0.0f;
+#pragma unroll
+    for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+        for (int dx = -1; dx <= 1; dx++) {
+            const int yy = y + dy, xx = x + dx;
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W) s = s + e[yy * W + xx];
+        }
+    return sqrtf(s) * 1.0001f;
+}
+__global__ __launch_bounds__(1024) void prune_select_kernel(RpnPruneArgs a) {
+    extern __shared__ unsigned mask[];
+    __shared__ int hist[256];
+    __shared__ unsigned s_prefix, s_mask;
+    __shared__ int s_remaining, s_total, s_wave_cnt[16];
+    const int l = blockIdx.x, v = blockIdx.y, tid = threadIdx.x;
+    const LevelSeg sg = a.seg[l][v];
+    const int H = sg.H, W = sg.W, npx = H * W, A = 3, n = npx * A;
+    const int k = n < a.pre_n ? n : a.pre_n;
+    const float* head = a.head[l] + sg.pix_off * (long long)a.head_ld;
+    const float* en = a.energy[l] + sg.pix_off;
+    int* rmap = a.row_map[l] + sg.pix_off;
+    const int words = (npx + 31) >> 5;
+    for (int i = tid; i < words; i += 1024) mask[i] = 0u;
+    if (tid == 0) { s_prefix = 0u; s_mask = 0u; s_remaining = k; }
+    __syncthreads();
+    auto bound = [&](int p, int an, float pn) { return a.c1[an] * pn + a.c0[an]; };
+    if (n > k) {
+        for (int pass = 0; pass < 4; pass++) {                  // the k-th largest of the lower bounds, 8 bits per pass
+            const int shift = 24 - 8 * pass;
+            if (tid < 256) hist[tid] = 0;
+            __syncthreads();
+            const unsigned prefix = s_prefix, msk = s_mask;
+            for (int p = tid; p < npx; p += 1024) {
+                const float pn = prune_patch_norm(en, p / W, p % W, H, W);
+                for (int an = 0; an < A; an++) {
+                    const unsigned key = det_orderable(head[(long long)p * a.head_ld + an] - bound(p, an, pn));
+                    if ((key & msk) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1);
+                }
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int cum = 0, rem = s_remaining;
+                for (int b = 255; b >= 0; b--) {
+                    const int h = hist[b];
+                    if (cum + h >= rem) { s_remaining = rem - cum; s_prefix = prefix | ((unsigned)b << shift); s_mask = msk | (255u << shift); break; }
+                    cum += h;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const unsigned tau = (n > k) ? s_prefix : 0u;               // orderable key of the k-th largest lower bound (0: every anchor stays)
+    for (int p = tid; p < npx; p += 1024) {
+        const float pn = prune_patch_norm(en, p / W, p % W, H, W);
+        bool keep = false;
+        for (int an = 0; an < A; an++) {
+            const float lg = head[(long long)p * a.head_ld + an];
+            const float ub = lg + bound(p, an, pn);
+            keep = keep || !(ub == ub) || det_orderable(ub) >= tau;          // NaN: never pruned
+        }
+        if (keep) atomicOr(&mask[p >> 5], 1u << (p & 31));
+    }
+    __syncthreads();
+    // ordered compaction of the selected pixels (ascending pixel index: neighbouring rows of the gathered conv share input pixels)
+    const int lane = tid & 63, wave = tid >> 6;
+    int base = 0;
+    for (int w0 = 0; w0 < words; w0 += 1024) {
+        const int wi = w0 + tid;
+        const unsigned bits = wi < words ? mask[wi] : 0u;
+        const int cnt = __popc(bits);
+        int inc = cnt;                                           // inclusive scan over the wavefront, then over the 16 wavefronts
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(inc, off, 64); if (lane >= off) inc += t; }
+        if (lane == 63) s_wave_cnt[wave] = inc;
+        __syncthreads();
+        int wbase = 0;
+        for (int q = 0; q < wave; q++) wbase += s_wave_cnt[q];
+        int o = base + wbase + inc - cnt;
+        unsigned b = bits;
+        while (b) { const int t = __ffs(b) - 1; b &= b - 1; rmap[o++] = wi * 32 + t; }
+        if (tid == 1023) s_total = wbase + inc;
+        __syncthreads();
+        base += s_total;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        a.nsel[l * a.V + v] = base;
+        if (a.stat) { atomicAdd(a.stat + 2 * l, (unsigned long long)base); atomicAdd(a.stat + 2 * l + 1, (unsigned long long)npx); }
+    }
+    // unselected pixels: their three logits can never reach the top-k -- park them below every real logit
+    float* headw = a.head_out[l] + sg.pix_off * (long long)a.head_ld;
+    for (int p = tid; p < npx; p += 1024)
+        if (!((mask[p >> 5] >> (p & 31)) & 1u)) { headw[(long long)p * a.head_ld] = -FLT_MAX; headw[(long long)p * a.head_ld + 1] = -FLT_MAX; headw[(long long)p * a.head_ld + 2] = -FLT_MAX; }
+}
+
+// the exact head rows of the selected pixels back into the dense [pixel][head_ld] map.  grid = (blocks, V, 2)
+__global__ __launch_bounds__(256) void prune_scatter_kernel(RpnPruneArgs a) {
+    const int l = blockIdx.z, v = blockIdx.y;
+    const LevelSeg sg = a.seg[l][v];
+    const int ns = a.nsel[l * a.V + v], ld = a.head_ld;
+    const int* rmap = a.row_map[l] + sg.pix_off;
+    const float* src = a.head_rows[l] + sg.pix_off * (long long)ld;
+    float* dst = a.head_out[l] + sg.pix_off * (long long)ld;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < ns * ld; i += gridDim.x * 256) {
+        const int r = i / ld, c = i - r * ld;
+        dst[(long long)rmap[r] * ld + c] = src[i];
+    }
+}
+}   // namespace
+
+void launch_rpn_prune_select(const RpnPruneArgs& a, int max_pix, hipStream_t st) {
+    for (int l = 0; l < 2; l++) hipLaunchKernelGGL(prune_energy_kernel, dim3(256, a.V), dim3(256), 0, st, a, l);
+    const size_t lds = (size_t)((max_pix + 31) / 32) * 4;
+    static PerDeviceOnce once;
+    allow_big_lds(once, prune_select_kernel);
+    hipLaunchKernelGGL(prune_select_kernel, dim3(2, a.V), dim3(1024), lds, st, a);
+}
+void launch_rpn_prune_scatter(const RpnPruneArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(prune_scatter_kernel, dim3(64, a.V, 2), dim3(256), 0, st, a);
+}

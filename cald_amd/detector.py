@@ -245,6 +245,12 @@ class HipDetector:
             views.append((g.permute(1, 2, 0).contiguous(), False, None, noise))
         return self.forward_views(views)
 
+    def set_rpn_prune(self, on):
+        """Certified RPN pruning of the exact sweeps (include/cald_hip.h cald_model_set_rpn_prune): returns the previous state."""
+        was = C.c_int(0)
+        _ffi.check(_ffi.lib().cald_model_set_rpn_prune(self.handle(), int(bool(on)), C.byref(was)))
+        return bool(was.value)
+
     def debug_tensor(self, name, view=0):
         shape = (C.c_int64 * 3)()
         cap = 1 << 26

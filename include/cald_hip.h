@@ -75,6 +75,11 @@ int cald_model_create(cald_ctx* ctx, const cald_model_cfg* cfg, cald_model** out
 int cald_model_load_tensor(cald_model* m, const char* key, const float* data, const int64_t* shape, int ndim);
 /* folds FrozenBatchNorm into per-channel scale/shift, repacks weights K-major for the MFMA kernels */
 int cald_model_finalize(cald_model* m);
+/* Exact (CALD_PRECISION_FP32) Faster R-CNN sweeps evaluate the RPN head of P2 / P3 exactly only at the pixels that can hold one of a
+ * level's rpn_pre_nms_top_n anchors, found by a split-fp16 look-ahead with a proven error bound (rpn_prune.hip):
+ * same detections bit for bit, ~1/8 less fp32 work.  On by default (environment CALD_RPN_PRUNE=0 turns it off for the process); this
+ * call switches it per model and returns the previous state in *was (may be null).  cald_forward always runs the dense head. */
+int cald_model_set_rpn_prune(cald_model* m, int on, int* was);
 int cald_model_destroy(cald_model* m);
 
 /* One detector input: task_model([tensor]) in cald_train.py:107 / :186.  The view is described by
@@ -238,6 +243,10 @@ int cald_profile_enable(cald_ctx* ctx, int on);
 /* gemm_flops = algorithmic FLOPs of the timed launches; the RoI-head layers (fc6 / fc7 / predictor) are counted on the
  * MEASURED proposal rows (device-side count after RPN NMS), not on the row capacity */
 int cald_profile_read(cald_ctx* ctx, double* gemm_ms, double* gemm_flops, int64_t* gemm_launches, double* total_ms);
+/* the exact sweep's certified RPN pruning: time and algorithmic FLOPs of its split-fp16 look-ahead launches
+ * (NOT part of cald_profile_read's figures, which then count the exact kernels only, the gathered launches on their selected rows) and
+ * the fraction of P2 / P3 pixels whose head was recomputed exactly */
+int cald_profile_prune(cald_ctx* ctx, double* lookahead_ms, double* lookahead_flops, double* selected_fraction_p2_p3);
 /* mean proposals per view (R of SURVEY 8d) over the Faster R-CNN forwards profiled since cald_profile_enable */
 int cald_profile_roi_rows(cald_ctx* ctx, double* mean_rows_per_view, int64_t* views);
 /* per-launch CSV (shape, algorithmic GFLOP, ms, TFLOP/s) of the launches recorded since cald_profile_enable */

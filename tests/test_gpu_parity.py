@@ -1466,3 +1466,35 @@ def test_sweep_audit_records_the_decisions_that_flip_between_precisions(hip):
     same = ~changed
     d = np.abs(me[same][:, [1, 5, 8, 12]] - mh[same][:, [1, 5, 8, 12]])      # IoU / level margins: smooth functions of the boxes
     assert float(np.median(d[np.isfinite(d)])) < 1e-5
+
+
+@pytest.mark.gpu
+def test_certified_rpn_pruning_is_bit_identical_to_the_dense_head(hip):
+    """rpn_prune.hip: the exact sweep evaluates the RPN head of P2 / P3 exactly only where one of the level's top-1000 anchors can sit
+    (split-fp16 look-ahead + proven error bound + gathered exact rows).  Full-size VOC and COCO-shaped images, ResNet-50 and -101:
+    consistency and cls_corr with the pruning on == with the pruning off, bit for bit (every other sweep test of this file runs with it
+    on and is compared with the CPU oracle); and it does prune: well under half of P2's pixels are recomputed."""
+    import ctypes as C
+    torch, ffi, L = hip["torch"], hip["ffi"], hip["L"]
+    from cald_amd import synth, sweep
+    for depth, shape, ncls, mn, mx, augs in ((50, "voc", 21, 600, 1000, ["flip", "cut_out", "smaller_resize"]),
+                                             (101, "coco", 91, 800, 1333, ["flip", "ga", "rotation"])):
+        sd = synth.pseudo_trained_frcnn(ncls, depth, seed=2)
+        make = hip["det"].fasterrcnn_resnet101_fpn_feature if depth == 101 else hip["det"].fasterrcnn_resnet50_fpn_feature
+        m = make(num_classes=ncls, min_size=mn, max_size=mx).to("cuda")
+        m.load_state_dict(sd); m.eval()
+        dev = [torch.from_numpy(im).cuda() for im in synth.make_pool(24, shape, 3)]
+        pos = list(range(24))
+        assert m.set_rpn_prune(True) is True                      # on by default
+        ffi.check(L.cald_profile_enable(hip["ctx"], 1))
+        c1, k1 = sweep.sweep_device_images(m, dev, pos, augs, bp=1.3, base_seed=7, batch_images=24)
+        ms, fl = C.c_double(), C.c_double(); frac = (C.c_double * 2)()
+        ffi.check(L.cald_profile_prune(hip["ctx"], C.byref(ms), C.byref(fl), frac))
+        ffi.check(L.cald_profile_enable(hip["ctx"], 0))
+        m.set_rpn_prune(False)
+        c0, k0 = sweep.sweep_device_images(m, dev, pos, augs, bp=1.3, base_seed=7, batch_images=24)
+        print("R%d %s: P2 %.3f, P3 %.3f of the pixels recomputed exactly; look-ahead %.1f TF-eq" % (depth, shape, frac[0], frac[1], fl.value / max(ms.value, 1e-9) / 1e9))
+        assert c1.tobytes() == c0.tobytes() and k1.tobytes() == k0.tobytes()
+        assert 0.0 < frac[0] < 0.5 and 0.0 < frac[1] <= 1.0 and ms.value > 0
+        del m
+        torch.cuda.empty_cache()
