@@ -511,7 +511,8 @@ def main():
     _ffi.check(L.cald_profile_read(ctx, C.byref(gm), C.byref(gf), C.byref(nl), C.byref(tot)))
     _ffi.check(L.cald_profile_roi_rows(ctx, C.byref(mean_r), C.byref(nviews)))
     look_ms, look_fl = C.c_double(), C.c_double(); sel_frac = (C.c_double * 2)()
-    _ffi.check(L.cald_profile_prune(ctx, C.byref(look_ms), C.byref(look_fl), sel_frac))
+    worst_ratio = C.c_double()
+    _ffi.check(L.cald_profile_prune(ctx, C.byref(look_ms), C.byref(look_fl), sel_frac, C.byref(worst_ratio)))
     if os.environ.get("CALD_PROFILE_DUMP"):
         _ffi.check(L.cald_profile_dump(ctx, os.environ["CALD_PROFILE_DUMP"].encode()))
     _ffi.check(L.cald_profile_enable(ctx, 0))
@@ -570,6 +571,7 @@ def main():
                                      "at the pixels that can hold a top-1000 anchor, found by a split-fp16 look-ahead with an error bound; detections bit-identical",
                              "lookahead_ms_per_step": look_ms.value / max(1, steps_local), "lookahead_tflops_eq": look_fl.value / max(look_ms.value, 1e-9) / 1e9,
                              "pixels_recomputed_exactly": {"P2": sel_frac[0], "P3": sel_frac[1]},
+                             "worst_observed_error_over_bound": worst_ratio.value,
                              "note": "achieved / frac / launches above count the fp32 kernels only, the gathered launches on their selected rows; "
                                      "the look-ahead launches (fp16 matrix pipe) are booked here"},
                          "reference_algorithmic_tflops": (0.8416e12 if headline else 0.0) * pool_total / dt / 1e12 if headline else None,

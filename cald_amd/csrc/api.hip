@@ -64,6 +64,8 @@ struct cald_ctx {
     hipEvent_t tot0 = nullptr, tot1 = nullptr; bool tot_open = false; double tot_ms = 0.0;
     // RoI-head GEMMs run on a device-side row count (proposals after NMS): the profile counts their algorithmic FLOPs on the
     // MEASURED rows, accumulated on the device while profiling (no host sync inside a forward)
+    float prune_worst = 0.0f;                     // largest ratio any sweep of this context has seen (cald_profile_prune)
+    float* d_prune_check = nullptr;               // rpn_prune.hip: running max of |look-ahead - exact| / bound (reset by every sweep call)
     unsigned long long* d_prune_stat = nullptr;   // rpn_prune.hip: selected / total pixels of P2, P3 while profiling
     unsigned long long* d_roi_rows = nullptr; double prof_roi_rows_cap = 0.0, prof_roi_flops_cap = 0.0; long long prof_roi_views = 0;
     std::map<PilKey, PilCoef> pil;
@@ -149,6 +151,8 @@ extern "C" int cald_ctx_create(int device, void* stream, cald_ctx** out) {
     HIPCHK(hipMemset(c->d_roi_rows, 0, 8));
     HIPCHK(hipMalloc((void**)&c->d_prune_stat, 32));
     HIPCHK(hipMemset(c->d_prune_stat, 0, 32));
+    HIPCHK(hipMalloc((void**)&c->d_prune_check, 8));
+    HIPCHK(hipMemset(c->d_prune_check, 0, 8));
     for (int i = 0; i < cald_ctx::NSTAGE; i++) {
         HIPCHK(hipHostMalloc((void**)&c->h_stage[i], sizeof(BatchPlan) + sizeof(ViewDesc) * CALD_MAX_VIEWS));
         HIPCHK(hipEventCreateWithFlags(&c->stage_ev[i], hipEventDisableTiming));
@@ -174,7 +178,7 @@ extern "C" int cald_ctx_destroy(cald_ctx* c) {
     if (c->train_scratch) hipFree(c->train_scratch);
     cald_internal_train_release(c);
     for (int i = 0; i < cald_ctx::NSTAGE; i++) { if (c->h_stage[i]) hipHostFree(c->h_stage[i]); if (c->stage_ev[i]) hipEventDestroy(c->stage_ev[i]); }
-    hipFree(c->d_plan); hipFree(c->d_views); hipFree(c->d_zeros); hipFree(c->d_roi_rows); hipFree(c->d_prune_stat);
+    hipFree(c->d_plan); hipFree(c->d_views); hipFree(c->d_zeros); hipFree(c->d_roi_rows); hipFree(c->d_prune_stat); hipFree(c->d_prune_check);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
     return 0;
@@ -217,7 +221,7 @@ extern "C" int cald_profile_read(cald_ctx* c, double* gemm_ms, double* gemm_flop
     return 0;
 }
 
-extern "C" int cald_profile_prune(cald_ctx* c, double* look_ms, double* look_flops, double* selected_frac2) {
+extern "C" int cald_profile_prune(cald_ctx* c, double* look_ms, double* look_flops, double* selected_frac2, double* worst_bound_ratio) {
     if (!c) return fail(CALD_ERR_INVALID, "ctx is null");
     HIPCHK(hipStreamSynchronize(c->stream));
     double ms = 0.0, fl = 0.0;
@@ -228,6 +232,7 @@ extern "C" int cald_profile_prune(cald_ctx* c, double* look_ms, double* look_flo
     if (look_ms) *look_ms = ms;
     if (look_flops) *look_flops = fl;
     if (selected_frac2) for (int l = 0; l < 2; l++) selected_frac2[l] = st[2 * l + 1] ? (double)st[2 * l] / (double)st[2 * l + 1] : 0.0;
+    if (worst_bound_ratio) *worst_bound_ratio = (double)c->prune_worst;
     return 0;
 }
 
@@ -1144,7 +1149,7 @@ static int forward_model(cald_model* m, int V, ViewDesc* views, const DetBuffers
             pr.feat[i] = F.Pf[i]; pr.seg[i] = dp->seg[2 + i]; pr.energy[i] = F.prune_energy[i]; pr.head[i] = F.rpn_h[i]; pr.head_out[i] = F.rpn_h[i];
             pr.head_rows[i] = F.prune_rows[i]; pr.row_map[i] = F.prune_map[i];
         }
-        pr.nsel = F.prune_nsel; pr.stat = c->prof ? c->d_prune_stat : nullptr;
+        pr.nsel = F.prune_nsel; pr.stat = c->prof ? c->d_prune_stat : nullptr; pr.check = c->d_prune_check;
         for (int q = 0; q < 3; q++) { pr.c1[q] = m->prune_c1[q]; pr.c0[q] = m->prune_c0[q]; }
         pr.head_ld = 15; pr.pre_n = m->cfg.rpn_pre_nms_top_n; pr.V = V;
         launch_rpn_prune_select(pr, max_pix2, st);
@@ -1678,6 +1683,7 @@ static int sweep_impl(cald_model* m, int n_images, const uint8_t* const* images_
     }
     int rc = 0;
     const int fwd_views = sweep_fwd_views();
+    if (m->prune) HIPCHK(hipMemsetAsync(c->d_prune_check, 0, 8, c->stream));
 
     // reference views of batch k -> detections into set k & 1, counts + boxes to the pinned host set, event
     auto enqueue_ref = [&](int k) -> int {
@@ -1904,6 +1910,14 @@ static int sweep_impl(cald_model* m, int n_images, const uint8_t* const* images_
     }
     for (int k = (NB >= 2 ? NB - 2 : 0); k < NB && !rc; k++) rc = finish(k);
     if (rc) hipStreamSynchronize(c->stream);
+    if (!rc && m->prune && NB > 0) {
+        // the certified pruning's bound, checked on every anchor that was evaluated both ways (15 - 60 % of P2 / P3): a violation means the
+        // look-ahead's error model is wrong on this data -- refuse the result rather than risk a detection the dense head would not give
+        float worst = 0.0f;
+        HIPCHK(hipMemcpy(&worst, c->d_prune_check, 4, hipMemcpyDeviceToHost));
+        c->prune_worst = worst > c->prune_worst ? worst : c->prune_worst;
+        if (!(worst <= 1.0f)) return fail(CALD_ERR_STATE, "RPN pruning: |look-ahead - exact| reached %.3g x its bound (must stay <= 1); rerun with CALD_RPN_PRUNE=0", (double)worst);
+    }
     return rc;
 }
 extern "C" int cald_sweep(cald_model* m, int n_images, const uint8_t* const* images_dev, const int* H, const int* W,

@@ -5,10 +5,10 @@
 // anchor's logit or deltas.  The RPN head (3 x 3 conv 256 -> 256 + ReLU, 1 x 1 -> 15; frcnn_la.py:199-203) is 23 % of a view's FLOPs and
 // P2 + P3 carry 94 % of its pixels.  The exact sweep therefore computes the head in two steps on those two levels:
 //   1. everywhere, cheaply: the 3 x 3 conv on the fp16 matrix pipe (conv_h3.hip, 3 MFMAs per product, ~2.5 x the fp32 rate), the 1 x 1 head on
-//      the exact kernel -> approximate logits L~ with a PROVEN error bound B(anchor) against the exact mode's own value L (below);
+//      the exact kernel -> approximate logits L~ with an error bound B(anchor) against the exact mode's own value L (below);
 //   2. only where it can matter, exactly: tau = the k-th largest LOWER bound L~ - B.  At least k anchors have L >= tau, so an anchor with
-//      L~ + B < tau is not among the k largest of L, whatever the rounding did.  The pixels that hold a surviving anchor (7 - 10 % of P2,
-//      ~half of P3) are recomputed by the exact kernels as gathered rows (ConvArgs::row_map) -- per output element the same k-ordered
+//      L~ + B < tau is not among the k largest of L, whatever the rounding did.  The pixels that hold a surviving anchor (~15 % of P2,
+//      ~60 % of P3 on the configs[1] pool) are recomputed by the exact kernels as gathered rows (ConvArgs::row_map) -- per output element the same k-ordered
 //      fp32 fma chain as the dense launch, hence the same bits -- and scattered back; all other anchors get logit -FLT_MAX.
 // The top-k, decode, NMS and everything after see the exact mode's values at every anchor that can be selected: the detections, and
 // with them scores and selection, are bit-identical to the unpruned sweep (tests: every sweep-vs-oracle test runs through this path;
@@ -23,6 +23,13 @@
 // both hidden vectors: |L~ - L| <= sum_c |v_ac| |h_e - h_f| + 2 g_h sum_c |v_ac| max(|h_e|, |h_f|), g_h = 256 u / (1 - 256 u), and
 // |h| <= |patch|_2 |w_c|_2 + |b_c|.  Per anchor a this is  B_a(p) = c1_a |patch(p)|_2 + c0_a  with two constants fixed at model finalize
 // (api.hip); both are inflated by 2 % for the float32 evaluation of the bound itself.
+// What is a theorem and what is a model: g_e and g_h are the textbook bounds of the fp32 chains the exact mode IS; the split error of the
+// operands is exact arithmetic on the formats; "one rounding of relative size 2^-23 per MFMA instruction" is a MODEL of
+// v_mfma_f32_32x32x16_f16's internal adder (tools/mfma_f16_probe.hip: the pipe aligns the 16 products to a common exponent with a finite
+// width; measured errors of whole layers stay below 2^-20 S, tests/test_gpu_parity.py::test_conv_f16x3_within_split_precision_of_exact,
+// i.e. > 50 x inside g_f S).  Because a model is not a proof, every sweep PUTS THE BOUND TO THE TEST: each selected anchor is evaluated
+// both ways, prune_scatter_kernel keeps max |L~ - L| / B over all of them (15 - 60 % of all anchors of the two levels, hundreds of thousands
+// per forward), and cald_sweep fails loudly if the ratio ever exceeds 1 (observed: < 0.1, cald_profile_prune).
 #include "common.h"
 #include "kernels.h"
 #include <cfloat>
@@ -142,18 +149,32 @@ __global__ __launch_bounds__(1024) void prune_select_kernel(RpnPruneArgs a) {
         if (!((mask[p >> 5] >> (p & 31)) & 1u)) { headw[(long long)p * a.head_ld] = -FLT_MAX; headw[(long long)p * a.head_ld + 1] = -FLT_MAX; headw[(long long)p * a.head_ld + 2] = -FLT_MAX; }
 }
 
-// the exact head rows of the selected pixels back into the dense [pixel][head_ld] map.  grid = (blocks, V, 2)
+// the exact head rows of the selected pixels back into the dense [pixel][head_ld] map -- and the bound put to the test: every selected anchor
+// has both values, the look-ahead's L~ (still in the map) and the exact L; max |L~ - L| / B over all of them goes to a.check[0]
+// (non-negative floats order like their bit patterns).  A ratio above 1 would mean the bound's model of the matrix pipe is wrong:
+// the sweep then fails loudly instead of returning detections that might differ from the dense head's (api.hip).  grid = (blocks, V, 2)
 __global__ __launch_bounds__(256) void prune_scatter_kernel(RpnPruneArgs a) {
     const int l = blockIdx.z, v = blockIdx.y;
     const LevelSeg sg = a.seg[l][v];
     const int ns = a.nsel[l * a.V + v], ld = a.head_ld;
     const int* rmap = a.row_map[l] + sg.pix_off;
     const float* src = a.head_rows[l] + sg.pix_off * (long long)ld;
+    const float* en = a.energy[l] + sg.pix_off;
     float* dst = a.head_out[l] + sg.pix_off * (long long)ld;
+    float worst = 0.0f;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < ns * ld; i += gridDim.x * 256) {
         const int r = i / ld, c = i - r * ld;
-        dst[(long long)rmap[r] * ld + c] = src[i];
+        const int p = rmap[r];
+        const float exact = src[i];
+        if (c < 3) {
+            const float approx = dst[(long long)p * ld + c];
+            const float B = a.c1[c] * prune_patch_norm(en, p / sg.W, p % sg.W, sg.H, sg.W) + a.c0[c];
+            const float ratio = fabsf(approx - exact) / B;
+            worst = (ratio == ratio) ? fmaxf(worst, ratio) : INFINITY;
+        }
+        dst[(long long)p * ld + c] = exact;
     }
+    if (worst > 0.0f && a.check) atomicMax(reinterpret_cast<unsigned*>(a.check), __float_as_uint(worst));
 }
 }   // namespace
 

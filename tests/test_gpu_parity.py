@@ -1488,12 +1488,14 @@ def test_certified_rpn_pruning_is_bit_identical_to_the_dense_head(hip):
         assert m.set_rpn_prune(True) is True                      # on by default
         ffi.check(L.cald_profile_enable(hip["ctx"], 1))
         c1, k1 = sweep.sweep_device_images(m, dev, pos, augs, bp=1.3, base_seed=7, batch_images=24)
-        ms, fl = C.c_double(), C.c_double(); frac = (C.c_double * 2)()
-        ffi.check(L.cald_profile_prune(hip["ctx"], C.byref(ms), C.byref(fl), frac))
+        ms, fl, worst = C.c_double(), C.c_double(), C.c_double(); frac = (C.c_double * 2)()
+        ffi.check(L.cald_profile_prune(hip["ctx"], C.byref(ms), C.byref(fl), frac, C.byref(worst)))
         ffi.check(L.cald_profile_enable(hip["ctx"], 0))
         m.set_rpn_prune(False)
         c0, k0 = sweep.sweep_device_images(m, dev, pos, augs, bp=1.3, base_seed=7, batch_images=24)
-        print("R%d %s: P2 %.3f, P3 %.3f of the pixels recomputed exactly; look-ahead %.1f TF-eq" % (depth, shape, frac[0], frac[1], fl.value / max(ms.value, 1e-9) / 1e9))
+        print("R%d %s: P2 %.3f, P3 %.3f of the pixels recomputed exactly; look-ahead %.1f TF-eq; worst |look-ahead - exact| / bound %.2e"
+              % (depth, shape, frac[0], frac[1], fl.value / max(ms.value, 1e-9) / 1e9, worst.value))
+        assert 0.0 < worst.value < 0.25          # the bound holds with a wide margin on every anchor evaluated both ways
         assert c1.tobytes() == c0.tobytes() and k1.tobytes() == k0.tobytes()
         assert 0.0 < frac[0] < 0.5 and 0.0 < frac[1] <= 1.0 and ms.value > 0
         del m
