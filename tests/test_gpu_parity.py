@@ -567,7 +567,7 @@ def test_full_size_64_image_batch_last_views_vs_oracle(hip, oracle):
     c, k = sweep.sweep_device_images(model, dev, pos, augs, base_seed=6, batch_images=64)
     c96, k96 = sweep.sweep_device_images(model, dev, pos, augs, base_seed=6, batch_images=35)
     np.testing.assert_array_equal(c, c96); np.testing.assert_array_equal(k, k96)
-    exact = [44, 61, 62, 63, 64, 69]
+    exact = [44, 63, 64, 69]                   # the last image of the full batch, the first and the last of the ragged tail, one inside
     P = oracle.prepare_frcnn(sd, 21, 50)
     oracle.set_threads(min(128, os.cpu_count() or 1))
     try:
@@ -669,7 +669,7 @@ def test_config3_full_size_frcnn_r50_coco(hip, oracle):
 def test_config4_full_size_frcnn_r101_coco_five_augs(hip, oracle):
     """BASELINE.json configs[4]: Faster R-CNN ResNet-101 FPN, COCO shapes, 5 augmentations (FCDR + G: flip, ga, cut_out,
     smaller_resize, rotation -> 6 views per image), exact fp32."""
-    _full_size_coco_case(hip, oracle, 101, ["flip", "ga", "cut_out", "smaller_resize", "rotation"], (0, 5, 7, 10), seed=1)   # 4 of 12: a ResNet-101 image with six views costs the CPU oracle ~20 s
+    _full_size_coco_case(hip, oracle, 101, ["flip", "ga", "cut_out", "smaller_resize", "rotation"], (0, 5, 10), seed=1)   # 3 of 12: a ResNet-101 image with six views costs the CPU oracle ~30 s
 
 
 def test_config4_full_size_f16x3_vs_exact(hip):

@@ -41,8 +41,12 @@ for key, pat in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write"), ("MFM
     for name in agg:
         for c in agg[name]:
             summary.setdefault(name, {})[c] = {"sum": agg[name][c], "dispatches": cnt[name][c], "avg": agg[name][c] / cnt[name][c]}
-def is_gemm(name):
-    return any(t in name for t in ("conv_mfma", "conv_p4", "conv_fused", "conv_stem", "conv_h3", "conv_h4"))
+def is_gemm(name):          # the exact mode's GEMM family; the split-fp16 look-ahead of rpn_prune.hip (conv_h3) is summarised apart
+    return any(t in name for t in ("conv_mfma", "conv_p4", "conv_fused", "conv_stem"))
+
+
+def is_lookahead(name):
+    return any(t in name for t in ("conv_h3", "conv_h4"))
 
 
 gemm_ns = gemm_calls = 0
@@ -71,5 +75,12 @@ if summary:
                          # counter bytes per launch / the --stats run's average launch duration of the same kernels
                          "avg_launch_ns": avg_ns,
                          "hbm_gbps": (bytes_per_launch / avg_ns) if (bytes_per_launch and avg_ns) else None}}
+    look = {k: v for k, v in summary.items() if is_lookahead(k)}
+    if look:
+        lf = sum(v.get("FETCH_SIZE", {}).get("sum", 0) for v in look.values()); lw = sum(v.get("WRITE_SIZE", {}).get("sum", 0) for v in look.values())
+        ln = sum(v.get("FETCH_SIZE", {}).get("dispatches", 0) for v in look.values())
+        lm = sum(v.get("SQ_VALU_MFMA_BUSY_CYCLES", {}).get("sum", 0) for v in look.values()); lg = sum(v.get("GRBM_GUI_ACTIVE", {}).get("sum", 0) for v in look.values())
+        out["rpn_prune_lookahead"] = {"dispatches": ln, "hbm_bytes_per_launch": ((2.0 * lf + lw) * 1024.0 / ln) if ln else None,
+                                      "mfma_busy": (lm / lg / 128.0) if lg else None}
     json.dump(out, open(os.path.join(dst, "%s_pmc.json" % tag), "w"), indent=1)
     print("pmc ->", os.path.join(dst, "%s_pmc.json" % tag), out["conv_mfma"])
