@@ -258,7 +258,9 @@ int cald_profile_dump(cald_ctx* ctx, const char* path);
  * cuDNN autograd.  cald_amd/train.py strings them into the Faster R-CNN training graph.  All pointers are DEVICE pointers,
  * activations are dense NHWC batches [N][H][W][C], every call is asynchronous on the context stream EXCEPT cald_train_preprocess,
  * cald_train_anchors and cald_train_rpn_proposals, which stage small host tables (view descriptors, base anchors, proposal counts)
- * and synchronise the context stream before they return. ---- */
+ * and synchronise the context stream before they return.
+ * Threading: the cald_train_* entry points share one process-wide cache of batch-geometry tables; they are NOT thread-safe, not even across
+ * contexts -- call them from one thread per process (one process per GPU is the model everywhere in this library). ---- */
 /* size in floats of the packed form of a torch-layout weight [Cout][Cin][KH][KW] (see cald_train_pack_conv) */
 int cald_train_packed_floats(int Cout, int Cin, int KH, int KW, int CinK, int mode, int64_t* floats_out);
 /* packs weight (+ optional bias / FrozenBatchNorm scale, shift: [Cout]) for the MFMA conv kernels, on the device.
