@@ -511,8 +511,8 @@ def main():
     _ffi.check(L.cald_profile_read(ctx, C.byref(gm), C.byref(gf), C.byref(nl), C.byref(tot)))
     _ffi.check(L.cald_profile_roi_rows(ctx, C.byref(mean_r), C.byref(nviews)))
     look_ms, look_fl = C.c_double(), C.c_double(); sel_frac = (C.c_double * 2)()
-    worst_ratio = C.c_double()
-    _ffi.check(L.cald_profile_prune(ctx, C.byref(look_ms), C.byref(look_fl), sel_frac, C.byref(worst_ratio)))
+    worst_ratio, pruned_fl = C.c_double(), C.c_double()
+    _ffi.check(L.cald_profile_prune(ctx, C.byref(look_ms), C.byref(look_fl), sel_frac, C.byref(worst_ratio), C.byref(pruned_fl)))
     if os.environ.get("CALD_PROFILE_DUMP"):
         _ffi.check(L.cald_profile_dump(ctx, os.environ["CALD_PROFILE_DUMP"].encode()))
     _ffi.check(L.cald_profile_enable(ctx, 0))
@@ -574,6 +574,11 @@ def main():
                              "worst_observed_error_over_bound": worst_ratio.value,
                              "note": "achieved / frac / launches above count the fp32 kernels only, the gathered launches on their selected rows; "
                                      "the look-ahead launches (fp16 matrix pipe) are booked here"},
+                         "algorithmic": None if look_ms.value <= 0 else {
+                             "tflops": (gf.value + pruned_fl.value) / ((gm.value + look_ms.value) * 1e-3) / 1e12,
+                             "frac": (gf.value + pruned_fl.value) / ((gm.value + look_ms.value) * 1e-3) / 1e12 / peak,
+                             "note": "the dense graph's fp32 FLOPs (executed + pruned away) / (fp32 kernel time + look-ahead time): the task contract's "
+                                     "'algorithmic FLOPs / launch duration'; `frac` above is the stricter one -- only FLOPs the fp32 kernels really execute"},
                          "reference_algorithmic_tflops": (0.8416e12 if headline else 0.0) * pool_total / dt / 1e12 if headline else None,
                          "note": "rank 0's launches, HIP events on the launch stream; RoI-head FLOPs counted on the measured proposal rows; "
                                  "reference_algorithmic_tflops = images/s x 0.84 TFLOP per image (4 views x 105.2 GMAC, SURVEY 8d), what the reference's dense graph would cost"},

@@ -95,7 +95,7 @@ SIGNATURES = {
     "cald_jpeg_decode_batch": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p)]),
     "cald_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "cald_profile_read": (C.c_int, [C.c_void_p, c_d, c_d, c_i64, c_d]),
-    "cald_profile_prune": (C.c_int, [C.c_void_p, c_d, c_d, c_d, c_d]),
+    "cald_profile_prune": (C.c_int, [C.c_void_p, c_d, c_d, c_d, c_d, c_d]),
     "cald_profile_roi_rows": (C.c_int, [C.c_void_p, c_d, c_i64]),
     "cald_profile_dump": (C.c_int, [C.c_void_p, C.c_char_p]),
     # training step (device pointers as c_void_p)

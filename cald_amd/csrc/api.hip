@@ -221,7 +221,7 @@ extern "C" int cald_profile_read(cald_ctx* c, double* gemm_ms, double* gemm_flop
     return 0;
 }
 
-extern "C" int cald_profile_prune(cald_ctx* c, double* look_ms, double* look_flops, double* selected_frac2, double* worst_bound_ratio) {
+extern "C" int cald_profile_prune(cald_ctx* c, double* look_ms, double* look_flops, double* selected_frac2, double* worst_bound_ratio, double* pruned_flops) {
     if (!c) return fail(CALD_ERR_INVALID, "ctx is null");
     HIPCHK(hipStreamSynchronize(c->stream));
     double ms = 0.0, fl = 0.0;
@@ -233,6 +233,11 @@ extern "C" int cald_profile_prune(cald_ctx* c, double* look_ms, double* look_flo
     if (look_flops) *look_flops = fl;
     if (selected_frac2) for (int l = 0; l < 2; l++) selected_frac2[l] = st[2 * l + 1] ? (double)st[2 * l] / (double)st[2 * l + 1] : 0.0;
     if (worst_bound_ratio) *worst_bound_ratio = (double)c->prune_worst;
+    if (pruned_flops) {      // exact FLOPs of the dense head that the gathered launches did NOT execute (cald_profile_read leaves them out)
+        double fl2 = 0.0;
+        for (int l = 0; l < 2; l++) if (st[2 * l + 1]) fl2 += c->prof_prune_flops_cap[l] * (1.0 - (double)st[2 * l] / (double)st[2 * l + 1]);
+        *pruned_flops = fl2;
+    }
     return 0;
 }
 
@@ -796,7 +801,7 @@ struct FwdBufs {
     // decision-margin audit (audit.hip): what the RPN / post-processing kernels leave behind for it
     unsigned long long *next_key, *trunc_key, *kept_key; float* post_maxc;
     // certified RPN pruning (rpn_prune.hip), levels P2 / P3
-    float *prune_energy[2], *prune_rows[2]; int *prune_map[2], *prune_nsel;
+    float *prune_energy[2], *prune_pn[2], *prune_rows[2]; int *prune_map[2], *prune_nsel;
 };
 
 static double fill_conv_args(cald_model* m, ConvArgs& a, const ConvLayer& L, const float* in, float* out, int lin, int lout, int V, bool relu,
@@ -994,7 +999,7 @@ static void fwd_layout(cald_model* m, Bump& B, FwdBufs& F, int V) {
     F.cbox = B.get<float>((size_t)V * 2 * m->key_cap * 4);
     F.key_count = B.get<int>(V);
     for (int i = 0; i < 2; i++) {
-        F.prune_energy[i] = B.get<float>(px[2 + i]); F.prune_rows[i] = B.get<float>(px[2 + i] * 15); F.prune_map[i] = B.get<int>(px[2 + i]);
+        F.prune_energy[i] = B.get<float>(px[2 + i]); F.prune_pn[i] = B.get<float>(px[2 + i]); F.prune_rows[i] = B.get<float>(px[2 + i] * 15); F.prune_map[i] = B.get<int>(px[2 + i]);
     }
     F.prune_nsel = B.get<int>((size_t)2 * V);
     F.next_key = B.get<unsigned long long>((size_t)V * 10); F.trunc_key = B.get<unsigned long long>((size_t)V * 2);
@@ -1146,7 +1151,7 @@ static int forward_model(cald_model* m, int V, ViewDesc* views, const DetBuffers
         if (c->prof) for (int i = 0; i < 2; i++) c->prof_prune_flops_cap[i] += 2.0 * (double)level_pix(m->plan, 2 + i, V) * (2304.0 * 256.0 + 256.0 * 15.0);
         RpnPruneArgs pr;
         for (int i = 0; i < 2; i++) {
-            pr.feat[i] = F.Pf[i]; pr.seg[i] = dp->seg[2 + i]; pr.energy[i] = F.prune_energy[i]; pr.head[i] = F.rpn_h[i]; pr.head_out[i] = F.rpn_h[i];
+            pr.feat[i] = F.Pf[i]; pr.seg[i] = dp->seg[2 + i]; pr.energy[i] = F.prune_energy[i]; pr.pnorm[i] = F.prune_pn[i]; pr.head[i] = F.rpn_h[i]; pr.head_out[i] = F.rpn_h[i];
             pr.head_rows[i] = F.prune_rows[i]; pr.row_map[i] = F.prune_map[i];
         }
         pr.nsel = F.prune_nsel; pr.stat = c->prof ? c->d_prune_stat : nullptr; pr.check = c->d_prune_check;

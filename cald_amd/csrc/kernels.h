@@ -150,6 +150,7 @@ struct RpnPruneArgs {
     const float* feat[2];        // P2, P3: fp32 [pixel][256]
     const LevelSeg* seg[2];
     float* energy[2];            // [pixel] scratch: sum of squares over the 256 channels
+    float* pnorm[2];             // [pixel] scratch: |3 x 3 patch|_2 (select kernel -> scatter kernel)
     const float* head[2];        // approximate head maps [pixel][head_ld] (logits = channels 0..2)
     float* head_out[2];          // the same buffers: unselected pixels get logit -FLT_MAX, selected ones their exact rows
     const float* head_rows[2];   // exact head rows of the selected pixels, compact [n_selected][head_ld] per view (at the view's pixel offset)

@@ -74,12 +74,14 @@ __global__ __launch_bounds__(1024) void prune_select_kernel(RpnPruneArgs a) {
     const int k = n < a.pre_n ? n : a.pre_n;
     const float* head = a.head[l] + sg.pix_off * (long long)a.head_ld;
     const float* en = a.energy[l] + sg.pix_off;
+    float* pnv = a.pnorm[l] + sg.pix_off;           // |patch|_2 per pixel: written once below, re-read by the SAME thread in every pass (and by the scatter kernel)
     int* rmap = a.row_map[l] + sg.pix_off;
     const int words = (npx + 31) >> 5;
     for (int i = tid; i < words; i += 1024) mask[i] = 0u;
     if (tid == 0) { s_prefix = 0u; s_mask = 0u; s_remaining = k; }
     __syncthreads();
     auto bound = [&](int p, int an, float pn) { return a.c1[an] * pn + a.c0[an]; };
+    for (int p = tid; p < npx; p += 1024) pnv[p] = prune_patch_norm(en, p / W, p % W, H, W);
     if (n > k) {
         for (int pass = 0; pass < 4; pass++) {                  // the k-th largest of the lower bounds, 8 bits per pass
             const int shift = 24 - 8 * pass;
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(1024) void prune_select_kernel(RpnPruneArgs a) {
             __syncthreads();
             const unsigned prefix = s_prefix, msk = s_mask;
             for (int p = tid; p < npx; p += 1024) {
-                const float pn = prune_patch_norm(en, p / W, p % W, H, W);
+                const float pn = pnv[p];
                 for (int an = 0; an < A; an++) {
                     const unsigned key = det_orderable(head[(long long)p * a.head_ld + an] - bound(p, an, pn));
                     if ((key & msk) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1);
@@ -107,7 +109,7 @@ __global__ __launch_bounds__(1024) void prune_select_kernel(RpnPruneArgs a) {
     }
     const unsigned tau = (n > k) ? s_prefix : 0u;               // orderable key of the k-th largest lower bound (0: every anchor stays)
     for (int p = tid; p < npx; p += 1024) {
-        const float pn = prune_patch_norm(en, p / W, p % W, H, W);
+        const float pn = pnv[p];
         bool keep = false;
         for (int an = 0; an < A; an++) {
             const float lg = head[(long long)p * a.head_ld + an];
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(256) void prune_scatter_kernel(RpnPruneArgs a) {
     const int ns = a.nsel[l * a.V + v], ld = a.head_ld;
     const int* rmap = a.row_map[l] + sg.pix_off;
     const float* src = a.head_rows[l] + sg.pix_off * (long long)ld;
-    const float* en = a.energy[l] + sg.pix_off;
+    const float* pnv = a.pnorm[l] + sg.pix_off;
     float* dst = a.head_out[l] + sg.pix_off * (long long)ld;
     float worst = 0.0f;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < ns * ld; i += gridDim.x * 256) {
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(256) void prune_scatter_kernel(RpnPruneArgs a) {
         const float exact = src[i];
         if (c < 3) {
             const float approx = dst[(long long)p * ld + c];
-            const float B = a.c1[c] * prune_patch_norm(en, p / sg.W, p % sg.W, sg.H, sg.W) + a.c0[c];
+            const float B = a.c1[c] * pnv[p] + a.c0[c];
             const float ratio = fabsf(approx - exact) / B;
             worst = (ratio == ratio) ? fmaxf(worst, ratio) : INFINITY;
         }

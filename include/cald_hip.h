@@ -246,8 +246,10 @@ int cald_profile_read(cald_ctx* ctx, double* gemm_ms, double* gemm_flops, int64_
 /* the exact sweep's certified RPN pruning: time and algorithmic FLOPs of its split-fp16 look-ahead launches
  * (NOT part of cald_profile_read's figures, which then count the exact kernels only, the gathered launches on their selected rows) and
  * the fraction of P2 / P3 pixels whose head was recomputed exactly; worst_bound_ratio = the largest |look-ahead - exact| / bound any sweep of
- * this context has observed on the anchors evaluated both ways (every sweep checks it and fails if it exceeds 1) */
-int cald_profile_prune(cald_ctx* ctx, double* lookahead_ms, double* lookahead_flops, double* selected_fraction_p2_p3, double* worst_bound_ratio);
+ * this context has observed on the anchors evaluated both ways (every sweep checks it and fails if it exceeds 1); pruned_flops = the
+ * dense head's exact FLOPs that were not executed */
+int cald_profile_prune(cald_ctx* ctx, double* lookahead_ms, double* lookahead_flops, double* selected_fraction_p2_p3, double* worst_bound_ratio,
+                       double* pruned_flops);
 /* mean proposals per view (R of SURVEY 8d) over the Faster R-CNN forwards profiled since cald_profile_enable */
 int cald_profile_roi_rows(cald_ctx* ctx, double* mean_rows_per_view, int64_t* views);
 /* per-launch CSV (shape, algorithmic GFLOP, ms, TFLOP/s) of the launches recorded since cald_profile_enable */

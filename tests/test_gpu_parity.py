@@ -1489,7 +1489,7 @@ def test_certified_rpn_pruning_is_bit_identical_to_the_dense_head(hip):
         ffi.check(L.cald_profile_enable(hip["ctx"], 1))
         c1, k1 = sweep.sweep_device_images(m, dev, pos, augs, bp=1.3, base_seed=7, batch_images=24)
         ms, fl, worst = C.c_double(), C.c_double(), C.c_double(); frac = (C.c_double * 2)()
-        ffi.check(L.cald_profile_prune(hip["ctx"], C.byref(ms), C.byref(fl), frac, C.byref(worst)))
+        ffi.check(L.cald_profile_prune(hip["ctx"], C.byref(ms), C.byref(fl), frac, C.byref(worst), None))
         ffi.check(L.cald_profile_enable(hip["ctx"], 0))
         m.set_rpn_prune(False)
         c0, k0 = sweep.sweep_device_images(m, dev, pos, augs, bp=1.3, base_seed=7, batch_images=24)
@@ -1500,3 +1500,35 @@ def test_certified_rpn_pruning_is_bit_identical_to_the_dense_head(hip):
         assert 0.0 < frac[0] < 0.5 and 0.0 < frac[1] <= 1.0 and ms.value > 0
         del m
         torch.cuda.empty_cache()
+
+
+@pytest.mark.gpu
+def test_certified_rpn_pruning_on_tiny_and_odd_images(hip, oracle):
+    """The pruning's corner cases: images so small that P2 / P3 hold fewer anchors than pre_nms_top_n (nothing can be pruned: every pixel is
+    selected and the gathered launch is the dense one in another order), odd sizes, a batch that mixes them with full-size views -- pruned ==
+    dense bit for bit, and == the oracle on the small ones."""
+    torch = hip["torch"]
+    from cald_amd import synth, sweep
+    sd = synth.pseudo_trained_frcnn(21, 50, seed=0)
+    m = hip["det"].fasterrcnn_resnet50_fpn_feature(num_classes=21, min_size=600, max_size=1000).to("cuda")
+    m.load_state_dict(sd); m.eval()
+    imgs = [synth.synth_image(900 + i, h, w) for i, (h, w) in enumerate([(375, 500), (32, 40), (500, 333), (61, 47), (97, 401), (375, 500)])]
+    dev = [torch.from_numpy(im).cuda() for im in imgs]
+    pos = list(range(len(dev)))
+    augs = ["flip", "cut_out", "smaller_resize"]
+    m.set_rpn_prune(True)
+    c1, k1 = sweep.sweep_device_images(m, dev, pos, augs, bp=1.3, base_seed=11, batch_images=6)
+    m.set_rpn_prune(False)
+    c0, k0 = sweep.sweep_device_images(m, dev, pos, augs, bp=1.3, base_seed=11, batch_images=6)
+    assert c1.tobytes() == c0.tobytes() and k1.tobytes() == k0.tobytes()
+    m2 = hip["det"].fasterrcnn_resnet50_fpn_feature(num_classes=21, min_size=64, max_size=128).to("cuda")      # P2 = 16 x 32 ... : 1 536 anchors, P3 384 < 1000
+    m2.load_state_dict(sd); m2.eval()
+    tiny = [synth.synth_image(950 + i, 64, 128) for i in range(3)]
+    td = [torch.from_numpy(im).cuda() for im in tiny]
+    a1 = sweep.sweep_device_images(m2, td, [0, 1, 2], ["flip"], bp=1.3, base_seed=3, batch_images=3)
+    m2.set_rpn_prune(False)
+    a0 = sweep.sweep_device_images(m2, td, [0, 1, 2], ["flip"], bp=1.3, base_seed=3, batch_images=3)
+    assert a1[0].tobytes() == a0[0].tobytes() and a1[1].tobytes() == a0[1].tobytes()
+    P = oracle.prepare_frcnn(sd, 21, 50)
+    wc, wk = oracle.get_uncertainty(P, tiny, ["flip"], 21, bp=1.3, min_size=64, max_size=128, base_seed=3, positions=[0, 1, 2])
+    np.testing.assert_array_equal(a1[0], np.array(wc)); np.testing.assert_array_equal(a1[1], np.stack(wk))
