@@ -801,7 +801,7 @@ struct FwdBufs {
     // decision-margin audit (audit.hip): what the RPN / post-processing kernels leave behind for it
     unsigned long long *next_key, *trunc_key, *kept_key; float* post_maxc;
     // certified RPN pruning (rpn_prune.hip), levels P2 / P3
-    float *prune_energy[2], *prune_pn[2], *prune_rows[2]; int *prune_map[2], *prune_nsel;
+    float *prune_energy[2], *prune_pn[2], *prune_rows[2]; int *prune_map[2], *prune_nsel; unsigned* prune_p16[2];
 };
 
 static double fill_conv_args(cald_model* m, ConvArgs& a, const ConvLayer& L, const float* in, float* out, int lin, int lout, int V, bool relu,
@@ -896,7 +896,7 @@ static int conv_pair_on(cald_model* m, const ConvLayer& L2, const ConvLayer& L3,
     return conv_on(m, L3, mid, out, lout, lout, V, true, residual);
 }
 // independent convolutions (bias / BN / ReLU epilogue only) issued as ONE launch when they fit the same tiled kernel
-struct ConvSpec { const ConvLayer* L; const float* in; float* out; int level; bool relu; const int* dyn = nullptr; const int* row_map = nullptr; };
+struct ConvSpec { const ConvLayer* L; const float* in; float* out; int level; bool relu; const int* dyn = nullptr; const int* row_map = nullptr; const unsigned* in16 = nullptr; };
 static int conv_group_on(cald_model* m, const ConvSpec* sp, int n, int V) {
     ConvArgs a[CALD_MAX_GROUP];
     double flops = 0.0; int tiles = 0;
@@ -904,6 +904,7 @@ static int conv_group_on(cald_model* m, const ConvSpec* sp, int n, int V) {
         const double f = fill_conv_args(m, a[i], *sp[i].L, sp[i].in, sp[i].out, sp[i].level, sp[i].level, V, sp[i].relu, nullptr, nullptr, 0, sp[i].dyn);
         if (f < 0.0) return (int)f;
         a[i].row_map = sp[i].row_map;
+        if (sp[i].in16) a[i].in16 = sp[i].in16;       // the input also exists in split form (rpn_prune.hip's look-ahead)
         flops += f; tiles += a[i].total_mtiles;
     }
     cald_ctx* c = m->ctx;
@@ -999,7 +1000,7 @@ static void fwd_layout(cald_model* m, Bump& B, FwdBufs& F, int V) {
     F.cbox = B.get<float>((size_t)V * 2 * m->key_cap * 4);
     F.key_count = B.get<int>(V);
     for (int i = 0; i < 2; i++) {
-        F.prune_energy[i] = B.get<float>(px[2 + i]); F.prune_pn[i] = B.get<float>(px[2 + i]); F.prune_rows[i] = B.get<float>(px[2 + i] * 15); F.prune_map[i] = B.get<int>(px[2 + i]);
+        F.prune_energy[i] = B.get<float>(px[2 + i]); F.prune_pn[i] = B.get<float>(px[2 + i]); F.prune_p16[i] = m->prune ? B.get<unsigned>(px[2 + i] * 256) : nullptr; F.prune_rows[i] = B.get<float>(px[2 + i] * 15); F.prune_map[i] = B.get<int>(px[2 + i]);
     }
     F.prune_nsel = B.get<int>((size_t)2 * V);
     F.next_key = B.get<unsigned long long>((size_t)V * 10); F.trunc_key = B.get<unsigned long long>((size_t)V * 2);
@@ -1141,22 +1142,24 @@ static int forward_model(cald_model* m, int V, ViewDesc* views, const DetBuffers
         // certified pruning (rpn_prune.hip): P2 / P3 first on the fp16 matrix pipe, then exactly at the pixels that can hold one of the
         // level's pre_nms_top_n anchors; P4..P6 dense as ever.  Same bits at every anchor the top-k can select.
         ConvSpec sp[5];
+        RpnPruneArgs pr;
+        static const bool look_h4 = !(getenv("CALD_RPN_PRUNE_H4") && atoi(getenv("CALD_RPN_PRUNE_H4")) == 0);     // 0: look-ahead on conv_h3's fp32 loader (A/B)
+        for (int i = 0; i < 2; i++) {
+            pr.feat[i] = F.Pf[i]; pr.seg[i] = dp->seg[2 + i]; pr.energy[i] = F.prune_energy[i]; pr.pnorm[i] = F.prune_pn[i]; pr.head[i] = F.rpn_h[i]; pr.head_out[i] = F.rpn_h[i];
+            pr.head_rows[i] = F.prune_rows[i]; pr.row_map[i] = F.prune_map[i]; pr.split[i] = look_h4 ? F.prune_p16[i] : nullptr;
+        }
+        pr.nsel = F.prune_nsel; pr.stat = c->prof ? c->d_prune_stat : nullptr; pr.check = c->d_prune_check;
+        for (int q = 0; q < 3; q++) { pr.c1[q] = m->prune_c1[q]; pr.c0[q] = m->prune_c0[q]; }
+        pr.head_ld = 15; pr.pre_n = m->cfg.rpn_pre_nms_top_n; pr.V = V;
+        launch_rpn_prune_energy(pr, st);
         prof_tag_now = 1;
-        for (int i = 0; i < 2; i++) sp[i] = {&m->rpn_conv16, F.Pf[i], F.rpn_tl[i], 2 + i, true};
+        for (int i = 0; i < 2; i++) { sp[i] = {&m->rpn_conv16, F.Pf[i], F.rpn_tl[i], 2 + i, true}; sp[i].in16 = pr.split[i]; }
         rc = conv_group_on(m, sp, 2, V);
         for (int i = 0; i < 2; i++) sp[i] = {&m->rpn_head, F.rpn_tl[i], F.rpn_h[i], 2 + i, false};
         if (!rc) rc = conv_group_on(m, sp, 2, V);
         prof_tag_now = 0;
         if (rc) return rc;
         if (c->prof) for (int i = 0; i < 2; i++) c->prof_prune_flops_cap[i] += 2.0 * (double)level_pix(m->plan, 2 + i, V) * (2304.0 * 256.0 + 256.0 * 15.0);
-        RpnPruneArgs pr;
-        for (int i = 0; i < 2; i++) {
-            pr.feat[i] = F.Pf[i]; pr.seg[i] = dp->seg[2 + i]; pr.energy[i] = F.prune_energy[i]; pr.pnorm[i] = F.prune_pn[i]; pr.head[i] = F.rpn_h[i]; pr.head_out[i] = F.rpn_h[i];
-            pr.head_rows[i] = F.prune_rows[i]; pr.row_map[i] = F.prune_map[i];
-        }
-        pr.nsel = F.prune_nsel; pr.stat = c->prof ? c->d_prune_stat : nullptr; pr.check = c->d_prune_check;
-        for (int q = 0; q < 3; q++) { pr.c1[q] = m->prune_c1[q]; pr.c0[q] = m->prune_c0[q]; }
-        pr.head_ld = 15; pr.pre_n = m->cfg.rpn_pre_nms_top_n; pr.V = V;
         launch_rpn_prune_select(pr, max_pix2, st);
         for (int i = 0; i < 5; i++) sp[i] = {&m->rpn_conv, F.Pf[i], F.rpn_tl[i], 2 + i, true};
         for (int i = 0; i < 2; i++) { sp[i].dyn = F.prune_nsel + i * V; sp[i].row_map = F.prune_map[i]; }      // gathered rows, compact output

@@ -150,6 +150,7 @@ struct RpnPruneArgs {
     const float* feat[2];        // P2, P3: fp32 [pixel][256]
     const LevelSeg* seg[2];
     float* energy[2];            // [pixel] scratch: sum of squares over the 256 channels
+    unsigned* split[2];          // optional [pixel][256] words: the split-fp16 form of P2 / P3 (h16.h) written by the energy kernel for the look-ahead conv
     float* pnorm[2];             // [pixel] scratch: |3 x 3 patch|_2 (select kernel -> scatter kernel)
     const float* head[2];        // approximate head maps [pixel][head_ld] (logits = channels 0..2)
     float* head_out[2];          // the same buffers: unselected pixels get logit -FLT_MAX, selected ones their exact rows
@@ -161,6 +162,7 @@ struct RpnPruneArgs {
     float c1[3], c0[3];          // bound per anchor: c1 * |patch|_2 + c0
     int head_ld, pre_n, V;
 };
+void launch_rpn_prune_energy(const RpnPruneArgs& a, hipStream_t st);       // before the look-ahead conv (writes its split-form input)
 void launch_rpn_prune_select(const RpnPruneArgs& a, int max_pix, hipStream_t st);
 void launch_rpn_prune_scatter(const RpnPruneArgs& a, hipStream_t st);
 

@@ -32,10 +32,13 @@
 // per forward), and cald_sweep fails loudly if the ratio ever exceeds 1 (observed: < 0.1, cald_profile_prune).
 #include "common.h"
 #include "kernels.h"
+#include "h16.h"
 #include <cfloat>
 
 namespace {
-// per pixel: sum over the 256 channels of P^2.  One wavefront per pixel (float4 per lane), 4 pixels per workgroup.
+// per pixel: sum over the 256 channels of P^2 -- and, on the way, the split-fp16 form of the pixel (h16.h) for the look-ahead conv: with it
+// the look-ahead runs on conv_h4 (operands HBM -> LDS by DMA, no split arithmetic in its k-loop) instead of conv_h3's fp32 loader; the
+// tensor is being read here anyway.  One wavefront per pixel (float4 per lane), 4 pixels per workgroup.
 __global__ __launch_bounds__(256) void prune_energy_kernel(RpnPruneArgs a, int l) {
     const int v = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const LevelSeg sg = a.seg[l][v];
@@ -43,6 +46,7 @@ __global__ __launch_bounds__(256) void prune_energy_kernel(RpnPruneArgs a, int l
     const float4* f = reinterpret_cast<const float4*>(a.feat[l] + sg.pix_off * 256ll);
     for (int p = blockIdx.x * 4 + wave; p < n; p += gridDim.x * 4) {
         const float4 x = f[(long long)p * 64 + lane];
+        if (a.split[l]) h16_store4(reinterpret_cast<unsigned char*>(a.split[l]) + (sg.pix_off + p) * 1024ll, 4 * lane, x);
         float s = (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w);
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) s = s + __shfl_xor(s, off, 64);
@@ -180,8 +184,10 @@ __global__ __launch_bounds__(256) void prune_scatter_kernel(RpnPruneArgs a) {
 }
 }   // namespace
 
-void launch_rpn_prune_select(const RpnPruneArgs& a, int max_pix, hipStream_t st) {
+void launch_rpn_prune_energy(const RpnPruneArgs& a, hipStream_t st) {
     for (int l = 0; l < 2; l++) hipLaunchKernelGGL(prune_energy_kernel, dim3(256, a.V), dim3(256), 0, st, a, l);
+}
+void launch_rpn_prune_select(const RpnPruneArgs& a, int max_pix, hipStream_t st) {
     const size_t lds = (size_t)((max_pix + 31) / 32) * 4;
     static PerDeviceOnce once;
     allow_big_lds(once, prune_select_kernel);
