@@ -643,19 +643,37 @@ extern "C" int cald_model_finalize(cald_model* m) {
             const HostTensor *wc, *bc, *wl;
             if ((rc = get_t(m, "rpn.head.conv.weight", &wc)) || (rc = get_t(m, "rpn.head.conv.bias", &bc)) || (rc = get_t(m, "rpn.head.cls_logits.weight", &wl))) return rc;
             const int K = 2304;
-            const double u = std::ldexp(1.0, -24);
-            const double g_e = K * u / (1.0 - K * u);                                        // the exact mode's fp32 fma chain of K terms
-            const double g_f = 3.0 * std::ldexp(1.0, -22) + (3.0 * K / 16.0) * std::ldexp(1.0, -23);   // split operands + 3K/16 accumulating MFMA instructions
+            const double u = std::ldexp(1.0, -24), gK = K * u / (1.0 - K * u);
             const double g_h = 256 * u / (1.0 - 256 * u);                                    // the 1 x 1 head's chain (same kernel on both hidden vectors)
             static const double slack = getenv("CALD_RPN_PRUNE_SLACK") ? atof(getenv("CALD_RPN_PRUNE_SLACK")) : 1.0;      // tuning experiments: scales the bound
-            std::vector<double> wn(256, 0.0);
-            for (int c = 0; c < 256; c++) { double q = 0.0; for (int k = 0; k < K; k++) { const double t = wc->data[(size_t)c * K + k]; q += t * t; } wn[c] = std::sqrt(q); }
+            // Running error analysis of a chain s_k = fl(s_(k-1) + t_k) (t_j = P_j w_j, fma: one rounding per step): |s_K - sum t| <= u sum_k |s_k|
+            // <= u (1 + gK) sum_j r_j |t_j|, r_j = K - j = the number of partial sums term j takes part in (j = its position in the chain, conv_k_index).
+            // Cauchy-Schwarz keeps the weights:  sum_j r_j |P_j| |w_j| <= |patch|_2 * A_c,  A_c = sqrt(sum_j (r_j w_cj)^2)  (~ K |w_c|_2 / sqrt 3:
+            // 1.7 x tighter than the textbook K u |patch| |w_c|).  The look-ahead's 3K/16 accumulating MFMA instructions (3 per 16-term k-step, same
+            // chain order) are bounded the same way with 2^-23 per instruction: term j is carried by 3 (K - j) / 16 + 3 of them.
+            std::vector<double> wn(256, 0.0), wa(256, 0.0);
+            for (int c = 0; c < 256; c++) {
+                double q = 0.0, qa = 0.0;
+                for (int ci = 0; ci < 256; ci++)
+                    for (int tap = 0; tap < 9; tap++) {
+                        const double t = wc->data[((size_t)c * 256 + ci) * 9 + tap];
+                        const double r = (double)(K - conv_k_index(tap, ci, 9, 256));
+                        q += t * t; qa += r * r * t * t;
+                    }
+                wn[c] = std::sqrt(q); wa[c] = std::sqrt(qa);
+            }
+            const double k_pos = u * (1.0 + gK) + (3.0 / 16.0) * std::ldexp(1.0, -23);       // multiplies A_c
+            const double k_flat = 3.0 * std::ldexp(1.0, -23) + 3.0 * std::ldexp(1.0, -22) + 2.0 * u + 2.0 * g_h;   // multiplies |w_c|_2: MFMA carry-over, operand split
+                                                                                             // (hi + lo of both operands, the dropped lo x lo), the two bias adds, the head's chains
             bool finite = true;
             for (int a = 0; a < 3; a++) {
-                double kap = 0.0, bet = 0.0;
-                for (int c = 0; c < 256; c++) { const double v = std::fabs((double)wl->data[(size_t)a * 256 + c]); kap += v * wn[c]; bet += v * std::fabs((double)bc->data[c]); }
-                m->prune_c1[a] = (float)(1.02 * slack * (g_e + g_f + 2.0 * g_h) * kap);
-                m->prune_c0[a] = (float)(1.02 * slack * 2.0 * g_h * bet + 1e-6);
+                double c1 = 0.0, c0 = 0.0;
+                for (int c = 0; c < 256; c++) {
+                    const double v = std::fabs((double)wl->data[(size_t)a * 256 + c]);
+                    c1 += v * (k_pos * wa[c] + k_flat * wn[c]); c0 += v * std::fabs((double)bc->data[c]) * (2.0 * u + 2.0 * g_h);
+                }
+                m->prune_c1[a] = (float)(1.02 * slack * c1);
+                m->prune_c0[a] = (float)(1.02 * slack * c0 + 1e-6);
                 finite = finite && std::isfinite(m->prune_c1[a]) && std::isfinite(m->prune_c0[a]);
             }
             m->prune = finite && m->rpn_conv16.w16 != nullptr;

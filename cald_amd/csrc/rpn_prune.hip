@@ -14,20 +14,23 @@
 // with them scores and selection, are bit-identical to the unpruned sweep (tests: every sweep-vs-oracle test runs through this path;
 // test_certified_rpn_pruning_* compares pruned and dense proposals at full size).
 //
-// The bound.  z = sum_k P_k w_kc over the 2 304 taps of hidden channel c.  The exact mode computes an fp32 fma chain z_e with
-// |z_e - z| <= g_e S, S = sum_k |P_k w_kc|, g_e = K u / (1 - K u), u = 2^-24 (Higham, Accuracy and Stability, sect. 3.1); the matrix-pipe
-// pass computes z_f with |z_f - z| <= g_f S: operands split into fp16 hi + lo (relative error <= 2^-22 each, the lo x lo term 2^-22 more)
-// and 3 K / 16 accumulating MFMA instructions, each rounding (and aligning) once at <= 2^-23 of the running magnitude: g_f = 3 * 2^-22 +
-// (3 K / 16) 2^-23.  ReLU and the bias are 1-Lipschitz / exact, so |h_e - h_f| <= (g_e + g_f) S <= (g_e + g_f) |patch|_2 |w_c|_2
-// (Cauchy-Schwarz; |patch|_2 from the 3 x 3 box sum of the per-pixel channel energy).  The 1 x 1 head is evaluated by the SAME exact kernel on
-// both hidden vectors: |L~ - L| <= sum_c |v_ac| |h_e - h_f| + 2 g_h sum_c |v_ac| max(|h_e|, |h_f|), g_h = 256 u / (1 - 256 u), and
-// |h| <= |patch|_2 |w_c|_2 + |b_c|.  Per anchor a this is  B_a(p) = c1_a |patch(p)|_2 + c0_a  with two constants fixed at model finalize
-// (api.hip); both are inflated by 2 % for the float32 evaluation of the bound itself.
+// The bound.  z = sum_j t_j, t_j = P_j w_cj over the K = 2 304 taps of hidden channel c, j = the tap's position in the k-ordered chain.
+// The exact mode computes the fp32 fma chain s_k = fl(s_(k-1) + t_k): one rounding of relative size u = 2^-24 per step, so
+// |z_e - z| <= u sum_k |s_k| <= u (1 + g_K) sum_j r_j |t_j| with r_j = K - j (term j takes part in that many partial sums; Higham, Accuracy and
+// Stability, sect. 4.2 -- the textbook K u sum |t_j| is the r_j <= K relaxation of it).  Cauchy-Schwarz keeps the weights:
+// sum_j r_j |P_j| |w_cj| <= |patch|_2 A_c, A_c = sqrt(sum_j (r_j w_cj)^2) ~ K |w_c|_2 / sqrt 3, with |patch|_2 from the 3 x 3 box sum of the per-pixel
+// channel energy.  The look-ahead splits both operands into fp16 hi + lo (relative error <= 2^-22 each, the dropped lo x lo term 2^-22 more:
+// exact statements about the formats) and accumulates with 3 MFMA instructions per 16-term k-step in the same chain order, each
+// rounding (and aligning) once at <= 2^-23 of the running magnitude: term j is carried by 3 (K - j) / 16 + 3 of them.  ReLU is 1-Lipschitz; the
+// bias add rounds once on each side.  The 1 x 1 head is evaluated by the SAME exact kernel on both hidden vectors:
+// |L~ - L| <= sum_c |v_ac| |h_e - h_f| + 2 g_h sum_c |v_ac| max(|h_e|, |h_f|), g_h = 256 u / (1 - 256 u), |h| <= |patch|_2 |w_c|_2 + |b_c|.
+// Per anchor a this is  B_a(p) = c1_a |patch(p)|_2 + c0_a  with two constants fixed at model finalize (api.hip, in double; inflated by 2 % for
+// the float32 evaluation of the bound itself).
 // What is a theorem and what is a model: g_e and g_h are the textbook bounds of the fp32 chains the exact mode IS; the split error of the
 // operands is exact arithmetic on the formats; "one rounding of relative size 2^-23 per MFMA instruction" is a MODEL of
 // v_mfma_f32_32x32x16_f16's internal adder (tools/mfma_f16_probe.hip: the pipe aligns the 16 products to a common exponent with a finite
 // width; measured errors of whole layers stay below 2^-20 S, tests/test_gpu_parity.py::test_conv_f16x3_within_split_precision_of_exact,
-// i.e. > 50 x inside g_f S).  Because a model is not a proof, every sweep PUTS THE BOUND TO THE TEST: each selected anchor is evaluated
+// i.e. far inside the modelled term).  Because a model is not a proof, every sweep PUTS THE BOUND TO THE TEST: each selected anchor is evaluated
 // both ways, prune_scatter_kernel keeps max |L~ - L| / B over all of them (15 - 60 % of all anchors of the two levels, hundreds of thousands
 // per forward), and cald_sweep fails loudly if the ratio ever exceeds 1 (observed: < 0.1, cald_profile_prune).
 #include "common.h"
