@@ -183,7 +183,9 @@ __global__ __launch_bounds__(256) void prune_scatter_kernel(RpnPruneArgs a) {
         }
         dst[(long long)p * ld + c] = exact;
     }
-    if (worst > 0.0f && a.check) atomicMax(reinterpret_cast<unsigned*>(a.check), __float_as_uint(worst));
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) worst = fmaxf(worst, __shfl_xor(worst, off, 64));      // one atomic per wavefront, not per element
+    if ((threadIdx.x & 63) == 0 && worst > 0.0f && a.check) atomicMax(reinterpret_cast<unsigned*>(a.check), __float_as_uint(worst));
 }
 }   // namespace
 
