@@ -853,3 +853,22 @@ def test_training_checker_frcnn_losses_match_the_reference_repo_copies(golden):
         o = F.binary_cross_entropy_with_logits(obj.flatten()[samp], lab)
         b = tt.smooth_l1_sum(deltas[pos], tgt[pos], 0.0) / len(samp)
         assert abs(float(o) - float(g["r%d_obj_f64" % k])) <= 1e-12 and abs(float(b) - float(g["r%d_box_f64" % k])) <= 1e-12
+
+
+def test_coco_bbox_ap_known_answers_from_the_designed_scene(golden, capsys):
+    """cald_amd.coco_eval against tests/golden/coco_ap_known_answers.npz: a scene in which every detection's fate at every IoU threshold
+    follows from its construction (a ground-truth box shrunk to a chosen IoU, a box that overlaps nothing, a box inside a crowd region),
+    turned into the twelve COCO statistics by oracle/make_known_answers_coco.py from the published definitions only -- that script runs
+    no matcher and none of this package's code.  Two categories, three images, all three area ranges, a crowd, maxDets 1 / 10 / 100."""
+    import json
+    from cald_amd.coco_eval import CocoGT, COCOeval
+    g = golden("coco_ap_known_answers")
+    images, cats = json.loads(str(g["images"])), json.loads(str(g["categories"]))
+    anns, dets = json.loads(str(g["annotations"])), json.loads(str(g["detections"]))
+    ev = COCOeval(CocoGT(images, anns, cats))
+    ev.add_results(dets)
+    ev.evaluate([im["id"] for im in images])
+    ev.accumulate()
+    got = ev.summarize(quiet=True)
+    np.testing.assert_allclose(got, g["stats"], rtol=0, atol=1e-12)
+    assert (g["stats"] > 0).all() and len(set(np.round(g["stats"], 6))) >= 10          # the scene separates the twelve numbers
