@@ -1709,7 +1709,7 @@ static int sweep_impl(cald_model* m, int n_images, const uint8_t* const* images_
     }
     int rc = 0;
     const int fwd_views = sweep_fwd_views();
-    if (m->prune) HIPCHK(hipMemsetAsync(c->d_prune_check, 0, 8, c->stream));
+    if (m->prune && !audit) HIPCHK(hipMemsetAsync(c->d_prune_check, 0, 8, c->stream));
 
     // reference views of batch k -> detections into set k & 1, counts + boxes to the pinned host set, event
     auto enqueue_ref = [&](int k) -> int {
@@ -1721,7 +1721,7 @@ static int sweep_impl(cald_model* m, int n_images, const uint8_t* const* images_
             views[i].src = images_dev[b.i0 + i]; views[i].H = H[b.i0 + i]; views[i].W = W[b.i0 + i];
         }
         const DetBuffers& D = *DS[k & 1];
-        int r = forward_model(m, b.nb, views.data(), D, audit ? d_vm[k & 1] : nullptr, true);
+        int r = forward_model(m, b.nb, views.data(), D, audit ? d_vm[k & 1] : nullptr, !audit);     // the audit wants every anchor's own logit: dense RPN head
         if (r) return r;
         if (hipMemcpyAsync(b.h_count, D.count, (size_t)b.nb * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
             hipMemcpyAsync(b.h_boxes, D.boxes, (size_t)b.nb * cap * 16, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
@@ -1889,7 +1889,7 @@ static int sweep_impl(cald_model* m, int n_images, const uint8_t* const* images_
             DetBuffers d2 = D; const size_t o = (size_t)(nb + a0);
             d2.boxes += o * cap * 4; d2.scores += o * cap; d2.labels += o * cap; d2.props += o * cap * 4;
             d2.prob_max += o * cap; d2.scores_cls += o * cap * C; d2.count += o;
-            if ((r = forward_model(m, nv, aviews.data() + a0, d2, audit ? d_vm[k & 1] + o * CALD_VM : nullptr, true))) return r;
+            if ((r = forward_model(m, nv, aviews.data() + a0, d2, audit ? d_vm[k & 1] + o * CALD_VM : nullptr, !audit))) return r;
         }
         // ---- scoring ----
         const int P = (int)pair_ref.size(), VV = nb + na;
@@ -1936,7 +1936,7 @@ static int sweep_impl(cald_model* m, int n_images, const uint8_t* const* images_
     }
     for (int k = (NB >= 2 ? NB - 2 : 0); k < NB && !rc; k++) rc = finish(k);
     if (rc) hipStreamSynchronize(c->stream);
-    if (!rc && m->prune && NB > 0) {
+    if (!rc && m->prune && !audit && NB > 0) {
         // the certified pruning's bound, checked on every anchor that was evaluated both ways (15 - 60 % of P2 / P3): a violation means the
         // look-ahead's error model is wrong on this data -- refuse the result rather than risk a detection the dense head would not give
         float worst = 0.0f;

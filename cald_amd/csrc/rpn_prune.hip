@@ -4,11 +4,11 @@
 // largest objectness logit -- 1 000 of 91 200 on P2, 1 000 of 22 800 on P3 at VOC size -- and nothing downstream ever reads another
 // anchor's logit or deltas.  The RPN head (3 x 3 conv 256 -> 256 + ReLU, 1 x 1 -> 15; frcnn_la.py:199-203) is 23 % of a view's FLOPs and
 // P2 + P3 carry 94 % of its pixels.  The exact sweep therefore computes the head in two steps on those two levels:
-//   1. everywhere, cheaply: the 3 x 3 conv on the fp16 matrix pipe (conv_h3.hip, 3 MFMAs per product, ~2.5 x the fp32 rate), the 1 x 1 head on
+//   1. everywhere, cheaply: the 3 x 3 conv on the fp16 matrix pipe (conv_h4.hip, 3 MFMAs per product, ~2.7 x the fp32 rate), the 1 x 1 head on
 //      the exact kernel -> approximate logits L~ with an error bound B(anchor) against the exact mode's own value L (below);
 //   2. only where it can matter, exactly: tau = the k-th largest LOWER bound L~ - B.  At least k anchors have L >= tau, so an anchor with
-//      L~ + B < tau is not among the k largest of L, whatever the rounding did.  The pixels that hold a surviving anchor (~15 % of P2,
-//      ~60 % of P3 on the configs[1] pool) are recomputed by the exact kernels as gathered rows (ConvArgs::row_map) -- per output element the same k-ordered
+//      L~ + B < tau is not among the k largest of L, whatever the rounding did.  The pixels that hold a surviving anchor (~10 % of P2,
+//      ~35 % of P3 on the configs[1] pool) are recomputed by the exact kernels as gathered rows (ConvArgs::row_map) -- per output element the same k-ordered
 //      fp32 fma chain as the dense launch, hence the same bits -- and scattered back; all other anchors get logit -FLT_MAX.
 // The top-k, decode, NMS and everything after see the exact mode's values at every anchor that can be selected: the detections, and
 // with them scores and selection, are bit-identical to the unpruned sweep (tests: every sweep-vs-oracle test runs through this path;
@@ -31,8 +31,8 @@
 // v_mfma_f32_32x32x16_f16's internal adder (tools/mfma_f16_probe.hip: the pipe aligns the 16 products to a common exponent with a finite
 // width; measured errors of whole layers stay below 2^-20 S, tests/test_gpu_parity.py::test_conv_f16x3_within_split_precision_of_exact,
 // i.e. far inside the modelled term).  Because a model is not a proof, every sweep PUTS THE BOUND TO THE TEST: each selected anchor is evaluated
-// both ways, prune_scatter_kernel keeps max |L~ - L| / B over all of them (15 - 60 % of all anchors of the two levels, hundreds of thousands
-// per forward), and cald_sweep fails loudly if the ratio ever exceeds 1 (observed: < 0.1, cald_profile_prune).
+// both ways, prune_scatter_kernel keeps max |L~ - L| / B over all of them (10 - 35 % of all anchors of the two levels, hundreds of thousands
+// per forward), and cald_sweep fails loudly if the ratio ever exceeds 1 (observed: 5e-5, cald_profile_prune).
 #include "common.h"
 #include "kernels.h"
 #include "h16.h"
