@@ -420,17 +420,49 @@ def main():
     model = model.to("cuda:%d" % local_rank)
     model.load_state_dict(sd)
     model.eval()
+    cabi_note = None
     if use_cabi:
-        # the C ABI's own communicator (cald_comm_init_rank): one per process, on the context's device and stream
+        # the C ABI's own communicator (cald_comm_init_rank): one per process, on the context's device and stream.  Every step is agreed on
+        # by all ranks through the launcher's process group, so that a rank that cannot bootstrap (a port taken, RCCL missing) sends the whole
+        # job to the torch.distributed gather instead of leaving its peers in a collective alone; the JSON line says which path ran.
         from cald_amd.comm import RcclComm
-        cabi_comm = RcclComm.from_store(rank, world, lambda uid: exchange_id_over_tcp(rank, world, uid), device=local_rank)
         import ctypes as C_
-        w_, r_ = C_.c_int(), C_.c_int()
-        _ffi.check(_ffi.lib().cald_comm_info(cabi_comm.handle, C_.byref(w_), C_.byref(r_)))
-        cabi_info = (w_.value, r_.value)
-        assert cabi_info == (world, rank), cabi_info
-        wp = sweep.shard_positions(world * 3, rank, world)            # warm-up on a 3-rows-per-rank pool: RCCL's first collective builds its rings
-        cabi_comm.allgather_scores(wp, np.zeros(len(wp)), np.zeros((len(wp), ncls - 1)), world * 3)
+
+        def all_ok(ok):
+            t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=coll_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(int(t.item()))
+        uid, err = None, None
+        try:
+            uid = exchange_id_over_tcp(rank, world, RcclComm.unique_id() if rank == 0 else None, timeout_s=60.0)
+            bootstrap = "128-byte id over TCP (MASTER_PORT + 29)"
+        except Exception as e:                       # noqa: BLE001 -- any failure here must not strand the other ranks
+            err = "tcp bootstrap: %r" % (e,)
+        if not all_ok(uid is not None):
+            box = [None]
+            if rank == 0:
+                try:
+                    box = [RcclComm.unique_id()]
+                except Exception as e:               # noqa: BLE001
+                    err = "ncclGetUniqueId: %r" % (e,)
+            dist.broadcast_object_list(box, src=0)
+            uid, bootstrap = box[0], "128-byte id through the launcher's process group (the TCP side channel failed: %s)" % err
+        if all_ok(uid is not None):
+            try:
+                cabi_comm = RcclComm.init_rank(uid, world, rank, device=local_rank)
+                w_, r_ = C_.c_int(), C_.c_int()
+                _ffi.check(_ffi.lib().cald_comm_info(cabi_comm.handle, C_.byref(w_), C_.byref(r_)))
+                cabi_info = (w_.value, r_.value)
+                assert cabi_info == (world, rank), cabi_info
+            except Exception as e:                   # noqa: BLE001
+                err, cabi_comm = "cald_comm_init_rank: %r" % (e,), None
+        if not all_ok(cabi_comm is not None):
+            if cabi_comm is not None:
+                cabi_comm.close()
+            cabi_comm, cabi_note = None, "C-ABI collective unavailable on some rank (%s): torch.distributed gathered the rows" % (err or "a peer failed")
+        else:
+            wp = sweep.shard_positions(world * 3, rank, world)            # warm-up on a 3-rows-per-rank pool: RCCL's first collective builds its rings
+            cabi_comm.allgather_scores(wp, np.zeros(len(wp)), np.zeros((len(wp), ncls - 1)), world * 3)
     labeled = synthetic_labeled_set(500, ncls, 0)
     budget = max(1, min(FULL_BUDGET, int(round(FULL_BUDGET * pool_total / float(FULL_POOL)))))
 
@@ -540,7 +572,8 @@ def main():
                        "steps_per_rank": steps_local},
             "rccl": {"backend": backend, "world_size": world, "ranks_seen": int(rows.shape[0]), "visible_gpus": ndev,
                      "shared_gpu": bool(share),
-                     "cabi": None if cabi_comm is None else {"world_size": cabi_info[0], "rank0": cabi_info[1], "bootstrap": "128-byte id over TCP (MASTER_PORT + 29)"},
+                     "cabi": ({"world_size": cabi_info[0], "rank0": cabi_info[1], "bootstrap": bootstrap} if cabi_comm is not None else
+                              ({"error": cabi_note} if cabi_note else None)),
                      "collective": ("cald_allgather_scores (C ABI: RCCL on the context's stream, device buffers, communicator from cald_comm_init_rank)" if cabi_comm is not None else
                                     "all_gather_into_tensor over RCCL (device buffers)" if backend == "nccl" else
                                     "all_gather_into_tensor over gloo: %d ranks on %d visible GPU(s), RCCL refuses two ranks on one device" % (world, ndev)

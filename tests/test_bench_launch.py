@@ -76,3 +76,20 @@ def test_bench_under_torch_distributed_run_weak_scaling():
     assert len(lines) == 1
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["pool_images"] == 128
     assert line["rccl"]["ranks_seen"] == 2 and [x["images"] for x in line["rccl"]["per_rank"]] == [64, 64]
+
+
+@pytest.mark.gpu
+def test_bench_cabi_collective_falls_back_together_when_a_rank_cannot_join():
+    """`--comm cabi` on a box where RCCL cannot form the communicator (two ranks on ONE device: ncclCommInitRank returns 'invalid usage'):
+    every step of the bootstrap is agreed on through the launcher's process group, so all ranks leave the C-ABI path TOGETHER, the rows
+    travel through torch.distributed, rc is 0, there is ONE JSON line, it says what happened -- nobody is left alone in a collective."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box where RCCL refuses the communicator (one visible GPU)")
+    p, line, lines = _run(["bench.py", "--gpus", "2", "--comm", "cabi", "--steps", "2", "--warmup", "1"] + FAST, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert len(lines) == 1 and line["n_gpus"] == 2
+    r = line["rccl"]
+    assert r["ranks_seen"] == 2 and r["backend"] == "gloo"
+    assert "error" in r["cabi"] and "cald_comm_init_rank" in r["cabi"]["error"]
+    assert line["config"]["n_selected"] > 0
