@@ -1532,3 +1532,45 @@ def test_certified_rpn_pruning_on_tiny_and_odd_images(hip, oracle):
     P = oracle.prepare_frcnn(sd, 21, 50)
     wc, wk = oracle.get_uncertainty(P, tiny, ["flip"], 21, bp=1.3, min_size=64, max_size=128, base_seed=3, positions=[0, 1, 2])
     np.testing.assert_array_equal(a1[0], np.array(wc)); np.testing.assert_array_equal(a1[1], np.stack(wk))
+
+
+@pytest.mark.gpu
+def test_f16x3_error_model_of_the_rpn_look_ahead_on_adversarial_operands(hip):
+    """The certified RPN pruning (rpn_prune.hip) bounds the split-fp16 look-ahead's error by a MODEL of v_mfma_f32_32x32x16_f16: operand
+    split <= 3 * 2^-22 per term, one rounding <= 2^-23 of the running magnitude per accumulating instruction, 3 K / 16 of them:
+    |z_f - z| <= (3 * 2^-22 + (3 K / 16) * 2^-23) * sum |a||w|.  Every sweep re-checks the resulting logit bound on real data; this test
+    attacks the model itself on the look-ahead's own layer shape (3 x 3, 256 -> 256, K = 2 304) with operands chosen to hurt: no
+    cancellation at all (every rounding pushes the same way), a 2^20 spread of magnitudes inside one dot product (alignment), exact
+    cancellation of huge terms (error relative to sum |a||w|, not to the result), activations at the format's limit (|x| ~ 4 000).
+    Expected values in float64."""
+    ffi, L = hip["ffi"], hip["L"]
+    H = W = 6; Cin = Cout = 256; K = 3
+    rs = np.random.RandomState(5)
+    def run(x, w):
+        out = np.empty((H, W, Cout), np.float32)
+        ffi.check(L.cald_op_conv2d_f16x3(hip["ctx"], ffi.ptr(x), H, W, Cin, ffi.ptr(w), Cout, K, K, 1, 1, None, None, None, None, 0, ffi.ptr(out)))
+        xp = np.zeros((H + 2, W + 2, Cin)); xp[1:-1, 1:-1] = x
+        want = np.zeros((H, W, Cout)); S = np.zeros((H, W, Cout))
+        w64 = w.astype(np.float64)
+        for kh in range(3):
+            for kw in range(3):
+                patch = xp[kh:kh + H, kw:kw + W]                                   # [H][W][Cin]
+                want += patch @ w64[:, :, kh, kw].T; S += np.abs(patch) @ np.abs(w64[:, :, kh, kw]).T
+        return np.abs(out - want), S
+    g = 3 * 2.0 ** -22 + (3 * 2304 / 16.0) * 2.0 ** -23
+    cases = {}
+    x = (1.0 + rs.rand(H, W, Cin) * 0.999).astype(np.float32); w = (1.0 + rs.rand(Cout, Cin, K, K) * 0.999).astype(np.float32)
+    cases["no cancellation"] = (x, w)
+    x = (rs.choice([-1, 1], (H, W, Cin)) * 2.0 ** rs.randint(-12, 9, (H, W, Cin)) * (1 + rs.rand(H, W, Cin))).astype(np.float32)
+    w = (rs.choice([-1, 1], (Cout, Cin, K, K)) * 2.0 ** rs.randint(-10, 1, (Cout, Cin, K, K)) * (1 + rs.rand(Cout, Cin, K, K))).astype(np.float32)
+    cases["2^20 spread"] = (x, w)
+    x = (rs.rand(H, W, Cin) * 3000 + 500).astype(np.float32); x[:, :, 1::2] = -x[:, :, 0::2]
+    w = np.repeat((rs.rand(Cout, Cin // 2, K, K) + 0.5).astype(np.float32), 2, axis=1)        # pairs (+x, -x) meet equal weights: the true sum is 0
+    cases["exact cancellation of huge terms"] = (np.ascontiguousarray(x), np.ascontiguousarray(w))
+    x = (rs.choice([-1, 1], (H, W, Cin)) * (3500 + 500 * rs.rand(H, W, Cin))).astype(np.float32); w = (rs.randn(Cout, Cin, K, K) * 0.03).astype(np.float32)
+    cases["activations at the limit"] = (x, w)
+    for name, (x, w) in cases.items():
+        err, S = run(x, w)
+        ratio = float((err / (g * S + 1e-30)).max())
+        print("f16x3 error model, %-34s max |err| / (g S) = %.4f   (max |err| %.3g, max S %.3g)" % (name, ratio, err.max(), S.max()))
+        assert ratio <= 1.0, (name, ratio)
