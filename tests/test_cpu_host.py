@@ -872,3 +872,36 @@ def test_coco_bbox_ap_known_answers_from_the_designed_scene(golden, capsys):
     got = ev.summarize(quiet=True)
     np.testing.assert_allclose(got, g["stats"], rtol=0, atol=1e-12)
     assert (g["stats"] > 0).all() and len(set(np.round(g["stats"], 6))) >= 10          # the scene separates the twelve numbers
+
+
+def test_transform_size_matches_torch_interpolate_output_shape(oracle):
+    """GeneralizedRCNNTransform.resize (torchvision 0.8.2, called at frcnn_la.py:234) sizes its output with
+    F.interpolate(scale_factor=s, recompute_scale_factor=True): floor(in * s) in torch's own arithmetic.  That is an INDEPENDENT
+    statement of the resized shape (neither the oracle nor the library): both must agree with it on a sweep of image sizes that
+    includes the float-product traps (333 * (600 / 333), 1 x N strips, sizes near the max-size switch)."""
+    import ctypes as C
+    import torch
+    import torch.nn.functional as F
+    from cald_amd import _ffi
+    L = _ffi.lib()
+    rng = np.random.RandomState(5)
+    sizes = [(375, 500), (500, 375), (333, 500), (500, 334), (480, 640), (427, 640), (640, 427), (333, 333), (600, 1000), (1000, 600),
+             (601, 1001), (599, 999), (800, 1333), (1333, 800), (37, 2000), (2000, 37), (17, 19), (1, 50), (50, 1), (999, 1665)]
+    sizes += [(int(h), int(w)) for h, w in zip(rng.randint(20, 1400, 400), rng.randint(20, 1400, 400))]
+    n = 0
+    for (H, W) in sizes:
+        for (mn, mx) in [(600, 1000), (800, 1333), (512, 512), (300, 500)]:
+            s = float(mn) / float(min(H, W))
+            if max(H, W) * s > mx:
+                s = float(mx) / float(max(H, W))
+            if int(np.floor(H * s)) < 1 or int(np.floor(W * s)) < 1:
+                continue
+            want = tuple(F.interpolate(torch.zeros(1, 1, H, W), scale_factor=s, mode="bilinear", recompute_scale_factor=True,
+                                       align_corners=False).shape[-2:])
+            want = want + tuple(-(-d // 32) * 32 for d in want)
+            assert oracle.transform_size(H, W, mn, mx) == want, (H, W, mn, mx)
+            v = [C.c_int() for _ in range(4)]
+            _ffi.check(L.cald_op_transform_size(H, W, mn, mx, *[C.byref(x) for x in v]))
+            assert tuple(x.value for x in v) == want, (H, W, mn, mx)
+            n += 1
+    assert n > 1500

@@ -12,7 +12,8 @@ pytestmark = pytest.mark.gpu
 def T():
     import torch
     from cald_amd import train_ops
-    assert torch.cuda.is_available()
+    if not torch.cuda.is_available():      # module-scoped: runs before conftest's function-scoped auto-skip
+        pytest.skip("needs an MI355X")
     return torch, train_ops
 
 
