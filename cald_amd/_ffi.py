@@ -69,6 +69,9 @@ SIGNATURES = {
     "cald_model_load_tensor": (C.c_int, [C.c_void_p, C.c_char_p, c_f, c_i64, C.c_int]),
     "cald_model_finalize": (C.c_int, [C.c_void_p]),
     "cald_model_set_rpn_prune": (C.c_int, [C.c_void_p, C.c_int, c_i]),
+    "cald_model_set_rpn_prune_capture": (C.c_int, [C.c_void_p, C.c_int]),
+    "cald_model_rpn_prune_bound": (C.c_int, [C.c_void_p, c_f, c_f]),
+    "cald_profile_prune_fallbacks": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "cald_model_destroy": (C.c_int, [C.c_void_p]),
     "cald_forward": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(View), C.POINTER(Dets)]),
     "cald_sweep": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), c_i, c_i, c_i64, C.POINTER(SweepCfg), c_d, c_d]),
@@ -86,6 +89,7 @@ SIGNATURES = {
     "cald_op_roi_align": (C.c_int, [C.c_void_p, C.POINTER(c_f), c_i, C.c_int, C.c_int, c_f, c_f]),
     "cald_op_conv2d": (C.c_int, [C.c_void_p, c_f, C.c_int, C.c_int, C.c_int, c_f, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_int, c_f, c_f, c_f, c_f, C.c_int, c_f]),
+    "cald_op_mfma_f16": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint16), C.POINTER(C.c_uint16), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_int64]),
     "cald_op_conv2d_f16x3": (C.c_int, [C.c_void_p, c_f, C.c_int, C.c_int, C.c_int, c_f, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_int, c_f, c_f, c_f, c_f, C.c_int, c_f]),
     "cald_op_conv_bench": (C.c_int, [C.c_void_p] + [C.c_int] * 12 + [c_d, c_d]),

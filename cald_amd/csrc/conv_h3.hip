@@ -291,3 +291,33 @@ bool launch_conv_h3(const ConvArgs& a, hipStream_t stream) {
     }
     return true;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// cald_op_mfma_f16: the instruction itself on caller-supplied operands (parity hook for oracle/mfma_f16_model.h).  One wave evaluates 32
+// dot products per instruction: case i of a block of 32 is row i of A and column i of B, D[i][i] its result; the tile is spilled to LDS
+// and lanes 0..31 read the diagonal.
+__global__ __launch_bounds__(256) void mfma_f16_probe_kernel(const unsigned short* __restrict__ A, const unsigned short* __restrict__ B,
+                                                             const unsigned* __restrict__ C, unsigned* __restrict__ D, const long long n) {
+    __shared__ float tile[4][32 * 33];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long base = ((long long)blockIdx.x * 4 + wave) * 32;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const long long ia = base + l31 < n ? base + l31 : n - 1;
+    const h8 a = __builtin_bit_cast(h8, *reinterpret_cast<const i32x4*>(A + ia * 16 + 8 * kh));
+    const h8 b = __builtin_bit_cast(h8, *reinterpret_cast<const i32x4*>(B + ia * 16 + 8 * kh));
+    f32x16 c;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const long long ic = base + 4 * kh + (r & 3) + 8 * (r >> 2);
+        c[r] = __builtin_bit_cast(float, C[ic < n ? ic : n - 1]);
+    }
+    const f32x16 d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; r++) tile[wave][(4 * kh + (r & 3) + 8 * (r >> 2)) * 33 + l31] = d[r];
+    __syncthreads();
+    if (lane < 32 && base + lane < n) D[base + lane] = __builtin_bit_cast(unsigned, tile[wave][lane * 33 + lane]);
+}
+void launch_mfma_f16_probe(const unsigned short* A, const unsigned short* B, const unsigned* C, unsigned* D, long long n, hipStream_t stream) {
+    const long long blocks = (n + 127) / 128;
+    hipLaunchKernelGGL(mfma_f16_probe_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, A, B, C, D, n);
+}

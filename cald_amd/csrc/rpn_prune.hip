@@ -32,7 +32,10 @@
 // width; measured errors of whole layers stay below 2^-20 S, tests/test_gpu_parity.py::test_conv_f16x3_within_split_precision_of_exact,
 // i.e. far inside the modelled term).  Because a model is not a proof, every sweep PUTS THE BOUND TO THE TEST: each selected anchor is evaluated
 // both ways, prune_scatter_kernel keeps max |L~ - L| / B over all of them (10 - 35 % of all anchors of the two levels, hundreds of thousands
-// per forward), and cald_sweep fails loudly if the ratio ever exceeds 1 (observed: 5e-5, cald_profile_prune).
+// per forward), and cald_sweep repeats itself with the dense head if the ratio ever exceeds 1 (observed: 5e-5, cald_profile_prune).
+// Round 6: the instruction IS now stated bit for bit (oracle/mfma_f16_model.h, pinned to the hardware on > 10^7 dot products), and the
+// constants in api.hip are derived from that statement -- a theorem about the model instead of a guess about the pipe; the all-anchor test
+// (tests: test_rpn_pruning_bound_holds_on_every_anchor) evaluates the bound on every anchor of P2 / P3, pruned ones included.
 #include "common.h"
 #include "kernels.h"
 #include "h16.h"
@@ -53,7 +56,13 @@ __global__ __launch_bounds__(256) void prune_energy_kernel(RpnPruneArgs a, int l
         float s = (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w);
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) s = s + __shfl_xor(s, off, 64);
-        if (lane == 0) a.energy[l][sg.pix_off + p] = s;
+        if (lane == 0) {
+            a.energy[l][sg.pix_off + p] = s;
+            // |x| >= 4094 would leave fp16's range after the split's 2^4 scale (the look-ahead's hi half becomes inf) and a non-finite activation
+            // voids every bound: either is visible in the pixel's energy (|x| >= 4094 => s >= 4094^2).  Flag it: the sweep then repeats itself with
+            // the dense head (api.hip) -- a pruned anchor is never evaluated both ways, so this cannot be left to the check on the selected ones.
+            if (!(s < 16760836.0f) && a.check) atomicMax(reinterpret_cast<unsigned*>(a.check) + 1, __float_as_uint(1.0f));
+        }
     }
 }
 

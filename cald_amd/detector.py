@@ -251,6 +251,17 @@ class HipDetector:
         _ffi.check(_ffi.lib().cald_model_set_rpn_prune(self.handle(), int(bool(on)), C.byref(was)))
         return bool(was.value)
 
+    def set_rpn_prune_capture(self, on):
+        """Test hook (cald_model_set_rpn_prune_capture): forward_views then takes the pruned RPN path and keeps the look-ahead's maps."""
+        _ffi.check(_ffi.lib().cald_model_set_rpn_prune_capture(self.handle(), int(bool(on))))
+
+    def rpn_prune_bound(self):
+        """(c1[3], c0[3]) of the pruning's per-anchor bound B_a(p) = c1[a] * |patch(p)|_2 + c0[a]."""
+        import numpy as np
+        c1 = np.zeros(3, np.float32); c0 = np.zeros(3, np.float32)
+        _ffi.check(_ffi.lib().cald_model_rpn_prune_bound(self.handle(), _ffi.ptr(c1), _ffi.ptr(c0)))
+        return c1, c0
+
     def debug_tensor(self, name, view=0):
         shape = (C.c_int64 * 3)()
         cap = 1 << 26

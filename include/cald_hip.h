@@ -76,10 +76,18 @@ int cald_model_load_tensor(cald_model* m, const char* key, const float* data, co
 /* folds FrozenBatchNorm into per-channel scale/shift, repacks weights K-major for the MFMA kernels */
 int cald_model_finalize(cald_model* m);
 /* Exact (CALD_PRECISION_FP32) Faster R-CNN sweeps evaluate the RPN head of P2 / P3 exactly only at the pixels that can hold one of a
- * level's rpn_pre_nms_top_n anchors, found by a split-fp16 look-ahead with a proven error bound (rpn_prune.hip):
- * same detections bit for bit, ~1/8 less fp32 work.  On by default (environment CALD_RPN_PRUNE=0 turns it off for the process); this
- * call switches it per model and returns the previous state in *was (may be null).  cald_forward always runs the dense head. */
+ * level's rpn_pre_nms_top_n anchors, found by a split-fp16 look-ahead whose error bound is derived from a bit-exact statement of the matrix
+ * instruction (oracle/mfma_f16_model.h, pinned to the hardware by the tests) and is checked at run time on every anchor evaluated both
+ * ways (rpn_prune.hip): same detections bit for bit, ~1/8 less fp32 work.  A sweep whose data leave the look-ahead's
+ * range (an activation of |x| >= 4094, a non-finite one) or exceed the bound is repeated with the dense head (cald_profile_prune_fallbacks
+ * counts them).  On by default (environment CALD_RPN_PRUNE=0 turns it off for the process); this call switches it per model and returns
+ * the previous state in *was (may be null).  cald_forward runs the dense head (unless capture mode is on, below). */
 int cald_model_set_rpn_prune(cald_model* m, int on, int* was);
+/* test hooks of the pruning: capture mode makes cald_forward take the pruned path too and keep the look-ahead's head maps as debug tensors
+ * ("rpn_look0/1": [H][W][15], logits = channels 0..2; "rpn_pnorm0/1": the per-pixel |3 x 3 patch|_2; "rpn0/1": the maps the top-k reads, exact
+ * at selected pixels and -FLT_MAX elsewhere); cald_model_rpn_prune_bound returns the constants of B_a(p) = c1[a] * pnorm(p) + c0[a], a < 3 */
+int cald_model_set_rpn_prune_capture(cald_model* m, int on);
+int cald_model_rpn_prune_bound(cald_model* m, float* c1, float* c0);
 int cald_model_destroy(cald_model* m);
 
 /* One detector input: task_model([tensor]) in cald_train.py:107 / :186.  The view is described by
@@ -216,6 +224,11 @@ int cald_op_conv2d(cald_ctx* ctx, const float* in, int H, int W, int Cin, const 
 int cald_op_conv2d_f16x3(cald_ctx* ctx, const float* in, int H, int W, int Cin, const float* weight, int Cout, int KH, int KW,
                          int stride, int pad, const float* bias, const float* bn_scale, const float* bn_shift,
                          const float* residual, int relu, float* out);
+/* Parity hook of CALD_PRECISION_F16X3's arithmetic primitive: n independent dot products D[i] = C[i] + sum_{k<16} A[i][k] B[i][k], each
+ * evaluated by the hardware as ONE output element of v_mfma_f32_32x32x16_f16 (the instruction conv_h3.hip / conv_h4.hip are built on;
+ * there is no reference function -- the reference has no fp16 path).  A, B: fp16 bit patterns [n][16], C / D: fp32
+ * bit patterns [n] (host).  tests/ hold oracle/mfma_f16_model.h, the CPU statement of that instruction, against it bit for bit. */
+int cald_op_mfma_f16(cald_ctx* ctx, const uint16_t* A, const uint16_t* B, const uint32_t* C, uint32_t* D, int64_t n);
 /* kernel-tuning aid (tools/bench_conv.py): average time of ONE conv layer shape (the model's own kernel selection) over a
  * ragged batch of n_views equal views filled with pseudo-random data; `group` > 1 issues that many independent copies as one
  * grouped launch (FPN / RPN style).  tflops_out counts algorithmic FLOPs (2 * M * Cout * KH*KW*Cin).  relu: bit 0 = ReLU in the
@@ -246,10 +259,12 @@ int cald_profile_read(cald_ctx* ctx, double* gemm_ms, double* gemm_flops, int64_
 /* the exact sweep's certified RPN pruning: time and algorithmic FLOPs of its split-fp16 look-ahead launches
  * (NOT part of cald_profile_read's figures, which then count the exact kernels only, the gathered launches on their selected rows) and
  * the fraction of P2 / P3 pixels whose head was recomputed exactly; worst_bound_ratio = the largest |look-ahead - exact| / bound any sweep of
- * this context has observed on the anchors evaluated both ways (every sweep checks it and fails if it exceeds 1); pruned_flops = the
- * dense head's exact FLOPs that were not executed */
+ * this context has observed on the anchors evaluated both ways (every sweep checks it and repeats itself with the dense head if it exceeds 1);
+ * pruned_flops = the dense head's exact FLOPs that were not executed */
 int cald_profile_prune(cald_ctx* ctx, double* lookahead_ms, double* lookahead_flops, double* selected_fraction_p2_p3, double* worst_bound_ratio,
                        double* pruned_flops);
+/* sweeps of this context that were repeated with the dense head (bound exceeded, or an activation outside the look-ahead's range) */
+int cald_profile_prune_fallbacks(cald_ctx* ctx, int64_t* n);
 /* mean proposals per view (R of SURVEY 8d) over the Faster R-CNN forwards profiled since cald_profile_enable */
 int cald_profile_roi_rows(cald_ctx* ctx, double* mean_rows_per_view, int64_t* views);
 /* per-launch CSV (shape, algorithmic GFLOP, ms, TFLOP/s) of the launches recorded since cald_profile_enable */

@@ -23,7 +23,7 @@ c_u8 = C.POINTER(C.c_uint8)
 
 def build(force=False):
     so = os.path.join(_HERE, "libcald_oracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("cald_oracle.c", "jpeg_oracle.c", "orc_math.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("cald_oracle.c", "jpeg_oracle.c", "orc_math.h", "f16x3_oracle.c", "f16x3_conv_body.inc", "mfma_f16_model.h")]
     if force or not os.path.exists(so) or any(os.path.exists(f) and os.path.getmtime(f) > os.path.getmtime(so) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "libcald_oracle.so"], stdout=subprocess.DEVNULL)
     return so
@@ -42,13 +42,19 @@ def lib():
         _LIB.orc_log.argtypes = [C.c_float]
         _LIB.orc_js_divergence.restype = C.c_float
         _LIB.orc_consistency_view.restype = C.c_float
+        _LIB.orc_f16x3_join.restype = C.c_float
+        _LIB.orc_f16x3_split_word.restype = C.c_uint32
+        _LIB.orc_f16x3_split_word.argtypes = [C.c_float]
+        _LIB.orc_f16x3_join.argtypes = [C.c_uint32]
         _LIB.orc_set_threads(C.c_int(min(32, os.cpu_count() or 1)))
+        _LIB.orc_f16x3_set_threads(C.c_int(min(32, os.cpu_count() or 1)))
     return _LIB
 
 
 def set_threads(n):
     """OpenMP threads of the conv / linear / RoIAlign loops (results do not depend on it: every output is one chain)."""
     lib().orc_set_threads(C.c_int(max(1, int(n))))
+    lib().orc_f16x3_set_threads(C.c_int(max(1, int(n))))
 
 
 def _p(a, t=c_f):
@@ -249,6 +255,77 @@ def linear(x, wk, bias=None, relu=False):
     return out
 
 
+# ----------------------------------------------------------------------------- CALD_PRECISION_F16X3 (oracle/f16x3_oracle.c, mfma_f16_model.h)
+c_u16 = C.POINTER(C.c_uint16)
+c_u32 = C.POINTER(C.c_uint32)
+c_i16 = C.POINTER(C.c_int16)
+
+
+def mfma_f16_dot16(A, B, Cin, fast=None):
+    """D = C + sum_k A[k] B[k] as v_mfma_f32_32x32x16_f16 computes one output element (gfx950).  A, B: [n][16] fp16 bit patterns
+    (uint16), Cin: [n] fp32 bit patterns (uint32).  fast=None: the integer statement of mfma_f16_model.h; 0 / 1: the double-precision
+    evaluation the convolution uses (portable loops / AVX-512)."""
+    A = np.ascontiguousarray(A, np.uint16).reshape(-1, 16); B = np.ascontiguousarray(B, np.uint16).reshape(-1, 16)
+    Cin = np.ascontiguousarray(Cin, np.uint32).reshape(-1)
+    assert A.shape == B.shape and A.shape[0] == Cin.shape[0]
+    D = np.empty_like(Cin)
+    n = C.c_long(A.shape[0])
+    if fast is None:
+        lib().orc_mfma_f16_dot16(_p(A, c_u16), _p(B, c_u16), _p(Cin, c_u32), _p(D, c_u32), n)
+    else:
+        if lib().orc_mfma_f16_dot16_fast(_p(A, c_u16), _p(B, c_u16), _p(Cin, c_u32), _p(D, c_u32), n, C.c_int(int(fast))) != 0:
+            return None            # this CPU lacks the instruction set
+    return D
+
+
+def uses_f16x3(Cin, Cout, KH, KW):
+    """Which layers of a CALD_PRECISION_F16X3 model run on the fp16 matrix pipe (cald_amd/csrc/api.hip make_conv: w16 is packed iff ...);
+    the others (the 15-channel RPN head) run the exact fp32 chain in that mode too."""
+    coutpad = -(-Cout // 128) * 128 if Cout >= 128 else (-(-Cout // 64) * 64 if Cout >= 64 else -(-Cout // 32) * 32)
+    return coutpad % 64 == 0 and ((Cin % 16 == 0 and KH * KW <= 32) or Cin == 4)
+
+
+def f16x3_weights(wk, KH, KW, Cin):
+    """Split weights of one layer (api.hip pack_w16): wk K-major [(kh, kw, cin)][Cout] -> prepared arrays in chain order."""
+    wk = f32(wk); K, N = wk.shape
+    assert K == KH * KW * Cin
+    Kpad = -(-K // 16) * 16; Npad = -(-N // 16) * 16
+    vh = np.empty((Kpad, Npad), np.float32); vl = np.empty((Kpad, Npad), np.float32)
+    eh = np.empty((Kpad, Npad), np.int16); el = np.empty((Kpad, Npad), np.int16)
+    uns = C.c_float()
+    S = lib().orc_f16x3_weights(_p(wk), C.c_int(KH), C.c_int(KW), C.c_int(Cin), C.c_int(N), C.c_int(Kpad), C.c_int(Npad),
+                                _p(vh), _p(vl), _p(eh, c_i16), _p(el, c_i16), C.byref(uns))
+    return dict(vh=vh, vl=vl, eh=eh, el=el, Kpad=Kpad, Npad=Npad, N=N, unscale=uns.value, S=S, KH=KH, KW=KW, Cin=Cin)
+
+
+def conv2d_f16x3(x, w, KH, KW, stride, pad, bias=None, bn=None, residual=None, up=None, relu=False, in_relu=False):
+    """The convolution of CALD_PRECISION_F16X3 (conv_h3.hip / conv_h4.hip), bit for bit.  w: K-major weights or f16x3_weights(...)."""
+    x = f32(x); H, W, Cin = x.shape
+    if not isinstance(w, dict):
+        w = f16x3_weights(w, KH, KW, Cin)
+    Cout = w["N"]
+    Ho = (H + 2 * pad - KH) // stride + 1
+    Wo = (W + 2 * pad - KW) // stride + 1
+    out = np.empty((Ho, Wo, Cout), np.float32)
+    upH = upW = 0
+    if up is not None:
+        up = f32(up); upH, upW = up.shape[:2]
+    lib().orc_conv2d_f16x3_nhwc(_p(x), C.c_int(H), C.c_int(W), C.c_int(Cin), _p(w["vh"]), _p(w["vl"]), _p(w["eh"], c_i16), _p(w["el"], c_i16),
+                                C.c_int(w["Kpad"]), C.c_int(w["Npad"]), C.c_float(w["unscale"]), C.c_int(Cout), C.c_int(KH), C.c_int(KW),
+                                C.c_int(stride), C.c_int(pad), C.c_int(int(in_relu)), _p(f32(bias)) if bias is not None else None,
+                                _p(bn[0]) if bn else None, _p(bn[1]) if bn else None,
+                                _p(f32(residual)) if residual is not None else None, _p(up), C.c_int(upH), C.c_int(upW),
+                                C.c_int(int(relu)), _p(out), C.c_int(Ho), C.c_int(Wo))
+    return out
+
+
+def f16x3_requantize(x):
+    """What an epilogue reads back from a tensor the mode keeps in split form only (h16.h h16_join of split16_word): 22 bits of x."""
+    x = f32(x); y = np.empty_like(x)
+    lib().orc_f16x3_requantize(_p(x), _p(y), C.c_long(x.size))
+    return y
+
+
 def maxpool3x3s2(x):
     x = f32(x); H, W, Cc = x.shape
     Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
@@ -385,19 +462,41 @@ def prepare_frcnn(sd, num_classes, depth=50):
     return P
 
 
-def _conv(P, name, x, wk, KH, KW, stride, pad, **kw):
-    """A conv layer of the model: the exact fp32 chain."""
+def _f16x3_layer(P, name, wk, KH, KW, Cin):
+    cache = P.setdefault("_f16x3_weights", {})
+    if name not in cache:
+        cache[name] = f16x3_weights(wk, KH, KW, Cin)
+    return cache[name]
+
+
+def _conv(P, name, x, wk, KH, KW, stride, pad, in_relu=False, **kw):
+    """A conv layer of the model.  precision "fp32": the exact fp32 chain.  precision "f16x3" (CALD_PRECISION_F16X3): the layers the
+    library runs on the fp16 matrix pipe (uses_f16x3) follow conv2d_f16x3; a residual / top-down operand is then read back from a tensor
+    the mode keeps in split form only (api.hip fwd_layout `only(...)`: block outputs, the downsample branch, the FPN laterals), i.e. as
+    h16_join(split16_word(value))."""
+    Cin, Cout = x.shape[2], wk.shape[1]
+    if P.get("precision", "fp32") == "f16x3" and uses_f16x3(Cin, Cout, KH, KW):
+        kw = dict(kw)
+        for k in ("residual", "up"):
+            if kw.get(k) is not None:
+                kw[k] = f16x3_requantize(kw[k])
+        return conv2d_f16x3(x, _f16x3_layer(P, name, wk, KH, KW, Cin), KH, KW, stride, pad, in_relu=in_relu, **kw)
+    if in_relu:
+        x = np.maximum(x, np.float32(0.0))
     return conv2d(x, wk, KH, KW, stride, pad, **kw)
 
 
 def _linear(P, name, x, wk, bias=None, relu=False):
+    if P.get("precision", "fp32") == "f16x3" and uses_f16x3(x.shape[1], wk.shape[1], 1, 1):
+        y = conv2d_f16x3(f32(x)[None], _f16x3_layer(P, name, wk, 1, 1, x.shape[1]), 1, 1, 1, 0, bias=bias, relu=relu)
+        return y[0]
     return linear(x, wk, bias, relu)
 
 
 def frcnn_backbone(P, x, keep=None):
     """ResNet body + FPN (rows A15, A16).  x: [Hp][Wp][4].  Returns [P2..P5, pool]."""
     wk, bn = P["conv1"]
-    y = conv2d(x, wk, 7, 7, 2, 3, bn=bn, relu=True)
+    y = _conv(P, "backbone.body.conv1.weight", x, wk, 7, 7, 2, 3, bn=bn, relu=True)
     if keep is not None: keep["conv1"] = y
     y = maxpool3x3s2(y)
     if keep is not None: keep["pool1"] = y
@@ -491,7 +590,7 @@ def prepare_retinanet(sd, num_classes, depth=50):
 def retina_backbone(P, x, keep=None):
     """ResNet body (C3..C5) + FPN + LastLevelP6P7(256, 256) (retinanet_cal.py:618-619)."""
     wk, bn = P["conv1"]
-    y = maxpool3x3s2(conv2d(x, wk, 7, 7, 2, 3, bn=bn, relu=True))
+    y = maxpool3x3s2(_conv(P, "backbone.body.conv1.weight", x, wk, 7, 7, 2, 3, bn=bn, relu=True))
     feats = []
     for blk in P["blocks"]:
         idn = y
@@ -512,7 +611,7 @@ def retina_backbone(P, x, keep=None):
         inner[i] = _conv(P, fi % i, feats[i], P["fpn_inner"][i][0], 1, 1, 1, 0, bias=P["fpn_inner"][i][1], up=inner[i + 1])
     outs = [_conv(P, fl % i, inner[i], P["fpn_layer"][i][0], 3, 3, 1, 1, bias=P["fpn_layer"][i][1]) for i in range(3)]
     p6 = _conv(P, "backbone.fpn.extra_blocks.p6.weight", outs[2], P["p6"][0], 3, 3, 2, 1, bias=P["p6"][1])
-    p7 = conv2d(np.maximum(p6, np.float32(0.0)), P["p7"][0], 3, 3, 2, 1, bias=P["p7"][1])     # relu-on-load layer: exact kernel in every mode
+    p7 = _conv(P, "backbone.fpn.extra_blocks.p7.weight", p6, P["p7"][0], 3, 3, 2, 1, in_relu=True, bias=P["p7"][1])     # ReLU while staging
     return outs + [p6, p7]
 
 

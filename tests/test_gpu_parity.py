@@ -1574,3 +1574,175 @@ def test_f16x3_error_model_of_the_rpn_look_ahead_on_adversarial_operands(hip):
         ratio = float((err / (g * S + 1e-30)).max())
         print("f16x3 error model, %-34s max |err| / (g S) = %.4f   (max |err| %.3g, max S %.3g)" % (name, ratio, err.max(), S.max()))
         assert ratio <= 1.0, (name, ratio)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# CALD_PRECISION_F16X3 against ITS CPU restatement (oracle/mfma_f16_model.h, oracle/f16x3_oracle.c): SURVEY 8g row X1
+# ---------------------------------------------------------------------------------------------------------------------------
+def _mfma_hw(hip, A, B, Cc):
+    ffi, L = hip["ffi"], hip["L"]
+    A = np.ascontiguousarray(A, np.uint16); B = np.ascontiguousarray(B, np.uint16); Cc = np.ascontiguousarray(Cc, np.uint32)
+    D = np.empty_like(Cc)
+    ffi.check(L.cald_op_mfma_f16(hip["ctx"], A.ctypes.data_as(C.POINTER(C.c_uint16)), B.ctypes.data_as(C.POINTER(C.c_uint16)),
+                                 Cc.ctypes.data_as(C.POINTER(C.c_uint32)), D.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_int64(Cc.shape[0])))
+    return D
+
+
+def _random_mfma_cases(rs, n, kind):
+    """fp16 operand / fp32 addend bit patterns without inf / nan, four regimes"""
+    if kind == "bits":            # every finite fp16 pattern, addends over 2^-63 .. 2^63: most terms fall out of every window
+        A = rs.randint(0, 1 << 16, (n, 16)).astype(np.uint16); B = rs.randint(0, 1 << 16, (n, 16)).astype(np.uint16)
+        A[(A & 0x7c00) == 0x7c00] &= 0xbbff; B[(B & 0x7c00) == 0x7c00] &= 0xbbff
+        Cc = (rs.randint(0, 2, n).astype(np.uint32) << 31) | (rs.randint(64, 191, n).astype(np.uint32) << 23) | rs.randint(0, 1 << 23, n).astype(np.uint32)
+        return A, B, Cc
+    spread = {"narrow": 1, "mid": 4, "wide": 9}[kind]
+    ea = rs.randint(-spread, spread + 1, (n, 16)) + rs.randint(-4, 5, (n, 1)); eb = rs.randint(-spread, spread + 1, (n, 16)) + rs.randint(-4, 5, (n, 1))
+    A = ((rs.randint(0, 2, (n, 16)) << 15) | ((ea + 15) << 10) | rs.randint(0, 1024, (n, 16))).astype(np.uint16)
+    B = ((rs.randint(0, 2, (n, 16)) << 15) | ((eb + 15) << 10) | rs.randint(0, 1024, (n, 16))).astype(np.uint16)
+    zero = rs.rand(n, 16) < 0.1
+    A[zero] = 0
+    ec = rs.randint(-30, 31, n)
+    Cc = ((rs.randint(0, 2, n).astype(np.uint32) << 31) | ((ec + 127).astype(np.uint32) << 23) | rs.randint(0, 1 << 23, n).astype(np.uint32))
+    Cc[rs.rand(n) < 0.05] = 0
+    return A, B, Cc.astype(np.uint32)
+
+
+def test_mfma_f16_model_equals_the_hardware(hip, oracle):
+    """oracle/mfma_f16_model.h == v_mfma_f32_32x32x16_f16, bit for bit, on more than 10^7 dot products: the directed families the model
+    was identified with (tools/mfma_model/gen_cases*.py: one product + addend over a 2^+-50 range, pairs by position and offset, exact
+    cancellation, one large + many small terms, addends just below a power of two, small terms under a large addend, signed zeros,
+    fp16 / fp32 subnormals) and 7.2 million random ones in four exponent regimes, including every finite fp16 bit pattern.  All three
+    evaluations of the model are held to the hardware: the integer statement and the two double-precision forms the convolution uses."""
+    import importlib.util, os, tempfile
+    total = 0
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as tmp:
+        for gen in ("gen_cases", "gen_cases2", "gen_cases3"):
+            spec = importlib.util.spec_from_file_location(gen, os.path.join(here, "tools", "mfma_model", gen + ".py"))
+            mod = importlib.util.module_from_spec(spec)
+            import sys
+            sys.path.insert(0, os.path.join(here, "tools", "mfma_model")); old_argv = sys.argv
+            try:
+                sys.argv = [gen, tmp]; spec.loader.exec_module(mod); mod.main()
+            finally:
+                sys.argv = old_argv; sys.path.pop(0)
+            raw = np.fromfile(os.path.join(tmp, "cases.bin"), np.uint8)
+            n = int(raw[:8].view(np.int64)[0])
+            A = raw[8:8 + n * 32].view(np.uint16).reshape(n, 16); B = raw[8 + n * 32:8 + n * 64].view(np.uint16).reshape(n, 16)
+            Cc = raw[8 + n * 64:8 + n * 68].view(np.uint32)
+            hw = _mfma_hw(hip, A, B, Cc)
+            for fast in (None, 0, 1):
+                got = oracle.mfma_f16_dot16(A, B, Cc, fast)
+                if got is None: continue                               # no AVX-512 on this host
+                bad = np.nonzero(got != hw)[0]
+                assert bad.size == 0, "%s (evaluation %r): %d of %d differ, first case %d: hw %08x model %08x" % (gen, fast, bad.size, n, bad[0], hw[bad[0]], got[bad[0]])
+            total += n
+    rs = np.random.RandomState(11)
+    for kind in ("narrow", "mid", "wide", "bits"):
+        n = 1800000
+        A, B, Cc = _random_mfma_cases(rs, n, kind)
+        hw = _mfma_hw(hip, A, B, Cc)
+        for fast in (None, 1):
+            got = oracle.mfma_f16_dot16(A, B, Cc, fast)
+            if got is None: continue
+            bad = np.nonzero(got != hw)[0]
+            assert bad.size == 0, "random %s (evaluation %r): %d of %d differ, first case %d: hw %08x model %08x" % (kind, fast, bad.size, n, bad[0], hw[bad[0]], got[bad[0]])
+        total += n
+    print("v_mfma_f32_32x32x16_f16 == its CPU model on %d dot products" % total)
+    assert total > 10000000
+
+
+def _conv_case_data(case):
+    H, W, Cin, Cout, K, stride, pad, bias, bn, res, relu = case
+    rs = np.random.RandomState(H * 1000 + Cout)
+    x = rs.randn(H, W, Cin).astype(np.float32)
+    x[rs.rand(H, W, Cin) < 0.3] = 0.0
+    w = (rs.randn(Cout, Cin, K, K) * np.sqrt(2.0 / (Cin * K * K))).astype(np.float32)
+    b = rs.randn(Cout).astype(np.float32) if bias else None
+    sc = (0.5 + rs.rand(Cout)).astype(np.float32) if bn else None
+    sh = rs.randn(Cout).astype(np.float32) if bn else None
+    Ho, Wo = (H + 2 * pad - K) // stride + 1, (W + 2 * pad - K) // stride + 1
+    r = rs.randn(Ho, Wo, Cout).astype(np.float32) if res else None
+    return x, w, b, sc, sh, r, Ho, Wo
+
+
+@pytest.mark.parametrize("scale", [1.0, 2.0 ** -9, 190.0])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_f16x3_equals_its_cpu_restatement(hip, oracle, case, scale):
+    """cald_op_conv2d_f16x3 (conv_h3.hip / conv_h4.hip) == oracle.conv2d_f16x3, byte for byte: operand split, k-tile order, the three
+    accumulating instructions per k-tile in the kernels' issue order, the instruction itself (mfma_f16_model.h), the fp32 epilogue.
+    `scale` moves the activations: 2^-9 puts the lo halves into fp16's subnormal range, 190 puts |16 x| near the top of the format.
+    Shapes the mode does not cover (the 15-channel RPN head) run the exact chain on both sides."""
+    H, W, Cin, Cout, K, stride, pad, bias, bn, res, relu = case
+    ffi, L = hip["ffi"], hip["L"]
+    x, w, b, sc, sh, r, Ho, Wo = _conv_case_data(case)
+    x = (x * np.float32(scale)).astype(np.float32)
+    out = np.empty((Ho, Wo, Cout), np.float32)
+    ffi.check(L.cald_op_conv2d_f16x3(hip["ctx"], ffi.ptr(x), H, W, Cin, ffi.ptr(w), Cout, K, K, stride, pad, ffi.ptr(b), ffi.ptr(sc),
+                                     ffi.ptr(sh), ffi.ptr(r), int(relu), ffi.ptr(out)))
+    wk = np.ascontiguousarray(w.transpose(2, 3, 1, 0).reshape(-1, Cout))
+    f = oracle.conv2d_f16x3 if oracle.uses_f16x3(Cin, Cout, K, K) else oracle.conv2d
+    want = f(x, wk, K, K, stride, pad, bias=b, bn=(sc, sh) if bn else None, residual=r, relu=relu)
+    bad = np.nonzero(out.view(np.uint32) != want.view(np.uint32))
+    assert out.tobytes() == want.tobytes(), "%d of %d outputs differ, max abs diff %g, first at %r" % (
+        bad[0].size, out.size, float(np.abs(out - want).max()), tuple(int(i[0]) for i in bad))
+
+
+@pytest.fixture(scope="module")
+def small_model_f16x3(hip, oracle):
+    from cald_amd import synth
+    sd = synth.pseudo_trained_frcnn(21, 50, seed=0)
+    model = hip["det"].fasterrcnn_resnet50_fpn_feature(num_classes=21, min_size=300, max_size=500, precision="f16x3")
+    model.to("cuda").load_state_dict(sd)
+    model.eval()
+    P = oracle.prepare_frcnn(sd, 21, 50)
+    P["precision"] = "f16x3"
+    return model, P
+
+
+def test_forward_f16x3_stagewise_bit_exact(hip, oracle, small_model_f16x3):
+    """Every stage of the detector forward in CALD_PRECISION_F16X3 against the oracle in the same precision, bit for bit (tensors the mode
+    keeps in split form only are handed out as hi + lo by cald_debug_tensor: compared with the same 22-bit value of the oracle's tensor)."""
+    torch = hip["torch"]
+    from cald_amd import synth
+    model, P = small_model_f16x3
+    img = synth.make_pool(3, "voc", 0, scale=0.5)[1]
+    rects = np.array([[20, 30, 60, 70], [100, 10, 130, 50]], np.int32)
+    q = oracle.f16x3_requantize
+    for flip, rc in ((False, None), (True, rects)):
+        keep = {}
+        want = oracle.frcnn_forward(P, img, 300, 500, flip=flip, rects=rc, keep=keep)
+        got = model.forward_views([(torch.from_numpy(img).cuda(), flip, rc)])[0]
+        stages = [("input", keep["input"]), ("conv1", keep["conv1"]), ("pool1", q(keep["pool1"]))]
+        stages += [("C%d" % (i + 2), q(keep["C"][i])) for i in range(4)]
+        stages += [("P%d" % (i + 2), keep["fpn"][i]) for i in range(4)] + [("P6", q(keep["fpn"][4]))]
+        stages += [("rpn%d" % i, keep["rpn_head"][i]) for i in range(5)]
+        for name, w in stages:
+            g = model.debug_tensor(name, 0)
+            assert g.shape == w.shape, (name, g.shape, w.shape)
+            assert g.tobytes() == w.tobytes(), "stage %s differs: max abs %g (%d of %d)" % (name, float(np.abs(g - w).max()), int((g != w).sum()), g.size)
+        n = keep["proposals"].shape[0]
+        gp = model.debug_tensor("proposals", 0).reshape(-1, 4)[:n]
+        assert gp.tobytes() == keep["proposals"].tobytes(), "proposals differ"
+        for name, w in (("roi", q(keep["roi"])), ("fc7", q(keep["fc7"])), ("pred", keep["pred"])):
+            g = model.debug_tensor(name, 0).reshape(1000, -1)[:n]
+            w = w.reshape(n, -1)
+            assert g.tobytes() == w.tobytes(), "stage %s differs: max abs %g" % (name, float(np.abs(g - w).max()))
+        for k in ("boxes", "scores", "labels", "props", "prob_max", "scores_cls"):
+            assert got[k].cpu().numpy().tobytes() == want[k].tobytes(), "output %s differs" % k
+
+
+def test_sweep_f16x3_matches_oracle(hip, oracle, small_model_f16x3):
+    """cald_sweep in CALD_PRECISION_F16X3 == the oracle's get_uncertainty in the same precision, bit for bit, same argsort: the mode's
+    selection is IDENTICAL to that of its CPU restatement (north_star's bar, which round 5 could only state statistically)."""
+    torch = hip["torch"]
+    from cald_amd import synth, sweep
+    model, P = small_model_f16x3
+    pool = synth.make_pool(6, "voc", 0, scale=0.5)
+    augs = ["flip", "cut_out", "smaller_resize"]
+    imgs = [torch.from_numpy(im).cuda() for im in pool]
+    cons, cls = sweep.sweep_device_images(model, imgs, list(range(len(pool))), augs, bp=1.3, base_seed=3, batch_images=4)
+    wc, wcls = oracle.get_uncertainty(P, pool, augs, 21, bp=1.3, min_size=300, max_size=500, base_seed=3)
+    np.testing.assert_array_equal(cons, np.array(wc))
+    np.testing.assert_array_equal(cls, np.stack(wcls))
+    np.testing.assert_array_equal(np.argsort(cons), np.argsort(np.array(wc)))

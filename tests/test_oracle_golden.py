@@ -286,3 +286,56 @@ def test_tv_known_answers_base_anchor_table(oracle, golden):
     g = golden("tv_known_answers")
     got = np.stack([oracle.base_anchors([s], [0.5, 1.0, 2.0]) for s in (32, 64, 128, 256, 512)])
     np.testing.assert_array_equal(got, g["base_anchors"].astype(np.float32))
+
+
+def test_mfma_f16_model_matches_the_hardware_sample_and_its_fast_forms(oracle):
+    """oracle/mfma_f16_model.h (the CPU statement of v_mfma_f32_32x32x16_f16, the primitive of CALD_PRECISION_F16X3) against results the
+    instruction itself produced on an MI355X (tests/golden/mfma_f16_hw.npz <- tools/mfma_model/make_golden.py: 1 000 cases of each
+    directed family), and the two double-precision evaluations oracle/f16x3_oracle.c convolves with against the integer statement on
+    two million random operands.  The `-m gpu` suite repeats the first half live on more than 10^7 cases."""
+    import os
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "mfma_f16_hw.npz"))
+    assert g["D"].size > 20000 and len(set(g["family"].tolist())) >= 20
+    for fast in (None, 0, 1):
+        got = oracle.mfma_f16_dot16(g["A"], g["B"], g["C"], fast)
+        if got is None: continue
+        bad = np.nonzero(got != g["D"])[0]
+        assert bad.size == 0, (fast, bad.size, g["family"][bad[:5]])
+    rs = np.random.RandomState(3)
+    n = 500000
+    for spread in (0, 3, 8, 14):
+        ea = np.clip(rs.randint(-spread, spread + 1, (n, 16)) + rs.randint(-3, 4, (n, 1)), -15, 15)
+        eb = np.clip(rs.randint(-spread, spread + 1, (n, 16)) + rs.randint(-3, 4, (n, 1)), -15, 15)
+        A = ((rs.randint(0, 2, (n, 16)) << 15) | ((ea + 15) << 10) | rs.randint(0, 1024, (n, 16))).astype(np.uint16)
+        B = ((rs.randint(0, 2, (n, 16)) << 15) | ((eb + 15) << 10) | rs.randint(0, 1024, (n, 16))).astype(np.uint16)
+        A[rs.rand(n, 16) < 0.15] = 0
+        Cc = ((rs.randint(0, 2, n).astype(np.uint32) << 31) | ((rs.randint(-40, 41, n) + 127).astype(np.uint32) << 23) | rs.randint(0, 1 << 23, n).astype(np.uint32))
+        Cc[rs.rand(n) < 0.05] = 0
+        want = oracle.mfma_f16_dot16(A, B, Cc)
+        for fast in (0, 1):
+            got = oracle.mfma_f16_dot16(A, B, Cc, fast)
+            if got is None: continue
+            assert np.array_equal(got, want), (spread, fast, int((got != want).sum()))
+
+
+def test_conv2d_f16x3_oracle_is_the_exact_conv_to_split_precision(oracle):
+    """oracle.conv2d_f16x3 (the CPU restatement of CALD_PRECISION_F16X3) stays within 2^-20 sum |a||w| of the exact chain, is the same in its
+    portable and AVX-512 forms, and does not depend on the thread count."""
+    rs = np.random.RandomState(1)
+    for (H, W, Cin, Cout, K, stride, pad) in [(13, 17, 4, 64, 7, 2, 3), (9, 11, 64, 64, 3, 1, 1), (7, 9, 32, 128, 1, 2, 0)]:
+        x = rs.randn(H, W, Cin).astype(np.float32); x[rs.rand(H, W, Cin) < 0.3] = 0
+        wk = (rs.randn(K * K * Cin, Cout) * np.sqrt(2.0 / (Cin * K * K))).astype(np.float32)
+        b = rs.randn(Cout).astype(np.float32)
+        assert oracle.uses_f16x3(Cin, Cout, K, K)
+        y = oracle.conv2d_f16x3(x, wk, K, K, stride, pad, bias=b, relu=True)
+        ex = oracle.conv2d(x, wk, K, K, stride, pad, bias=b, relu=True)
+        mag = oracle.conv2d(np.abs(x), np.abs(wk), K, K, stride, pad)
+        assert np.all(np.abs(y - ex) <= mag * 2.0 ** -20 + 1e-6)
+        oracle.lib().orc_f16x3_force_portable(1); oracle.set_threads(1)
+        try:
+            y0 = oracle.conv2d_f16x3(x, wk, K, K, stride, pad, bias=b, relu=True)
+        finally:
+            oracle.lib().orc_f16x3_force_portable(0); oracle.set_threads(8)
+        assert y0.tobytes() == y.tobytes()
+    assert not oracle.uses_f16x3(256, 15, 1, 1) and oracle.uses_f16x3(1024, 105, 1, 1) and oracle.uses_f16x3(256, 36, 3, 3)
