@@ -57,8 +57,10 @@ static inline float h_to_f32(uint16_t h) {
     else v = ldexpf((float)(m | 1024), ef - 25);
     return (h & 0x8000) ? -v : v;
 }
-/* exponent the instruction's alignment sees: exp field - 15, subnormals -14 */
-static inline int h_align_exp(uint16_t h) { const int ef = (h >> 10) & 31; return ef ? ef - 15 : -14; }
+/* exponent the instruction's alignment sees: exp field - 15, subnormals -14; a zero operand takes no part: F16X3_ZERO_EXP keeps its
+ * exponent sum below every real one */
+#define F16X3_ZERO_EXP (-4096)
+static inline int h_align_exp(uint16_t h) { const int ef = (h >> 10) & 31; return (h & 0x7fffu) == 0 ? F16X3_ZERO_EXP : (ef ? ef - 15 : -14); }
 
 /* one operand element: hi | lo << 16 of `scaled` (the float ALREADY multiplied by its power-of-two scale) */
 static inline uint32_t split_word(float scaled) {
@@ -167,30 +169,26 @@ F16X3_T __m256 pass8_finish(__m512d P, __m256 accf, __m256i emax32) {
     return _mm256_mask_mov_ps(passthrough, valid, r);
 }
 F16X3_T void pass8_avx512(float* acc, const float* av, const int* aE, const float* const* bv, const int16_t* const* bE) {
+    /* bE holds F16X3_ZERO_EXP for a zero operand: its exponent sum can never be the maximum, no mask needed */
     __m512i emax = _mm512_set1_epi32(-4096);
     for (int k = 0; k < 8; k++) {
         if (av[k] == 0.0f) continue;
-        const __m512 b = _mm512_loadu_ps(bv[k]);
-        const __mmask16 nz = _mm512_cmp_ps_mask(b, _mm512_setzero_ps(), _CMP_NEQ_UQ);
-        const __m512i e = _mm512_add_epi32(_mm512_set1_epi32(aE[k]), _mm512_cvtepi16_epi32(_mm256_loadu_si256((const __m256i*)bE[k])));
-        emax = _mm512_mask_max_epi32(emax, nz, emax, e);
+        emax = _mm512_max_epi32(emax, _mm512_add_epi32(_mm512_set1_epi32(aE[k]), _mm512_cvtepi16_epi32(_mm256_loadu_si256((const __m256i*)bE[k]))));
     }
-    const __m256i em_lo = _mm512_castsi512_si256(emax), em_hi = _mm512_extracti64x4_epi64(emax, 1);
-    const __mmask8 any_lo = _mm256_cmpgt_epi32_mask(em_lo, _mm256_set1_epi32(-2000)), any_hi = _mm256_cmpgt_epi32_mask(em_hi, _mm256_set1_epi32(-2000));
-    const __m512d up_lo = pow2_pd(_mm512_maskz_sub_epi64(any_lo, _mm512_set1_epi64(24), _mm512_cvtepi32_epi64(em_lo)));
-    const __m512d up_hi = pow2_pd(_mm512_maskz_sub_epi64(any_hi, _mm512_set1_epi64(24), _mm512_cvtepi32_epi64(em_hi)));
-    __m512d P_lo = _mm512_setzero_pd(), P_hi = _mm512_setzero_pd();
+    const __mmask16 any = _mm512_cmpgt_epi32_mask(emax, _mm512_set1_epi32(-2000));
+    /* 2^(24 - emax) as a float: products are exact in fp32 (22 bits), so is their scaling by a power of two; the cut towards zero at
+     * 2^(emax - 24) is the truncating conversion to int32 (|p| 2^(24 - emax) < 2^26), and the sum of eight stays below 2^29 */
+    const __m512 up = _mm512_castsi512_ps(_mm512_slli_epi32(_mm512_add_epi32(_mm512_maskz_sub_epi32(any, _mm512_set1_epi32(24), emax), _mm512_set1_epi32(127)), 23));
+    __m512i P = _mm512_setzero_si512();
     for (int k = 0; k < 8; k++) {
         if (av[k] == 0.0f) continue;
-        const __m512d a = _mm512_set1_pd((double)av[k]);
-        const __m512 b = _mm512_loadu_ps(bv[k]);
-        const __m512d b_lo = _mm512_cvtps_pd(_mm512_castps512_ps256(b)), b_hi = _mm512_cvtps_pd(_mm512_extractf32x8_ps(b, 1));
-        P_lo = _mm512_add_pd(P_lo, _mm512_roundscale_pd(_mm512_mul_pd(_mm512_mul_pd(a, b_lo), up_lo), _MM_FROUND_TO_ZERO | _MM_FROUND_NO_EXC));
-        P_hi = _mm512_add_pd(P_hi, _mm512_roundscale_pd(_mm512_mul_pd(_mm512_mul_pd(a, b_hi), up_hi), _MM_FROUND_TO_ZERO | _MM_FROUND_NO_EXC));
+        const __m512 p = _mm512_mul_ps(_mm512_mul_ps(_mm512_set1_ps(av[k]), _mm512_loadu_ps(bv[k])), up);
+        P = _mm512_add_epi32(P, _mm512_cvttps_epi32(p));
     }
+    const __m256i em_lo = _mm512_castsi512_si256(emax), em_hi = _mm512_extracti64x4_epi64(emax, 1);
     const __m512 accv = _mm512_loadu_ps(acc);
-    const __m256 r_lo = pass8_finish(P_lo, _mm512_castps512_ps256(accv), em_lo);
-    const __m256 r_hi = pass8_finish(P_hi, _mm512_extractf32x8_ps(accv, 1), em_hi);
+    const __m256 r_lo = pass8_finish(_mm512_cvtepi32_pd(_mm512_castsi512_si256(P)), _mm512_castps512_ps256(accv), em_lo);
+    const __m256 r_hi = pass8_finish(_mm512_cvtepi32_pd(_mm512_extracti64x4_epi64(P, 1)), _mm512_extractf32x8_ps(accv, 1), em_hi);
     _mm256_storeu_ps(acc, r_lo); _mm256_storeu_ps(acc + 8, r_hi);
 }
 #endif

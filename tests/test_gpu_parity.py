@@ -1536,28 +1536,29 @@ def test_certified_rpn_pruning_on_tiny_and_odd_images(hip, oracle):
 
 @pytest.mark.gpu
 def test_f16x3_error_model_of_the_rpn_look_ahead_on_adversarial_operands(hip):
-    """The certified RPN pruning (rpn_prune.hip) bounds the split-fp16 look-ahead's error by a MODEL of v_mfma_f32_32x32x16_f16: operand
-    split <= 3 * 2^-22 per term, one rounding <= 2^-23 of the running magnitude per accumulating instruction, 3 K / 16 of them:
-    |z_f - z| <= (3 * 2^-22 + (3 K / 16) * 2^-23) * sum |a||w|.  Every sweep re-checks the resulting logit bound on real data; this test
-    attacks the model itself on the look-ahead's own layer shape (3 x 3, 256 -> 256, K = 2 304) with operands chosen to hurt: no
-    cancellation at all (every rounding pushes the same way), a 2^20 spread of magnitudes inside one dot product (alignment), exact
-    cancellation of huge terms (error relative to sum |a||w|, not to the result), activations at the format's limit (|x| ~ 4 000).
-    Expected values in float64."""
+    """The certified RPN pruning (rpn_prune.hip) bounds the split-fp16 look-ahead's error with constants derived from the bit-exact statement
+    of v_mfma_f32_32x32x16_f16 (oracle/mfma_f16_model.h; api.hip: operand split <= 3 * 2^-22 per term, per pass <= 2^-23 (1 + 2^-6) of the
+    running magnitude + 10 * 2^-24 of the pass's own products, 6 K / 16 + 6 passes, plus the absolute terms of fp16's subnormal range):
+        |z_f - z| <= g * sum |a||w| + 2^-29 sum |w| + 48 * 2^-(25 + S) |patch|_2 + 8640 * 2^-42 max |w|.
+    This test attacks that inequality on the look-ahead's own layer (3 x 3, 256 -> 256, K = 2 304) at a REAL level size (38 x 50) with
+    operands chosen to hurt: no cancellation at all, a 2^20 spread of magnitudes inside one dot product, exact cancellation of huge terms,
+    activations at the format's limit (|x| ~ 4 000), activations all below 2^-7 (every lo half subnormal: the absolute term), a 2^12 spread
+    of the weights (small weights' lo halves subnormal).  Expected values in float64."""
     ffi, L = hip["ffi"], hip["L"]
-    H = W = 6; Cin = Cout = 256; K = 3
+    H, W = 38, 50; Cin = Cout = 256; K = 3
     rs = np.random.RandomState(5)
     def run(x, w):
         out = np.empty((H, W, Cout), np.float32)
         ffi.check(L.cald_op_conv2d_f16x3(hip["ctx"], ffi.ptr(x), H, W, Cin, ffi.ptr(w), Cout, K, K, 1, 1, None, None, None, None, 0, ffi.ptr(out)))
         xp = np.zeros((H + 2, W + 2, Cin)); xp[1:-1, 1:-1] = x
-        want = np.zeros((H, W, Cout)); S = np.zeros((H, W, Cout))
+        want = np.zeros((H, W, Cout)); S = np.zeros((H, W, Cout)); e2 = np.zeros((H, W))
         w64 = w.astype(np.float64)
         for kh in range(3):
             for kw in range(3):
                 patch = xp[kh:kh + H, kw:kw + W]                                   # [H][W][Cin]
-                want += patch @ w64[:, :, kh, kw].T; S += np.abs(patch) @ np.abs(w64[:, :, kh, kw]).T
-        return np.abs(out - want), S
-    g = 3 * 2.0 ** -22 + (3 * 2304 / 16.0) * 2.0 ** -23
+                want += patch @ w64[:, :, kh, kw].T; S += np.abs(patch) @ np.abs(w64[:, :, kh, kw]).T; e2 += (patch * patch).sum(-1)
+        return np.abs(out - want), S, np.sqrt(e2)
+    g = 3 * 2.0 ** -22 + 10 * 2.0 ** -24 * (1 + 2.0 ** -10) + (6 * 2304 / 16.0 + 6) * 2.0 ** -23 * (1 + 2.0 ** -6)
     cases = {}
     x = (1.0 + rs.rand(H, W, Cin) * 0.999).astype(np.float32); w = (1.0 + rs.rand(Cout, Cin, K, K) * 0.999).astype(np.float32)
     cases["no cancellation"] = (x, w)
@@ -1569,11 +1570,91 @@ def test_f16x3_error_model_of_the_rpn_look_ahead_on_adversarial_operands(hip):
     cases["exact cancellation of huge terms"] = (np.ascontiguousarray(x), np.ascontiguousarray(w))
     x = (rs.choice([-1, 1], (H, W, Cin)) * (3500 + 500 * rs.rand(H, W, Cin))).astype(np.float32); w = (rs.randn(Cout, Cin, K, K) * 0.03).astype(np.float32)
     cases["activations at the limit"] = (x, w)
+    x = (rs.choice([-1, 1], (H, W, Cin)) * 2.0 ** -8 * rs.rand(H, W, Cin)).astype(np.float32); w = (rs.randn(Cout, Cin, K, K) * 0.03).astype(np.float32)
+    cases["all activations below 2^-7"] = (x, w)
+    x = np.abs(rs.randn(H, W, Cin)).astype(np.float32)
+    w = (rs.choice([-1, 1], (Cout, Cin, K, K)) * 2.0 ** rs.randint(-12, 1, (Cout, Cin, K, K)) * (1 + rs.rand(Cout, Cin, K, K))).astype(np.float32)
+    cases["2^12 spread of the weights"] = (x, w)
     for name, (x, w) in cases.items():
-        err, S = run(x, w)
-        ratio = float((err / (g * S + 1e-30)).max())
-        print("f16x3 error model, %-34s max |err| / (g S) = %.4f   (max |err| %.3g, max S %.3g)" % (name, ratio, err.max(), S.max()))
+        err, S, pn = run(x, w)
+        S16 = 14 - int(np.frexp(np.abs(w).max())[1])
+        absolute = 2.0 ** -29 * np.abs(w.astype(np.float64)).sum(axis=(1, 2, 3))[None, None, :] + 48 * 2.0 ** -(25 + S16) * pn[:, :, None] + 8640 * 2.0 ** -42 * float(np.abs(w).max())
+        ratio = float((err / (g * S + absolute + 1e-300)).max())
+        print("f16x3 error bound, %-34s max |err| / bound = %.4f   (max |err| %.3g, max S %.3g, absolute part %.3g)" % (name, ratio, err.max(), S.max(), absolute.max()))
         assert ratio <= 1.0, (name, ratio)
+
+
+@pytest.mark.gpu
+def test_rpn_pruning_bound_holds_on_every_anchor(hip):
+    """The certified pruning's premise, checked where the sweeps cannot see it: on EVERY anchor of P2 / P3 -- the pruned ones included, which
+    no sweep evaluates both ways -- |look-ahead logit - exact logit| <= B_a(p) = c1[a] |patch(p)|_2 + c0[a]; every anchor of the dense head's
+    top pre_nms_top_n is among the selected ones and carries the dense head's bits; detections equal the dense forward's.  Full-size VOC
+    (ResNet-50) and COCO-shaped (ResNet-101) views.  Capture mode (cald_model_set_rpn_prune_capture) makes cald_forward take the pruned
+    path and keep the look-ahead's maps."""
+    torch = hip["torch"]
+    from cald_amd import synth
+    for depth, shape, ncls, mn, mx in ((50, "voc", 21, 600, 1000), (101, "coco", 91, 800, 1333)):
+        sd = synth.pseudo_trained_frcnn(ncls, depth, seed=2)
+        make = hip["det"].fasterrcnn_resnet101_fpn_feature if depth == 101 else hip["det"].fasterrcnn_resnet50_fpn_feature
+        m = make(num_classes=ncls, min_size=mn, max_size=mx).to("cuda")
+        m.load_state_dict(sd); m.eval()
+        pool = synth.make_pool(4, shape, 5)
+        views = [(torch.from_numpy(im).cuda(), bool(i & 1), None) for i, im in enumerate(pool)]
+        c1, c0 = m.rpn_prune_bound()
+        m.set_rpn_prune_capture(True)
+        got_p = m.forward_views(views)
+        cap = [{n: m.debug_tensor(n, v) for n in ("rpn_look0", "rpn_look1", "rpn_pnorm0", "rpn_pnorm1", "rpn0", "rpn1")} for v in range(len(views))]
+        m.set_rpn_prune_capture(False)
+        got_d = m.forward_views(views)
+        worst = 0.0; nanch = 0; nsel = [0, 0]; npix = [0, 0]
+        for v in range(len(views)):
+            for k in ("boxes", "scores", "labels", "props", "prob_max", "scores_cls"):
+                assert got_p[v][k].cpu().numpy().tobytes() == got_d[v][k].cpu().numpy().tobytes(), (depth, v, k)
+            for l in range(2):
+                dense = m.debug_tensor("rpn%d" % l, v)[:, :, :3].astype(np.float64)
+                look = cap[v]["rpn_look%d" % l][:, :, :3].astype(np.float64); pn = cap[v]["rpn_pnorm%d" % l][:, :, 0].astype(np.float64)
+                pruned = cap[v]["rpn%d" % l][:, :, :3]
+                B = c1[None, None, :].astype(np.float64) * pn[:, :, None] + c0[None, None, :].astype(np.float64)
+                ratio = np.abs(look - dense) / B
+                assert np.all(ratio <= 1.0), (depth, v, l, float(ratio.max()))
+                worst = max(worst, float(ratio.max())); nanch += ratio.size
+                sel = pruned[:, :, 0] != -np.finfo(np.float32).max                              # a pixel is selected or parked as a whole
+                assert np.array_equal(pruned[sel], dense.astype(np.float32)[sel])                # selected anchors carry the dense head's bits
+                flat = dense.reshape(-1); k = min(1000, flat.size)
+                order = np.lexsort((np.arange(flat.size), -flat))[:k]                            # (logit desc, index asc): filter_proposals' top-k
+                assert sel.reshape(-1)[order // 3].all(), (depth, v, l)
+                nsel[l] += int(sel.sum()); npix[l] += sel.size
+        print("R%d %s: bound holds on all %d anchors of P2 / P3 (worst |look-ahead - exact| / bound %.2e); selected %.3f of P2, %.3f of P3"
+              % (depth, shape, nanch, worst, nsel[0] / npix[0], nsel[1] / npix[1]))
+        assert nsel[0] < 0.5 * npix[0]
+        del m
+        torch.cuda.empty_cache()
+
+
+@pytest.mark.gpu
+def test_rpn_pruning_falls_back_to_the_dense_head_outside_its_range(hip):
+    """An activation of |x| >= 4094 on P2 / P3 leaves fp16's range after the split's 2^4 scale: the look-ahead would be inf / NaN there and a
+    PRUNED anchor is never evaluated both ways.  The energy kernel flags it and the sweep repeats itself with the dense head: same results
+    as with the pruning switched off, one fallback counted (it used to do all the work and then fail)."""
+    import ctypes as C
+    torch, ffi, L = hip["torch"], hip["ffi"], hip["L"]
+    from cald_amd import synth, sweep
+    sd = dict(synth.pseudo_trained_frcnn(21, 50, seed=0))
+    b = np.array(sd["backbone.fpn.layer_blocks.0.bias"], np.float32).copy(); b[7] += 5000.0        # one P2 channel sits at ~5 000
+    sd["backbone.fpn.layer_blocks.0.bias"] = b
+    m = hip["det"].fasterrcnn_resnet50_fpn_feature(num_classes=21, min_size=300, max_size=500).to("cuda")
+    m.load_state_dict(sd); m.eval()
+    dev = [torch.from_numpy(im).cuda() for im in synth.make_pool(5, "voc", 1, scale=0.5)]
+    n0 = C.c_int64(); ffi.check(L.cald_profile_prune_fallbacks(hip["ctx"], C.byref(n0)))
+    assert m.set_rpn_prune(True) is True
+    a1 = sweep.sweep_device_images(m, dev, list(range(5)), ["flip", "cut_out"], bp=1.3, base_seed=1, batch_images=3)
+    n1 = C.c_int64(); ffi.check(L.cald_profile_prune_fallbacks(hip["ctx"], C.byref(n1)))
+    assert n1.value == n0.value + 1
+    assert m.set_rpn_prune(False) is True                         # the fallback left the switch as it was
+    a0 = sweep.sweep_device_images(m, dev, list(range(5)), ["flip", "cut_out"], bp=1.3, base_seed=1, batch_images=3)
+    assert a1[0].tobytes() == a0[0].tobytes() and a1[1].tobytes() == a0[1].tobytes()
+    n2 = C.c_int64(); ffi.check(L.cald_profile_prune_fallbacks(hip["ctx"], C.byref(n2)))
+    assert n2.value == n1.value
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
@@ -1746,3 +1827,58 @@ def test_sweep_f16x3_matches_oracle(hip, oracle, small_model_f16x3):
     np.testing.assert_array_equal(cons, np.array(wc))
     np.testing.assert_array_equal(cls, np.stack(wcls))
     np.testing.assert_array_equal(np.argsort(cons), np.argsort(np.array(wc)))
+
+
+def test_retinanet_f16x3_forward_and_sweep_match_oracle(hip, oracle):
+    """RetinaNet in CALD_PRECISION_F16X3 against the oracle in the same precision: P3..P7 (P7's conv reads P6 through a ReLU while
+    staging; P3..P5 / P7 exist in split form only), the 36-channel regression head (tile 64: on the matrix pipe) and the 189-channel
+    classification head, detections of one view, then a 3-image sweep -- bit for bit."""
+    torch = hip["torch"]
+    from cald_amd import synth, sweep
+    sd = synth.pseudo_trained_retinanet(21, 50, seed=0)
+    model = hip["det"].retinanet_resnet50_fpn_cal(num_classes=21, min_size=300, max_size=500, precision="f16x3")
+    model.to("cuda").load_state_dict(sd); model.eval()
+    P = oracle.prepare_retinanet(sd, 21, 50); P["precision"] = "f16x3"
+    q = oracle.f16x3_requantize
+    pool = synth.make_pool(3, "voc", 0, scale=0.5)
+    keep = {}
+    want = oracle.retina_forward(P, pool[1], 300, 500, flip=True, keep=keep)
+    got = model.forward_views([(torch.from_numpy(pool[1]).cuda(), True, None)])[0]
+    for i in range(5):
+        fp = keep["fpn"][i] if i == 3 else q(keep["fpn"][i])              # P6 keeps its fp32 form (read through the ReLU); the others are split-only
+        for name, w in (("P%d" % (i + 3), fp), ("cls%d" % i, keep["cls"][i]), ("reg%d" % i, keep["reg"][i])):
+            g = model.debug_tensor(name, 0)
+            assert g.shape == w.shape, (name, g.shape, w.shape)
+            assert g.tobytes() == w.tobytes(), "stage %s differs: max abs %g (%d of %d)" % (name, float(np.abs(g - w).max()), int((g != w).sum()), g.size)
+    for k in ("boxes", "scores", "labels", "prob_max", "scores_cls"):
+        assert got[k].cpu().numpy().tobytes() == want[k].tobytes(), "output %s differs" % k
+    augs = ["flip", "cut_out"]
+    cons, cls = sweep.sweep_device_images(model, [torch.from_numpy(im).cuda() for im in pool], [0, 1, 2], augs, bp=1.3, base_seed=5, batch_images=3)
+    wc, wcls = oracle.get_uncertainty(P, pool, augs, 21, bp=1.3, min_size=300, max_size=500, base_seed=5)
+    np.testing.assert_array_equal(cons, np.array(wc))
+    np.testing.assert_array_equal(cls, np.stack(wcls))
+
+
+def test_config4_one_image_at_size_f16x3_vs_its_cpu_restatement(hip, oracle):
+    """BASELINE.json configs[4] in its own precision AND against a CPU path: Faster R-CNN ResNet-101 FPN, 91 classes, 800 / 1333, a
+    COCO-shaped image with the five augmentations (6 views), precision="f16x3" -- consistency and cls_corr equal the oracle's f16x3
+    restatement bit for bit (the exact mode's analogue is test_config4_full_size_frcnn_r101_coco_five_augs)."""
+    import os
+    torch = hip["torch"]
+    from cald_amd import synth, sweep
+    sd = synth.pseudo_trained_frcnn(91, 101, seed=1)
+    m = hip["det"].fasterrcnn_resnet101_fpn_feature(num_classes=91, min_size=800, max_size=1333, precision="f16x3").to("cuda")
+    m.load_state_dict(sd); m.eval()
+    pool = synth.make_pool(4, "coco", 0)
+    augs = ["flip", "ga", "cut_out", "smaller_resize", "rotation"]
+    c1, k1 = sweep.sweep_device_images(m, [torch.from_numpy(im).cuda() for im in pool], [0, 1, 2, 3], augs, base_seed=4, batch_images=4)
+    P = oracle.prepare_frcnn(sd, 91, 101); P["precision"] = "f16x3"
+    oracle.set_threads(min(128, os.cpu_count() or 1))
+    try:
+        wc, wk = oracle.get_uncertainty(P, [pool[2]], augs, 91, bp=1.3, min_size=800, max_size=1333, base_seed=4, positions=[2])
+    finally:
+        oracle.set_threads(min(32, os.cpu_count() or 1))
+    assert c1[2] == wc[0], (c1[2], wc[0])
+    np.testing.assert_array_equal(k1[2], wk[0])
+    del m
+    torch.cuda.empty_cache()
