@@ -888,7 +888,7 @@ static double fill_conv_args(cald_model* m, ConvArgs& a, const ConvLayer& L, con
             return (double)fail(CALD_ERR_UNSUPPORTED, "a view's activation tensor exceeds 2 GB (level %d -> %d, %lld x %d / %lld x %d elements)", lin, lout, pin, L.Cin, pout, L.Cout);
         }
     }
-    a.in16 = nullptr; a.out16 = nullptr; a.ex16 = 0;
+    a.in16 = nullptr; a.out16 = nullptr; a.ex16 = 0; a.energy4 = nullptr;
     if (!m->split.empty()) {
         const float* ex = residual ? residual : up;
         if (ex) {
@@ -959,7 +959,8 @@ static int conv_pair_on(cald_model* m, const ConvLayer& L2, const ConvLayer& L3,
     return conv_on(m, L3, mid, out, lout, lout, V, true, residual);
 }
 // independent convolutions (bias / BN / ReLU epilogue only) issued as ONE launch when they fit the same tiled kernel
-struct ConvSpec { const ConvLayer* L; const float* in; float* out; int level; bool relu; const int* dyn = nullptr; const int* row_map = nullptr; const unsigned* in16 = nullptr; };
+struct ConvSpec { const ConvLayer* L; const float* in; float* out; int level; bool relu; const int* dyn = nullptr; const int* row_map = nullptr; const unsigned* in16 = nullptr;
+                  unsigned* out16 = nullptr; float* energy4 = nullptr; };      // out16 / energy4: conv_p4.hip's pruning extras (P2 / P3 of the FPN output convs)
 static int conv_group_on(cald_model* m, const ConvSpec* sp, int n, int V) {
     ConvArgs a[CALD_MAX_GROUP];
     double flops = 0.0; int tiles = 0;
@@ -968,6 +969,8 @@ static int conv_group_on(cald_model* m, const ConvSpec* sp, int n, int V) {
         if (f < 0.0) return (int)f;
         a[i].row_map = sp[i].row_map;
         if (sp[i].in16) a[i].in16 = sp[i].in16;       // the input also exists in split form (rpn_prune.hip's look-ahead)
+        if (sp[i].out16) a[i].out16 = sp[i].out16;
+        a[i].energy4 = sp[i].energy4;
         flops += f; tiles += a[i].total_mtiles;
     }
     cald_ctx* c = m->ctx;
@@ -1065,7 +1068,7 @@ static void fwd_layout(cald_model* m, Bump& B, FwdBufs& F, int V) {
     for (int i = 0; i < 2; i++) {
         F.prune_energy[i] = F.prune_pn[i] = F.prune_rows[i] = F.prune_look[i] = nullptr; F.prune_map[i] = nullptr; F.prune_p16[i] = nullptr;
         if (!m->prune) continue;           // RetinaNet never gets here; f16x3 / pruning-off models do not pay for the scratch
-        F.prune_energy[i] = B.get<float>(px[2 + i]); F.prune_pn[i] = B.get<float>(px[2 + i]); F.prune_p16[i] = B.get<unsigned>(px[2 + i] * 256);
+        F.prune_energy[i] = B.get<float>(px[2 + i] * 4); F.prune_pn[i] = B.get<float>(px[2 + i]); F.prune_p16[i] = B.get<unsigned>(px[2 + i] * 256);
         F.prune_rows[i] = B.get<float>(px[2 + i] * 15); F.prune_map[i] = B.get<int>(px[2 + i]);
         if (m->prune_capture) F.prune_look[i] = B.get<float>(px[2 + i] * 15);
     }
@@ -1188,12 +1191,17 @@ static int forward_model(cald_model* m, int V, ViewDesc* views, const DetBuffers
         return 0;
     }
     // ---- FPN (row A16) ----
+    static const bool look_h4 = !(getenv("CALD_RPN_PRUNE_H4") && atoi(getenv("CALD_RPN_PRUNE_H4")) == 0);     // 0: look-ahead on conv_h3's fp32 loader (A/B)
+    static const bool fuse_env = !(getenv("CALD_RPN_PRUNE_FUSED") && atoi(getenv("CALD_RPN_PRUNE_FUSED")) == 0);   // 0: round 5's separate energy pass (A/B)
+    const bool prune_fused = m->prune && prune_ok && look_h4 && fuse_env;
     if ((rc = conv_on(m, m->fpn_inner[3], F.Cf[3], F.inner[3], 5, 5, V, false))) return rc;
     for (int i = 2; i >= 0; i--)
         if ((rc = conv_on(m, m->fpn_inner[i], F.Cf[i], F.inner[i], 2 + i, 2 + i, V, false, nullptr, F.inner[i + 1], 3 + i))) return rc;
     {
         ConvSpec sp[4];
         for (int i = 0; i < 4; i++) sp[i] = {&m->fpn_layer[i], F.inner[i], F.Pf[i], 2 + i, false};
+        if (prune_fused)          // the pruning's per-pixel energy and the look-ahead's split-fp16 operand come out of these convs' epilogues (conv_p4.hip)
+            for (int i = 0; i < 2; i++) { sp[i].out16 = F.prune_p16[i]; sp[i].energy4 = F.prune_energy[i]; }
         if ((rc = conv_group_on(m, sp, 4, V))) return rc;
     }
     {   // LastLevelMaxPool: max_pool2d(P5, 1, 2) = every other pixel of every other row; in F16X3 the copy runs on P5's split twin
@@ -1210,7 +1218,6 @@ static int forward_model(cald_model* m, int V, ViewDesc* views, const DetBuffers
         // level's pre_nms_top_n anchors; P4..P6 dense as ever.  Same bits at every anchor the top-k can select.
         ConvSpec sp[5];
         RpnPruneArgs pr;
-        static const bool look_h4 = !(getenv("CALD_RPN_PRUNE_H4") && atoi(getenv("CALD_RPN_PRUNE_H4")) == 0);     // 0: look-ahead on conv_h3's fp32 loader (A/B)
         for (int i = 0; i < 2; i++) {
             pr.feat[i] = F.Pf[i]; pr.seg[i] = dp->seg[2 + i]; pr.energy[i] = F.prune_energy[i]; pr.pnorm[i] = F.prune_pn[i]; pr.head[i] = F.rpn_h[i]; pr.head_out[i] = F.rpn_h[i];
             pr.head_rows[i] = F.prune_rows[i]; pr.row_map[i] = F.prune_map[i]; pr.split[i] = look_h4 ? F.prune_p16[i] : nullptr;
@@ -1218,7 +1225,8 @@ static int forward_model(cald_model* m, int V, ViewDesc* views, const DetBuffers
         pr.nsel = F.prune_nsel; pr.stat = c->prof ? c->d_prune_stat : nullptr; pr.check = c->d_prune_check;
         for (int q = 0; q < 3; q++) { pr.c1[q] = m->prune_c1[q]; pr.c0[q] = m->prune_c0[q]; }
         pr.head_ld = 15; pr.pre_n = m->cfg.rpn_pre_nms_top_n; pr.V = V;
-        launch_rpn_prune_energy(pr, st);
+        pr.energy_parts = prune_fused ? 4 : 1;
+        if (!prune_fused) launch_rpn_prune_energy(pr, st);
         prof_tag_now = 1;
         for (int i = 0; i < 2; i++) { sp[i] = {&m->rpn_conv16, F.Pf[i], F.rpn_tl[i], 2 + i, true}; sp[i].in16 = pr.split[i]; }
         rc = conv_group_on(m, sp, 2, V);

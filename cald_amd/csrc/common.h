@@ -63,6 +63,10 @@ struct ConvArgs {
     // move operands HBM -> LDS with buffer_load ... lds.  Null = fp32 only.
     const unsigned* in16;
     unsigned* out16;
+    // conv_p4.hip, exact mode, the FPN output convs of P2 / P3 under the certified RPN pruning (rpn_prune.hip): per pixel four partial sums of
+    // squares over the 256 output channels ([pixel][4]: n-tile x wave column, 64 channels each) -- the energy the pruning's bound needs -- and,
+    // through out16, the split-fp16 copy its look-ahead conv reads.  Both were a separate pass over P2 / P3 (prune_energy_kernel) in round 5.
+    float* energy4;
     int ex16;              // `residual` / `up` point at a split-form tensor (same element count) instead of an fp32 one
 };
 

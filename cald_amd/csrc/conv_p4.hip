@@ -9,7 +9,7 @@
 //     conflict-free.  Weights are pre-packed in that order at model finalize (ConvArgs::w4), so B is staged with
 //     coalesced 16-byte loads + ds_write_b128; A is staged with two ds_write_b64 per gathered float4.
 //   Per k-tile and wave: 32 MFMA, 8 ds_read_b128, 6 LDS writes, 4 buffer loads, ~10 VALU.
-#include "common.h"
+#include "h16.h"
 #include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -64,6 +64,21 @@ __device__ __forceinline__ void p4_epilogue(const ConvArgs& a, const f32x16 (&ac
             s_src[tid] = (sy * upW + sx) * out_ld * 4;
         }
         __syncthreads();
+    }
+    // The FPN output convs of P2 / P3 under the certified RPN pruning also leave (i) the split-fp16 copy of their output (h16.h) for the
+    // look-ahead conv and (ii) per pixel the sum of squares over this wave's 64 channels for the bound -- what prune_energy_kernel did in a
+    // second pass over the tensor.  Compiled into the plain (EPI 0, no mask) kernels only; wave-uniform branches elsewhere.
+    constexpr bool EXTRA = EPI == 0 && !MASK;
+    const bool want16 = EXTRA && a.out16 != nullptr, wantE = EXTRA && a.energy4 != nullptr;
+    unsigned char* const out16_v = want16 ? reinterpret_cast<unsigned char*>(a.out16) + so.pix_off * (long long)out_ld * 4 : nullptr;
+    const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void*)(want16 ? (void*)out16_v : (void*)out_v), 0, 0x7FFE0000, 0x00020000);
+    const bool odd = (lane & 1) != 0;
+    float sq[TM][16];
+    if (EXTRA) {
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) sq[i][r] = 0.0f;
     }
 #pragma unroll
     for (int j = 0; j < TN; j++) {
@@ -148,6 +163,41 @@ __device__ __forceinline__ void p4_epilogue(const ConvArgs& a, const f32x16 (&ac
                     if (m < Mv && nok && !((a.exp_flags & 1) && val[r] != 12345.678f)) out_v[(long long)m * out_ld + n] = val[r];
                 }
             }
+            if (EXTRA) {
+                if (wantE) {
+#pragma unroll
+                    for (int r = 0; r < 16; r++) sq[i][r] = sq[i][r] + (nok ? val[r] * val[r] : 0.0f);
+                }
+                if (want16) {       // lanes l and l ^ 1 hold neighbouring channels: the even lane stores {hi, hi}, the odd one {lo, lo} (h16.h)
+                    const int poff = h16_pair_off(nc);
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const unsigned w = h16_split(val[r]);
+                        const unsigned pw = h16_pair_word(w, h16_partner(w), odd);
+                        const int m = mbase + (r & 3) + 8 * (r >> 2);
+                        if (full_tile) __builtin_amdgcn_raw_buffer_store_b32(pw, rsS, nok ? mbase * row_b + poff : 0x7FFF0000, ((r & 3) + 8 * (r >> 2)) * row_b, 0);
+                        else if (m < Mv && nok) *reinterpret_cast<unsigned*>(out16_v + (long long)m * row_b + poff) = pw;
+                    }
+                }
+            }
+        }
+    }
+    if (EXTRA) {
+        if (wantE) {
+            // sum over the wave's 32 column lanes, in lane order (a fixed order: the energy, and with it the pruning's selection, is the same
+            // from run to run): each lane parks its 32 row partials in LDS (free after the k-loop), then lane L adds up row L of the wave's 64
+            __syncthreads();
+            float* const red = smem + wave * (64 * 33);
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) red[(i * 32 + 4 * kh_lane + (r & 3) + 8 * (r >> 2)) * 33 + l31] = sq[i][r];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the wave's own LDS writes have landed (one wave = one reduction, no barrier)
+            float e = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 32; q++) e = e + red[lane * 33 + q];
+            const int m = m0 + wm * TM * 32 + lane;
+            if (m < Mv) a.energy4[(so.pix_off + m) * 4 + (n0 / (64 * TN)) * 2 + wn] = e;
         }
     }
 }

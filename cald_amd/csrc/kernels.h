@@ -149,7 +149,8 @@ void launch_cls_corr(const DetBuffers& det, const int* ref_sel, const int* ref_n
 struct RpnPruneArgs {
     const float* feat[2];        // P2, P3: fp32 [pixel][256]
     const LevelSeg* seg[2];
-    float* energy[2];            // [pixel] scratch: sum of squares over the 256 channels
+    float* energy[2];            // [pixel][energy_parts] scratch: sum of squares over the 256 channels (4 partial sums of 64 channels each when the FPN
+                                 // output conv's epilogue wrote them, ConvArgs::energy4; 1 when prune_energy_kernel did)
     unsigned* split[2];          // optional [pixel][256] words: the split-fp16 form of P2 / P3 (h16.h) written by the energy kernel for the look-ahead conv
     float* pnorm[2];             // [pixel] scratch: |3 x 3 patch|_2 (select kernel -> scatter kernel)
     const float* head[2];        // approximate head maps [pixel][head_ld] (logits = channels 0..2)
@@ -160,7 +161,7 @@ struct RpnPruneArgs {
     unsigned long long* stat;    // optional [4]: selected / total pixels of P2 and P3 accumulated over the calls (profiling), or null
     float* check;                // [2]: running max of |look-ahead - exact| / bound over the selected anchors (must stay <= 1); 1.0f once an activation left the split's range
     float c1[3], c0[3];          // bound per anchor: c1 * |patch|_2 + c0
-    int head_ld, pre_n, V;
+    int head_ld, pre_n, V, energy_parts;
 };
 void launch_rpn_prune_energy(const RpnPruneArgs& a, hipStream_t st);       // before the look-ahead conv (writes its split-form input)
 void launch_rpn_prune_select(const RpnPruneArgs& a, int max_pix, hipStream_t st);

@@ -68,14 +68,18 @@ __global__ __launch_bounds__(256) void prune_energy_kernel(RpnPruneArgs a, int l
 
 // per (level, view): tau by radix select over the lower bounds, the pixel mask, the ordered list of selected pixels.
 // grid = (2, V), block = 1024, dynamic LDS = one bit per pixel.
-__device__ __forceinline__ float prune_patch_norm(const float* e, int y, int x, int H, int W) {
+// (the 1.0001 covers the fp32 rounding of the 9 x 256 squares' sum in whatever order: <= 2 304 u = 1.4e-4 relative, half of it after the root)
+__device__ __forceinline__ float prune_patch_norm(const float* e, int parts, int y, int x, int H, int W) {
     float s = 0.0f;
 #pragma unroll
     for (int dy = -1; dy <= 1; dy++)
 #pragma unroll
         for (int dx = -1; dx <= 1; dx++) {
             const int yy = y + dy, xx = x + dx;
-            if (yy >= 0 && yy < H && xx >= 0 && xx < W) s = s + e[yy * W + xx];
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+                const float* q = e + (yy * W + xx) * parts;
+                s = s + (parts == 4 ? (q[0] + q[1]) + (q[2] + q[3]) : q[0]);
+            }
         }
     return sqrtf(s) * 1.0001f;
 }
@@ -89,7 +93,7 @@ __global__ __launch_bounds__(1024) void prune_select_kernel(RpnPruneArgs a) {
     const int H = sg.H, W = sg.W, npx = H * W, A = 3, n = npx * A;
     const int k = n < a.pre_n ? n : a.pre_n;
     const float* head = a.head[l] + sg.pix_off * (long long)a.head_ld;
-    const float* en = a.energy[l] + sg.pix_off;
+    const float* en = a.energy[l] + sg.pix_off * a.energy_parts;
     float* pnv = a.pnorm[l] + sg.pix_off;           // |patch|_2 per pixel: written once below, re-read by the SAME thread in every pass (and by the scatter kernel)
     int* rmap = a.row_map[l] + sg.pix_off;
     const int words = (npx + 31) >> 5;
@@ -97,7 +101,13 @@ __global__ __launch_bounds__(1024) void prune_select_kernel(RpnPruneArgs a) {
     if (tid == 0) { s_prefix = 0u; s_mask = 0u; s_remaining = k; }
     __syncthreads();
     auto bound = [&](int p, int an, float pn) { return a.c1[an] * pn + a.c0[an]; };
-    for (int p = tid; p < npx; p += 1024) pnv[p] = prune_patch_norm(en, p / W, p % W, H, W);
+    for (int p = tid; p < npx; p += 1024) {
+        const float pn = prune_patch_norm(en, a.energy_parts, p / W, p % W, H, W);
+        pnv[p] = pn;
+        // the range of the split (see prune_energy_kernel): a patch norm below 4094 means every |x| in the patch is; anything else -- a large
+        // activation, inf, NaN -- sends the sweep back to the dense head
+        if (!(pn < 4094.0f) && a.check) atomicMax(reinterpret_cast<unsigned*>(a.check) + 1, __float_as_uint(1.0f));
+    }
     if (n > k) {
         for (int pass = 0; pass < 4; pass++) {                  // the k-th largest of the lower bounds, 8 bits per pass
             const int shift = 24 - 8 * pass;
