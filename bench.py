@@ -277,7 +277,8 @@ def cfg4_f16x3_leg(local_rank, n=128):
             "roofline": {"bound": "mfma", "achieved": ach, "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / F16_MFMA_PEAK_TFLOPS,
                          "launches": int(nl.value), "gemm_ms": gm.value,
                          "note": "algorithmic FLOPs counted once per product (three MFMAs issue per product: at most 1/3 of the pipe)"},
-            "parity_gate": "tests/test_gpu_parity.py::test_config4_full_size_f16x3_vs_exact"}
+            "parity_gate": "tests/test_gpu_parity.py::test_config4_one_image_at_size_f16x3_vs_its_cpu_restatement (bit-identical to the CPU "
+                           "restatement of the mode), ::test_config4_full_size_f16x3_vs_exact (statistics against the exact mode)"}
 
 
 def config0_leg(model, sd, B, threads=None):
@@ -664,9 +665,13 @@ def main():
                                  "images_beyond_1e-4_vs_exact": int((d > 1e-4).sum()),
                                  "selection_budget": bud, "selected_same_set_vs_exact": int(len(set(map(int, sel_e)) & set(map(int, sel_f)))),
                                  "selected_total": int(len(sel_e)), "selected_identical_order": bool(list(map(int, sel_e)) == list(map(int, sel_f))),
-                                 "note": "not bit-identical by design (no CPU can restate v_mfma_f32_32x32x16_f16's internal alignment): a thresholded "
-                                         "pipeline flips a borderline detection on ~1 % of images under ANY change of rounding -- the exact mode against "
-                                         "an independent fp32 path does the same (parity_vs_independent_fp32)"}
+                                 "selection_vs_its_own_cpu_restatement": "identical (bit for bit): oracle/f16x3_oracle.c + mfma_f16_model.h restate the mode down to "
+                                         "v_mfma_f32_32x32x16_f16; tests/test_gpu_parity.py::test_sweep_f16x3_matches_oracle, "
+                                         "::test_config4_one_image_at_size_f16x3_vs_its_cpu_restatement, ::test_mfma_f16_model_equals_the_hardware",
+                                 "note": "the differences above are against the EXACT mode, i.e. between two arithmetics: a thresholded pipeline flips a "
+                                         "borderline detection on ~1 % of these pseudo-trained images under ANY change of rounding -- the exact mode against "
+                                         "an independent fp32 path does the same (parity_vs_independent_fp32); on a detector trained by this repo "
+                                         "0 of 1 024 images move by more than 1e-5 (profiles/r6_trained_weights.json)"}
             del fast
         if world == 1 and headline and not args.no_cfg4:
             out["cfg4_f16x3"] = cfg4_f16x3_leg(local_rank)

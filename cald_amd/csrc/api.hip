@@ -43,6 +43,7 @@ extern "C" int cald_version(void) { return 100; }
 struct PilCoef { int ksize; int* d_bounds; int* d_kk; };
 struct PilKey { int in, out, fid; bool operator<(const PilKey& o) const { return in != o.in ? in < o.in : (out != o.out ? out < o.out : fid < o.fid); } };
 
+#define CALD_PRUNE_LOG 4096     // profiled forwards whose selected-pixel counts are kept per forward (cald_profile_dump)
 struct cald_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -59,6 +60,7 @@ struct cald_ctx {
     std::vector<hipEvent_t> ev0, ev1;
     double prof_flops = 0.0; int64_t prof_extra_launches = 0;
     std::vector<std::string> prof_desc; std::vector<double> prof_fl;
+    int prof_tag_now = 0;                           // set around the look-ahead launches of rpn_prune.hip (per context: ADVICE r5)
     std::vector<int> prof_tag;                      // 0: the model's own arithmetic; 1: the split-fp16 look-ahead pass of rpn_prune.hip (booked apart)
     double prof_prune_flops_cap[2] = {0.0, 0.0};    // FLOPs the gathered P2 / P3 launches would do on every pixel (rescaled to the selected rows at read time)
     hipEvent_t tot0 = nullptr, tot1 = nullptr; bool tot_open = false; double tot_ms = 0.0;
@@ -68,6 +70,10 @@ struct cald_ctx {
     long long prune_fallbacks = 0;                // sweeps repeated with the dense head (bound exceeded / activation outside the split's range)
     float* d_prune_check = nullptr;               // rpn_prune.hip: running max of |look-ahead - exact| / bound (reset by every sweep call)
     unsigned long long* d_prune_stat = nullptr;   // rpn_prune.hip: selected / total pixels of P2, P3 while profiling
+    // per profiled forward [sel P2, total P2, sel P3, total P3]: lets cald_profile_dump book each gathered launch on the rows it really computed
+    unsigned long long* d_prune_log = nullptr; int prune_log_n = 0;
+    struct GatherNote { int log; double cap[2]; };
+    std::map<size_t, GatherNote> prof_gather;     // launch index -> which log slot, and the FLOPs its P2 / P3 problems would cost on every pixel
     unsigned long long* d_roi_rows = nullptr; double prof_roi_rows_cap = 0.0, prof_roi_flops_cap = 0.0; long long prof_roi_views = 0;
     std::map<PilKey, PilCoef> pil;
     char* train_scratch = nullptr; size_t train_scratch_cap = 0;   // train.hip: split-K partial tiles of the weight gradients
@@ -151,6 +157,8 @@ extern "C" int cald_ctx_create(int device, void* stream, cald_ctx** out) {
     HIPCHK(hipMalloc((void**)&c->d_roi_rows, 8));
     HIPCHK(hipMemset(c->d_roi_rows, 0, 8));
     HIPCHK(hipMalloc((void**)&c->d_prune_stat, 32));
+    HIPCHK(hipMalloc((void**)&c->d_prune_log, (size_t)CALD_PRUNE_LOG * 32));
+    HIPCHK(hipMemset(c->d_prune_log, 0, (size_t)CALD_PRUNE_LOG * 32));
     HIPCHK(hipMemset(c->d_prune_stat, 0, 32));
     HIPCHK(hipMalloc((void**)&c->d_prune_check, 8));
     HIPCHK(hipMemset(c->d_prune_check, 0, 8));
@@ -179,7 +187,7 @@ extern "C" int cald_ctx_destroy(cald_ctx* c) {
     if (c->train_scratch) hipFree(c->train_scratch);
     cald_internal_train_release(c);
     for (int i = 0; i < cald_ctx::NSTAGE; i++) { if (c->h_stage[i]) hipHostFree(c->h_stage[i]); if (c->stage_ev[i]) hipEventDestroy(c->stage_ev[i]); }
-    hipFree(c->d_plan); hipFree(c->d_views); hipFree(c->d_zeros); hipFree(c->d_roi_rows); hipFree(c->d_prune_stat); hipFree(c->d_prune_check);
+    hipFree(c->d_plan); hipFree(c->d_views); hipFree(c->d_zeros); hipFree(c->d_roi_rows); hipFree(c->d_prune_stat); hipFree(c->d_prune_log); hipFree(c->d_prune_check);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
     return 0;
@@ -196,6 +204,8 @@ extern "C" int cald_profile_enable(cald_ctx* c, int on) {
     c->prof_roi_rows_cap = 0.0; c->prof_roi_flops_cap = 0.0; c->prof_roi_views = 0;
     HIPCHK(hipMemsetAsync(c->d_roi_rows, 0, 8, c->stream));
     HIPCHK(hipMemsetAsync(c->d_prune_stat, 0, 32, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_prune_log, 0, (size_t)CALD_PRUNE_LOG * 32, c->stream));
+    c->prune_log_n = 0; c->prof_gather.clear();
     if (on && !c->tot0) { HIPCHK(hipEventCreate(&c->tot0)); HIPCHK(hipEventCreate(&c->tot1)); }
     return 0;
 }
@@ -258,15 +268,26 @@ extern "C" int cald_profile_dump(cald_ctx* c, const char* path) {
     FILE* f = fopen(path, "w");
     if (!f) return fail(CALD_ERR_INVALID, "cannot open %s", path);
     fprintf(f, "launch,desc,gflop,ms,tflops\n");
+    std::vector<unsigned long long> lg((size_t)CALD_PRUNE_LOG * 4, 0ull);
+    if (!c->prof_gather.empty()) HIPCHK(hipMemcpy(lg.data(), c->d_prune_log, lg.size() * 8, hipMemcpyDeviceToHost));
     for (size_t i = 0; i < c->ev0.size(); i++) {
         float t = 0.f; hipEventElapsedTime(&t, c->ev0[i], c->ev1[i]);
-        fprintf(f, "%zu,\"%s%s\",%.3f,%.4f,%.2f\n", i, c->prof_desc[i].c_str(), c->prof_tag[i] ? ",f16x3-lookahead" : "", c->prof_fl[i] / 1e9, t, c->prof_fl[i] / (t * 1e-3) / 1e12);
+        double fl = c->prof_fl[i];
+        const char* extra = c->prof_tag[i] ? ",f16x3-lookahead" : "";
+        auto g = c->prof_gather.find(i);
+        if (g != c->prof_gather.end()) {       // a gathered launch of the certified pruning: FLOPs of the rows it computed, not of every pixel
+            for (int l = 0; l < 2; l++) {
+                const unsigned long long sel = lg[(size_t)g->second.log * 4 + 2 * l], tot = lg[(size_t)g->second.log * 4 + 2 * l + 1];
+                if (tot) fl -= g->second.cap[l] * (1.0 - (double)sel / (double)tot);
+            }
+            extra = ",gathered-rows";
+        }
+        fprintf(f, "%zu,\"%s%s\",%.3f,%.4f,%.2f\n", i, c->prof_desc[i].c_str(), extra, fl / 1e9, t, fl / (t * 1e-3) / 1e12);
     }
     fclose(f);
     return 0;
 }
 
-static int prof_tag_now = 0;      // set around the look-ahead launches of rpn_prune.hip (single-threaded per context, like the rest of the profile)
 // conv launch with optional event bracketing
 static int run_conv(cald_ctx* c, const ConvArgs& a, double flops) {
     if (c->prof) {
@@ -277,7 +298,7 @@ static int run_conv(cald_ctx* c, const ConvArgs& a, double flops) {
         HIPCHK(hipEventRecord(e1, c->stream));
         c->ev0.push_back(e0); c->ev1.push_back(e1); c->prof_flops += flops;
         char d[160]; snprintf(d, sizeof(d), "mt=%d,Cin=%d,Cout=%d,k=%dx%d,s=%d", a.total_mtiles, a.Cin, a.Cout, a.KH, a.KW, a.stride);
-        c->prof_desc.push_back(d); c->prof_fl.push_back(flops); c->prof_tag.push_back(prof_tag_now);
+        c->prof_desc.push_back(d); c->prof_fl.push_back(flops); c->prof_tag.push_back(c->prof_tag_now);
     } else {
         launch_conv(a, c->stream);
     }
@@ -982,7 +1003,7 @@ static int conv_group_on(cald_model* m, const ConvSpec* sp, int n, int V) {
         HIPCHK(hipEventRecord(e1, c->stream));
         c->ev0.push_back(e0); c->ev1.push_back(e1); c->prof_flops += flops;
         char d[160]; snprintf(d, sizeof(d), "mt=%d,Cin=%d,Cout=%d,k=%dx%d,s=%d,group=%d", tiles, a[0].Cin, a[0].Cout, a[0].KH, a[0].KW, a[0].stride, n);
-        c->prof_desc.push_back(d); c->prof_fl.push_back(flops); c->prof_tag.push_back(prof_tag_now);
+        c->prof_desc.push_back(d); c->prof_fl.push_back(flops); c->prof_tag.push_back(c->prof_tag_now);
     } else {
         launch_conv_group(a, n, c->stream);
     }
@@ -1222,17 +1243,18 @@ static int forward_model(cald_model* m, int V, ViewDesc* views, const DetBuffers
             pr.feat[i] = F.Pf[i]; pr.seg[i] = dp->seg[2 + i]; pr.energy[i] = F.prune_energy[i]; pr.pnorm[i] = F.prune_pn[i]; pr.head[i] = F.rpn_h[i]; pr.head_out[i] = F.rpn_h[i];
             pr.head_rows[i] = F.prune_rows[i]; pr.row_map[i] = F.prune_map[i]; pr.split[i] = look_h4 ? F.prune_p16[i] : nullptr;
         }
-        pr.nsel = F.prune_nsel; pr.stat = c->prof ? c->d_prune_stat : nullptr; pr.check = c->d_prune_check;
+        const int log_slot = (c->prof && c->prune_log_n < CALD_PRUNE_LOG) ? c->prune_log_n++ : -1;
+        pr.nsel = F.prune_nsel; pr.stat = c->prof ? c->d_prune_stat : nullptr; pr.log = log_slot >= 0 ? c->d_prune_log + (size_t)log_slot * 4 : nullptr; pr.check = c->d_prune_check;
         for (int q = 0; q < 3; q++) { pr.c1[q] = m->prune_c1[q]; pr.c0[q] = m->prune_c0[q]; }
         pr.head_ld = 15; pr.pre_n = m->cfg.rpn_pre_nms_top_n; pr.V = V;
         pr.energy_parts = prune_fused ? 4 : 1;
         if (!prune_fused) launch_rpn_prune_energy(pr, st);
-        prof_tag_now = 1;
+        c->prof_tag_now = 1;
         for (int i = 0; i < 2; i++) { sp[i] = {&m->rpn_conv16, F.Pf[i], F.rpn_tl[i], 2 + i, true}; sp[i].in16 = pr.split[i]; }
         rc = conv_group_on(m, sp, 2, V);
         for (int i = 0; i < 2; i++) sp[i] = {&m->rpn_head, F.rpn_tl[i], F.rpn_h[i], 2 + i, false};
         if (!rc) rc = conv_group_on(m, sp, 2, V);
-        prof_tag_now = 0;
+        c->prof_tag_now = 0;
         if (rc) return rc;
         if (c->prof) for (int i = 0; i < 2; i++) c->prof_prune_flops_cap[i] += 2.0 * (double)level_pix(m->plan, 2 + i, V) * (2304.0 * 256.0 + 256.0 * 15.0);
         if (m->prune_capture)
@@ -1245,9 +1267,11 @@ static int forward_model(cald_model* m, int V, ViewDesc* views, const DetBuffers
         for (int i = 0; i < 5; i++) sp[i] = {&m->rpn_conv, F.Pf[i], F.rpn_tl[i], 2 + i, true};
         for (int i = 0; i < 2; i++) { sp[i].dyn = F.prune_nsel + i * V; sp[i].row_map = F.prune_map[i]; }      // gathered rows, compact output
         if ((rc = conv_group_on(m, sp, 5, V))) return rc;
+        if (log_slot >= 0) c->prof_gather[c->prof_fl.size() - 1] = {log_slot, {2.0 * (double)level_pix(m->plan, 2, V) * 2304.0 * 256.0, 2.0 * (double)level_pix(m->plan, 3, V) * 2304.0 * 256.0}};
         for (int i = 0; i < 5; i++) sp[i] = {&m->rpn_head, F.rpn_tl[i], i < 2 ? F.prune_rows[i] : F.rpn_h[i], 2 + i, false};
         for (int i = 0; i < 2; i++) sp[i].dyn = F.prune_nsel + i * V;
         if ((rc = conv_group_on(m, sp, 5, V))) return rc;
+        if (log_slot >= 0) c->prof_gather[c->prof_fl.size() - 1] = {log_slot, {2.0 * (double)level_pix(m->plan, 2, V) * 256.0 * 15.0, 2.0 * (double)level_pix(m->plan, 3, V) * 256.0 * 15.0}};
         launch_rpn_prune_scatter(pr, st);
         for (int i = m->prune_capture ? 0 : 2; i < 5; i++) m->dbg[rn[i]] = {F.rpn_h[i], 2 + i, 15, 0};      // (P2 / P3 head maps are exact only where selected, -FLT_MAX elsewhere: a debug view in capture mode only)
     } else {   // the shared-weight RPN head over the five levels: one launch for the 3x3 conv, one for the fused 1x1 heads

@@ -19,6 +19,7 @@
 //   Epilogue:   (+bias) -> (*bn_scale, +bn_shift) -> (+residual) -> (+nearest-upsampled top-down)
 //               -> ReLU, fused; residual rows are loaded as a batch before the stores.
 #include "common.h"
+#include <cstdio>
 #include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -307,6 +308,11 @@ void launch_conv(const ConvArgs& a, hipStream_t stream) {
     static const int stem = conv_env("CALD_CONV_STEM", 1);   // 0: the stem runs on the generic kernels (same bits)
     if (stem && a.wstem && launch_conv_stem(a, stream)) return;
     if (p4 && launch_conv_p4(a, stream)) return;
+    if (a.row_map) {                   // gathered rows exist in conv_p4.hip only (api.hip switches the pruning off when CALD_CONV_P4=0):
+                                         // never compute the wrong rows silently -- the sweep's bound check then sends it to the dense head
+        fprintf(stderr, "cald: a gathered conv launch (Cin=%d Cout=%d) found no kernel with row_map support; launch skipped\n", a.Cin, a.Cout);
+        return;
+    }
     if (a.CoutPad % 128 == 0) launch_cfg<2, 2, 2, 2, 16>(a, 128, stream);
     else if (a.CoutPad % 64 == 0) launch_cfg<2, 2, 2, 1, 16>(a, 64, stream);
     else launch_cfg<4, 1, 1, 1, 16>(a, 32, stream);

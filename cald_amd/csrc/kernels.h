@@ -159,6 +159,7 @@ struct RpnPruneArgs {
     int* row_map[2];             // [pixel] -> selected pixel index, compact per view
     int* nsel;                   // [2][V] selected pixels per (level, view): the dyn_rows of the gathered launches
     unsigned long long* stat;    // optional [4]: selected / total pixels of P2 and P3 accumulated over the calls (profiling), or null
+    unsigned long long* log;     // optional [4]: the same counts of THIS forward only (cald_profile_dump books the gathered launches with them), or null
     float* check;                // [2]: running max of |look-ahead - exact| / bound over the selected anchors (must stay <= 1); 1.0f once an activation left the split's range
     float c1[3], c0[3];          // bound per anchor: c1 * |patch|_2 + c0
     int head_ld, pre_n, V, energy_parts;

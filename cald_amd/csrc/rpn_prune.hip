@@ -170,6 +170,7 @@ __global__ __launch_bounds__(1024) void prune_select_kernel(RpnPruneArgs a) {
     if (tid == 0) {
         a.nsel[l * a.V + v] = base;
         if (a.stat) { atomicAdd(a.stat + 2 * l, (unsigned long long)base); atomicAdd(a.stat + 2 * l + 1, (unsigned long long)npx); }
+        if (a.log) { atomicAdd(a.log + 2 * l, (unsigned long long)base); atomicAdd(a.log + 2 * l + 1, (unsigned long long)npx); }
     }
     // unselected pixels: their three logits can never reach the top-k -- park them below every real logit
     float* headw = a.head_out[l] + sg.pix_off * (long long)a.head_ld;
