@@ -538,7 +538,7 @@ def test_full_size_properties_and_oracle_spot_check(hip, oracle):
         np.testing.assert_array_equal(c1, cw); np.testing.assert_array_equal(k1, kw)
     assert np.all(c1 >= 0) and np.all(c1 <= 1.0) and len(np.unique(np.round(c1, 6))) > 6
     P = oracle.prepare_frcnn(sd, 21, 50)
-    exact = [0, 3, 4, 8, 9, 11]                                                                   # 6 of the 12 images, bit for bit
+    exact = [0, 4, 9, 11]                                                                         # 4 of the 12 images, bit for bit
     import os
     oracle.set_threads(min(128, os.cpu_count() or 1))
     try:
@@ -648,7 +648,7 @@ def test_config2_full_size_retinanet_voc(hip, oracle):
     np.testing.assert_array_equal(c1, cw); np.testing.assert_array_equal(k1, kw)
     assert np.all(c1 >= 0) and np.all(c1 <= 1.0) and len(np.unique(np.round(c1, 6))) > 6 and (k1 > 0).any()
     P = oracle.prepare_retinanet(sd, 21, 50)
-    exact = (0, 2, 5, 7, 8, 11)                         # 6 of the 12 images (the GPU suite has a 20-minute budget)
+    exact = (0, 5, 8, 11)                               # 4 of the 12 images (the GPU suite has a 20-minute budget; round 6 added the f16x3 oracle's cases)
     oracle.set_threads(min(128, os.cpu_count() or 1))
     try:
         wc, wk = oracle.get_uncertainty(P, [pool[i] for i in exact], augs, 21, bp=1.3, min_size=600, max_size=1000, base_seed=3, positions=list(exact))
@@ -663,13 +663,13 @@ def test_config2_full_size_retinanet_voc(hip, oracle):
 
 def test_config3_full_size_frcnn_r50_coco(hip, oracle):
     """BASELINE.json configs[3]: Faster R-CNN ResNet-50 FPN, COCO shapes, 91 classes, 800/1333, flip / cut_out / smaller_resize."""
-    _full_size_coco_case(hip, oracle, 50, ["flip", "cut_out", "smaller_resize"], (0, 3, 5, 6, 8, 11), seed=0)
+    _full_size_coco_case(hip, oracle, 50, ["flip", "cut_out", "smaller_resize"], (0, 3, 6, 11), seed=0)
 
 
 def test_config4_full_size_frcnn_r101_coco_five_augs(hip, oracle):
     """BASELINE.json configs[4]: Faster R-CNN ResNet-101 FPN, COCO shapes, 5 augmentations (FCDR + G: flip, ga, cut_out,
     smaller_resize, rotation -> 6 views per image), exact fp32."""
-    _full_size_coco_case(hip, oracle, 101, ["flip", "ga", "cut_out", "smaller_resize", "rotation"], (0, 5, 10), seed=1)   # 3 of 12: a ResNet-101 image with six views costs the CPU oracle ~30 s
+    _full_size_coco_case(hip, oracle, 101, ["flip", "ga", "cut_out", "smaller_resize", "rotation"], (0, 10), seed=1)   # 2 of 12: a ResNet-101 image with six views costs the CPU oracle ~30 s (a third one runs in f16x3 against the f16x3 oracle below)
 
 
 def test_config4_full_size_f16x3_vs_exact(hip):
