@@ -1882,3 +1882,40 @@ def test_config4_one_image_at_size_f16x3_vs_its_cpu_restatement(hip, oracle):
     np.testing.assert_array_equal(k1[2], wk[0])
     del m
     torch.cuda.empty_cache()
+
+
+def test_pruning_is_bit_identical_on_a_detector_trained_here(hip):
+    """The certified pruning (and the exact sweep as a whole) on weights with TRAINED statistics instead of the pseudo-trained ones every other
+    test uses: 300 steps of this repo's own training step (cald_amd/train.py <-> cald_train.py:40-74) on the labelled synthetic set of
+    tools/trained_weights_study.py, then a 24-image sweep with the pruning on and off: bit-identical, no dense fallback, and the RPN has
+    learned enough that the pruning recomputes fewer pixels than on the weights it started from (profiles/r6_trained_weights.json has the
+    2 400-step version: 2.6 % of P2 instead of 11.7 %)."""
+    import ctypes as C
+    import importlib.util, os
+    torch, ffi, L = hip["torch"], hip["ffi"], hip["L"]
+    from cald_amd import synth, sweep
+    spec = importlib.util.spec_from_file_location("tws", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "trained_weights_study.py"))
+    tws = importlib.util.module_from_spec(spec); spec.loader.exec_module(tws)
+    sd, hist, _ = tws.train_detector(300, 128, 4, seed=0, log=lambda *a: None)
+    assert hist[-1]["loss_objectness"] < 0.25 * hist[0]["loss_objectness"]
+    dev = [torch.from_numpy(im).cuda() for im in synth.make_pool(24, "voc", 3)]
+    pos = list(range(24)); augs = ["flip", "cut_out", "smaller_resize"]
+    frac = {}
+    for tag, w in (("start", synth.pseudo_trained_frcnn(21, 50, seed=0)), ("trained", sd)):
+        m = hip["det"].fasterrcnn_resnet50_fpn_feature(num_classes=21, min_size=600, max_size=1000).to("cuda")
+        m.load_state_dict(w); m.eval()
+        n0 = C.c_int64(); ffi.check(L.cald_profile_prune_fallbacks(hip["ctx"], C.byref(n0)))
+        ffi.check(L.cald_profile_enable(hip["ctx"], 1))
+        c1, k1 = sweep.sweep_device_images(m, dev, pos, augs, bp=1.3, base_seed=7, batch_images=24)
+        f = (C.c_double * 2)(); worst = C.c_double()
+        ffi.check(L.cald_profile_prune(hip["ctx"], None, None, f, C.byref(worst), None))
+        ffi.check(L.cald_profile_enable(hip["ctx"], 0))
+        n1 = C.c_int64(); ffi.check(L.cald_profile_prune_fallbacks(hip["ctx"], C.byref(n1)))
+        m.set_rpn_prune(False)
+        c0, k0 = sweep.sweep_device_images(m, dev, pos, augs, bp=1.3, base_seed=7, batch_images=24)
+        assert c1.tobytes() == c0.tobytes() and k1.tobytes() == k0.tobytes(), tag
+        assert n1.value == n0.value and worst.value < 0.25, (tag, n1.value - n0.value, worst.value)
+        frac[tag] = (f[0], f[1])
+        del m; torch.cuda.empty_cache()
+    print("pruning recomputes P2 %.3f / P3 %.3f of the pixels on the starting weights, %.3f / %.3f after 300 training steps" % (frac["start"] + frac["trained"]))
+    assert frac["trained"][0] < frac["start"][0]

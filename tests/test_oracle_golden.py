@@ -339,3 +339,26 @@ def test_conv2d_f16x3_oracle_is_the_exact_conv_to_split_precision(oracle):
             oracle.lib().orc_f16x3_force_portable(0); oracle.set_threads(8)
         assert y0.tobytes() == y.tobytes()
     assert not oracle.uses_f16x3(256, 15, 1, 1) and oracle.uses_f16x3(1024, 105, 1, 1) and oracle.uses_f16x3(256, 36, 3, 3)
+
+
+def test_f16x3_oracle_reproduces_the_gpu_golden(oracle):
+    """oracle/f16x3_oracle.c (the CPU restatement of CALD_PRECISION_F16X3) against bits an MI355X produced in that mode
+    (tests/golden/f16x3_gpu_small.npz <- tools/make_golden_f16x3.py, run on the GPU box): stage tensors of one forward by SHA-1, its
+    detections, and a 2-image sweep -- so a CPU-only box also sees the f16x3 oracle pinned to the hardware, not only to itself."""
+    import hashlib, os
+    from conftest import GOLDEN
+    from cald_amd import synth
+    path = os.path.join(GOLDEN, "f16x3_gpu_small.npz")
+    g = np.load(path)
+    sd = synth.pseudo_trained_frcnn(21, 50, seed=0)
+    P = oracle.prepare_frcnn(sd, 21, 50); P["precision"] = "f16x3"
+    pool = synth.make_pool(2, "voc", 0, scale=0.4)
+    keep = {}
+    want = oracle.frcnn_forward(P, pool[0], 240, 400, keep=keep)
+    for name, t in (("conv1", keep["conv1"]), ("P2", keep["fpn"][0]), ("P3", keep["fpn"][1]), ("P4", keep["fpn"][2]), ("P5", keep["fpn"][3]),
+                    ("rpn0", keep["rpn_head"][0]), ("rpn4", keep["rpn_head"][4])):
+        assert hashlib.sha1(np.ascontiguousarray(t).tobytes()).digest() == g["sha1_" + name].tobytes(), name
+    np.testing.assert_array_equal(want["boxes"], g["boxes"]); np.testing.assert_array_equal(want["scores"], g["scores"])
+    np.testing.assert_array_equal(want["labels"], g["labels"])
+    wc, wk = oracle.get_uncertainty(P, pool, ["flip"], 21, bp=1.3, min_size=240, max_size=400, base_seed=3)
+    np.testing.assert_array_equal(np.array(wc), g["consistency"]); np.testing.assert_array_equal(np.stack(wk), g["cls_corr"])
