@@ -84,7 +84,7 @@ def train_detector(steps, n_train, batch, seed=0, log=print):
             loss = model(ims, tgs); total = sum(loss.values())
             opt.zero_grad(); total.backward(); opt.step()
             if step % 100 == 0 or step == steps - 1:
-                v = {k: float(x) for k, x in loss.items()}
+                v = {k: float(x.detach()) for k, x in loss.items()}
                 if not np.isfinite(sum(v.values())): raise RuntimeError("loss is not finite at step %d: %r" % (step, v))      # cald_train.py:62-65
                 hist.append(dict(step=step, lr=lr, **v)); log("step %4d lr %.4f  %s" % (step, lr, "  ".join("%s %.4f" % kv for kv in v.items())))
             step += 1
