@@ -1459,16 +1459,19 @@ void launch_mfma_f16_probe(const unsigned short* A, const unsigned short* B, con
 extern "C" int cald_op_mfma_f16(cald_ctx* c, const uint16_t* A, const uint16_t* B, const uint32_t* C, uint32_t* D, int64_t n) {
     if (!c || !A || !B || !C || !D || n < 1) return fail(CALD_ERR_INVALID, "cald_op_mfma_f16: null argument or n < 1");
     HIPCHK(hipSetDevice(c->device));
-    unsigned short *dA = nullptr, *dB = nullptr; unsigned *dC = nullptr, *dD = nullptr;
-    HIPCHK(hipMalloc((void**)&dA, (size_t)n * 32)); HIPCHK(hipMalloc((void**)&dB, (size_t)n * 32));
-    HIPCHK(hipMalloc((void**)&dC, (size_t)n * 4)); HIPCHK(hipMalloc((void**)&dD, (size_t)n * 4));
-    HIPCHK(hipMemcpyAsync(dA, A, (size_t)n * 32, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(dB, B, (size_t)n * 32, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(dC, C, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
-    launch_mfma_f16_probe(dA, dB, dC, dD, (long long)n, c->stream);
-    HIPCHK(hipMemcpyAsync(D, dD, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    struct Bufs {       // freed on every exit path
+        void* p[4] = {nullptr, nullptr, nullptr, nullptr};
+        ~Bufs() { for (void* q : p) if (q) hipFree(q); }
+    } d;
+    HIPCHK(hipMalloc(&d.p[0], (size_t)n * 32)); HIPCHK(hipMalloc(&d.p[1], (size_t)n * 32));
+    HIPCHK(hipMalloc(&d.p[2], (size_t)n * 4)); HIPCHK(hipMalloc(&d.p[3], (size_t)n * 4));
+    HIPCHK(hipMemcpyAsync(d.p[0], A, (size_t)n * 32, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(d.p[1], B, (size_t)n * 32, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(d.p[2], C, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    launch_mfma_f16_probe((const unsigned short*)d.p[0], (const unsigned short*)d.p[1], (const unsigned*)d.p[2], (unsigned*)d.p[3], (long long)n, c->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(D, d.p[3], (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    hipFree(dA); hipFree(dB); hipFree(dC); hipFree(dD);
     return 0;
 }
 extern "C" int cald_op_conv2d_f16x3(cald_ctx* c, const float* in, int H, int W, int Cin, const float* weight, int Cout, int KH, int KW,

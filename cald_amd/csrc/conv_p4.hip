@@ -69,7 +69,7 @@ __device__ __forceinline__ void p4_epilogue(const ConvArgs& a, const f32x16 (&ac
     // look-ahead conv and (ii) per pixel the sum of squares over this wave's 64 channels for the bound -- what prune_energy_kernel did in a
     // second pass over the tensor.  Compiled into the plain (EPI 0, no mask) kernels only; wave-uniform branches elsewhere.
     constexpr bool EXTRA = EPI == 0 && !MASK;
-    const bool want16 = EXTRA && a.out16 != nullptr, wantE = EXTRA && a.energy4 != nullptr;
+    const bool want16 = EXTRA && a.out16 != nullptr, wantE = EXTRA && TN == 2 && a.energy4 != nullptr;      // energy4 has four slots: 2 n-tiles of 128 x 2 wave columns (Cout = 256)
     unsigned char* const out16_v = want16 ? reinterpret_cast<unsigned char*>(a.out16) + so.pix_off * (long long)out_ld * 4 : nullptr;
     const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void*)(want16 ? (void*)out16_v : (void*)out_v), 0, 0x7FFE0000, 0x00020000);
     const bool odd = (lane & 1) != 0;

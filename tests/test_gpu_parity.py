@@ -866,15 +866,22 @@ def test_two_ranks_on_hardware_equal_one_rank(hip, small_model):
     loader = [((torch.from_numpy(im),), (None,)) for im in pool]
     c1, k1 = sweep.get_uncertainty(model, loader, ["flip", "cut_out", "smaller_resize"], 21, bp=1.3, base_seed=6)
     backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, backend, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=600) for _ in procs]
-    for p in procs:
-        p.join(timeout=120)
+    for attempt in range(2):
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, backend, q)) for r in range(2)]
+        for p in procs:
+            p.start()
+        res = [q.get(timeout=600) for _ in procs]
+        for p in procs:
+            p.join(timeout=120)
+        # a rank that could not START (rendezvous on a port somebody else grabbed between the probe and the bind: seen once in ~10 suite runs)
+        # gets one more try on a fresh port; a rank that ran and returned different numbers never does
+        if attempt == 0 and any(r[3] is not None and r[1] is None for r in res):
+            print("two-rank launch failed once, retrying on a new port:", [r[3] for r in res])
+            continue
+        break
     assert sorted(r[0] for r in res) == [0, 1]
     for rank, cons, cls, err in res:
         assert err is None, "rank %d failed: %s" % (rank, err)
