@@ -62,7 +62,8 @@ struct cald_ctx {
     std::vector<std::string> prof_desc; std::vector<double> prof_fl;
     int prof_tag_now = 0;                           // set around the look-ahead launches of rpn_prune.hip (per context: ADVICE r5)
     std::vector<int> prof_tag;                      // 0: the model's own arithmetic; 1: the split-fp16 look-ahead pass of rpn_prune.hip (booked apart)
-    double prof_prune_flops_cap[2] = {0.0, 0.0};    // FLOPs the gathered P2 / P3 launches would do on every pixel (rescaled to the selected rows at read time)
+    double prof_prune_flops_cap[2] = {0.0, 0.0};    // FLOPs the gathered P2 / P3 launches are booked with (every pixel, once per selection stage; rescaled to the selected rows at read time)
+    int prof_prune_stage_launches = 1;              // selection stages per forward: the booked FLOPs hold that many copies of the dense head
     hipEvent_t tot0 = nullptr, tot1 = nullptr; bool tot_open = false; double tot_ms = 0.0;
     // RoI-head GEMMs run on a device-side row count (proposals after NMS): the profile counts their algorithmic FLOPs on the
     // MEASURED rows, accumulated on the device while profiling (no host sync inside a forward)
@@ -225,7 +226,8 @@ extern "C" int cald_profile_read(cald_ctx* c, double* gemm_ms, double* gemm_flop
     if (c->prof_roi_rows_cap > 0.0) fl -= c->prof_roi_flops_cap * (1.0 - (double)rows / c->prof_roi_rows_cap);
     unsigned long long st[4] = {0, 0, 0, 0};     // the gathered RPN launches were booked on every pixel of P2 / P3: rescale to the selected rows
     HIPCHK(hipMemcpy(st, c->d_prune_stat, 32, hipMemcpyDeviceToHost));
-    for (int l = 0; l < 2; l++) if (st[2 * l + 1]) fl -= c->prof_prune_flops_cap[l] * (1.0 - (double)st[2 * l] / (double)st[2 * l + 1]);
+    // booked: one dense head per selection stage; executed: the selected rows of all stages together
+    for (int l = 0; l < 2; l++) if (st[2 * l + 1]) fl -= c->prof_prune_flops_cap[l] * (1.0 - (double)st[2 * l] / ((double)c->prof_prune_stage_launches * (double)st[2 * l + 1]));
     if (gemm_flops) *gemm_flops = fl;
     if (launches) *launches = (int64_t)c->ev0.size() - look_n + c->prof_extra_launches;   // a timed region can hold several kernel launches
     if (total_ms) *total_ms = c->tot_ms;
@@ -246,7 +248,7 @@ extern "C" int cald_profile_prune(cald_ctx* c, double* look_ms, double* look_flo
     if (worst_bound_ratio) *worst_bound_ratio = (double)c->prune_worst;
     if (pruned_flops) {      // exact FLOPs of the dense head that the gathered launches did NOT execute (cald_profile_read leaves them out)
         double fl2 = 0.0;
-        for (int l = 0; l < 2; l++) if (st[2 * l + 1]) fl2 += c->prof_prune_flops_cap[l] * (1.0 - (double)st[2 * l] / (double)st[2 * l + 1]);
+        for (int l = 0; l < 2; l++) if (st[2 * l + 1]) fl2 += c->prof_prune_flops_cap[l] / (double)c->prof_prune_stage_launches * (1.0 - (double)st[2 * l] / (double)st[2 * l + 1]);
         *pruned_flops = fl2;
     }
     return 0;
@@ -884,7 +886,7 @@ struct FwdBufs {
     // decision-margin audit (audit.hip): what the RPN / post-processing kernels leave behind for it
     unsigned long long *next_key, *trunc_key, *kept_key; float* post_maxc;
     // certified RPN pruning (rpn_prune.hip), levels P2 / P3
-    float *prune_energy[2], *prune_pn[2], *prune_rows[2]; int *prune_map[2], *prune_nsel; unsigned* prune_p16[2];
+    float *prune_energy[2], *prune_pn[2], *prune_rows[2][2]; int *prune_map[2][2], *prune_nsel[2]; unsigned* prune_p16[2]; unsigned* prune_tau;      // [stage][level] row lists of the two selection stages
     float* prune_look[2];        // capture mode only: the look-ahead's head map before select / scatter overwrite it
 };
 
@@ -1087,13 +1089,15 @@ static void fwd_layout(cald_model* m, Bump& B, FwdBufs& F, int V) {
     F.cbox = B.get<float>((size_t)V * 2 * m->key_cap * 4);
     F.key_count = B.get<int>(V);
     for (int i = 0; i < 2; i++) {
-        F.prune_energy[i] = F.prune_pn[i] = F.prune_rows[i] = F.prune_look[i] = nullptr; F.prune_map[i] = nullptr; F.prune_p16[i] = nullptr;
+        F.prune_energy[i] = F.prune_pn[i] = F.prune_look[i] = nullptr; F.prune_p16[i] = nullptr;
+        for (int s2 = 0; s2 < 2; s2++) { F.prune_rows[s2][i] = nullptr; F.prune_map[s2][i] = nullptr; }
         if (!m->prune) continue;           // RetinaNet never gets here; f16x3 / pruning-off models do not pay for the scratch
         F.prune_energy[i] = B.get<float>(px[2 + i] * 4); F.prune_pn[i] = B.get<float>(px[2 + i]); F.prune_p16[i] = B.get<unsigned>(px[2 + i] * 256);
-        F.prune_rows[i] = B.get<float>(px[2 + i] * 15); F.prune_map[i] = B.get<int>(px[2 + i]);
+        for (int s2 = 0; s2 < 2; s2++) { F.prune_rows[s2][i] = B.get<float>(px[2 + i] * 15); F.prune_map[s2][i] = B.get<int>(px[2 + i]); }
         if (m->prune_capture) F.prune_look[i] = B.get<float>(px[2 + i] * 15);
     }
-    F.prune_nsel = m->prune ? B.get<int>((size_t)2 * V) : nullptr;
+    for (int s2 = 0; s2 < 2; s2++) F.prune_nsel[s2] = m->prune ? B.get<int>((size_t)2 * V) : nullptr;
+    F.prune_tau = m->prune ? B.get<unsigned>((size_t)2 * V) : nullptr;
     F.next_key = B.get<unsigned long long>((size_t)V * 10); F.trunc_key = B.get<unsigned long long>((size_t)V * 2);
     F.kept_key = B.get<unsigned long long>((size_t)V * m->det_cap()); F.post_maxc = B.get<float>(V);
 }
@@ -1239,14 +1243,19 @@ static int forward_model(cald_model* m, int V, ViewDesc* views, const DetBuffers
         // level's pre_nms_top_n anchors; P4..P6 dense as ever.  Same bits at every anchor the top-k can select.
         ConvSpec sp[5];
         RpnPruneArgs pr;
+        static const int stages_env = (getenv("CALD_RPN_PRUNE_STAGES") && atoi(getenv("CALD_RPN_PRUNE_STAGES")) == 1) ? 1 : 2;   // 1: round 5's single-stage rule (A/B)
+        const int stages = stages_env;
         for (int i = 0; i < 2; i++) {
             pr.feat[i] = F.Pf[i]; pr.seg[i] = dp->seg[2 + i]; pr.energy[i] = F.prune_energy[i]; pr.pnorm[i] = F.prune_pn[i]; pr.head[i] = F.rpn_h[i]; pr.head_out[i] = F.rpn_h[i];
-            pr.head_rows[i] = F.prune_rows[i]; pr.row_map[i] = F.prune_map[i]; pr.split[i] = look_h4 ? F.prune_p16[i] : nullptr;
+            pr.split[i] = look_h4 ? F.prune_p16[i] : nullptr;
+            for (int s2 = 0; s2 < 2; s2++) { pr.head_rows[s2][i] = F.prune_rows[s2][i]; pr.row_map[s2][i] = F.prune_map[s2][i]; }
         }
-        const int log_slot = (c->prof && c->prune_log_n < CALD_PRUNE_LOG) ? c->prune_log_n++ : -1;
-        pr.nsel = F.prune_nsel; pr.stat = c->prof ? c->d_prune_stat : nullptr; pr.log = log_slot >= 0 ? c->d_prune_log + (size_t)log_slot * 4 : nullptr; pr.check = c->d_prune_check;
+        int log_slot[2] = {-1, -1};
+        for (int s2 = 0; s2 < stages; s2++) log_slot[s2] = (c->prof && c->prune_log_n < CALD_PRUNE_LOG) ? c->prune_log_n++ : -1;
+        for (int s2 = 0; s2 < 2; s2++) { pr.nsel[s2] = F.prune_nsel[s2]; pr.log[s2] = log_slot[s2] >= 0 ? c->d_prune_log + (size_t)log_slot[s2] * 4 : nullptr; }
+        pr.tau_key = F.prune_tau; pr.stat = c->prof ? c->d_prune_stat : nullptr; pr.check = c->d_prune_check;
         for (int q = 0; q < 3; q++) { pr.c1[q] = m->prune_c1[q]; pr.c0[q] = m->prune_c0[q]; }
-        pr.head_ld = 15; pr.pre_n = m->cfg.rpn_pre_nms_top_n; pr.V = V;
+        pr.head_ld = 15; pr.pre_n = m->cfg.rpn_pre_nms_top_n; pr.V = V; pr.stages = stages;
         pr.energy_parts = prune_fused ? 4 : 1;
         if (!prune_fused) launch_rpn_prune_energy(pr, st);
         c->prof_tag_now = 1;
@@ -1256,22 +1265,36 @@ static int forward_model(cald_model* m, int V, ViewDesc* views, const DetBuffers
         if (!rc) rc = conv_group_on(m, sp, 2, V);
         c->prof_tag_now = 0;
         if (rc) return rc;
-        if (c->prof) for (int i = 0; i < 2; i++) c->prof_prune_flops_cap[i] += 2.0 * (double)level_pix(m->plan, 2 + i, V) * (2304.0 * 256.0 + 256.0 * 15.0);
+        // FLOPs the gathered launches are booked with when they cover every pixel (each stage's launches are: cald_profile_read / _dump rescale them)
+        const double cap_conv[2] = {2.0 * (double)level_pix(m->plan, 2, V) * 2304.0 * 256.0, 2.0 * (double)level_pix(m->plan, 3, V) * 2304.0 * 256.0};
+        const double cap_head[2] = {2.0 * (double)level_pix(m->plan, 2, V) * 256.0 * 15.0, 2.0 * (double)level_pix(m->plan, 3, V) * 256.0 * 15.0};
         if (m->prune_capture)
             for (int i = 0; i < 2; i++) {
                 HIPCHK(hipMemcpyAsync(F.prune_look[i], F.rpn_h[i], (size_t)level_pix(m->plan, 2 + i, V) * 15 * sizeof(float), hipMemcpyDeviceToDevice, st));
                 const char* ln[2] = {"rpn_look0", "rpn_look1"}; const char* bn[2] = {"rpn_pnorm0", "rpn_pnorm1"};
                 m->dbg[ln[i]] = {F.prune_look[i], 2 + i, 15, 0}; m->dbg[bn[i]] = {F.prune_pn[i], 2 + i, 1, 0};
             }
-        launch_rpn_prune_select(pr, max_pix2, st);
-        for (int i = 0; i < 5; i++) sp[i] = {&m->rpn_conv, F.Pf[i], F.rpn_tl[i], 2 + i, true};
-        for (int i = 0; i < 2; i++) { sp[i].dyn = F.prune_nsel + i * V; sp[i].row_map = F.prune_map[i]; }      // gathered rows, compact output
-        if ((rc = conv_group_on(m, sp, 5, V))) return rc;
-        if (log_slot >= 0) c->prof_gather[c->prof_fl.size() - 1] = {log_slot, {2.0 * (double)level_pix(m->plan, 2, V) * 2304.0 * 256.0, 2.0 * (double)level_pix(m->plan, 3, V) * 2304.0 * 256.0}};
-        for (int i = 0; i < 5; i++) sp[i] = {&m->rpn_head, F.rpn_tl[i], i < 2 ? F.prune_rows[i] : F.rpn_h[i], 2 + i, false};
-        for (int i = 0; i < 2; i++) sp[i].dyn = F.prune_nsel + i * V;
-        if ((rc = conv_group_on(m, sp, 5, V))) return rc;
-        if (log_slot >= 0) c->prof_gather[c->prof_fl.size() - 1] = {log_slot, {2.0 * (double)level_pix(m->plan, 2, V) * 256.0 * 15.0, 2.0 * (double)level_pix(m->plan, 3, V) * 256.0 * 15.0}};
+        // stage s2 < stages - 1 recomputes P2 / P3 rows only; the last stage's launches also carry the dense levels P4..P6
+        for (int s2 = 0; s2 < stages; s2++) {
+            const bool last = s2 == stages - 1;
+            const int np = last ? 5 : 2;
+            launch_rpn_prune_select(pr, max_pix2, s2, st);
+            for (int i = 0; i < np; i++) sp[i] = {&m->rpn_conv, F.Pf[i], F.rpn_tl[i], 2 + i, true};
+            for (int i = 0; i < 2; i++) { sp[i].dyn = F.prune_nsel[s2] + i * V; sp[i].row_map = F.prune_map[s2][i]; }      // gathered rows, compact output
+            if ((rc = conv_group_on(m, sp, np, V))) return rc;
+            if (c->prof) {
+                for (int i = 0; i < 2; i++) c->prof_prune_flops_cap[i] += cap_conv[i];
+                if (log_slot[s2] >= 0) c->prof_gather[c->prof_fl.size() - 1] = {log_slot[s2], {cap_conv[0], cap_conv[1]}};
+            }
+            for (int i = 0; i < np; i++) sp[i] = {&m->rpn_head, F.rpn_tl[i], i < 2 ? F.prune_rows[s2][i] : F.rpn_h[i], 2 + i, false};
+            for (int i = 0; i < 2; i++) sp[i].dyn = F.prune_nsel[s2] + i * V;
+            if ((rc = conv_group_on(m, sp, np, V))) return rc;
+            if (c->prof) {
+                for (int i = 0; i < 2; i++) c->prof_prune_flops_cap[i] += cap_head[i];
+                if (log_slot[s2] >= 0) c->prof_gather[c->prof_fl.size() - 1] = {log_slot[s2], {cap_head[0], cap_head[1]}};
+            }
+        }
+        if (c->prof) c->prof_prune_stage_launches = stages;
         launch_rpn_prune_scatter(pr, st);
         for (int i = m->prune_capture ? 0 : 2; i < 5; i++) m->dbg[rn[i]] = {F.rpn_h[i], 2 + i, 15, 0};      // (P2 / P3 head maps are exact only where selected, -FLT_MAX elsewhere: a debug view in capture mode only)
     } else {   // the shared-weight RPN head over the five levels: one launch for the 3x3 conv, one for the fused 1x1 heads

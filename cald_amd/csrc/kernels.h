@@ -155,17 +155,21 @@ struct RpnPruneArgs {
     float* pnorm[2];             // [pixel] scratch: |3 x 3 patch|_2 (select kernel -> scatter kernel)
     const float* head[2];        // approximate head maps [pixel][head_ld] (logits = channels 0..2)
     float* head_out[2];          // the same buffers: unselected pixels get logit -FLT_MAX, selected ones their exact rows
-    const float* head_rows[2];   // exact head rows of the selected pixels, compact [n_selected][head_ld] per view (at the view's pixel offset)
-    int* row_map[2];             // [pixel] -> selected pixel index, compact per view
-    int* nsel;                   // [2][V] selected pixels per (level, view): the dyn_rows of the gathered launches
+    // Two selection stages (rpn_prune.hip): stage 0 = the pixels holding an anchor whose LOWER bound reaches tau (at least k anchors: their exact
+    // logits give a sharper threshold), stage 1 = the remaining pixels with an upper bound at or above that threshold.  Single-stage mode
+    // (stages == 1, round 5's rule) uses the stage-0 arrays only.
+    const float* head_rows[2][2];   // [stage][level] exact head rows of the selected pixels, compact [n_selected][head_ld] per view (at the view's pixel offset)
+    int* row_map[2][2];          // [stage][level]: [pixel] -> selected pixel index, compact per view
+    int* nsel[2];                // [stage]: [2][V] selected pixels per (level, view): the dyn_rows of the gathered launches
+    unsigned* tau_key;           // [2][V] orderable key of tau (written by stage 0, read by stage 1)
     unsigned long long* stat;    // optional [4]: selected / total pixels of P2 and P3 accumulated over the calls (profiling), or null
-    unsigned long long* log;     // optional [4]: the same counts of THIS forward only (cald_profile_dump books the gathered launches with them), or null
+    unsigned long long* log[2];  // optional, per stage [4]: the same counts of THIS forward's stage only (cald_profile_dump books the gathered launches with them), or null
     float* check;                // [2]: running max of |look-ahead - exact| / bound over the selected anchors (must stay <= 1); 1.0f once an activation left the split's range
     float c1[3], c0[3];          // bound per anchor: c1 * |patch|_2 + c0
-    int head_ld, pre_n, V, energy_parts;
+    int head_ld, pre_n, V, energy_parts, stages;
 };
 void launch_rpn_prune_energy(const RpnPruneArgs& a, hipStream_t st);       // before the look-ahead conv (writes its split-form input)
-void launch_rpn_prune_select(const RpnPruneArgs& a, int max_pix, hipStream_t st);
+void launch_rpn_prune_select(const RpnPruneArgs& a, int max_pix, int stage, hipStream_t st);   // stage 0 (or the only one), then -- after stage 0's exact rows exist -- stage 1
 void launch_rpn_prune_scatter(const RpnPruneArgs& a, hipStream_t st);
 
 // audit.hip -- decision margins of one Faster R-CNN forward (cascade mode: which images may differ from the exact mode by more than

@@ -83,6 +83,14 @@ __device__ __forceinline__ float prune_patch_norm(const float* e, int parts, int
         }
     return sqrtf(s) * 1.0001f;
 }
+// MODE 0: the single-stage rule (round 5): select every pixel holding an anchor whose upper bound reaches tau, park the rest.
+// MODE 1: stage 0 of the two-stage rule: tau as above (kept in a.tau_key), select the pixels holding an anchor whose LOWER bound reaches tau -- at
+//         least k anchors, the ones that are certainly good.  Nothing is parked yet.
+// MODE 2: stage 1: the exact logits of stage 0's pixels are known now (a.head_rows[0]); tau' = the k-th largest of them is a threshold that k
+//         real anchors reach, so an anchor with upper bound < max(tau, tau') cannot be among the k largest.  Select the remaining pixels whose
+//         upper bound reaches it, park everything selected by neither stage.  The band of "maybe" anchors below the threshold is one bound wide
+//         instead of two: 7.3 % instead of 9.7 % of P2, 24 % instead of 45 % of P3 recomputed (tools/prune_two_stage_potential.py).
+template <int MODE>
 __global__ __launch_bounds__(1024) void prune_select_kernel(RpnPruneArgs a) {
     extern __shared__ unsigned mask[];
     __shared__ int hist[256];
@@ -92,33 +100,48 @@ __global__ __launch_bounds__(1024) void prune_select_kernel(RpnPruneArgs a) {
     const LevelSeg sg = a.seg[l][v];
     const int H = sg.H, W = sg.W, npx = H * W, A = 3, n = npx * A;
     const int k = n < a.pre_n ? n : a.pre_n;
-    const float* head = a.head[l] + sg.pix_off * (long long)a.head_ld;
+    const int ld = a.head_ld;
+    const float* head = a.head[l] + sg.pix_off * (long long)ld;
     const float* en = a.energy[l] + sg.pix_off * a.energy_parts;
     float* pnv = a.pnorm[l] + sg.pix_off;           // |patch|_2 per pixel: written once below, re-read by the SAME thread in every pass (and by the scatter kernel)
-    int* rmap = a.row_map[l] + sg.pix_off;
+    constexpr int ST = MODE == 2 ? 1 : 0;           // which stage's row list this launch writes
+    int* rmap = a.row_map[ST][l] + sg.pix_off;
     const int words = (npx + 31) >> 5;
     for (int i = tid; i < words; i += 1024) mask[i] = 0u;
     if (tid == 0) { s_prefix = 0u; s_mask = 0u; s_remaining = k; }
     __syncthreads();
-    auto bound = [&](int p, int an, float pn) { return a.c1[an] * pn + a.c0[an]; };
-    for (int p = tid; p < npx; p += 1024) {
-        const float pn = prune_patch_norm(en, a.energy_parts, p / W, p % W, H, W);
-        pnv[p] = pn;
-        // the range of the split (see prune_energy_kernel): a patch norm below 4094 means every |x| in the patch is; anything else -- a large
-        // activation, inf, NaN -- sends the sweep back to the dense head
-        if (!(pn < 4094.0f) && a.check) atomicMax(reinterpret_cast<unsigned*>(a.check) + 1, __float_as_uint(1.0f));
+    auto bound = [&](int an, float pn) { return a.c1[an] * pn + a.c0[an]; };
+    if (MODE != 2) {
+        for (int p = tid; p < npx; p += 1024) {
+            const float pn = prune_patch_norm(en, a.energy_parts, p / W, p % W, H, W);
+            pnv[p] = pn;
+            // the range of the split (see prune_energy_kernel): a patch norm below 4094 means every |x| in the patch is; anything else -- a large
+            // activation, inf, NaN -- sends the sweep back to the dense head
+            if (!(pn < 4094.0f) && a.check) atomicMax(reinterpret_cast<unsigned*>(a.check) + 1, __float_as_uint(1.0f));
+        }
     }
-    if (n > k) {
-        for (int pass = 0; pass < 4; pass++) {                  // the k-th largest of the lower bounds, 8 bits per pass
+    // ---- the k-th largest of: the lower bounds over all anchors (MODE 0, 1) / the exact logits of stage 0's pixels (MODE 2) ----
+    const int ns0 = MODE == 2 ? a.nsel[0][l * a.V + v] : 0;
+    const float* rows0 = MODE == 2 ? a.head_rows[0][l] + sg.pix_off * (long long)ld : nullptr;
+    const bool all_kept = n <= k;
+    if (!all_kept) {
+        for (int pass = 0; pass < 4; pass++) {                  // 8 bits per pass
             const int shift = 24 - 8 * pass;
             if (tid < 256) hist[tid] = 0;
             __syncthreads();
             const unsigned prefix = s_prefix, msk = s_mask;
-            for (int p = tid; p < npx; p += 1024) {
-                const float pn = pnv[p];
-                for (int an = 0; an < A; an++) {
-                    const unsigned key = det_orderable(head[(long long)p * a.head_ld + an] - bound(p, an, pn));
+            if (MODE == 2) {
+                for (int i = tid; i < ns0 * A; i += 1024) {
+                    const unsigned key = det_orderable(rows0[(long long)(i / A) * ld + (i % A)]);
                     if ((key & msk) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1);
+                }
+            } else {
+                for (int p = tid; p < npx; p += 1024) {
+                    const float pn = pnv[p];
+                    for (int an = 0; an < A; an++) {
+                        const unsigned key = det_orderable(head[(long long)p * ld + an] - bound(an, pn));
+                        if ((key & msk) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1);
+                    }
                 }
             }
             __syncthreads();
@@ -133,14 +156,28 @@ __global__ __launch_bounds__(1024) void prune_select_kernel(RpnPruneArgs a) {
             __syncthreads();
         }
     }
-    const unsigned tau = (n > k) ? s_prefix : 0u;               // orderable key of the k-th largest lower bound (0: every anchor stays)
+    unsigned tau = all_kept ? 0u : s_prefix;                    // orderable key (0: every anchor stays)
+    unsigned tau_lb = tau;
+    if (MODE == 1 && tid == 0) a.tau_key[l * a.V + v] = tau;
+    if (MODE == 2) {
+        tau_lb = a.tau_key[l * a.V + v];                        // stage 0's threshold on the lower bounds
+        // fewer than k exact logits can only mean stage 0 kept everything (all_kept) -- otherwise its pixels hold >= k anchors
+        tau = (ns0 * A >= k && tau > tau_lb) ? tau : tau_lb;
+    }
     for (int p = tid; p < npx; p += 1024) {
         const float pn = pnv[p];
-        bool keep = false;
+        bool keep = false, first = false;
         for (int an = 0; an < A; an++) {
-            const float lg = head[(long long)p * a.head_ld + an];
-            const float ub = lg + bound(p, an, pn);
-            keep = keep || !(ub == ub) || det_orderable(ub) >= tau;          // NaN: never pruned
+            const float lg = head[(long long)p * ld + an];
+            const float B = bound(an, pn);
+            const float ub = lg + B, lb = lg - B;
+            if (MODE == 0) keep = keep || !(ub == ub) || det_orderable(ub) >= tau;             // NaN: never pruned
+            if (MODE == 1) keep = keep || !(lb == lb) || det_orderable(lb) >= tau;
+            if (MODE == 2) { first = first || !(lb == lb) || det_orderable(lb) >= tau_lb; keep = keep || !(ub == ub) || det_orderable(ub) >= tau; }
+        }
+        if (MODE == 2) {
+            if (first) keep = false;                                                            // already exact since stage 0
+            else if (!keep) { float* hw = a.head_out[l] + (sg.pix_off + p) * (long long)ld; hw[0] = -FLT_MAX; hw[1] = -FLT_MAX; hw[2] = -FLT_MAX; }
         }
         if (keep) atomicOr(&mask[p >> 5], 1u << (p & 31));
     }
@@ -168,26 +205,28 @@ __global__ __launch_bounds__(1024) void prune_select_kernel(RpnPruneArgs a) {
         __syncthreads();
     }
     if (tid == 0) {
-        a.nsel[l * a.V + v] = base;
-        if (a.stat) { atomicAdd(a.stat + 2 * l, (unsigned long long)base); atomicAdd(a.stat + 2 * l + 1, (unsigned long long)npx); }
-        if (a.log) { atomicAdd(a.log + 2 * l, (unsigned long long)base); atomicAdd(a.log + 2 * l + 1, (unsigned long long)npx); }
+        a.nsel[ST][l * a.V + v] = base;
+        if (a.stat) { atomicAdd(a.stat + 2 * l, (unsigned long long)base); if (MODE != 2) atomicAdd(a.stat + 2 * l + 1, (unsigned long long)npx); }
+        if (a.log[ST]) { atomicAdd(a.log[ST] + 2 * l, (unsigned long long)base); atomicAdd(a.log[ST] + 2 * l + 1, (unsigned long long)npx); }
     }
-    // unselected pixels: their three logits can never reach the top-k -- park them below every real logit
-    float* headw = a.head_out[l] + sg.pix_off * (long long)a.head_ld;
-    for (int p = tid; p < npx; p += 1024)
-        if (!((mask[p >> 5] >> (p & 31)) & 1u)) { headw[(long long)p * a.head_ld] = -FLT_MAX; headw[(long long)p * a.head_ld + 1] = -FLT_MAX; headw[(long long)p * a.head_ld + 2] = -FLT_MAX; }
+    if (MODE == 0) {
+        // unselected pixels: their three logits can never reach the top-k -- park them below every real logit
+        float* headw = a.head_out[l] + sg.pix_off * (long long)ld;
+        for (int p = tid; p < npx; p += 1024)
+            if (!((mask[p >> 5] >> (p & 31)) & 1u)) { headw[(long long)p * ld] = -FLT_MAX; headw[(long long)p * ld + 1] = -FLT_MAX; headw[(long long)p * ld + 2] = -FLT_MAX; }
+    }
 }
 
 // the exact head rows of the selected pixels back into the dense [pixel][head_ld] map -- and the bound put to the test: every selected anchor
 // has both values, the look-ahead's L~ (still in the map) and the exact L; max |L~ - L| / B over all of them goes to a.check[0]
-// (non-negative floats order like their bit patterns).  A ratio above 1 would mean the bound's model of the matrix pipe is wrong:
-// the sweep then fails loudly instead of returning detections that might differ from the dense head's (api.hip).  grid = (blocks, V, 2)
+// (non-negative floats order like their bit patterns).  A ratio above 1 means the bound does not hold on this data: the sweep then repeats
+// itself with the dense head (api.hip).  grid = (blocks, V, 2 * stages): z = level + 2 * stage
 __global__ __launch_bounds__(256) void prune_scatter_kernel(RpnPruneArgs a) {
-    const int l = blockIdx.z, v = blockIdx.y;
+    const int l = blockIdx.z & 1, st = blockIdx.z >> 1, v = blockIdx.y;
     const LevelSeg sg = a.seg[l][v];
-    const int ns = a.nsel[l * a.V + v], ld = a.head_ld;
-    const int* rmap = a.row_map[l] + sg.pix_off;
-    const float* src = a.head_rows[l] + sg.pix_off * (long long)ld;
+    const int ns = a.nsel[st][l * a.V + v], ld = a.head_ld;
+    const int* rmap = a.row_map[st][l] + sg.pix_off;
+    const float* src = a.head_rows[st][l] + sg.pix_off * (long long)ld;
     const float* pnv = a.pnorm[l] + sg.pix_off;
     float* dst = a.head_out[l] + sg.pix_off * (long long)ld;
     float worst = 0.0f;
@@ -212,12 +251,13 @@ __global__ __launch_bounds__(256) void prune_scatter_kernel(RpnPruneArgs a) {
 void launch_rpn_prune_energy(const RpnPruneArgs& a, hipStream_t st) {
     for (int l = 0; l < 2; l++) hipLaunchKernelGGL(prune_energy_kernel, dim3(256, a.V), dim3(256), 0, st, a, l);
 }
-void launch_rpn_prune_select(const RpnPruneArgs& a, int max_pix, hipStream_t st) {
+void launch_rpn_prune_select(const RpnPruneArgs& a, int max_pix, int stage, hipStream_t st) {
     const size_t lds = (size_t)((max_pix + 31) / 32) * 4;
-    static PerDeviceOnce once;
-    allow_big_lds(once, prune_select_kernel);
-    hipLaunchKernelGGL(prune_select_kernel, dim3(2, a.V), dim3(1024), lds, st, a);
+    static PerDeviceOnce once0, once1, once2;
+    if (a.stages == 1) { allow_big_lds(once0, prune_select_kernel<0>); hipLaunchKernelGGL(prune_select_kernel<0>, dim3(2, a.V), dim3(1024), lds, st, a); }
+    else if (stage == 0) { allow_big_lds(once1, prune_select_kernel<1>); hipLaunchKernelGGL(prune_select_kernel<1>, dim3(2, a.V), dim3(1024), lds, st, a); }
+    else { allow_big_lds(once2, prune_select_kernel<2>); hipLaunchKernelGGL(prune_select_kernel<2>, dim3(2, a.V), dim3(1024), lds, st, a); }
 }
 void launch_rpn_prune_scatter(const RpnPruneArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(prune_scatter_kernel, dim3(64, a.V, 2), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(prune_scatter_kernel, dim3(64, a.V, 2 * a.stages), dim3(256), 0, st, a);
 }
