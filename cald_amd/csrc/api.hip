@@ -911,7 +911,7 @@ static double fill_conv_args(cald_model* m, ConvArgs& a, const ConvLayer& L, con
             return (double)fail(CALD_ERR_UNSUPPORTED, "a view's activation tensor exceeds 2 GB (level %d -> %d, %lld x %d / %lld x %d elements)", lin, lout, pin, L.Cin, pout, L.Cout);
         }
     }
-    a.in16 = nullptr; a.out16 = nullptr; a.ex16 = 0; a.energy4 = nullptr;
+    a.in16 = nullptr; a.out16 = nullptr; a.ex16 = 0; a.energy4 = nullptr; a.trace = nullptr;
     if (!m->split.empty()) {
         const float* ex = residual ? residual : up;
         if (ex) {
@@ -1562,6 +1562,20 @@ extern "C" int cald_op_conv_bench(cald_ctx* c, int V, int H, int W, int Cin, int
     HIPCHK(hipEventSynchronize(e1));
     float ms = 0.f; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
     hipEventDestroy(e0); hipEventDestroy(e1);
+    if (const char* tp = getenv("CALD_CONV_TRACE")) {       // one more launch with the per-workgroup timeline recorded (conv_p4.hip), dumped raw
+        const size_t nblk = 1u << 17;
+        unsigned long long* d_tr;
+        if ((rc = sd.alloc(&d_tr, nblk * 64))) return rc;
+        HIPCHK(hipMemsetAsync(d_tr, 0, nblk * 64, c->stream));
+        for (int gi = 0; gi < group; gi++) a[gi].trace = d_tr;
+        launch();
+        HIPCHK(hipStreamSynchronize(c->stream));
+        std::vector<unsigned long long> h(nblk * 8);
+        HIPCHK(hipMemcpy(h.data(), d_tr, nblk * 64, hipMemcpyDeviceToHost));
+        size_t used = nblk; while (used > 0 && h[(used - 1) * 8] == 0) used--;
+        if (FILE* f = fopen(tp, "wb")) { fwrite(h.data(), 64, used, f); fclose(f); }
+        for (int gi = 0; gi < group; gi++) a[gi].trace = nullptr;
+    }
     *ms_out = (double)ms / iters;
     if (tflops_out) *tflops_out = 2.0 * (double)V * Ho * Wo * Cout * (double)K * group / (*ms_out * 1e-3) / 1e12;
     return 0;

@@ -19,6 +19,20 @@ struct LevelSeg {
     int pad_;
 };
 
+// The view an M tile belongs to: the largest v in [0, V) with seg[v].tile_start <= mt (tile_start is the running sum of the views' tile
+// counts: non-decreasing, seg[0].tile_start == 0).  A bisection -- seven dependent scalar loads at 92 views where the linear scan it
+// replaced made one per view before it, i.e. ~45 on average in front of every workgroup's first operand load.
+#if defined(__HIPCC__)
+__device__ __forceinline__ int seg_find_view(const LevelSeg* __restrict__ seg, const int V, const int mt) {
+    int lo = 0, hi = V - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (seg[mid].tile_start <= mt) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+#endif
+
 // One batch plan = geometry of every level for every view (+ sentinel entry V for tile_start).
 struct BatchPlan {
     LevelSeg seg[CALD_MAX_LEVELS][CALD_MAX_VIEWS + 1];
@@ -68,6 +82,10 @@ struct ConvArgs {
     // through out16, the split-fp16 copy its look-ahead conv reads.  Both were a separate pass over P2 / P3 (prune_energy_kernel) in round 5.
     float* energy4;
     int ex16;              // `residual` / `up` point at a split-form tensor (same element count) instead of an fp32 one
+    // tuning only (cald_op_conv_bench under CALD_CONV_TRACE; null in the product path): per workgroup eight 64-bit words -- s_memtime at
+    // entry, after the prologue's first barrier, after the k-loop, after the epilogue's last store was issued, after the stores drained;
+    // HW_ID; XCC_ID; blockIdx -- the timeline of a launch on the chip (tools/conv_trace.py)
+    unsigned long long* trace;
 };
 
 // Several independent conv problems in ONE launch (the five FPN levels under the shared-weight RPN / RetinaNet heads, the

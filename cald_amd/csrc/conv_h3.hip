@@ -58,8 +58,7 @@ __device__ __forceinline__ void conv_h3_body(const ConvArgs& a, const int blk) {
         else { const int r = b - MT8 * NT; mt = MT8 + r / NT; nt = r % NT; }
     }
     const int n0 = nt * BN;
-    int v = 0;
-    while (v + 1 < a.V && a.seg_out[v + 1].tile_start <= mt) v++;
+    const int v = seg_find_view(a.seg_out, a.V, mt);
     const LevelSeg so = a.seg_out[v];
     const LevelSeg si = a.seg_in[v];
     const int Ho = so.H, Wo = so.W, Hi = si.H, Wi = si.W;

@@ -56,8 +56,7 @@ __device__ __forceinline__ void conv_h4_body(const ConvArgs& a, const int blk) {
     int Wi_l = 1;
     if (ldA) {
         const int mt = 2 * mt2 + (lw >> 1);
-        int v = 0;
-        while (v + 1 < a.V && a.seg_out[v + 1].tile_start <= mt) v++;
+        const int v = seg_find_view(a.seg_out, a.V, mt);
         const LevelSeg so = a.seg_out[v], si = a.seg_in[v];
         const int Wo = so.W, Hi = si.H, Wi = si.W;
         Wi_l = Wi;
@@ -250,8 +249,7 @@ __device__ __forceinline__ void conv_h4_body(const ConvArgs& a, const int blk) {
     // ---------------- epilogue (h16.h) ----------------
     const int mt = 2 * mt2 + wm;
     if (mt >= a.total_mtiles) return;
-    int v = 0;
-    while (v + 1 < a.V && a.seg_out[v + 1].tile_start <= mt) v++;
+    const int v = seg_find_view(a.seg_out, a.V, mt);
     const LevelSeg so = a.seg_out[v];
     int Mv = so.H * so.W;
     if (a.dyn_rows) { const int d = a.dyn_rows[v]; Mv = d < Mv ? d : Mv; }

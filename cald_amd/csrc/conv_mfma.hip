@@ -57,8 +57,7 @@ __global__ __launch_bounds__(256, (BK == 32 ? 2 : 3)) void conv_mfma_f32_kernel(
     const int n0 = nt * BN;
 
     // ---- which view does this M tile belong to (wave-uniform scan of the plan) ----
-    int v = 0;
-    while (v + 1 < a.V && a.seg_out[v + 1].tile_start <= mt) v++;
+    const int v = seg_find_view(a.seg_out, a.V, mt);
     const LevelSeg so = a.seg_out[v];
     const LevelSeg si = a.seg_in[v];
     const int Ho = so.H, Wo = so.W, Hi = si.H, Wi = si.W;

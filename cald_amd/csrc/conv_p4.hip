@@ -45,11 +45,16 @@ __device__ __forceinline__ void p4_epilogue(const ConvArgs& a, const f32x16 (&ac
     const bool relu = a.relu != 0, has_bias = a.bias != nullptr, has_bn = a.scale != nullptr;
     constexpr bool has_mask = MASK;
     const float* __restrict__ mask_v = has_mask ? a.mask + so.pix_off * (long long)out_ld : out_v;
-    const bool full_tile = m0 + BM <= Mv && !(a.exp_flags & 1);
     const int row_b = out_ld * 4;
-    const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc((void*)out_v, 0, 0x7FFE0000, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)(EPI != 0 ? ex_v : out_v), 0, 0x7FFE0000, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc((void*)mask_v, 0, 0x7FFE0000, 0x00020000);
+    // The descriptors of everything addressed by output row END at the view's last valid row: a row past it loads zeros and its store is
+    // dropped by the hardware, so a view's last, partial tile runs the same branch-free code as a full one (no per-element row tests, no
+    // 64-bit addresses).  A lane of a padded output channel uses an offset beyond any descriptor.  (exp_flags bit 0, a tuning experiment:
+    // a zero-sized output descriptor drops every store.)
+    const unsigned long long vb64 = (unsigned long long)Mv * (unsigned)row_b;
+    const unsigned valid_b = vb64 < 0x7FFE0000ull ? (unsigned)vb64 : 0x7FFE0000u;
+    const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc((void*)out_v, 0, (a.exp_flags & 1) ? 0 : valid_b, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)(EPI != 0 ? ex_v : out_v), 0, EPI == 1 ? valid_b : 0x7FFE0000, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc((void*)mask_v, 0, valid_b, 0x00020000);
     // FPN top-down (EPI 2): the nearest-neighbour source pixel of each of the tile's 128 rows is computed ONCE (one thread per
     // row; the LDS tile buffers are free after the k-loop's last barrier) instead of by every lane for each of its 32 rows
     const int Mlast = Mv - 1;
@@ -71,7 +76,7 @@ __device__ __forceinline__ void p4_epilogue(const ConvArgs& a, const f32x16 (&ac
     constexpr bool EXTRA = EPI == 0 && !MASK;
     const bool want16 = EXTRA && a.out16 != nullptr, wantE = EXTRA && TN == 2 && a.energy4 != nullptr;      // energy4 has four slots: 2 n-tiles of 128 x 2 wave columns (Cout = 256)
     unsigned char* const out16_v = want16 ? reinterpret_cast<unsigned char*>(a.out16) + so.pix_off * (long long)out_ld * 4 : nullptr;
-    const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void*)(want16 ? (void*)out16_v : (void*)out_v), 0, 0x7FFE0000, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void*)(want16 ? (void*)out16_v : (void*)out_v), 0, valid_b, 0x00020000);
     const bool odd = (lane & 1) != 0;
     float sq[TM][16];
     if (EXTRA) {
@@ -80,40 +85,59 @@ __device__ __forceinline__ void p4_epilogue(const ConvArgs& a, const f32x16 (&ac
 #pragma unroll
             for (int r = 0; r < 16; r++) sq[i][r] = 0.0f;
     }
+    // Every load of the epilogue is issued BEFORE its first store: the per-channel bias / BN terms of both column tiles, then the residual
+    // (or top-down) values of all TM x TN accumulator tiles.  Stores and loads go through different buffer resources the compiler cannot
+    // tell apart, so a load written after a store stays after it -- tile by tile that was four dependent round trips to HBM per workgroup
+    // (load 16, wait, store 16, load the next 16 ...), as long as the whole k-loop of a K = 128 layer.  64 + 64 live registers plus
+    // temporaries fit the 168 of three workgroups per CU now that no path of the epilogue carries 64-bit addresses or row tests (PRE <
+    // NTILE would request tile t + PRE between tile t's arithmetic and its stores).
+    float bs_[TN], sc_[TN], sh_[TN];
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+        const int n = n0 + wn * TN * 32 + j * 32 + l31;
+        const int nc = n < a.Cout ? n : 0;
+        bs_[j] = has_bias ? a.bias[nc] : 0.0f;
+        sc_[j] = has_bn ? a.scale[nc] : 1.0f;
+        sh_[j] = has_bn ? a.shift[nc] : 0.0f;
+    }
+    constexpr int NTILE = TM * TN, PRE = NTILE;
+    float extra_[EPI != 0 ? NTILE : 1][16];
+    auto load_extra = [&](const int t, float (&extra)[16]) {      // tile t = j * TM + i
+        const int j = t / TM, i = t - j * TM;
+        const int n = n0 + wn * TN * 32 + j * 32 + l31;
+        const bool nok = n < a.Cout;
+        const int nc = nok ? n : 0;
+        const int mbase = m0 + wm * TM * 32 + i * 32 + 4 * kh_lane;
+        if (EPI == 1) {
+            const int vo = nok ? (mbase * out_ld + n) * 4 : 0x7FFF0000;
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                extra[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsX, vo, ((r & 3) + 8 * (r >> 2)) * row_b, 0));
+        } else if (EPI == 2) {
+            const int rl = wm * TM * 32 + i * 32 + 4 * kh_lane;          // tile-local row of accumulator register 0
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const i32x4 so4 = *reinterpret_cast<const i32x4*>(s_src + rl + 8 * q);
+#pragma unroll
+                for (int jj = 0; jj < 4; jj++)
+                    extra[4 * q + jj] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsX, so4[jj] + nc * 4, 0, 0));
+            }
+        }
+    };
+    if (EPI != 0) {
+#pragma unroll
+        for (int t = 0; t < PRE; t++) load_extra(t, extra_[EPI != 0 ? t : 0]);
+    }
 #pragma unroll
     for (int j = 0; j < TN; j++) {
         const int n = n0 + wn * TN * 32 + j * 32 + l31;
         const bool nok = n < a.Cout;
         const int nc = nok ? n : 0;
-        const float bs = has_bias ? a.bias[nc] : 0.0f;
-        const float sc = has_bn ? a.scale[nc] : 1.0f;
-        const float sh = has_bn ? a.shift[nc] : 0.0f;
+        const float bs = bs_[j], sc = sc_[j], sh = sh_[j];
 #pragma unroll
         for (int i = 0; i < TM; i++) {
             const int mbase = m0 + wm * TM * 32 + i * 32 + 4 * kh_lane;
-            float extra[16];
-            if (EPI == 1 && full_tile) {
-                const int vo = nok ? (mbase * out_ld + n) * 4 : 0x7FFF0000;
-#pragma unroll
-                for (int r = 0; r < 16; r++)
-                    extra[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsX, vo, ((r & 3) + 8 * (r >> 2)) * row_b, 0));
-            } else if (EPI == 2) {
-                const int rl = wm * TM * 32 + i * 32 + 4 * kh_lane;          // tile-local row of accumulator register 0
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const i32x4 so4 = *reinterpret_cast<const i32x4*>(s_src + rl + 8 * q);
-#pragma unroll
-                    for (int jj = 0; jj < 4; jj++)
-                        extra[4 * q + jj] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsX, so4[jj] + nc * 4, 0, 0));
-                }
-            } else if (EPI == 1) {
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    int m = mbase + (r & 3) + 8 * (r >> 2);
-                    m = m < Mlast ? m : Mlast;
-                    extra[r] = ex_v[(long long)m * out_ld + nc];
-                }
-            }
+            const float (&extra)[16] = extra_[EPI != 0 ? j * TM + i : 0];
             float val[16];
 #pragma unroll
             for (int r = 0; r < 16; r++) val[r] = acc[i][j][r];
@@ -133,36 +157,19 @@ __device__ __forceinline__ void p4_epilogue(const ConvArgs& a, const f32x16 (&ac
 #pragma unroll
                 for (int r = 0; r < 16; r++) val[r] = val[r] > 0.0f ? val[r] : 0.0f;
             }
+            if (EPI != 0 && j * TM + i + PRE < NTILE) load_extra(j * TM + i + PRE, extra_[EPI != 0 ? j * TM + i + PRE : 0]);
+            const int vo = nok ? (mbase * out_ld + n) * 4 : 0x7FFF0000;
             if (has_mask) {      // training backward: ReLU backward of the layer this data gradient flows into (wave-uniform branch)
                 float mk[16];
-                if (full_tile) {
-                    const int vo = nok ? (mbase * out_ld + n) * 4 : 0x7FFF0000;
 #pragma unroll
-                    for (int r = 0; r < 16; r++)
-                        mk[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsM, vo, ((r & 3) + 8 * (r >> 2)) * row_b, 0));
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 16; r++) {
-                        int m = mbase + (r & 3) + 8 * (r >> 2);
-                        m = m < Mlast ? m : Mlast;
-                        mk[r] = mask_v[(long long)m * out_ld + nc];
-                    }
-                }
+                for (int r = 0; r < 16; r++)
+                    mk[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsM, vo, ((r & 3) + 8 * (r >> 2)) * row_b, 0));
 #pragma unroll
                 for (int r = 0; r < 16; r++) val[r] = mk[r] > 0.0f ? val[r] : 0.0f;
             }
-            if (full_tile) {
-                const int vo = nok ? (mbase * out_ld + n) * 4 : 0x7FFF0000;
 #pragma unroll
-                for (int r = 0; r < 16; r++)
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val[r]), rsO, vo, ((r & 3) + 8 * (r >> 2)) * row_b, 0);
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int m = mbase + (r & 3) + 8 * (r >> 2);
-                    if (m < Mv && nok && !((a.exp_flags & 1) && val[r] != 12345.678f)) out_v[(long long)m * out_ld + n] = val[r];
-                }
-            }
+            for (int r = 0; r < 16; r++)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val[r]), rsO, vo, ((r & 3) + 8 * (r >> 2)) * row_b, 0);
             if (EXTRA) {
                 if (wantE) {
 #pragma unroll
@@ -174,9 +181,7 @@ __device__ __forceinline__ void p4_epilogue(const ConvArgs& a, const f32x16 (&ac
                     for (int r = 0; r < 16; r++) {
                         const unsigned w = h16_split(val[r]);
                         const unsigned pw = h16_pair_word(w, h16_partner(w), odd);
-                        const int m = mbase + (r & 3) + 8 * (r >> 2);
-                        if (full_tile) __builtin_amdgcn_raw_buffer_store_b32(pw, rsS, nok ? mbase * row_b + poff : 0x7FFF0000, ((r & 3) + 8 * (r >> 2)) * row_b, 0);
-                        else if (m < Mv && nok) *reinterpret_cast<unsigned*>(out16_v + (long long)m * row_b + poff) = pw;
+                        __builtin_amdgcn_raw_buffer_store_b32(pw, rsS, nok ? mbase * row_b + poff : 0x7FFF0000, ((r & 3) + 8 * (r >> 2)) * row_b, 0);
                     }
                 }
             }
@@ -222,6 +227,13 @@ __device__ __forceinline__ void conv_p4_body(const ConvArgs& a, const int blk, c
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int NT = a.CoutPad / BN;
+    unsigned long long* const trace = (a.trace && blockIdx.x < (1u << 17)) ? a.trace + (size_t)blockIdx.x * 8 : nullptr;
+    if (trace && tid == 0) {
+        trace[0] = __builtin_amdgcn_s_memtime();
+        trace[5] = (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_ID
+        trace[6] = (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 20);    // XCC_ID
+        trace[7] = blockIdx.x;
+    }
     int mt, nt;
     if (a.KH * a.KW > 1) {
         // filters with a spatial extent: XCD-contiguous map: block b runs on XCD b % 8; XCD x owns the contiguous M-tile range [x * CH, (x + 1) * CH), so
@@ -236,8 +248,7 @@ __device__ __forceinline__ void conv_p4_body(const ConvArgs& a, const int blk, c
         else { const int r = b - MT8 * NT; mt = MT8 + r / NT; nt = r % NT; }
     }
     const int n0 = nt * BN;
-    int v = 0;
-    while (v + 1 < a.V && a.seg_out[v + 1].tile_start <= mt) v++;
+    const int v = seg_find_view(a.seg_out, a.V, mt);
     const LevelSeg so = a.seg_out[v];
     const LevelSeg si = a.seg_in[v];
     const int Ho = so.H, Wo = so.W, Hi = si.H, Wi = si.W;
@@ -387,6 +398,7 @@ __device__ __forceinline__ void conv_p4_body(const ConvArgs& a, const int blk, c
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    if (trace && tid == 0) trace[1] = __builtin_amdgcn_s_memtime();
 
     // fragment read offsets (floats) inside a tile buffer, kq = 0; kq = 1 adds BM*8 (A) / BN*8 (B)
     const int kh_lane = lane >> 5, l31 = lane & 31;
@@ -528,6 +540,7 @@ __device__ __forceinline__ void conv_p4_body(const ConvArgs& a, const int blk, c
 #undef P4_MFMA
 #undef P4_TILE
 
+    if (trace && tid == 0) trace[2] = __builtin_amdgcn_s_memtime();
     if constexpr (FUSE) {
         // ---- bottleneck tail: T = relu(bn2(acc)) (conv2's own epilogue arithmetic, bit for bit what the unfused kernel stores) never
         // leaves the CU -- it is laid down in LDS as the A operand of conv3 (plain channel order = conv3's chain order), conv3's weights
@@ -652,6 +665,11 @@ __device__ __forceinline__ void conv_p4_body(const ConvArgs& a, const int blk, c
     } else {
         p4_epilogue<EPI, MASK, TM, TN>(a, acc, smem, v, so, m0, Mv, n0);
     }
+    if (trace && tid == 0) {
+        trace[3] = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        trace[4] = __builtin_amdgcn_s_memtime();
+    }
 }
 
 template <int EPI, bool C4, int TN, int TAPS>
@@ -664,6 +682,9 @@ __global__ __launch_bounds__(256, 3) void conv_p4_group_kernel(const ConvGroup g
 }
 // bottleneck conv2 + conv3 in one launch (the two problems of a ConvGroup: p[0] = conv2, p[1] = conv3); 48 KB of LDS -> 3 workgroups / CU
 __global__ __launch_bounds__(256, 3) void conv_p4_fused_kernel(const ConvGroup g) { conv_p4_body<8, false, 1, 9>(g.p[0], blockIdx.x, &g.p[1]); }
+
+// CALD_P4_EXP: kernel-tuning experiments (tools/bench_conv.py): bit 0 = drop the output stores
+static inline int p4_exp_env() { static const int e = getenv("CALD_P4_EXP") ? atoi(getenv("CALD_P4_EXP")) : 0; return e; }
 
 // filter shape -> k-loop variant
 static inline int p4_taps(const ConvArgs& a) {
@@ -721,7 +742,7 @@ bool launch_conv_p4_fused(const ConvArgs& c2, const ConvArgs& c3, hipStream_t st
 // returns true if this variant handled the launch
 bool launch_conv_p4(const ConvArgs& a_in, hipStream_t stream) {
     if (!a_in.w4 || a_in.CoutPad % 64 != 0) return false;
-    static const int exp_env = getenv("CALD_P4_EXP") ? atoi(getenv("CALD_P4_EXP")) : 0;          // tuning experiments (tools/bench_conv.py)
+    const int exp_env = p4_exp_env();
     static const int pad_lds = getenv("CALD_P4_PADLDS") ? atoi(getenv("CALD_P4_PADLDS")) : 0;    // extra dynamic LDS: caps workgroups per CU
     ConvArgs a = a_in; a.exp_flags = exp_env;
     bool wide = a.CoutPad % 128 == 0;
