@@ -53,6 +53,13 @@ class AugSpec(C.Structure):
     _fields_ = [("kind", C.c_int), ("param", C.c_double)]
 
 
+class PackJob(C.Structure):
+    """cald_pack_job of include/cald_hip.h: the arguments of one cald_train_pack_conv call (device pointers)."""
+    _fields_ = [("weight", C.c_void_p), ("bias", C.c_void_p), ("bn_scale", C.c_void_p), ("bn_shift", C.c_void_p),
+                ("Cout", C.c_int), ("Cin", C.c_int), ("KH", C.c_int), ("KW", C.c_int), ("CinK", C.c_int), ("mode", C.c_int),
+                ("packed", C.c_void_p)]
+
+
 class SweepCfg(C.Structure):
     _fields_ = [("base_seed", C.c_uint64), ("bp", C.c_float), ("batch_images", C.c_int), ("n_augs", C.c_int),
                 ("augs", AugSpec * MAX_AUGS)]
@@ -105,6 +112,10 @@ SIGNATURES = {
     # training step (device pointers as c_void_p)
     "cald_train_packed_floats": (C.c_int, [C.c_int] * 6 + [c_i64]),
     "cald_train_pack_conv": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 6 + [C.c_void_p]),
+    "cald_train_pack_plan_scratch_floats": (C.c_int, [C.c_int, C.POINTER(PackJob), c_i64]),
+    "cald_train_pack_plan_create": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(PackJob), C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]),
+    "cald_train_pack_plan_run": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "cald_train_pack_plan_destroy": (C.c_int, [C.c_void_p]),
     "cald_train_conv": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p] + [C.c_int] * 8
                         + [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
     "cald_train_conv_group": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_i, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p)] + [C.c_int] * 8
@@ -120,6 +131,8 @@ SIGNATURES = {
     "cald_train_upsample_bwd": (C.c_int, [C.c_void_p] + [C.c_int] * 6 + [C.c_void_p, C.c_void_p]),
     "cald_train_rpn_proposals": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_i, C.POINTER(C.c_void_p), c_i, C.c_int, C.c_int, C.c_int,
                                            C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
+    "cald_train_roi_sample_host": (C.c_int, [C.c_int, c_i, c_i, c_i, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_int,
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_i, c_i, c_i]),
     "cald_train_anchors": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_i, C.c_void_p]),
     "cald_train_match": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
     "cald_train_box_encode": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),

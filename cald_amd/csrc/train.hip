@@ -23,6 +23,7 @@
 #include "kernels.h"
 #include "sortnms.h"
 #include "../../include/cald_hip.h"
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -83,11 +84,49 @@ static int dense_seg(cald_ctx* c, int N, int H, int W, const LevelSeg** out) {
     return 0;
 }
 
+// Small host tables on their way to the device without stopping the host: a ring of pinned slots + device slots per context.  A slot
+// is reused only after the stream has passed the event recorded behind its last consumer (in practice never waited for).
+struct StageRing { char* host; char* dev; hipEvent_t ev[8]; bool used[8]; int next; };
+static const size_t kStageSlot = sizeof(ViewDesc) * CALD_MAX_VIEWS;
+static std::map<cald_ctx*, StageRing> g_stage;
+static int stage_upload(cald_ctx* c, const void* src, size_t bytes, hipStream_t st, const void** dev_out, int* slot_out) {
+    if (bytes > kStageSlot) TFAIL(CALD_ERR_INVALID, "staging slot too small");
+    std::lock_guard<std::mutex> lk(g_seg_mu);
+    auto it = g_stage.find(c);
+    if (it == g_stage.end()) {
+        StageRing r; memset(&r, 0, sizeof(r));
+        THIP(hipHostMalloc((void**)&r.host, kStageSlot * 8, hipHostMallocDefault));
+        THIP(hipMalloc((void**)&r.dev, kStageSlot * 8));
+        for (int i = 0; i < 8; i++) THIP(hipEventCreateWithFlags(&r.ev[i], hipEventDisableTiming));
+        it = g_stage.emplace(c, r).first;
+    }
+    StageRing& r = it->second;
+    const int s = r.next; r.next = (s + 1) & 7;
+    if (r.used[s]) THIP(hipEventSynchronize(r.ev[s]));
+    memcpy(r.host + kStageSlot * s, src, bytes);
+    THIP(hipMemcpyAsync(r.dev + kStageSlot * s, r.host + kStageSlot * s, bytes, hipMemcpyHostToDevice, st));
+    *dev_out = r.dev + kStageSlot * s; *slot_out = s;
+    return 0;
+}
+static int stage_consumed(cald_ctx* c, int slot, hipStream_t st) {
+    std::lock_guard<std::mutex> lk(g_seg_mu);
+    StageRing& r = g_stage[c];
+    THIP(hipEventRecord(r.ev[slot], st));
+    r.used[slot] = true;
+    return 0;
+}
+
 extern "C" int cald_train_seg_cache_size(void) { std::lock_guard<std::mutex> lk(g_seg_mu); return (int)g_seg.size(); }
 void cald_internal_train_release(cald_ctx* c) {
     std::lock_guard<std::mutex> lk(g_seg_mu);
     for (auto it = g_seg.begin(); it != g_seg.end();) {
         if (std::get<0>(it->first) == c) { hipFree(it->second); it = g_seg.erase(it); } else ++it;
+    }
+    auto sr = g_stage.find(c);
+    if (sr != g_stage.end()) {
+        for (int i = 0; i < 8; i++) hipEventDestroy(sr->second.ev[i]);
+        hipHostFree(sr->second.host); hipFree(sr->second.dev);
+        g_stage.erase(sr);
     }
 }
 
@@ -100,8 +139,8 @@ void cald_internal_train_release(cald_ctx* c) {
 //         [tap][Cin] (the RoIAlign output [R][49][256]): K rows = tap * Cin + ci
 // mode 3: data gradient of a mode-2 layer: K rows = co of a CinK-channel dY, N = tap * Cin + ci
 struct PackArgs { const float* w; float* wk; float* w4; int Cout, Cin, taps, CinK, Kpad, NPad, mode; const float* rowscale; };
-__global__ void pack_weight_kernel(PackArgs a) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void pack_weight_body(const PackArgs& a, long long blk) {
+    const long long i = blk * 256 + threadIdx.x;
     if (i >= (long long)a.Kpad * a.NPad) return;
     const int k = (int)(i / a.NPad), n = (int)(i - (long long)k * a.NPad);
     int tap, ci;
@@ -124,11 +163,12 @@ __global__ void pack_weight_kernel(PackArgs a) {
     const int kt = k >> 4, kk = k & 15, kq = kk >> 3, j = (kk & 7) >> 1, h = kk & 1;
     a.w4[(((long long)(kt * 2 + kq) * a.NPad + n) * 2 + h) * 4 + j] = v;
 }
+__global__ __launch_bounds__(256) void pack_weight_kernel(PackArgs a) { pack_weight_body(a, blockIdx.x); }
 // Forward packs (modes 0, 2) in two coalesced passes: (1) every torch row n (Cin * taps contiguous floats) is read in order and
 // written to T[n][k] (k = position in the chain order: neighbours stay inside one 16-channel chunk); (2) a tiled LDS transpose
 // T[n][k] -> wk[k][n] + the conv_p4 layout.  (pack_weight_kernel reads with a stride of one whole row between lanes.)
-__global__ void pack_rows_kernel(PackArgs a, float* T) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void pack_rows_body(const PackArgs& a, float* T, long long blk) {
+    const long long i = blk * 256 + threadIdx.x;
     const long long row = (long long)a.Cin * a.taps;
     if (i >= (long long)a.Cout * row) return;
     const int n = (int)(i / row); const int r = (int)(i - (long long)n * row);
@@ -138,9 +178,10 @@ __global__ void pack_rows_kernel(PackArgs a, float* T) {
     else k = (a.CinK % 16 == 0 && a.taps <= 32) ? ((ci >> 4) * a.taps + tap) * 16 + (ci & 15) : tap * a.CinK + ci;
     T[(long long)n * a.Kpad + k] = a.w[i];
 }
-__global__ __launch_bounds__(256) void pack_transpose_kernel(PackArgs a, const float* T) {
+__global__ __launch_bounds__(256) void pack_rows_kernel(PackArgs a, float* T) { pack_rows_body(a, T, blockIdx.x); }
+__device__ __forceinline__ void pack_transpose_body(const PackArgs& a, const float* T, int bx, int by) {
     __shared__ float tile[32][33];
-    const int k0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    const int k0 = bx * 32, n0 = by * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     for (int r = ty; r < 32; r += 8) {
         const int n = n0 + r, k = k0 + tx;
@@ -156,12 +197,32 @@ __global__ __launch_bounds__(256) void pack_transpose_kernel(PackArgs a, const f
         a.w4[(((long long)(kt * 2 + kq) * a.NPad + n) * 2 + h) * 4 + j] = v;
     }
 }
-__global__ void pack_vec_kernel(const float* bias, const float* scale, const float* shift, int n, float* dst, int npad) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void pack_transpose_kernel(PackArgs a, const float* T) { pack_transpose_body(a, T, blockIdx.x, blockIdx.y); }
+__device__ __forceinline__ void pack_vec_body(const float* bias, const float* scale, const float* shift, int n, float* dst, int npad, int blk) {
+    const int i = blk * 256 + threadIdx.x;
     if (i >= npad) return;
     dst[i] = (bias && i < n) ? bias[i] : 0.0f;
     dst[npad + i] = (scale && i < n) ? scale[i] : 0.0f;
     dst[2 * npad + i] = (shift && i < n) ? shift[i] : 0.0f;
+}
+__global__ __launch_bounds__(256) void pack_vec_kernel(const float* bias, const float* scale, const float* shift, int n, float* dst, int npad) {
+    pack_vec_body(bias, scale, shift, n, dst, npad, blockIdx.x);
+}
+// Every trainable layer's packs in TWO launches (cald_train_pack_plan_*): the optimizer changes all weights at once, and ~220 launches of
+// 2 - 9 us each kept the side stream busy for 1.5 ms at the start of a step -- longer than the frozen stem + layer 1 the main stream
+// runs meanwhile.  A launch covers a list of segments (kind, job, first block); a workgroup finds its segment by bisection.
+struct PackJobDev { PackArgs a; float* T; const float *bias, *scale, *shift; float* vec; int n_true, gx; };
+struct PackSeg { int kind, job; unsigned first; };          // kind 0 rows (modes 0 / 2), 1 whole pack (modes 1 / 3), 2 epilogue vectors, 3 transpose
+__global__ __launch_bounds__(256) void pack_plan_kernel(const PackSeg* __restrict__ segs, int nseg, const PackJobDev* __restrict__ jobs) {
+    int lo = 0, hi = nseg - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (segs[mid].first <= blockIdx.x) lo = mid; else hi = mid - 1; }
+    const PackSeg sg = segs[lo];
+    const PackJobDev& j = jobs[sg.job];
+    const unsigned blk = blockIdx.x - sg.first;
+    if (sg.kind == 0) pack_rows_body(j.a, j.T, blk);
+    else if (sg.kind == 1) pack_weight_body(j.a, blk);
+    else if (sg.kind == 2) pack_vec_body(j.bias, j.scale, j.shift, j.n_true, j.vec, j.a.NPad, (int)blk);
+    else pack_transpose_body(j.a, j.T, (int)(blk % (unsigned)j.gx), (int)(blk / (unsigned)j.gx));
 }
 
 struct PackGeom { int K, Kpad, NPad, n_true, cin_conv; long long floats; };
@@ -209,6 +270,94 @@ extern "C" int cald_train_pack_conv(cald_ctx* c, const float* w, const float* bi
     if (mode == 0 || mode == 2)     // the data-gradient packs carry no epilogue vectors (cald_train_conv never reads them: flags 0)
         hipLaunchKernelGGL(pack_vec_kernel, dim3(blocks), dim3(256), 0, st, bias, scale, shift, nt, vec, g.NPad);
     THIP(hipGetLastError());
+    return 0;
+}
+
+struct cald_pack_plan {
+    int device; PackSeg *seg1, *seg2; PackJobDev* jobs; int nseg1, nseg2; unsigned blocks1, blocks2;
+};
+static long long plan_round64(long long x) { return (x + 63) / 64 * 64; }
+static int pack_plan_check(int n, const cald_pack_job* jobs) {
+    if (n < 1 || !jobs) TFAIL(CALD_ERR_INVALID, "no jobs");
+    for (int i = 0; i < n; i++) {
+        const cald_pack_job& q = jobs[i];
+        if (!q.weight || !q.packed) TFAIL(CALD_ERR_INVALID, "job %d: null weight / packed", i);
+        if (q.Cout < 1 || q.Cin < 1 || q.KH < 1 || q.KW < 1 || q.mode < 0 || q.mode > 3) TFAIL(CALD_ERR_INVALID, "job %d: bad shape / mode", i);
+        if (q.mode != 2 && (q.CinK % 4 || q.CinK < (q.mode == 0 ? q.Cin : q.Cout))) TFAIL(CALD_ERR_INVALID, "job %d: CinK must be a multiple of 4 and cover the contracted channels", i);
+    }
+    return 0;
+}
+extern "C" int cald_train_pack_plan_scratch_floats(int n, const cald_pack_job* jobs, int64_t* floats_out) {
+    if (!floats_out) TFAIL(CALD_ERR_INVALID, "null argument");
+    if (int rc = pack_plan_check(n, jobs)) return rc;
+    long long tot = 0;
+    for (int i = 0; i < n; i++) {
+        const cald_pack_job& q = jobs[i];
+        if (q.mode == 0 || q.mode == 2) tot += plan_round64((long long)q.Cout * pack_geom(q.Cout, q.Cin, q.KH, q.KW, q.CinK, q.mode).Kpad);
+    }
+    *floats_out = tot;
+    return 0;
+}
+extern "C" int cald_train_pack_plan_create(cald_ctx* c, int n, const cald_pack_job* jobs, float* scratch, int64_t scratch_floats, cald_pack_plan** out) {
+    if (!c || !out) TFAIL(CALD_ERR_INVALID, "null argument");
+    int64_t need = 0;
+    if (int rc = cald_train_pack_plan_scratch_floats(n, jobs, &need)) return rc;
+    if (need && (!scratch || scratch_floats < need)) TFAIL(CALD_ERR_INVALID, "scratch of %lld floats needed", (long long)need);
+    THIP(hipSetDevice(cald_internal_device(c)));
+    std::vector<PackJobDev> dj(n);
+    std::vector<PackSeg> s1, s2;
+    unsigned b1 = 0, b2 = 0;
+    long long toff = 0;
+    for (int i = 0; i < n; i++) {
+        const cald_pack_job& q = jobs[i];
+        const PackGeom g = pack_geom(q.Cout, q.Cin, q.KH, q.KW, q.CinK, q.mode);
+        const long long nn = (long long)g.Kpad * g.NPad;
+        const bool fwd = q.mode == 0 || q.mode == 2;
+        PackJobDev& d = dj[i];
+        d.a = PackArgs{q.weight, q.packed, q.packed + nn, q.Cout, q.Cin, q.KH * q.KW, q.CinK, g.Kpad, g.NPad, q.mode, fwd ? nullptr : q.bn_scale};
+        d.T = nullptr; d.bias = q.bias; d.scale = q.bn_scale; d.shift = q.bn_shift; d.vec = q.packed + 2 * nn; d.n_true = g.n_true;
+        d.gx = (g.Kpad + 31) / 32;
+        if (fwd) {
+            d.T = scratch + toff; toff += plan_round64((long long)q.Cout * g.Kpad);
+            const long long src = (long long)q.Cout * q.Cin * q.KH * q.KW;
+            s1.push_back(PackSeg{0, i, b1}); b1 += (unsigned)((src + 255) / 256);
+            s1.push_back(PackSeg{2, i, b1}); b1 += (unsigned)((g.NPad + 255) / 256);
+            s2.push_back(PackSeg{3, i, b2}); b2 += (unsigned)(d.gx * ((g.NPad + 31) / 32));
+        } else {
+            s1.push_back(PackSeg{1, i, b1}); b1 += (unsigned)((nn + 255) / 256);
+        }
+    }
+    cald_pack_plan* p = new cald_pack_plan();
+    p->device = cald_internal_device(c); p->seg1 = p->seg2 = nullptr; p->jobs = nullptr;
+    p->nseg1 = (int)s1.size(); p->nseg2 = (int)s2.size(); p->blocks1 = b1; p->blocks2 = b2;
+    auto fail = [&](hipError_t e) { hipFree(p->seg1); hipFree(p->seg2); hipFree(p->jobs); delete p; return cald_internal_fail(CALD_ERR_HIP, "pack plan: %s", hipGetErrorString(e)); };
+    hipError_t e;
+    if ((e = hipMalloc((void**)&p->jobs, sizeof(PackJobDev) * n)) != hipSuccess) return fail(e);
+    if ((e = hipMalloc((void**)&p->seg1, sizeof(PackSeg) * (s1.size() + 1))) != hipSuccess) return fail(e);
+    if ((e = hipMalloc((void**)&p->seg2, sizeof(PackSeg) * (s2.size() + 1))) != hipSuccess) return fail(e);
+    if ((e = hipMemcpy(p->jobs, dj.data(), sizeof(PackJobDev) * n, hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
+    if ((e = hipMemcpy(p->seg1, s1.data(), sizeof(PackSeg) * s1.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
+    if (!s2.empty() && (e = hipMemcpy(p->seg2, s2.data(), sizeof(PackSeg) * s2.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
+    // k positions no source element maps to (channel / K padding) stay zero for the plan's lifetime: the scratch is the plan's own
+    if (need && (e = hipMemset(scratch, 0, (size_t)need * 4)) != hipSuccess) return fail(e);
+    *out = p;
+    return 0;
+}
+extern "C" int cald_train_pack_plan_run(cald_ctx* c, const cald_pack_plan* p) {
+    if (!c || !p) TFAIL(CALD_ERR_INVALID, "null argument");
+    if (p->device != cald_internal_device(c)) TFAIL(CALD_ERR_INVALID, "plan belongs to another device");
+    THIP(hipSetDevice(p->device));
+    hipStream_t st = cald_internal_stream(c);
+    hipLaunchKernelGGL(pack_plan_kernel, dim3(p->blocks1), dim3(256), 0, st, (const PackSeg*)p->seg1, p->nseg1, (const PackJobDev*)p->jobs);
+    if (p->blocks2) hipLaunchKernelGGL(pack_plan_kernel, dim3(p->blocks2), dim3(256), 0, st, (const PackSeg*)p->seg2, p->nseg2, (const PackJobDev*)p->jobs);
+    THIP(hipGetLastError());
+    return 0;
+}
+extern "C" int cald_train_pack_plan_destroy(cald_pack_plan* p) {
+    if (!p) return 0;
+    hipSetDevice(p->device);
+    hipFree(p->seg1); hipFree(p->seg2); hipFree(p->jobs);
+    delete p;
     return 0;
 }
 
@@ -861,13 +1010,83 @@ extern "C" int cald_train_rpn_proposals(cald_ctx* c, int N, int Hp, int Wp, cons
                 b[0] = rintf(-ws / 2.0f); b[1] = rintf(-hs / 2.0f); b[2] = rintf(ws / 2.0f); b[3] = rintf(hs / 2.0f);
             }
     }
-    THIP(hipMemcpyAsync(d_views, hv.data(), sizeof(ViewDesc) * N, hipMemcpyHostToDevice, st));
-    THIP(hipMemcpyAsync(d_base, base, sizeof(base), hipMemcpyHostToDevice, st));
-    THIP(hipStreamSynchronize(st));   // the host arrays above are stack / vector storage
+    // the two host tables go through the pinned staging ring (one blob: base anchors, then the view descriptors), so the call returns with
+    // the proposal kernels enqueued instead of first waiting for everything before them on the stream (the whole body + FPN + RPN head)
+    std::vector<char> blob(256 + sizeof(ViewDesc) * N);
+    memcpy(blob.data(), base, sizeof(base)); memcpy(blob.data() + 256, hv.data(), sizeof(ViewDesc) * N);
+    const bool ring = blob.size() <= kStageSlot;
+    const void* dv = nullptr; int slot = 0;
+    if (ring) {
+        if (int rc = stage_upload(c, blob.data(), blob.size(), st, &dv, &slot)) return rc;
+        d_base = (float*)dv; d_views = (ViewDesc*)((const char*)dv + 256);
+    } else {
+        THIP(hipMemcpyAsync(d_views, hv.data(), sizeof(ViewDesc) * N, hipMemcpyHostToDevice, st));
+        THIP(hipMemcpyAsync(d_base, base, sizeof(base), hipMemcpyHostToDevice, st));
+        THIP(hipStreamSynchronize(st));   // the host arrays above are stack / vector storage
+    }
     ra.views = d_views; ra.base_anchors = d_base; ra.head_ld = head_ld; ra.A = 3; ra.V = N; ra.pre_n = pre_n; ra.post_n = post_n;
     ra.nms_thr = nms_thr; ra.min_size = min_size; ra.proposals = proposals_out; ra.prop_stride = post_n; ra.prop_count = counts_out;
     launch_rpn(ra, st);
     THIP(hipGetLastError());
+    if (ring) return stage_consumed(c, slot, st);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// RoI sampling on the host (roi_heads.select_training_samples: labels from the match results, BalancedPositiveNegativeSampler, the
+// index lists the loss kernels read) for all images of a batch in one call.  The forward pass stops for this -- the GPU waits while
+// the host turns match results into sample indices -- and the numpy version of the loop cost 0.6 ms per step.
+// Candidate table of image i: `slots[i]` proposal rows (the first counts[i] are used) followed by n_gt[i] ground-truth rows; images
+// back to back.  The sampler keeps the k candidates with the smallest keys of each class (keys: iid uniform draws handed in by the
+// caller, one per table row: every k-subset is equally likely -- what randperm(n)[:k] selects).
+// ---------------------------------------------------------------------------------------------------------------------
+extern "C" int cald_train_roi_sample_host(int N, const int* slots, const int* n_gt, const int* counts, const int32_t* matched,
+                                          const int64_t* gt_labels, const double* keys, int batch, double pos_fraction, int pred_ld, int num_classes,
+                                          int64_t* keep_rows, int64_t* gt_sel, int64_t* labels_out, float* img_col, int64_t* pos_rows,
+                                          int64_t* pred_idx, int* R_out, int* n_pos_out, int* per_image_out) {
+    if (N < 1 || !slots || !n_gt || !matched || !keys || !keep_rows || !gt_sel || !labels_out || !img_col || !pos_rows || !pred_idx || !R_out || !n_pos_out)
+        TFAIL(CALD_ERR_INVALID, "null argument");
+    if (batch < 1 || pos_fraction < 0.0 || pos_fraction > 1.0) TFAIL(CALD_ERR_INVALID, "bad sampler parameters");
+    long long row0 = 0, g0 = 0, gtot = 0;
+    for (int i = 0; i < N; i++) gtot += n_gt[i];
+    int R = 0, npos_all = 0;
+    std::vector<std::pair<double, int>> pos, neg;
+    std::vector<int> kept;
+    std::vector<int64_t> lab;
+    for (int i = 0; i < N; i++) {
+        const int used = counts ? counts[i] : slots[i];
+        if (used < 0 || used > slots[i] || n_gt[i] < 0) TFAIL(CALD_ERR_INVALID, "image %d: bad counts", i);
+        const int rows = slots[i] + n_gt[i];
+        pos.clear(); neg.clear(); lab.assign(rows, -1);
+        for (int r = 0; r < rows; r++) {
+            if (r >= used && r < slots[i]) continue;                       // an unused proposal slot: not a candidate
+            const int m = matched[row0 + r];
+            int64_t l;
+            if (n_gt[i] == 0) l = 0;
+            else if (m >= 0) { if (m >= n_gt[i]) TFAIL(CALD_ERR_INVALID, "image %d: match index out of range", i); l = gt_labels ? gt_labels[g0 + m] : 1; }
+            else l = m == -1 ? 0 : -1;                                     // below the low threshold: background; between thresholds: ignored
+            lab[r] = l;
+            if (l >= 1) pos.emplace_back(keys[row0 + r], r); else if (l == 0) neg.emplace_back(keys[row0 + r], r);
+        }
+        int num_pos = (int)(batch * pos_fraction); if (num_pos > (int)pos.size()) num_pos = (int)pos.size();
+        int num_neg = batch - num_pos; if (num_neg > (int)neg.size()) num_neg = (int)neg.size();
+        if (num_pos < (int)pos.size()) std::nth_element(pos.begin(), pos.begin() + num_pos, pos.end());
+        if (num_neg < (int)neg.size()) std::nth_element(neg.begin(), neg.begin() + num_neg, neg.end());
+        kept.clear();
+        for (int k = 0; k < num_pos; k++) kept.push_back(pos[k].second);
+        for (int k = 0; k < num_neg; k++) kept.push_back(neg[k].second);
+        std::sort(kept.begin(), kept.end());
+        for (int r : kept) {
+            const int m = matched[row0 + r];
+            keep_rows[R] = row0 + r; labels_out[R] = lab[r]; img_col[R] = (float)i;
+            gt_sel[R] = n_gt[i] ? g0 + (m > 0 ? m : 0) : gtot;           // images without ground truth point at the extra all-zero box
+            if (lab[r] > 0) { pos_rows[npos_all] = R; pred_idx[npos_all] = (int64_t)R * pred_ld + num_classes + 4 * lab[r]; npos_all++; }
+            R++;
+        }
+        if (per_image_out) per_image_out[i] = (int)kept.size();
+        row0 += rows; g0 += n_gt[i];
+    }
+    *R_out = R; *n_pos_out = npos_all;
     return 0;
 }
 
@@ -1372,15 +1591,17 @@ extern "C" int cald_train_preprocess(cald_ctx* c, int N, const uint8_t* const* i
         hv[v].Ho = hv[v].H; hv[v].Wo = hv[v].W; hv[v].noise = remainders ? remainders[v] : nullptr;
         if (hv[v].Hr > Hp || hv[v].Wr > Wp) TFAIL(CALD_ERR_INVALID, "resized image %d exceeds the padded batch size", v);
     }
-    void* scratch = nullptr;
-    if (int rc = cald_internal_scratch(c, sizeof(ViewDesc) * N, &scratch)) return rc;
-    THIP(hipMemcpyAsync(scratch, hv.data(), sizeof(ViewDesc) * N, hipMemcpyHostToDevice, st));
-    THIP(hipStreamSynchronize(st));
+    // the descriptors travel through a pinned staging ring: the call returns without waiting for the stream (it used to stop the host
+    // twice, and with it the start of every training step until the previous step had left the GPU)
+    const void* dv = nullptr; int slot = 0;
+    if (int rc = stage_upload(c, hv.data(), sizeof(ViewDesc) * N, st, &dv, &slot)) return rc;
     const LevelSeg* s0;
     if (int rc = dense_seg(c, N, Hp, Wp, &s0)) return rc;
-    launch_preprocess((const ViewDesc*)scratch, s0, out, N, Hp * Wp, st);
+    launch_preprocess((const ViewDesc*)dv, s0, out, N, Hp * Wp, st);
     THIP(hipGetLastError());
-    THIP(hipStreamSynchronize(st));   // the descriptors live in the shared scratch
+    if (int rc = stage_consumed(c, slot, st)) return rc;
+    static const bool sync_env = getenv("CALD_TRAIN_PREPROCESS_SYNC") && atoi(getenv("CALD_TRAIN_PREPROCESS_SYNC"));   // A/B switch
+    if (sync_env) THIP(hipStreamSynchronize(st));
     return 0;
 }
 /* max_pool2d(3, 2, 1): in [N][H][W][C] -> out [N][(H-1)/2+1][(W-1)/2+1][C] */

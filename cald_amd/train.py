@@ -37,6 +37,7 @@ from . import train_ops as ops
 # 1: 3x3 stride-2 data gradients as four phase convolutions on the un-dilated dY (4x fewer FLOPs; measured SLOWER at batch 4 -- 100.4
 # vs 104.4 images/s on one box -- because the four small launches are latency-bound); default: one conv on the zero-stuffed grid
 _S2_PHASES = __import__("os").environ.get("CALD_TRAIN_S2_PHASES", "0") != "0"
+_PACK_PLAN = __import__("os").environ.get("CALD_TRAIN_PACK_PLAN", "1") != "0"      # all trainable layers re-packed in two launches per step
 
 
 def _bn_fold(sd, prefix, eps=1e-5):
@@ -53,7 +54,7 @@ def choose_k(n, k, generator=None):
     sequential uniform draws from the CPU generator, repeats skipped."""
     if k >= n:
         return torch.arange(n)
-    if 4 * k > n:
+    if 4 * k > n or n <= 8192:          # a few thousand candidates (the RoI sampler's): one permutation costs less than draw-and-dedupe
         return torch.randperm(n, generator=generator)[:k]
     got = np.empty(0, np.int64)
     while len(got) < k:
@@ -62,6 +63,23 @@ def choose_k(n, k, generator=None):
         _, first = np.unique(allv, return_index=True)
         got = allv[np.sort(first)][:k]
     return torch.from_numpy(got)
+
+
+class _Samples(dict):
+    """{"rpn": [(pos, neg)], "box": [(pos, neg)]} of the last forward (sorted candidate numbers per image); the RoI half is derived from
+    the sampler's table rows on first use -- nothing on the step's critical path needs it."""
+
+    def __init__(self, rpn, box, box_fn):
+        super().__init__(rpn=rpn)
+        self._box_fn = box_fn
+        if box_fn is None:
+            self["box"] = box
+
+    def __missing__(self, key):
+        if key == "box" and self._box_fn is not None:
+            self["box"] = self._box_fn()
+            return self["box"]
+        raise KeyError(key)
 
 
 class _Conv(object):
@@ -95,6 +113,14 @@ class _Conv(object):
             self._pk_version = self.net.version
             self._pkd_version = -1
         return self._pk
+
+    def _plan_packs(self):
+        """The forward and data-gradient PackedConv of a trainable layer for a PackPlan (allocated, not packed, on first use)."""
+        if self._pk is None:
+            self._pk = ops.PackedConv(self.w, self.b, self.scale, self.shift, CinK=self.cin_k, mode=self.mode, taps=self.taps, pack=False)
+        if self._pkd is None:
+            self._pkd = ops.PackedConv(self.w, scale=self.scale, CinK=self.out_ld, mode=3 if self.mode == 2 else 1, taps=self.taps, pack=False)
+        return [self._pk, self._pkd]
 
     def _is_s2(self):
         return _S2_PHASES and self.stride == 2 and self.K == 3 and self.pad == 1 and self.w.dim() == 4
@@ -271,6 +297,7 @@ class _TrainerBase(object):
         # weight gradients run on a second stream: at batch 4 most layers fill a fraction of the 256 CUs, and dW / dX of one layer
         # are independent.  CALD_TRAIN_SIDE_STREAM=0 keeps everything on one stream.
         self.side = self.aux = None
+        self._pack_plan = None
         if __import__("os").environ.get("CALD_TRAIN_SIDE_STREAM", "1") != "0":
             from .detector import get_side_ctx
             st = torch.cuda.Stream(device=self.dev)
@@ -378,6 +405,15 @@ class _TrainerBase(object):
         prev, ops._WGRAD_CTX[0] = ops._WGRAD_CTX[0], ctx
         try:
             with torch.cuda.stream(st):                     # torch-side helpers of the packers (sub-filter gathers) run on this stream too
+                planned = [cv for cv in self.convs if cv.trainable and not cv._is_s2()] if _PACK_PLAN else []
+                if planned:
+                    # every layer's two forms in two launches: ~220 per-layer launches kept this stream busy for 1.5 ms, longer than
+                    # the frozen layers cover (tools/train_event_timeline.py: layer 2 started 1.5 ms after the optimizer step)
+                    if self._pack_plan is None:
+                        self._pack_plan = ops.PackPlan([pk for cv in planned for pk in cv._plan_packs()], self.dev)
+                    self._pack_plan.run()
+                    for cv in planned:
+                        cv._pk_version = cv._pkd_version = self.version
                 for cv in self.convs:
                     if cv.trainable:
                         cv._packed(); cv._packed_grad()
@@ -418,15 +454,18 @@ class _TrainerBase(object):
         """normalize + resize + pad on the device, stem, the four body stages.  Returns feats C2..C5."""
         x = ops.preprocess(u8, img_sizes, Hp, Wp, rem)
         x = ops.maxpool(self.stem.fwd(x, relu=True))
+        self._mark("stem")
         feats = []
         waited = self.side is None
-        for trainable, blocks in self.layers:
+        for li, (trainable, blocks) in enumerate(self.layers):
             if trainable and not waited:                    # first layer that reads a freshly packed weight
                 self._main.wait_event(self._packs_ready)
                 waited = True
             for blk in blocks:
                 x = blk.fwd(x)
             feats.append(x)
+            if li < 3:
+                self._mark("layer%d" % (li + 1))
         if not waited:
             self._main.wait_event(self._packs_ready)
         self._mark("body")
@@ -448,6 +487,8 @@ class _TrainerBase(object):
             if gC[li] is not None:
                 g = gC[li] if g is None else ops.add(gC[li], g)
             ops.relu_bwd_(g, blocks[-1].out)                # the layer's last ReLU: the only elementwise pass of the layer
+            if li < 3:
+                self._mark("bwd layer%d" % (li + 2))
             for bi in range(len(blocks) - 1, -1, -1):
                 # inside a layer the block input is the previous block's output and receives this gradient only: its ReLU backward is
                 # fused; at the top of a layer the input also feeds an FPN lateral, whose gradient is added first (next iteration)
@@ -528,6 +569,7 @@ class FasterRCNNTrainer(_TrainerBase):
                     return head_off[l] + (img * lvl_pix[l] + pix) * 16 + a, a
                 n_gt = [int(g.shape[0]) for g in gts]
                 gt_off = np.cumsum([0] + n_gt)
+                gt_labels_cat = np.ascontiguousarray(torch.cat(gt_labels).numpy()) if sum(n_gt) else np.zeros(1, np.int64)
                 gts_all = torch.cat(gts + [torch.zeros((1, 4), device=self.dev)])      # last row: the "matched box" of images without ground truth
                 matched_dev = torch.full((N, A_img), -1, dtype=torch.int32, device=self.dev)
                 for i in range(N):
@@ -628,41 +670,76 @@ class FasterRCNNTrainer(_TrainerBase):
                 if fixed_rows:
                     matched_dev[int(pr_off[-1]):] = counts.to(torch.int32)
                 matched_all = matched_dev.cpu().numpy()
+                # ---- the GPU waits from here to the host->device copy below: everything in between is host time on the step's critical path ----
+                T = int(pr_off[-1])
                 if fixed_rows:
-                    counts = [int(v) for v in matched_all[int(pr_off[-1]):]]
+                    counts = [int(v) for v in matched_all[T:]]
                     proposals = [props[i, :counts[i]] for i in range(N)]
+                else:
+                    counts = list(slots)
+                if self.sampler == "choose_k":
+                    # one C call for the whole batch (cald_train_roi_sample_host): labels, the balanced sampler (the k smallest of iid
+                    # uniform keys per class -- one generator call for all images), every index list of the loss kernels.  The numpy
+                    # loop below did the same in 0.6 ms per step.
+                    # keys are drawn per (image, post_n proposal slots + ground truth) whatever the table's shape, so that the fixed-row and
+                    # the compact table (speculative path, proposals handed in) select the same candidates from the same generator state
+                    post = cfg["post_n"]
+                    if all(sl <= post for sl in slots):
+                        keys = torch.rand(sum(post + g for g in n_gt), generator=self.generator, dtype=torch.float64).numpy()
+                        if any(sl != post for sl in slots):
+                            ko = np.cumsum([0] + [post + g for g in n_gt])
+                            keys = np.concatenate([keys[np.r_[ko[i]:ko[i] + slots[i], ko[i] + post:ko[i] + post + n_gt[i]]] for i in range(N)])
+                    else:
+                        keys = torch.rand(T, generator=self.generator, dtype=torch.float64).numpy()
+                    roi_np, img_col_np, R, n_posr, per_img = ops.roi_sample_host(slots, n_gt, counts if fixed_rows else None, matched_all, gt_labels_cat, keys,
+                                                                                  cfg["box_batch"], cfg["box_pos"], self.pred_ld, Ccls)
+                    packed2 = torch.from_numpy(roi_np).to(self.dev)
+                    img_col_dev = torch.from_numpy(img_col_np).to(self.dev)
+                    roi_labels_np = roi_np[2 * R:3 * R]
+                    n_posrows = n_posr
+                    def box_samples_fn(keep=roi_np[:R].copy(), lab=roi_labels_np.copy(), per_img=per_img, counts=list(counts), slots=list(slots), pr_off=pr_off.copy()):
+                        out, o = [], 0
+                        for i in range(N):                      # table row -> compact candidate number (used proposals, then the ground truth)
+                            r = keep[o:o + per_img[i]] - pr_off[i]
+                            c = np.where(r < slots[i], r, r - slots[i] + counts[i])
+                            l = lab[o:o + per_img[i]]
+                            out.append((c[l > 0], c[l == 0])); o += per_img[i]
+                        return out
+                    box_samples = None
+                else:
                     # compact candidate number -> row of the fixed-row table (the used proposal slots, then the ground truth)
                     rowmap = [np.concatenate([np.arange(counts[i]), slots[i] + np.arange(n_gt[i])]).astype(np.int64) for i in range(N)]
-                else:
-                    rowmap = [np.arange(n_pr[i], dtype=np.int64) for i in range(N)]
-                keep_all, lab_all, gtsel_all, img_col = [], [], [], []
-                for i in range(N):
-                    m = matched_all[pr_off[i]:pr_off[i + 1]][rowmap[i]]
-                    if n_gt[i]:
-                        labels = gt_labels[i].numpy()[np.maximum(m, 0)].copy()
-                        labels[m == -1] = 0
-                        labels[m == -2] = -1
-                    else:
-                        labels = np.zeros(len(m), np.int64)
-                    pos, neg = torch.from_numpy(np.flatnonzero(labels >= 1)), torch.from_numpy(np.flatnonzero(labels == 0))
-                    sp, sn = self._sample(pos, neg, cfg["box_batch"], cfg["box_pos"])
-                    box_samples.append((np.sort(sp.numpy()), np.sort(sn.numpy())))
-                    keep = np.sort(np.concatenate([sp.numpy(), sn.numpy()]))
-                    keep_all.append(pr_off[i] + rowmap[i][keep]); lab_all.append(labels[keep])
-                    gtsel_all.append(gt_off[i] + np.maximum(m[keep], 0) if n_gt[i] else np.full(len(keep), gt_off[-1], np.int64))
-                    img_col.append(np.full(len(keep), float(i), np.float32))
-                roi_labels_np = np.concatenate(lab_all).astype(np.int64)
-                R = len(roi_labels_np)
-                pos_rows = np.flatnonzero(roi_labels_np > 0)
-                pred_idx_np = pos_rows * self.pred_ld + Ccls + 4 * roi_labels_np[pos_rows]
-                packed2 = torch.from_numpy(np.concatenate([np.concatenate(keep_all), np.concatenate(gtsel_all), roi_labels_np, pred_idx_np, pos_rows]).astype(np.int64)).to(self.dev)
+                    keep_all, lab_all, gtsel_all, img_col = [], [], [], []
+                    for i in range(N):
+                        m = matched_all[pr_off[i]:pr_off[i + 1]][rowmap[i]]
+                        if n_gt[i]:
+                            labels = gt_labels[i].numpy()[np.maximum(m, 0)].copy()
+                            labels[m == -1] = 0
+                            labels[m == -2] = -1
+                        else:
+                            labels = np.zeros(len(m), np.int64)
+                        pos, neg = torch.from_numpy(np.flatnonzero(labels >= 1)), torch.from_numpy(np.flatnonzero(labels == 0))
+                        sp, sn = self._sample(pos, neg, cfg["box_batch"], cfg["box_pos"])
+                        box_samples.append((np.sort(sp.numpy()), np.sort(sn.numpy())))
+                        keep = np.sort(np.concatenate([sp.numpy(), sn.numpy()]))
+                        keep_all.append(pr_off[i] + rowmap[i][keep]); lab_all.append(labels[keep])
+                        gtsel_all.append(gt_off[i] + np.maximum(m[keep], 0) if n_gt[i] else np.full(len(keep), gt_off[-1], np.int64))
+                        img_col.append(np.full(len(keep), float(i), np.float32))
+                    roi_labels_np = np.concatenate(lab_all).astype(np.int64)
+                    R = len(roi_labels_np)
+                    pos_rows = np.flatnonzero(roi_labels_np > 0)
+                    n_posrows = len(pos_rows)
+                    pred_idx_np = pos_rows * self.pred_ld + Ccls + 4 * roi_labels_np[pos_rows]
+                    packed2 = torch.from_numpy(np.concatenate([np.concatenate(keep_all), np.concatenate(gtsel_all), roi_labels_np, pred_idx_np, pos_rows]).astype(np.int64)).to(self.dev)
+                    img_col_dev = torch.from_numpy(np.concatenate(img_col)).to(self.dev)
+                    box_samples_fn = None
                 keep_sel, gt_sel2, labels_dev = packed2[:R], packed2[R:2 * R], packed2[2 * R:3 * R]
-                pred_idx, pos_sel = packed2[3 * R:3 * R + len(pos_rows)], packed2[3 * R + len(pos_rows):]
+                pred_idx, pos_sel = packed2[3 * R:3 * R + n_posrows], packed2[3 * R + n_posrows:3 * R + 2 * n_posrows]
                 boxes = pr_all[keep_sel]
-                rois = torch.cat([torch.from_numpy(np.concatenate(img_col)).to(self.dev)[:, None], boxes], dim=1).contiguous()
+                rois = torch.cat([img_col_dev[:, None], boxes], dim=1).contiguous()
                 roi_gt = gts_all[gt_sel2]
                 box_tgt = ops.box_encode(roi_gt.contiguous(), boxes.contiguous(), cfg["w"])[pos_sel].contiguous()
-                roi_labels = torch.from_numpy(roi_labels_np)
+                roi_labels = torch.from_numpy(np.ascontiguousarray(roi_labels_np))
             finally:
                 ops._WGRAD_CTX[0] = prev
         if on_aux:
@@ -678,7 +755,7 @@ class FasterRCNNTrainer(_TrainerBase):
         self.last = dict(N=N, R=R, feats=feats, inner=inner, P=P, tl=tl, heads=heads, head_flat=head_flat, head_sizes=head_sizes, level_hw=level_hw,
                          obj_idx=obj_idx, obj_lab=obj_lab, box_idx=box_idx, rpn_tgt=rpn_tgt, rois=rois, roi_rows=roi_rows, f6=f6, f7=f7, pred=pred,
                          labels=labels_dev, pred_idx=pred_idx, box_tgt=box_tgt, proposals=proposals, roi_labels=roi_labels,
-                         samples=dict(rpn=rpn_samples, box=box_samples), spec=spec)
+                         samples=_Samples(rpn_samples, box_samples, box_samples_fn), spec=spec)
         mark("box head")
         losses = {
             "loss_classifier": ops.softmax_ce(pred.view(R, -1), labels_dev, Ccls),
@@ -734,9 +811,10 @@ class FasterRCNNTrainer(_TrainerBase):
     def _rpn_branch_data(self, L, gts_):
         """Second half: the 3x3 conv's data gradient on the five levels -> gradients wrt P2..P5 and the pooled level."""
         P = L["P"]
-        gP = [self.rpn_conv.bwd(gts_[i], x=P[i], wgrad=False) for i in range(4)]
-        gpool = self.rpn_conv.bwd(gts_[4], x=P[4], wgrad=False)
-        return gP, gpool
+        for i in range(5):
+            self.rpn_conv._count(P[i], 1)
+        g = ops.conv_group(gts_, self.rpn_conv._packed_grad(), pad=1)       # the five levels in one launch, like the forward
+        return g[:4], g[4]
 
     def _commit_speculative(self):
         """The speculative weight gradients of the RPN branch become the real ones: moved (or added) into the flat gradient buffer, on
@@ -776,6 +854,7 @@ class FasterRCNNTrainer(_TrainerBase):
                 groi = self.fc6.bwd(g6)
                 gP_roi = [torch.zeros_like(p) for p in P[:4]]
                 ops.roi_align_bwd_(gP_roi, L["rois"], groi.view(R, 49, -1))
+                self._mark("bwd box head (aux)")
             finally:
                 ops._WGRAD_CTX[0] = prev
         spec = L.get("spec")
@@ -786,6 +865,7 @@ class FasterRCNNTrainer(_TrainerBase):
             gts_ = self._rpn_branch_weights(L, gscale[2], gscale[3])
         L["spec"] = None
         gP, gpool = self._rpn_branch_data(L, gts_)      # on the main stream, beside the box-head branch on the batch-only stream
+        self._mark("bwd rpn branch")
         if aux is not None:
             main.wait_stream(aux[0])
             for t in gP_roi:
@@ -800,7 +880,9 @@ class FasterRCNNTrainer(_TrainerBase):
         for i in range(4):
             need = self.layers[i][0]                                                       # the body layer producing feats[i] is trainable
             gC[i] = self.lat[i].bwd(ginner[i], need_dx=need)
+        self._mark("bwd fpn")
         self._body_backward(gC)
+        self._mark("bwd body dgrad")
         self._join_side()
         return self.grads
 

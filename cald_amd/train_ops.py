@@ -41,7 +41,7 @@ def packed_floats(Cout, Cin, KH, KW, CinK, mode):
 class PackedConv(object):
     """A torch-layout weight [Cout, Cin, KH, KW] (+ bias / frozen-BN scale, shift) in the layout the MFMA kernels read."""
 
-    def __init__(self, weight, bias=None, scale=None, shift=None, CinK=None, mode=0, taps=None, out=None):
+    def __init__(self, weight, bias=None, scale=None, shift=None, CinK=None, mode=0, taps=None, out=None, pack=True):
         _chk(weight, "weight")
         if mode in (2, 3):                               # linear on [tap][Cin] rows, torch weight [Cout, Cin * taps] (3: its data gradient)
             self.Cout, self.Cin, self.KH, self.KW = weight.shape[0], weight.shape[1] // taps, taps, 1
@@ -57,8 +57,45 @@ class PackedConv(object):
         assert self.buf.numel() >= n
         # gradient packs (modes 1, 3) carry no epilogue vectors: a scale given there is folded into the filter rows
         self.flags = ((FLAG_BIAS if bias is not None else 0) | (FLAG_BN if scale is not None else 0)) if mode in (0, 2) else 0
-        _ffi.check(_ffi.lib().cald_train_pack_conv(_wctx(weight), _p(weight), _p(bias), _p(scale), _p(shift), self.Cout,
-                                                   self.Cin, self.KH, self.KW, self.CinK, mode, _p(self.buf)))
+        # what a PackPlan needs to repeat this pack (the tensors are kept alive: the plan holds their device pointers)
+        self.src = (weight, bias, scale, shift)
+        if pack:
+            _ffi.check(_ffi.lib().cald_train_pack_conv(_wctx(weight), _p(weight), _p(bias), _p(scale), _p(shift), self.Cout,
+                                                       self.Cin, self.KH, self.KW, self.CinK, mode, _p(self.buf)))
+
+    def job(self):
+        w, b, sc, sh = self.src
+        q = _ffi.PackJob()
+        q.weight, q.bias, q.bn_scale, q.bn_shift = [t.data_ptr() if t is not None else None for t in (w, b, sc, sh)]
+        q.Cout, q.Cin, q.KH, q.KW, q.CinK, q.mode, q.packed = self.Cout, self.Cin, self.KH, self.KW, self.CinK, self.mode, self.buf.data_ptr()
+        return q
+
+
+class PackPlan(object):
+    """All of a model's PackedConv buffers re-packed in two launches (cald_train_pack_plan_*): after an optimizer step every trainable
+    weight has changed, and one cald_train_pack_conv per layer and form is ~220 launches of a few microseconds each."""
+
+    def __init__(self, packs, device):
+        self.packs = list(packs)                         # keeps weights and packed buffers alive
+        n = len(self.packs)
+        self.jobs = (_ffi.PackJob * n)(*[pk.job() for pk in self.packs])
+        need = C.c_int64()
+        _ffi.check(_ffi.lib().cald_train_pack_plan_scratch_floats(n, self.jobs, C.byref(need)))
+        self.scratch = torch.empty(max(int(need.value), 1), dtype=torch.float32, device=device)
+        self.handle = C.c_void_p()
+        _ffi.check(_ffi.lib().cald_train_pack_plan_create(get_ctx(self.scratch.device.index), n, self.jobs, _p(self.scratch), int(need.value),
+                                                          C.byref(self.handle)))
+
+    def run(self):
+        _ffi.check(_ffi.lib().cald_train_pack_plan_run(_wctx(self.scratch), self.handle))
+
+    def __del__(self):
+        h, self.handle = getattr(self, "handle", None), None
+        if h:
+            try:
+                _ffi.lib().cald_train_pack_plan_destroy(h)
+            except Exception:
+                pass
 
 
 def conv(x, pk, stride=1, pad=0, relu=False, residual=None, up=None, out=None, out_ld=None, mask=None):
@@ -231,6 +268,26 @@ def match(boxes, gt, hi, lo, allow_low_quality, out=None):
     _ffi.check(_ffi.lib().cald_train_match(_wctx(boxes), boxes.shape[0], _p(boxes), gt.shape[0], _p(gt), hi, lo, int(allow_low_quality),
                                            _p(out), None))
     return out
+
+
+def roi_sample_host(slots, n_gt, counts, matched, gt_labels_cat, keys, batch, pos_fraction, pred_ld, num_classes):
+    """cald_train_roi_sample_host: RoI labels + balanced sampling + loss index lists of a whole batch on the host, one call.
+    Returns (int64 block [keep rows | gt rows | labels | pred_idx | pos_rows], img_col float32 [R], R, n_pos, RoIs per image)."""
+    import numpy as np
+    N = len(slots)
+    cap = N * batch
+    assert matched.dtype == np.int32 and matched.flags.c_contiguous and keys.dtype == np.float64 and gt_labels_cat.dtype == np.int64
+    buf = np.empty(5 * cap, np.int64)
+    img = np.empty(cap, np.float32)
+    R, n_pos, per = C.c_int(), C.c_int(), (C.c_int * N)()
+    vp = lambda a, off=0: C.c_void_p(a.ctypes.data + off)
+    _ffi.check(_ffi.lib().cald_train_roi_sample_host(N, _int_array(slots), _int_array(n_gt), _int_array(counts) if counts is not None else None, vp(matched),
+                                                     vp(gt_labels_cat), vp(keys), int(batch), float(pos_fraction), int(pred_ld), int(num_classes),
+                                                     vp(buf), vp(buf, 8 * cap), vp(buf, 16 * cap), vp(img), vp(buf, 32 * cap), vp(buf, 24 * cap),
+                                                     C.byref(R), C.byref(n_pos), per))
+    R, n_pos = int(R.value), int(n_pos.value)
+    out = np.concatenate([buf[:R], buf[cap:cap + R], buf[2 * cap:2 * cap + R], buf[3 * cap:3 * cap + n_pos], buf[4 * cap:4 * cap + n_pos]])
+    return out, img[:R].copy(), R, n_pos, [int(v) for v in per]
 
 
 def box_encode(reference, proposals, weights):

@@ -273,9 +273,9 @@ int cald_profile_dump(cald_ctx* ctx, const char* path);
 /* ---- training step: the device operators behind task_model(images, targets) / losses.backward() /
  * optimizer.step() of cald_train.py:40-74 (detection/engine.py:19-61), which the reference delegates to torchvision 0.8.2 +
  * cuDNN autograd.  cald_amd/train.py strings them into the Faster R-CNN training graph.  All pointers are DEVICE pointers,
- * activations are dense NHWC batches [N][H][W][C], every call is asynchronous on the context stream EXCEPT cald_train_preprocess,
- * cald_train_anchors and cald_train_rpn_proposals, which stage small host tables (view descriptors, base anchors, proposal counts)
- * and synchronise the context stream before they return.
+ * activations are dense NHWC batches [N][H][W][C], every call is asynchronous on the context stream EXCEPT cald_train_anchors and
+ * cald_train_rpn_proposals, which stage small host tables (base anchors, proposal counts) and synchronise the context stream before
+ * they return (cald_train_preprocess sends its view descriptors through a pinned staging ring and does not wait).
  * Threading: the cald_train_* entry points share one process-wide cache of batch-geometry tables; they are NOT thread-safe, not even across
  * contexts -- call them from one thread per process (one process per GPU is the model everywhere in this library). ---- */
 /* size in floats of the packed form of a torch-layout weight [Cout][Cin][KH][KW] (see cald_train_pack_conv) */
@@ -288,6 +288,21 @@ int cald_train_packed_floats(int Cout, int Cin, int KH, int KW, int CinK, int mo
  *   mode 3  data gradient of a mode-2 layer (dY rows with channel stride CinK >= Cout -> rows laid out [tap][Cin]) */
 int cald_train_pack_conv(cald_ctx* ctx, const float* weight, const float* bias, const float* bn_scale, const float* bn_shift,
                          int Cout, int Cin, int KH, int KW, int CinK, int mode, float* packed);
+/* Every trainable layer's packs in two launches: the optimizer step changes all weights at once (cald_train.py:62-64), and one
+ * cald_train_pack_conv per layer and form is ~220 launch-bound launches at the start of every step.  A plan records the jobs (the
+ * arguments of cald_train_pack_conv, device pointers that stay valid for the plan's lifetime); cald_train_pack_plan_run packs them
+ * all on the context stream, bit for bit what the per-layer calls write.  scratch: device memory of
+ * cald_train_pack_plan_scratch_floats floats owned by the plan until it is destroyed (zeroed by create). */
+typedef struct cald_pack_job {
+    const float *weight, *bias, *bn_scale, *bn_shift;
+    int Cout, Cin, KH, KW, CinK, mode;
+    float* packed;
+} cald_pack_job;
+typedef struct cald_pack_plan cald_pack_plan;
+int cald_train_pack_plan_scratch_floats(int n, const cald_pack_job* jobs, int64_t* floats_out);
+int cald_train_pack_plan_create(cald_ctx* ctx, int n, const cald_pack_job* jobs, float* scratch, int64_t scratch_floats, cald_pack_plan** plan_out);
+int cald_train_pack_plan_run(cald_ctx* ctx, const cald_pack_plan* plan);
+int cald_train_pack_plan_destroy(cald_pack_plan* plan);
 /* out[N][Ho][Wo][out_ld] = epilogue(conv(in[N][H][W][CinK], packed)); flags: 1 bias, 2 scale/shift, 4 ReLU; residual (same
  * shape as out) and up ([N][Hup][Wup][Cout], nearest-upsampled) are added before the ReLU.  With mode 1 the call computes the
  * data gradient of a stride-1 conv (pad = K - 1 - forward pad); Cout / Cin are always those of the FORWARD weight.  mask (or
@@ -327,6 +342,18 @@ int cald_train_upsample_bwd(cald_ctx* ctx, int N, int Hf, int Wf, int Hc, int Wc
 int cald_train_rpn_proposals(cald_ctx* ctx, int N, int Hp, int Wp, const int* image_sizes, const float* const* heads,
                              const int* level_hw, int head_ld, int pre_n, int post_n, float nms_thr, float min_size,
                              float* proposals_out, int* counts_out);
+/* roi_heads.select_training_samples on the HOST for a whole batch (labels from Matcher results, BalancedPositiveNegativeSampler,
+ * the index lists of the loss kernels): torchvision 0.8.2's RoIHeads as frcnn_la.py:198-222 builds it.  All pointers are HOST
+ * pointers.  Candidate table: per image slots[i] proposal rows (the first counts[i] used; counts null = all) then n_gt[i]
+ * ground-truth rows, images back to back; matched = cald_train_match values per table row; gt_labels = the images' labels back to
+ * back; keys = one iid uniform draw per table row (the k smallest of a class are kept: every k-subset equally likely).  Outputs
+ * (capacity N * batch): table row, ground-truth row (sum n_gt = the extra zero box of images without boxes), label, image index per
+ * sampled RoI in (image, table row) order; pos_rows / pred_idx (row * pred_ld + num_classes + 4 * label) of the foreground RoIs;
+ * per_image_out[N] (may be null) = RoIs sampled per image. */
+int cald_train_roi_sample_host(int N, const int* slots, const int* n_gt, const int* counts, const int32_t* matched,
+                               const int64_t* gt_labels, const double* keys, int batch, double pos_fraction, int pred_ld, int num_classes,
+                               int64_t* keep_rows, int64_t* gt_sel, int64_t* labels_out, float* img_col, int64_t* pos_rows,
+                               int64_t* pred_idx, int* R_out, int* n_pos_out, int* per_image_out);
 /* AnchorGenerator: all anchors of one padded image over five levels, order (level, y, x, anchor): anchors_out [sum Hl*Wl*A][4].
  * kind 0 = Faster R-CNN (A = 3, frcnn_la.py:185-187), kind 1 = RetinaNet (A = 9, retinanet_cal.py:346-351) */
 int cald_train_anchors(cald_ctx* ctx, int kind, int Hp, int Wp, const int* level_hw, float* anchors_out);

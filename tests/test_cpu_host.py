@@ -905,3 +905,47 @@ def test_transform_size_matches_torch_interpolate_output_shape(oracle):
             assert tuple(x.value for x in v) == want, (H, W, mn, mx)
             n += 1
     assert n > 1500
+
+
+def test_roi_sample_host_labels_balanced_sampling_and_index_lists():
+    """cald_train_roi_sample_host (the training forward's one host stop) against a plain numpy restatement of
+    roi_heads.select_training_samples: labels from the Matcher values (>= 0 -> the ground truth's label, -1 -> background, -2 ->
+    ignored), unused proposal slots skipped, min(batch * fraction, #pos) positives + the rest negatives = the smallest keys of each
+    class, rows in (image, table row) order, the loss kernels' index lists, images without ground truth all background."""
+    from cald_amd import train_ops
+    rs = np.random.RandomState(5)
+    for case in range(6):
+        N = 1 + case % 4
+        slots = [int(rs.randint(20, 400)) for _ in range(N)]
+        n_gt = [int(rs.randint(0, 4)) if case else 2 for _ in range(N)]
+        counts = [int(rs.randint(1, s + 1)) for s in slots] if case % 2 else None
+        batch, frac, pred_ld, ncls = [(64, 0.25), (512, 0.25), (16, 0.5)][case % 3] + (108, 21)
+        rows = [s + g for s, g in zip(slots, n_gt)]
+        T = sum(rows)
+        matched = np.concatenate([np.where(rs.rand(r) < 0.2, rs.randint(0, max(g, 1), r), np.where(rs.rand(r) < 0.1, -2, -1)).astype(np.int32)
+                                  if g else np.full(r, -1, np.int32) for r, g in zip(rows, n_gt)] + [np.zeros(N, np.int32)])
+        gt_labels = np.concatenate([rs.randint(1, ncls, g).astype(np.int64) for g in n_gt] + [np.zeros(1, np.int64)])
+        keys = rs.rand(T)
+        blk, img, R, n_pos, per = train_ops.roi_sample_host(slots, n_gt, counts, matched, gt_labels, keys, batch, frac, pred_ld, ncls)
+        keep, gsel, lab, pidx, prow = blk[:R], blk[R:2 * R], blk[2 * R:3 * R], blk[3 * R:3 * R + n_pos], blk[3 * R + n_pos:]
+        assert len(blk) == 3 * R + 2 * n_pos and sum(per) == R
+        o, r0, g0, want_keep, want_lab, want_g, want_img = 0, 0, 0, [], [], [], []
+        for i in range(N):
+            used = counts[i] if counts is not None else slots[i]
+            cand = np.concatenate([np.arange(used), slots[i] + np.arange(n_gt[i])])
+            m = matched[r0 + cand]
+            l = np.where(m >= 0, gt_labels[g0 + np.maximum(m, 0)], np.where(m == -1, 0, -1)) if n_gt[i] else np.zeros(len(cand), np.int64)
+            pos, neg = cand[l >= 1], cand[l == 0]
+            k_pos = min(int(batch * frac), len(pos)); k_neg = min(batch - k_pos, len(neg))
+            sp = pos[np.argsort(keys[r0 + pos], kind="stable")[:k_pos]]; sn = neg[np.argsort(keys[r0 + neg], kind="stable")[:k_neg]]
+            kp = np.sort(np.concatenate([sp, sn]))
+            assert per[i] == len(kp)
+            lmap = dict(zip(cand.tolist(), l.tolist())); mmap = dict(zip(cand.tolist(), m.tolist()))
+            want_keep += [r0 + c for c in kp]; want_lab += [lmap[c] for c in kp]; want_img += [float(i)] * len(kp)
+            want_g += [(g0 + max(mmap[c], 0)) if n_gt[i] else sum(n_gt) for c in kp]
+            r0 += rows[i]; g0 += n_gt[i]
+        assert keep.tolist() == want_keep and lab.tolist() == want_lab and gsel.tolist() == want_g and img.tolist() == want_img
+        assert prow.tolist() == [r for r in range(R) if lab[r] > 0]
+        assert pidx.tolist() == [r * pred_ld + ncls + 4 * int(lab[r]) for r in range(R) if lab[r] > 0]
+    with pytest.raises(RuntimeError):
+        train_ops.roi_sample_host([10], [1], [11], np.zeros(12, np.int32), np.ones(1, np.int64), np.zeros(11), 8, 0.25, 108, 21)
