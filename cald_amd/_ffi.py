@@ -133,6 +133,7 @@ SIGNATURES = {
                                            C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     "cald_train_roi_sample_host": (C.c_int, [C.c_int, c_i, c_i, c_i, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_int,
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_i, c_i, c_i]),
+    "cald_train_roi_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_float] * 4 + [C.c_void_p, C.c_void_p]),
     "cald_train_anchors": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_i, C.c_void_p]),
     "cald_train_match": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
     "cald_train_box_encode": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),

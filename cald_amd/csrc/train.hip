@@ -1197,13 +1197,42 @@ extern "C" int cald_train_anchors(cald_ctx* c, int kind, int Hp, int Wp, const i
 }
 
 // BoxCoder.encode_single (torchvision 0.8.2 _utils.py): regression targets of `proposals` towards `reference` boxes
+__device__ __forceinline__ float4 box_encode_one(const float4 r, const float4 p, float wx, float wy, float ww, float wh) {
+    const float ex_w = p.z - p.x, ex_h = p.w - p.y, ex_cx = p.x + 0.5f * ex_w, ex_cy = p.y + 0.5f * ex_h;
+    const float gt_w = r.z - r.x, gt_h = r.w - r.y, gt_cx = r.x + 0.5f * gt_w, gt_cy = r.y + 0.5f * gt_h;
+    return make_float4(wx * (gt_cx - ex_cx) / ex_w, wy * (gt_cy - ex_cy) / ex_h, ww * det_logf(gt_w / ex_w), wh * det_logf(gt_h / ex_h));
+}
 __global__ void box_encode_kernel(const float4* reference, const float4* proposals, int n, float wx, float wy, float ww, float wh, float4* out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float4 r = reference[i], p = proposals[i];
-    const float ex_w = p.z - p.x, ex_h = p.w - p.y, ex_cx = p.x + 0.5f * ex_w, ex_cy = p.y + 0.5f * ex_h;
-    const float gt_w = r.z - r.x, gt_h = r.w - r.y, gt_cx = r.x + 0.5f * gt_w, gt_cy = r.y + 0.5f * gt_h;
-    out[i] = make_float4(wx * (gt_cx - ex_cx) / ex_w, wy * (gt_cy - ex_cy) / ex_h, ww * det_logf(gt_w / ex_w), wh * det_logf(gt_h / ex_h));
+    out[i] = box_encode_one(reference[i], proposals[i], wx, wy, ww, wh);
+}
+// What follows the RoI sampler on the device, in one launch: the sampled boxes gathered into RoIAlign's [R][5] rows (image index, box)
+// and the regression targets of the foreground rows.  idx: the sampler's int64 block with stride `cap` between its lists
+// (cald_train_roi_sample_host's outputs uploaded as they are: table rows | ground-truth rows | labels | pred_idx | pos_rows | image
+// index as float32 in the first 4 * R bytes of the sixth list).
+__global__ void roi_gather_kernel(const float4* __restrict__ table, const float4* __restrict__ gts, const long long* __restrict__ idx, int cap, int R, int n_pos,
+                                  float wx, float wy, float ww, float wh, float* __restrict__ rois, float4* __restrict__ box_tgt) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < R) {
+        const float4 b = table[idx[i]];
+        float* o = rois + (long long)i * 5;
+        o[0] = reinterpret_cast<const float*>(idx + 5ll * cap)[i]; o[1] = b.x; o[2] = b.y; o[3] = b.z; o[4] = b.w;
+    }
+    if (i < n_pos) {
+        const long long r = idx[4ll * cap + i];
+        box_tgt[i] = box_encode_one(gts[idx[(long long)cap + r]], table[idx[r]], wx, wy, ww, wh);
+    }
+}
+extern "C" int cald_train_roi_gather(cald_ctx* c, const float* table, const float* gts, const int64_t* idx, int cap, int R, int n_pos,
+                                     float wx, float wy, float ww, float wh, float* rois_out, float* box_tgt_out) {
+    if (!c || !table || !gts || !idx || !rois_out || (n_pos > 0 && !box_tgt_out)) TFAIL(CALD_ERR_INVALID, "null argument");
+    if (R < 0 || n_pos < 0 || n_pos > R || R > cap) TFAIL(CALD_ERR_INVALID, "0 <= n_pos <= R <= cap");
+    THIP(hipSetDevice(cald_internal_device(c)));
+    if (R > 0) hipLaunchKernelGGL(roi_gather_kernel, dim3((R + 255) / 256), dim3(256), 0, cald_internal_stream(c), (const float4*)table, (const float4*)gts,
+                                  (const long long*)idx, cap, R, n_pos, wx, wy, ww, wh, rois_out, (float4*)box_tgt_out);
+    THIP(hipGetLastError());
+    return 0;
 }
 extern "C" int cald_train_box_encode(cald_ctx* c, int n, const float* reference, const float* proposals, float wx, float wy, float ww, float wh,
                                      float* out) {

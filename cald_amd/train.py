@@ -65,21 +65,26 @@ def choose_k(n, k, generator=None):
     return torch.from_numpy(got)
 
 
-class _Samples(dict):
-    """{"rpn": [(pos, neg)], "box": [(pos, neg)]} of the last forward (sorted candidate numbers per image); the RoI half is derived from
-    the sampler's table rows on first use -- nothing on the step's critical path needs it."""
+class _LazyDict(dict):
+    """A dict some of whose entries are computed on first use (zero-argument callables in `lazy`): what only tests and inspection read
+    from the last forward (the proposals as a list, the sampled candidates per image, the RoI labels on the host) stays off the step's
+    critical path -- the GPU is waiting while the forward's one host stop runs."""
 
-    def __init__(self, rpn, box, box_fn):
-        super().__init__(rpn=rpn)
-        self._box_fn = box_fn
-        if box_fn is None:
-            self["box"] = box
+    def __init__(self, lazy, **kw):
+        super().__init__(**kw)
+        self._lazy = dict(lazy)
 
     def __missing__(self, key):
-        if key == "box" and self._box_fn is not None:
-            self["box"] = self._box_fn()
-            return self["box"]
+        if key in self._lazy:
+            self[key] = self._lazy.pop(key)()
+            return self[key]
         raise KeyError(key)
+
+    def get(self, key, default=None):
+        try:
+            return self[key]
+        except KeyError:
+            return default
 
 
 class _Conv(object):
@@ -298,6 +303,7 @@ class _TrainerBase(object):
         # are independent.  CALD_TRAIN_SIDE_STREAM=0 keeps everything on one stream.
         self.side = self.aux = None
         self._pack_plan = None
+        self._roi_pin = None
         if __import__("os").environ.get("CALD_TRAIN_SIDE_STREAM", "1") != "0":
             from .detector import get_side_ctx
             st = torch.cuda.Stream(device=self.dev)
@@ -673,16 +679,20 @@ class FasterRCNNTrainer(_TrainerBase):
                 # ---- the GPU waits from here to the host->device copy below: everything in between is host time on the step's critical path ----
                 T = int(pr_off[-1])
                 if fixed_rows:
-                    counts = [int(v) for v in matched_all[T:]]
-                    proposals = [props[i, :counts[i]] for i in range(N)]
+                    counts_np = matched_all[T:]
+                    counts = None                           # as a list only where someone asks (self.last["proposals"], the randperm sampler)
                 else:
-                    counts = list(slots)
+                    counts_np, counts = None, list(slots)
+                lazy = {}
+                if fixed_rows:
+                    lazy["proposals"] = lambda props=props, c=counts_np.copy(): [props[i, :int(c[i])] for i in range(N)]
                 if self.sampler == "choose_k":
                     # one C call for the whole batch (cald_train_roi_sample_host): labels, the balanced sampler (the k smallest of iid
-                    # uniform keys per class -- one generator call for all images), every index list of the loss kernels.  The numpy
-                    # loop below did the same in 0.6 ms per step.
-                    # keys are drawn per (image, post_n proposal slots + ground truth) whatever the table's shape, so that the fixed-row and
-                    # the compact table (speculative path, proposals handed in) select the same candidates from the same generator state
+                    # uniform keys per class -- one generator call for all images), every index list of the loss kernels, written into
+                    # pinned memory and uploaded as one block; one kernel (cald_train_roi_gather) then builds RoIAlign's rows and the
+                    # regression targets.  The numpy loop of the other branch + eight small torch ops cost 0.6 ms of GPU idle per step.
+                    # Keys are drawn per (image, post_n proposal slots + ground truth) whatever the table's shape, so that the fixed-row and
+                    # the compact table (speculative path, proposals handed in) select the same candidates from the same generator state.
                     post = cfg["post_n"]
                     if all(sl <= post for sl in slots):
                         keys = torch.rand(sum(post + g for g in n_gt), generator=self.generator, dtype=torch.float64).numpy()
@@ -691,22 +701,31 @@ class FasterRCNNTrainer(_TrainerBase):
                             keys = np.concatenate([keys[np.r_[ko[i]:ko[i] + slots[i], ko[i] + post:ko[i] + post + n_gt[i]]] for i in range(N)])
                     else:
                         keys = torch.rand(T, generator=self.generator, dtype=torch.float64).numpy()
-                    roi_np, img_col_np, R, n_posr, per_img = ops.roi_sample_host(slots, n_gt, counts if fixed_rows else None, matched_all, gt_labels_cat, keys,
-                                                                                  cfg["box_batch"], cfg["box_pos"], self.pred_ld, Ccls)
-                    packed2 = torch.from_numpy(roi_np).to(self.dev)
-                    img_col_dev = torch.from_numpy(img_col_np).to(self.dev)
-                    roi_labels_np = roi_np[2 * R:3 * R]
-                    n_posrows = n_posr
-                    def box_samples_fn(keep=roi_np[:R].copy(), lab=roi_labels_np.copy(), per_img=per_img, counts=list(counts), slots=list(slots), pr_off=pr_off.copy()):
+                    cap = N * cfg["box_batch"]
+                    if self._roi_pin is None or self._roi_pin.numel() < 6 * cap:
+                        self._roi_pin = torch.empty(6 * cap, dtype=torch.int64, pin_memory=True)
+                    pin_np = self._roi_pin.numpy()
+                    _, _, R, n_posrows, per_img = ops.roi_sample_host(slots, n_gt, counts_np, matched_all, gt_labels_cat, keys, cfg["box_batch"], cfg["box_pos"],
+                                                                      self.pred_ld, Ccls, out=pin_np)
+                    packed2 = torch.empty(6 * cap, dtype=torch.int64, device=self.dev)
+                    packed2.copy_(self._roi_pin[:6 * cap], non_blocking=True)       # the pinned block is rewritten only after the next step's stop
+                    rois, box_tgt = ops.roi_gather(pr_all, gts_all, packed2, cap, R, n_posrows, cfg["w"])
+                    keep_sel, labels_dev = packed2[:R], packed2[2 * cap:2 * cap + R]
+                    pred_idx = packed2[3 * cap:3 * cap + n_posrows]
+                    keep_np, roi_labels_np = pin_np[:R].copy(), pin_np[2 * cap:2 * cap + R].copy()
+                    def box_samples_fn(keep=keep_np, lab=roi_labels_np, per_img=per_img, cn=None if counts_np is None else counts_np.copy(), slots=list(slots),
+                                       pr_off=pr_off.copy()):
                         out, o = [], 0
                         for i in range(N):                      # table row -> compact candidate number (used proposals, then the ground truth)
                             r = keep[o:o + per_img[i]] - pr_off[i]
-                            c = np.where(r < slots[i], r, r - slots[i] + counts[i])
+                            c = np.where(r < slots[i], r, r - slots[i] + (slots[i] if cn is None else int(cn[i])))
                             l = lab[o:o + per_img[i]]
                             out.append((c[l > 0], c[l == 0])); o += per_img[i]
                         return out
                     box_samples = None
                 else:
+                    if counts is None:
+                        counts = [int(v) for v in counts_np]
                     # compact candidate number -> row of the fixed-row table (the used proposal slots, then the ground truth)
                     rowmap = [np.concatenate([np.arange(counts[i]), slots[i] + np.arange(n_gt[i])]).astype(np.int64) for i in range(N)]
                     keep_all, lab_all, gtsel_all, img_col = [], [], [], []
@@ -733,13 +752,15 @@ class FasterRCNNTrainer(_TrainerBase):
                     packed2 = torch.from_numpy(np.concatenate([np.concatenate(keep_all), np.concatenate(gtsel_all), roi_labels_np, pred_idx_np, pos_rows]).astype(np.int64)).to(self.dev)
                     img_col_dev = torch.from_numpy(np.concatenate(img_col)).to(self.dev)
                     box_samples_fn = None
-                keep_sel, gt_sel2, labels_dev = packed2[:R], packed2[R:2 * R], packed2[2 * R:3 * R]
-                pred_idx, pos_sel = packed2[3 * R:3 * R + n_posrows], packed2[3 * R + n_posrows:3 * R + 2 * n_posrows]
-                boxes = pr_all[keep_sel]
-                rois = torch.cat([img_col_dev[:, None], boxes], dim=1).contiguous()
-                roi_gt = gts_all[gt_sel2]
-                box_tgt = ops.box_encode(roi_gt.contiguous(), boxes.contiguous(), cfg["w"])[pos_sel].contiguous()
-                roi_labels = torch.from_numpy(np.ascontiguousarray(roi_labels_np))
+                    keep_sel, gt_sel2, labels_dev = packed2[:R], packed2[R:2 * R], packed2[2 * R:3 * R]
+                    pred_idx, pos_sel = packed2[3 * R:3 * R + n_posrows], packed2[3 * R + n_posrows:3 * R + 2 * n_posrows]
+                    boxes = pr_all[keep_sel]
+                    rois = torch.cat([img_col_dev[:, None], boxes], dim=1).contiguous()
+                    roi_gt = gts_all[gt_sel2]
+                    box_tgt = ops.box_encode(roi_gt.contiguous(), boxes.contiguous(), cfg["w"])[pos_sel].contiguous()
+                lazy["roi_labels"] = lambda l=roi_labels_np: torch.from_numpy(np.ascontiguousarray(l))
+                if "proposals" not in lazy:
+                    lazy["proposals"] = lambda p=proposals: p
             finally:
                 ops._WGRAD_CTX[0] = prev
         if on_aux:
@@ -752,10 +773,11 @@ class FasterRCNNTrainer(_TrainerBase):
         f6 = self.fc6.fwd(roi_rows.view(1, 1, R, -1), relu=True)
         f7 = self.fc7.fwd(f6, relu=True)
         pred = self.pred.fwd(f7)
-        self.last = dict(N=N, R=R, feats=feats, inner=inner, P=P, tl=tl, heads=heads, head_flat=head_flat, head_sizes=head_sizes, level_hw=level_hw,
+        self.last = _LazyDict(lazy, N=N, R=R, feats=feats, inner=inner, P=P, tl=tl, heads=heads, head_flat=head_flat, head_sizes=head_sizes, level_hw=level_hw,
                          obj_idx=obj_idx, obj_lab=obj_lab, box_idx=box_idx, rpn_tgt=rpn_tgt, rois=rois, roi_rows=roi_rows, f6=f6, f7=f7, pred=pred,
-                         labels=labels_dev, pred_idx=pred_idx, box_tgt=box_tgt, proposals=proposals, roi_labels=roi_labels,
-                         samples=_Samples(rpn_samples, box_samples, box_samples_fn), spec=spec)
+                         labels=labels_dev, pred_idx=pred_idx, box_tgt=box_tgt,
+                         samples=_LazyDict({"box": box_samples_fn} if box_samples_fn is not None else {}, rpn=rpn_samples,
+                                           **({} if box_samples_fn is not None else {"box": box_samples})), spec=spec)
         mark("box head")
         losses = {
             "loss_classifier": ops.softmax_ce(pred.view(R, -1), labels_dev, Ccls),

@@ -270,24 +270,43 @@ def match(boxes, gt, hi, lo, allow_low_quality, out=None):
     return out
 
 
-def roi_sample_host(slots, n_gt, counts, matched, gt_labels_cat, keys, batch, pos_fraction, pred_ld, num_classes):
+def roi_sample_host(slots, n_gt, counts, matched, gt_labels_cat, keys, batch, pos_fraction, pred_ld, num_classes, out=None):
     """cald_train_roi_sample_host: RoI labels + balanced sampling + loss index lists of a whole batch on the host, one call.
-    Returns (int64 block [keep rows | gt rows | labels | pred_idx | pos_rows], img_col float32 [R], R, n_pos, RoIs per image)."""
+    slots / n_gt: sequences or ctypes int arrays; counts: None, a sequence, or an int32 numpy view (the device's counts as copied back).
+    out: int64 numpy array of 6 * N * batch elements (e.g. pinned memory) that receives the six lists with stride cap = N * batch:
+    table rows | ground-truth rows | labels | pred_idx | pos_rows | image index (float32 in the first 4 R bytes).
+    Returns (out, cap, R, n_pos, RoIs per image)."""
     import numpy as np
     N = len(slots)
-    cap = N * batch
+    cap = N * int(batch)
     assert matched.dtype == np.int32 and matched.flags.c_contiguous and keys.dtype == np.float64 and gt_labels_cat.dtype == np.int64
-    buf = np.empty(5 * cap, np.int64)
-    img = np.empty(cap, np.float32)
+    if out is None:
+        out = np.empty(6 * cap, np.int64)
+    assert out.dtype == np.int64 and out.size >= 6 * cap and out.flags.c_contiguous
     R, n_pos, per = C.c_int(), C.c_int(), (C.c_int * N)()
-    vp = lambda a, off=0: C.c_void_p(a.ctypes.data + off)
-    _ffi.check(_ffi.lib().cald_train_roi_sample_host(N, _int_array(slots), _int_array(n_gt), _int_array(counts) if counts is not None else None, vp(matched),
-                                                     vp(gt_labels_cat), vp(keys), int(batch), float(pos_fraction), int(pred_ld), int(num_classes),
-                                                     vp(buf), vp(buf, 8 * cap), vp(buf, 16 * cap), vp(img), vp(buf, 32 * cap), vp(buf, 24 * cap),
-                                                     C.byref(R), C.byref(n_pos), per))
-    R, n_pos = int(R.value), int(n_pos.value)
-    out = np.concatenate([buf[:R], buf[cap:cap + R], buf[2 * cap:2 * cap + R], buf[3 * cap:3 * cap + n_pos], buf[4 * cap:4 * cap + n_pos]])
-    return out, img[:R].copy(), R, n_pos, [int(v) for v in per]
+    base = out.ctypes.data
+    if counts is None:
+        cp = None
+    elif isinstance(counts, np.ndarray):
+        assert counts.dtype == np.int32 and counts.size >= N
+        cp = C.cast(C.c_void_p(counts.ctypes.data), C.POINTER(C.c_int))
+    else:
+        cp = _int_array(counts)
+    ia = lambda v: v if isinstance(v, C.Array) else _int_array(v)
+    _ffi.check(_ffi.lib().cald_train_roi_sample_host(N, ia(slots), ia(n_gt), cp, C.c_void_p(matched.ctypes.data), C.c_void_p(gt_labels_cat.ctypes.data),
+                                                     C.c_void_p(keys.ctypes.data), int(batch), float(pos_fraction), int(pred_ld), int(num_classes),
+                                                     C.c_void_p(base), C.c_void_p(base + 8 * cap), C.c_void_p(base + 16 * cap), C.c_void_p(base + 40 * cap),
+                                                     C.c_void_p(base + 32 * cap), C.c_void_p(base + 24 * cap), C.byref(R), C.byref(n_pos), per))
+    return out, cap, int(R.value), int(n_pos.value), list(per)
+
+
+def roi_gather(table, gts_all, idx_dev, cap, R, n_pos, weights):
+    """cald_train_roi_gather: RoIAlign rows [R, 5] and the foreground rows' regression targets [n_pos, 4] from the uploaded sampler block."""
+    rois = torch.empty((R, 5), dtype=torch.float32, device=table.device)
+    box_tgt = torch.empty((n_pos, 4), dtype=torch.float32, device=table.device)
+    _ffi.check(_ffi.lib().cald_train_roi_gather(_wctx(table), _p(table), _p(gts_all), _p(idx_dev), int(cap), int(R), int(n_pos),
+                                                *[float(w) for w in weights], _p(rois), _p(box_tgt)))
+    return rois, box_tgt
 
 
 def box_encode(reference, proposals, weights):

@@ -354,6 +354,12 @@ int cald_train_roi_sample_host(int N, const int* slots, const int* n_gt, const i
                                const int64_t* gt_labels, const double* keys, int batch, double pos_fraction, int pred_ld, int num_classes,
                                int64_t* keep_rows, int64_t* gt_sel, int64_t* labels_out, float* img_col, int64_t* pos_rows,
                                int64_t* pred_idx, int* R_out, int* n_pos_out, int* per_image_out);
+/* The device side of the RoI sampling in one launch: idx = cald_train_roi_sample_host's six output lists uploaded with stride cap
+ * (table rows | ground-truth rows | labels | pred_idx | pos_rows | image index as float32); table = the candidate boxes [rows][4],
+ * gts = all ground-truth boxes + one zero box.  rois_out [R][5] (image index, box) for cald_train_roi_align; box_tgt_out [n_pos][4] =
+ * BoxCoder.encode of the foreground rows (weights wx..wh), the arithmetic of cald_train_box_encode. */
+int cald_train_roi_gather(cald_ctx* ctx, const float* table, const float* gts, const int64_t* idx, int cap, int R, int n_pos,
+                          float wx, float wy, float ww, float wh, float* rois_out, float* box_tgt_out);
 /* AnchorGenerator: all anchors of one padded image over five levels, order (level, y, x, anchor): anchors_out [sum Hl*Wl*A][4].
  * kind 0 = Faster R-CNN (A = 3, frcnn_la.py:185-187), kind 1 = RetinaNet (A = 9, retinanet_cal.py:346-351) */
 int cald_train_anchors(cald_ctx* ctx, int kind, int Hp, int Wp, const int* level_hw, float* anchors_out);

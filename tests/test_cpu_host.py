@@ -926,9 +926,10 @@ def test_roi_sample_host_labels_balanced_sampling_and_index_lists():
                                   if g else np.full(r, -1, np.int32) for r, g in zip(rows, n_gt)] + [np.zeros(N, np.int32)])
         gt_labels = np.concatenate([rs.randint(1, ncls, g).astype(np.int64) for g in n_gt] + [np.zeros(1, np.int64)])
         keys = rs.rand(T)
-        blk, img, R, n_pos, per = train_ops.roi_sample_host(slots, n_gt, counts, matched, gt_labels, keys, batch, frac, pred_ld, ncls)
-        keep, gsel, lab, pidx, prow = blk[:R], blk[R:2 * R], blk[2 * R:3 * R], blk[3 * R:3 * R + n_pos], blk[3 * R + n_pos:]
-        assert len(blk) == 3 * R + 2 * n_pos and sum(per) == R
+        blk, cap, R, n_pos, per = train_ops.roi_sample_host(slots, n_gt, counts, matched, gt_labels, keys, batch, frac, pred_ld, ncls)
+        keep, gsel, lab, pidx, prow = blk[:R], blk[cap:cap + R], blk[2 * cap:2 * cap + R], blk[3 * cap:3 * cap + n_pos], blk[4 * cap:4 * cap + n_pos]
+        img = blk[5 * cap:].view(np.float32)[:R]
+        assert cap == N * batch and sum(per) == R
         o, r0, g0, want_keep, want_lab, want_g, want_img = 0, 0, 0, [], [], [], []
         for i in range(N):
             used = counts[i] if counts is not None else slots[i]

@@ -32,7 +32,6 @@ marks = []
 def mark(name):
     ev = torch.cuda.Event(enable_timing=True); ev.record(torch.cuda.current_stream()); marks.append((name, ev))
 net._mark = mark
-net._host_probe = []
 import time
 host = []
 for i in range(steps):
@@ -59,5 +58,4 @@ for k in range(steps // 2, steps):
 print("median ms after the previous step's 'sgd done' (GPU clock, stream of the section):")
 for name, v in rows.items():
     print("  %-14s %7.2f" % (name, float(np.median(v))))
-print("host us in the RoI sampling between D2H and H2D: median %.0f" % (np.median(net._host_probe[steps // 2:]) * 1e6))
 print("host ms per step: forward %.2f  backward %.2f  sgd %.2f" % tuple(np.median(np.array(host[steps // 2:]), axis=0) * 1e3))
