@@ -339,7 +339,8 @@ extern "C" int cald_train_pack_plan_create(cald_ctx* c, int n, const cald_pack_j
     if ((e = hipMemcpy(p->seg1, s1.data(), sizeof(PackSeg) * s1.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
     if (!s2.empty() && (e = hipMemcpy(p->seg2, s2.data(), sizeof(PackSeg) * s2.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
     // k positions no source element maps to (channel / K padding) stay zero for the plan's lifetime: the scratch is the plan's own
-    if (need && (e = hipMemset(scratch, 0, (size_t)need * 4)) != hipSuccess) return fail(e);
+    // (on the context stream: ordered after whatever used this memory before and before the first cald_train_pack_plan_run)
+    if (need && (e = hipMemsetAsync(scratch, 0, (size_t)need * 4, cald_internal_stream(c))) != hipSuccess) return fail(e);
     *out = p;
     return 0;
 }

@@ -83,7 +83,8 @@ class PackPlan(object):
         _ffi.check(_ffi.lib().cald_train_pack_plan_scratch_floats(n, self.jobs, C.byref(need)))
         self.scratch = torch.empty(max(int(need.value), 1), dtype=torch.float32, device=device)
         self.handle = C.c_void_p()
-        _ffi.check(_ffi.lib().cald_train_pack_plan_create(get_ctx(self.scratch.device.index), n, self.jobs, _p(self.scratch), int(need.value),
+        # (the context whose stream run() will use: the scratch is zeroed on that stream)
+        _ffi.check(_ffi.lib().cald_train_pack_plan_create(_wctx(self.scratch), n, self.jobs, _p(self.scratch), int(need.value),
                                                           C.byref(self.handle)))
 
     def run(self):

@@ -292,7 +292,8 @@ int cald_train_pack_conv(cald_ctx* ctx, const float* weight, const float* bias, 
  * cald_train_pack_conv per layer and form is ~220 launch-bound launches at the start of every step.  A plan records the jobs (the
  * arguments of cald_train_pack_conv, device pointers that stay valid for the plan's lifetime); cald_train_pack_plan_run packs them
  * all on the context stream, bit for bit what the per-layer calls write.  scratch: device memory of
- * cald_train_pack_plan_scratch_floats floats owned by the plan until it is destroyed (zeroed by create). */
+ * cald_train_pack_plan_scratch_floats floats owned by the plan until it is destroyed (zeroed by create on ctx's stream: run the
+ * plan on that stream, or on one ordered after it). */
 typedef struct cald_pack_job {
     const float *weight, *bias, *bn_scale, *bn_shift;
     int Cout, Cin, KH, KW, CinK, mode;
