@@ -576,6 +576,39 @@ def test_pack_plan_writes_the_per_layer_packs_bit_for_bit(T):
             assert torch.equal(a[1][k], b[1][k]), k
 
 
+def test_roi_gather_equals_the_torch_gathers_and_box_encode(T):
+    """cald_train_roi_gather (one kernel behind the RoI sampler: RoIAlign's [R, 5] rows and the foreground rows' BoxCoder.encode) against the
+    eight torch ops + cald_train_box_encode it replaced, on the sampler's own output block: identical bits."""
+    torch, ops = T
+    rs = np.random.RandomState(11)
+    N, batch, post = 3, 64, 200
+    n_gt = [3, 0, 2]
+    slots = [post] * N
+    rows = [post + g for g in n_gt]
+    T_ = sum(rows)
+    xy = rs.rand(T_, 2).astype(np.float32) * 300
+    table = torch.from_numpy(np.concatenate([xy, xy + 5 + rs.rand(T_, 2).astype(np.float32) * 120], axis=1)).cuda()
+    g_xy = rs.rand(sum(n_gt) + 1, 2).astype(np.float32) * 300
+    gts_all = torch.from_numpy(np.concatenate([g_xy, g_xy + 20 + rs.rand(len(g_xy), 2).astype(np.float32) * 100], axis=1)).cuda()
+    gts_all[-1] = 0
+    matched = np.concatenate([np.where(rs.rand(r) < 0.25, rs.randint(0, max(g, 1), r), -1).astype(np.int32) if g else np.full(r, -1, np.int32)
+                              for r, g in zip(rows, n_gt)] + [np.array([post, post - 7, post - 50], np.int32)])
+    gt_labels = np.concatenate([rs.randint(1, 21, g).astype(np.int64) for g in n_gt] + [np.zeros(1, np.int64)])
+    blk, cap, R, n_pos, per = ops.roi_sample_host(slots, n_gt, matched[T_:], matched, gt_labels, rs.rand(T_), batch, 0.25, 108, 21)
+    assert R > 0 and n_pos > 0 and cap == N * batch
+    dev = torch.from_numpy(blk).cuda()
+    w = (10.0, 10.0, 5.0, 5.0)
+    rois, tgt = ops.roi_gather(table, gts_all, dev, cap, R, n_pos, w)
+    keep, gsel, pos = dev[:R], dev[cap:cap + R], dev[4 * cap:4 * cap + n_pos]
+    img = torch.from_numpy(blk[5 * cap:].view(np.float32)[:R].copy()).cuda()
+    boxes = table[keep]
+    want_rois = torch.cat([img[:, None], boxes], dim=1)
+    want_tgt = ops.box_encode(gts_all[gsel].contiguous(), boxes.contiguous(), w)[pos]
+    torch.cuda.synchronize()
+    assert torch.equal(rois, want_rois)
+    assert torch.equal(tgt.view(torch.int32), want_tgt.contiguous().view(torch.int32))
+
+
 def _vec_floats(ops, pk):
     """floats of the three epilogue vectors at the end of a packed buffer"""
     two_kn = ops.packed_floats(pk.Cout, pk.Cin, pk.KH, pk.KW, pk.CinK, pk.mode)
