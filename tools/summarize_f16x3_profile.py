@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Condenses gpurun_out/prof_<tag>/ of tools/profile_f16x3.sh into profiles/r4_f16x3_kernel_stats.csv and profiles/r4_f16x3_pmc.json:
 per conv kernel the MFMA-busy fraction (SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE / 128: cycles per SIMD vs cycles per XCD) and the LDS
-counters, with the hash of the kernel sources they were measured on.  Usage: python tools/summarize_f16x3_profile.py r4h"""
+counters, with the hash of the kernel sources they were measured on.  Usage: python tools/summarize_f16x3_profile.py r4h [r4]"""
 import collections
 import csv
 import glob
@@ -14,6 +14,7 @@ sys.path.insert(0, root)
 import bench  # noqa: E402
 
 tag = sys.argv[1]
+prefix = sys.argv[2] if len(sys.argv) > 2 else "r4"      # profiles/<prefix>_f16x3_*
 src = os.path.join(root, "gpurun_out", "prof_" + tag)
 
 
@@ -39,11 +40,11 @@ for n, c in agg.items():
                   "SQ_WAIT_INST_LDS": c.get("SQ_WAIT_INST_LDS"), "SQ_WAVE_CYCLES": c.get("SQ_WAVE_CYCLES")}
 json.dump({"command": "tools/profile_f16x3.sh: bench.py --steps 2 --warmup 1 --model frcnn101 --shape coco --augs FCDRG --precision f16x3 "
                       "(BASELINE configs[4], one GPU)", "csrc_sha1": bench.csrc_sha1(), "per_kernel": out},
-          open(os.path.join(root, "profiles", "r4_f16x3_pmc.json"), "w"), indent=1)
+          open(os.path.join(root, "profiles", prefix + "_f16x3_pmc.json"), "w"), indent=1)
 for n, v in sorted(out.items(), key=lambda kv: -kv[1]["GRBM_GUI_ACTIVE"])[:8]:
     print("%-55s n=%4d  MFMA busy %.1f / 128 = %.3f" % (n[:55], v["dispatches"], v["mfma_busy_of_128_per_xcd_cycle"], v["mfma_busy_frac"]))
 rows = list(csv.DictReader(open(newest("stats/**/*kernel_stats.csv"))))
-with open(os.path.join(root, "profiles", "r4_f16x3_kernel_stats.csv"), "w") as f:
+with open(os.path.join(root, "profiles", prefix + "_f16x3_kernel_stats.csv"), "w") as f:
     w = csv.writer(f)
     w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
     for r in rows:
